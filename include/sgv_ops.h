@@ -1,0 +1,212 @@
+/*
+ * sgv_ops.h -- C ABI of libsgv_hip.so, the MI355X (gfx950) kernel library behind the
+ * StyleGAN-V synthesis/discriminator op stack.
+ *
+ * Every entry point is plain C: raw device pointers, sizes, strides, a HIP stream passed as
+ * void*.  No torch types cross this boundary.  The library owns nothing: callers allocate
+ * inputs/outputs (the Python host layer uses torch's caching allocator) and pass the stream
+ * the work must be ordered on.  No entry point allocates device memory or synchronises, so
+ * every launch is hipGraph-capturable.  All functions return 0 on success or a negative
+ * SGV_ERR_* code; sgv_last_error() returns a thread-local message for the last failure.
+ * Nothing throws across the ABI.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the
+ * universome/stylegan-v checkout):
+ *
+ *   sgv_upfirdn2d      <- `_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1,
+ *                          pady0, pady1, flip, gain)`  src/torch_utils/ops/upfirdn2d.cpp:16,98-101
+ *                          (kernel parameter block: src/torch_utils/ops/upfirdn2d.h:14-40)
+ *   sgv_bias_act       <- `_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain,
+ *                          clamp)`  src/torch_utils/ops/bias_act.cpp:32,94-97
+ *                          (kernel parameter block: src/torch_utils/ops/bias_act.h:12-31)
+ *   sgv_weight_sqsum / sgv_demod_coefs / sgv_scale_channels
+ *                      <- the weight (de)modulation arithmetic of `modulated_conv2d`
+ *                          src/training/networks.py:57-74 (no native counterpart in the
+ *                          reference: it materialises w[N,O,I,kh,kw] in PyTorch)
+ *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail
+ *                          src/training/motion.py:201-212
+ *   sgv_gemm_f32       <- `torch.addmm` / `matmul` of FullyConnectedLayer and the dense 1x1
+ *                          convolutions  src/training/layers.py:133-137,
+ *                          src/torch_utils/ops/conv2d_resample.py:40-54
+ *   sgv_prof_*         <- no reference counterpart: per-launch HIP-event timing used by
+ *                          bench.py to report roofline numbers.
+ */
+#ifndef SGV_OPS_H
+#define SGV_OPS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGV_VERSION 100 /* major*100 + minor */
+
+/* element types (the reference dispatches double/float/half: upfirdn2d.cpp:59, bias_act.cpp:76;
+ * bf16 is this library's extension) */
+enum sgv_dtype { SGV_F32 = 0, SGV_F16 = 1, SGV_BF16 = 2, SGV_F64 = 3 };
+
+enum sgv_error {
+    SGV_OK = 0,
+    SGV_ERR_INVALID_ARG = -1, /* precondition of the reference's TORCH_CHECKs violated */
+    SGV_ERR_TOO_LARGE = -2,   /* numel > INT_MAX (upfirdn2d.cpp:22-23,36; bias_act.cpp:40) */
+    SGV_ERR_UNSUPPORTED = -3, /* dtype / activation index not implemented */
+    SGV_ERR_LAUNCH = -4       /* hipLaunchKernel failed */
+};
+
+/* ---------------------------------------------------------------------------------------
+ * upfirdn2d: pad -> zero-insert (up) -> FIR -> decimate (down).
+ * Sizes/strides are in ELEMENTS, ordered [w, h, c, n] exactly like upfirdn2d.h:25-30.
+ * out_w = (in_w*up_x + pad_x0 + pad_x1 - f_w + down_x) / down_x  (C division), same for h
+ * (upfirdn2d.cpp:32-33).  The caller computes it and allocates y; the library re-derives it
+ * and rejects a mismatch.
+ */
+typedef struct sgv_upfirdn2d_params {
+    const void* x;  /* [n, c, in_h, in_w] with arbitrary dense strides */
+    const float* f; /* [f_h, f_w] fp32, device memory */
+    void* y;        /* [n, c, out_h, out_w] */
+    int32_t up_x, up_y;
+    int32_t down_x, down_y;
+    int32_t pad_x0, pad_x1, pad_y0, pad_y1;
+    int32_t flip; /* 0: true convolution, 1: correlation (upfirdn2d.py:153) */
+    float gain;
+    int32_t in_w, in_h, in_c, in_n;
+    int64_t in_sw, in_sh, in_sc, in_sn; /* x strides */
+    int32_t f_w, f_h;
+    int64_t f_sw, f_sh; /* filter strides */
+    int32_t out_w, out_h;
+    int64_t out_sw, out_sh, out_sc, out_sn; /* y strides */
+} sgv_upfirdn2d_params;
+
+int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* stream);
+
+/* Which kernel sgv_upfirdn2d would run for p: 0 = generic gather kernel, 1 = register-window
+ * row walker (the fast path for contiguous NCHW, up/down in {1,2}).  For tests/benchmarks. */
+int sgv_upfirdn2d_kernel_kind(const sgv_upfirdn2d_params* p, int dtype);
+
+/* ---------------------------------------------------------------------------------------
+ * bias_act: y = clamp(act(x + b) * gain) and its first/second derivative forms.
+ * Field meaning is that of bias_act.h:12-31.  act is the reference's cuda_idx (1..9:
+ * linear, relu, lrelu, tanh, sigmoid, elu, selu, softplus, swish; bias_act.py:23-33).
+ * grad: 0 forward, 1 first derivative (x holds dy), 2 second derivative (bias_act.cu:51-142).
+ * NULL pointers mean "absent" (the reference passes an empty tensor).
+ * clamp < 0 disables clamping.  All tensors share one dense layout of size_x elements.
+ */
+typedef struct sgv_bias_act_params {
+    const void* x;
+    const void* b;    /* [size_b] or NULL */
+    const void* xref; /* or NULL */
+    const void* yref; /* or NULL */
+    const void* dy;   /* or NULL */
+    void* y;
+    int32_t grad;
+    int32_t act;
+    float alpha, gain, clamp;
+    int32_t size_x;
+    int32_t size_b;
+    int32_t step_b; /* x.stride(dim) in elements (bias_act.cpp:73) */
+} sgv_bias_act_params;
+
+int sgv_bias_act(const sgv_bias_act_params* p, int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight (de)modulation of modulated_conv2d (networks.py:57-62) without the [N,O,I,kh,kw]
+ * temporary:  d[n,o] = rsqrt( sum_i s[n,i]^2 * wsq[o,i] + eps ),  wsq[o,i] = sum_k W[o,i,k]^2.
+ * All fp32.
+ */
+/* wsq[o*I + i] = sum_{k<kk} w[(o*I + i)*kk + k]^2 ; w contiguous [O, I, kk] */
+int sgv_weight_sqsum(const float* w, float* wsq, int32_t oc, int32_t ic, int32_t kk, void* stream);
+/* dcoefs[n*O + o] = rsqrt(sum_i (styles[n*I+i])^2 * wsq[o*I+i] + eps) */
+int sgv_demod_coefs(const float* styles, const float* wsq, float* dcoefs, int32_t n, int32_t oc,
+                    int32_t ic, float eps, void* stream);
+/* y[n,c,hw] = x[n,c,hw] * s[n*C + c] (+ optional per-[n,hw] noise), contiguous NCHW,
+ * x/y of dtype `dtype`, s fp32.  Used for x*styles and x*dcoefs (networks.py:66,70-71). */
+int sgv_scale_channels(const void* x, const float* s, void* y, int32_t n, int32_t c, int32_t hw,
+                       int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * AlignedTimeEncoder element-wise tail (motion.py:201-212), fp32:
+ *   raw(tau) = freqs[j]*periods[r,j]*tau + phases[r,j]*phase_scales[j]
+ *   pos(tau) = [sin raw(tau) | cos raw(tau)]                       (2*nf wide)
+ *   out[r,:] = pos(t) - lerp(pos(t_left), pos(t_right), alpha) + lerp(al[r,:], ar[r,:], alpha)
+ * periods already include the tanh()+1 of motion.py:196.  Accurate sinf/cosf (arguments reach
+ * ~1e3 rad).  rows = batch*frames.
+ */
+typedef struct sgv_time_encode_params {
+    const float* periods; /* [rows, nf] */
+    const float* phases;  /* [rows, nf] */
+    const float* al;      /* [rows, 2*nf] aligners from the left code  */
+    const float* ar;      /* [rows, 2*nf] aligners from the right code */
+    const float* freqs;        /* [nf] */
+    const float* phase_scales; /* [nf] */
+    const float* t;       /* [rows] */
+    const float* t_left;  /* [rows] */
+    const float* t_right; /* [rows] */
+    const float* alpha;   /* [rows] */
+    float* out;           /* [rows, 2*nf] */
+    int32_t rows, nf;
+} sgv_time_encode_params;
+
+int sgv_time_encode(const sgv_time_encode_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Dense (batched) GEMM on the matrix cores, fp32 in / fp32 accumulate on
+ * v_mfma_f32_32x32x2_f32 (exact fp32, same rounding as an fmaf chain over k):
+ *     C[b][M,N] = A[b][M,K] * op(B[b]) (+ bias),   all row-major, ld* in elements.
+ *   trans_b = 1: B is stored [N,K]  ->  FullyConnectedLayer `x @ w.t()` (layers.py:133-137):
+ *                A = activations [rows, in], B = weight [out, in], bias per column (bias_mode 1).
+ *   trans_b = 0: B is stored [K,N]  ->  a 1x1 convolution on NCHW (conv2d_resample.py:40-54):
+ *                A = weight [Cout, Cin] shared by the batch (stride_a = 0), B = x[n] [Cin, H*W],
+ *                C = y[n] [Cout, H*W], bias per row (bias_mode 2).
+ */
+typedef struct sgv_gemm_params {
+    const float* a;
+    const float* b;
+    const float* bias; /* or NULL */
+    float* c;
+    int32_t m, n, k;
+    int64_t lda, ldb, ldc;
+    int32_t trans_b;
+    int32_t batch;
+    int64_t stride_a, stride_b, stride_c; /* elements between consecutive batch entries */
+    int32_t bias_mode;                    /* 0 none, 1 bias[N] per column, 2 bias[M] per row */
+} sgv_gemm_params;
+
+int sgv_gemm_f32(const sgv_gemm_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Per-launch timing (bench.py roofline leg).  When enabled, every sgv_* launch is bracketed by
+ * two HIP events on its own stream; sgv_prof_collect synchronises those events and reports, per
+ * kernel family, launch count, summed milliseconds and summed algorithmic bytes
+ * (upfirdn2d: (numel(x)+numel(y))*sizeof(T); bias_act: all streams read + written).
+ */
+enum sgv_kernel_family {
+    SGV_K_UPFIRDN2D_ROWS = 0,
+    SGV_K_UPFIRDN2D_GENERIC = 1,
+    SGV_K_BIAS_ACT = 2,
+    SGV_K_MODULATE = 3,
+    SGV_K_TIME_ENCODE = 4,
+    SGV_K_GEMM = 5,
+    SGV_K_COUNT = 6
+};
+typedef struct sgv_prof_entry {
+    int64_t launches;
+    double ms;
+    double bytes; /* algorithmic bytes */
+    double flops; /* algorithmic flops (GEMM), else 0 */
+} sgv_prof_entry;
+
+int sgv_prof_enable(int32_t max_records); /* allocates the event pool (host side only) */
+int sgv_prof_disable(void);
+int sgv_prof_collect(sgv_prof_entry* out /* [SGV_K_COUNT] */); /* syncs events, resets pool */
+
+/* Total number of kernel launches issued through this library since load (all threads). */
+int64_t sgv_launch_count(void);
+
+int sgv_version(void);
+const char* sgv_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGV_OPS_H */

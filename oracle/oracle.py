@@ -1,0 +1,162 @@
+"""ctypes front-end of oracle/sgv_oracle.c plus small numpy restatements -- TEST INFRASTRUCTURE ONLY.
+
+`parity pinned`: the C restatement is checked against golden vectors produced by importing the
+reference's own Python implementations (tests/golden/make_golden.py -> tests/golden/*.npz) in
+tests/test_oracle.py.  The reference's native CUDA sources cannot be compiled in this image.
+
+All functions take and return CPU torch tensors (so bfloat16 works without numpy support).
+"""
+
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import torch
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+_SRC = os.path.join(_DIR, 'sgv_oracle.c')
+_LIB = os.path.join(_DIR, '_build', 'libsgv_oracle.so')
+_STAMP = _LIB + '.md5'
+_lib = None
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2, torch.float64: 3}
+
+
+def _digest():
+    with open(_SRC, 'rb') as fh:
+        return hashlib.md5(fh.read()).hexdigest()
+
+
+def build(force=False):
+    """gcc the restatement into oracle/_build/ (recipe: oracle/Makefile)."""
+    fresh = os.path.isfile(_LIB) and os.path.isfile(_STAMP) and open(_STAMP).read().strip() == _digest()
+    if force or not fresh:
+        if os.path.isfile(_LIB):
+            os.remove(_LIB)
+        res = subprocess.run(['make', '-C', _DIR], capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError('oracle build failed:\n' + res.stderr)
+        with open(_STAMP, 'w') as fh:
+            fh.write(_digest())
+    return _LIB
+
+
+def _get():
+    global _lib
+    if _lib is None:
+        lib = ctypes.CDLL(build())
+        i, i64, f, vp = ctypes.c_int, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+        lib.oracle_upfirdn2d_out_size.restype = i
+        lib.oracle_upfirdn2d_out_size.argtypes = [i] * 6
+        lib.oracle_upfirdn2d.restype = i
+        lib.oracle_upfirdn2d.argtypes = [vp, vp, vp, i] + [i] * 8 + [i, f] + [i] * 4 + [i64] * 4 + [i, i] + [i64] * 2 + [i64] * 4
+        lib.oracle_bias_act.restype = i
+        lib.oracle_bias_act.argtypes = [vp] * 6 + [i, i, i, f, f, f, i64, i64, i64]
+        _lib = lib
+    return _lib
+
+
+def upfirdn2d_out_size(in_size, up, down, pad0, pad1, taps):
+    return int(_get().oracle_upfirdn2d_out_size(in_size, up, down, pad0, pad1, taps))
+
+
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
+def _pad4(p):
+    if isinstance(p, int):
+        return p, p, p, p
+    p = tuple(p)
+    return (p[0], p[0], p[1], p[1]) if len(p) == 2 else p
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1.0):
+    """Oracle upfirdn2d on a CPU tensor x [N,C,H,W] (any dense strides) with an fp32 filter
+    ([fh,fw], [taps] separable, or None).  Separable filters run as two passes with sqrt(gain) each,
+    like the reference's native path (upfirdn2d.py:236-240)."""
+    assert x.device.type == 'cpu' and x.ndim == 4
+    if f is None:
+        f = torch.ones([1, 1], dtype=torch.float32)
+    f = f.detach().to(torch.float32).cpu()
+    upx, upy = _pair(up)
+    downx, downy = _pair(down)
+    px0, px1, py0, py1 = _pad4(padding)
+    if f.ndim == 1:
+        g = float(np.sqrt(gain))
+        y = _upfirdn2d_one(x, f.unsqueeze(0), upx, 1, downx, 1, px0, px1, 0, 0, flip_filter, g)
+        return _upfirdn2d_one(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, py0, py1, flip_filter, g)
+    return _upfirdn2d_one(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip_filter, float(gain))
+
+
+def _upfirdn2d_one(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain):
+    lib = _get()
+    n, c, h, w = x.shape
+    fh, fw = f.shape
+    ow = upfirdn2d_out_size(w, upx, downx, px0, px1, fw)
+    oh = upfirdn2d_out_size(h, upy, downy, py0, py1, fh)
+    if ow < 1 or oh < 1:
+        raise RuntimeError('output must be at least 1x1')
+    cl = x.stride(1) == 1 and c > 1 and x.is_contiguous(memory_format=torch.channels_last)
+    y = torch.empty([n, c, oh, ow], dtype=x.dtype, memory_format=torch.channels_last if cl else torch.contiguous_format)
+    sn, sc, sh, sw = x.stride()
+    on, oc, osh, osw = y.stride()
+    rc = lib.oracle_upfirdn2d(x.data_ptr(), f.data_ptr(), y.data_ptr(), _DT[x.dtype],
+                              upx, upy, downx, downy, px0, px1, py0, py1, int(bool(flip)), float(gain),
+                              w, h, c, n, sw, sh, sc, sn, fw, fh, f.stride(1), f.stride(0), osw, osh, oc, on)
+    assert rc == 0
+    return y
+
+
+_ACT_IDX = {'linear': 1, 'relu': 2, 'lrelu': 3, 'tanh': 4, 'sigmoid': 5, 'elu': 6, 'selu': 7, 'softplus': 8, 'swish': 9}
+_ACT_DEFAULTS = {'linear': (0, 1), 'relu': (0, np.sqrt(2)), 'lrelu': (0.2, np.sqrt(2)), 'tanh': (0, 1), 'sigmoid': (0, 1),
+                 'elu': (0, 1), 'selu': (0, 1), 'softplus': (0, 1), 'swish': (0, np.sqrt(2))}
+
+
+def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, grad=0, xref=None, yref=None, dy=None):
+    """Oracle bias_act kernel call (any grad order) on dense CPU tensors sharing x's layout."""
+    lib = _get()
+    assert x.device.type == 'cpu'
+    da, dg = _ACT_DEFAULTS[act]
+    alpha = float(da if alpha is None else alpha)
+    gain = float(dg if gain is None else gain)
+    clamp = float(-1 if clamp is None else clamp)
+    y = torch.empty_like(x)
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    for t in (xref, yref, dy):
+        assert t is None or (t.shape == x.shape and t.stride() == x.stride() and t.dtype == x.dtype)
+    rc = lib.oracle_bias_act(x.data_ptr(), ptr(b), ptr(xref), ptr(yref), ptr(dy), y.data_ptr(), _DT[x.dtype], grad,
+                             _ACT_IDX[act], alpha, gain, clamp, x.numel(), b.numel() if b is not None else 1,
+                             x.stride(dim) if b is not None else 1)
+    assert rc == 0
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# numpy restatements of the small fp32 formulas (python loops are fine at test sizes).
+
+
+def modulated_demod_coefs(weight, styles, eps=1e-8):
+    """d[n,o] = rsqrt(sum_{i,kh,kw} (W[o,i,kh,kw]*s[n,i])^2 + eps) -- networks.py:57-62, computed the
+    reference's way (materialising w[N,O,I,kh,kw]) in float64, returned as float64."""
+    w = weight.detach().double().numpy()
+    s = styles.detach().double().numpy()
+    ww = w[None] * s[:, None, :, None, None]
+    return torch.from_numpy(1.0 / np.sqrt((ww ** 2).sum(axis=(2, 3, 4)) + eps))
+
+
+def time_encode(periods, phases, al, ar, freqs, phase_scales, t, t_left, t_right, alpha):
+    """AlignedTimeEncoder tail (motion.py:201-212) in float64 numpy.  periods include tanh()+1."""
+    P, Ph = periods.double().numpy(), phases.double().numpy()
+    fr, ps = freqs.double().numpy().reshape(1, -1), phase_scales.double().numpy().reshape(1, -1)
+    a = alpha.double().numpy().reshape(-1, 1)
+
+    def pos(tau):
+        raw = fr * P * tau.double().numpy().reshape(-1, 1) + Ph * ps
+        return np.concatenate([np.sin(raw), np.cos(raw)], axis=1)
+
+    rem = pos(t_left) * (1 - a) + pos(t_right) * a
+    add = al.double().numpy() * (1 - a) + ar.double().numpy() * a
+    return torch.from_numpy(pos(t) - rem + add)

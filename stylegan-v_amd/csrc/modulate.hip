@@ -1,0 +1,137 @@
+// Weight (de)modulation arithmetic of modulated_conv2d (src/training/networks.py:57-74) for gfx950.
+//
+// The reference materialises w[N,O,I,kh,kw] = W * s just to reduce it to d[N,O] (906 MB at N=96 for
+// a 512->512 3x3 layer).  Algebraically
+//     d[n,o] = rsqrt( sum_i s[n,i]^2 * q[o,i] + eps ),   q[o,i] = sum_k W[o,i,k]^2
+// so three small kernels replace it:
+//   weight_sqsum_kernel  q[o,i]                 HBM-bound over the weights: (kk+1)*O*I*4 bytes
+//   demod_coefs_kernel   d[n,o]                 one wave per output, lanes stride over i, DPP/shuffle
+//                                               butterfly reduction (the "per-style demodulation
+//                                               reduction"); q rows are L2-resident
+//   scale_channels_kernel y[n,c,:] = x[n,c,:] * s[n,c]   HBM stream, 16 B per lane
+//
+// Algorithmic bytes: sqsum (kk+1)*O*I*4; demod (O*I + N*I + N*O)*4; scale 2*numel(x)*sizeof(T).
+
+#include "sgv_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__global__ __launch_bounds__(256) void weight_sqsum_kernel(const float* __restrict__ w, float* __restrict__ q, int total, int kk) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const float* p = w + (size_t)idx * kk;
+    float acc = 0.f;
+    for (int k = 0; k < kk; k++) acc = __builtin_fmaf(p[k], p[k], acc);
+    q[idx] = acc;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// grid = (ceil(O/4), N); block = 256 = 4 waves; wave w of block bx handles o = bx*4 + w for sample n = by.
+__global__ __launch_bounds__(256) void demod_coefs_kernel(const float* __restrict__ s, const float* __restrict__ q,
+                                                          float* __restrict__ d, int n_samples, int oc, int ic, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.y;
+    if (o >= oc) return;
+    const float* sr = s + (size_t)n * ic;
+    const float* qr = q + (size_t)o * ic;
+    float acc = 0.f;
+    for (int i = lane; i < ic; i += 64) {
+        float sv = sr[i];
+        acc = __builtin_fmaf(sv * sv, qr[i], acc);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) d[(size_t)n * oc + o] = 1.0f / sqrtf(acc + eps);
+}
+
+template <typename T> struct vec16 {
+    static constexpr int N = 16 / sizeof(T);
+    T e[N];
+} __attribute__((aligned(16)));
+
+// Vector path: hw % N == 0 so a 16-B vector never straddles two planes.
+template <typename T>
+__global__ __launch_bounds__(256) void scale_channels_vec_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                                 T* __restrict__ y, int nvec, int hw) {
+    constexpr int N = vec16<T>::N;
+    const vec16<T>* xv = (const vec16<T>*)x;
+    vec16<T>* yv = (vec16<T>*)y;
+    for (int vi = blockIdx.x * blockDim.x + threadIdx.x; vi < nvec; vi += gridDim.x * blockDim.x) {
+        const float sc = s[(vi * N) / hw];
+        vec16<T> v = xv[vi], o;
+#pragma unroll
+        for (int k = 0; k < N; k++) sgv_traits<T>::store(&o.e[k], sgv_traits<T>::load(&v.e[k]) * sc);
+        yv[vi] = o;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void scale_channels_scalar_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                                    T* __restrict__ y, int total, int hw) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+        sgv_traits<T>::store(y + i, sgv_traits<T>::load(x + i) * s[i / hw]);
+}
+
+template <typename T>
+void launch_scale(const void* x, const float* s, void* y, int total, int hw, hipStream_t stream) {
+    constexpr int N = vec16<T>::N;
+    const bool vec_ok = (hw % N == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    int work = vec_ok ? total / N : total;
+    int blocks = (work + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (vec_ok)
+        hipLaunchKernelGGL(scale_channels_vec_kernel<T>, dim3(blocks), dim3(256), 0, stream, (const T*)x, s, (T*)y, work, hw);
+    else
+        hipLaunchKernelGGL(scale_channels_scalar_kernel<T>, dim3(blocks), dim3(256), 0, stream, (const T*)x, s, (T*)y, total, hw);
+}
+
+}  // namespace
+
+extern "C" int sgv_weight_sqsum(const float* w, float* wsq, int32_t oc, int32_t ic, int32_t kk, void* stream_) {
+    if (!w || !wsq) return sgv_fail(SGV_ERR_INVALID_ARG, "weight_sqsum: NULL pointer");
+    if (oc < 1 || ic < 1 || kk < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "weight_sqsum: sizes must be positive");
+    if ((int64_t)oc * ic * kk > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "weight_sqsum: weight is too large");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int total = oc * ic;
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, (double)total * (kk + 1) * 4.0);
+    hipLaunchKernelGGL(weight_sqsum_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, w, wsq, total, kk);
+    return sgv_check_launch("weight_sqsum_kernel");
+}
+
+extern "C" int sgv_demod_coefs(const float* styles, const float* wsq, float* dcoefs, int32_t n, int32_t oc, int32_t ic,
+                               float eps, void* stream_) {
+    if (!styles || !wsq || !dcoefs) return sgv_fail(SGV_ERR_INVALID_ARG, "demod_coefs: NULL pointer");
+    if (n < 1 || oc < 1 || ic < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "demod_coefs: sizes must be positive");
+    if (n > 65535) return sgv_fail(SGV_ERR_TOO_LARGE, "demod_coefs: batch is too large");
+    hipStream_t stream = (hipStream_t)stream_;
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, ((double)oc * ic + (double)n * ic + (double)n * oc) * 4.0);
+    hipLaunchKernelGGL(demod_coefs_kernel, dim3((oc + 3) / 4, n), dim3(256), 0, stream, styles, wsq, dcoefs, n, oc, ic, eps);
+    return sgv_check_launch("demod_coefs_kernel");
+}
+
+extern "C" int sgv_scale_channels(const void* x, const float* s, void* y, int32_t n, int32_t c, int32_t hw, int dtype,
+                                  void* stream_) {
+    if (!x || !s || !y) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_channels: NULL pointer");
+    if (n < 1 || c < 1 || hw < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_channels: sizes must be positive");
+    if ((int64_t)n * c * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "scale_channels: x is too large");
+    const size_t es = sgv_dtype_size(dtype);
+    if (es == 0) return sgv_fail(SGV_ERR_UNSUPPORTED, "scale_channels: unknown dtype %d", dtype);
+    hipStream_t stream = (hipStream_t)stream_;
+    const int total = n * c * hw;
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, 2.0 * total * es + (double)n * c * 4.0);
+    switch (dtype) {
+        case SGV_F32: launch_scale<float>(x, s, y, total, hw, stream); break;
+        case SGV_F16: launch_scale<sgv_half_t>(x, s, y, total, hw, stream); break;
+        case SGV_BF16: launch_scale<sgv_bf16_t>(x, s, y, total, hw, stream); break;
+        case SGV_F64: return sgv_fail(SGV_ERR_UNSUPPORTED, "scale_channels: fp64 not supported");
+    }
+    return sgv_check_launch("scale_channels_kernel");
+}

@@ -1,0 +1,80 @@
+// Shared helpers for libsgv_hip.so (gfx950 only).  Not part of the public ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/sgv_ops.h"
+
+// ---------------------------------------------------------------------------------------------
+// Storage types.  fp16/bf16 are moved as raw 16-bit words and widened to fp32 in registers
+// (fp32 internal accumulate, the reference's InternalType<half>=float: upfirdn2d.cu:15-18).
+
+struct sgv_half_t { uint16_t bits; };
+struct sgv_bf16_t { uint16_t bits; };
+
+template <typename T> struct sgv_traits;
+template <> struct sgv_traits<float> {
+    typedef float acc_t;
+    static __device__ __forceinline__ float load(const float* p) { return *p; }
+    static __device__ __forceinline__ void store(float* p, float v) { *p = v; }
+};
+template <> struct sgv_traits<double> {
+    typedef double acc_t;
+    static __device__ __forceinline__ double load(const double* p) { return *p; }
+    static __device__ __forceinline__ void store(double* p, double v) { *p = v; }
+};
+template <> struct sgv_traits<sgv_half_t> {
+    typedef float acc_t;
+    static __device__ __forceinline__ float load(const sgv_half_t* p) {
+        _Float16 h; __builtin_memcpy(&h, p, 2); return (float)h;
+    }
+    static __device__ __forceinline__ void store(sgv_half_t* p, float v) {
+        _Float16 h = (_Float16)v; __builtin_memcpy(p, &h, 2);  // v_cvt_f16_f32: round-to-nearest-even
+    }
+};
+template <> struct sgv_traits<sgv_bf16_t> {
+    typedef float acc_t;
+    static __device__ __forceinline__ float load(const sgv_bf16_t* p) {
+        return __builtin_bit_cast(float, (uint32_t)p->bits << 16);
+    }
+    static __device__ __forceinline__ void store(sgv_bf16_t* p, float v) {
+        uint32_t u = __builtin_bit_cast(uint32_t, v);
+        if ((u & 0x7fffffffu) > 0x7f800000u) { p->bits = (uint16_t)((u >> 16) | 0x40); return; }  // quiet NaN
+        u += 0x7fffu + ((u >> 16) & 1u);  // round-to-nearest-even
+        p->bits = (uint16_t)(u >> 16);
+    }
+};
+
+static inline size_t sgv_dtype_size(int dtype) {
+    switch (dtype) {
+        case SGV_F32: return 4;
+        case SGV_F16: return 2;
+        case SGV_BF16: return 2;
+        case SGV_F64: return 8;
+        default: return 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Error reporting / launch accounting / profiling (implemented in sgv_runtime.hip).
+
+int sgv_fail(int code, const char* fmt, ...);
+
+struct sgv_launch_scope {
+    // Brackets one kernel launch: bumps the launch counter and, when profiling is enabled,
+    // records a start/stop HIP event pair on `stream`.
+    sgv_launch_scope(int family, hipStream_t stream, double bytes, double flops = 0.0);
+    ~sgv_launch_scope();
+    int slot;
+    hipStream_t stream;
+};
+
+static inline int sgv_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return SGV_OK;
+}

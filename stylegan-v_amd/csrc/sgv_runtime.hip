@@ -1,0 +1,92 @@
+// Error strings, launch accounting and the per-launch HIP-event profiler of libsgv_hip.so.
+#include "sgv_common.h"
+
+#include <atomic>
+#include <mutex>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+static std::atomic<int64_t> g_launches{0};
+
+int sgv_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char* sgv_last_error(void) { return g_err; }
+extern "C" int sgv_version(void) { return SGV_VERSION; }
+extern "C" int64_t sgv_launch_count(void) { return g_launches.load(); }
+
+// ---------------------------------------------------------------------------------------------
+// Profiler: a fixed pool of event pairs; one record per launch while enabled.
+
+struct prof_record {
+    hipEvent_t start, stop;
+    int family;
+    double bytes, flops;
+};
+
+static std::mutex g_prof_mu;
+static std::vector<prof_record> g_prof_pool;
+static std::atomic<int> g_prof_next{0};
+static std::atomic<bool> g_prof_on{false};
+
+extern "C" int sgv_prof_enable(int32_t max_records) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (max_records <= 0) return sgv_fail(SGV_ERR_INVALID_ARG, "sgv_prof_enable: max_records must be > 0");
+    while ((int)g_prof_pool.size() < max_records) {
+        prof_record r{};
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess)
+            return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_enable: hipEventCreate failed");
+        g_prof_pool.push_back(r);
+    }
+    g_prof_next = 0;
+    g_prof_on = true;
+    return SGV_OK;
+}
+
+extern "C" int sgv_prof_disable(void) {
+    g_prof_on = false;
+    return SGV_OK;
+}
+
+extern "C" int sgv_prof_collect(sgv_prof_entry* out) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!out) return sgv_fail(SGV_ERR_INVALID_ARG, "sgv_prof_collect: out is NULL");
+    for (int k = 0; k < SGV_K_COUNT; k++) out[k] = sgv_prof_entry{0, 0.0, 0.0, 0.0};
+    int n = g_prof_next.load();
+    if (n > (int)g_prof_pool.size()) n = (int)g_prof_pool.size();
+    for (int i = 0; i < n; i++) {
+        prof_record& r = g_prof_pool[i];
+        if (hipEventSynchronize(r.stop) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_collect: event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+        sgv_prof_entry& e = out[r.family];
+        e.launches += 1;
+        e.ms += ms;
+        e.bytes += r.bytes;
+        e.flops += r.flops;
+    }
+    g_prof_next = 0;
+    return SGV_OK;
+}
+
+sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops) : slot(-1), stream(s) {
+    g_launches.fetch_add(1, std::memory_order_relaxed);
+    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    int i = g_prof_next.fetch_add(1);
+    if (i >= (int)g_prof_pool.size()) return;  // pool exhausted: launch is simply not recorded
+    prof_record& r = g_prof_pool[i];
+    r.family = family;
+    r.bytes = bytes;
+    r.flops = flops;
+    slot = i;
+    (void)hipEventRecord(r.start, stream);
+}
+
+sgv_launch_scope::~sgv_launch_scope() {
+    if (slot >= 0) (void)hipEventRecord(g_prof_pool[slot].stop, stream);
+}

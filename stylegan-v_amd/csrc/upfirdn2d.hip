@@ -1,0 +1,442 @@
+// upfirdn2d for gfx950: pad -> zero-insert -> FIR -> decimate.
+//
+// Semantics follow the reference op exactly (src/torch_utils/ops/upfirdn2d.cu:43-48,60-89 for
+// the receptive-field / tap walk, upfirdn2d.cpp:32-33 for the output size).  Two kernels:
+//
+//  * upfirdn2d_generic_kernel  -- one lane per output element, any strides / factors / filter
+//    size / dtype (incl. fp64, channels_last).  The correctness backstop.
+//  * upfirdn2d_rows_kernel     -- the hot path.  Contiguous NCHW, up/down in {1,2} per axis (never
+//    both), filter <= 4x4 (2-D) .  HBM-bound streaming design with NO LDS and NO barriers:
+//      - a wave owns a strip of output rows of one (or, for narrow images, several) planes;
+//        each lane owns VEC=4 adjacent output columns (16 B of fp32 per row -> one dwordx4 store,
+//        the wave writes 1 KiB contiguous per row);
+//      - the lane keeps a sliding window of the input rows its outputs need in VGPRs
+//        (WR x NEED floats) and walks down the strip: every input element is loaded from global
+//        memory once per strip (vertical halo = (FH-1)/strip rows, absorbed by L2 because the four
+//        waves of a workgroup own four consecutive strips of the same plane), horizontal halo is
+//        the 3..6 extra columns each lane loads (L1/TA hits on the neighbour lane's lines);
+//      - filter taps are wave-uniform -> the compiler keeps them in SGPRs (s_load), the MAC loop is
+//        pure v_fma_f32 with an SGPR operand;
+//      - up/down factors, padded filter size and the launch-constant phase (pad mod up) are
+//        template parameters, so every window index is static and lives in a register.
+//    Tap order per output is ascending input row, then ascending input column, as one fmaf chain:
+//    the same order as the reference loop, so results are bit-identical to the scalar oracle
+//    (oracle/sgv_oracle.c) -- zero-padded taps contribute fma(0,f,acc)==acc.
+//
+// Algorithmic bytes per launch (what the roofline is computed from):
+//    (numel(x) + numel(y)) * sizeof(T)   [+ 4*fw*fh, negligible]       
+
+#include "sgv_common.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+__host__ __device__ __forceinline__ int floor_div(int a, int b) {
+    // floor(a / b) for b > 0 without relying on negative-division rounding (upfirdn2d.cu:20-24).
+    int t = 1 - a / b;
+    return (a + t * b) / b - t;
+}
+
+template <typename A> __device__ __forceinline__ A fma_acc(A a, A b, A c);
+template <> __device__ __forceinline__ float fma_acc<float>(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+template <> __device__ __forceinline__ double fma_acc<double>(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// ---------------------------------------------------------------------------------------------
+// Generic kernel.
+
+struct generic_params {
+    const void* x;
+    const float* f;
+    void* y;
+    int up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip;
+    float gain;
+    int in_w, in_h, in_c, in_n;
+    int64_t in_sw, in_sh, in_sc, in_sn;
+    int f_w, f_h;
+    int64_t f_sw, f_sh;
+    int out_w, out_h;
+    int64_t out_sw, out_sh, out_sc, out_sn;
+    int64_t total;  // out_w*out_h*in_c*in_n
+    int chan_minor;  // 1: iterate channels fastest (channels_last), 0: x fastest
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void upfirdn2d_generic_kernel(generic_params p) {
+    typedef typename sgv_traits<T>::acc_t acc_t;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < p.total; idx += (int64_t)gridDim.x * blockDim.x) {
+        int ox, oy, c, n;
+        int64_t r = idx;
+        if (p.chan_minor) {
+            c = (int)(r % p.in_c); r /= p.in_c;
+            ox = (int)(r % p.out_w); r /= p.out_w;
+            oy = (int)(r % p.out_h); n = (int)(r / p.out_h);
+        } else {
+            ox = (int)(r % p.out_w); r /= p.out_w;
+            oy = (int)(r % p.out_h); r /= p.out_h;
+            c = (int)(r % p.in_c); n = (int)(r / p.in_c);
+        }
+        // Receptive field (upfirdn2d.cu:43-48, 60-65).
+        int mid_y = oy * p.down_y + p.up_y - 1 - p.pad_y0;
+        int in_y = min(max(floor_div(mid_y, p.up_y), 0), p.in_h);
+        int h = min(max(floor_div(mid_y + p.f_h, p.up_y), 0), p.in_h) - in_y;
+        int fy = mid_y + p.f_h - (in_y + 1) * p.up_y;
+        int mid_x = ox * p.down_x + p.up_x - 1 - p.pad_x0;
+        int in_x = min(max(floor_div(mid_x, p.up_x), 0), p.in_w);
+        int w = min(max(floor_div(mid_x + p.f_w, p.up_x), 0), p.in_w) - in_x;
+        int fx = mid_x + p.f_w - (in_x + 1) * p.up_x;
+        int step_x = -p.up_x, step_y = -p.up_y;
+        if (p.flip) { fy = p.f_h - 1 - fy; fx = p.f_w - 1 - fx; step_x = p.up_x; step_y = p.up_y; }
+
+        const T* xp = (const T*)p.x + in_x * p.in_sw + in_y * p.in_sh + c * p.in_sc + n * p.in_sn;
+        acc_t v = 0;
+        for (int j = 0; j < h; j++) {
+            const float* fp = p.f + (fy + j * step_y) * p.f_sh + fx * p.f_sw;
+            const T* xr = xp + j * p.in_sh;
+            for (int i = 0; i < w; i++)
+                v = fma_acc<acc_t>(sgv_traits<T>::load(xr + i * p.in_sw), (acc_t)fp[i * step_x * p.f_sw], v);
+        }
+        v *= (acc_t)p.gain;
+        sgv_traits<T>::store((T*)p.y + ox * p.out_sw + oy * p.out_sh + c * p.out_sc + n * p.out_sn, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-walker kernel.
+
+struct rows_params {
+    const void* x;
+    const float* f;
+    void* y;
+    int pad_x0, pad_y0, flip;
+    float gain;
+    int in_w, in_h, out_w, out_h;
+    int planes;  // n*c
+    int f_w, f_h;
+    int64_t f_sw, f_sh;
+    int lpr_log2;        // lanes per image row = 1 << lpr_log2 (<= 64)
+    int col_groups;      // ceil(column blocks / lanes per row)
+    int strips;          // strips per plane
+    int strip_h;         // output rows per strip (multiple of UPY)
+    int plane_groups;    // ceil(planes / planes per wave)
+    int xtra;            // 1: the lane owning columns [out_w-1-VEC, out_w-1) also writes column out_w-1
+};
+
+constexpr int VEC = 4;
+
+template <typename T, int N> struct vec_of;
+template <int N> struct vec_of<float, N> { typedef float type __attribute__((ext_vector_type(N), aligned(4))); };
+template <int N> struct vec_of<sgv_half_t, N> { typedef uint16_t type __attribute__((ext_vector_type(N), aligned(2))); };
+template <int N> struct vec_of<sgv_bf16_t, N> { typedef uint16_t type __attribute__((ext_vector_type(N), aligned(2))); };
+
+template <typename T> __device__ __forceinline__ float widen(uint16_t b);
+template <> __device__ __forceinline__ float widen<sgv_half_t>(uint16_t b) { sgv_half_t h{b}; return sgv_traits<sgv_half_t>::load(&h); }
+template <> __device__ __forceinline__ float widen<sgv_bf16_t>(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+template <typename T> __device__ __forceinline__ uint16_t narrow(float v) { T t; sgv_traits<T>::store(&t, v); return t.bits; }
+
+// Load N contiguous elements starting at p (element-aligned only) into dst[0..N) as fp32.
+template <typename T, int N> struct row_loader {
+    static __device__ __forceinline__ void run(const T* p, float* dst) {
+        if constexpr (N >= 4) {
+            typename vec_of<T, 4>::type v = *(const typename vec_of<T, 4>::type*)p;
+            if constexpr (sizeof(T) == 4) { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
+            else { dst[0] = widen<T>(v[0]); dst[1] = widen<T>(v[1]); dst[2] = widen<T>(v[2]); dst[3] = widen<T>(v[3]); }
+            row_loader<T, N - 4>::run(p + 4, dst + 4);
+        } else if constexpr (N >= 2) {
+            typename vec_of<T, 2>::type v = *(const typename vec_of<T, 2>::type*)p;
+            if constexpr (sizeof(T) == 4) { dst[0] = v[0]; dst[1] = v[1]; }
+            else { dst[0] = widen<T>(v[0]); dst[1] = widen<T>(v[1]); }
+            row_loader<T, N - 2>::run(p + 2, dst + 2);
+        } else if constexpr (N == 1) {
+            dst[0] = sgv_traits<T>::load(p);
+        }
+    }
+};
+
+template <typename T, int UPX, int UPY, int DOWNX, int DOWNY, int FWP, int FHP, int R0X, int R0Y, int XTRA>
+__global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(rows_params p) {
+    constexpr int TX = FWP / UPX;                                  // taps per output along x
+    constexpr int TY = FHP / UPY;                                  // taps per output along y
+    constexpr int NOUT = VEC + XTRA;                               // outputs computed per lane per row
+    constexpr int NEED = (R0X + (NOUT - 1) * DOWNX) / UPX + TX;    // input columns per lane
+    constexpr int G = UPY;                                         // output rows per loop iteration
+    constexpr int ADV = DOWNY * G / UPY;                           // input rows consumed per iteration
+    constexpr int WR = (R0Y + (G - 1) * DOWNY) / UPY + TY;         // window rows
+    static_assert(FWP % UPX == 0 && FHP % UPY == 0, "padded filter must be a multiple of up");
+    static_assert(WR >= ADV, "window smaller than advance");
+
+    const int lane = threadIdx.x & 63;
+    // readfirstlane: the wave index is uniform, but only provably so to the compiler this way; everything
+    // derived from it (strip bounds, row validity) then lives in SGPRs and branches on SCC.
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // wave id -> (plane group, column group, strip); strips fastest so the waves of a workgroup
+    // own consecutive strips of one plane group (their halo rows meet in L1/L2).
+    const int strip = wave % p.strips;
+    const int cg = (wave / p.strips) % p.col_groups;
+    const int pg = wave / (p.strips * p.col_groups);
+    if (pg >= p.plane_groups) return;
+
+    const int lpr = 1 << p.lpr_log2;
+    const int plane = pg * (64 >> p.lpr_log2) + (lane >> p.lpr_log2);
+    const int cb = cg * lpr + (lane & (lpr - 1));
+    const int ox0 = cb * VEC;
+    const int n_main = p.xtra ? p.out_w - 1 : p.out_w;  // columns covered by the VEC-wide blocks
+    if (plane >= p.planes || ox0 >= n_main) return;
+
+    // Flipped, zero-padded filter taps (wave-uniform; upfirdn2d.cu:118-130).
+    float ff[FHP][FWP];
+#pragma unroll
+    for (int a = 0; a < FHP; a++)
+#pragma unroll
+        for (int b = 0; b < FWP; b++) {
+            float t = 0.f;
+            if (a < p.f_h && b < p.f_w) {
+                int fa = p.flip ? a : p.f_h - 1 - a;
+                int fb = p.flip ? b : p.f_w - 1 - b;
+                t = p.f[fa * p.f_sh + fb * p.f_sw];
+            }
+            ff[a][b] = t;
+        }
+
+    const T* xplane = (const T*)p.x + (size_t)plane * p.in_h * p.in_w;
+    T* yplane = (T*)p.y + (size_t)plane * p.out_h * p.out_w;
+
+    // First input column of this lane's window; exact because ox0*DOWNX is a multiple of UPX.
+    const int inx0 = (ox0 * DOWNX + UPX - 1 - p.pad_x0 - R0X) / UPX;  // numerator divisible by UPX
+    const bool cols_inside = (inx0 >= 0) && (inx0 + NEED <= p.in_w);
+
+    const int oy_a = strip * p.strip_h;
+    const int oy_b = min(oy_a + p.strip_h, p.out_h);
+    if (oy_a >= oy_b) return;
+    const int iny0 = (oy_a * DOWNY + UPY - 1 - p.pad_y0 - R0Y) / UPY;  // divisible as well
+
+    float win[WR][NEED];
+
+    auto load_row = [&](int iy, float* dst) {
+        if (iy < 0 || iy >= p.in_h) {
+#pragma unroll
+            for (int i = 0; i < NEED; i++) dst[i] = 0.f;
+            return;
+        }
+        const T* row = xplane + (size_t)iy * p.in_w;
+        if (cols_inside) {
+            row_loader<T, NEED>::run(row + inx0, dst);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NEED; i++) {
+                int c = inx0 + i;
+                dst[i] = (c >= 0 && c < p.in_w) ? sgv_traits<T>::load(row + c) : 0.f;
+            }
+        }
+    };
+
+    // Prologue: rows that the first iteration does not load itself.
+#pragma unroll
+    for (int r = 0; r < WR - ADV; r++) load_row(iny0 + r, win[ADV + r]);
+
+    const bool store_vec = (ox0 + VEC <= n_main);
+    const bool store_xtra = XTRA && (ox0 + VEC == p.out_w - 1);
+
+    int iy_next = iny0 + (WR - ADV);
+#pragma unroll 4
+    for (int oy = oy_a; oy < oy_b; oy += G) {
+        // Slide the window down by ADV rows and fetch the new rows.
+#pragma unroll
+        for (int r = 0; r < WR - ADV; r++)
+#pragma unroll
+            for (int i = 0; i < NEED; i++) win[r][i] = win[r + ADV][i];
+#pragma unroll
+        for (int q = 0; q < ADV; q++) load_row(iy_next + q, win[WR - ADV + q]);
+        iy_next += ADV;
+
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            if (oy + u >= oy_b) break;
+            constexpr int dummy = 0; (void)dummy;
+            const int ry = (R0Y + u * DOWNY) / UPY;
+            const int fy0 = UPY - 1 - ((R0Y + u * DOWNY) % UPY);
+            float out[NOUT];
+#pragma unroll
+            for (int v = 0; v < NOUT; v++) {
+                const int cx = (R0X + v * DOWNX) / UPX;
+                const int fx0 = UPX - 1 - ((R0X + v * DOWNX) % UPX);
+                float acc = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < TY; ky++)
+#pragma unroll
+                    for (int kx = 0; kx < TX; kx++)
+                        acc = __builtin_fmaf(win[ry + ky][cx + kx], ff[fy0 + ky * UPY][fx0 + kx * UPX], acc);
+                out[v] = acc * p.gain;
+            }
+            T* yrow = yplane + (size_t)(oy + u) * p.out_w + ox0;
+            if (store_vec) {
+                typename vec_of<T, VEC>::type sv;
+                if constexpr (sizeof(T) == 4) { sv[0] = out[0]; sv[1] = out[1]; sv[2] = out[2]; sv[3] = out[3]; }
+                else { sv[0] = narrow<T>(out[0]); sv[1] = narrow<T>(out[1]); sv[2] = narrow<T>(out[2]); sv[3] = narrow<T>(out[3]); }
+                *(typename vec_of<T, VEC>::type*)yrow = sv;
+            } else {
+#pragma unroll
+                for (int v = 0; v < VEC; v++)
+                    if (ox0 + v < n_main) sgv_traits<T>::store(yrow + v, out[v]);
+            }
+            if constexpr (XTRA) {
+                if (store_xtra) sgv_traits<T>::store(yrow + VEC, out[VEC]);
+            }
+        }
+    }
+}
+
+inline int pymod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
+
+typedef void (*rows_fn)(rows_params);
+
+// Instantiation table: (up, down) per axis in {(1,1),(2,1),(1,2)}; 4x4 padded filter for 2-D, and
+// the phase R0 = (up-1-pad0) mod up where up == 2.
+template <typename T, int UPX, int UPY, int DOWNX, int DOWNY, int FWP, int FHP>
+rows_fn pick_phase(int r0x, int r0y, int xtra) {
+#define SGV_PICK(RX, RY)                                                                                  \
+    if (r0x == RX && r0y == RY)                                                                           \
+        return xtra ? (rows_fn)upfirdn2d_rows_kernel<T, UPX, UPY, DOWNX, DOWNY, FWP, FHP, RX, RY, 1>      \
+                    : (rows_fn)upfirdn2d_rows_kernel<T, UPX, UPY, DOWNX, DOWNY, FWP, FHP, RX, RY, 0>;
+    SGV_PICK(0, 0)
+    if constexpr (UPX == 2) { SGV_PICK(1, 0) }
+    if constexpr (UPY == 2) { SGV_PICK(0, 1) }
+    if constexpr (UPX == 2 && UPY == 2) { SGV_PICK(1, 1) }
+#undef SGV_PICK
+    return nullptr;
+}
+
+template <typename T>
+rows_fn pick_rows_kernel(const sgv_upfirdn2d_params* p, int r0x, int r0y, int xtra) {
+    const int ux = p->up_x, uy = p->up_y, dx = p->down_x, dy = p->down_y;
+    if (p->f_w > 4 || p->f_h > 4) return nullptr;
+    if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return pick_phase<T, 1, 1, 1, 1, 4, 4>(r0x, r0y, xtra);
+    if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return pick_phase<T, 2, 2, 1, 1, 4, 4>(r0x, r0y, xtra);
+    if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return pick_phase<T, 1, 1, 2, 2, 4, 4>(r0x, r0y, xtra);
+    return nullptr;
+}
+
+bool dense_nchw(int w, int h, int c, int64_t sw, int64_t sh, int64_t sc, int64_t sn) {
+    return sw == 1 && sh == w && sc == (int64_t)w * h && sn == (int64_t)w * h * c;
+}
+
+struct rows_plan {
+    rows_fn fn;
+    rows_params rp;
+    int blocks;
+};
+
+bool plan_rows(const sgv_upfirdn2d_params* p, int dtype, rows_plan* plan) {
+    if (dtype == SGV_F64) return false;
+    if (!dense_nchw(p->in_w, p->in_h, p->in_c, p->in_sw, p->in_sh, p->in_sc, p->in_sn)) return false;
+    if (!dense_nchw(p->out_w, p->out_h, p->in_c, p->out_sw, p->out_sh, p->out_sc, p->out_sn)) return false;
+    const int r0x = pymod(p->up_x - 1 - p->pad_x0, p->up_x);
+    const int r0y = pymod(p->up_y - 1 - p->pad_y0, p->up_y);
+    const int xtra = (p->out_w > VEC && p->out_w % VEC == 1) ? 1 : 0;
+    rows_fn fn = nullptr;
+    if (dtype == SGV_F32) fn = pick_rows_kernel<float>(p, r0x, r0y, xtra);
+    if (dtype == SGV_F16) fn = pick_rows_kernel<sgv_half_t>(p, r0x, r0y, xtra);
+    if (dtype == SGV_BF16) fn = pick_rows_kernel<sgv_bf16_t>(p, r0x, r0y, xtra);
+    if (!fn) return false;
+
+    rows_params& rp = plan->rp;
+    rp.x = p->x; rp.f = p->f; rp.y = p->y;
+    rp.pad_x0 = p->pad_x0; rp.pad_y0 = p->pad_y0; rp.flip = p->flip; rp.gain = p->gain;
+    rp.in_w = p->in_w; rp.in_h = p->in_h; rp.out_w = p->out_w; rp.out_h = p->out_h;
+    rp.planes = p->in_c * p->in_n;
+    rp.f_w = p->f_w; rp.f_h = p->f_h; rp.f_sw = p->f_sw; rp.f_sh = p->f_sh;
+    rp.xtra = xtra;
+    const int n_main = xtra ? p->out_w - 1 : p->out_w;
+    const int cbs = (n_main + VEC - 1) / VEC;
+    int lpr_log2 = 0;
+    while ((1 << lpr_log2) < cbs && lpr_log2 < 6) lpr_log2++;
+    rp.lpr_log2 = lpr_log2;
+    rp.col_groups = (cbs + (1 << lpr_log2) - 1) >> lpr_log2;
+    const int ppw = 64 >> lpr_log2;
+    rp.plane_groups = (rp.planes + ppw - 1) / ppw;
+    // Strip height: aim for >= ~16K waves so all 1024 SIMDs hold several waves, keep strips >= 8 rows
+    // (halo overhead (FH-1)/strip_h) and a multiple of the row group G = up_y.
+    const int g = p->up_y;
+    int64_t base_waves = (int64_t)rp.plane_groups * rp.col_groups;
+    int strip_h = 32;
+    while (strip_h > 8 && base_waves * ((p->out_h + strip_h - 1) / strip_h) < 16384) strip_h >>= 1;
+    if (strip_h > p->out_h) strip_h = p->out_h;
+    strip_h = ((strip_h + g - 1) / g) * g;
+    rp.strip_h = strip_h;
+    rp.strips = (p->out_h + strip_h - 1) / strip_h;
+    int64_t waves = base_waves * rp.strips;
+    int64_t blocks = (waves + 3) / 4;
+    if (blocks > 0x7fffffff) return false;
+    plan->fn = fn;
+    plan->blocks = (int)blocks;
+    return true;
+}
+
+int validate(const sgv_upfirdn2d_params* p, int dtype) {
+    if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: params is NULL");
+    if (sgv_dtype_size(dtype) == 0) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d: unknown dtype %d", dtype);
+    if (!p->x || !p->f || !p->y) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: x, f and y must be non-NULL");
+    if (p->f_w < 1 || p->f_h < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: f must be at least 1x1");
+    if (p->up_x < 1 || p->up_y < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: upsampling factor must be at least 1");
+    if (p->down_x < 1 || p->down_y < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: downsampling factor must be at least 1");
+    if (p->in_w < 1 || p->in_h < 1 || p->in_c < 1 || p->in_n < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: empty input");
+    if ((int64_t)p->in_w * p->in_h * p->in_c * p->in_n > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: x is too large");
+    const int ow = (p->in_w * p->up_x + p->pad_x0 + p->pad_x1 - p->f_w + p->down_x) / p->down_x;
+    const int oh = (p->in_h * p->up_y + p->pad_y0 + p->pad_y1 - p->f_h + p->down_y) / p->down_y;
+    if (ow < 1 || oh < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: output must be at least 1x1");
+    if (ow != p->out_w || oh != p->out_h)
+        return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: out size %dx%d does not match the derived %dx%d", p->out_w, p->out_h, ow, oh);
+    if ((int64_t)ow * oh * p->in_c * p->in_n > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: output is too large");
+    return SGV_OK;
+}
+
+template <typename T>
+void launch_generic(const generic_params& gp, hipStream_t stream) {
+    int64_t blocks = (gp.total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(upfirdn2d_generic_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, stream, gp);
+}
+
+}  // namespace
+
+extern "C" int sgv_upfirdn2d_kernel_kind(const sgv_upfirdn2d_params* p, int dtype) {
+    int rc = validate(p, dtype);
+    if (rc != SGV_OK) return rc;
+    rows_plan plan;
+    return plan_rows(p, dtype, &plan) ? 1 : 0;
+}
+
+extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* stream_) {
+    int rc = validate(p, dtype);
+    if (rc != SGV_OK) return rc;
+    hipStream_t stream = (hipStream_t)stream_;
+    const double bytes = ((double)p->in_w * p->in_h + (double)p->out_w * p->out_h) * p->in_c * p->in_n * sgv_dtype_size(dtype);
+
+    rows_plan plan;
+    if (plan_rows(p, dtype, &plan)) {
+        sgv_launch_scope scope(SGV_K_UPFIRDN2D_ROWS, stream, bytes);
+        hipLaunchKernelGGL(plan.fn, dim3((unsigned)plan.blocks), dim3(256), 0, stream, plan.rp);
+        return sgv_check_launch("upfirdn2d_rows_kernel");
+    }
+
+    generic_params gp;
+    gp.x = p->x; gp.f = p->f; gp.y = p->y;
+    gp.up_x = p->up_x; gp.up_y = p->up_y; gp.down_x = p->down_x; gp.down_y = p->down_y;
+    gp.pad_x0 = p->pad_x0; gp.pad_y0 = p->pad_y0; gp.flip = p->flip; gp.gain = p->gain;
+    gp.in_w = p->in_w; gp.in_h = p->in_h; gp.in_c = p->in_c; gp.in_n = p->in_n;
+    gp.in_sw = p->in_sw; gp.in_sh = p->in_sh; gp.in_sc = p->in_sc; gp.in_sn = p->in_sn;
+    gp.f_w = p->f_w; gp.f_h = p->f_h; gp.f_sw = p->f_sw; gp.f_sh = p->f_sh;
+    gp.out_w = p->out_w; gp.out_h = p->out_h;
+    gp.out_sw = p->out_sw; gp.out_sh = p->out_sh; gp.out_sc = p->out_sc; gp.out_sn = p->out_sn;
+    gp.total = (int64_t)p->out_w * p->out_h * p->in_c * p->in_n;
+    gp.chan_minor = (p->in_sc == 1 && p->in_c > 1) ? 1 : 0;
+    sgv_launch_scope scope(SGV_K_UPFIRDN2D_GENERIC, stream, bytes);
+    switch (dtype) {
+        case SGV_F32: launch_generic<float>(gp, stream); break;
+        case SGV_F16: launch_generic<sgv_half_t>(gp, stream); break;
+        case SGV_BF16: launch_generic<sgv_bf16_t>(gp, stream); break;
+        case SGV_F64: launch_generic<double>(gp, stream); break;
+        default: return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d: unknown dtype %d", dtype);
+    }
+    return sgv_check_launch("upfirdn2d_generic_kernel");
+}

@@ -1,0 +1,245 @@
+"""Native-library loader: builds and loads ``csrc/libsgv_hip.so`` (hand-written gfx950 HIP kernels
+behind the C ABI of ``include/sgv_ops.h``).
+
+Replaces the reference's JIT plugin loader ``custom_ops.get_plugin`` (src/torch_utils/custom_ops.py:46-124),
+which shells out to nvcc through ``torch.utils.cpp_extension.load``.  Differences, on purpose:
+
+* ahead-of-time ``hipcc --offload-arch=gfx950`` into the source tree (the .so ships with the repo
+  snapshot; nothing lands in ``~/.cache``), keyed by an md5 over the sources like the reference's
+  digest-named build dir (custom_ops.py:80-89);
+* a failed build/load is cached and re-raised -- the reference's ``upfirdn2d._init`` retries a full
+  build on every call because it never sets ``_inited`` (upfirdn2d.py:26-35);
+* there is NO silent fallback: an op invoked on a GPU tensor with ``impl='cuda'`` raises if the
+  library is unavailable (the reference warns once and falls back to the slow path forever,
+  bias_act.py:49-50).
+"""
+
+import ctypes
+import hashlib
+import os
+import shutil
+import subprocess
+import threading
+from concurrent.futures import ThreadPoolExecutor
+
+verbosity = 'brief'  # 'none' | 'brief' | 'full'  (same knob as custom_ops.py:23)
+
+_PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC_DIR = os.path.join(_PKG_DIR, 'csrc')
+INCLUDE_DIR = os.path.join(os.path.dirname(_PKG_DIR), 'include')
+LIB_PATH = os.path.join(CSRC_DIR, 'libsgv_hip.so')
+_HASH_PATH = LIB_PATH + '.md5'
+GPU_ARCH = 'gfx950'
+
+_lock = threading.Lock()
+_lib = None
+_load_error = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def _sources():
+    hip = sorted(f for f in os.listdir(CSRC_DIR) if f.endswith('.hip'))
+    hdr = sorted(f for f in os.listdir(CSRC_DIR) if f.endswith('.h'))
+    return [os.path.join(CSRC_DIR, f) for f in hip], [os.path.join(CSRC_DIR, f) for f in hdr] + [os.path.join(INCLUDE_DIR, 'sgv_ops.h')]
+
+
+def source_digest():
+    md5 = hashlib.md5()
+    hip, hdr = _sources()
+    for path in hip + hdr:
+        md5.update(os.path.basename(path).encode())
+        with open(path, 'rb') as fh:
+            md5.update(fh.read())
+    md5.update(GPU_ARCH.encode())
+    return md5.hexdigest()
+
+
+def is_built():
+    if not (os.path.isfile(LIB_PATH) and os.path.isfile(_HASH_PATH)):
+        return False
+    with open(_HASH_PATH) as fh:
+        return fh.read().strip() == source_digest()
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.isfile(exe):
+        raise NativeLibraryError('hipcc not found; cannot build libsgv_hip.so')
+    return exe
+
+
+def build_native(force=False):
+    """Compile every csrc/*.hip for gfx950 and link libsgv_hip.so in-tree.  Returns the .so path."""
+    with _lock:
+        if not force and is_built():
+            return LIB_PATH
+        hipcc = _hipcc()
+        hip, _ = _sources()
+        obj_dir = os.path.join(CSRC_DIR, '_build')
+        os.makedirs(obj_dir, exist_ok=True)
+        flags = ['--offload-arch=' + GPU_ARCH, '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value']
+
+        def compile_one(src):
+            obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + '.o')
+            cmd = [hipcc] + flags + ['-c', src, '-o', obj]
+            if verbosity == 'full':
+                print(' '.join(cmd))
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise NativeLibraryError('hipcc failed for %s:\n%s' % (src, res.stderr[-4000:]))
+            return obj
+
+        if verbosity != 'none':
+            print('[sgv] building libsgv_hip.so for %s (%d sources)...' % (GPU_ARCH, len(hip)), flush=True)
+        with ThreadPoolExecutor(max_workers=min(8, len(hip))) as pool:
+            objs = list(pool.map(compile_one, hip))
+        tmp = LIB_PATH + '.tmp.%d' % os.getpid()
+        res = subprocess.run([hipcc, '--offload-arch=' + GPU_ARCH, '-shared', '-o', tmp] + objs, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise NativeLibraryError('link failed:\n%s' % res.stderr[-4000:])
+        os.replace(tmp, LIB_PATH)
+        with open(_HASH_PATH, 'w') as fh:
+            fh.write(source_digest())
+        return LIB_PATH
+
+
+def get_native(build=True):
+    """Return the loaded ctypes library, building it first if the in-tree .so is stale/missing.
+
+    Raises NativeLibraryError (cached) if it cannot be provided.
+    """
+    global _lib, _load_error
+    if _lib is not None:
+        return _lib
+    if _load_error is not None:
+        raise _load_error
+    try:
+        if not is_built():
+            if not build or os.environ.get('SGV_NO_BUILD') == '1':
+                raise NativeLibraryError('libsgv_hip.so is missing or stale (%s) and building is disabled' % LIB_PATH)
+            build_native()
+        lib = ctypes.CDLL(LIB_PATH)
+        _declare(lib)
+        if lib.sgv_version() // 100 != 1:
+            raise NativeLibraryError('libsgv_hip.so ABI version mismatch: %d' % lib.sgv_version())
+        _lib = lib
+        return lib
+    except Exception as exc:  # cache the failure: never retry a broken build per call
+        _load_error = exc if isinstance(exc, NativeLibraryError) else NativeLibraryError(str(exc))
+        raise _load_error
+
+
+def native_loaded():
+    return _lib is not None
+
+
+# ----------------------------------------------------------------------------------------------
+# ctypes mirror of include/sgv_ops.h
+
+c_void_p, c_int, c_int32, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
+
+SGV_F32, SGV_F16, SGV_BF16, SGV_F64 = 0, 1, 2, 3
+SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm']
+
+
+class Upfirdn2dParams(ctypes.Structure):
+    _fields_ = [
+        ('x', c_void_p), ('f', c_void_p), ('y', c_void_p),
+        ('up_x', c_int32), ('up_y', c_int32), ('down_x', c_int32), ('down_y', c_int32),
+        ('pad_x0', c_int32), ('pad_x1', c_int32), ('pad_y0', c_int32), ('pad_y1', c_int32),
+        ('flip', c_int32), ('gain', c_float),
+        ('in_w', c_int32), ('in_h', c_int32), ('in_c', c_int32), ('in_n', c_int32),
+        ('in_sw', c_int64), ('in_sh', c_int64), ('in_sc', c_int64), ('in_sn', c_int64),
+        ('f_w', c_int32), ('f_h', c_int32), ('f_sw', c_int64), ('f_sh', c_int64),
+        ('out_w', c_int32), ('out_h', c_int32),
+        ('out_sw', c_int64), ('out_sh', c_int64), ('out_sc', c_int64), ('out_sn', c_int64),
+    ]
+
+
+class BiasActParams(ctypes.Structure):
+    _fields_ = [
+        ('x', c_void_p), ('b', c_void_p), ('xref', c_void_p), ('yref', c_void_p), ('dy', c_void_p), ('y', c_void_p),
+        ('grad', c_int32), ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float),
+        ('size_x', c_int32), ('size_b', c_int32), ('step_b', c_int32),
+    ]
+
+
+class TimeEncodeParams(ctypes.Structure):
+    _fields_ = [(name, c_void_p) for name in
+                ['periods', 'phases', 'al', 'ar', 'freqs', 'phase_scales', 't', 't_left', 't_right', 'alpha', 'out']] + \
+               [('rows', c_int32), ('nf', c_int32)]
+
+
+class GemmParams(ctypes.Structure):
+    _fields_ = [
+        ('a', c_void_p), ('b', c_void_p), ('bias', c_void_p), ('c', c_void_p),
+        ('m', c_int32), ('n', c_int32), ('k', c_int32),
+        ('lda', c_int64), ('ldb', c_int64), ('ldc', c_int64),
+        ('trans_b', c_int32), ('batch', c_int32),
+        ('stride_a', c_int64), ('stride_b', c_int64), ('stride_c', c_int64),
+        ('bias_mode', c_int32),
+    ]
+
+
+class ProfEntry(ctypes.Structure):
+    _fields_ = [('launches', c_int64), ('ms', c_double), ('bytes', c_double), ('flops', c_double)]
+
+
+# name -> (restype, argtypes); also the list of symbols include/sgv_ops.h declares.
+ABI_SYMBOLS = {
+    'sgv_upfirdn2d': (c_int, [ctypes.POINTER(Upfirdn2dParams), c_int, c_void_p]),
+    'sgv_upfirdn2d_kernel_kind': (c_int, [ctypes.POINTER(Upfirdn2dParams), c_int]),
+    'sgv_bias_act': (c_int, [ctypes.POINTER(BiasActParams), c_int, c_void_p]),
+    'sgv_weight_sqsum': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
+    'sgv_demod_coefs': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'sgv_scale_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'sgv_time_encode': (c_int, [ctypes.POINTER(TimeEncodeParams), c_void_p]),
+    'sgv_gemm_f32': (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
+    'sgv_prof_enable': (c_int, [c_int32]),
+    'sgv_prof_disable': (c_int, []),
+    'sgv_prof_collect': (c_int, [ctypes.POINTER(ProfEntry)]),
+    'sgv_launch_count': (c_int64, []),
+    'sgv_version': (c_int, []),
+    'sgv_last_error': (ctypes.c_char_p, []),
+}
+
+
+def _declare(lib):
+    for name, (restype, argtypes) in ABI_SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = restype
+        fn.argtypes = argtypes
+
+
+def check(rc, lib=None):
+    """Map a C-ABI error code to the Python exception the reference's TORCH_CHECK would raise."""
+    if rc == 0:
+        return
+    lib = lib or get_native()
+    msg = lib.sgv_last_error().decode(errors='replace')
+    raise RuntimeError(msg or ('libsgv_hip error %d' % rc))
+
+
+def launch_count():
+    return int(get_native().sgv_launch_count()) if native_loaded() else 0
+
+
+# ----------------------------------------------------------------------------------------------
+# Profiling helpers used by bench.py
+
+def prof_enable(max_records=1 << 16):
+    check(get_native().sgv_prof_enable(max_records))
+
+
+def prof_disable():
+    check(get_native().sgv_prof_disable())
+
+
+def prof_collect():
+    entries = (ProfEntry * len(SGV_K_NAMES))()
+    check(get_native().sgv_prof_collect(entries))
+    return {name: dict(launches=int(e.launches), ms=float(e.ms), bytes=float(e.bytes), flops=float(e.flops))
+            for name, e in zip(SGV_K_NAMES, entries)}

@@ -1,0 +1,292 @@
+#!/usr/bin/env python3
+"""Generates the golden fixtures in tests/golden/*.npz by IMPORTING THE REFERENCE.
+
+Run in the build container only (needs /root/reference, read-only):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+The reference ships no op tests or golden vectors (its only test is tests/test_data_utils.py), so
+parity is pinned on outputs of the reference's own implementations executed here on CPU:
+`_upfirdn2d_ref` (src/torch_utils/ops/upfirdn2d.py:169-208), `_bias_act_ref`
+(src/torch_utils/ops/bias_act.py:94-123), `conv2d_resample` (conv2d_resample.py:59), `fma` (fma.py:15),
+`modulated_conv2d` (src/training/networks.py:29-86), `Generator` / `Discriminator`
+(networks.py:370-401, 580-673), `MotionMappingNetwork` (src/training/motion.py:18-156) and
+`StyleGAN2Loss.accumulate_gradients` (src/training/loss.py:74-173), plus autograd through them for
+first and second derivatives.  Everything is seeded; fixtures are float32 (float64 where noted).
+Nothing from the reference is copied into this repository -- only numbers.
+"""
+import json
+import os
+import sys
+
+os.environ.setdefault('PYTHONDONTWRITEBYTECODE', '1')
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = '/root/reference'
+sys.path[:0] = [os.path.join(HERE, '_shims'), REF, os.path.join(REF, 'src')]
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from src.torch_utils.ops import upfirdn2d as R_ufd, bias_act as R_ba, conv2d_resample as R_cr, fma as R_fma  # noqa: E402
+
+
+def save(name, arrays, meta):
+    arrays = {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in arrays.items()}
+    arrays['__meta__'] = np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8)
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print('%-28s %7.1f KiB  %d arrays' % (name + '.npz', os.path.getsize(path) / 1024, len(arrays)))
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_upfirdn2d():
+    g = torch.Generator().manual_seed(1234)
+    cases = []
+    f4 = [1, 3, 3, 1]
+    sym6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466,
+            0.787641141030194, 0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578,
+            0.0017677118642428036, -0.007800708325034148]  # augment.py wavelet 'sym6' low-pass taps
+    # (shape, filter, up, down, padding, flip, gain) -- hot-path calls of SURVEY.md 2.2 first.
+    hot = [
+        ((2, 3, 17, 17), f4, 1, 1, [1, 1, 1, 1], False, 4),       # G conv0 FIR after conv_transpose
+        ((2, 3, 17, 17), f4, 1, 1, [2, 2, 2, 2], True, 4),        # ... its backward
+        ((2, 3, 8, 8), f4, 2, 1, [2, 1, 2, 1], False, 4),         # G skip-RGB upsample
+        ((2, 3, 16, 16), f4, 1, 2, [1, 1, 1, 1], True, 4),        # ... its backward
+        ((2, 5, 16, 16), f4, 1, 2, [1, 1, 1, 1], False, 1),       # D skip down2
+        ((2, 5, 16, 16), f4, 1, 1, [2, 2, 2, 2], False, 1),       # D conv1 pre-FIR -> 17x17
+        ((1, 2, 33, 33), f4, 1, 1, [1, 1, 1, 1], False, 4),
+        ((1, 2, 32, 32), f4, 1, 1, [2, 2, 2, 2], False, 1),       # out width 33: ragged tail column
+        ((1, 2, 12, 20), sym6, (2, 1), 1, [6, 5, 0, 0], False, 2),   # ADA separable passes as 2-D [1,12] / [12,1]
+        ((1, 2, 12, 20), sym6, 1, (2, 1), [5, 5, 0, 0], True, 1),
+    ]
+    for shape, f, up, down, pad, flip, gain in hot:
+        cases.append(dict(shape=shape, f=f, fdim=(2 if f is f4 else 1), up=up, down=down, padding=pad, flip=flip, gain=gain))
+    rng = np.random.RandomState(7)
+    for _ in range(40):  # random configs incl. crops, mixed up&down, non-square filters
+        upx, upy = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+        dnx, dny = int(rng.randint(1, 4)), int(rng.randint(1, 4))
+        fw, fh = int(rng.randint(1, 7)), int(rng.randint(1, 7))
+        h, w = int(rng.randint(5, 14)), int(rng.randint(5, 14))
+        pad = [int(v) for v in rng.randint(-2, 5, size=4)]
+        ow = (w * upx + pad[0] + pad[1] - fw + dnx) // dnx
+        oh = (h * upy + pad[2] + pad[3] - fh + dny) // dny
+        if ow < 1 or oh < 1:
+            continue
+        f = rng.randn(fh, fw).astype(np.float32).tolist()
+        cases.append(dict(shape=(2, 3, h, w), f=f, fdim=2, up=(upx, upy), down=(dnx, dny), padding=pad, flip=bool(rng.randint(2)),
+                          gain=float(rng.uniform(0.5, 3))))
+    cases.append(dict(shape=(1, 2, 9, 11), f=sym6, fdim=1, up=2, down=1, padding=[6, 5, 6, 5], flip=False, gain=4))  # truly separable call
+    cases.append(dict(shape=(1, 2, 24, 22), f=sym6, fdim=1, up=1, down=2, padding=[5, 5, 5, 5], flip=True, gain=1))
+    cases.append(dict(shape=(2, 2, 6, 6), f=None, fdim=0, up=1, down=1, padding=0, flip=False, gain=1))
+    arrays, meta = {}, []
+    for i, c in enumerate(cases):
+        x = torch.randn(c['shape'], generator=g, dtype=torch.float64).requires_grad_(True)
+        if c['f'] is None:
+            f = None
+        else:
+            f = torch.tensor(c['f'], dtype=torch.float32)
+            if c['fdim'] == 2 and f.ndim == 1:
+                f = R_ufd.setup_filter(c['f'])
+        y = R_ufd.upfirdn2d(x, f, up=c['up'], down=c['down'], padding=c['padding'], flip_filter=c['flip'], gain=c['gain'], impl='ref')
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64).requires_grad_(True)
+        (dx,) = torch.autograd.grad(y, x, dy, create_graph=True)
+        v = torch.randn(dx.shape, generator=g, dtype=torch.float64)
+        (ddy,) = torch.autograd.grad((dx * v).sum(), dy)
+        arrays.update({f'c{i}_x': x, f'c{i}_y': y, f'c{i}_dy': dy, f'c{i}_dx': dx, f'c{i}_v': v, f'c{i}_ddy': ddy})
+        if f is not None:
+            arrays[f'c{i}_f'] = f
+        meta.append({k: c[k] for k in ('up', 'down', 'padding', 'flip', 'gain')} | {'has_f': f is not None})
+    save('upfirdn2d', arrays, meta)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_bias_act():
+    g = torch.Generator().manual_seed(99)
+    arrays, meta = {}, []
+    variants = [dict(shape=(2, 5, 6, 6), dim=1, bias=True, clamp=None, gain=None, alpha=None),
+                dict(shape=(2, 5, 6, 6), dim=1, bias=True, clamp=0.7, gain=1.7, alpha=0.3),
+                dict(shape=(4, 12), dim=1, bias=True, clamp=None, gain=None, alpha=None),
+                dict(shape=(3, 4, 5), dim=2, bias=True, clamp=1.1, gain=None, alpha=None),
+                dict(shape=(2, 3, 4, 4), dim=1, bias=False, clamp=0.5, gain=0.9, alpha=None)]
+    i = 0
+    for act in R_ba.activation_funcs:
+        for v in variants:
+            x = (torch.randn(v['shape'], generator=g, dtype=torch.float64) * 1.5).requires_grad_(True)
+            b = torch.randn([v['shape'][v['dim']]], generator=g, dtype=torch.float64).requires_grad_(True) if v['bias'] else None
+            y = R_ba.bias_act(x, b, dim=v['dim'], act=act, alpha=v['alpha'], gain=v['gain'], clamp=v['clamp'], impl='ref')
+            dy = torch.randn(y.shape, generator=g, dtype=torch.float64).requires_grad_(True)
+            ins = [x] + ([b] if b is not None else [])
+            grads = torch.autograd.grad(y, ins, dy, create_graph=True)
+            w = torch.randn(x.shape, generator=g, dtype=torch.float64)
+            second = torch.autograd.grad((grads[0] * w).sum(), [dy, x], allow_unused=True)
+            arrays.update({f'c{i}_x': x, f'c{i}_y': y, f'c{i}_dy': dy, f'c{i}_dx': grads[0], f'c{i}_w': w, f'c{i}_ddy': second[0]})
+            arrays[f'c{i}_ddx'] = second[1] if second[1] is not None else torch.zeros_like(x)
+            if b is not None:
+                arrays[f'c{i}_b'] = b
+                arrays[f'c{i}_db'] = grads[1]
+            meta.append(dict(act=act, dim=v['dim'], clamp=v['clamp'], gain=v['gain'], alpha=v['alpha'], has_b=b is not None))
+            i += 1
+    save('bias_act', arrays, meta)
+
+
+# ------------------------------------------------------------------------------------------------
+def gen_conv_ops():
+    from training.networks import modulated_conv2d as R_modconv
+    g = torch.Generator().manual_seed(5)
+    arrays, meta = {}, []
+    f = R_ufd.setup_filter([1, 3, 3, 1])
+    arrays['f'] = f
+    cr = [dict(cin=4, cout=6, k=3, up=1, down=1, padding=1, flip_weight=True), dict(cin=4, cout=6, k=3, up=2, down=1, padding=1, flip_weight=False),
+          dict(cin=4, cout=6, k=3, up=1, down=2, padding=1, flip_weight=True), dict(cin=4, cout=6, k=1, up=1, down=2, padding=0, flip_weight=True),
+          dict(cin=4, cout=6, k=1, up=2, down=1, padding=0, flip_weight=True), dict(cin=4, cout=3, k=1, up=1, down=1, padding=0, flip_weight=True),
+          dict(cin=4, cout=6, k=3, up=1, down=1, padding=[1, 0, 2, 1], flip_weight=True), dict(cin=4, cout=4, k=3, up=2, down=2, padding=1, flip_weight=True)]
+    for i, c in enumerate(cr):
+        x = torch.randn([2, c['cin'], 8, 8], generator=g, dtype=torch.float64).requires_grad_(True)
+        w = torch.randn([c['cout'], c['cin'], c['k'], c['k']], generator=g, dtype=torch.float64).requires_grad_(True)
+        y = R_cr.conv2d_resample(x=x, w=w, f=f, up=c['up'], down=c['down'], padding=c['padding'], flip_weight=c['flip_weight'])
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        dx, dw = torch.autograd.grad(y, [x, w], dy)
+        arrays.update({f'cr{i}_x': x, f'cr{i}_w': w, f'cr{i}_y': y, f'cr{i}_dy': dy, f'cr{i}_dx': dx, f'cr{i}_dw': dw})
+        meta.append(dict(kind='conv2d_resample', **c))
+    mc = [dict(cin=5, cout=7, k=3, up=1, demodulate=True, fused=False, noise=False), dict(cin=5, cout=7, k=3, up=2, demodulate=True, fused=False, noise=True),
+          dict(cin=5, cout=3, k=1, up=1, demodulate=False, fused=False, noise=False), dict(cin=5, cout=7, k=3, up=1, demodulate=True, fused=True, noise=False),
+          dict(cin=5, cout=7, k=3, up=2, demodulate=True, fused=True, noise=False), dict(cin=5, cout=3, k=1, up=1, demodulate=False, fused=True, noise=False)]
+    for i, c in enumerate(mc):
+        x = torch.randn([3, c['cin'], 8, 8], generator=g, dtype=torch.float64).requires_grad_(True)
+        w = torch.randn([c['cout'], c['cin'], c['k'], c['k']], generator=g, dtype=torch.float64).requires_grad_(True)
+        s = (torch.randn([3, c['cin']], generator=g, dtype=torch.float64) + 1).requires_grad_(True)
+        res = 8 * c['up']
+        noise = torch.randn([3, 1, res, res], generator=g, dtype=torch.float64) if c['noise'] else None
+        y = R_modconv(x=x, weight=w, styles=s, noise=noise, up=c['up'], padding=c['k'] // 2, resample_filter=f, demodulate=c['demodulate'],
+                      flip_weight=(c['up'] == 1), fused_modconv=c['fused'])
+        dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+        dx, dw, ds = torch.autograd.grad(y, [x, w, s], dy)
+        arrays.update({f'mc{i}_x': x, f'mc{i}_w': w, f'mc{i}_s': s, f'mc{i}_y': y, f'mc{i}_dy': dy, f'mc{i}_dx': dx, f'mc{i}_dw': dw, f'mc{i}_ds': ds})
+        if noise is not None:
+            arrays[f'mc{i}_noise'] = noise
+        meta.append(dict(kind='modulated_conv2d', **c))
+    a = torch.randn([2, 3, 4, 4], generator=g, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn([2, 3, 1, 1], generator=g, dtype=torch.float64).requires_grad_(True)
+    c_ = torch.randn([2, 1, 4, 4], generator=g, dtype=torch.float64).requires_grad_(True)
+    y = R_fma.fma(a, b, c_)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    da, db, dc = torch.autograd.grad(y, [a, b, c_], dy)
+    arrays.update(dict(fma_a=a, fma_b=b, fma_c=c_, fma_y=y, fma_dy=dy, fma_da=da, fma_db=db, fma_dc=dc))
+    save('conv_ops', arrays, meta)
+
+
+# ------------------------------------------------------------------------------------------------
+def small_cfgs():
+    from omegaconf import OmegaConf
+    sampling = dict(type='random', num_frames_per_video=3, max_num_frames=64, total_dists=[1, 2, 4, 8, 16, 32], max_dist=32, name='random3_max32')
+    gen = dict(sampling=sampling, use_noise=False, input=dict(type='temporal'), w_dim=32, z_dim=32, c_dim=0,
+               motion=dict(z_dim=24, v_dim=24, motion_z_distance=4, gen_strategy='conv', kernel_size=5, use_fractional_t=True, fourier=True),
+               time_enc=dict(cond_type='concat_const', dim=8, min_period_len=4, max_period_len=64, phase_dropout_std=1.0))
+    dis = dict(sampling=sampling, concat_res=16, num_frames_div_factor=2, dummy_c=False)
+    return OmegaConf.create(gen), OmegaConf.create(dis), sampling
+
+
+def build_small_models(res=32):
+    from training.networks import Generator, Discriminator
+    gcfg, dcfg, _ = small_cfgs()
+    torch.manual_seed(2024)
+    G = Generator(c_dim=0, w_dim=32, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=2, cfg=gcfg),
+                  synthesis_kwargs=dict(channel_base=res * 16, channel_max=32, num_fp16_res=0, conv_clamp=None), cfg=gcfg)
+    D = Discriminator(c_dim=0, img_resolution=res, img_channels=3, channel_base=res * 16, channel_max=32, num_fp16_res=0, conv_clamp=None,
+                      mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2), cfg=dcfg)
+    # biases / noise strengths start at zero in the reference; randomise them so the fixtures exercise them
+    with torch.no_grad():
+        for mod in (G, D):
+            for name, p in mod.named_parameters():
+                if name.endswith('bias') and p.abs().sum() == 0:
+                    p.copy_(torch.randn_like(p) * 0.1)
+    return G, D
+
+
+def gen_networks():
+    G, D = build_small_models()
+    g = torch.Generator().manual_seed(77)
+    B, F = 4, 3
+    z = torch.randn([B, 32], generator=g)
+    c = torch.zeros([B, 0])
+    t = torch.sort(torch.rand([B, F], generator=g) * 40, dim=1).values
+    traj_len = G.synthesis.motion_encoder.get_max_traj_len(t) + G.synthesis.motion_encoder.num_additional_codes
+    motion_z = torch.randn([B, traj_len, 24], generator=g)
+    arrays = {'z': z, 't': t, 'motion_z': motion_z}
+    for name, p in G.state_dict().items():
+        arrays['G.' + name] = p
+    for name, p in D.state_dict().items():
+        arrays['D.' + name] = p
+
+    G.train(); D.train()
+    menc = G.synthesis.motion_encoder(c, t, motion_z=motion_z)
+    arrays['motion_v'] = menc['motion_v']
+    ws = G.mapping(z, c, skip_w_avg_update=True)
+    arrays['ws'] = ws
+    img_train = G.synthesis(ws, t=t, c=c, motion_z=motion_z)
+    arrays['img_train'] = img_train
+    G.eval()
+    arrays['img_eval'] = G.synthesis(ws, t=t, c=c, motion_z=motion_z)  # fused_modconv path
+    arrays['img_trunc'] = G(z, c, t, truncation_psi=0.7, motion_z=motion_z)
+    G.train()
+
+    real = torch.rand([B * F, 3, 32, 32], generator=g) * 2 - 1
+    arrays['real'] = real
+    logits = D(img_train.detach(), c, t)['image_logits']
+    arrays['logits_fake'] = logits
+    # Gmain gradient (loss.py:84-99)
+    G.zero_grad(); D.zero_grad()
+    img = G.synthesis(G.mapping(z, c, skip_w_avg_update=True), t=t, c=c, motion_z=motion_z)
+    loss_g = torch.nn.functional.softplus(-D(img, c, t)['image_logits']).mean()
+    loss_g.backward()
+    arrays['loss_Gmain'] = loss_g
+    for name, p in G.named_parameters():
+        arrays['gradG.' + name] = p.grad if p.grad is not None else torch.zeros_like(p)
+    # Dmain + R1 gradient on real images (loss.py:141-173), gamma = 1
+    G.zero_grad(); D.zero_grad()
+    real_tmp = real.clone().requires_grad_(True)
+    logits_real = D(real_tmp, c, t)['image_logits']
+    (r1_grads,) = torch.autograd.grad(logits_real.sum(), real_tmp, create_graph=True)
+    r1 = r1_grads.square().sum([1, 2, 3])
+    loss_r1 = (r1 * 0.5).view(-1, F).mean(dim=1)
+    loss_d = (torch.nn.functional.softplus(-logits_real) + loss_r1).mean()
+    loss_d.backward()
+    arrays['logits_real'] = logits_real
+    arrays['r1_penalty'] = r1
+    arrays['loss_Dreal_r1'] = loss_d
+    for name, p in D.named_parameters():
+        arrays['gradD.' + name] = p.grad if p.grad is not None else torch.zeros_like(p)
+    gcfg, dcfg, sampling = small_cfgs()
+    meta = dict(B=B, F=F, res=32, channel_base=512, channel_max=32, w_dim=32, z_dim=32, mapping_layers=2, mbstd_group_size=2,
+                generator_cfg=dict(gcfg), discriminator_cfg=dict(dcfg), G_params=sum(p.numel() for p in G.parameters()),
+                D_params=sum(p.numel() for p in D.parameters()))
+    save('networks', arrays, json.loads(json.dumps(meta, default=lambda o: dict(o))))
+
+
+def gen_time_encoder():
+    """AlignedTimeEncoder + motion-code gather in float64 for a tight kernel tolerance."""
+    from training.motion import MotionMappingNetwork
+    gcfg, _, _ = small_cfgs()
+    torch.manual_seed(11)
+    enc = MotionMappingNetwork(gcfg).double()
+    g = torch.Generator().manual_seed(3)
+    B, F = 5, 3
+    t = torch.sort(torch.rand([B, F], generator=g, dtype=torch.float64) * 60, dim=1).values
+    c = torch.zeros([B, 0], dtype=torch.float64)
+    L = enc.get_max_traj_len(t) + enc.num_additional_codes
+    mz = torch.randn([B, L, 24], generator=g, dtype=torch.float64)
+    out = enc(c, t, motion_z=mz)
+    arrays = {'t': t, 'motion_z': mz, 'motion_v': out['motion_v']}
+    for name, p in enc.state_dict().items():
+        arrays['enc.' + name] = p
+    save('time_encoder', arrays, dict(B=B, F=F))
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(4)
+    gen_upfirdn2d()
+    gen_bias_act()
+    gen_conv_ops()
+    gen_networks()
+    gen_time_encoder()
