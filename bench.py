@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Headline benchmark: StyleGAN-V G+D training-step throughput at 256^2 on N MI355X (one node).
+
+    python bench.py --gpus 1 --steps 16 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2], "FFS 256x256 full G+D train step + PL/R1 reg, bs=32, fp32"):
+FaceForensics-config generator/discriminator (cfg=auto: fmaps 0.5, mapping depth 2, 3 frames per
+video), random-init weights, synthetic frames and latents, fp32.  A "step" is one iteration of the
+reference's phase schedule (src/training/training_loop.py:351-404): Gmain every iteration, Greg every
+4th (a no-op because configs/model/stylegan-v.yaml sets pl_weight 0 -- and the reference's PL term
+cannot run with 3 frames per video), Dmain every iteration, Dreg (R1, double backward)
+every 16th, each followed by nan_to_num + Adam, then the G_ema update.  Per-GPU batch is fixed
+(weak scaling): `--batch-gpu` videos x 3 frames per rank; DDP all-reduces G/D gradients over RCCL.
+
+The single JSON line carries, besides the contract fields:
+  roofline      the hand-written upfirdn2d row-walker kernel: algorithmic bytes / HIP-event time summed over
+                every launch inside the timed steps (events recorded by the C ABI on the launch stream)
+  kernels       the same accounting for every native kernel family
+  cpu_baseline  the same training step on the host CPU through the plain-PyTorch op path (a restatement
+                of the reference's CPU fallback ops), on a bounded sample (1 video = 3 frames per step)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling 6290 GB/s
+HBM_COPY_GBPS = 6290.0
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(res, frames, seconds_cap):
+    """One G+D iteration per batch of ONE video (3 frames) on the host cores, plain-PyTorch ops."""
+    from stylegan_v_amd.training import config as cfgs
+    from stylegan_v_amd.training.train_step import TrainStep
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    threads = max(1, min(cores, 64))
+    torch.set_num_threads(threads)
+    g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=res, batch_size=1, num_gpus=1, fp32=True, num_frames_per_video=frames)
+    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=1, world_size=1, ddp=False)
+    t0 = time.time()
+    ts.step()  # iteration 0 runs all four phases (incl. the R1 double backward)
+    first = time.time() - t0
+    done, spent = 1, first
+    while spent + first * 0.6 < seconds_cap and done < 4:
+        t1 = time.time()
+        ts.step()
+        spent += time.time() - t1
+        done += 1
+    model = ''
+    try:
+        with open('/proc/cpuinfo') as fh:
+            for line in fh:
+                if line.startswith('model name'):
+                    model = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return dict(value=done * frames / spent, unit='img/s', cores=threads, kind='port', cpu=model,
+                sample=f'{done} training iteration(s) at batch 1 video x {frames} frames, {res}x{res}, fp32 (iteration 0 includes Greg+Dreg), {spent:.1f} s')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=16)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch-gpu', type=int, default=32, help='videos per GPU (x3 frames each)')
+    ap.add_argument('--res', type=int, default=256)
+    ap.add_argument('--frames', type=int, default=3)
+    ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline leg; 0 disables it')
+    ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}'
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    from stylegan_v_amd.torch_utils import custom_ops
+    from stylegan_v_amd.training import config as cfgs
+    from stylegan_v_amd.training.train_step import TrainStep
+    custom_ops.verbosity = 'none' if rank else 'brief'
+    custom_ops.get_native()  # fail loudly here if the HIP library is missing
+
+    # The reference sets cudnn.benchmark=True (training_loop.py:140).  MIOpen in this image ships no gfx950 find-db, so
+    # "find" would time every solver (incl. the naive one) on full-size tensors for many minutes: use immediate mode.
+    import stylegan_v_amd
+    stylegan_v_amd.configure_miopen(immediate=os.environ.get('SGV_MIOPEN_FIND', '0') != '1')
+    global_batch = args.batch_gpu * world
+    g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=True,
+                                                      num_frames_per_video=args.frames)
+    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        tw = time.perf_counter()
+        ts.step()
+        torch.cuda.synchronize()
+        if rank == 0:
+            log(f'[bench] warm-up iteration {i}: {time.perf_counter() - tw:.2f} s (includes MIOpen kernel compilation on a cold cache)')
+    # Start the timed window on an iteration that runs the regularisation phases, whatever the warm-up was.
+    ts.batch_idx = 0
+    launches0 = custom_ops.launch_count()
+    if not args.no_prof:
+        custom_ops.prof_enable(1 << 17)
+    barrier()
+    t0 = time.perf_counter()
+    phases_run = {}
+    for _ in range(args.steps):
+        for name in ts.step():
+            phases_run[name] = phases_run.get(name, 0) + 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches = custom_ops.launch_count() - launches0
+    prof = None
+    if not args.no_prof:
+        custom_ops.prof_disable()
+        prof = custom_ops.prof_collect()
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    frames_total = global_batch * args.frames * args.steps
+    value = frames_total / elapsed
+
+    if rank == 0:
+        kernels = {}
+        roofline = None
+        if prof is not None:
+            for name, e in prof.items():
+                if e['launches'] == 0:
+                    continue
+                k = dict(launches=e['launches'], ms_total=e['ms'], avg_us=1e3 * e['ms'] / e['launches'])
+                if e['bytes'] > 0:
+                    k['GBps'] = e['bytes'] / (e['ms'] * 1e-3) / 1e9
+                    k['bytes_per_launch'] = e['bytes'] / e['launches']
+                if e['flops'] > 0:
+                    k['TFLOPs'] = e['flops'] / (e['ms'] * 1e-3) / 1e12
+                kernels[name] = k
+            r = prof['upfirdn2d_rows']
+            if r['launches']:
+                achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
+                roofline = dict(kernel='upfirdn2d_rows_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
+                                frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=None, launches=r['launches'],
+                                avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
+                                note='all launches inside the timed steps (every layer size, fwd+bwd+double-bwd), size-weighted')
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            log('[bench] timing the CPU baseline leg ...')
+            cpu = cpu_baseline(args.res, args.frames, args.cpu_seconds)
+        out = dict(metric='G+D train-step images/sec at 256^2', value=value, unit='img/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload=f'FFS {args.res}x{args.res} full G+D train step (Gmain+Greg+Dmain+Dreg/R1), cfg=auto fmaps 0.5, fp32',
+                               videos_per_gpu=args.batch_gpu, frames_per_video=args.frames, frames_per_gpu=args.batch_gpu * args.frames,
+                               global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
+                               pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
+                               native_launches_per_step=launches / args.steps),
+                   roofline=roofline, kernels=kernels, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

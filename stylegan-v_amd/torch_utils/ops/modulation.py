@@ -1,0 +1,100 @@
+"""Weight (de)modulation primitives of ``modulated_conv2d`` (reference: src/training/networks.py:57-74).
+
+The reference forms w[N,O,I,kh,kw] = W * s in PyTorch only to reduce it to the demodulation
+coefficients d[N,O]; here d comes from two small kernels that never build that tensor
+(csrc/modulate.hip: ``sgv_weight_sqsum`` + ``sgv_demod_coefs``), and the per-sample channel scaling
+x * s[n, c] (pre-conv styles, post-conv dcoefs; networks.py:66,70-71) is one streaming kernel
+(``sgv_scale_channels``).  GPU fp32 tensors take the native path; everything else (CPU, fp64
+gradcheck) evaluates the same algebra with PyTorch ops.  Backward passes are written with
+differentiable tensor ops, so gradients of any order are available.
+"""
+
+import torch
+
+from .. import custom_ops
+from .upfirdn2d import _DTYPE_CODES
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def weight_sqsum_ref(weight):
+    return weight.float().square().sum(dim=[2, 3])
+
+
+def demod_coefs_ref(weight, styles, eps=1e-8):
+    """d[n,o] = rsqrt(sum_i s[n,i]^2 * sum_k W[o,i,k]^2 + eps): networks.py:59-61 without w[N,O,I,k,k]."""
+    q = weight.square().sum(dim=[2, 3])  # [O, I]
+    return (styles.square() @ q.t() + eps).rsqrt()
+
+
+class _DemodCoefsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight, styles, eps):
+        lib = custom_ops.get_native()
+        w = weight.contiguous()
+        s = styles.contiguous()
+        oc, ic, kh, kw = w.shape
+        n = s.shape[0]
+        q = torch.empty([oc, ic], dtype=torch.float32, device=w.device)
+        d = torch.empty([n, oc], dtype=torch.float32, device=w.device)
+        with torch.cuda.device_of(w):
+            custom_ops.check(lib.sgv_weight_sqsum(w.data_ptr(), q.data_ptr(), oc, ic, kh * kw, _stream(w)), lib)
+            custom_ops.check(lib.sgv_demod_coefs(s.data_ptr(), q.data_ptr(), d.data_ptr(), n, oc, ic, float(eps), _stream(w)), lib)
+        ctx.save_for_backward(weight, styles, q, d)
+        return d
+
+    @staticmethod
+    def backward(ctx, grad_d):
+        weight, styles, q, d = ctx.saved_tensors
+        # d = (s^2 q^T + eps)^(-1/2)  =>  dd/d(s^2 q^T) = -d^3 / 2
+        g = grad_d * (-0.5) * d.pow(3)  # [N, O]
+        grad_w = grad_s = None
+        if ctx.needs_input_grad[0]:
+            grad_q = g.t() @ styles.square()  # [O, I]
+            grad_w = 2 * weight * grad_q[:, :, None, None]
+        if ctx.needs_input_grad[1]:
+            grad_s = 2 * styles * (g @ q)  # [N, I]
+        return grad_w, grad_s, None
+
+
+def demod_coefs(weight, styles, eps=1e-8):
+    """Demodulation coefficients [N, O] for weight [O, I, kh, kw] and styles [N, I]."""
+    if weight.is_cuda and weight.dtype == torch.float32 and styles.dtype == torch.float32:
+        return _DemodCoefsFn.apply(weight, styles, eps)
+    return demod_coefs_ref(weight, styles, eps)
+
+
+class _ScaleChannelsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, s):
+        lib = custom_ops.get_native()
+        xc = x.contiguous()
+        sc = s.contiguous()
+        n, c = xc.shape[:2]
+        hw = xc.numel() // max(n * c, 1)
+        y = torch.empty_like(xc)
+        if xc.numel():
+            with torch.cuda.device_of(xc):
+                custom_ops.check(lib.sgv_scale_channels(xc.data_ptr(), sc.data_ptr(), y.data_ptr(), n, c, hw, _DTYPE_CODES[xc.dtype], _stream(xc)), lib)
+        ctx.save_for_backward(x, s)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, s = ctx.saved_tensors
+        dx = ds = None
+        if ctx.needs_input_grad[0]:
+            dx = scale_channels(dy, s)
+        if ctx.needs_input_grad[1]:
+            ds = (dy.float() * x.float()).sum(dim=[2, 3]).to(s.dtype)
+        return dx, ds
+
+
+def scale_channels(x, s):
+    """x[N,C,H,W] * s[N,C] broadcast over H,W; s is fp32 (computed in fp32, stored in x's dtype)."""
+    if x.is_cuda and x.ndim == 4 and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and s.dtype == torch.float32 \
+            and x.is_contiguous() and x.numel() < 2 ** 31:
+        return _ScaleChannelsFn.apply(x, s)
+    return x * s.to(x.dtype).reshape(x.shape[0], x.shape[1], 1, 1)

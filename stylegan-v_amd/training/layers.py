@@ -1,0 +1,289 @@
+"""Building blocks shared by the generator and the discriminator.
+
+Module/parameter names mirror the reference's ``src/training/layers.py`` so that checkpoints map
+one-to-one: ``MappingNetwork`` (:22), ``FullyConnectedLayer`` (:108), ``Conv2dLayer`` (:142),
+``GenInput`` (:201), ``TemporalInput`` (:230), ``TemporalDifferenceEncoder`` (:255),
+``FixedTimeEncoder`` (:301), ``EqLRConv1d`` (:331), ``sample_frames`` (:377),
+``construct_log_spaced_freqs`` (:439).  Numerics follow SURVEY.md appendix E; all bias/activation
+work goes through the fused ``bias_act`` kernel and every resampling step through ``upfirdn2d``.
+"""
+
+import math
+import random
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from ..torch_utils import misc
+from ..torch_utils.ops import bias_act, conv2d_resample, upfirdn2d
+
+
+@misc.profiled_function
+def normalize_2nd_moment(x, dim=1, eps=1e-8):
+    return x * (x.square().mean(dim=dim, keepdim=True) + eps).rsqrt()
+
+
+class FullyConnectedLayer(torch.nn.Module):
+    """Equalised-learning-rate dense layer: weight stored as randn/lr_mul, used as W*lr_mul/sqrt(in)."""
+
+    def __init__(self, in_features, out_features, bias=True, activation='linear', lr_multiplier=1, bias_init=0):
+        super().__init__()
+        self.activation = activation
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], float(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / math.sqrt(in_features)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        if self.activation == 'linear' and b is not None:
+            return torch.addmm(b.unsqueeze(0), x, w.t())
+        return bias_act.bias_act(x.matmul(w.t()), b, act=self.activation)
+
+    def extra_repr(self):
+        return f'in={self.weight.shape[1]}, out={self.weight.shape[0]}, act={self.activation}'
+
+
+class MappingNetwork(torch.nn.Module):
+    """z (and/or an embedded label c) -> w through ``num_layers`` dense+lrelu layers; tracks the running
+    mean of w for truncation; optionally broadcasts to ``num_ws`` copies."""
+
+    def __init__(self, z_dim, c_dim, w_dim, num_ws, num_layers=8, embed_features=None, layer_features=None,
+                 activation='lrelu', lr_multiplier=0.01, w_avg_beta=0.995, cfg=None):
+        super().__init__()
+        self.cfg = cfg if cfg is not None else {}
+        self.z_dim, self.c_dim, self.w_dim, self.num_ws = z_dim, c_dim, w_dim, num_ws
+        self.num_layers, self.w_avg_beta = num_layers, w_avg_beta
+        embed_features = 0 if c_dim == 0 else (w_dim if embed_features is None else embed_features)
+        layer_features = w_dim if layer_features is None else layer_features
+        widths = [z_dim + embed_features] + [layer_features] * (num_layers - 1) + [w_dim]
+        if c_dim > 0:
+            self.embed = FullyConnectedLayer(c_dim, embed_features)
+        for idx, (fin, fout) in enumerate(zip(widths[:-1], widths[1:])):
+            setattr(self, f'fc{idx}', FullyConnectedLayer(fin, fout, activation=activation, lr_multiplier=lr_multiplier))
+        if num_ws is not None and w_avg_beta is not None:
+            self.register_buffer('w_avg', torch.zeros([w_dim]))
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
+        parts = []
+        if self.z_dim > 0:
+            misc.assert_shape(z, [None, self.z_dim])
+            parts.append(normalize_2nd_moment(z.to(torch.float32)))
+        if self.c_dim > 0:
+            misc.assert_shape(c, [None, self.c_dim])
+            parts.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
+        x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+        for idx in range(self.num_layers):
+            x = getattr(self, f'fc{idx}')(x)
+        if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
+            self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
+        if self.num_ws is not None:
+            x = x.unsqueeze(1).repeat([1, self.num_ws, 1])
+        if truncation_psi != 1:
+            assert self.w_avg_beta is not None
+            if self.num_ws is None or truncation_cutoff is None:
+                x = self.w_avg.lerp(x, truncation_psi)
+            else:
+                x[:, :truncation_cutoff] = self.w_avg.lerp(x[:, :truncation_cutoff], truncation_psi)
+        return x
+
+
+class Conv2dLayer(torch.nn.Module):
+    """Non-modulated convolution (+ optional FIR resampling) followed by the fused bias/activation kernel."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=True, activation='linear', up=1, down=1,
+                 resample_filter=(1, 3, 3, 1), conv_clamp=None, channels_last=False, trainable=True, instance_norm=False,
+                 lr_multiplier=1.0):
+        super().__init__()
+        self.activation, self.up, self.down, self.conv_clamp = activation, up, down, conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(list(resample_filter)))
+        self.padding = kernel_size // 2
+        self.weight_gain = 1 / math.sqrt(in_channels * kernel_size ** 2)
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.instance_norm, self.lr_multiplier = instance_norm, lr_multiplier
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        weight = torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt)
+        bias_t = torch.zeros([out_channels]) if bias else None
+        if trainable:
+            self.weight = torch.nn.Parameter(weight)
+            self.bias = torch.nn.Parameter(bias_t) if bias_t is not None else None
+        else:
+            self.register_buffer('weight', weight)
+            if bias_t is not None:
+                self.register_buffer('bias', bias_t)
+            else:
+                self.bias = None
+
+    def forward(self, x, gain=1):
+        w = self.weight * (self.weight_gain * self.lr_multiplier)
+        b = self.bias.to(x.dtype) * self.lr_multiplier if self.bias is not None else None
+        x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+                                            padding=self.padding, flip_weight=(self.up == 1))
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        x = bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        if self.instance_norm:
+            x = (x - x.mean(dim=(2, 3), keepdim=True)) / (x.std(dim=(2, 3), keepdim=True) + 1e-8)
+        return x
+
+
+class TemporalInput(torch.nn.Module):
+    """4x4 synthesis input: a learned constant concatenated with the motion code broadcast over the 4x4 grid."""
+
+    def __init__(self, cfg, channel_dim, motion_v_dim):
+        super().__init__()
+        self.cfg = cfg
+        self.motion_v_dim = motion_v_dim
+        self.const = torch.nn.Parameter(torch.randn(1, channel_dim, 4, 4))
+
+    def get_dim(self):
+        return self.motion_v_dim + self.const.shape[1]
+
+    def forward(self, motion_v):
+        n = motion_v.shape[0]
+        side = self.const.shape[2:]
+        return torch.cat([self.const.expand(n, -1, -1, -1), motion_v[:, :, None, None].expand(-1, -1, *side)], dim=1)
+
+
+class GenInput(torch.nn.Module):
+    def __init__(self, cfg, channel_dim, motion_v_dim=None):
+        super().__init__()
+        self.cfg = cfg
+        if cfg.input.type == 'const':
+            self.input = torch.nn.Parameter(torch.randn([channel_dim, 4, 4]))
+            self.total_dim = channel_dim
+        elif cfg.input.type == 'temporal':
+            self.input = TemporalInput(cfg, channel_dim, motion_v_dim=motion_v_dim)
+            self.total_dim = self.input.get_dim()
+        else:
+            raise NotImplementedError(f'Unknown input type: {cfg.input.type}')
+
+    def forward(self, batch_size, motion_v=None, dtype=None, memory_format=None):
+        if self.cfg.input.type == 'const':
+            x = self.input.to(dtype=dtype, memory_format=memory_format)
+            return x.unsqueeze(0).repeat([batch_size, 1, 1, 1])
+        return self.input(motion_v=motion_v)
+
+
+def construct_log_spaced_freqs(max_num_frames, skip_small_t_freqs=0):
+    """pi * 2^k / T for k = 0..log2(T)-1, T = max_num_frames rounded up to a power of two."""
+    time_resolution = 2 ** math.ceil(math.log2(max_num_frames))
+    num = int(math.ceil(math.log2(time_resolution)))
+    powers = 2.0 ** torch.arange(num - skip_small_t_freqs, dtype=torch.float32)
+    return (powers * math.pi / time_resolution).unsqueeze(0)
+
+
+class FixedTimeEncoder(torch.nn.Module):
+    def __init__(self, max_num_frames, skip_small_t_freqs=0):
+        super().__init__()
+        assert max_num_frames >= 1
+        self.register_buffer('fourier_coefs', construct_log_spaced_freqs(max_num_frames, skip_small_t_freqs=skip_small_t_freqs))
+
+    def get_dim(self):
+        return self.fourier_coefs.shape[1] * 2
+
+    def forward(self, t):
+        assert t.ndim == 2
+        raw = self.fourier_coefs * t.reshape(-1, 1).float()
+        return torch.cat([raw.sin(), raw.cos()], dim=1)
+
+
+class TemporalDifferenceEncoder(torch.nn.Module):
+    """Discriminator-side embedding of the time gaps between the frames of a clip:
+    learned table lookup of round(dt) concatenated with fixed Fourier features of dt."""
+
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        if cfg.sampling.num_frames_per_video > 1:
+            self.d = 256
+            self.const_embed = torch.nn.Embedding(cfg.sampling.max_num_frames, self.d)
+            self.time_encoder = FixedTimeEncoder(cfg.sampling.max_num_frames, skip_small_t_freqs=cfg.get('skip_small_t_freqs', 0))
+
+    def get_dim(self):
+        nf = self.cfg.sampling.num_frames_per_video
+        if nf == 1:
+            return 1
+        per_diff = self.d + self.time_encoder.get_dim()
+        return per_diff if self.cfg.sampling.type == 'uniform' else per_diff * (nf - 1)
+
+    def forward(self, t):
+        nf = self.cfg.sampling.num_frames_per_video
+        misc.assert_shape(t, [None, nf])
+        if nf == 1:
+            return torch.zeros(len(t), 1, device=t.device)
+        diffs = (t[:, 1] - t[:, 0]) if self.cfg.sampling.type == 'uniform' else (t[:, 1:] - t[:, :-1]).reshape(-1)
+        table = self.const_embed(diffs.float().round().long())
+        fourier = self.time_encoder(diffs.unsqueeze(1))
+        return torch.cat([table, fourier], dim=1).reshape(t.shape[0], -1)
+
+
+class EqLRConv1d(torch.nn.Module):
+    """Equalised-lr 1-D convolution of the motion trajectory network (lrelu slope 0.2, no sqrt(2) gain)."""
+
+    def __init__(self, in_features, out_features, kernel_size, padding=0, stride=1, activation='linear', lr_multiplier=1.0,
+                 bias=True, bias_init=0.0):
+        super().__init__()
+        assert activation in ('lrelu', 'linear')
+        self.activation, self.padding, self.stride = activation, padding, stride
+        self.weight = torch.nn.Parameter(torch.randn([out_features, in_features, kernel_size]) / lr_multiplier)
+        self.bias = torch.nn.Parameter(torch.full([out_features], float(bias_init))) if bias else None
+        self.weight_gain = lr_multiplier / math.sqrt(in_features * kernel_size)
+        self.bias_gain = lr_multiplier
+
+    def forward(self, x):
+        assert x.ndim == 3
+        w = self.weight.to(x.dtype) * self.weight_gain
+        b = self.bias
+        if b is not None:
+            b = b.to(x.dtype)
+            if self.bias_gain != 1:
+                b = b * self.bias_gain
+        y = F.conv1d(x, w, bias=None, stride=self.stride, padding=self.padding)
+        # bias + leaky-relu through the fused kernel (gain 1: the reference applies F.leaky_relu without sqrt(2))
+        return bias_act.bias_act(y, b, dim=1, act=self.activation, gain=1)
+
+
+# ------------------------------------------------------------------------------------------------
+# Host-side frame-index sampling (layers.py:377-435 contract): which frames of a video a clip uses.
+
+
+def sample_frames(cfg, total_video_len, **kwargs):
+    if cfg['type'] == 'random':
+        return random_frame_sampling(cfg, total_video_len, **kwargs)
+    if cfg['type'] == 'uniform':
+        return uniform_frame_sampling(cfg, total_video_len, **kwargs)
+    raise NotImplementedError(cfg['type'])
+
+
+def random_frame_sampling(cfg, total_video_len, use_fractional_t=False):
+    nf = cfg['num_frames_per_video']
+    lo, hi = nf - 1, min(total_video_len - 1, cfg.get('max_dist', float('inf')))
+    dists = cfg.get('total_dists')
+    choices = [d for d in dists if lo <= d <= hi] if isinstance(dists, (list, tuple)) else range(lo, hi)
+    span = random.choice(choices)
+    offset = random.random() * (total_video_len - span - 1) if use_fractional_t else random.randint(0, total_video_len - span - 1)
+    idx = [offset]
+    if nf > 1:
+        idx.append(offset + span)
+    if nf > 2:
+        idx.extend(offset + d for d in random.sample(range(1, span), k=nf - 2))
+    return np.array(sorted(idx))
+
+
+def uniform_frame_sampling(cfg, total_video_len, use_fractional_t=False):
+    nf = cfg['num_frames_per_video']
+    dists = cfg.get('dists_between_frames')
+    if isinstance(dists, (list, tuple)):
+        valid = [d for d in dists if d <= cfg['max_dist_between_frames'] and d * nf - d + 1 <= total_video_len]
+        d = random.choice(valid)
+    else:
+        d = random.randint(1, min(cfg.get('max_dist', float('inf')), total_video_len // nf))
+    total = d * nf - d + 1
+    offset = random.random() * (total_video_len - total) if use_fractional_t else random.randint(0, total_video_len - total)
+    return offset + np.arange(nf) * d

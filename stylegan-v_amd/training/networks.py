@@ -1,0 +1,410 @@
+"""StyleGAN-V generator and discriminator on top of the native op layer.
+
+Module tree and parameter names mirror the reference's ``src/training/networks.py`` (checkpoints map
+one-to-one): ``modulated_conv2d`` (:29-86), ``SynthesisLayer`` (:90), ``ToRGBLayer`` (:148),
+``SynthesisBlock`` (:167), ``SynthesisNetwork`` (:270), ``Generator`` (:370), ``DiscriminatorBlock``
+(:405), ``MinibatchStdLayer`` (:492), ``DiscriminatorEpilogue`` (:518), ``Discriminator`` (:580).
+Architecture/numerics per SURVEY.md appendix E.
+
+What is different underneath (MI355X-first, same results to fp32 round-off):
+  * weight demodulation never builds w[N,O,I,kh,kw]: d = rsqrt(s^2 . sum_k W^2 + eps) comes from
+    ``ops.modulation.demod_coefs`` (csrc/modulate.hip, wave-shuffle reduction);
+  * the per-sample channel scalings x*s and y*d are single streaming kernels (``scale_channels``);
+  * every FIR resampling / bias+activation step is a hand-written gfx950 kernel (upfirdn2d, bias_act);
+  * low-precision blocks can run bf16 as well as the reference's fp16 (``lowp_dtype``).
+3x3 convolutions stay on MIOpen, as the reference leaves them to cuDNN.
+"""
+
+import math
+
+import numpy as np
+import torch
+
+from ..torch_utils import misc
+from ..torch_utils.ops import bias_act, conv2d_resample, fma, modulation, upfirdn2d
+from .layers import Conv2dLayer, FullyConnectedLayer, GenInput, MappingNetwork, TemporalDifferenceEncoder
+from .motion import MotionMappingNetwork
+
+
+@misc.profiled_function
+def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, resample_filter=None, demodulate=True,
+                     flip_weight=True, fused_modconv=True):
+    """y[n,o] = d[n,o] * conv(x[n,i] * s[n,i], W[o,i])  with  d = rsqrt(sum_{i,k}(W*s)^2 + 1e-8)  (+ noise).
+
+    x [N,I,H,W], weight [O,I,kh,kw], styles [N,I], noise broadcastable to the output or None.
+    ``fused_modconv=True`` evaluates the same function as one grouped convolution with per-sample
+    weights (the reference's inference path, networks.py:77-86); ``False`` scales activations before
+    and after a shared-weight convolution (training path, networks.py:65-74).
+    """
+    n = x.shape[0]
+    oc, ic, kh, kw = weight.shape
+    misc.assert_shape(x, [n, ic, None, None])
+    misc.assert_shape(styles, [n, ic])
+
+    # fp16 range guard of the reference (networks.py:50-52); bf16/fp32 have the exponent range and skip it.
+    if x.dtype == torch.float16 and demodulate:
+        weight = weight * (1 / math.sqrt(ic * kh * kw) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+        styles = styles / styles.norm(float('inf'), dim=1, keepdim=True)
+
+    dcoefs = modulation.demod_coefs(weight, styles) if demodulate else None  # [N, O], fp32
+
+    if not fused_modconv:
+        x = modulation.scale_channels(x, styles.float())
+        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
+                                            flip_weight=flip_weight)
+        if demodulate and noise is not None:
+            return fma.fma(x, dcoefs.to(x.dtype).reshape(n, -1, 1, 1), noise.to(x.dtype))
+        if demodulate:
+            return modulation.scale_channels(x, dcoefs)
+        if noise is not None:
+            return x.add_(noise.to(x.dtype))
+        return x
+
+    # Grouped-convolution formulation: per-sample weights [N*O, I, kh, kw], batch folded into channels.
+    w = weight.unsqueeze(0) * styles.reshape(n, 1, ic, 1, 1)
+    if demodulate:
+        w = w * dcoefs.reshape(n, oc, 1, 1, 1)
+    x = x.reshape(1, n * ic, *x.shape[2:])
+    x = conv2d_resample.conv2d_resample(x=x, w=w.reshape(n * oc, ic, kh, kw).to(x.dtype), f=resample_filter, up=up, down=down,
+                                        padding=padding, groups=n, flip_weight=flip_weight)
+    x = x.reshape(n, oc, *x.shape[2:])
+    if noise is not None:
+        x = x.add_(noise)
+    return x
+
+
+class SynthesisLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, resolution, kernel_size=3, up=1, activation='lrelu',
+                 resample_filter=(1, 3, 3, 1), conv_clamp=None, channels_last=False, cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.resolution, self.up, self.activation, self.conv_clamp = resolution, up, activation, conv_clamp
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(list(resample_filter)))
+        self.padding = kernel_size // 2
+        self.act_gain = bias_act.activation_funcs[activation].def_gain
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        if cfg.use_noise:
+            self.register_buffer('noise_const', torch.randn([resolution, resolution]))
+            self.noise_strength = torch.nn.Parameter(torch.zeros([]))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+        assert noise_mode in ('random', 'const', 'none')
+        misc.assert_shape(x, [None, self.weight.shape[1], self.resolution // self.up, self.resolution // self.up])
+        styles = self.affine(w)
+        noise = None
+        if self.cfg.use_noise and noise_mode == 'random':
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
+        if self.cfg.use_noise and noise_mode == 'const':
+            noise = self.noise_const * self.noise_strength
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
+                             resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+
+
+class ToRGBLayer(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, kernel_size=1, conv_clamp=None, channels_last=False):
+        super().__init__()
+        self.conv_clamp = conv_clamp
+        self.affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)
+        fmt = torch.channels_last if channels_last else torch.contiguous_format
+        self.weight = torch.nn.Parameter(torch.randn([out_channels, in_channels, kernel_size, kernel_size]).to(memory_format=fmt))
+        self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
+        self.weight_gain = 1 / math.sqrt(in_channels * kernel_size ** 2)
+
+    def forward(self, x, w, fused_modconv=True):
+        styles = self.affine(w) * self.weight_gain
+        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
+
+
+class SynthesisBlock(torch.nn.Module):
+    def __init__(self, in_channels, out_channels, w_dim, motion_v_dim, resolution, img_channels, is_last, architecture='skip',
+                 resample_filter=(1, 3, 3, 1), conv_clamp=None, use_fp16=False, fp16_channels_last=False, lowp_dtype=torch.float16,
+                 cfg=None, **layer_kwargs):
+        assert architecture in ('orig', 'skip', 'resnet')
+        super().__init__()
+        self.cfg = cfg
+        self.in_channels, self.w_dim, self.resolution, self.img_channels = in_channels, w_dim, resolution, img_channels
+        self.is_last, self.architecture, self.use_fp16, self.lowp_dtype = is_last, architecture, use_fp16, lowp_dtype
+        self.channels_last = use_fp16 and fp16_channels_last
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(list(resample_filter)))
+        self.num_conv = self.num_torgb = 0
+        common = dict(w_dim=w_dim, resolution=resolution, conv_clamp=conv_clamp, channels_last=self.channels_last, kernel_size=3, cfg=cfg)
+        if in_channels == 0:
+            self.input = GenInput(cfg, out_channels, motion_v_dim=motion_v_dim)
+            conv1_in = self.input.total_dim
+        else:
+            self.conv0 = SynthesisLayer(in_channels, out_channels, up=2, resample_filter=resample_filter, **common, **layer_kwargs)
+            self.num_conv += 1
+            conv1_in = out_channels
+        self.conv1 = SynthesisLayer(conv1_in, out_channels, **common, **layer_kwargs)
+        self.num_conv += 1
+        if is_last or architecture == 'skip':
+            self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp, channels_last=self.channels_last)
+            self.num_torgb += 1
+        if in_channels != 0 and architecture == 'resnet':
+            self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2, resample_filter=resample_filter,
+                                    channels_last=self.channels_last)
+
+    def forward(self, x, img, ws, motion_v=None, force_fp32=False, fused_modconv=None, **layer_kwargs):
+        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+        w_iter = iter(ws.unbind(dim=1))
+        dtype = self.lowp_dtype if self.use_fp16 and not force_fp32 else torch.float32
+        fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if fused_modconv is None:  # reference policy (networks.py:230-232)
+            fused_modconv = (not self.training) and (dtype == torch.float32 or (isinstance(x, torch.Tensor) and int(x.shape[0]) == 1))
+
+        if self.in_channels == 0:
+            x = self.input(ws.shape[0], motion_v=motion_v, dtype=dtype, memory_format=fmt)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+        else:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
+            x = x.to(dtype=dtype, memory_format=fmt)
+            if self.architecture == 'resnet':
+                y = self.skip(x, gain=math.sqrt(0.5))
+                x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+                x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=math.sqrt(0.5), **layer_kwargs)
+                x = y.add_(x)
+            else:
+                x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+                x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+
+        if img is not None:
+            misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
+            img = upfirdn2d.upsample2d(img, self.resample_filter)
+        if self.is_last or self.architecture == 'skip':
+            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            img = img.add_(y) if img is not None else y
+        assert x.dtype == dtype
+        assert img is None or img.dtype == torch.float32
+        return x, img
+
+
+class SynthesisNetwork(torch.nn.Module):
+    def __init__(self, w_dim, img_resolution, img_channels, channel_base=32768, channel_max=512, num_fp16_res=0, cfg=None, **block_kwargs):
+        assert img_resolution >= 4 and img_resolution & (img_resolution - 1) == 0
+        super().__init__()
+        self.w_dim, self.cfg, self.img_resolution, self.img_channels = w_dim, cfg, img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(2, self.img_resolution_log2 + 1)]
+        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+
+        if cfg.motion.v_dim > 0:
+            self.motion_encoder = MotionMappingNetwork(cfg)
+            self.motion_v_dim = self.motion_encoder.get_dim()
+        else:
+            self.motion_encoder, self.motion_v_dim = None, 0
+
+        self.num_ws = 0
+        for res in self.block_resolutions:
+            block = SynthesisBlock(channels[res // 2] if res > 4 else 0, channels[res],
+                                   w_dim=w_dim + (self.motion_v_dim if cfg.time_enc.cond_type == 'concat_w' else 0),
+                                   motion_v_dim=self.motion_v_dim, resolution=res, img_channels=img_channels,
+                                   is_last=(res == img_resolution), use_fp16=(res >= fp16_resolution), cfg=cfg, **block_kwargs)
+            self.num_ws += block.num_conv + (block.num_torgb if res == img_resolution else 0)
+            setattr(self, f'b{res}', block)
+
+    def forward(self, ws, t=None, c=None, motion_z=None, motion_v=None, **block_kwargs):
+        assert len(ws) == len(c) == len(t), f'Wrong shape: {ws.shape}, {c.shape}, {t.shape}'
+        assert t.ndim == 2, f'Wrong shape: {t.shape}'
+        misc.assert_shape(ws, [None, self.num_ws, self.w_dim])
+        frames = t.shape[1]
+        cond = self.cfg.time_enc.cond_type
+        if self.motion_encoder is None:
+            motion_v = None
+        elif motion_v is None:
+            motion_v = self.motion_encoder(c, t, motion_z=motion_z)['motion_v']  # [B*F, motion_v_dim]
+        ws = ws.repeat_interleave(frames, dim=0)  # every frame of a video shares its w: [B*F, num_ws, w_dim]
+        if motion_v is not None and cond == 'concat_w':
+            ws = torch.cat([ws, motion_v.unsqueeze(1).expand(-1, self.num_ws, -1)], dim=2)
+        elif motion_v is not None and cond == 'sum_w':
+            ws = ws + motion_v.unsqueeze(1)
+        ws = ws.to(torch.float32)
+
+        x = img = None
+        w_idx = 0
+        for res in self.block_resolutions:
+            block = getattr(self, f'b{res}')
+            # each ToRGB shares its w with the next block's conv0: advance by num_conv only (networks.py:354-357)
+            cur_ws = ws.narrow(1, w_idx, block.num_conv + block.num_torgb)
+            w_idx += block.num_conv
+            x, img = block(x, img, cur_ws, motion_v=motion_v if cond == 'concat_const' else None, **block_kwargs)
+        return img
+
+
+class Generator(torch.nn.Module):
+    def __init__(self, c_dim, w_dim, img_resolution, img_channels, mapping_kwargs=None, synthesis_kwargs=None, cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.sampling_dict = dict(cfg.sampling)
+        self.z_dim, self.c_dim, self.w_dim = cfg.z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        self.synthesis = SynthesisNetwork(w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels, cfg=cfg, **(synthesis_kwargs or {}))
+        self.num_ws = self.synthesis.num_ws
+        self.mapping = MappingNetwork(z_dim=self.z_dim, c_dim=c_dim, w_dim=w_dim, num_ws=self.num_ws, **(mapping_kwargs or {}))
+
+    def forward(self, z, c, t, truncation_psi=1, truncation_cutoff=None, **synthesis_kwargs):
+        assert len(z) == len(c) == len(t), f'Wrong shape: {z.shape}, {c.shape}, {t.shape}'
+        assert t.ndim == 2, f'Wrong shape: {t.shape}'
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff)
+        return self.synthesis(ws, t=t, c=c, **synthesis_kwargs)  # [B*F, C, H, W]
+
+
+# ------------------------------------------------------------------------------------------------
+
+
+class DiscriminatorBlock(torch.nn.Module):
+    def __init__(self, in_channels, tmp_channels, out_channels, resolution, img_channels, first_layer_idx, architecture='resnet',
+                 activation='lrelu', resample_filter=(1, 3, 3, 1), conv_clamp=None, use_fp16=False, fp16_channels_last=False,
+                 freeze_layers=0, lowp_dtype=torch.float16, cfg=None):
+        assert architecture in ('orig', 'skip', 'resnet')
+        super().__init__()
+        self.cfg = cfg
+        self.in_channels, self.resolution, self.img_channels = in_channels, resolution, img_channels
+        self.first_layer_idx, self.architecture, self.use_fp16, self.lowp_dtype = first_layer_idx, architecture, use_fp16, lowp_dtype
+        self.channels_last = use_fp16 and fp16_channels_last
+        self.register_buffer('resample_filter', upfirdn2d.setup_filter(list(resample_filter)))
+        self.num_layers = 0
+
+        def next_trainable():  # Freeze-D bookkeeping: layers below `freeze_layers` become buffers
+            trainable = (self.first_layer_idx + self.num_layers) >= freeze_layers
+            self.num_layers += 1
+            return trainable
+
+        conv0_in = in_channels if in_channels > 0 else tmp_channels
+        common = dict(conv_clamp=conv_clamp, channels_last=self.channels_last)
+        if in_channels == 0 or architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, tmp_channels, kernel_size=1, activation=activation, trainable=next_trainable(), **common)
+        self.conv0 = Conv2dLayer(conv0_in, tmp_channels, kernel_size=3, activation=activation, trainable=next_trainable(), **common)
+        self.conv1 = Conv2dLayer(tmp_channels, out_channels, kernel_size=3, activation=activation, down=2, trainable=next_trainable(),
+                                 resample_filter=resample_filter, **common)
+        if architecture == 'resnet':
+            self.skip = Conv2dLayer(conv0_in, out_channels, kernel_size=1, bias=False, down=2, trainable=next_trainable(),
+                                    resample_filter=resample_filter, channels_last=self.channels_last)
+
+    def forward(self, x, img, force_fp32=False):
+        dtype = self.lowp_dtype if self.use_fp16 and not force_fp32 else torch.float32
+        fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
+        if x is not None:
+            misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+            x = x.to(dtype=dtype, memory_format=fmt)
+        if self.in_channels == 0 or self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            img = img.to(dtype=dtype, memory_format=fmt)
+            y = self.fromrgb(img)
+            x = x + y if x is not None else y
+            img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
+        if self.architecture == 'resnet':
+            y = self.skip(x, gain=math.sqrt(0.5))
+            x = self.conv1(self.conv0(x), gain=math.sqrt(0.5))
+            x = y.add_(x)
+        else:
+            x = self.conv1(self.conv0(x))
+        assert x.dtype == dtype
+        return x, img
+
+
+class MinibatchStdLayer(torch.nn.Module):
+    """Appends, per group of `group_size` samples, the channel/pixel-averaged std over the group as extra feature map(s)."""
+
+    def __init__(self, group_size, num_channels=1):
+        super().__init__()
+        self.group_size, self.num_channels = group_size, num_channels
+
+    def forward(self, x):
+        n, c, h, w = x.shape
+        g = min(self.group_size, n) if self.group_size is not None else n
+        f = self.num_channels
+        y = x.reshape(g, -1, f, c // f, h, w)          # [G, n/G, F, c, H, W]
+        y = y - y.mean(dim=0)
+        y = (y.square().mean(dim=0) + 1e-8).sqrt()     # std over the group
+        y = y.mean(dim=[2, 3, 4]).reshape(-1, f, 1, 1)  # [n/G, F, 1, 1]
+        return torch.cat([x, y.repeat(g, 1, h, w)], dim=1)
+
+
+class DiscriminatorEpilogue(torch.nn.Module):
+    def __init__(self, in_channels, cmap_dim, resolution, img_channels, architecture='resnet', mbstd_group_size=4, mbstd_num_channels=1,
+                 activation='lrelu', conv_clamp=None, cfg=None):
+        assert architecture in ('orig', 'skip', 'resnet')
+        super().__init__()
+        self.cfg = cfg
+        self.in_channels, self.cmap_dim, self.resolution, self.img_channels, self.architecture = in_channels, cmap_dim, resolution, img_channels, architecture
+        if architecture == 'skip':
+            self.fromrgb = Conv2dLayer(img_channels, in_channels, kernel_size=1, activation=activation)
+        self.mbstd = MinibatchStdLayer(group_size=mbstd_group_size, num_channels=mbstd_num_channels) if mbstd_num_channels > 0 else None
+        self.conv = Conv2dLayer(in_channels + mbstd_num_channels, in_channels, kernel_size=3, activation=activation, conv_clamp=conv_clamp)
+        self.fc = FullyConnectedLayer(in_channels * resolution ** 2, in_channels, activation=activation)
+        self.out = FullyConnectedLayer(in_channels, 1 if cmap_dim == 0 else cmap_dim)
+
+    def forward(self, x, img, cmap, force_fp32=False):
+        misc.assert_shape(x, [None, self.in_channels, self.resolution, self.resolution])
+        x = x.to(dtype=torch.float32, memory_format=torch.contiguous_format)
+        if self.architecture == 'skip':
+            misc.assert_shape(img, [None, self.img_channels, self.resolution, self.resolution])
+            x = x + self.fromrgb(img.to(dtype=torch.float32, memory_format=torch.contiguous_format))
+        if self.mbstd is not None:
+            x = self.mbstd(x)
+        x = self.out(self.fc(self.conv(x).flatten(1)))
+        if self.cmap_dim > 0:  # projection discriminator on the conditioning embedding
+            misc.assert_shape(cmap, [None, self.cmap_dim])
+            x = (x * cmap).sum(dim=1, keepdim=True) * (1 / math.sqrt(self.cmap_dim))
+        return x
+
+
+class Discriminator(torch.nn.Module):
+    def __init__(self, c_dim, img_resolution, img_channels, architecture='resnet', channel_base=32768, channel_max=512, num_fp16_res=0,
+                 conv_clamp=None, cmap_dim=None, block_kwargs=None, mapping_kwargs=None, epilogue_kwargs=None, cfg=None):
+        super().__init__()
+        self.cfg = cfg
+        self.c_dim, self.img_resolution, self.img_channels = c_dim, img_resolution, img_channels
+        self.img_resolution_log2 = int(np.log2(img_resolution))
+        self.block_resolutions = [2 ** i for i in range(self.img_resolution_log2, 2, -1)]
+        channels = {res: min(channel_base // res, channel_max) for res in self.block_resolutions + [4]}
+        fp16_resolution = max(2 ** (self.img_resolution_log2 + 1 - num_fp16_res), 8)
+        frames = cfg.sampling.num_frames_per_video
+        if cmap_dim is None:
+            cmap_dim = channels[4]
+        self.time_encoder = TemporalDifferenceEncoder(cfg) if frames > 1 else None
+        if self.time_encoder is not None:
+            assert self.time_encoder.get_dim() > 0
+        if c_dim == 0 and self.time_encoder is None:
+            cmap_dim = 0
+        total_c_dim = c_dim + (0 if self.time_encoder is None else self.time_encoder.get_dim())
+        common = dict(img_channels=img_channels, architecture=architecture, conv_clamp=conv_clamp)
+        layer_idx = 0
+        for res in self.block_resolutions:
+            in_ch = channels[res] if res < img_resolution else 0
+            out_ch = channels[res // 2]
+            # frames are concatenated along channels at `concat_res`: halve the producer's width, widen the consumer
+            if res // 2 == cfg.concat_res:
+                out_ch //= cfg.num_frames_div_factor
+            if res == cfg.concat_res:
+                in_ch = (in_ch // cfg.num_frames_div_factor) * frames
+            block = DiscriminatorBlock(in_ch, channels[res], out_ch, resolution=res, first_layer_idx=layer_idx, use_fp16=(res >= fp16_resolution),
+                                       cfg=cfg, **(block_kwargs or {}), **common)
+            setattr(self, f'b{res}', block)
+            layer_idx += block.num_layers
+        if c_dim > 0 or self.time_encoder is not None:
+            self.mapping = MappingNetwork(z_dim=0, c_dim=total_c_dim, w_dim=cmap_dim, num_ws=None, w_avg_beta=None, **(mapping_kwargs or {}))
+        self.b4 = DiscriminatorEpilogue(channels[4], cmap_dim=cmap_dim, resolution=4, cfg=cfg, **(epilogue_kwargs or {}), **common)
+
+    def forward(self, img, c, t, **block_kwargs):
+        frames = self.cfg.sampling.num_frames_per_video
+        assert len(img) == t.shape[0] * t.shape[1], f'Wrong shape: {img.shape}, {t.shape}'
+        assert t.ndim == 2, f'Wrong shape: {t.shape}'
+        if self.time_encoder is not None:
+            c = torch.cat([c, self.time_encoder(t.reshape(-1, frames))], dim=1)
+            if self.cfg.dummy_c:
+                c = c * 0.0
+        x = None
+        for res in self.block_resolutions:
+            if res == self.cfg.concat_res:
+                x = x.reshape(-1, frames * x.shape[1], *x.shape[2:])  # [B*F, C, h, w] -> [B, F*C, h, w]
+            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+        cmap = self.mapping(None, c) if c.shape[1] > 0 else None
+        return {'image_logits': self.b4(x, img, cmap).squeeze(1)}

@@ -1,0 +1,156 @@
+"""One G+D training iteration of StyleGAN-V on one rank, plus the data-parallel wrapping.
+
+This is the benchmark driver's view of the reference training loop (src/training/training_loop.py):
+model construction (:163-165), DDP wrap of G.mapping / G.synthesis / D with ``broadcast_buffers=False``
+(:215-232), the lazy-regularisation phase list with rescaled Adam hyper-parameters (:238-252), and the
+per-iteration body (:330-404): fresh latents and frame times per phase, zero_grad -> accumulate_gradients
+-> nan_to_num on every gradient -> Adam step, then the G_ema update.  Dataset I/O, snapshots, metrics,
+logging and the launch machinery of the reference are out of scope; real frames are synthetic
+(uniform uint8 noise scaled to [-1, 1]) and frame times are drawn like ``layers.sample_frames``.
+
+Multi-GPU: one process per GPU; the only collective is DDP's bucketed gradient all-reduce over
+RCCL/xGMI (gloo on CPU for tests), gated per phase exactly as the reference gates it (loss.py:45-69).
+"""
+
+import copy
+import math
+
+import numpy as np
+import torch
+
+from ..torch_utils import misc
+from . import config as cfgs
+from .loss import StyleGAN2Loss
+from .networks import Discriminator, Generator
+
+
+def build_models(g_kwargs, d_kwargs, device, seed=0):
+    torch.manual_seed(seed)
+    G = Generator(**g_kwargs).train().requires_grad_(False).to(device)
+    D = Discriminator(**d_kwargs).train().requires_grad_(False).to(device)
+    G_ema = copy.deepcopy(G).eval()
+    return G, D, G_ema
+
+
+def sample_frame_times(sampling, batch, generator=None, device='cpu'):
+    """Sorted fractional frame positions [batch, F] within a clip of `max_num_frames` frames, distance between first
+    and last frame drawn from `total_dists` capped by `max_dist` (layers.random_frame_sampling with use_fractional_t)."""
+    nf, total = sampling.num_frames_per_video, sampling.max_num_frames
+    hi = min(total - 1, sampling.get('max_dist', 10 ** 9))
+    dists = [d for d in (sampling.get('total_dists') or range(nf - 1, hi)) if nf - 1 <= d <= hi] or [max(nf - 1, 1)]
+    g = generator
+    span = torch.tensor(dists, dtype=torch.float32)[torch.randint(len(dists), [batch], generator=g)]
+    offset = torch.rand([batch], generator=g) * (total - span - 1)
+    cols = [offset]
+    if nf > 1:
+        cols.append(offset + span)
+    for _ in range(nf - 2):
+        cols.append(offset + 1 + torch.rand([batch], generator=g) * (span - 1).clamp(min=0))
+    return torch.stack(cols, dim=1).sort(dim=1).values.to(device)
+
+
+class TrainStep:
+    """Holds G, D, G_ema, optimisers and the loss; ``step()`` runs one iteration of the phase schedule."""
+
+    def __init__(self, g_kwargs, d_kwargs, train_cfg, device, batch_gpu, world_size=1, rank=0, seed=0, ddp=None, bucket_cap_mb=25):
+        self.device, self.batch_gpu, self.world_size, self.rank = torch.device(device), batch_gpu, world_size, rank
+        self.train_cfg = train_cfg
+        self.G, self.D, self.G_ema = build_models(g_kwargs, d_kwargs, device, seed=seed)
+        self.sampling = g_kwargs['cfg'].sampling
+        self.frames = self.sampling.num_frames_per_video
+        self.res, self.img_channels = g_kwargs['img_resolution'], g_kwargs['img_channels']
+        self.z_dim = self.G.z_dim
+        self.gen = torch.Generator().manual_seed(seed * world_size + rank)  # rank-specific latents (training_loop.py:137-139)
+        self.batch_size = batch_gpu * world_size
+
+        # DDP wrappers only add the gradient all-reduce; parameters stay shared with the raw modules.
+        self.ddp = (world_size > 1) if ddp is None else ddp
+        modules = dict(G_mapping=self.G.mapping, G_synthesis=self.G.synthesis, D=self.D)
+        if self.ddp:
+            ids = [self.device.index] if self.device.type == 'cuda' else None
+            for name, mod in list(modules.items()):
+                mod.requires_grad_(True)
+                modules[name] = torch.nn.parallel.DistributedDataParallel(mod, device_ids=ids, broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb)
+                mod.requires_grad_(False)
+            for p in misc.params_and_buffers(self.G_ema):  # G_ema: sync initial values only
+                torch.distributed.broadcast(p, src=0)
+        self.loss = StyleGAN2Loss(cfg=g_kwargs['cfg'], device=self.device, r1_gamma=train_cfg.r1_gamma, pl_weight=train_cfg.pl_weight, **modules)
+
+        # Phase list with lazy regularisation (training_loop.py:238-252): reg every `interval` iterations with
+        # lr and betas rescaled by c = interval / (interval + 1).
+        self.phases = []
+        for name, module, interval in (('G', self.G, train_cfg.G_reg_interval), ('D', self.D, train_cfg.D_reg_interval)):
+            if interval is None:
+                opt = torch.optim.Adam(module.parameters(), lr=train_cfg.lr, betas=tuple(train_cfg.betas), eps=1e-8)
+                self.phases.append(dict(name=name + 'both', module=module, opt=opt, interval=1))
+            else:
+                ratio = interval / (interval + 1)
+                opt = torch.optim.Adam(module.parameters(), lr=train_cfg.lr * ratio, betas=tuple(b ** ratio for b in train_cfg.betas), eps=1e-8)
+                self.phases.append(dict(name=name + 'main', module=module, opt=opt, interval=1))
+                self.phases.append(dict(name=name + 'reg', module=module, opt=opt, interval=interval))
+        self.cur_nimg = 0
+        self.batch_idx = 0
+        self.last_losses = {}
+
+    # -- synthetic inputs -------------------------------------------------------------------------
+    def synthetic_real_batch(self):
+        """uint8-like noise frames scaled as training_loop.py:335: [batch_gpu, F, C, H, W] in [-1, 1]."""
+        raw = torch.randint(0, 256, [self.batch_gpu, self.frames, self.img_channels, self.res, self.res], generator=self.gen, dtype=torch.uint8)
+        return raw.to(self.device).to(torch.float32) / 127.5 - 1
+
+    def _latents(self):
+        z = torch.randn([self.batch_gpu, self.z_dim], generator=self.gen).to(self.device)
+        c = torch.zeros([self.batch_gpu, 0], device=self.device)
+        t = sample_frame_times(self.sampling, self.batch_gpu, generator=self.gen, device=self.device)
+        return z, c, t
+
+    # -- one iteration ----------------------------------------------------------------------------
+    def step(self, real_img=None, real_t=None):
+        if real_img is None:
+            real_img = self.synthetic_real_batch()
+        if real_t is None:
+            real_t = sample_frame_times(self.sampling, self.batch_gpu, generator=self.gen, device=self.device)
+        real_c = torch.zeros([self.batch_gpu, 0], device=self.device)
+        ran = []
+        for phase in self.phases:
+            if self.batch_idx % phase['interval'] != 0:
+                continue
+            gen_z, gen_c, gen_t = self._latents()
+            phase['opt'].zero_grad(set_to_none=True)
+            phase['module'].requires_grad_(True)
+            losses = self.loss.accumulate_gradients(phase=phase['name'], real_img=real_img, real_c=real_c, real_t=real_t, gen_z=gen_z,
+                                                    gen_c=gen_c, gen_t=gen_t, sync=True, gain=phase['interval'])
+            phase['module'].requires_grad_(False)
+            for p in phase['module'].parameters():
+                if p.grad is not None:
+                    misc.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
+            phase['opt'].step()
+            self.last_losses.update(losses)
+            ran.append(phase['name'])
+
+        # G_ema (training_loop.py:392-400)
+        ema_nimg = self.train_cfg.ema_kimg * 1000
+        if self.train_cfg.ema_rampup is not None:
+            ema_nimg = min(ema_nimg, self.cur_nimg * self.train_cfg.ema_rampup)
+        beta = 0.5 ** (self.batch_size / max(ema_nimg, 1e-8))
+        with torch.no_grad():
+            ema_params = list(self.G_ema.parameters())
+            torch._foreach_lerp_(ema_params, [p.detach() for p in self.G.parameters()], 1 - beta)  # p_ema.lerp(p, 1-beta) == p.lerp(p_ema, beta)
+            for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
+                b_ema.copy_(b)
+        self.cur_nimg += self.batch_size * self.frames
+        self.batch_idx += 1
+        return ran
+
+
+def smoke_step(device):
+    """Tiny G+D: one full iteration (Gmain, Greg no-op, Dmain, Dreg incl. R1 double-backward) on `device`."""
+    g_kwargs, d_kwargs = cfgs.small_test_model_kwargs(res=32)
+    train_cfg = cfgs.Config(r1_gamma=1.0, lr=0.0025, betas=(0.0, 0.99), ema_kimg=1.0, ema_rampup=0.05, G_reg_interval=4, D_reg_interval=16, pl_weight=0.0)
+    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=4, world_size=1)
+    ran = ts.step()
+    assert ran == ['Gmain', 'Greg', 'Dmain', 'Dreg'], ran
+    for name, p in list(ts.G.named_parameters()) + list(ts.D.named_parameters()):
+        assert torch.isfinite(p).all(), name
+    assert 'r1_penalty' in ts.last_losses and math.isfinite(float(ts.last_losses['r1_penalty']))
+    return ts

@@ -1,0 +1,141 @@
+"""GPU parity of the modulation, temporal-encoder and MFMA GEMM kernels (through the C ABI)."""
+import pytest
+import torch
+
+import oracle
+from stylegan_v_amd.torch_utils import custom_ops
+from stylegan_v_amd.torch_utils.ops import gemm, modulation, time_encode
+from util import Golden, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.mark.parametrize('shape', [(7, 5, 3, 3), (512, 512, 3, 3), (3, 64, 1, 1), (33, 1000, 3, 3)])
+def test_demod_coefs_vs_reference_formula(shape):
+    g = torch.Generator().manual_seed(1)
+    w = torch.randn(shape, generator=g)
+    s = torch.randn([6, shape[1]], generator=g) + 1
+    before = custom_ops.launch_count()
+    d = modulation.demod_coefs(w.to(DEV), s.to(DEV))
+    assert custom_ops.launch_count() == before + 2
+    # tolerance: fp32 accumulation over I*k*k <= 9000 terms vs the fp64 restatement of networks.py:57-61
+    assert_close(d, oracle.modulated_demod_coefs(w, s), atol=0, rtol=2e-5, what='dcoefs')
+
+
+def test_demod_coefs_gradients():
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn([6, 5, 3, 3], generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
+    s = (torch.randn([4, 5], generator=g, dtype=torch.float64) + 1).to(DEV).requires_grad_(True)
+    ww = w.unsqueeze(0) * s.reshape(4, 1, -1, 1, 1)
+    d_ref = (ww.square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    gw_ref, gs_ref = torch.autograd.grad(d_ref.square().sum(), [w, s])
+    w32, s32 = w.detach().float().requires_grad_(True), s.detach().float().requires_grad_(True)
+    d = modulation.demod_coefs(w32, s32)
+    gw, gs = torch.autograd.grad(d.square().sum(), [w32, s32])
+    assert_close(gw, gw_ref, atol=1e-5, rtol=1e-4, what='dW')
+    assert_close(gs, gs_ref, atol=1e-5, rtol=1e-4, what='ds')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(3, 5, 4, 4), (2, 7, 3, 5), (4, 64, 32, 32)])
+def test_scale_channels(dtype, shape):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(shape, generator=g).to(dtype)
+    s = torch.randn(shape[:2], generator=g)
+    y = modulation.scale_channels(x.to(DEV), s.to(DEV))
+    ref = (x.float() * s.reshape(*shape[:2], 1, 1)).to(dtype)
+    assert torch.equal(y.cpu(), ref)
+    xg = x.to(DEV).requires_grad_(True)
+    sg = s.to(DEV).requires_grad_(True)
+    dy = torch.randn(shape, generator=g).to(dtype).to(DEV)
+    dx, ds = torch.autograd.grad(modulation.scale_channels(xg, sg), [xg, sg], dy)
+    assert torch.equal(dx.cpu(), (dy.cpu().float() * s.reshape(*shape[:2], 1, 1)).to(dtype))
+    assert_close(ds, (dy.cpu().float() * x.float()).sum([2, 3]), atol=1e-3, rtol=1e-3, what='ds')
+
+
+def test_time_encode_vs_oracle_and_reference_module():
+    g = torch.Generator().manual_seed(4)
+    rows, nf = 96, 256
+    periods = torch.rand([rows, nf], generator=g) * 2
+    phases = torch.randn([rows, nf], generator=g)
+    al, ar = torch.randn([rows, 2 * nf], generator=g), torch.randn([rows, 2 * nf], generator=g)
+    freqs = (2 * 3.141592653589793 / 2 ** torch.linspace(10, 4, nf)).reshape(1, -1)  # periods 1024 .. 16 frames, as the FFS config
+    ps = torch.linspace(1, 64, nf).reshape(1, -1)
+    t = torch.rand([rows], generator=g) * 1024
+    tl = t - t % 16
+    tr = tl + 16
+    alpha = (t % 16) / 16
+    args = (periods, phases, al, ar, freqs, ps, t, tl, tr, alpha)
+    before = custom_ops.launch_count()
+    out = time_encode.time_encode(*[a.to(DEV) for a in args])
+    assert custom_ops.launch_count() == before + 1
+    ref64 = oracle.time_encode(*args)
+    # |raw| reaches ~1e3 rad: an fp32 argument carries ~6e-5 absolute error before sin/cos, four such terms per output
+    assert_close(out, ref64, atol=5e-4, rtol=0, what='vs fp64 oracle')
+    same_fp32 = time_encode.time_encode_ref(*args)
+    assert_close(out, same_fp32, atol=3e-4, rtol=0, what='vs fp32 torch expression')
+    # gradients of the fused node vs autograd through the plain expression (fp32 both)
+    pg = [a.to(DEV).requires_grad_(i < 4) for i, a in enumerate(args)]
+    pr = [a.to(DEV).requires_grad_(i < 4) for i, a in enumerate(args)]
+    w = torch.randn(out.shape, generator=g).to(DEV)
+    g1 = torch.autograd.grad((time_encode.time_encode(*pg) * w).sum(), pg[:4])
+    g2 = torch.autograd.grad((time_encode.time_encode_ref(*pr) * w).sum(), pr[:4])
+    for a, b, name in zip(g1, g2, ('periods', 'phases', 'al', 'ar')):
+        assert_close(a, b, atol=2e-2 if name == 'periods' else 1e-3, rtol=1e-3, what=name)
+
+
+@pytest.mark.parametrize('m,n,k', [(96, 512, 512), (32, 512, 512), (1, 7, 3), (130, 129, 17), (257, 64, 1000), (96, 64, 8192)])
+def test_gemm_linear_vs_fp64(m, n, k):
+    g = torch.Generator().manual_seed(m * 7 + n)
+    x, w, b = torch.randn([m, k], generator=g), torch.randn([n, k], generator=g), torch.randn([n], generator=g)
+    y = gemm.linear(x.to(DEV), w.to(DEV), b.to(DEV))
+    ref = x.double() @ w.double().t() + b.double()
+    assert_close(y, ref, atol=1e-5 * k ** 0.5 * 4, rtol=1e-5, what='linear')  # fp32 accumulation over k terms of N(0,1) products
+    # asymmetric operand check (transposition bugs): y[i,j] depends on (i,j) asymmetrically
+    xa = torch.arange(m * k, dtype=torch.float32).reshape(m, k) % 7
+    wa = (torch.arange(n * k, dtype=torch.float32).reshape(n, k) % 5) * 0.5
+    ya = gemm.linear(xa.to(DEV), wa.to(DEV))
+    assert torch.equal(ya.cpu(), xa @ wa.t()) or (ya.cpu() - xa @ wa.t()).abs().max() < 1e-3
+
+
+def test_gemm_linear_gradients():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn([37, 70], generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn([45, 70], generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn([45], generator=g).to(DEV).requires_grad_(True)
+    dy = torch.randn([37, 45], generator=g).to(DEV)
+    got = torch.autograd.grad(gemm.linear(x, w, b), [x, w, b], dy)
+    ref = torch.autograd.grad(torch.nn.functional.linear(x.double(), w.double(), b.double()), [x, w, b], dy.double())
+    for a, r, name in zip(got, ref, 'xwb'):
+        assert_close(a, r, atol=2e-4, rtol=1e-5, what='d' + name)
+
+
+@pytest.mark.parametrize('n,cin,cout,h', [(3, 64, 128, 16), (2, 256, 512, 32), (2, 3, 64, 32), (1, 130, 70, 9)])
+def test_gemm_conv1x1(n, cin, cout, h):
+    g = torch.Generator().manual_seed(n + cin)
+    x = torch.randn([n, cin, h, h], generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn([cout, cin, 1, 1], generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn([cout], generator=g).to(DEV).requires_grad_(True)
+    y = gemm.conv1x1(x, w, b)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double())
+    assert_close(y, ref, atol=2e-5 * cin ** 0.5, rtol=2e-6, what='conv1x1')
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    got = torch.autograd.grad(y, [x, w, b], dy)
+    want = torch.autograd.grad(ref, [x, w, b], dy.double())
+    for a, r, name in zip(got, want, 'xwb'):
+        assert_close(a, r, atol=1e-3, rtol=1e-4, what='d' + name)
+
+
+def test_reference_time_encoder_golden_on_gpu():
+    """The whole motion encoder (conv1d trajectory -> gather -> fused tail) against the reference module's fp64 output."""
+    from stylegan_v_amd.training.motion import MotionMappingNetwork
+    from stylegan_v_amd.training.config import small_test_configs
+    G = Golden('time_encoder')
+    gcfg, _ = small_test_configs()
+    enc = MotionMappingNetwork(gcfg)
+    enc.load_state_dict({k[len('enc.'):]: G.t(k, torch.float32) for k in G.keys('enc.')})
+    enc = enc.to(DEV)
+    t = G.t('t', torch.float32, DEV)
+    out = enc(torch.zeros([t.shape[0], 0], device=DEV), t, motion_z=G.t('motion_z', torch.float32, DEV))
+    assert_close(out['motion_v'], G.t('motion_v'), atol=1e-3, rtol=1e-3, what='motion_v')

@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmarks of the hand-written HIP kernels against the MI355X roofline.
+
+    python tools/ops_bench.py [--frames 32] [--reps 20] [--json out.json] [--only upfirdn2d]
+
+Shapes are the hot-path calls of the FFS 256^2 config (SURVEY.md 8(d) shape table); `--frames` is
+the number of frames N (32 = the 1.078 GB headline upfirdn2d call, 96 = one training minibatch).
+Achieved GB/s = ALGORITHMIC bytes / time: upfirdn2d (numel(x)+numel(y))*sizeof(T); bias_act
+all streams read + written.  Timing: HIP events on the launch stream (torch's current stream, which is
+the stream the C ABI launches on), L2/MALL flushed between repetitions by cycling through enough
+distinct buffers to exceed the 256 MiB Infinity Cache.
+"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stylegan_v_amd.torch_utils import custom_ops  # noqa: E402
+from stylegan_v_amd.torch_utils.ops import bias_act, gemm, modulation, upfirdn2d  # noqa: E402
+
+HBM_PEAK = 8.0e12      # spec
+HBM_COPY = 6.29e12     # measured float4 copy ceiling (MI355X_MICROARCH.md)
+F32_MFMA_PEAK = 157.3e12
+
+
+def time_call(fn, make_args, reps, min_bytes_cycle=600e6, bytes_per_call=1.0):
+    """Median / min ms of fn(*args) over `reps`, rotating over enough argument sets to defeat the 256 MiB L3."""
+    nsets = max(2, min(8, int(min_bytes_cycle // max(bytes_per_call, 1.0)) + 1))
+    sets = [make_args() for _ in range(nsets)]
+    for s in sets:
+        fn(*s)
+    torch.cuda.synchronize()
+    times = []
+    for r in range(reps):
+        s = sets[r % nsets]
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn(*s)
+        e1.record()
+        e1.synchronize()
+        times.append(e0.elapsed_time(e1))
+    times.sort()
+    return times[len(times) // 2], times[0]
+
+
+def bench_upfirdn2d(N, reps, dtype):
+    dev = 'cuda'
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=dev)
+    es = torch.empty([], dtype=dtype).element_size()
+    rows = []
+    calls = []
+    # (label, C, H_in, kwargs) per SURVEY.md 8(d)
+    for c, r in ((64, 256), (128, 128), (256, 64), (512, 32), (512, 16), (512, 8)):
+        calls.append((f'G conv0 FIR {r+1}->{r}', c, r + 1, dict(padding=1, gain=4)))
+        calls.append((f'D conv1 preFIR {r}->{r+1}', c, r, dict(padding=2)))
+        calls.append((f'D skip down2 {r}->{r//2}', c, r, dict(down=2, padding=1)))
+        calls.append((f'bwd(D skip) up2 {r//2}->{r}', c, r // 2, dict(up=2, padding=[2, 1, 2, 1], flip_filter=True)))
+    calls.append(('G RGB up2 128->256', 3, 128, dict(up=2, padding=[2, 1, 2, 1], gain=4)))
+    for label, c, h, kw in calls:
+        shape = [N, c, h, h]
+        x0 = torch.empty(shape, dtype=dtype, device=dev)
+        y0 = upfirdn2d.upfirdn2d(x0, f, **kw)
+        nbytes = (x0.numel() + y0.numel()) * es
+        del x0, y0
+        med, best = time_call(lambda x: upfirdn2d.upfirdn2d(x, f, **kw), lambda: (torch.randn(shape, device=dev).to(dtype),), reps, bytes_per_call=nbytes)
+        rows.append(dict(kernel='upfirdn2d', call=label, shape=shape, dtype=str(dtype).split('.')[-1], bytes=nbytes, ms=med, ms_min=best,
+                         GBps=nbytes / med / 1e6, frac_of_8TBps=nbytes / (med * 1e-3) / HBM_PEAK, frac_of_copy=nbytes / (med * 1e-3) / HBM_COPY))
+    return rows
+
+
+def bench_bias_act(N, reps, dtype):
+    dev = 'cuda'
+    es = torch.empty([], dtype=dtype).element_size()
+    rows = []
+    for c, r in ((64, 256), (128, 128), (256, 64), (512, 32), (512, 8)):
+        shape = [N, c, r, r]
+        b = torch.randn([c], device=dev).to(dtype)
+        n = N * c * r * r
+        med, best = time_call(lambda x: bias_act.bias_act(x, b, act='lrelu', clamp=256), lambda: (torch.randn(shape, device=dev).to(dtype),), reps, bytes_per_call=2 * n * es)
+        rows.append(dict(kernel='bias_act', call=f'fwd lrelu+clamp C{c} {r}x{r}', shape=shape, dtype=str(dtype).split('.')[-1], bytes=2 * n * es, ms=med, ms_min=best,
+                         GBps=2 * n * es / med / 1e6, frac_of_8TBps=2 * n * es / (med * 1e-3) / HBM_PEAK, frac_of_copy=2 * n * es / (med * 1e-3) / HBM_COPY))
+        # grad=1 form: dy + yref -> dx (3 streams)
+        lib = custom_ops.get_native()
+        from stylegan_v_amd.torch_utils.ops.bias_act import _native_call
+        med, best = time_call(lambda dy, y: _native_call(dy, b, None, y, None, 1, 1, 3, 0.2, 2 ** 0.5, 256.0),
+                              lambda: (torch.randn(shape, device=dev).to(dtype), torch.randn(shape, device=dev).to(dtype)), reps, bytes_per_call=3 * n * es)
+        rows.append(dict(kernel='bias_act', call=f'grad1 lrelu C{c} {r}x{r}', shape=shape, dtype=str(dtype).split('.')[-1], bytes=3 * n * es, ms=med, ms_min=best,
+                         GBps=3 * n * es / med / 1e6, frac_of_8TBps=3 * n * es / (med * 1e-3) / HBM_PEAK, frac_of_copy=3 * n * es / (med * 1e-3) / HBM_COPY))
+        del lib
+    return rows
+
+
+def bench_copy(N, reps):
+    """torch's own device-to-device copy of the headline tensor, as the achievable-bandwidth yardstick."""
+    shape = [N, 64, 256, 256]
+    n = N * 64 * 256 * 256
+    med, best = time_call(lambda x, y: y.copy_(x), lambda: (torch.randn(shape, device='cuda'), torch.empty(shape, device='cuda')), reps, bytes_per_call=8 * n)
+    return [dict(kernel='torch.copy_', call='d2d copy', shape=shape, dtype='float32', bytes=8 * n, ms=med, ms_min=best, GBps=8 * n / med / 1e6,
+                 frac_of_8TBps=8 * n / (med * 1e-3) / HBM_PEAK, frac_of_copy=8 * n / (med * 1e-3) / HBM_COPY)]
+
+
+def bench_modulation(N, reps):
+    dev = 'cuda'
+    rows = []
+    for o, i, k in ((512, 512, 3), (512, 1024, 3), (256, 512, 3), (64, 128, 3), (3, 64, 1)):
+        w = torch.randn([o, i, k, k], device=dev)
+        s = torch.randn([N, i], device=dev)
+        med, best = time_call(lambda: modulation.demod_coefs(w, s), lambda: (), reps)
+        ref_ms, _ = time_call(lambda: ((w.unsqueeze(0) * s.reshape(N, 1, -1, 1, 1)).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt(), lambda: (), max(3, reps // 4))
+        nbytes = (o * i * k * k + o * i * 2 + N * i + N * o) * 4
+        rows.append(dict(kernel='demod_coefs', call=f'O{o} I{i} k{k} N{N}', bytes=nbytes, ms=med, ms_min=best, GBps=nbytes / med / 1e6,
+                         reference_formulation_ms=ref_ms, speedup_vs_reference_formulation=ref_ms / med))
+    for c, r in ((64, 256), (128, 128), (512, 32)):
+        shape = [N, c, r, r]
+        s = torch.randn([N, c], device=dev)
+        n = N * c * r * r
+        med, best = time_call(lambda x: modulation.scale_channels(x, s), lambda: (torch.randn(shape, device=dev),), reps, bytes_per_call=8 * n)
+        rows.append(dict(kernel='scale_channels', call=f'C{c} {r}x{r}', shape=shape, bytes=8 * n, ms=med, ms_min=best, GBps=8 * n / med / 1e6,
+                         frac_of_8TBps=8 * n / (med * 1e-3) / HBM_PEAK, frac_of_copy=8 * n / (med * 1e-3) / HBM_COPY))
+    return rows
+
+
+def bench_gemm(N, reps):
+    dev = 'cuda'
+    rows = []
+    for label, fn, mk, flops in (
+        ('D b64 skip 1x1 [N,256,32,32]x[512,256]', lambda x, w: gemm.conv1x1(x, w), lambda: (torch.randn([N, 256, 32, 32], device=dev), torch.randn([512, 256, 1, 1], device=dev)), 2.0 * N * 32 * 32 * 256 * 512),
+        ('D b128 skip 1x1 [N,128,64,64]x[256,128]', lambda x, w: gemm.conv1x1(x, w), lambda: (torch.randn([N, 128, 64, 64], device=dev), torch.randn([256, 128, 1, 1], device=dev)), 2.0 * N * 64 * 64 * 128 * 256),
+        ('FC affine [N,512]x[512,512]', lambda x, w: gemm.linear(x, w), lambda: (torch.randn([N, 512], device=dev), torch.randn([512, 512], device=dev)), 2.0 * N * 512 * 512),
+        ('FC epilogue [N,8192]x[512,8192]', lambda x, w: gemm.linear(x, w), lambda: (torch.randn([N, 8192], device=dev), torch.randn([512, 8192], device=dev)), 2.0 * N * 8192 * 512),
+        ('square 4096^3', lambda x, w: gemm.linear(x, w), lambda: (torch.randn([4096, 4096], device=dev), torch.randn([4096, 4096], device=dev)), 2.0 * 4096 ** 3),
+    ):
+        med, best = time_call(fn, mk, reps)
+        args = mk()
+        if args[1].ndim == 4:
+            tfn = lambda x, w: torch.nn.functional.conv2d(x, w)  # noqa: E731
+        else:
+            tfn = lambda x, w: x @ w.t()  # noqa: E731
+        tmed, _ = time_call(tfn, mk, reps)
+        rows.append(dict(kernel='gemm_f32_mfma', call=label, flops=flops, ms=med, ms_min=best, TFLOPs=flops / med / 1e9, frac_of_f32_mfma_peak=flops / (med * 1e-3) / F32_MFMA_PEAK,
+                         torch_ms=tmed, torch_TFLOPs=flops / tmed / 1e9))
+    return rows
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--frames', type=int, default=32)
+    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--json', type=str, default=None)
+    ap.add_argument('--only', type=str, default=None)
+    ap.add_argument('--dtypes', type=str, default='float32')
+    args = ap.parse_args()
+    assert torch.cuda.is_available()
+    custom_ops.get_native()
+    rows = []
+    dts = [getattr(torch, d) for d in args.dtypes.split(',')]
+    if args.only in (None, 'copy'):
+        rows += bench_copy(args.frames, args.reps)
+    for dt in dts:
+        if args.only in (None, 'upfirdn2d'):
+            rows += bench_upfirdn2d(args.frames, args.reps, dt)
+        if args.only in (None, 'bias_act'):
+            rows += bench_bias_act(args.frames, args.reps, dt)
+    if args.only in (None, 'modulation'):
+        rows += bench_modulation(args.frames, args.reps)
+    if args.only in (None, 'gemm'):
+        rows += bench_gemm(args.frames, args.reps)
+    for r in rows:
+        extra = f"{r['GBps']:9.1f} GB/s  {100*r.get('frac_of_8TBps', 0):5.1f}% of 8TB/s  {100*r.get('frac_of_copy', 0):5.1f}% of 6.29" if 'GBps' in r else \
+                f"{r['TFLOPs']:7.1f} TF ({100*r['frac_of_f32_mfma_peak']:4.1f}% of 157.3)  torch {r['torch_TFLOPs']:7.1f} TF"
+        if 'speedup_vs_reference_formulation' in r:
+            extra += f"  x{r['speedup_vs_reference_formulation']:.1f} vs w[N,O,I,k,k]"
+        print(f"{r['kernel']:16s} {r['call']:44s} {r['ms']:9.4f} ms  {extra}")
+    if args.json:
+        os.makedirs(os.path.dirname(os.path.abspath(args.json)), exist_ok=True)
+        with open(args.json, 'w') as fh:
+            json.dump(dict(device=torch.cuda.get_device_name(0), frames=args.frames, rows=rows), fh, indent=1)
+
+
+if __name__ == '__main__':
+    main()
