@@ -1,19 +1,29 @@
-"""conv2d / conv_transpose2d entry points of the op layer.
+"""conv2d / conv_transpose2d with well-behaved higher-order gradients on ROCm.
 
 Boundary names of the reference's ``src/torch_utils/ops/conv2d_gradfix.py`` (``conv2d`` :35,
 ``conv_transpose2d`` :40, ``no_weight_gradients`` :26, module globals ``enabled`` :22 and
-``weight_gradients_disabled`` :23), which ``loss.py``, ``training_loop.py`` and ``augment.py`` import
-by name.  The reference's custom autograd path only ever activates on torch 1.7-1.10
-(conv2d_gradfix.py:53) and calls cuDNN-only ATen ops; on current PyTorch the stock convolutions
-already support arbitrary-order gradients, so both functions forward to ``torch.nn.functional``
-(MIOpen on ROCm).  ``no_weight_gradients()`` keeps its flag semantics so callers can still query it.
+``weight_gradients_disabled`` :23), imported by name from ``loss.py``, ``training_loop.py`` and
+``augment.py``.
+
+Why it exists here: stock autograd differentiates a convolution's backward pass
+(``_convolution_double_backward``) by re-expressing the weight-gradient as a convolution whose *kernel*
+is the full-size output gradient (dilation = stride, batch folded into channels).  MIOpen has no fast
+solver for a 256x256 "kernel" and falls back to im2col + one GEMM per sample: measured on MI355X, the
+R1 phase (double backward through D, every 16th iteration) took ~10 s per iteration that way -- half of
+the whole training time.  The reference solved the same problem on cuDNN with a custom op that is disabled
+on torch >= 1.11 (conv2d_gradfix.py:53) and calls cuDNN-only ATen entry points (:143).  This version keeps
+the idea and uses backend-neutral ATen ops: every derivative of a convolution is computed with ordinary
+forward / backward-data / backward-weight convolutions of the ORIGINAL geometry
+(``aten.convolution`` and ``aten.convolution_backward`` with an output mask), nested autograd Functions
+make any order available, and ``no_weight_gradients()`` really skips the weight-gradient convolution
+(used by the R1 / path-length passes, loss.py:111,162).  The convolutions themselves stay on MIOpen.
 """
 
 import contextlib
 
 import torch
 
-enabled = False                    # kept for API compatibility; has no effect
+enabled = True                     # False -> plain torch.nn.functional calls
 weight_gradients_disabled = False  # set inside no_weight_gradients()
 
 
@@ -28,11 +38,95 @@ def no_weight_gradients():
         weight_gradients_disabled = previous
 
 
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else tuple(int(i) for i in v)
+
+
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
-                                      dilation=dilation, groups=groups)
+    if _use_custom(input):
+        cfg = (False, _pair(stride), _pair(padding), (0, 0), _pair(dilation), int(groups))
+        return _Conv.apply(input, weight, bias, cfg)
+    return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    if _use_custom(input):
+        cfg = (True, _pair(stride), _pair(padding), _pair(output_padding), _pair(dilation), int(groups))
+        return _Conv.apply(input, weight, bias, cfg)
     return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
+
+
+def _use_custom(input):
+    assert isinstance(input, torch.Tensor)
+    return enabled and input.ndim == 4 and torch.is_grad_enabled()
+
+
+def _aten_conv(x, w, b, cfg):
+    transposed, stride, padding, output_padding, dilation, groups = cfg
+    return torch.ops.aten.convolution(x, w, b, stride, padding, dilation, transposed, output_padding, groups)
+
+
+def _data_grad_cfg(cfg, input_hw, output_hw, kernel_hw):
+    """Geometry of the convolution that maps d(output) back to d(input): the opposite kind (conv <-> transposed
+    conv) with the same stride/padding/dilation; a forward conv needs the output_padding that restores the
+    exact input size."""
+    transposed, stride, padding, _, dilation, groups = cfg
+    if transposed:
+        return (False, stride, padding, (0, 0), dilation, groups)
+    out_pad = tuple(input_hw[i] - ((output_hw[i] - 1) * stride[i] - 2 * padding[i] + dilation[i] * (kernel_hw[i] - 1) + 1) for i in range(2))
+    assert all(0 <= out_pad[i] < max(stride[i], dilation[i]) for i in range(2)), 'inconsistent convolution geometry'
+    return (True, stride, padding, out_pad, dilation, groups)
+
+
+class _Conv(torch.autograd.Function):
+    """y = conv(x, w) (+ b) of either kind; cfg = (transposed, stride, padding, output_padding, dilation, groups)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cfg):
+        ctx.cfg = cfg
+        ctx.has_bias = b is not None
+        ctx.save_for_backward(x, w)
+        return _aten_conv(x, w, b, cfg)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            bcfg = _data_grad_cfg(ctx.cfg, x.shape[2:], dy.shape[2:], w.shape[2:])
+            dx = _Conv.apply(dy, w, None, bcfg)
+            assert dx.shape == x.shape
+        if ctx.needs_input_grad[1] and not weight_gradients_disabled:
+            dw = _ConvGradWeight.apply(dy, x, ctx.cfg, tuple(w.shape))
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum([0, 2, 3])
+        return dx, dw, db, None
+
+
+class _ConvGradWeight(torch.autograd.Function):
+    """dw = d<dy, conv(x, w)>/dw, as one backward-weight convolution; bilinear in (dy, x), so its own
+    derivatives are again plain convolutions."""
+
+    @staticmethod
+    def forward(ctx, dy, x, cfg, w_shape):
+        transposed, stride, padding, output_padding, dilation, groups = cfg
+        ctx.cfg = cfg
+        ctx.save_for_backward(dy, x)
+        w_like = x.new_empty(w_shape)  # only its shape/dtype are read when output_mask selects the weight gradient
+        _, dw, _ = torch.ops.aten.convolution_backward(dy, x, w_like, None, stride, padding, dilation, transposed, output_padding, groups,
+                                                       [False, True, False])
+        return dw
+
+    @staticmethod
+    def backward(ctx, d_dw):
+        dy, x = ctx.saved_tensors
+        g_dy = g_x = None
+        if ctx.needs_input_grad[0]:   # dw is linear in dy: the forward convolution of x with the incoming gradient as weight
+            g_dy = _Conv.apply(x, d_dw, None, ctx.cfg)
+            assert g_dy.shape == dy.shape
+        if ctx.needs_input_grad[1]:   # and linear in x: the data-gradient convolution of dy with that weight
+            bcfg = _data_grad_cfg(ctx.cfg, x.shape[2:], dy.shape[2:], d_dw.shape[2:])
+            g_x = _Conv.apply(dy, d_dw, None, bcfg)
+            assert g_x.shape == x.shape
+        return g_dy, g_x, None, None

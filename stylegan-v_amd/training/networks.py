@@ -49,7 +49,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
     dcoefs = modulation.demod_coefs(weight, styles) if demodulate else None  # [N, O], fp32
 
     if not fused_modconv:
-        x = modulation.scale_channels(x, styles.float())
+        x = modulation.scale_channels(x, styles)
         x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
                                             flip_weight=flip_weight)
         if demodulate and noise is not None:

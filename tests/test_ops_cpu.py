@@ -1,0 +1,193 @@
+"""Host logic of the op layer on CPU: argument handling, padding arithmetic, the plain-PyTorch path
+(`impl='ref'` / CPU tensors) against the reference's golden outputs, conv2d_resample / modulated_conv2d /
+fma decompositions, grid_sample second-order gradients, dispatch rules."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from stylegan_v_amd.torch_utils.ops import bias_act as ba
+from stylegan_v_amd.torch_utils.ops import conv2d_gradfix, conv2d_resample, fma, grid_sample_gradfix, modulation, time_encode
+from stylegan_v_amd.torch_utils.ops import upfirdn2d as ufd
+from stylegan_v_amd.training.networks import modulated_conv2d
+from util import Golden, assert_close
+
+UFD = Golden('upfirdn2d')
+BA = Golden('bias_act')
+CONV = Golden('conv_ops')
+
+
+def test_setup_filter_contract():
+    f = ufd.setup_filter([1, 3, 3, 1])
+    assert f.shape == (4, 4) and f.dtype == torch.float32
+    assert_close(f, torch.outer(torch.tensor([1., 3, 3, 1]), torch.tensor([1., 3, 3, 1])) / 64, atol=1e-7)
+    assert ufd.setup_filter(None).tolist() == [[1.0]]
+    f12 = ufd.setup_filter(list(range(1, 13)))
+    assert f12.ndim == 1 and abs(f12.sum().item() - 1) < 1e-6          # >= 8 taps stay separable
+    assert ufd.setup_filter([1, 2, 1], separable=True).ndim == 1
+    g = ufd.setup_filter([1, 2], gain=4, flip_filter=True, normalize=False)
+    assert torch.equal(g, torch.tensor([[4., 2.], [2., 1.]]) * 4)          # gain^(ndim/2), flipped on both axes
+    assert ufd._parse_padding(3) == (3, 3, 3, 3) and ufd._parse_padding([1, 2]) == (1, 1, 2, 2)
+    assert ufd._get_filter_size(None) == (1, 1) and ufd._get_filter_size(torch.zeros(5, 3)) == (3, 5)
+    with pytest.raises(AssertionError):
+        ufd.upfirdn2d(torch.zeros(1, 1, 4, 4), None, impl='fast')
+
+
+@pytest.mark.parametrize('i', range(len(UFD.meta)))
+def test_upfirdn2d_torch_path_matches_reference_and_oracle(i):
+    m = UFD.meta[i]
+    kw = dict(up=m['up'], down=m['down'], padding=m['padding'], flip_filter=m['flip'], gain=m['gain'])
+    f = UFD.t(f'c{i}_f') if m['has_f'] else None
+    x = UFD.t(f'c{i}_x').requires_grad_(True)
+    y = ufd.upfirdn2d(x, f, **kw)                       # CPU tensor -> plain PyTorch path
+    assert_close(y, UFD.t(f'c{i}_y'), atol=1e-12, rtol=1e-12, what='y')
+    assert_close(y, oracle.upfirdn2d(x.detach(), f, **kw), atol=5e-6, rtol=1e-6, what='vs oracle')
+    dy = UFD.t(f'c{i}_dy')
+    (dx,) = torch.autograd.grad(y, x, dy)
+    assert_close(dx, UFD.t(f'c{i}_dx'), atol=1e-12, rtol=1e-12, what='dx')
+
+
+def test_resampling_wrappers_padding_arithmetic():
+    f = ufd.setup_filter([1, 3, 3, 1])
+    x = torch.randn(2, 3, 8, 8)
+    assert ufd.upsample2d(x, f).shape == (2, 3, 16, 16)
+    assert ufd.downsample2d(x, f).shape == (2, 3, 4, 4)
+    assert ufd.filter2d(x, f).shape == (2, 3, 8, 8)
+    assert torch.equal(ufd.upsample2d(x, f), ufd.upfirdn2d(x, f, up=2, padding=[2, 1, 2, 1], gain=4))
+    assert torch.equal(ufd.downsample2d(x, f), ufd.upfirdn2d(x, f, down=2, padding=[1, 1, 1, 1]))
+    assert torch.equal(ufd.filter2d(x, f), ufd.upfirdn2d(x, f, padding=[2, 1, 2, 1]))
+    # constant images keep their level (DC gain 1) away from the zero-padded border
+    ones = torch.ones(1, 1, 16, 16)
+    assert_close(ufd.upsample2d(ones, f)[:, :, 4:-4, 4:-4], torch.ones(1, 1, 24, 24), atol=1e-6)
+    assert_close(ufd.downsample2d(ones, f)[:, :, 2:-2, 2:-2], torch.ones(1, 1, 4, 4), atol=1e-6)
+
+
+@pytest.mark.parametrize('i', range(len(BA.meta)))
+def test_bias_act_torch_path_matches_reference(i):
+    m = BA.meta[i]
+    kw = dict(dim=m['dim'], act=m['act'], alpha=m['alpha'], gain=m['gain'], clamp=m['clamp'])
+    x = BA.t(f'c{i}_x').requires_grad_(True)
+    b = BA.t(f'c{i}_b').requires_grad_(True) if m['has_b'] else None
+    y = ba.bias_act(x, b, **kw)
+    assert_close(y, BA.t(f'c{i}_y'), atol=1e-12, rtol=1e-12, what='y')
+    grads = torch.autograd.grad(y, [x] + ([b] if b is not None else []), BA.t(f'c{i}_dy'))
+    assert_close(grads[0], BA.t(f'c{i}_dx'), atol=1e-12, rtol=1e-12, what='dx')
+    if b is not None:
+        assert_close(grads[1], BA.t(f'c{i}_db'), atol=1e-11, rtol=1e-11, what='db')
+
+
+def test_activation_table_contract():
+    assert list(ba.activation_funcs) == ['linear', 'relu', 'lrelu', 'tanh', 'sigmoid', 'elu', 'selu', 'softplus', 'swish']
+    assert [s.cuda_idx for s in ba.activation_funcs.values()] == list(range(1, 10))
+    assert ba.activation_funcs['lrelu'].def_alpha == 0.2 and abs(ba.activation_funcs['lrelu'].def_gain - np.sqrt(2)) < 1e-12
+    assert ba.activation_funcs['swish'].ref == 'x' and ba.activation_funcs['linear'].ref == ''
+    assert not ba.activation_funcs['relu'].has_2nd_grad and ba.activation_funcs['tanh'].has_2nd_grad
+
+
+@pytest.mark.parametrize('i', [k for k, m in enumerate(CONV.meta) if m['kind'] == 'conv2d_resample'])
+def test_conv2d_resample_matches_reference(i):
+    m = CONV.meta[i]
+    x, w = CONV.t(f'cr{i}_x').requires_grad_(True), CONV.t(f'cr{i}_w').requires_grad_(True)
+    y = conv2d_resample.conv2d_resample(x=x, w=w, f=CONV.t('f'), up=m['up'], down=m['down'], padding=m['padding'], flip_weight=m['flip_weight'])
+    assert_close(y, CONV.t(f'cr{i}_y'), atol=1e-10, rtol=1e-10, what='y')
+    dx, dw = torch.autograd.grad(y, [x, w], CONV.t(f'cr{i}_dy'))
+    assert_close(dx, CONV.t(f'cr{i}_dx'), atol=1e-10, rtol=1e-10, what='dx')
+    assert_close(dw, CONV.t(f'cr{i}_dw'), atol=1e-10, rtol=1e-10, what='dw')
+
+
+def test_modulated_conv2d_matches_reference():
+    base = sum(1 for m in CONV.meta if m['kind'] == 'conv2d_resample')
+    f = CONV.t('f')
+    for j, m in enumerate(CONV.meta[base:]):
+        x, w, s = (CONV.t(f'mc{j}_{k}').requires_grad_(True) for k in 'xws')
+        noise = CONV.t(f'mc{j}_noise') if m['noise'] else None
+        y = modulated_conv2d(x=x, weight=w, styles=s, noise=noise, up=m['up'], padding=m['k'] // 2, resample_filter=f, demodulate=m['demodulate'],
+                             flip_weight=(m['up'] == 1), fused_modconv=m['fused'])
+        assert_close(y, CONV.t(f'mc{j}_y'), atol=1e-9, rtol=1e-9, what=f'y {m}')
+        dx, dw, ds = torch.autograd.grad(y, [x, w, s], CONV.t(f'mc{j}_dy'))
+        assert_close(dx, CONV.t(f'mc{j}_dx'), atol=1e-9, rtol=1e-9, what=f'dx {m}')
+        assert_close(dw, CONV.t(f'mc{j}_dw'), atol=1e-8, rtol=1e-9, what=f'dw {m}')
+        assert_close(ds, CONV.t(f'mc{j}_ds'), atol=1e-8, rtol=1e-9, what=f'ds {m}')
+
+
+def test_demod_coefs_algebra_equals_reference_formulation():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn([9, 6, 3, 3], generator=g, dtype=torch.float64)
+    s = torch.randn([4, 6], generator=g, dtype=torch.float64)
+    assert_close(modulation.demod_coefs(w, s), oracle.modulated_demod_coefs(w, s), atol=1e-13, rtol=1e-13)
+
+
+def test_fma_matches_reference_and_unbroadcasts():
+    a, b, c = (CONV.t('fma_' + k).requires_grad_(True) for k in 'abc')
+    y = fma.fma(a, b, c)
+    assert_close(y, CONV.t('fma_y'), atol=1e-14)
+    da, db, dc = torch.autograd.grad(y, [a, b, c], CONV.t('fma_dy'))
+    for got, key in ((da, 'fma_da'), (db, 'fma_db'), (dc, 'fma_dc')):
+        assert_close(got, CONV.t(key), atol=1e-13)
+    assert torch.autograd.gradgradcheck(fma.fma, (a, b, c))
+
+
+def test_time_encode_expression_gradients():
+    g = torch.Generator().manual_seed(1)
+    rows, nf = 5, 4
+    p = [torch.randn([rows, nf], generator=g, dtype=torch.float64).requires_grad_(True) for _ in range(2)]
+    al, ar = (torch.randn([rows, 2 * nf], generator=g, dtype=torch.float64).requires_grad_(True) for _ in range(2))
+    fr, ps = torch.rand([1, nf], generator=g, dtype=torch.float64), torch.rand([1, nf], generator=g, dtype=torch.float64) + 1
+    t = torch.rand([rows], generator=g, dtype=torch.float64) * 50
+    tl = t - t % 4
+    args = (p[0], p[1], al, ar, fr, ps, t, tl, tl + 4, (t % 4) / 4)
+    out = time_encode.time_encode(*args)
+    assert_close(out, oracle.time_encode(*[a.detach() for a in args]), atol=1e-12)
+    # the hand-written backward of the fused node == autograd through the expression
+    w = torch.randn(out.shape, generator=g, dtype=torch.float64)
+    ref = torch.autograd.grad((out * w).sum(), [p[0], p[1], al, ar])
+
+    class Ctx:
+        needs_input_grad = [True] * 4 + [False] * 6
+        saved_tensors = (p[0].detach(), p[1].detach(), fr, ps, t, tl, tl + 4, (t % 4) / 4)
+    got = time_encode._TimeEncodeFn.backward(Ctx, w)
+    for a, r in zip(got[:4], ref):
+        assert_close(a, r, atol=1e-11, rtol=1e-11)
+
+
+def test_grid_sample_gradfix_second_order():
+    """R1 through an augmentation resampler needs d/d(input) of grid_sample's backward."""
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn([2, 3, 6, 6], generator=g, dtype=torch.float64, requires_grad=True)
+    theta = torch.tensor([[[0.9, 0.1, 0.05], [-0.1, 1.1, 0.0]]], dtype=torch.float64).repeat(2, 1, 1)
+    grid = torch.nn.functional.affine_grid(theta, [2, 3, 6, 6], align_corners=False)
+    y = grid_sample_gradfix.grid_sample(x, grid)
+    assert_close(y, torch.nn.functional.grid_sample(x, grid, mode='bilinear', padding_mode='zeros', align_corners=False), atol=1e-14)
+    (gx,) = torch.autograd.grad(y.square().sum(), x, create_graph=True)
+    gx.square().sum().backward()          # would raise with the stock op
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+    assert torch.autograd.gradgradcheck(lambda t: grid_sample_gradfix.grid_sample(t, grid), (x,))
+
+
+def test_conv2d_gradfix_boundary_names():
+    assert conv2d_gradfix.weight_gradients_disabled is False
+    with conv2d_gradfix.no_weight_gradients():
+        assert conv2d_gradfix.weight_gradients_disabled is True
+    assert conv2d_gradfix.weight_gradients_disabled is False
+    x, w = torch.randn(1, 2, 5, 5), torch.randn(3, 2, 3, 3)
+    assert torch.equal(conv2d_gradfix.conv2d(x, w, padding=1), torch.nn.functional.conv2d(x, w, padding=1))
+    assert conv2d_gradfix.conv_transpose2d(x, w.transpose(0, 1), stride=2).shape == (1, 3, 11, 11)
+
+
+def test_gpu_dispatch_has_no_silent_fallback(monkeypatch):
+    """A GPU tensor with impl='cuda' must reach the native library; if that is unavailable the op raises."""
+    from stylegan_v_amd.torch_utils import custom_ops
+
+    class FakeCuda(torch.Tensor):
+        @property
+        def device(self):
+            return torch.device('cuda', 0)
+
+    def boom(*a, **k):
+        raise custom_ops.NativeLibraryError('libsgv_hip.so unavailable (test)')
+    monkeypatch.setattr(custom_ops, 'get_native', boom)
+    x = torch.zeros(1, 1, 4, 4).as_subclass(FakeCuda)
+    with pytest.raises((custom_ops.NativeLibraryError, RuntimeError)):
+        ufd.upfirdn2d(x, None)
+    with pytest.raises((custom_ops.NativeLibraryError, RuntimeError)):
+        ba.bias_act(x, None, act='lrelu')
