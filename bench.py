@@ -15,7 +15,7 @@ every 16th, each followed by nan_to_num + Adam, then the G_ema update.  Per-GPU 
 (weak scaling): `--batch-gpu` videos x 3 frames per rank; DDP all-reduces G/D gradients over RCCL.
 
 The single JSON line carries, besides the contract fields:
-  roofline      the hand-written upfirdn2d row-walker kernel: algorithmic bytes / HIP-event time summed over
+  roofline      the hand-written upfirdn2d lane-exchange kernel (every upfirdn2d call of the step selects it): algorithmic bytes / HIP-event time summed over
                 every launch inside the timed steps (events recorded by the C ABI on the launch stream)
   kernels       the same accounting for every native kernel family
   cpu_baseline  the same training step on the host CPU through the plain-PyTorch op path (a restatement
@@ -165,10 +165,10 @@ def main():
                 if e['flops'] > 0:
                     k['TFLOPs'] = e['flops'] / (e['ms'] * 1e-3) / 1e12
                 kernels[name] = k
-            r = prof['upfirdn2d_rows']
+            r = prof['upfirdn2d_lanes']
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-                roofline = dict(kernel='upfirdn2d_rows_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
+                roofline = dict(kernel='upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
                                 frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=None, launches=r['launches'],
                                 avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
                                 note='all launches inside the timed steps (every layer size, fwd+bwd+double-bwd), size-weighted')

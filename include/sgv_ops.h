@@ -80,8 +80,9 @@ typedef struct sgv_upfirdn2d_params {
 
 int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* stream);
 
-/* Which kernel sgv_upfirdn2d would run for p: 0 = generic gather kernel, 1 = register-window
- * row walker (the fast path for contiguous NCHW, up/down in {1,2}).  For tests/benchmarks. */
+/* Which kernel sgv_upfirdn2d would run for p: 0 = generic gather kernel, 1 = register-window row walker
+ * (contiguous NCHW, up/down in {1,2}, filter <= 4x4), 2 = lane-exchange kernel (the four hot-path geometries at
+ * >= 129 output columns).  For tests/benchmarks. */
 int sgv_upfirdn2d_kernel_kind(const sgv_upfirdn2d_params* p, int dtype);
 
 /* ---------------------------------------------------------------------------------------
@@ -187,7 +188,8 @@ enum sgv_kernel_family {
     SGV_K_MODULATE = 3,
     SGV_K_TIME_ENCODE = 4,
     SGV_K_GEMM = 5,
-    SGV_K_COUNT = 6
+    SGV_K_UPFIRDN2D_LANES = 6,
+    SGV_K_COUNT = 7
 };
 typedef struct sgv_prof_entry {
     int64_t launches;

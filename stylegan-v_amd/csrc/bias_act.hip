@@ -4,9 +4,8 @@
 // operation -- same order of bias add, activation, `y *= gain * dy`, clamp -- so linear / relu /
 // lrelu (only exactly-rounded add/mul/select) are bit-identical to the scalar oracle.
 //
-// Design: pure HBM stream (AI ~0.4 flop/B).  One lane moves 16 B per stream per iteration
-// (dwordx4 for fp32, 8 x 16-bit for fp16/bf16, 2 x fp64), grid capped at 256 CUs x 8 blocks with a
-// grid-stride loop.  The bias index (xi / step_b) % size_b (bias_act.cu:44) is evaluated once per
+// Design: pure HBM stream (AI ~0.4 flop/B).  One lane moves one 16-B vector per stream
+// (dwordx4 for fp32, 8 x 16-bit for fp16/bf16, 2 x fp64); the grid covers the whole tensor.  The bias index (xi / step_b) % size_b (bias_act.cu:44) is evaluated once per
 // 16-B vector when step_b is a multiple of the vector length (NCHW feature maps: step_b = H*W),
 // as a vector load when step_b == 1 (fully-connected: bias runs along the fastest axis), and per
 // element otherwise.  Activation and grad order are template parameters; the presence of each
@@ -105,7 +104,7 @@ template <typename T> struct vec16 {
 // size_b % N == 0), 3 per element.  bmode and the presence of xref/yref/dy are wave-uniform runtime
 // values (scalar branches); activation and grad order are template parameters.
 template <typename T, int A, int G>
-__global__ __launch_bounds__(256) void bias_act_kernel(ba_params p, int bmode) {
+__global__ __launch_bounds__(256) void bias_act_kernel(ba_params p, int bmode, int nt_store) {
     typedef typename sgv_traits<T>::acc_t S;
     constexpr int N = vec16<T>::N;
     const S alpha = (S)p.alpha, gain = (S)p.gain, clamp = (S)p.clamp;
@@ -120,6 +119,9 @@ __global__ __launch_bounds__(256) void bias_act_kernel(ba_params p, int bmode) {
     const bool has_yref = (G > 0) && yrv != nullptr;
     const bool has_dy = dyv != nullptr;  // the reference multiplies by dy at every grad order (bias_act.cu:133)
 
+    // One 16-B vector per lane and a grid that covers the tensor: on MI355X many short-lived workgroups sweeping a
+    // compact window of memory stream HBM ~25 % faster than 2048 persistent grid-stride blocks (6.1 vs 4.9 TB/s on a
+    // float4 copy of 1 GB).  The loop only runs more than once for tensors beyond 2^31 / 16 vectors per grid limit.
     for (int vi = blockIdx.x * blockDim.x + threadIdx.x; vi < nvec; vi += gridDim.x * blockDim.x) {
         vec16<T> vx = xv[vi], vxr = vx, vyr = vx, vdy = vx, vo;
         if (has_xref) vxr = xrv[vi];
@@ -149,7 +151,12 @@ __global__ __launch_bounds__(256) void bias_act_kernel(ba_params p, int bmode) {
             S dy = has_dy ? sgv_traits<T>::load(&vdy.e[k]) : (S)1;
             sgv_traits<T>::store(&vo.e[k], ba_eval<S, A, G>(x, bias[k], xr, yr, dy, alpha, gain, clamp));
         }
-        yv[vi] = vo;
+        if (nt_store) {
+            typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(__builtin_bit_cast(u4, vo), (u4*)&yv[vi]);
+        } else {
+            yv[vi] = vo;
+        }
     }
 
     // Tail (size_x not a multiple of the vector length): handled by the first lanes of block 0.
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(256) void bias_act_kernel(ba_params p, int bmode) {
     }
 }
 
-typedef void (*ba_fn)(ba_params, int);
+typedef void (*ba_fn)(ba_params, int, int);
 
 template <typename T, int A>
 ba_fn pick_grad(int grad) {
@@ -234,11 +241,12 @@ extern "C" int sgv_bias_act(const sgv_bias_act_params* p, int dtype, void* strea
 
     const int nvec = p->size_x / nvecel;
     int blocks = (nvec + 255) / 256;
-    if (blocks > 2048) blocks = 2048;  // 256 CUs x 8 blocks, grid-stride beyond
     if (blocks < 1) blocks = 1;
+    // outputs larger than the 256 MiB Infinity Cache cannot be re-read from cache by the next op: stream them past it
+    const int nt_store = ((double)p->size_x * es > 300e6) ? 1 : 0;
     const int streams = 2 + (xr ? 1 : 0) + (yr ? 1 : 0) + (dy ? 1 : 0);
     const double bytes = (double)p->size_x * es * streams + (p->b ? (double)p->size_b * es : 0.0);
     sgv_launch_scope scope(SGV_K_BIAS_ACT, stream, bytes);
-    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, stream, kp, bmode);
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, stream, kp, bmode, nt_store);
     return sgv_check_launch("bias_act_kernel");
 }

@@ -84,8 +84,7 @@ void launch_scale(const void* x, const float* s, void* y, int total, int hw, hip
     constexpr int N = vec16<T>::N;
     const bool vec_ok = (hw % N == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
     int work = vec_ok ? total / N : total;
-    int blocks = (work + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    int blocks = (work + 255) / 256;  // one vector per lane, grid covers the tensor (see bias_act.hip)
     if (blocks < 1) blocks = 1;
     if (vec_ok)
         hipLaunchKernelGGL(scale_channels_vec_kernel<T>, dim3(blocks), dim3(256), 0, stream, (const T*)x, s, (T*)y, work, hw);

@@ -1,0 +1,373 @@
+// Kernel laboratory for the upfirdn2d FIR hot call ([N,64,257,257] -> [N,64,256,256], fp32, 4x4 taps, pad 1).
+// Standalone (no torch): hipcc --offload-arch=gfx950 -O3 tools/ufd_lab.hip -o ufd_lab && ./ufd_lab [N]
+// Times design variants with HIP events and checks each against a naive per-output kernel.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include <string>
+#include <dlfcn.h>
+#include "../include/sgv_ops.h"
+#pragma clang fp contract(off)
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+struct P { const float* x; const float* f; float* y; int in_w, in_h, out_w, out_h, planes, pad; float gain; int strip_h; };
+
+// ---------------- reference: one lane per output ----------------
+__global__ void k_naive(P p) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)p.planes * p.out_h * p.out_w;
+    if (idx >= total) return;
+    int ox = idx % p.out_w; long r = idx / p.out_w; int oy = r % p.out_h; int pl = r / p.out_h;
+    const float* xp = p.x + (size_t)pl * p.in_h * p.in_w;
+    float v = 0.f;
+    for (int j = 0; j < 4; j++) for (int i = 0; i < 4; i++) {
+        int iy = oy - p.pad + j, ix = ox - p.pad + i;
+        float xv = (iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) ? xp[(size_t)iy * p.in_w + ix] : 0.f;
+        v = __builtin_fmaf(xv, p.f[(3 - j) * 4 + (3 - i)], v);
+    }
+    p.y[idx] = v * p.gain;
+}
+
+// ---------------- copy ceiling: float4 in -> float4 out, same bytes ----------------
+__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ a, float4* __restrict__ b, long n4) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) b[i] = a[i];
+}
+
+typedef float fv4 __attribute__((ext_vector_type(4)));
+template <int NTL, int NTS, int U>
+__global__ __launch_bounds__(256) void k_copy2(const fv4* __restrict__ a, fv4* __restrict__ b, long n4) {
+    // each block handles a contiguous chunk of U*256 float4; U loads in flight per lane
+    long base = (long)blockIdx.x * (256 * U) + threadIdx.x;
+    fv4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { long i = base + u * 256; if (i < n4) v[u] = NTL ? __builtin_nontemporal_load(a + i) : a[i]; }
+#pragma unroll
+    for (int u = 0; u < U; u++) { long i = base + u * 256; if (i < n4) { if (NTS) __builtin_nontemporal_store(v[u], b + i); else b[i] = v[u]; } }
+}
+
+// ---------------- V1: lane-per-column walker, DPP neighbour exchange ----------------
+// A wave owns 64 consecutive output columns of a strip of rows of one plane.  Per input row each lane loads ONE
+// float (its tap-0 column) -- 256 B contiguous per wave, any alignment -- plus lanes 0..2 load the 3 halo columns to
+// the right; taps 1..3 come from the neighbour lanes through wave_shl:1 DPP moves.  4-row sliding window in VGPRs.
+__device__ __forceinline__ float wave_shl1(float v, float fill63) {
+    // lane i <- lane i+1 ; lane 63 <- fill63
+    int r = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, fill63), __builtin_bit_cast(int, v), 0x130 /*wave_shl:1*/, 0xf, 0xf, false);
+    return __builtin_bit_cast(float, r);
+}
+
+template <int PF>
+__global__ __launch_bounds__(256) void k_cols(P p, int colgroups, int strips) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = wave % strips;
+    const int cg = (wave / strips) % colgroups;
+    const int pl = wave / (strips * colgroups);
+    if (pl >= p.planes) return;
+    float ff[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) ff[a][b] = p.f[(3 - a) * 4 + (3 - b)];
+    const float* xp = p.x + (size_t)pl * p.in_h * p.in_w;
+    float* yp = p.y + (size_t)pl * p.out_h * p.out_w;
+    const int ox = cg * 64 + lane;
+    const int ix0 = ox - p.pad;                  // tap-0 input column of this lane
+    const int ixh = cg * 64 + 64 - p.pad + lane; // halo column (lanes 0..2)
+    const bool main_ok = ix0 >= 0 && ix0 < p.in_w;
+    const bool halo_ok = lane < 3 && ixh < p.in_w && ixh >= 0;
+    const int oy_a = strip * p.strip_h, oy_b = min(oy_a + p.strip_h, p.out_h);
+    const int iy0 = oy_a - p.pad;
+
+    float win[4][4];
+    auto load_row = [&](int iy, float* dst) {
+        float m = 0.f, h = 0.f;
+        if (iy >= 0 && iy < p.in_h) {
+            const float* row = xp + (size_t)iy * p.in_w;
+            if (main_ok) m = row[ix0];
+            if (halo_ok) h = row[ixh];
+        }
+        // taps 1..3 from the lanes to the right; lane 63 / 62 / 61 pull from the halo values held by lanes 0..2
+        float h0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), 0));
+        float h1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), 1));
+        float h2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, h), 2));
+        dst[0] = m;
+        dst[1] = wave_shl1(dst[0], h0);
+        dst[2] = wave_shl1(dst[1], h1);
+        dst[3] = wave_shl1(dst[2], h2);
+    };
+#pragma unroll
+    for (int r = 0; r < 3; r++) load_row(iy0 + r, win[1 + r]);
+    int iy = iy0 + 3;
+    const bool st_ok = ox < p.out_w;
+#pragma unroll 4
+    for (int oy = oy_a; oy < oy_b; oy++) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) win[r][i] = win[r + 1][i];
+        load_row(iy++, win[3]);
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[j][i], ff[j][i], acc);
+        if (st_ok) yp[(size_t)oy * p.out_w + ox] = acc * p.gain;
+    }
+}
+
+// ---------------- V2: lane owns 2 columns (8 B loads/stores), DPP exchange of pairs ----------------
+// Same idea at twice the bytes per memory instruction: lane loads x[c], x[c+1] (taps 0,1 of its first output) and
+// needs x[c+2..c+4]: the neighbour's pair plus the neighbour's neighbour's first element.
+__global__ __launch_bounds__(256) void k_cols2(P p, int colgroups, int strips) {
+    typedef float f2 __attribute__((ext_vector_type(2), aligned(4)));
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = wave % strips;
+    const int cg = (wave / strips) % colgroups;
+    const int pl = wave / (strips * colgroups);
+    if (pl >= p.planes) return;
+    float ff[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) ff[a][b] = p.f[(3 - a) * 4 + (3 - b)];
+    const float* xp = p.x + (size_t)pl * p.in_h * p.in_w;
+    float* yp = p.y + (size_t)pl * p.out_h * p.out_w;
+    const int ox = cg * 128 + lane * 2;
+    const int ix0 = ox - p.pad;
+    const int ixh = cg * 128 + 128 - p.pad + lane * 2;  // halo pair (lanes 0..1 -> 4 columns, 3 needed)
+    const bool main_vec = ix0 >= 0 && ix0 + 1 < p.in_w;
+    const bool halo_vec = lane < 2 && ixh >= 0 && ixh + 1 < p.in_w;
+    const int oy_a = strip * p.strip_h, oy_b = min(oy_a + p.strip_h, p.out_h);
+    const int iy0 = oy_a - p.pad;
+    float win[4][5];
+    auto load_row = [&](int iy, float* dst) {
+        float m0 = 0.f, m1 = 0.f, g0 = 0.f, g1 = 0.f;
+        if (iy >= 0 && iy < p.in_h) {
+            const float* row = xp + (size_t)iy * p.in_w;
+            if (main_vec) { f2 v = *(const f2*)(row + ix0); m0 = v[0]; m1 = v[1]; }
+            else { if (ix0 >= 0 && ix0 < p.in_w) m0 = row[ix0]; if (ix0 + 1 >= 0 && ix0 + 1 < p.in_w) m1 = row[ix0 + 1]; }
+            if (halo_vec) { f2 v = *(const f2*)(row + ixh); g0 = v[0]; g1 = v[1]; }
+            else if (lane < 2) { if (ixh >= 0 && ixh < p.in_w) g0 = row[ixh]; if (ixh + 1 >= 0 && ixh + 1 < p.in_w) g1 = row[ixh + 1]; }
+        }
+        float h0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0), 0));
+        float h1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g1), 0));
+        float h2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, g0), 1));
+        dst[0] = m0; dst[1] = m1;
+        dst[2] = wave_shl1(m0, h0);       // x[c+2] = next lane's m0
+        dst[3] = wave_shl1(m1, h1);       // x[c+3] = next lane's m1
+        dst[4] = wave_shl1(dst[2], h2);   // x[c+4] = next-next lane's m0
+    };
+#pragma unroll
+    for (int r = 0; r < 3; r++) load_row(iy0 + r, win[1 + r]);
+    int iy = iy0 + 3;
+#pragma unroll 4
+    for (int oy = oy_a; oy < oy_b; oy++) {
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int i = 0; i < 5; i++) win[r][i] = win[r + 1][i];
+        load_row(iy++, win[3]);
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int i = 0; i < 4; i++) { a0 = __builtin_fmaf(win[j][i], ff[j][i], a0); a1 = __builtin_fmaf(win[j][i + 1], ff[j][i], a1); }
+        float* yr = yp + (size_t)oy * p.out_w + ox;
+        if (ox + 1 < p.out_w) { f2 o; o[0] = a0 * p.gain; o[1] = a1 * p.gain; *(f2*)yr = o; }
+        else if (ox < p.out_w) yr[0] = a0 * p.gain;
+    }
+}
+
+
+// ---------------- V3: lane owns 4 columns (16 B unaligned loads / aligned stores), DPP halo, explicit prefetch ----------------
+// Loads are always in-bounds vector loads (base clamped into the row, edge lanes fixed up with selects: no divergent
+// slow path); the 3 halo columns of the wave come from one masked dword load by lanes 0..2; rows are software-pipelined
+// PF deep (loads of the next PF rows in flight while the current PF rows are filtered).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
+
+struct rawrow { float m[4]; float h; };
+
+template <int PF, int NT>
+__global__ __launch_bounds__(256) void k_cols4(P p, int colgroups, int strips) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = wave % strips;
+    const int cg = (wave / strips) % colgroups;
+    const int pl = wave / (strips * colgroups);
+    if (pl >= p.planes) return;
+    float ff[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) ff[a][b] = p.f[(3 - a) * 4 + (3 - b)];
+    const float* xp = p.x + (size_t)pl * p.in_h * p.in_w;
+    float* yp = p.y + (size_t)pl * p.out_h * p.out_w;
+    const int ox = cg * 256 + lane * 4;
+    const int ix0 = ox - p.pad;
+    // clamp the 4-wide load window into [0, in_w-4]; `sh` = how far it moved (positive: window moved right)
+    const int base = min(max(ix0, 0), p.in_w - 4);
+    const int sh = base - ix0;      // in [-3, 3] for edge lanes, 0 inside
+    const bool lane_dead = (ix0 >= p.in_w) || (ix0 + 3 < 0);
+    const int ixh = cg * 256 + 256 - p.pad + lane;
+    const bool halo_ok = lane < 3 && ixh >= 0 && ixh < p.in_w;
+    const int oy_a = strip * p.strip_h, oy_b = min(oy_a + p.strip_h, p.out_h);
+    const int iy0 = oy_a - p.pad;
+
+    auto issue = [&](int iy, rawrow& r) {
+        r.m[0] = r.m[1] = r.m[2] = r.m[3] = 0.f; r.h = 0.f;
+        if (iy >= 0 && iy < p.in_h) {   // wave-uniform
+            const float* row = xp + (size_t)iy * p.in_w;
+            if (!lane_dead) { f4u v = (NT == 2) ? __builtin_nontemporal_load((const f4u*)(row + base)) : *(const f4u*)(row + base); r.m[0] = v[0]; r.m[1] = v[1]; r.m[2] = v[2]; r.m[3] = v[3]; }
+            if (halo_ok) r.h = row[ixh];
+        }
+    };
+    auto expand = [&](const rawrow& r, float* dst) {
+        float m[4];
+        // undo the clamp: m[i] = column ix0+i = loaded[(i - sh)] if 0 <= i - sh < 4 else 0
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float v = r.m[i];
+#pragma unroll
+            for (int d = 1; d <= 3; d++) {
+                if (i - d >= 0) v = (sh == d) ? r.m[i - d] : v;
+                else v = (sh == d) ? 0.f : v;
+                if (i + d < 4) v = (sh == -d) ? r.m[i + d] : v;
+                else v = (sh == -d) ? 0.f : v;
+            }
+            m[i] = v;
+        }
+        float h0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.h), 0));
+        float h1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.h), 1));
+        float h2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, r.h), 2));
+        dst[0] = m[0]; dst[1] = m[1]; dst[2] = m[2]; dst[3] = m[3];
+        dst[4] = wave_shl1(m[0], h0);
+        dst[5] = wave_shl1(m[1], h1);
+        dst[6] = wave_shl1(m[2], h2);
+    };
+
+    float win[4][7];
+    rawrow cur[PF], nxt[PF];
+    {   // prologue: 3 window rows, then the first PF raw rows
+        rawrow t;
+#pragma unroll
+        for (int r = 0; r < 3; r++) { issue(iy0 + r, t); expand(t, win[1 + r]); }
+    }
+    int iy = iy0 + 3;
+#pragma unroll
+    for (int k = 0; k < PF; k++) issue(iy + k, cur[k]);
+    iy += PF;
+    const bool st_vec = ox + 3 < p.out_w;
+    for (int oy = oy_a; oy < oy_b; oy += PF) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) issue(iy + k, nxt[k]);   // next group's loads go out before this group's math
+        iy += PF;
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+            if (oy + k >= oy_b) break;
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int i = 0; i < 7; i++) win[r][i] = win[r + 1][i];
+            expand(cur[k], win[3]);
+            float o[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[j][v + i], ff[j][i], acc);
+                o[v] = acc * p.gain;
+            }
+            float* yr = yp + (size_t)(oy + k) * p.out_w + ox;
+            if (st_vec) {
+                f4u sv; sv[0] = o[0]; sv[1] = o[1]; sv[2] = o[2]; sv[3] = o[3];
+                if (NT) __builtin_nontemporal_store(sv, (f4u*)yr); else *(f4u*)yr = sv;
+            } else {
+#pragma unroll
+                for (int v = 0; v < 4; v++) if (ox + v < p.out_w) yr[v] = o[v];
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PF; k++) cur[k] = nxt[k];
+    }
+}
+
+int main(int argc, char** argv) {
+    int N = argc > 1 ? atoi(argv[1]) : 32;
+    int C = 64, IH = argc > 2 ? atoi(argv[2]) : 257, IW = IH, pad = argc > 3 ? atoi(argv[3]) : 1;
+    int OW = IW + 2 * pad - 3, OH = IH + 2 * pad - 3;
+    int planes = N * C;
+    size_t nx = (size_t)planes * IH * IW, ny = (size_t)planes * OH * OW;
+    printf("FIR %dx%d -> %dx%d, planes %d, pad %d, bytes %.3f GB\n", IH, IW, OH, OW, planes, pad, (nx + ny) * 4 / 1e9);
+    const int NBUF = 3;
+    float *x[NBUF], *y, *yref, *f;
+    for (int i = 0; i < NBUF; i++) CK(hipMalloc(&x[i], nx * 4 + 64));
+    CK(hipMalloc(&y, ny * 4 + 64)); CK(hipMalloc(&yref, ny * 4 + 64)); CK(hipMalloc(&f, 64));
+    std::vector<float> hx(nx), hf(16);
+    unsigned s = 12345;
+    for (size_t i = 0; i < nx; i++) { s = s * 1664525u + 1013904223u; hx[i] = ((s >> 8) & 0xffff) / 65536.f - 0.5f; }
+    float t1[4] = {1, 3, 3, 1};
+    for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) hf[a * 4 + b] = t1[a] * t1[b] / 64.f;
+    for (int i = 0; i < NBUF; i++) CK(hipMemcpy(x[i], hx.data(), nx * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(f, hf.data(), 64, hipMemcpyHostToDevice));
+    P p{x[0], f, yref, IW, IH, OW, OH, planes, pad, 4.0f, 32};
+    hipLaunchKernelGGL(k_naive, dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, 0, p);
+    CK(hipDeviceSynchronize());
+    std::vector<float> href(ny), hy(ny);
+    CK(hipMemcpy(href.data(), yref, ny * 4, hipMemcpyDeviceToHost));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto bench = [&](const char* name, auto launch, bool check) {
+        CK(hipMemset(y, 0xff, ny * 4));
+        for (int w = 0; w < 2; w++) launch(x[w % NBUF], y);
+        CK(hipDeviceSynchronize());
+        if (check) {
+            CK(hipMemcpy(hy.data(), y, ny * 4, hipMemcpyDeviceToHost));
+            size_t bad = 0; for (size_t i = 0; i < ny; i++) if (!(hy[i] == href[i])) bad++;
+            if (bad) printf("  !! %s: %zu mismatches\n", name, bad);
+        }
+        float best = 1e9, tot = 0; int reps = 12;
+        for (int r = 0; r < reps; r++) {
+            CK(hipEventRecord(e0)); launch(x[r % NBUF], y); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best; tot += ms;
+        }
+        double gb = (nx + ny) * 4 / 1e9;
+        printf("%-34s avg %8.4f ms  min %8.4f ms   %7.1f GB/s (min %7.1f)  %5.1f%% of 8 TB/s\n", name, tot / reps, best, gb / (tot / reps) * 1e3, gb / best * 1e3, gb / (tot / reps) * 1e3 / 80.0);
+    };
+    bench("copy float4 (same bytes)", [&](const float* xi, float* yo) {
+        long n4 = (long)(ny / 4); hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const float4*)xi, (float4*)yo, n4); }, false);
+    // the production library through its C ABI, same harness
+    void* so = dlopen("stylegan-v_amd/csrc/libsgv_hip.so", RTLD_NOW);
+    typedef int (*ufd_fn)(const sgv_upfirdn2d_params*, int, void*);
+    ufd_fn sgv = so ? (ufd_fn)dlsym(so, "sgv_upfirdn2d") : nullptr;
+    if (sgv) {
+        sgv_upfirdn2d_params q{};
+        q.f = f; q.up_x = q.up_y = q.down_x = q.down_y = 1; q.pad_x0 = q.pad_x1 = q.pad_y0 = q.pad_y1 = pad; q.flip = 0; q.gain = 4.0f;
+        q.in_w = IW; q.in_h = IH; q.in_c = C; q.in_n = N; q.in_sw = 1; q.in_sh = IW; q.in_sc = (int64_t)IW * IH; q.in_sn = (int64_t)IW * IH * C;
+        q.f_w = q.f_h = 4; q.f_sw = 1; q.f_sh = 4; q.out_w = OW; q.out_h = OH; q.out_sw = 1; q.out_sh = OW; q.out_sc = (int64_t)OW * OH; q.out_sn = (int64_t)OW * OH * C;
+        bench("libsgv_hip sgv_upfirdn2d (C ABI)", [&](const float* xi, float* yo) { sgv_upfirdn2d_params r = q; r.x = xi; r.y = yo; if (sgv(&r, 0, nullptr)) printf("sgv error\n"); }, true);
+    } else printf("libsgv_hip.so not found: %s\n", dlerror());
+#define RUNC(NTL, NTS, U) { std::string nm = std::string("copy2 ntl") + #NTL + " nts" + #NTS + " U" + #U; \
+      bench(nm.c_str(), [&](const float* xi, float* yo) { long n4 = (long)(ny / 4); hipLaunchKernelGGL((k_copy2<NTL, NTS, U>), dim3((unsigned)((n4 + 256 * U - 1) / (256 * U))), dim3(256), 0, 0, (const fv4*)xi, (fv4*)yo, n4); }, false); }
+    RUNC(0, 0, 1) RUNC(1, 1, 4)
+    for (int sh : {8, 16}) {
+        int strips4 = (OH + sh - 1) / sh; int cgs4 = (OW + 255) / 256; long waves4 = (long)planes * cgs4 * strips4; P q4 = p; q4.strip_h = sh;
+#define RUN4(PFV, NTV) { std::string nm = std::string("V3 cols dwordx4 PF") + #PFV + " NT" + #NTV + " strip " + std::to_string(sh); \
+          bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q4; r.x = xi; r.y = yo; hipLaunchKernelGGL((k_cols4<PFV, NTV>), dim3((unsigned)((waves4 + 3) / 4)), dim3(256), 0, 0, r, cgs4, strips4); }, true); }
+        RUN4(1, 1) RUN4(2, 1) RUN4(4, 1)
+    }
+    for (int sh : std::vector<int>{}) {
+        int strips = (OH + sh - 1) / sh;
+        { int cgs = (OW + 63) / 64; long waves = (long)planes * cgs * strips; P q = p; q.strip_h = sh; q.y = y;
+          std::string nm = "V1 cols dword strip " + std::to_string(sh);
+          bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q; r.x = xi; r.y = yo; hipLaunchKernelGGL(k_cols<0>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, r, cgs, strips); }, true); }
+        { int cgs = (OW + 127) / 128; long waves = (long)planes * cgs * strips; P q = p; q.strip_h = sh; q.y = y;
+          std::string nm = "V2 cols dwordx2 strip " + std::to_string(sh);
+          bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q; r.x = xi; r.y = yo; hipLaunchKernelGGL(k_cols2, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, 0, r, cgs, strips); }, true); }
+    }
+    return 0;
+}
