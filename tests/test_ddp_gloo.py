@@ -1,0 +1,133 @@
+"""Data-parallel path on CPU: two processes (gloo) each run the training step's phases on half of a batch; the
+all-reduced gradients must equal the single-process gradients of the whole batch, gradient synchronisation must be
+gated per phase like the reference gates it (misc.ddp_sync / loss.py:45-69), and ranks must stay consistent."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _make(world, rank, batch_gpu, ddp):
+    from stylegan_v_amd.training import config as cfgs
+    from stylegan_v_amd.training.train_step import TrainStep
+    g_kwargs, d_kwargs = cfgs.small_test_model_kwargs(res=32)
+    # D's minibatch-std groups must not straddle ranks for the equivalence: group size 2 with 2 videos per rank
+    train_cfg = cfgs.Config(r1_gamma=1.0, lr=0.0025, betas=(0.0, 0.99), ema_kimg=1.0, ema_rampup=0.05, G_reg_interval=4, D_reg_interval=16,
+                            pl_weight=0.0)
+    return TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=batch_gpu, world_size=world, rank=rank, seed=0, ddp=ddp)
+
+
+def _phase_grads(ts, phase, real_img, real_t, z, t):
+    c = torch.zeros([z.shape[0], 0])
+    mod = ts.G if phase.startswith('G') else ts.D
+    for p in list(ts.G.parameters()) + list(ts.D.parameters()):
+        p.grad = None
+    mod.requires_grad_(True)
+    ts.loss.accumulate_gradients(phase=phase, real_img=real_img, real_c=c, real_t=real_t, gen_z=z, gen_c=c, gen_t=t, sync=True, gain=1)
+    mod.requires_grad_(False)
+    return {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+
+
+def _inputs():
+    g = torch.Generator().manual_seed(123)
+    B, F = 4, 3
+    real = torch.rand([B, F, 3, 32, 32], generator=g) * 2 - 1
+    real_t = torch.sort(torch.rand([B, F], generator=g) * 30, dim=1).values
+    z = torch.randn([B, 32], generator=g)
+    t = torch.sort(torch.rand([B, F], generator=g) * 30, dim=1).values
+    return real, real_t, z, t
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        ts = _make(world, rank, batch_gpu=2, ddp=True)
+        real, real_t, z, t = _inputs()
+        sl = slice(rank * 2, rank * 2 + 2)
+        # motion noise is drawn inside G: fix it per video so both runs see the same trajectories
+        torch.manual_seed(1000)
+        res = {}
+        for phase in ('Gmain', 'Dmain', 'Dreg'):
+            torch.manual_seed(77 + rank)  # rank-local RNG stream for the in-forward randn
+            res[phase] = _phase_grads(ts, phase, real[sl], real_t[sl], z[sl], t[sl])
+        # gating: a D-only phase must leave G's DDP wrappers un-synchronised and vice versa (no hang == correct gating)
+        ran = ts.step()
+        assert ran == ['Gmain', 'Greg', 'Dmain', 'Dreg']
+        from stylegan_v_amd.torch_utils import misc
+        misc.check_ddp_consistency(ts.G, ignore_regex=r'.*\.w_avg')
+        misc.check_ddp_consistency(ts.D)
+        torch.save(res, os.path.join(out_dir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_two_ranks_match_single_process(tmp_path, monkeypatch):
+    # Reference semantics to make the comparison exact: the generator draws motion noise with torch.randn inside
+    # forward; patch it to a deterministic function of the video's latent so single- and multi-process runs agree.
+    import stylegan_v_amd.training.motion as motion
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_worker_entry, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=540)
+        assert p.exitcode == 0, f'rank process failed with exit code {p.exitcode}'
+    r0 = torch.load(tmp_path / 'rank0.pt')
+    r1 = torch.load(tmp_path / 'rank1.pt')
+
+    _patch_motion_noise(motion)
+    ts = _make(1, 0, batch_gpu=4, ddp=False)
+    real, real_t, z, t = _inputs()
+    # D's minibatch-std layer groups sample k with sample k + N/G (networks.py:506): order the single-process batch so
+    # that its groups are exactly the per-rank groups {0,1} and {2,3}.
+    perm = [0, 2, 1, 3]
+    real, real_t, z, t = real[perm], real_t[perm], z[perm], t[perm]
+    for phase in ('Gmain', 'Dmain', 'Dreg'):
+        single = _phase_grads(ts, phase, real, real_t, z, t)
+        assert set(single) == set(r0[phase]) == set(r1[phase])
+        for name, g in single.items():
+            assert torch.allclose(r0[phase][name], r1[phase][name], atol=0, rtol=0), f'{phase} {name}: ranks disagree after all-reduce'
+            err = (r0[phase][name] - g).abs().max().item()
+            scale = g.abs().max().item() + 1e-6
+            assert err <= 2e-4 * scale + 1e-6, f'{phase} {name}: DDP grad differs from the single-process grad by {err:.3e} (scale {scale:.3e})'
+
+
+def _patch_motion_noise(motion):
+    """Deterministic motion noise: seeded per video by the first frame time (same in every process)."""
+    orig = motion.MotionMappingNetwork.generate_motion_u_codes
+
+    def patched(self, c, t, motion_z=None):
+        if motion_z is None:
+            traj_len = self.get_max_traj_len(t) + self.num_additional_codes
+            rows = []
+            for i in range(t.shape[0]):
+                g = torch.Generator().manual_seed(int(t[i, 0].item() * 1e6) % (2 ** 31))
+                rows.append(torch.randn([64, self.cfg.motion.z_dim], generator=g))
+            motion_z = torch.stack(rows)[:, :max(traj_len, 1)]
+            assert motion_z.shape[1] >= traj_len
+        return orig(self, c, t, motion_z=motion_z)
+    motion.MotionMappingNetwork.generate_motion_u_codes = patched
+
+
+def _worker_entry(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import stylegan_v_amd.training.motion as motion
+    _patch_motion_noise(motion)
+    _worker(rank, world, port, out_dir)
