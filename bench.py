@@ -41,6 +41,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic_per_launch(prefix='upfirdn2d_lanes'):
+    """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes over this same command
+    (profiles/r01_pmc_bench_step_FETCH_WRITE.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; on gfx950 FETCH_SIZE
+    counts half of a wide coalesced read -- calibrated on a float4 copy in profiles/r01_pmc_headline_call_FETCH_WRITE.json --
+    so reads are doubled; WRITE_SIZE is exact).  bench.py cannot collect counters on itself; None if the file is absent."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_bench_step_FETCH_WRITE.json')
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        kb = n = 0.0
+        for name, e in d['FETCH_SIZE'].items():
+            if name.startswith(prefix):
+                kb += 2.0 * e['total_KB'] + d['WRITE_SIZE'][name]['total_KB']
+                n += e['launches']
+        return kb * 1024.0 / n if n else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(res, frames, seconds_cap):
     """One G+D iteration per batch of ONE video (3 frames) on the host cores, plain-PyTorch ops."""
     from stylegan_v_amd.training import config as cfgs
@@ -169,7 +188,8 @@ def main():
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
                 roofline = dict(kernel='upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
-                                frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=None, launches=r['launches'],
+                                frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch(), launches=r['launches'],
+                                traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, profiles/r01_pmc_bench_step_FETCH_WRITE.json (reads x2, gfx950 correction)',
                                 avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
                                 note='all launches inside the timed steps (every layer size, fwd+bwd+double-bwd), size-weighted')
         cpu = None

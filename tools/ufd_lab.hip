@@ -341,7 +341,8 @@ int main(int argc, char** argv) {
     bench("copy float4 (same bytes)", [&](const float* xi, float* yo) {
         long n4 = (long)(ny / 4); hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const float4*)xi, (float4*)yo, n4); }, false);
     // the production library through its C ABI, same harness
-    void* so = dlopen("stylegan-v_amd/csrc/libsgv_hip.so", RTLD_NOW);
+    const char* so_path = getenv("SGV_LIB") ? getenv("SGV_LIB") : "stylegan-v_amd/csrc/libsgv_hip.so";
+    void* so = dlopen(so_path, RTLD_NOW);
     typedef int (*ufd_fn)(const sgv_upfirdn2d_params*, int, void*);
     ufd_fn sgv = so ? (ufd_fn)dlsym(so, "sgv_upfirdn2d") : nullptr;
     if (sgv) {
