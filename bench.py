@@ -105,6 +105,8 @@ def main():
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline leg; 0 disables it')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
+    ap.add_argument('--lowp', choices=['none', 'fp16', 'bf16'], default='none',
+                    help='mixed precision in the 4 highest resolutions (reference: fp16; BASELINE config 4: bf16). Default: full fp32')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -122,15 +124,21 @@ def main():
     from stylegan_v_amd.training import config as cfgs
     from stylegan_v_amd.training.train_step import TrainStep
     custom_ops.verbosity = 'none' if rank else 'brief'
-    custom_ops.get_native()  # fail loudly here if the HIP library is missing
+    # fail loudly here if the HIP library is missing; rank 0 goes first so that a stale in-tree .so is rebuilt once
+    if rank == 0:
+        custom_ops.get_native()
+    if world > 1:
+        torch.distributed.barrier()
+    custom_ops.get_native()
 
     # The reference sets cudnn.benchmark=True (training_loop.py:140).  MIOpen in this image ships no gfx950 find-db, so
     # "find" would time every solver (incl. the naive one) on full-size tensors for many minutes: use immediate mode.
     import stylegan_v_amd
     stylegan_v_amd.configure_miopen(immediate=os.environ.get('SGV_MIOPEN_FIND', '0') != '1')
     global_batch = args.batch_gpu * world
-    g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=True,
-                                                      num_frames_per_video=args.frames)
+    lowp = {'none': None, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.lowp]
+    g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=(lowp is None),
+                                                      num_frames_per_video=args.frames, lowp_dtype=lowp)
     ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank)
 
     def barrier():
@@ -197,8 +205,9 @@ def main():
             log('[bench] timing the CPU baseline leg ...')
             cpu = cpu_baseline(args.res, args.frames, args.cpu_seconds)
         out = dict(metric='G+D train-step images/sec at 256^2', value=value, unit='img/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=f'FFS {args.res}x{args.res} full G+D train step (Gmain+Greg+Dmain+Dreg/R1), cfg=auto fmaps 0.5, fp32',
+                   ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype={'none': 'f32', 'fp16': 'f16 (blocks >= 32^2; f32 accumulate, f32 master weights)', 'bf16': 'bf16 (blocks >= 32^2; f32 accumulate, f32 master weights)'}[args.lowp], data='synthetic',
+                   config=dict(workload=f'FFS {args.res}x{args.res} full G+D train step (Gmain+Greg+Dmain+Dreg/R1), cfg=auto fmaps 0.5, ' + ('fp32' if lowp is None else args.lowp + ' mixed precision') + ', aug=noaug',
                                videos_per_gpu=args.batch_gpu, frames_per_video=args.frames, frames_per_gpu=args.batch_gpu * args.frames,
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,

@@ -7,7 +7,7 @@
 //  * upfirdn2d_generic_kernel  -- one lane per output element, any strides / factors / filter
 //    size / dtype (incl. fp64, channels_last).  The correctness backstop.
 //  * upfirdn2d_rows_kernel     -- the hot path.  Contiguous NCHW, up/down in {1,2} per axis (never
-//    both), filter <= 4x4 (2-D) .  HBM-bound streaming design with NO LDS and NO barriers:
+//    both), filter <= 4x4 (2-D) or a 1-D pass of <= 12 taps.  HBM-bound streaming design with NO LDS and NO barriers:
 //      - a wave owns a strip of output rows of one (or, for narrow images, several) planes;
 //        each lane owns VEC=4 adjacent output columns (16 B of fp32 per row -> one dwordx4 store,
 //        the wave writes 1 KiB contiguous per row);
@@ -183,9 +183,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(rows_params p) {
     // must only read lanes that executed the load.
     float ff[FHP][FWP];
     {
-        const int ta = (lane >> 2) & 3, tb = lane & 3;
+        static_assert(FHP * FWP <= 64, "one tap per lane");
+        const int ta = lane / FWP, tb = lane % FWP;
         float t = 0.f;
-        if (lane < 16 && ta < p.f_h && tb < p.f_w) {
+        if (lane < FHP * FWP && ta < p.f_h && tb < p.f_w) {
             const int fa = p.flip ? ta : p.f_h - 1 - ta;
             const int fb = p.flip ? tb : p.f_w - 1 - tb;
             t = p.f[fa * p.f_sh + fb * p.f_sw];
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_rows_kernel(rows_params p) {
 #pragma unroll
         for (int a = 0; a < FHP; a++)
 #pragma unroll
-            for (int b = 0; b < FWP; b++) ff[a][b] = lane_bcast(t, a * 4 + b);
+            for (int b = 0; b < FWP; b++) ff[a][b] = lane_bcast(t, a * FWP + b);
     }
 
     // readfirstlane: the wave index is uniform, but only provably so to the compiler this way; everything
@@ -583,10 +584,24 @@ rows_fn pick_phase(int r0x, int r0y, int xtra) {
 template <typename T>
 rows_fn pick_rows_kernel(const sgv_upfirdn2d_params* p, int r0x, int r0y, int xtra) {
     const int ux = p->up_x, uy = p->up_y, dx = p->down_x, dy = p->down_y;
-    if (p->f_w > 4 || p->f_h > 4) return nullptr;
-    if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return pick_phase<T, 1, 1, 1, 1, 4, 4>(r0x, r0y, xtra);
-    if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return pick_phase<T, 2, 2, 1, 1, 4, 4>(r0x, r0y, xtra);
-    if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return pick_phase<T, 1, 1, 2, 2, 4, 4>(r0x, r0y, xtra);
+    if (p->f_w <= 4 && p->f_h <= 4) {
+        if (ux == 1 && uy == 1 && dx == 1 && dy == 1) return pick_phase<T, 1, 1, 1, 1, 4, 4>(r0x, r0y, xtra);
+        if (ux == 2 && uy == 2 && dx == 1 && dy == 1) return pick_phase<T, 2, 2, 1, 1, 4, 4>(r0x, r0y, xtra);
+        if (ux == 1 && uy == 1 && dx == 2 && dy == 2) return pick_phase<T, 1, 1, 2, 2, 4, 4>(r0x, r0y, xtra);
+    }
+    // One-dimensional passes of separable filters up to 12 taps: the ADA augmentation pipe resamples with the 12-tap
+    // 'sym6' wavelet as a horizontal then a vertical upfirdn2d (src/training/augment.py:289,300; the reference serves
+    // them with its 1x12 / 12x1 / 1x24 tile kernels, upfirdn2d.cu:250-339).
+    if (p->f_h == 1 && p->f_w <= 12 && uy == 1 && dy == 1) {
+        if (ux == 1 && dx == 1) return pick_phase<T, 1, 1, 1, 1, 12, 1>(r0x, r0y, xtra);
+        if (ux == 2 && dx == 1) return pick_phase<T, 2, 1, 1, 1, 12, 1>(r0x, r0y, xtra);
+        if (ux == 1 && dx == 2) return pick_phase<T, 1, 1, 2, 1, 12, 1>(r0x, r0y, xtra);
+    }
+    if (p->f_w == 1 && p->f_h <= 12 && ux == 1 && dx == 1) {
+        if (uy == 1 && dy == 1) return pick_phase<T, 1, 1, 1, 1, 1, 12>(r0x, r0y, xtra);
+        if (uy == 2 && dy == 1) return pick_phase<T, 1, 2, 1, 1, 1, 12>(r0x, r0y, xtra);
+        if (uy == 1 && dy == 2) return pick_phase<T, 1, 1, 1, 2, 1, 12>(r0x, r0y, xtra);
+    }
     return nullptr;
 }
 

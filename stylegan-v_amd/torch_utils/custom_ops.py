@@ -223,6 +223,33 @@ def check(rc, lib=None):
     raise RuntimeError(msg or ('libsgv_hip error %d' % rc))
 
 
+def raw_stream(tensor):
+    """hipStream_t (as int) of torch's CURRENT stream on the tensor's device -- the stream the C ABI must launch on."""
+    import torch
+    return torch._C._cuda_getCurrentRawStream(tensor.device.index)
+
+
+class device_guard:
+    """Make the tensor's device current for the launch (what the reference's OptionalCUDAGuard does, upfirdn2d.cpp:31);
+    a no-op -- and no Python context-manager overhead worth mentioning -- in the one-process-per-GPU case."""
+    __slots__ = ('idx', 'prev')
+
+    def __init__(self, tensor):
+        self.idx = tensor.device.index
+
+    def __enter__(self):
+        import torch
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            import torch
+            torch.cuda.set_device(self.prev)
+        return False
+
+
 def launch_count():
     return int(get_native().sgv_launch_count()) if native_loaded() else 0
 

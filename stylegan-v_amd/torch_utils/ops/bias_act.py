@@ -116,20 +116,12 @@ def _native_call(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp):
     y = torch.empty_like(x)
     if x.numel() == 0:
         return y
-    p = custom_ops.BiasActParams()
-    p.x, p.y = x.data_ptr(), y.data_ptr()
-    p.b = b.data_ptr() if b is not None else None
-    p.xref = xref.data_ptr() if xref is not None else None
-    p.yref = yref.data_ptr() if yref is not None else None
-    p.dy = dy.data_ptr() if dy is not None else None
-    p.grad, p.act = grad, act_idx
-    p.alpha, p.gain, p.clamp = alpha, gain, clamp
-    p.size_x = x.numel()
-    p.size_b = b.numel() if b is not None else 0
-    p.step_b = x.stride(dim) if b is not None else 1
-    with torch.cuda.device_of(x):
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        custom_ops.check(lib.sgv_bias_act(p, _DTYPE_CODES[x.dtype], stream), lib)
+    p = custom_ops.BiasActParams(x.data_ptr(), b.data_ptr() if b is not None else None, xref.data_ptr() if xref is not None else None,
+                                 yref.data_ptr() if yref is not None else None, dy.data_ptr() if dy is not None else None, y.data_ptr(),
+                                 grad, act_idx, alpha, gain, clamp, x.numel(), b.numel() if b is not None else 0,
+                                 x.stride(dim) if b is not None else 1)
+    with custom_ops.device_guard(x):
+        custom_ops.check(lib.sgv_bias_act(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
     return y
 
 

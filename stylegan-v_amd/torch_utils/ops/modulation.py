@@ -16,7 +16,7 @@ from .upfirdn2d import _DTYPE_CODES
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return custom_ops.raw_stream(t)
 
 
 def weight_sqsum_ref(weight):
@@ -39,7 +39,7 @@ class _DemodCoefsFn(torch.autograd.Function):
         n = s.shape[0]
         q = torch.empty([oc, ic], dtype=torch.float32, device=w.device)
         d = torch.empty([n, oc], dtype=torch.float32, device=w.device)
-        with torch.cuda.device_of(w):
+        with custom_ops.device_guard(w):
             custom_ops.check(lib.sgv_weight_sqsum(w.data_ptr(), q.data_ptr(), oc, ic, kh * kw, _stream(w)), lib)
             custom_ops.check(lib.sgv_demod_coefs(s.data_ptr(), q.data_ptr(), d.data_ptr(), n, oc, ic, float(eps), _stream(w)), lib)
         ctx.save_for_backward(weight, styles, q, d)
@@ -76,7 +76,7 @@ class _ScaleChannelsFn(torch.autograd.Function):
         hw = xc.numel() // max(n * c, 1)
         y = torch.empty_like(xc)
         if xc.numel():
-            with torch.cuda.device_of(xc):
+            with custom_ops.device_guard(xc):
                 custom_ops.check(lib.sgv_scale_channels(xc.data_ptr(), sc.data_ptr(), y.data_ptr(), n, c, hw, _DTYPE_CODES[xc.dtype], _stream(xc)), lib)
         ctx.save_for_backward(x, s)
         return y

@@ -151,20 +151,12 @@ def _native_call(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain)
                     memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     if y.numel() == 0 or x.numel() == 0:
         return y
-    p = custom_ops.Upfirdn2dParams()
-    p.x, p.f, p.y = x.data_ptr(), f2d.data_ptr(), y.data_ptr()
-    p.up_x, p.up_y, p.down_x, p.down_y = upx, upy, downx, downy
-    p.pad_x0, p.pad_x1, p.pad_y0, p.pad_y1 = px0, px1, py0, py1
-    p.flip, p.gain = int(bool(flip)), float(gain)
-    p.in_w, p.in_h, p.in_c, p.in_n = w, h, c, n
-    p.in_sn, p.in_sc, p.in_sh, p.in_sw = x.stride()
-    p.f_w, p.f_h = fw, fh
-    p.f_sh, p.f_sw = f2d.stride()
-    p.out_w, p.out_h = ow, oh
-    p.out_sn, p.out_sc, p.out_sh, p.out_sw = y.stride()
-    with torch.cuda.device_of(x):
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        custom_ops.check(lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], stream), lib)
+    xs, fs, ys = x.stride(), f2d.stride(), y.stride()
+    p = custom_ops.Upfirdn2dParams(x.data_ptr(), f2d.data_ptr(), y.data_ptr(), upx, upy, downx, downy, px0, px1, py0, py1,
+                                   int(bool(flip)), float(gain), w, h, c, n, xs[3], xs[2], xs[1], xs[0], fw, fh, fs[1], fs[0],
+                                   ow, oh, ys[3], ys[2], ys[1], ys[0])
+    with custom_ops.device_guard(x):
+        custom_ops.check(lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
     return y
 
 

@@ -60,7 +60,7 @@ def discriminator_config(sampling=None):
     return Config(sampling=sampling or sampling_config(), concat_res=16, num_frames_div_factor=2, dummy_c=False)
 
 
-def model_kwargs(resolution=256, batch_size=32, num_gpus=1, fp32=True, min_period_len=16, num_frames_per_video=3):
+def model_kwargs(resolution=256, batch_size=32, num_gpus=1, fp32=True, min_period_len=16, num_frames_per_video=3, lowp_dtype=None):
     """Constructor arguments of G and D as src/train.py:138-200 derives them for cfg='auto'.
 
     fmaps 0.5 below 512^2 else 1 (:158), mapping depth 2 (:139), mbstd group min(batch_gpu, 4) (:157),
@@ -71,10 +71,14 @@ def model_kwargs(resolution=256, batch_size=32, num_gpus=1, fp32=True, min_perio
     gcfg = generator_config(samp, min_period_len=min_period_len)
     dcfg = discriminator_config(samp)
     synth = dict(channel_base=int(fmaps * 32768), channel_max=512, num_fp16_res=0 if fp32 else 4, conv_clamp=None if fp32 else 256)
+    block_kwargs = {}
+    if not fp32 and lowp_dtype is not None:  # reference mixed precision is fp16 (networks.py:227,461); bf16 is this build's extension
+        synth['lowp_dtype'] = lowp_dtype
+        block_kwargs['lowp_dtype'] = lowp_dtype
     g_kwargs = dict(c_dim=0, w_dim=512, img_resolution=resolution, img_channels=3, mapping_kwargs=dict(num_layers=2, cfg=gcfg),
                     synthesis_kwargs=synth, cfg=gcfg)
     d_kwargs = dict(c_dim=0, img_resolution=resolution, img_channels=3, channel_base=int(fmaps * 32768), channel_max=512,
-                    num_fp16_res=0 if fp32 else 4, conv_clamp=None if fp32 else 256, mapping_kwargs=dict(num_layers=2),
+                    num_fp16_res=0 if fp32 else 4, conv_clamp=None if fp32 else 256, block_kwargs=block_kwargs, mapping_kwargs=dict(num_layers=2),
                     epilogue_kwargs=dict(mbstd_group_size=min(batch_size // num_gpus, 4)), cfg=dcfg)
     train = dict(r1_gamma=0.0002 * resolution ** 2 / batch_size, lr=0.002 if resolution >= 1024 else 0.0025, betas=(0.0, 0.99),
                  ema_kimg=batch_size * 10 / 32, ema_rampup=0.05, G_reg_interval=4, D_reg_interval=16, pl_weight=0.0)

@@ -128,6 +128,37 @@ def test_upfirdn2d_row_walker_shapes_bit_exact(cfg, dtype):
                 assert_bit_equal(y, ref, what=f'{cfg} {shape} filter#{fi} flip={flip} {dtype} kind={kind}')
 
 
+SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466, 0.787641141030194,
+        0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578, 0.0017677118642428036, -0.007800708325034148]
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+def test_upfirdn2d_ada_separable_passes_bit_exact(dtype):
+    """The ADA pipe's resampling (augment.py:289,300): separable 12-tap 'sym6' up x2 then, after the warp, down x2 with
+    a crop (negative padding) and a flipped filter.  Each 1-D pass must select the row-walker kernel and match the oracle."""
+    g = torch.Generator().manual_seed(21)
+    f = torch.tensor(SYM6)
+    for shape in ((2, 9, 76, 76), (1, 3, 33, 140), (1, 2, 268, 268)):
+        x = torch.randn(shape, generator=g).to(dtype)
+        xg, fg = x.to(DEV), f.to(DEV)
+        # one-dimensional passes as the native layer sees them
+        for up, down, pad, f2 in (((2, 1), 1, [6, 5, 0, 0], f.unsqueeze(0)), ((1, 2), 1, [0, 0, 6, 5], f.unsqueeze(1)),
+                                  (1, (2, 1), [-1, -1, 0, 0], f.unsqueeze(0)), (1, (1, 2), [0, 0, -1, -1], f.unsqueeze(1)),
+                                  (1, 1, [6, 5, 0, 0], f.unsqueeze(0)), (1, 1, [0, 0, 5, 6], f.unsqueeze(1))):
+            assert _kind(xg, f2.to(DEV).contiguous(), up, down, pad) == 1
+            for flip in (False, True):
+                y = ufd.upfirdn2d(xg, f2.to(DEV), up=up, down=down, padding=pad, flip_filter=flip, gain=2)
+                assert_bit_equal(y, oracle.upfirdn2d(x, f2, up=up, down=down, padding=pad, flip_filter=flip, gain=2), what=f'{shape} up={up} down={down} {dtype}')
+        # and the public separable entry points (two launches each)
+        before = custom_ops.launch_count()
+        up = ufd.upsample2d(xg, fg, up=2, padding=2)
+        assert custom_ops.launch_count() == before + 2
+        assert_bit_equal(up, oracle.upfirdn2d(x, f, up=2, padding=[8, 7, 8, 7], gain=4), what='upsample2d sym6')
+        dn = ufd.downsample2d(up, fg, down=2, padding=-4, flip_filter=True)
+        ref_dn = oracle.upfirdn2d(up.cpu(), f, down=2, padding=[1, 1, 1, 1], flip_filter=True)
+        assert_bit_equal(dn, ref_dn, what='downsample2d sym6')
+
+
 def test_upfirdn2d_generic_layouts():
     """channels_last, sliced (non-dense) inputs and fp64 go to the generic kernel and still match."""
     g = torch.Generator().manual_seed(3)
