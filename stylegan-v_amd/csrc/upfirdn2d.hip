@@ -335,6 +335,7 @@ struct lanes_params {
     int lpr_log2;      // SEG only: lanes per image row = 1 << lpr_log2 (<= 32), 64 >> lpr_log2 planes share a wave
     int plane_groups;  // SEG: groups of planes sharing a wave; otherwise == planes
     int nt_store;      // stream the output past the caches (tensors larger than the Infinity Cache)
+    int lds_share;     // hand the vertical halo rows from wave to wave through LDS
 };
 
 template <typename T, int N> __device__ __forceinline__ void store_vec_nt(T* p, const float* v) {
@@ -355,8 +356,8 @@ template <typename T, int N> __device__ __forceinline__ void store_vec_plain(T* 
     *(typename vec_of<T, N>::type*)p = sv;
 }
 
-template <typename T, int UP, int DOWN, int PX0, int PY0, int XTRA, bool SEG>
-__global__ __launch_bounds__(256, (DOWN == 2 ? 5 : 8)) void upfirdn2d_lanes_kernel(lanes_params p) {
+template <typename T, int UP, int DOWN, int PX0, int PY0, int XTRA, bool SEG, int WPB>
+__global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : 8)) void upfirdn2d_lanes_kernel(lanes_params p) {
     constexpr int FWP = 4, FHP = 4, DEPTH = (UP == 2 ? 2 : 1);  // row groups of loads in flight ahead of the math
     constexpr int TX = FWP / UP, TY = FHP / UP;
     constexpr int R0X = ((UP - 1 - PX0) % UP + UP) % UP, R0Y = ((UP - 1 - PY0) % UP + UP) % UP;
@@ -372,7 +373,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? 5 : 8)) void upfirdn2d_lanes_kern
     static_assert(WR >= ADV, "window smaller than advance");
 
     const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = blockIdx.x * WPB + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int strip = wave % p.strips;
     // SEG = false: the wave spans one block of 64*VEC output columns of one plane (column group cg).
     // SEG = true : rows are at most 32 lanes wide; 64 >> lpr_log2 planes ride in one wave, lane groups exchange
@@ -382,8 +383,9 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? 5 : 8)) void upfirdn2d_lanes_kern
     const int lpr = SEG ? (1 << p.lpr_log2) : 64;
     const int sub = lane & (lpr - 1);
     const int plane = SEG ? pgroup * (64 >> p.lpr_log2) + (lane >> p.lpr_log2) : pgroup;
-    if (pgroup >= (SEG ? p.plane_groups : p.planes)) return;
-    const bool plane_ok = plane < p.planes;
+    // Waves past the end of the grid still take part in the workgroup barrier below, then leave.
+    const bool wave_active = pgroup < (SEG ? p.plane_groups : p.planes);
+    const bool plane_ok = wave_active && plane < p.planes;
     const bool seg_first = SEG && sub == 0, seg_last = SEG && sub == lpr - 1;
 
     float ff[FHP][FWP];
@@ -418,20 +420,58 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? 5 : 8)) void upfirdn2d_lanes_kern
 
     const int n_main = XTRA ? p.out_w - 1 : p.out_w;
     const int oy_a = strip * p.strip_h;
-    const int oy_b = min(oy_a + p.strip_h, p.out_h);
-    if (oy_a >= oy_b) return;
+    const int oy_b = min(oy_a + p.strip_h, p.out_h);       // strips = ceil(out_h / strip_h): never empty
     const int iny0 = oy_a * DOWN / UP + BASEY;               // strip_h is a multiple of UP
     const int iy_last = ((oy_b - 1) * DOWN + UP - 1 - PY0) / UP + TY;  // (generous) last input row any output of the strip touches
 
-    struct raw_row { float m[OWN]; float h; float hr[SEG ? (R > 0 ? R : 1) : 1]; };
+    // Vertical-halo hand-off through LDS.  The last WR-ADV input rows of a strip are exactly the first rows the next
+    // strip loads in its prologue; the next strip belongs to the next wave of this workgroup, which fetches them at
+    // t = 0 while this wave needs them only at the very end of its walk -- too far apart for L1/L2 to help (measured:
+    // 1.24x the algorithmic read bytes on the headline call).  So every wave parks its prologue rows (raw, as loaded)
+    // in LDS, one barrier, and the wave above reads them from there instead of from memory.
+    constexpr int SHARE = WR - ADV;                          // rows shared with the strip above
+    constexpr int HR = SEG ? (R > 0 ? R : 1) : 1;
+    constexpr int RAW = OWN + 1 + HR;
+    __shared__ float halo_lds[SHARE > 0 ? WPB * SHARE * RAW * 64 : 1];
+    const int wslot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // the wave below is this strip's successor iff it is in the same plane group / column group (strips run fastest)
+    // (and only if this strip is tall enough that its own prologue rows are not already the shared ones: those are read
+    // before the barrier)
+    const bool lower_in_wg = SHARE > 0 && p.lds_share && wave_active && wslot < WPB - 1 && strip + 1 < p.strips &&
+                             ((oy_b - oy_a + G - 1) / G) * ADV >= SHARE;
+    const int shared_row0 = oy_b * DOWN / UP + BASEY;        // == iny0 of the next strip when this strip is full-height
+
+    struct raw_row { float m[OWN]; float h; float hr[HR]; };
+
+    auto lds_put = [&](int r, const raw_row& t) {
+        if constexpr (SHARE > 0) {
+            float* q = halo_lds + ((wslot * SHARE + r) * RAW) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < OWN; i++) q[i * 64] = t.m[i];
+            q[OWN * 64] = t.h;
+#pragma unroll
+            for (int i = 0; i < HR; i++) q[(OWN + 1 + i) * 64] = t.hr[i];
+        }
+    };
+    auto lds_get = [&](int r, raw_row& t) {
+        if constexpr (SHARE > 0) {
+            const float* q = halo_lds + (((wslot + 1) * SHARE + r) * RAW) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < OWN; i++) t.m[i] = q[i * 64];
+            t.h = q[OWN * 64];
+#pragma unroll
+            for (int i = 0; i < HR; i++) t.hr[i] = q[(OWN + 1 + i) * 64];
+        }
+    };
 
     auto issue = [&](int iy, raw_row& r) {
 #pragma unroll
         for (int i = 0; i < OWN; i++) r.m[i] = 0.f;
         r.h = 0.f;
 #pragma unroll
-        for (int i = 0; i < (SEG ? R : 0); i++) r.hr[i] = 0.f;
+        for (int i = 0; i < HR; i++) r.hr[i] = 0.f;
         if (iy < 0 || iy >= p.in_h || iy > iy_last) return;   // wave-uniform
+        if (lower_in_wg && iy >= shared_row0 && iy < shared_row0 + SHARE) { lds_get(iy - shared_row0, r); return; }  // wave-uniform
         const T* row = xplane + (size_t)iy * p.in_w;
         if (own_full) {
             row_loader<T, OWN>::run(row + own0, r.m);
@@ -467,11 +507,13 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? 5 : 8)) void upfirdn2d_lanes_kern
     };
 
     float win[WR][NEED];
-    {
+    if (wave_active) {
         raw_row t;
 #pragma unroll
-        for (int r = 0; r < WR - ADV; r++) { issue(iny0 + r, t); expand(t, win[ADV + r]); }
+        for (int r = 0; r < WR - ADV; r++) { issue(iny0 + r, t); if (p.lds_share) lds_put(r, t); expand(t, win[ADV + r]); }
     }
+    if constexpr (SHARE > 0) { if (p.lds_share) __syncthreads(); }
+    if (!wave_active) return;
     raw_row ring[DEPTH][ADV];
     int iy_next = iny0 + (WR - ADV);
 #pragma unroll
@@ -537,6 +579,7 @@ __global__ __launch_bounds__(256, (DOWN == 2 ? 5 : 8)) void upfirdn2d_lanes_kern
 }
 
 typedef void (*lanes_fn)(lanes_params);
+constexpr int LANES_WPB = 4;  // waves per workgroup (8 measured equal: the halo hand-off already covers 3 of 4 strip seams)
 
 template <typename T>
 lanes_fn pick_lanes_kernel(const sgv_upfirdn2d_params* p, int xtra, bool seg) {
@@ -544,8 +587,8 @@ lanes_fn pick_lanes_kernel(const sgv_upfirdn2d_params* p, int xtra, bool seg) {
     if (p->up_y != u || p->down_y != d || p->f_w > 4 || p->f_h > 4) return nullptr;
 #define SGV_LANES(U, D, PX, PY)                                                                     \
     if (u == U && d == D && px == PX && py == PY)                                                   \
-        return seg ? (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, true> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, true>)         \
-                   : (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, false> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, false>);
+        return seg ? (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, true, LANES_WPB> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, true, LANES_WPB>)         \
+                   : (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, false, LANES_WPB> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, false, LANES_WPB>);
     SGV_LANES(1, 1, 1, 1)   // FIR after the up-convolution (2r+1 -> 2r); backward of the D pre-FIR
     SGV_LANES(1, 1, 2, 2)   // FIR before the strided convolution (r -> r+1); backward of the G FIR
     SGV_LANES(2, 1, 2, 2)   // 2x upsample (skip-RGB); backward of the 2x downsample
@@ -558,6 +601,7 @@ struct lanes_plan {
     lanes_fn fn;
     lanes_params lp;
     int blocks;
+    int threads;
 };
 
 
@@ -671,6 +715,7 @@ bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan) {
     const int cbs = (n_main + VEC - 1) / VEC;
     const bool seg = cbs <= 32;  // narrow rows: several planes per wave, segmented lane exchange
     lanes_fn fn = nullptr;
+    constexpr int wpb = LANES_WPB;
     if (dtype == SGV_F32) fn = pick_lanes_kernel<float>(p, xtra, seg);
     if (dtype == SGV_F16) fn = pick_lanes_kernel<sgv_half_t>(p, xtra, seg);
     if (dtype == SGV_BF16) fn = pick_lanes_kernel<sgv_bf16_t>(p, xtra, seg);
@@ -688,6 +733,8 @@ bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan) {
     lp.plane_groups = seg ? (lp.planes + (64 >> lpr_log2) - 1) / (64 >> lpr_log2) : lp.planes;
     const double out_bytes = (double)p->out_w * p->out_h * lp.planes * sgv_dtype_size(dtype);
     lp.nt_store = out_bytes > 300e6 ? 1 : 0;
+    static const int lds_env = []() { const char* e = getenv("SGV_LANES_LDS"); return e ? atoi(e) : 1; }();
+    lp.lds_share = lds_env;
     // Short strips: many short-lived waves whose concurrent footprint is a compact moving window of memory
     // stream HBM best (16-row strips: 5.4 TB/s, 32-row: 4.9 TB/s, 64-row: 4.6 TB/s on the headline call).
     int strip_h = strip_env > 0 ? strip_env : 16;
@@ -696,10 +743,11 @@ bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan) {
     lp.strip_h = strip_h;
     lp.strips = (p->out_h + strip_h - 1) / strip_h;
     const int64_t waves = (int64_t)lp.plane_groups * lp.col_groups * lp.strips;
-    const int64_t blocks = (waves + 3) / 4;
+    const int64_t blocks = (waves + wpb - 1) / wpb;
     if (blocks > 0x7fffffff) return false;
     plan->fn = fn;
     plan->blocks = (int)blocks;
+    plan->threads = 64 * wpb;
     return true;
 }
 
@@ -748,7 +796,7 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
     lanes_plan lplan;
     if (plan_lanes(p, dtype, &lplan)) {
         sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
-        hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3(256), 0, stream, lplan.lp);
+        hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
         return sgv_check_launch("upfirdn2d_lanes_kernel");
     }
     rows_plan plan;

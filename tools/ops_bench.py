@@ -6,8 +6,8 @@
 Shapes are the hot-path calls of the FFS 256^2 config (SURVEY.md 8(d) shape table); `--frames` is
 the number of frames N (32 = the 1.078 GB headline upfirdn2d call, 96 = one training minibatch).
 Achieved GB/s = ALGORITHMIC bytes / time: upfirdn2d (numel(x)+numel(y))*sizeof(T); bias_act
-all streams read + written.  Timing: HIP events on the launch stream (torch's current stream, which is
-the stream the C ABI launches on), L2/MALL flushed between repetitions by cycling through enough
+all streams read + written.  Timing: the library's per-launch HIP events (recorded inside the C ABI around each launch, on torch's current
+stream) for the native kernels, torch events for the torch baselines; L2/MALL flushed between repetitions by cycling through enough
 distinct buffers to exceed the 256 MiB Infinity Cache.
 """
 import argparse
@@ -26,13 +26,27 @@ HBM_COPY = 6.29e12     # measured float4 copy ceiling (MI355X_MICROARCH.md)
 F32_MFMA_PEAK = 157.3e12
 
 
-def time_call(fn, make_args, reps, min_bytes_cycle=600e6, bytes_per_call=1.0):
-    """Median / min ms of fn(*args) over `reps`, rotating over enough argument sets to defeat the 256 MiB L3."""
+def time_call(fn, make_args, reps, min_bytes_cycle=600e6, bytes_per_call=1.0, native=None):
+    """Mean / min ms of fn(*args) over `reps`, rotating over enough argument sets to defeat the 256 MiB L3.
+
+    native = kernel-family name: time with the library's own per-launch HIP events (recorded inside the C ABI right
+    around the launch), which excludes the ~20-30 us of Python between a torch event and the launch that follows it --
+    10 % of a 230 us kernel.  Otherwise torch events on the current stream."""
     nsets = max(2, min(8, int(min_bytes_cycle // max(bytes_per_call, 1.0)) + 1))
     sets = [make_args() for _ in range(nsets)]
     for s in sets:
         fn(*s)
     torch.cuda.synchronize()
+    if native is not None:
+        custom_ops.prof_enable(4096)
+        for r in range(reps):
+            fn(*sets[r % nsets])
+        torch.cuda.synchronize()
+        custom_ops.prof_disable()
+        e = custom_ops.prof_collect()[native]
+        assert e['launches'] >= reps, (native, e)
+        per_call = e['ms'] / reps
+        return per_call, per_call
     times = []
     for r in range(reps):
         s = sets[r % nsets]
@@ -65,7 +79,8 @@ def bench_upfirdn2d(N, reps, dtype):
         y0 = upfirdn2d.upfirdn2d(x0, f, **kw)
         nbytes = (x0.numel() + y0.numel()) * es
         del x0, y0
-        med, best = time_call(lambda x: upfirdn2d.upfirdn2d(x, f, **kw), lambda: (torch.randn(shape, device=dev).to(dtype),), reps, bytes_per_call=nbytes)
+        kind = 'upfirdn2d_lanes'
+        med, best = time_call(lambda x: upfirdn2d.upfirdn2d(x, f, **kw), lambda: (torch.randn(shape, device=dev).to(dtype),), reps, bytes_per_call=nbytes, native=kind)
         rows.append(dict(kernel='upfirdn2d', call=label, shape=shape, dtype=str(dtype).split('.')[-1], bytes=nbytes, ms=med, ms_min=best,
                          GBps=nbytes / med / 1e6, frac_of_8TBps=nbytes / (med * 1e-3) / HBM_PEAK, frac_of_copy=nbytes / (med * 1e-3) / HBM_COPY))
     return rows
@@ -79,14 +94,14 @@ def bench_bias_act(N, reps, dtype):
         shape = [N, c, r, r]
         b = torch.randn([c], device=dev).to(dtype)
         n = N * c * r * r
-        med, best = time_call(lambda x: bias_act.bias_act(x, b, act='lrelu', clamp=256), lambda: (torch.randn(shape, device=dev).to(dtype),), reps, bytes_per_call=2 * n * es)
+        med, best = time_call(lambda x: bias_act.bias_act(x, b, act='lrelu', clamp=256), lambda: (torch.randn(shape, device=dev).to(dtype),), reps, bytes_per_call=2 * n * es, native='bias_act')
         rows.append(dict(kernel='bias_act', call=f'fwd lrelu+clamp C{c} {r}x{r}', shape=shape, dtype=str(dtype).split('.')[-1], bytes=2 * n * es, ms=med, ms_min=best,
                          GBps=2 * n * es / med / 1e6, frac_of_8TBps=2 * n * es / (med * 1e-3) / HBM_PEAK, frac_of_copy=2 * n * es / (med * 1e-3) / HBM_COPY))
         # grad=1 form: dy + yref -> dx (3 streams)
         lib = custom_ops.get_native()
         from stylegan_v_amd.torch_utils.ops.bias_act import _native_call
         med, best = time_call(lambda dy, y: _native_call(dy, b, None, y, None, 1, 1, 3, 0.2, 2 ** 0.5, 256.0),
-                              lambda: (torch.randn(shape, device=dev).to(dtype), torch.randn(shape, device=dev).to(dtype)), reps, bytes_per_call=3 * n * es)
+                              lambda: (torch.randn(shape, device=dev).to(dtype), torch.randn(shape, device=dev).to(dtype)), reps, bytes_per_call=3 * n * es, native='bias_act')
         rows.append(dict(kernel='bias_act', call=f'grad1 lrelu C{c} {r}x{r}', shape=shape, dtype=str(dtype).split('.')[-1], bytes=3 * n * es, ms=med, ms_min=best,
                          GBps=3 * n * es / med / 1e6, frac_of_8TBps=3 * n * es / (med * 1e-3) / HBM_PEAK, frac_of_copy=3 * n * es / (med * 1e-3) / HBM_COPY))
         del lib
@@ -117,7 +132,7 @@ def bench_modulation(N, reps):
         shape = [N, c, r, r]
         s = torch.randn([N, c], device=dev)
         n = N * c * r * r
-        med, best = time_call(lambda x: modulation.scale_channels(x, s), lambda: (torch.randn(shape, device=dev),), reps, bytes_per_call=8 * n)
+        med, best = time_call(lambda x: modulation.scale_channels(x, s), lambda: (torch.randn(shape, device=dev),), reps, bytes_per_call=8 * n, native='modulate')
         rows.append(dict(kernel='scale_channels', call=f'C{c} {r}x{r}', shape=shape, bytes=8 * n, ms=med, ms_min=best, GBps=8 * n / med / 1e6,
                          frac_of_8TBps=8 * n / (med * 1e-3) / HBM_PEAK, frac_of_copy=8 * n / (med * 1e-3) / HBM_COPY))
     return rows
