@@ -16,6 +16,8 @@
  *   sgv_upfirdn2d      <- `_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1,
  *                          pady0, pady1, flip, gain)`  src/torch_utils/ops/upfirdn2d.cpp:16,98-101
  *                          (kernel parameter block: src/torch_utils/ops/upfirdn2d.h:14-40)
+ *   sgv_upfirdn2d_fused <- no single reference op: upfirdn2d + x*dcoefs + bias_act of a synthesis layer
+ *                          src/training/networks.py:65-74,141-143 in one kernel (forward and backward forms)
  *   sgv_bias_act       <- `_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain,
  *                          clamp)`  src/torch_utils/ops/bias_act.cpp:32,94-97
  *                          (kernel parameter block: src/torch_utils/ops/bias_act.h:12-31)
@@ -79,6 +81,30 @@ typedef struct sgv_upfirdn2d_params {
 } sgv_upfirdn2d_params;
 
 int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* stream);
+
+/* Fused "FIR + scale + bias + activation + clamp" (the honest reading of north_star's `filtered_lrelu`: the
+ * reference has no such op; it runs upfirdn2d -> x*dcoefs -> bias_act as three passes after every up-sampling
+ * synthesis convolution, networks.py:65-74,141-143 + conv2d_resample.py:138-139).
+ *   mode 1  y  = clamp(act(upfirdn2d(x) * scale[n,c] + bias[c]) * gain)                    (forward)
+ *   mode 2  dx = upfirdn2d(g * scale[n,c]),  g = dy * act'(.) * gain masked by the clamp,   (backward of mode 1; the
+ *           x = dy, yref = the forward output; additionally sum_g[n,c] += sum(g) and         upfirdn2d params describe the
+ *           sum_gv[n,c] += sum(g * preactivation) over every plane, from which                transposed FIR, i.e. pad 2)
+ *           dbias[c] = sum_n sum_g[n,c] and dscale[n,c] = (sum_gv - bias[c]*sum_g) / scale[n,c].
+ * act: 1 linear or 3 lrelu (bias_act.py:23-33 indices).  scale / bias may be NULL (1 / 0).  Supported for the
+ * lane-exchange kernel's FIR geometries only (mode 1: up=down=1, pad0 1; mode 2: up=down=1, pad0 2; 4x4 filter,
+ * dense NCHW); anything else returns SGV_ERR_UNSUPPORTED and the caller composes the three ops. */
+typedef struct sgv_fir_epilogue {
+    int32_t mode;
+    const float* scale; /* [n*c] fp32 or NULL */
+    const float* bias;  /* [c] fp32 or NULL */
+    const void* yref;   /* mode 2: [n,c,in_h,in_w], dtype/layout of x */
+    float* sum_g;       /* mode 2: [n*c], zero-initialised by the caller, accumulated with atomics */
+    float* sum_gv;      /* mode 2: [n*c], likewise */
+    int32_t act;
+    float alpha, gain, clamp; /* clamp < 0: none */
+} sgv_fir_epilogue;
+
+int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dtype, void* stream);
 
 /* Which kernel sgv_upfirdn2d would run for p: 0 = generic gather kernel, 1 = register-window row walker
  * (contiguous NCHW, up/down in {1,2}, filter <= 4x4), 2 = lane-exchange kernel (the four hot-path geometries at

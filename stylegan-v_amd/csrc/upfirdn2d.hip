@@ -336,6 +336,15 @@ struct lanes_params {
     int plane_groups;  // SEG: groups of planes sharing a wave; otherwise == planes
     int nt_store;      // stream the output past the caches (tensors larger than the Infinity Cache)
     int lds_share;     // hand the vertical halo rows from wave to wave through LDS
+    // fused epilogue / prologue (EPI != 0), see sgv_fir_epilogue in include/sgv_ops.h
+    const float* ep_scale;  // [planes] or NULL
+    const float* ep_bias;   // [chans] or NULL
+    const void* ep_yref;    // EPI == 2: forward output, same shape as x
+    float* ep_sum_g;        // EPI == 2: [planes]
+    float* ep_sum_gv;       // EPI == 2: [planes]
+    int ep_act;             // 1 linear, 3 lrelu
+    float ep_alpha, ep_gain, ep_clamp;
+    int chans;
 };
 
 template <typename T, int N> __device__ __forceinline__ void store_vec_nt(T* p, const float* v) {
@@ -356,8 +365,15 @@ template <typename T, int N> __device__ __forceinline__ void store_vec_plain(T* 
     *(typename vec_of<T, N>::type*)p = sv;
 }
 
-template <typename T, int UP, int DOWN, int PX0, int PY0, int XTRA, bool SEG, int WPB>
-__global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : 8)) void upfirdn2d_lanes_kernel(lanes_params p) {
+// EPI = 0: plain upfirdn2d.
+// EPI = 1: fused forward epilogue   y = clamp(act(upfirdn2d(x) * scale[n,c] + bias[c]) * gain)  -- the FIR, the
+//          demodulation scaling and the bias/activation/clamp of a StyleGAN synthesis layer in ONE pass over the
+//          activation instead of three (networks.py:65-74,141-143 + conv2d_resample.py:138-139).
+// EPI = 2: fused backward prologue  dx = upfirdn2d(g * scale),  g = d(bias_act)/dx at yref applied to the incoming
+//          gradient (bias_act.cu:60-61,133-142 grad=1 form), evaluated while the rows are loaded; the per-plane sums
+//          sum(g) and sum(g * preactivation) that give the bias and scale gradients are accumulated on the way.
+template <typename T, int UP, int DOWN, int PX0, int PY0, int XTRA, bool SEG, int WPB, int EPI>
+__global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI == 2 ? 6 : 8))) void upfirdn2d_lanes_kernel(lanes_params p) {
     constexpr int FWP = 4, FHP = 4, DEPTH = (UP == 2 ? 2 : 1);  // row groups of loads in flight ahead of the math
     constexpr int TX = FWP / UP, TY = FHP / UP;
     constexpr int R0X = ((UP - 1 - PX0) % UP + UP) % UP, R0Y = ((UP - 1 - PY0) % UP + UP) % UP;
@@ -407,6 +423,13 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : 8)) void upfirdn2d_lanes
     T* yplane = (T*)p.y + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
     const int cb = SEG ? sub : cg * 64 + lane;
     const int ox0 = cb * VEC;
+    float ep_sc = 1.f, ep_bi = 0.f;
+    if constexpr (EPI != 0) {
+        if (plane_ok && p.ep_scale) ep_sc = p.ep_scale[plane];
+        if (plane_ok && p.ep_bias) ep_bi = p.ep_bias[plane % p.chans];
+    }
+    const T* yrefplane = (EPI == 2) ? (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w : nullptr;
+    float sum_g = 0.f, sum_gv = 0.f;
     const int own0 = cb * OWN;                               // first owned input column
     const bool own_full = plane_ok && own0 + OWN <= p.in_w;
     const bool own_none = !plane_ok || own0 >= p.in_w;
@@ -442,6 +465,30 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : 8)) void upfirdn2d_lanes
     const int shared_row0 = oy_b * DOWN / UP + BASEY;        // == iny0 of the next strip when this strip is full-height
 
     struct raw_row { float m[OWN]; float h; float hr[HR]; };
+
+    // rows this strip accounts for in the plane sums (every input row exactly once over the strips of a plane)
+    const int own_lo = iny0;
+    const int own_hi = (strip + 1 < p.strips) ? shared_row0 : 0x7fffffff;
+    // bias -> activation -> gain -> clamp, the operation order of bias_act.cu:51-142 (grad 0)
+    auto epi_fwd = [&](float u) {
+        float t = u * ep_sc;
+        t = t + ep_bi;
+        if (p.ep_act == 3) t = (t > 0.f) ? t : t * p.ep_alpha;
+        t *= p.ep_gain;
+        if (p.ep_clamp >= 0.f) t = (t > -p.ep_clamp & t < p.ep_clamp) ? t : (t >= 0.f) ? p.ep_clamp : -p.ep_clamp;
+        return t;
+    };
+    // grad-1 form (bias_act.cu:60-61,133-142): g = dy * act'(pre) * gain, zero where the forward output was clamped;
+    // `pre` returns the pre-activation value recovered from the stored output (lrelu is invertible).
+    auto epi_grad = [&](float dy, float yref, float& pre) {
+        const float yy = (p.ep_gain != 0.f) ? yref / p.ep_gain : 0.f;
+        float g = dy;
+        pre = yy;
+        if (p.ep_act == 3) { g = (yy > 0.f) ? dy : dy * p.ep_alpha; pre = (yy > 0.f) ? yy : yy / p.ep_alpha; }
+        g *= p.ep_gain;
+        if (p.ep_clamp >= 0.f) g = (yref > -p.ep_clamp & yref < p.ep_clamp) ? g : 0.f;
+        return g;
+    };
 
     auto lds_put = [&](int r, const raw_row& t) {
         if constexpr (SHARE > 0) {
@@ -488,6 +535,40 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : 8)) void upfirdn2d_lanes
             }
         } else {
             if (halo_ok) r.h = sgv_traits<T>::load(row + halo_col);
+        }
+        if constexpr (EPI == 2) {
+            // The rows just loaded hold the incoming gradient dy; turn them into g * scale with the forward output at
+            // the same positions.  Rows in [own_lo, own_hi) belong to this strip for the purpose of the plane sums.
+            const T* yrow = yrefplane + (size_t)iy * p.in_w;
+            const bool counted = iy >= own_lo && iy < own_hi;
+            float yr[OWN];
+#pragma unroll
+            for (int i = 0; i < OWN; i++) yr[i] = 0.f;
+            if (own_full) {
+                row_loader<T, OWN>::run(yrow + own0, yr);
+            } else if (!own_none) {
+#pragma unroll
+                for (int i = 0; i < OWN; i++)
+                    if (own0 + i < p.in_w) yr[i] = sgv_traits<T>::load(yrow + own0 + i);
+            }
+#pragma unroll
+            for (int i = 0; i < OWN; i++) {
+                float pre;
+                const float g = epi_grad(r.m[i], yr[i], pre);
+                if (counted) { sum_g += g; sum_gv = __builtin_fmaf(g, pre, sum_gv); }
+                r.m[i] = g * ep_sc;
+            }
+            float pre;
+            if constexpr (SEG) {
+                if (seg_last && plane_ok) {
+#pragma unroll
+                    for (int i = 0; i < R; i++)
+                        if (seg_halo0 + i < p.in_w) r.hr[i] = epi_grad(r.hr[i], sgv_traits<T>::load(yrow + seg_halo0 + i), pre) * ep_sc;
+                }
+            } else {
+                // the outer-halo columns belong to this plane too (non-SEG: one plane per wave), so ep_sc is the right scale
+                if (halo_ok) r.h = epi_grad(r.h, sgv_traits<T>::load(yrow + halo_col), pre) * lane_bcast(ep_sc, 0);
+            }
         }
     };
 
@@ -560,6 +641,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : 8)) void upfirdn2d_lanes
                         for (int kx = 0; kx < TX; kx++)
                             acc = __builtin_fmaf(win[ry + ky][cx + kx], ff[fy0 + ky * UP][fx0 + kx * UP], acc);
                     out[v] = acc * p.gain;
+                    if constexpr (EPI == 1) out[v] = epi_fwd(out[v]);
                 }
                 T* yrow = yplane + (size_t)(oyd + u) * p.out_w + ox0;
                 if (store_vec) {
@@ -576,19 +658,38 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : 8)) void upfirdn2d_lanes
             }
         }
     }
+    if constexpr (EPI == 2) {
+        // reduce over the lanes that share a plane (the whole wave, or one lane group with SEG), then one atomic per plane
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            if (off < lpr) { sum_g += __shfl_xor(sum_g, off, 64); sum_gv += __shfl_xor(sum_gv, off, 64); }
+        }
+        if (sub == 0 && plane_ok) {
+            atomicAdd(p.ep_sum_g + plane, sum_g);
+            atomicAdd(p.ep_sum_gv + plane, sum_gv);
+        }
+    }
 }
 
 typedef void (*lanes_fn)(lanes_params);
 constexpr int LANES_WPB = 4;  // waves per workgroup (8 measured equal: the halo hand-off already covers 3 of 4 strip seams)
 
 template <typename T>
-lanes_fn pick_lanes_kernel(const sgv_upfirdn2d_params* p, int xtra, bool seg) {
+lanes_fn pick_lanes_kernel(const sgv_upfirdn2d_params* p, int xtra, bool seg, int epi) {
     const int u = p->up_x, d = p->down_x, px = p->pad_x0, py = p->pad_y0;
     if (p->up_y != u || p->down_y != d || p->f_w > 4 || p->f_h > 4) return nullptr;
+#define SGV_LANES_EPI(U, D, PX, PY, E)                                                                \
+    if (u == U && d == D && px == PX && py == PY && epi == E)                                            \
+        return seg ? (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, true, LANES_WPB, E> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, true, LANES_WPB, E>)         \
+                   : (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, false, LANES_WPB, E> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, false, LANES_WPB, E>);
+    SGV_LANES_EPI(1, 1, 1, 1, 1)   // synthesis-layer epilogue: FIR (2r+1 -> 2r) * dcoefs + bias -> lrelu -> clamp
+    SGV_LANES_EPI(1, 1, 2, 2, 2)   // its backward: lrelu'/clamp mask * dcoefs -> FIR (2r -> 2r+1), plane sums
+#undef SGV_LANES_EPI
+    if (epi != 0) return nullptr;
 #define SGV_LANES(U, D, PX, PY)                                                                     \
     if (u == U && d == D && px == PX && py == PY)                                                   \
-        return seg ? (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, true, LANES_WPB> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, true, LANES_WPB>)         \
-                   : (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, false, LANES_WPB> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, false, LANES_WPB>);
+        return seg ? (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, true, LANES_WPB, 0> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, true, LANES_WPB, 0>)         \
+                   : (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, false, LANES_WPB, 0> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, false, LANES_WPB, 0>);
     SGV_LANES(1, 1, 1, 1)   // FIR after the up-convolution (2r+1 -> 2r); backward of the D pre-FIR
     SGV_LANES(1, 1, 2, 2)   // FIR before the strided convolution (r -> r+1); backward of the G FIR
     SGV_LANES(2, 1, 2, 2)   // 2x upsample (skip-RGB); backward of the 2x downsample
@@ -706,7 +807,7 @@ bool plan_rows(const sgv_upfirdn2d_params* p, int dtype, rows_plan* plan) {
 }
 
 
-bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan) {
+bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan, const sgv_fir_epilogue* epi = nullptr) {
     if (dtype == SGV_F64) return false;
     if (!dense_nchw(p->in_w, p->in_h, p->in_c, p->in_sw, p->in_sh, p->in_sc, p->in_sn)) return false;
     if (!dense_nchw(p->out_w, p->out_h, p->in_c, p->out_sw, p->out_sh, p->out_sc, p->out_sn)) return false;
@@ -716,9 +817,10 @@ bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan) {
     const bool seg = cbs <= 32;  // narrow rows: several planes per wave, segmented lane exchange
     lanes_fn fn = nullptr;
     constexpr int wpb = LANES_WPB;
-    if (dtype == SGV_F32) fn = pick_lanes_kernel<float>(p, xtra, seg);
-    if (dtype == SGV_F16) fn = pick_lanes_kernel<sgv_half_t>(p, xtra, seg);
-    if (dtype == SGV_BF16) fn = pick_lanes_kernel<sgv_bf16_t>(p, xtra, seg);
+    const int emode = epi ? epi->mode : 0;
+    if (dtype == SGV_F32) fn = pick_lanes_kernel<float>(p, xtra, seg, emode);
+    if (dtype == SGV_F16) fn = pick_lanes_kernel<sgv_half_t>(p, xtra, seg, emode);
+    if (dtype == SGV_BF16) fn = pick_lanes_kernel<sgv_bf16_t>(p, xtra, seg, emode);
     if (!fn) return false;
     static const int strip_env = []() { const char* e = getenv("SGV_LANES_STRIP"); return e ? atoi(e) : 0; }();
     lanes_params& lp = plan->lp;
@@ -735,6 +837,12 @@ bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan) {
     lp.nt_store = out_bytes > 300e6 ? 1 : 0;
     static const int lds_env = []() { const char* e = getenv("SGV_LANES_LDS"); return e ? atoi(e) : 1; }();
     lp.lds_share = lds_env;
+    lp.ep_scale = nullptr; lp.ep_bias = nullptr; lp.ep_yref = nullptr; lp.ep_sum_g = nullptr; lp.ep_sum_gv = nullptr;
+    lp.ep_act = 1; lp.ep_alpha = 0.f; lp.ep_gain = 1.f; lp.ep_clamp = -1.f; lp.chans = p->in_c;
+    if (epi) {
+        lp.ep_scale = epi->scale; lp.ep_bias = epi->bias; lp.ep_yref = epi->yref; lp.ep_sum_g = epi->sum_g; lp.ep_sum_gv = epi->sum_gv;
+        lp.ep_act = epi->act; lp.ep_alpha = epi->alpha; lp.ep_gain = epi->gain; lp.ep_clamp = epi->clamp;
+    }
     // Short strips: many short-lived waves whose concurrent footprint is a compact moving window of memory
     // stream HBM best (16-row strips: 5.4 TB/s, 32-row: 4.9 TB/s, 64-row: 4.6 TB/s on the headline call).
     int strip_h = strip_env > 0 ? strip_env : 16;
@@ -826,4 +934,24 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
         default: return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d: unknown dtype %d", dtype);
     }
     return sgv_check_launch("upfirdn2d_generic_kernel");
+}
+
+extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dtype, void* stream_) {
+    int rc = validate(p, dtype);
+    if (rc != SGV_OK) return rc;
+    if (!e) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: epilogue is NULL");
+    if (e->mode != 1 && e->mode != 2) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode must be 1 (forward epilogue) or 2 (backward prologue)");
+    if (e->act != 1 && e->act != 3) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: only linear (1) and lrelu (3) are fusable");
+    if (e->act == 3 && e->alpha == 0.f) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: lrelu with alpha 0 is not invertible");
+    if (e->mode == 2 && (!e->yref || !e->sum_g || !e->sum_gv)) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode 2 needs yref, sum_g and sum_gv");
+    hipStream_t stream = (hipStream_t)stream_;
+    lanes_plan lplan;
+    if (!plan_lanes(p, dtype, &lplan, e))
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: geometry/layout not covered by the fused kernel (mode 1: up=down=1 pad 1, mode 2: up=down=1 pad 2, 4x4 filter, dense NCHW)");
+    const double es = (double)sgv_dtype_size(dtype);
+    const double nin = (double)p->in_w * p->in_h * p->in_c * p->in_n, nout = (double)p->out_w * p->out_h * p->in_c * p->in_n;
+    const double bytes = (e->mode == 2 ? 2.0 * nin : nin) * es + nout * es;
+    sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
+    hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
+    return sgv_check_launch("upfirdn2d_lanes_kernel (fused)");
 }

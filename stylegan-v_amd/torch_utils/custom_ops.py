@@ -167,6 +167,11 @@ class BiasActParams(ctypes.Structure):
     ]
 
 
+class FirEpilogue(ctypes.Structure):
+    _fields_ = [('mode', c_int32), ('scale', c_void_p), ('bias', c_void_p), ('yref', c_void_p), ('sum_g', c_void_p), ('sum_gv', c_void_p),
+                ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
+
+
 class TimeEncodeParams(ctypes.Structure):
     _fields_ = [(name, c_void_p) for name in
                 ['periods', 'phases', 'al', 'ar', 'freqs', 'phase_scales', 't', 't_left', 't_right', 'alpha', 'out']] + \
@@ -192,6 +197,7 @@ class ProfEntry(ctypes.Structure):
 ABI_SYMBOLS = {
     'sgv_upfirdn2d': (c_int, [ctypes.POINTER(Upfirdn2dParams), c_int, c_void_p]),
     'sgv_upfirdn2d_kernel_kind': (c_int, [ctypes.POINTER(Upfirdn2dParams), c_int]),
+    'sgv_upfirdn2d_fused': (c_int, [ctypes.POINTER(Upfirdn2dParams), ctypes.POINTER(FirEpilogue), c_int, c_void_p]),
     'sgv_bias_act': (c_int, [ctypes.POINTER(BiasActParams), c_int, c_void_p]),
     'sgv_weight_sqsum': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_demod_coefs': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),

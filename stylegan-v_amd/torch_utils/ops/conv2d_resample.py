@@ -45,6 +45,33 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     return op(x, w, stride=stride, padding=padding, groups=groups)
 
 
+def upsampling_conv_parts(x, w, f, up, padding=0, groups=1, flip_weight=True):
+    """First half of the `up > 1` branch of conv2d_resample: the stride-`up` transposed convolution, WITHOUT the FIR
+    that follows it.  Returns (y, fir_padding): ``upfirdn2d(y, f, padding=fir_padding, gain=up**2)`` completes the op.
+    Used by the synthesis layer to fuse that FIR with the demodulation / bias / activation epilogue."""
+    assert up > 1
+    out_ch, in_ch_per_group, kh, kw = _get_weight_shape(w)
+    fw, fh = _get_filter_size(f)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    px0 += (fw + up - 1) // 2
+    px1 += (fw - up) // 2
+    py0 += (fh + up - 1) // 2
+    py1 += (fh - up) // 2
+    if groups == 1:
+        wt = w.transpose(0, 1)
+    else:
+        wt = w.reshape(groups, out_ch // groups, in_ch_per_group, kh, kw).transpose(1, 2)
+        wt = wt.reshape(groups * in_ch_per_group, out_ch // groups, kh, kw)
+    px0 -= kw - 1
+    px1 -= kw - up
+    py0 -= kh - 1
+    py1 -= kh - up
+    pxt = max(min(-px0, -px1), 0)
+    pyt = max(min(-py0, -py1), 0)
+    y = _conv2d_wrapper(x=x, w=wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
+    return y, [px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt]
+
+
 @misc.profiled_function
 def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight=True, flip_filter=False):
     """x ``[N, Cin, H, W]``, w ``[Cout, Cin/groups, kh, kw]``, f from ``upfirdn2d.setup_filter``.

@@ -1,0 +1,114 @@
+"""Fused "FIR -> per-sample channel scale -> bias -> activation -> clamp" epilogue of an up-sampling synthesis layer.
+
+The reference has no such op (there is no ``filtered_lrelu`` in this StyleGAN2-ADA-vintage code
+base).  After every ``up=2`` modulated convolution it runs three full passes over the activation:
+``upfirdn2d`` (conv2d_resample.py:138-139) -> ``x * dcoefs`` (networks.py:70-71) -> ``bias_act`` (networks.py:141-143).
+``fir_bias_act`` computes exactly that composition; on the GPU it is ONE kernel forward
+(``sgv_upfirdn2d_fused`` mode 1) and ONE kernel backward (mode 2: activation derivative and clamp mask applied while the
+gradient rows are loaded, transposed FIR, and the per-plane sums that give the bias and scale gradients accumulated on
+the way).  For fp32 the forward result is bit-identical to the three-op composition (same fp32 operations in the same
+order).  Anything the fused kernel does not cover -- CPU tensors, other paddings, double backward -- runs the
+composition of the three ops, which is the definition of the result.
+"""
+
+import torch
+
+from .. import custom_ops
+from . import bias_act as _ba
+from . import modulation as _mod
+from . import upfirdn2d as _ufd
+from .upfirdn2d import _DTYPE_CODES
+
+enabled = True  # module switch (training with path-length regularisation needs double backward -> composition)
+
+
+def fir_bias_act_composed(x, f, scale=None, bias=None, padding=1, fir_gain=1, act='lrelu', alpha=None, gain=None, clamp=None, flip_filter=False):
+    """The definition: three ops, differentiable to any order."""
+    y = _ufd.upfirdn2d(x, f, padding=padding, gain=fir_gain, flip_filter=flip_filter)
+    if scale is not None:
+        y = _mod.scale_channels(y, scale)
+    return _ba.bias_act(y, bias.to(y.dtype) if bias is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)
+
+
+def _ufd_params(x, f, y, pads, flip, gain):
+    n, c, h, w = x.shape
+    xs, fs, ys = x.stride(), f.stride(), y.stride()
+    return custom_ops.Upfirdn2dParams(x.data_ptr(), f.data_ptr(), y.data_ptr(), 1, 1, 1, 1, pads[0], pads[1], pads[2], pads[3],
+                                      int(bool(flip)), float(gain), w, h, c, n, xs[3], xs[2], xs[1], xs[0], f.shape[1], f.shape[0], fs[1], fs[0],
+                                      y.shape[3], y.shape[2], ys[3], ys[2], ys[1], ys[0])
+
+
+class _FusedFirBiasActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f, scale, bias, cfg):
+        pads, fir_gain, flip, act, alpha, gain, clamp = cfg
+        lib = custom_ops.get_native()
+        x = x.contiguous()
+        n, c, h, w = x.shape
+        fh, fw = f.shape
+        oh = _ufd.output_size(h, 1, 1, pads[2], pads[3], fh)
+        ow = _ufd.output_size(w, 1, 1, pads[0], pads[1], fw)
+        y = torch.empty([n, c, oh, ow], dtype=x.dtype, device=x.device)
+        sc = scale.reshape(-1).contiguous().float() if scale is not None else None
+        bi = bias.contiguous().float() if bias is not None else None
+        e = custom_ops.FirEpilogue(1, sc.data_ptr() if sc is not None else None, bi.data_ptr() if bi is not None else None, None, None, None,
+                                   _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
+        with custom_ops.device_guard(x):
+            custom_ops.check(lib.sgv_upfirdn2d_fused(_ufd_params(x, f, y, pads, flip, fir_gain), e, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
+        ctx.cfg = cfg
+        ctx.x_shape = x.shape
+        ctx.has_scale, ctx.has_bias = scale is not None, bias is not None
+        ctx.scale_shape = scale.shape if scale is not None else None
+        ctx.save_for_backward(y, f, sc, bi)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        pads, fir_gain, flip, act, alpha, gain, clamp = ctx.cfg
+        y, f, sc, bi = ctx.saved_tensors
+        lib = custom_ops.get_native()
+        dy = dy.contiguous()
+        n, c, ih, iw = ctx.x_shape
+        oh, ow = y.shape[2], y.shape[3]
+        fh, fw = f.shape
+        # the gradient of upfirdn2d is upfirdn2d with the padding of upfirdn2d.py:251-261 and the filter flip inverted
+        bpads = (fw - pads[0] - 1, iw - ow + pads[0], fh - pads[2] - 1, ih - oh + pads[2])
+        dx = torch.empty(ctx.x_shape, dtype=dy.dtype, device=dy.device)
+        sums = torch.zeros([2, n * c], dtype=torch.float32, device=dy.device)
+        e = custom_ops.FirEpilogue(2, sc.data_ptr() if sc is not None else None, None, y.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(),
+                                   _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
+        with custom_ops.device_guard(dy):
+            custom_ops.check(lib.sgv_upfirdn2d_fused(_ufd_params(dy, f, dx, bpads, not flip, fir_gain), e, _DTYPE_CODES[dy.dtype], custom_ops.raw_stream(dy)), lib)
+        d_scale = d_bias = None
+        sum_g, sum_gv = sums[0].reshape(n, c), sums[1].reshape(n, c)
+        if ctx.has_bias and ctx.needs_input_grad[3]:
+            d_bias = sum_g.sum(0)
+        if ctx.has_scale and ctx.needs_input_grad[2]:
+            b_row = bi.reshape(1, c) if bi is not None else 0.0
+            d_scale = ((sum_gv - b_row * sum_g) / sc.reshape(n, c)).reshape(ctx.scale_shape)
+        return dx, None, d_scale, d_bias, None
+
+
+def _fusable(x, f, scale, bias, pads, act, alpha):
+    if not (enabled and x.is_cuda and x.ndim == 4 and x.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+        return False
+    if f is None or f.ndim != 2 or f.shape[0] > 4 or f.shape[1] > 4 or not f.is_cuda:
+        return False
+    if tuple(pads) != (1, 1, 1, 1) or act not in ('linear', 'lrelu') or (act == 'lrelu' and alpha == 0):
+        return False
+    if scale is not None and (scale.dtype != torch.float32 or scale.numel() != x.shape[0] * x.shape[1]):
+        return False
+    return True  # the fused node is first-order only: differentiating it twice raises (once_differentiable); see `enabled`
+
+
+def fir_bias_act(x, f, scale=None, bias=None, padding=1, fir_gain=1, act='lrelu', alpha=None, gain=None, clamp=None, flip_filter=False):
+    """clamp(act(upfirdn2d(x, f, padding, gain=fir_gain) * scale[n,c] + bias[c]) * gain).
+
+    x [N,C,H,W]; f 2-D fp32 filter; scale [N,C] fp32 or None; bias [C] or None; act/alpha/gain/clamp as ``bias_act``."""
+    pads = _ufd._parse_padding(padding)
+    spec, alpha_f, gain_f, clamp_f = _ba._resolve(act, alpha, gain, clamp)
+    if _fusable(x, f, scale, bias, pads, act, alpha_f):
+        return _FusedFirBiasActFn.apply(x, f, scale, bias, (pads, float(fir_gain), bool(flip_filter), act, alpha_f, gain_f, clamp_f))
+    return fir_bias_act_composed(x, f, scale=scale, bias=bias, padding=padding, fir_gain=fir_gain, act=act, alpha=alpha, gain=gain, clamp=clamp,
+                                 flip_filter=flip_filter)

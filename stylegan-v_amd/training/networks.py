@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, fma, modulation, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_resample, fma, fused_fir_act, modulation, upfirdn2d
 from .layers import Conv2dLayer, FullyConnectedLayer, GenInput, MappingNetwork, TemporalDifferenceEncoder
 from .motion import MotionMappingNetwork
 
@@ -99,9 +99,22 @@ class SynthesisLayer(torch.nn.Module):
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
         if self.cfg.use_noise and noise_mode == 'const':
             noise = self.noise_const * self.noise_strength
+        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        if self.up == 2 and not fused_modconv and noise is None and fused_fir_act.enabled and x.is_cuda and self.activation in ('linear', 'lrelu'):
+            # Up-sampling layer, training path: x*s -> transposed conv -> [FIR * dcoefs + bias -> act -> clamp] where the
+            # bracket is one kernel (ops/fused_fir_act.py) instead of upfirdn2d + scale + bias_act.
+            weight, s = self.weight, styles
+            if x.dtype == torch.float16:  # same fp16 range guard as modulated_conv2d
+                weight = weight * (1 / math.sqrt(weight[0].numel()) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+                s = s / s.norm(float('inf'), dim=1, keepdim=True)
+            dcoefs = modulation.demod_coefs(weight, s)
+            x = modulation.scale_channels(x, s)
+            x, fir_pad = conv2d_resample.upsampling_conv_parts(x, weight.to(x.dtype), self.resample_filter, up=self.up, padding=self.padding,
+                                                               flip_weight=False)
+            return fused_fir_act.fir_bias_act(x, self.resample_filter, scale=dcoefs, bias=self.bias, padding=fir_pad, fir_gain=self.up ** 2,
+                                              act=self.activation, gain=self.act_gain * gain, clamp=clamp)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
-        clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
 
 

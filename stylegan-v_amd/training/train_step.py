@@ -74,6 +74,9 @@ class TrainStep:
                 mod.requires_grad_(False)
             for p in misc.params_and_buffers(self.G_ema):  # G_ema: sync initial values only
                 torch.distributed.broadcast(p, src=0)
+        if train_cfg.pl_weight != 0:  # path-length regularisation differentiates G twice: the fused epilogue node is first-order only
+            from ..torch_utils.ops import fused_fir_act
+            fused_fir_act.enabled = False
         self.loss = StyleGAN2Loss(cfg=g_kwargs['cfg'], device=self.device, r1_gamma=train_cfg.r1_gamma, pl_weight=train_cfg.pl_weight, **modules)
 
         # Phase list with lazy regularisation (training_loop.py:238-252): reg every `interval` iterations with

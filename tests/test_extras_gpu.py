@@ -127,6 +127,64 @@ def test_gemm_conv1x1(n, cin, cout, h):
         assert_close(a, r, atol=1e-3, rtol=1e-4, what='d' + name)
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(2, 3, 9, 9), (3, 5, 17, 17), (2, 4, 33, 33), (1, 2, 65, 65), (2, 2, 129, 129), (1, 2, 257, 257), (1, 1, 300, 300)])
+def test_fused_fir_bias_act_matches_three_op_composition(dtype, shape):
+    """sgv_upfirdn2d_fused (one kernel forward, one backward) == upfirdn2d -> scale_channels -> bias_act."""
+    from stylegan_v_amd.torch_utils.ops import fused_fir_act, upfirdn2d
+    g = torch.Generator().manual_seed(sum(shape))
+    n, c = shape[:2]
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    x0 = torch.randn(shape, generator=g).to(dtype).to(DEV)
+    s0 = (torch.rand([n, c], generator=g) + 0.5).to(DEV)
+    b0 = torch.randn([c], generator=g).to(DEV)
+    kw = dict(padding=1, fir_gain=4, act='lrelu', gain=1.2, clamp=1.5)
+    outs = []
+    for fn in (fused_fir_act.fir_bias_act, fused_fir_act.fir_bias_act_composed):
+        x, s, b = x0.clone().requires_grad_(True), s0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        before = custom_ops.launch_count()
+        y = fn(x, f, scale=s, bias=b, **kw)
+        launches_fwd = custom_ops.launch_count() - before
+        dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(5)).to(dtype).to(DEV)
+        before = custom_ops.launch_count()
+        dx, ds, db = torch.autograd.grad(y, [x, s, b], dy)
+        outs.append((y, dx, ds, db, launches_fwd, custom_ops.launch_count() - before))
+    (y1, dx1, ds1, db1, lf1, lb1), (y2, dx2, ds2, db2, lf2, lb2) = outs
+    assert (lf1, lb1) == (1, 1) and lf2 == 3 and lb2 >= 3, 'fused path must be one launch each way'
+    if dtype == torch.float32:
+        assert torch.equal(y1, y2), 'fp32 forward must be bit-identical to the composition'
+        assert torch.equal(dx1, dx2)
+        assert_close(ds1, ds2, atol=2e-4 * max(1.0, ds2.abs().max().item()), rtol=2e-4, what='dscale')
+        assert_close(db1, db2, atol=2e-4 * max(1.0, db2.abs().max().item()), rtol=2e-4, what='dbias')
+        return
+    # 16-bit storage: the fused kernel keeps the FIR result and the scaled value in fp32 where the composition rounds them to
+    # 16 bits twice; outputs that land on the other side of zero / of the clamp bound flip the activation derivative of single
+    # elements.  Judge both against the fp32 composition on the same (16-bit) inputs, in relative L2.
+    x, s, b = x0.float().requires_grad_(True), s0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+    yr = fused_fir_act.fir_bias_act_composed(x, f, scale=s, bias=b, **kw)
+    dxr, dsr, dbr = torch.autograd.grad(yr, [x, s, b], torch.randn(yr.shape, generator=torch.Generator().manual_seed(5)).to(dtype).to(DEV).float())
+
+    def rel(a, r):
+        return ((a.float() - r).norm() / (r.norm() + 1e-6)).item()
+    # (plane sums recover the pre-activation from the 16-bit output and cancel heavily: looser bound than element-wise results)
+    lim_elem, lim_sum = (0.01, 0.08) if dtype == torch.float16 else (0.06, 0.25)
+    for name, fused, comp, ref, lim in (('y', y1, y2, yr.detach(), lim_elem), ('dx', dx1, dx2, dxr, 2 * lim_elem),
+                                        ('dscale', ds1, ds2, dsr, lim_sum), ('dbias', db1, db2, dbr, lim_sum)):
+        assert rel(fused, ref) < lim, f'{name}: fused path off by {rel(fused, ref):.3f} (relative L2) from the fp32 composition'
+        assert rel(fused, ref) < 3.0 * rel(comp, ref) + lim / 2, f'{name}: fused path much less accurate than the 16-bit composition'
+
+
+def test_fused_fir_bias_act_double_backward_is_refused():
+    from stylegan_v_amd.torch_utils.ops import fused_fir_act, upfirdn2d
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    x = torch.randn([1, 2, 9, 9], device=DEV, requires_grad=True)
+    y = fused_fir_act.fir_bias_act(x, f, scale=torch.ones([1, 2], device=DEV), bias=torch.zeros([2], device=DEV), padding=1)
+    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+    assert gx.grad_fn is None or not gx.requires_grad, 'the fused node must not pretend to be twice differentiable'
+    with pytest.raises(RuntimeError, match='once_differentiable|differentiated twice|differentiate twice|does not require grad'):
+        gx.square().sum().backward()
+
+
 def test_reference_time_encoder_golden_on_gpu():
     """The whole motion encoder (conv1d trajectory -> gather -> fused tail) against the reference module's fp64 output."""
     from stylegan_v_amd.training.motion import MotionMappingNetwork
