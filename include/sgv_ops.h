@@ -25,6 +25,9 @@
  *                      <- the weight (de)modulation arithmetic of `modulated_conv2d`
  *                          src/training/networks.py:57-74 (no native counterpart in the
  *                          reference: it materialises w[N,O,I,kh,kw] in PyTorch)
+ *   sgv_pointwise_small / sgv_pointwise_outer
+ *                      <- the 1x1 `conv2d` of ToRGBLayer (networks.py:148-163, C_out = 3) and of the discriminator's
+ *                          `fromrgb` layer (networks.py:447, C_in = 3) and their gradients, conv2d_resample.py:40-54
  *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail
  *                          src/training/motion.py:201-212
  *   sgv_gemm_f32       <- `torch.addmm` / `matmul` of FullyConnectedLayer and the dense 1x1
@@ -152,6 +155,27 @@ int sgv_scale_channels(const void* x, const float* s, void* y, int32_t n, int32_
                        int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * 1x1 convolutions with <= 4 channels on one side, as HBM streams (ToRGB Cin->3, fromRGB 3->C; NCHW, fp32 accumulate):
+ *   kind 0 (many -> few):  y[n,f,p] = sum_m w[n,f,m] * x[n,m,p]     w: [n or 1][c_few][c_many] fp32
+ *   kind 1 (few -> many):  y[n,m,p] = sum_f w[n,m,f] * x[n,f,p]     w: [n or 1][c_many][c_few] fp32
+ * w_stride_n = elements between the weight sets of consecutive samples (0: shared).  hw = H*W must be a multiple of 4.
+ * sgv_pointwise_outer is the weight-gradient reduction  out[n,f,m] += sum_p a[n,f,p] * b[n,m,p]  (fp32, atomics;
+ * the caller zero-initialises `out`).
+ */
+typedef struct sgv_pointwise_params {
+    const void* x;
+    const float* w;
+    void* y;
+    int32_t n, c_many, c_few, hw;
+    int64_t w_stride_n;
+    int32_t kind;
+} sgv_pointwise_params;
+
+int sgv_pointwise_small(const sgv_pointwise_params* p, int dtype, void* stream);
+int sgv_pointwise_outer(const void* a_few, const void* b_many, float* out, int32_t n, int32_t c_few, int32_t c_many, int32_t hw,
+                        int dtype, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * AlignedTimeEncoder element-wise tail (motion.py:201-212), fp32:
  *   raw(tau) = freqs[j]*periods[r,j]*tau + phases[r,j]*phase_scales[j]
  *   pos(tau) = [sin raw(tau) | cos raw(tau)]                       (2*nf wide)
@@ -215,7 +239,8 @@ enum sgv_kernel_family {
     SGV_K_TIME_ENCODE = 4,
     SGV_K_GEMM = 5,
     SGV_K_UPFIRDN2D_LANES = 6,
-    SGV_K_COUNT = 7
+    SGV_K_POINTWISE = 7,
+    SGV_K_COUNT = 8
 };
 typedef struct sgv_prof_entry {
     int64_t launches;

@@ -142,7 +142,7 @@ def native_loaded():
 c_void_p, c_int, c_int32, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 SGV_F32, SGV_F16, SGV_BF16, SGV_F64 = 0, 1, 2, 3
-SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes']
+SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise']
 
 
 class Upfirdn2dParams(ctypes.Structure):
@@ -170,6 +170,11 @@ class BiasActParams(ctypes.Structure):
 class FirEpilogue(ctypes.Structure):
     _fields_ = [('mode', c_int32), ('scale', c_void_p), ('bias', c_void_p), ('yref', c_void_p), ('sum_g', c_void_p), ('sum_gv', c_void_p),
                 ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
+
+
+class PointwiseParams(ctypes.Structure):
+    _fields_ = [('x', c_void_p), ('w', c_void_p), ('y', c_void_p), ('n', c_int32), ('c_many', c_int32), ('c_few', c_int32), ('hw', c_int32),
+                ('w_stride_n', c_int64), ('kind', c_int32)]
 
 
 class TimeEncodeParams(ctypes.Structure):
@@ -202,6 +207,8 @@ ABI_SYMBOLS = {
     'sgv_weight_sqsum': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_demod_coefs': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
     'sgv_scale_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'sgv_pointwise_small': (c_int, [ctypes.POINTER(PointwiseParams), c_int, c_void_p]),
+    'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_time_encode': (c_int, [ctypes.POINTER(TimeEncodeParams), c_void_p]),
     'sgv_gemm_f32': (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
     'sgv_prof_enable': (c_int, [c_int32]),

@@ -17,6 +17,7 @@ import torch
 
 from .. import misc
 from . import conv2d_gradfix
+from . import pointwise as _pw
 from . import upfirdn2d as _ufd
 from .upfirdn2d import _get_filter_size, _parse_padding
 
@@ -31,6 +32,10 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     out_ch, in_ch_per_group, kh, kw = _get_weight_shape(w)
     if not flip_weight and (kh > 1 or kw > 1):
         w = w.flip([2, 3])
+    # 1x1 convolution with <= 4 channels on one side (fromRGB, un-modulated ToRGB): a memory stream, not a GEMM.
+    if kh == 1 and kw == 1 and stride == 1 and padding in (0, [0, 0], (0, 0)) and not transpose and groups == 1 \
+            and min(out_ch, in_ch_per_group) <= 4 and _pw.enabled and x.is_cuda and x.is_contiguous() and (x.shape[2] * x.shape[3]) % 4 == 0:
+        return _pw.pointwise_conv(x, w.reshape(1, out_ch, in_ch_per_group))
     # channels_last 1x1 convolutions with few channels are a plain matrix product (conv2d_resample.py:40-50).
     if kh == 1 and kw == 1 and stride == 1 and padding in (0, [0, 0], (0, 0)) and not transpose:
         if x.stride(1) == 1 and min(out_ch, in_ch_per_group) < 64:

@@ -1,0 +1,109 @@
+"""1x1 convolutions with at most 4 channels on one side (ToRGB, fromRGB) as HBM-bound streaming kernels.
+
+Reference: the 1x1 ``conv2d`` of ``ToRGBLayer`` (src/training/networks.py:148-163, C_out = 3, modulated) and of the
+discriminator's ``fromrgb`` layer (networks.py:447, C_in = 3), dispatched through conv2d_resample.py:40-54 to cuDNN.
+MIOpen runs these shapes at ~1.8 TFLOP/s; they are memory streams (1.4 flop/B) and ``csrc/pointwise.hip`` treats them
+so.  ``pointwise_conv(x, w)`` takes per-sample (or shared) weights ``w [N or 1, Cout, Cin]`` -- ToRGB folds its styles
+into them, so the separate x*s pass goes away.  Both autograd nodes below are written in terms of each other, so
+gradients of any order are available (R1 differentiates the discriminator's fromRGB twice).
+"""
+
+import torch
+
+from .. import custom_ops
+from .upfirdn2d import _DTYPE_CODES
+
+enabled = True
+
+
+def pointwise_conv_ref(x, w):
+    """y[n,o,p] = sum_i w[n or 0, o, i] x[n,i,p] with plain PyTorch."""
+    n, ci, h, wd = x.shape
+    y = torch.matmul(w.to(x.dtype), x.reshape(n, ci, h * wd))
+    return y.reshape(n, w.shape[1], h, wd)
+
+
+def outer_ref(a, b):
+    """out[n,f,m] = sum_p a[n,f,p] b[n,m,p] (fp32)."""
+    n = a.shape[0]
+    return torch.matmul(a.reshape(n, a.shape[1], -1).float(), b.reshape(n, b.shape[1], -1).float().transpose(1, 2))
+
+
+def _native_ok(x, few, many):
+    return (enabled and x.is_cuda and x.ndim == 4 and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and 1 <= few <= 4 and few <= many
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and x.shape[0] <= 65535)
+
+
+class _PointwiseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w):
+        lib = custom_ops.get_native()
+        xc = x.contiguous()
+        wc = w.contiguous().float()
+        n, ci, h, wd = xc.shape
+        b, co, _ = wc.shape
+        kind = 0 if co <= ci else 1  # 0: many -> few
+        y = torch.empty([n, co, h, wd], dtype=xc.dtype, device=xc.device)
+        p = custom_ops.PointwiseParams(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), n, max(ci, co), min(ci, co), h * wd,
+                                       co * ci if b > 1 else 0, kind)
+        with custom_ops.device_guard(xc):
+            custom_ops.check(lib.sgv_pointwise_small(p, _DTYPE_CODES[xc.dtype], custom_ops.raw_stream(xc)), lib)
+        ctx.save_for_backward(x, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = pointwise_conv(dy, w.transpose(1, 2))
+        if ctx.needs_input_grad[1]:
+            co, ci = w.shape[1], w.shape[2]
+            dw = outer(dy, x) if co <= ci else outer(x, dy).transpose(1, 2)  # [N, co, ci]
+            if w.shape[0] == 1:
+                dw = dw.sum(0, keepdim=True)
+            dw = dw.to(w.dtype)
+        return dx, dw
+
+
+class _OuterFn(torch.autograd.Function):
+    """out[n,f,m] = sum_p a[n,f,p] * b[n,m,p]: a has <= 4 channels."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = custom_ops.get_native()
+        ac, bc = a.contiguous(), b.contiguous()
+        n, f, h, wd = ac.shape
+        m = bc.shape[1]
+        out = torch.zeros([n, f, m], dtype=torch.float32, device=ac.device)
+        with custom_ops.device_guard(ac):
+            custom_ops.check(lib.sgv_pointwise_outer(ac.data_ptr(), bc.data_ptr(), out.data_ptr(), n, f, m, h * wd, _DTYPE_CODES[ac.dtype],
+                                                     custom_ops.raw_stream(ac)), lib)
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, b = ctx.saved_tensors
+        da = db = None
+        if ctx.needs_input_grad[0]:  # da[n,f,p] = sum_m dout[n,f,m] b[n,m,p]
+            da = pointwise_conv(b, dout).to(a.dtype)
+        if ctx.needs_input_grad[1]:  # db[n,m,p] = sum_f dout[n,f,m] a[n,f,p]
+            db = pointwise_conv(a, dout.transpose(1, 2)).to(b.dtype)
+        return da, db
+
+
+def pointwise_conv(x, w):
+    """x [N,Cin,H,W], w [N or 1, Cout, Cin] -> [N,Cout,H,W]; one of Cin / Cout must be <= 4 for the native path."""
+    assert x.ndim == 4 and w.ndim == 3 and w.shape[2] == x.shape[1] and w.shape[0] in (1, x.shape[0])
+    co, ci = w.shape[1], w.shape[2]
+    if _native_ok(x, min(co, ci), max(co, ci)) and w.is_cuda:
+        return _PointwiseFn.apply(x, w)
+    return pointwise_conv_ref(x, w)
+
+
+def outer(a, b):
+    """a [N,F,H,W] (F <= 4), b [N,M,H,W] -> fp32 [N,F,M]."""
+    if _native_ok(a, a.shape[1], b.shape[1]) and b.is_cuda and b.dtype == a.dtype and b.shape[1] >= a.shape[1]:
+        return _OuterFn.apply(a, b)
+    return outer_ref(a, b)

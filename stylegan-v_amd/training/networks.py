@@ -21,7 +21,7 @@ import numpy as np
 import torch
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, fma, fused_fir_act, modulation, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_resample, fma, fused_fir_act, modulation, pointwise, upfirdn2d
 from .layers import Conv2dLayer, FullyConnectedLayer, GenInput, MappingNetwork, TemporalDifferenceEncoder
 from .motion import MotionMappingNetwork
 
@@ -130,7 +130,15 @@ class ToRGBLayer(torch.nn.Module):
 
     def forward(self, x, w, fused_modconv=True):
         styles = self.affine(w) * self.weight_gain
-        x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
+        oc, ic, kh, kw = self.weight.shape
+        if kh == 1 and kw == 1 and oc <= 4 and pointwise.enabled and x.is_cuda and x.is_contiguous():
+            # y[n,o] = sum_i x[n,i] * (W[o,i] * s[n,i]): the style goes into per-sample weights [N,3,I] and the whole layer is
+            # one pass over x (csrc/pointwise.hip) instead of x*s followed by a C_out=3 convolution.  Same function for
+            # either value of `fused_modconv` (no demodulation here).
+            w_ps = self.weight.reshape(1, oc, ic) * styles.reshape(-1, 1, ic)
+            x = pointwise.pointwise_conv(x, w_ps)
+        else:
+            x = modulated_conv2d(x=x, weight=self.weight, styles=styles, demodulate=False, fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), clamp=self.conv_clamp)
 
 

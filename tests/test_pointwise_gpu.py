@@ -1,0 +1,85 @@
+"""ToRGB / fromRGB streaming 1x1 kernels (csrc/pointwise.hip) against torch's conv2d / matmul in fp64/fp32."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stylegan_v_amd.torch_utils.ops import pointwise, conv2d_resample
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w):
+    n = x.shape[0]
+    y = torch.matmul(w.double().expand(n, -1, -1), x.double().reshape(n, x.shape[1], -1))
+    return y.reshape(n, w.shape[1], *x.shape[2:])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('n,ci,co,h,w,shared', [
+    (3, 64, 3, 32, 32, False), (2, 512, 3, 4, 4, False), (2, 37, 3, 10, 6, False), (4, 128, 3, 64, 64, True),
+    (3, 3, 64, 32, 32, True), (2, 3, 128, 16, 16, False), (2, 1, 5, 8, 8, True), (2, 7, 1, 8, 8, False), (1, 4, 4, 6, 6, True),
+    (2, 96, 2, 129, 4, False),
+])
+def test_pointwise_forward(dtype, n, ci, co, h, w, shared):
+    torch.manual_seed(n * 1000 + ci * 10 + co)
+    x = torch.randn(n, ci, h, w, device='cuda').to(dtype)
+    wt = torch.randn(1 if shared else n, co, ci, device='cuda') / ci ** 0.5
+    y = pointwise.pointwise_conv(x, wt)
+    assert y.dtype == dtype and y.shape == (n, co, h, w)
+    tol = {torch.float32: 2e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    assert_close(y.double(), _ref(x, wt), atol=tol, rtol=tol)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16])
+@pytest.mark.parametrize('n,f,m,h,w', [(3, 3, 64, 32, 32), (2, 3, 512, 4, 4), (2, 1, 9, 130, 2), (2, 4, 4, 64, 64), (2, 3, 32, 128, 128)])
+def test_outer(dtype, n, f, m, h, w):
+    torch.manual_seed(f * 100 + m)
+    a = torch.randn(n, f, h, w, device='cuda').to(dtype)
+    b = torch.randn(n, m, h, w, device='cuda').to(dtype)
+    out = pointwise.outer(a, b)
+    ref = torch.matmul(a.double().reshape(n, f, -1), b.double().reshape(n, m, -1).transpose(1, 2))
+    assert out.dtype == torch.float32
+    scale = (h * w) ** 0.5
+    assert_close(out.double() / scale, ref / scale, atol=2e-5 if dtype == torch.float32 else 1e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize('n,ci,co,shared', [(2, 16, 3, False), (2, 3, 16, True), (2, 16, 3, True), (2, 3, 8, False)])
+def test_pointwise_first_and_second_order_gradients(n, ci, co, shared):
+    torch.manual_seed(7)
+    x = torch.randn(n, ci, 6, 6, device='cuda', requires_grad=True)
+    wt = (torch.randn(1 if shared else n, co, ci, device='cuda') / ci ** 0.5).requires_grad_(True)
+    x2 = x.detach().clone().requires_grad_(True)
+    w2 = wt.detach().clone().requires_grad_(True)
+
+    def loss(fn, xx, ww):
+        y = fn(xx, ww)
+        g, gw = torch.autograd.grad((y * y.sin()).sum(), [xx, ww], create_graph=True)
+        return y, g, gw, (g.square().sum() + gw.square().sum())
+
+    y, g, gw, r = loss(pointwise.pointwise_conv, x, wt)
+    yr, gr, gwr, rr = loss(pointwise.pointwise_conv_ref, x2, w2)
+    assert_close(y, yr, atol=1e-5, rtol=1e-5)
+    assert_close(g, gr, atol=1e-5, rtol=1e-5)
+    assert_close(gw, gwr, atol=1e-4, rtol=1e-5)
+    r.backward()
+    rr.backward()
+    assert_close(x.grad, x2.grad, atol=1e-4, rtol=1e-4)
+    assert_close(wt.grad, w2.grad, atol=1e-3, rtol=1e-4)
+
+
+def test_conv2d_resample_uses_stream_kernel_for_fromrgb_shape():
+    from stylegan_v_amd.torch_utils import custom_ops
+    torch.manual_seed(3)
+    x = torch.randn(4, 3, 32, 32, device='cuda', requires_grad=True)
+    w = torch.randn(24, 3, 1, 1, device='cuda', requires_grad=True)
+    before = custom_ops.launch_count()
+    y = conv2d_resample.conv2d_resample(x, w)
+    assert custom_ops.launch_count() == before + 1
+    yr = F.conv2d(x.detach(), w.detach())
+    assert_close(y, yr, atol=1e-5, rtol=1e-5)
+    gx, gw = torch.autograd.grad(y.square().sum(), [x, w])
+    xr, wr = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+    gxr, gwr = torch.autograd.grad(F.conv2d(xr, wr).square().sum(), [xr, wr])
+    assert_close(gx, gxr, atol=1e-4, rtol=1e-4)
+    assert_close(gw, gwr, atol=1e-3, rtol=1e-4)

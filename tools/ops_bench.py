@@ -19,7 +19,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stylegan_v_amd.torch_utils import custom_ops  # noqa: E402
-from stylegan_v_amd.torch_utils.ops import bias_act, gemm, modulation, upfirdn2d  # noqa: E402
+from stylegan_v_amd.torch_utils.ops import bias_act, gemm, modulation, pointwise, upfirdn2d  # noqa: E402
 
 HBM_PEAK = 8.0e12      # spec
 HBM_COPY = 6.29e12     # measured float4 copy ceiling (MI355X_MICROARCH.md)
@@ -138,6 +138,31 @@ def bench_modulation(N, reps):
     return rows
 
 
+def bench_pointwise(N, reps, dtype):
+    """ToRGB (C -> 3), fromRGB (3 -> C) and their weight-gradient reduction against torch's conv2d (MIOpen)."""
+    dev = 'cuda'
+    es = torch.empty([], dtype=dtype).element_size()
+    rows = []
+    for c, r in ((64, 256), (128, 128), (256, 64), (512, 32)):
+        nbytes = (c + 3) * N * r * r * es
+        for label, fn, tfn, mk in (
+            (f'ToRGB {c}->3 {r}x{r} (per-sample w)', lambda x, w: pointwise.pointwise_conv(x, w), lambda x, w: torch.nn.functional.conv2d(x, w[0, :, :, None, None]),
+             lambda: (torch.randn([N, c, r, r], device=dev).to(dtype), torch.randn([N, 3, c], device=dev))),
+            (f'fromRGB 3->{c} {r}x{r}', lambda x, w: pointwise.pointwise_conv(x, w), lambda x, w: torch.nn.functional.conv2d(x, w[0, :, :, None, None].to(x.dtype)),
+             lambda: (torch.randn([N, 3, r, r], device=dev).to(dtype), torch.randn([1, c, 3], device=dev))),
+            (f'dW outer 3x{c} {r}x{r}', lambda a, b: pointwise.outer(a, b), None,
+             lambda: (torch.randn([N, 3, r, r], device=dev).to(dtype), torch.randn([N, c, r, r], device=dev).to(dtype))),
+        ):
+            med, best = time_call(fn, mk, reps, bytes_per_call=nbytes, native='pointwise')
+            row = dict(kernel='pointwise', call=label, dtype=str(dtype).split('.')[-1], bytes=nbytes, ms=med, ms_min=best, GBps=nbytes / med / 1e6,
+                       frac_of_8TBps=nbytes / (med * 1e-3) / HBM_PEAK, frac_of_copy=nbytes / (med * 1e-3) / HBM_COPY)
+            if tfn is not None:
+                tw = (lambda x, w: tfn(x, w.to(x.dtype)))
+                row['miopen_conv2d_ms'], _ = time_call(tw, mk, max(3, reps // 4), bytes_per_call=nbytes)
+            rows.append(row)
+    return rows
+
+
 def bench_gemm(N, reps):
     dev = 'cuda'
     rows = []
@@ -179,6 +204,8 @@ def main():
             rows += bench_upfirdn2d(args.frames, args.reps, dt)
         if args.only in (None, 'bias_act'):
             rows += bench_bias_act(args.frames, args.reps, dt)
+        if args.only in (None, 'pointwise'):
+            rows += bench_pointwise(args.frames, args.reps, dt)
     if args.only in (None, 'modulation'):
         rows += bench_modulation(args.frames, args.reps)
     if args.only in (None, 'gemm'):
@@ -186,6 +213,8 @@ def main():
     for r in rows:
         extra = f"{r['GBps']:9.1f} GB/s  {100*r.get('frac_of_8TBps', 0):5.1f}% of 8TB/s  {100*r.get('frac_of_copy', 0):5.1f}% of 6.29" if 'GBps' in r else \
                 f"{r['TFLOPs']:7.1f} TF ({100*r['frac_of_f32_mfma_peak']:4.1f}% of 157.3)  torch {r['torch_TFLOPs']:7.1f} TF"
+        if 'miopen_conv2d_ms' in r:
+            extra += f"  (MIOpen conv2d {r['miopen_conv2d_ms']:.3f} ms)"
         if 'speedup_vs_reference_formulation' in r:
             extra += f"  x{r['speedup_vs_reference_formulation']:.1f} vs w[N,O,I,k,k]"
         print(f"{r['kernel']:16s} {r['call']:44s} {r['ms']:9.4f} ms  {extra}")
