@@ -1,0 +1,194 @@
+// Templated fp32 MFMA GEMM kernel shared by gemm.hip (the product entry point) and tools/gemm_lab.hip (variant timing).
+//
+//   C[b][M,N] = A[b][M,K] * op(B[b]) (+ bias)          A row-major (k contiguous); B row-major [K,N] (TRANS_B=0) or [N,K] (TRANS_B=1)
+//
+// Workgroup = 256 threads = 4 waves as 2x2, output tile 128x128, each wave 64x64 = 2x2 v_mfma_f32_32x32x2_f32 tiles (64
+// accumulator VGPRs).  K is walked in BK-deep tiles staged through LDS k-major ("[k][row]", rows padded by 4 floats: the
+// MFMA operand fetch -- lanes 0-31 consecutive rows at k, lanes 32-63 at k+1 -- is a conflict-free ds_read_b32).
+// Global loads of tile t+1 are issued before the MFMAs of tile t (register staging).  DBUF = 1 adds a second LDS buffer so
+// one barrier per K tile suffices (the store of tile t+1 cannot overtake readers of tile t-1: they are a barrier behind).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sgv_gemm {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128;
+constexpr int LDT = BM + 4;  // padded row length of the k-major LDS tiles
+
+struct gemm_params {
+    const float* a;
+    const float* b;
+    const float* bias;
+    float* c;
+    int m, n, k;
+    int64_t lda, ldb, ldc;
+    int trans_b;
+    int64_t stride_a, stride_b, stride_c;
+    int bias_mode;
+    int tiles_m, tiles_n;
+};
+
+// [128 rows x BK] block of a row-major [rows, K] matrix (k contiguous): thread t -> row t/4 (+64 per pass), k-quad t%4 (+4 per k-pass).
+template <int BK> struct frag_rk { float v[2 * (BK / 16)][4]; };
+
+template <int BK, int FULL>
+__device__ __forceinline__ void load_rowmajor_k(const float* base, int64_t ld, int row0, int rows, int k0, int kdim, frag_rk<BK>& f) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int kp = 0; kp < BK / 16; kp++)
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int r = row0 + (t >> 2) + pass * 64;
+            const int kq = k0 + kp * 16 + (t & 3) * 4;
+            const float* p = base + (int64_t)r * ld + kq;
+            const bool row_ok = r < rows;
+            float* o = f.v[kp * 2 + pass];
+            if (FULL || (row_ok && kq + 3 < kdim && ((((uintptr_t)p) & 15) == 0))) {
+                float4 q = *(const float4*)p;
+                o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = (row_ok && kq + i < kdim) ? p[i] : 0.f;
+            }
+        }
+}
+
+template <int BK>
+__device__ __forceinline__ void store_rowmajor_k(float (*lds)[LDT], const frag_rk<BK>& f) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int kp = 0; kp < BK / 16; kp++)
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int r = (t >> 2) + pass * 64;
+            const int kq = kp * 16 + (t & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < 4; i++) lds[kq + i][r] = f.v[kp * 2 + pass][i];
+        }
+}
+
+// [BK x 128 cols] block of a row-major [K, cols] matrix (col contiguous): thread t -> k = t/32 (+8 per pass), col-quad t%32.
+template <int BK> struct frag_kc { float v[BK / 8][4]; };
+
+template <int BK, int FULL>
+__device__ __forceinline__ void load_rowmajor_c(const float* base, int64_t ld, int col0, int cols, int k0, int kdim, frag_kc<BK>& f) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int pass = 0; pass < BK / 8; pass++) {
+        const int kk = k0 + (t >> 5) + pass * 8;
+        const int cq = col0 + (t & 31) * 4;
+        const float* p = base + (int64_t)kk * ld + cq;
+        const bool k_ok = kk < kdim;
+        if (FULL || (k_ok && cq + 3 < cols && ((((uintptr_t)p) & 15) == 0))) {
+            float4 q = *(const float4*)p;
+            f.v[pass][0] = q.x; f.v[pass][1] = q.y; f.v[pass][2] = q.z; f.v[pass][3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; i++) f.v[pass][i] = (k_ok && cq + i < cols) ? p[i] : 0.f;
+        }
+    }
+}
+
+template <int BK>
+__device__ __forceinline__ void store_rowmajor_c(float (*lds)[LDT], const frag_kc<BK>& f) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int pass = 0; pass < BK / 8; pass++) {
+        const int kk = (t >> 5) + pass * 8;
+        const int cq = (t & 31) * 4;
+        *(float4*)&lds[kk][cq] = make_float4(f.v[pass][0], f.v[pass][1], f.v[pass][2], f.v[pass][3]);
+    }
+}
+
+// FULL = 1: the host guarantees m % 128 == n % 128 == k % BK == 0 and 16-B aligned rows -> no bounds or alignment branches.
+template <int TRANS_B, int BK, int DBUF, int MINWG, int FULL>
+__global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
+    __shared__ __attribute__((aligned(16))) float As[DBUF + 1][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[DBUF + 1][BK][LDT];
+
+    const int tile = blockIdx.x;
+    const int tm = tile % p.tiles_m;  // M fastest: consecutive workgroups share the B panel
+    const int tn = tile / p.tiles_m;
+    const int batch = blockIdx.y;
+    const float* A = p.a + batch * p.stride_a;
+    const float* B = p.b + batch * p.stride_b;
+    float* C = p.c + batch * p.stride_c;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    frag_rk<BK> fa;
+    frag_rk<BK> fb_t;
+    frag_kc<BK> fb_n;
+    load_rowmajor_k<BK, FULL>(A, p.lda, m0, p.m, 0, p.k, fa);
+    if (TRANS_B) load_rowmajor_k<BK, FULL>(B, p.ldb, n0, p.n, 0, p.k, fb_t);
+    else load_rowmajor_c<BK, FULL>(B, p.ldb, n0, p.n, 0, p.k, fb_n);
+
+    int cur = 0;
+    for (int k0 = 0; k0 < p.k; k0 += BK) {
+        if (!DBUF) __syncthreads();  // previous tile fully consumed
+        store_rowmajor_k<BK>(As[cur], fa);
+        if (TRANS_B) store_rowmajor_k<BK>(Bs[cur], fb_t);
+        else store_rowmajor_c<BK>(Bs[cur], fb_n);
+        __syncthreads();
+        if (k0 + BK < p.k) {  // prefetch the next tile into registers; lands during the MFMAs below
+            load_rowmajor_k<BK, FULL>(A, p.lda, m0, p.m, k0 + BK, p.k, fa);
+            if (TRANS_B) load_rowmajor_k<BK, FULL>(B, p.ldb, n0, p.n, k0 + BK, p.k, fb_t);
+            else load_rowmajor_c<BK, FULL>(B, p.ldb, n0, p.n, k0 + BK, p.k, fb_n);
+        }
+        // Operands of step kk+2 are fetched from LDS while the four MFMAs of step kk run.
+        float a0 = As[cur][lk][wm + lr], a1 = As[cur][lk][wm + 32 + lr];
+        float b0 = Bs[cur][lk][wn + lr], b1 = Bs[cur][lk][wn + 32 + lr];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+            if (kk + 2 < BK) {
+                na0 = As[cur][kk + 2 + lk][wm + lr];
+                na1 = As[cur][kk + 2 + lk][wm + 32 + lr];
+                nb0 = Bs[cur][kk + 2 + lk][wn + lr];
+                nb1 = Bs[cur][kk + 2 + lk][wn + 32 + lr];
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+        if (DBUF) cur ^= 1;
+    }
+
+    // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = n0 + wn + j * 32 + lr;
+            if (!FULL && col >= p.n) continue;
+            const float bcol = (p.bias_mode == 1) ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (!FULL && row >= p.m) continue;
+                float v = acc[i][j][e] + bcol;
+                if (p.bias_mode == 2) v += p.bias[row];
+                C[(int64_t)row * p.ldc + col] = v;
+            }
+        }
+}
+
+}  // namespace sgv_gemm

@@ -17,6 +17,7 @@ import torch
 
 from .. import misc
 from . import conv2d_gradfix
+from . import gemm as _gemm
 from . import pointwise as _pw
 from . import upfirdn2d as _ufd
 from .upfirdn2d import _get_filter_size, _parse_padding
@@ -36,6 +37,10 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     if kh == 1 and kw == 1 and stride == 1 and padding in (0, [0, 0], (0, 0)) and not transpose and groups == 1 \
             and min(out_ch, in_ch_per_group) <= 4 and _pw.enabled and x.is_cuda and x.is_contiguous() and (x.shape[2] * x.shape[3]) % 4 == 0:
         return _pw.pointwise_conv(x, w.reshape(1, out_ch, in_ch_per_group))
+    # Dense fp32 1x1 convolution on whole 128x128 tiles (the discriminator's skip branches): own MFMA GEMM on NCHW.
+    if kh == 1 and kw == 1 and stride == 1 and padding in (0, [0, 0], (0, 0)) and not transpose and groups == 1 and _gemm.enabled \
+            and w.dtype == torch.float32 and _gemm.is_full_tile_conv1x1(x, out_ch):
+        return _gemm.conv1x1(x, w)
     # channels_last 1x1 convolutions with few channels are a plain matrix product (conv2d_resample.py:40-50).
     if kh == 1 and kw == 1 and stride == 1 and padding in (0, [0, 0], (0, 0)) and not transpose:
         if x.stride(1) == 1 and min(out_ch, in_ch_per_group) < 64:

@@ -11,6 +11,8 @@ import torch
 
 from .. import custom_ops
 
+enabled = True  # conv2d_resample routes whole-tile fp32 1x1 convolutions here
+
 
 def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0, sc=0, bias_mode=0):
     lib = custom_ops.get_native()
@@ -22,6 +24,11 @@ def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0,
     with torch.cuda.device_of(c):
         custom_ops.check(lib.sgv_gemm_f32(p, torch.cuda.current_stream(c.device).cuda_stream), lib)
     return c
+
+
+def _gradfix():
+    from . import conv2d_gradfix
+    return conv2d_gradfix
 
 
 def _native_ok(*tensors):
@@ -96,12 +103,50 @@ class _Conv1x1Fn(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = conv1x1(dy, w2.t().reshape(w2.shape[1], w2.shape[0], 1, 1))
-        if ctx.needs_input_grad[1]:
-            n, cout = dy.shape[:2]
-            dw = torch.einsum('nop,nip->oi', dy.reshape(n, cout, -1), x.reshape(n, x.shape[1], -1)).reshape(w.shape)
+        if ctx.needs_input_grad[1] and not _gradfix().weight_gradients_disabled:  # same switch as conv2d_gradfix.py:23
+            dw = conv1x1_weight_grad(dy, x).reshape(w.shape)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = dy.sum([0, 2, 3])
         return dx, dw, db
+
+
+class _Conv1x1WeightGradFn(torch.autograd.Function):
+    """dw[o,i] = sum_{n,p} dy[n,o,p] x[n,i,p]: one [Cout,HW] x [Cin,HW]^T product per sample (K = H*W, both operands k-contiguous
+    in NCHW), summed over the batch.  Differentiable (R1 differentiates the discriminator's skip convolutions twice)."""
+
+    @staticmethod
+    def forward(ctx, dy, x):
+        dyc, xc = dy.contiguous(), x.contiguous()
+        n, cout, h, wd = dyc.shape
+        cin, hw = xc.shape[1], h * wd
+        per = torch.empty([n, cout, cin], dtype=torch.float32, device=x.device)
+        _launch(dyc, xc, None, per, cout, cin, hw, hw, hw, cin, True, batch=n, sa=cout * hw, sb=cin * hw, sc=cout * cin)
+        ctx.save_for_backward(dy, x)
+        return per.sum(0)
+
+    @staticmethod
+    def backward(ctx, g):  # g [Cout, Cin]
+        dy, x = ctx.saved_tensors
+        d_dy = d_x = None
+        if ctx.needs_input_grad[0]:
+            d_dy = conv1x1(x, g)
+        if ctx.needs_input_grad[1]:
+            d_x = conv1x1(dy, g.t())
+        return d_dy, d_x
+
+
+def conv1x1_weight_grad(dy, x):
+    """dy [N,Cout,H,W], x [N,Cin,H,W] -> [Cout,Cin]."""
+    if _native_ok(dy, x) and dy.ndim == 4:
+        return _Conv1x1WeightGradFn.apply(dy, x)
+    n = dy.shape[0]
+    return torch.einsum('nop,nip->oi', dy.reshape(n, dy.shape[1], -1), x.reshape(n, x.shape[1], -1))
+
+
+def is_full_tile_conv1x1(x, cout):
+    """Shapes on which the MFMA kernel runs its branch-free path (and beats MIOpen's 1x1: 110-119 vs 76 TFLOP/s)."""
+    return (x.ndim == 4 and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and cout % 128 == 0 and (x.shape[2] * x.shape[3]) % 128 == 0
+            and x.shape[1] % 16 == 0)
 
 
 def conv1x1(x, w, b=None):

@@ -11,6 +11,7 @@ gradients of any order are available (R1 differentiates the discriminator's from
 import torch
 
 from .. import custom_ops
+from . import conv2d_gradfix
 from .upfirdn2d import _DTYPE_CODES
 
 enabled = True
@@ -49,6 +50,7 @@ class _PointwiseFn(torch.autograd.Function):
         with custom_ops.device_guard(xc):
             custom_ops.check(lib.sgv_pointwise_small(p, _DTYPE_CODES[xc.dtype], custom_ops.raw_stream(xc)), lib)
         ctx.save_for_backward(x, w)
+        ctx.shared_w = b == 1  # a layer's own weight (not ToRGB's per-sample product of weight and styles)
         return y
 
     @staticmethod
@@ -57,7 +59,7 @@ class _PointwiseFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = pointwise_conv(dy, w.transpose(1, 2))
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not (ctx.shared_w and conv2d_gradfix.weight_gradients_disabled):
             co, ci = w.shape[1], w.shape[2]
             dw = outer(dy, x) if co <= ci else outer(x, dy).transpose(1, 2)  # [N, co, ci]
             if w.shape[0] == 1:

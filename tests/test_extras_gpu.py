@@ -85,7 +85,8 @@ def test_time_encode_vs_oracle_and_reference_module():
         assert_close(a, b, atol=2e-2 if name == 'periods' else 1e-3, rtol=1e-3, what=name)
 
 
-@pytest.mark.parametrize('m,n,k', [(96, 512, 512), (32, 512, 512), (1, 7, 3), (130, 129, 17), (257, 64, 1000), (96, 64, 8192)])
+@pytest.mark.parametrize('m,n,k', [(96, 512, 512), (32, 512, 512), (1, 7, 3), (130, 129, 17), (257, 64, 1000), (96, 64, 8192), (256, 384, 96), (128, 128, 16), (384, 256, 48),
+                                   (256, 128, 2048)])
 def test_gemm_linear_vs_fp64(m, n, k):
     g = torch.Generator().manual_seed(m * 7 + n)
     x, w, b = torch.randn([m, k], generator=g), torch.randn([n, k], generator=g), torch.randn([n], generator=g)
@@ -111,7 +112,29 @@ def test_gemm_linear_gradients():
         assert_close(a, r, atol=2e-4, rtol=1e-5, what='d' + name)
 
 
-@pytest.mark.parametrize('n,cin,cout,h', [(3, 64, 128, 16), (2, 256, 512, 32), (2, 3, 64, 32), (1, 130, 70, 9)])
+def test_conv2d_resample_routes_whole_tile_1x1_to_mfma_gemm_with_second_order_grads():
+    """The discriminator's skip convolution (down=2 FIR, then 1x1) must reach sgv_gemm_f32 and stay twice differentiable (R1)."""
+    from stylegan_v_amd.torch_utils.ops import conv2d_resample, upfirdn2d
+    g = torch.Generator().manual_seed(5)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device=DEV)
+    x = torch.randn([2, 32, 32, 32], generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn([128, 32, 1, 1], generator=g) / 32 ** 0.5).to(DEV).requires_grad_(True)
+    custom_ops.prof_enable(256)
+    y = conv2d_resample.conv2d_resample(x, w, f=f, down=2)
+    custom_ops.prof_disable()
+    assert custom_ops.prof_collect()['gemm']['launches'] == 1
+    xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(upfirdn2d.upfirdn2d(xr, f, down=2, padding=1, impl='ref'), wr)
+    assert_close(y, yr, atol=1e-5, rtol=1e-5)
+
+    def r1(yy, xx, ww):
+        gx, = torch.autograd.grad(yy.tanh().sum(), [xx], create_graph=True)
+        return torch.autograd.grad(gx.square().sum(), [xx, ww])
+    for a, r, name in zip(r1(y, x, w), r1(yr, xr, wr), 'xw'):
+        assert_close(a, r, atol=1e-4, rtol=1e-4, what='R1 d' + name)
+
+
+@pytest.mark.parametrize('n,cin,cout,h', [(3, 64, 128, 16), (2, 256, 512, 32), (2, 3, 64, 32), (1, 130, 70, 9), (2, 128, 256, 64), (2, 512, 512, 16), (2, 48, 128, 16)])
 def test_gemm_conv1x1(n, cin, cout, h):
     g = torch.Generator().manual_seed(n + cin)
     x = torch.randn([n, cin, h, h], generator=g).to(DEV).requires_grad_(True)

@@ -169,17 +169,18 @@ def bench_gemm(N, reps):
     for label, fn, mk, flops in (
         ('D b64 skip 1x1 [N,256,32,32]x[512,256]', lambda x, w: gemm.conv1x1(x, w), lambda: (torch.randn([N, 256, 32, 32], device=dev), torch.randn([512, 256, 1, 1], device=dev)), 2.0 * N * 32 * 32 * 256 * 512),
         ('D b128 skip 1x1 [N,128,64,64]x[256,128]', lambda x, w: gemm.conv1x1(x, w), lambda: (torch.randn([N, 128, 64, 64], device=dev), torch.randn([256, 128, 1, 1], device=dev)), 2.0 * N * 64 * 64 * 128 * 256),
+        ('D b32 skip 1x1 [N,512,16,16]x[512,512]', lambda x, w: gemm.conv1x1(x, w), lambda: (torch.randn([N, 512, 16, 16], device=dev), torch.randn([512, 512, 1, 1], device=dev)), 2.0 * N * 16 * 16 * 512 * 512),
         ('FC affine [N,512]x[512,512]', lambda x, w: gemm.linear(x, w), lambda: (torch.randn([N, 512], device=dev), torch.randn([512, 512], device=dev)), 2.0 * N * 512 * 512),
         ('FC epilogue [N,8192]x[512,8192]', lambda x, w: gemm.linear(x, w), lambda: (torch.randn([N, 8192], device=dev), torch.randn([512, 8192], device=dev)), 2.0 * N * 8192 * 512),
         ('square 4096^3', lambda x, w: gemm.linear(x, w), lambda: (torch.randn([4096, 4096], device=dev), torch.randn([4096, 4096], device=dev)), 2.0 * 4096 ** 3),
     ):
-        med, best = time_call(fn, mk, reps)
+        med, best = time_call(fn, mk, reps, bytes_per_call=200e6, native='gemm')
         args = mk()
         if args[1].ndim == 4:
             tfn = lambda x, w: torch.nn.functional.conv2d(x, w)  # noqa: E731
         else:
             tfn = lambda x, w: x @ w.t()  # noqa: E731
-        tmed, _ = time_call(tfn, mk, reps)
+        tmed, _ = time_call(tfn, mk, reps, bytes_per_call=200e6)
         rows.append(dict(kernel='gemm_f32_mfma', call=label, flops=flops, ms=med, ms_min=best, TFLOPs=flops / med / 1e9, frac_of_f32_mfma_peak=flops / (med * 1e-3) / F32_MFMA_PEAK,
                          torch_ms=tmed, torch_TFLOPs=flops / tmed / 1e9))
     return rows
