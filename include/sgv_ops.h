@@ -28,6 +28,7 @@
  *   sgv_pointwise_small / sgv_pointwise_outer
  *                      <- the 1x1 `conv2d` of ToRGBLayer (networks.py:148-163, C_out = 3) and of the discriminator's
  *                          `fromrgb` layer (networks.py:447, C_in = 3) and their gradients, conv2d_resample.py:40-54
+ *   sgv_conv3x3_wrw    <- `Conv2dGradWeight` of conv2d_gradfix.py:140-170 (cudnn_convolution_backward_weight) for 3x3 stride-1 layers
  *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail
  *                          src/training/motion.py:201-212
  *   sgv_gemm_f32       <- `torch.addmm` / `matmul` of FullyConnectedLayer and the dense 1x1
@@ -176,6 +177,24 @@ int sgv_pointwise_outer(const void* a_few, const void* b_many, float* out, int32
                         int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Weight gradient of a 3x3 / stride 1 / pad 1 convolution on dense NCHW tensors:
+ *   dw[o,i,ky,kx] = sum_{n,y,x} dy[n,o,y,x] * x[n,i,y+ky-1,x+kx-1]          dw: [c_out, c_in, 3, 3] fp32 (overwritten)
+ * terms = 3: fp32 emulated on the bf16 matrix pipe with hi/lo splitting (bf16x3, ~2^-17 relative per product, fp32
+ * accumulation); terms = 1: plain bf16 products.  sgv_conv3x3_wrw_supported() tells whether a shape/dtype is served
+ * (fp32, channels % 64 == 0, w % 32 == 0, h <= 32 or h % 32 == 0); everything else stays with the vendor library.
+ */
+typedef struct sgv_conv_wrw_params {
+    const void* dy; /* [n, c_out, h, w] */
+    const void* x;  /* [n, c_in, h, w] */
+    float* dw;
+    int32_t n, c_out, c_in, h, w;
+    int32_t terms;
+} sgv_conv_wrw_params;
+
+int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* stream);
+int sgv_conv3x3_wrw_supported(int32_t n, int32_t c_out, int32_t c_in, int32_t h, int32_t w, int dtype);
+
+/* ---------------------------------------------------------------------------------------
  * AlignedTimeEncoder element-wise tail (motion.py:201-212), fp32:
  *   raw(tau) = freqs[j]*periods[r,j]*tau + phases[r,j]*phase_scales[j]
  *   pos(tau) = [sin raw(tau) | cos raw(tau)]                       (2*nf wide)
@@ -240,7 +259,8 @@ enum sgv_kernel_family {
     SGV_K_GEMM = 5,
     SGV_K_UPFIRDN2D_LANES = 6,
     SGV_K_POINTWISE = 7,
-    SGV_K_COUNT = 8
+    SGV_K_CONV_WRW = 8,
+    SGV_K_COUNT = 9
 };
 typedef struct sgv_prof_entry {
     int64_t launches;

@@ -1,0 +1,53 @@
+// C ABI entry of the 3x3 / stride-1 / pad-1 convolution weight gradient (kernel: wrw_kernel.h).
+//
+// Replaces, for the shapes it supports, the `Conv2dGradWeight` node of the reference's conv2d_gradfix
+// (src/torch_utils/ops/conv2d_gradfix.py:140-170: `torch._C._jit_get_operation('aten::cudnn_convolution_backward_weight')`).
+
+#include "sgv_common.h"
+#include "wrw_kernel.h"
+
+#include <algorithm>
+
+using namespace sgv_wrw;
+
+namespace {
+
+bool supported(int n, int o, int i, int h, int w, int dtype) {
+    return dtype == SGV_F32 && n >= 1 && o >= TO && i >= TI && o % TO == 0 && i % TI == 0 && w >= SEG && w % SEG == 0 && h >= 1 &&
+           (h <= 32 || h % 32 == 0) && (int64_t)n * std::max(o, i) * h * w <= INT32_MAX;
+}
+
+}  // namespace
+
+extern "C" int sgv_conv3x3_wrw_supported(int32_t n, int32_t c_out, int32_t c_in, int32_t h, int32_t w, int dtype) {
+    return supported(n, c_out, c_in, h, w, dtype) ? 1 : 0;
+}
+
+extern "C" int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* stream_) {
+    if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: params is NULL");
+    if (!p->dy || !p->x || !p->dw) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: NULL pointer");
+    if (!supported(p->n, p->c_out, p->c_in, p->h, p->w, dtype))
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw: needs fp32, channels %% 64 == 0, W %% 32 == 0, H <= 32 or H %% 32 == 0 (got n=%d o=%d i=%d h=%d w=%d dtype=%d)",
+                        p->n, p->c_out, p->c_in, p->h, p->w, dtype);
+    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms must be 1 (bf16 products) or 3 (bf16x3 fp32 emulation)");
+    if ((((uintptr_t)p->dy) | ((uintptr_t)p->x)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: dy and x must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    wrw_params kp{};
+    kp.dy = (const float*)p->dy; kp.x = (const float*)p->x; kp.dw = p->dw;
+    kp.n = p->n; kp.o = p->c_out; kp.i = p->c_in; kp.h = p->h; kp.w = p->w;
+    kp.rows = std::min(p->h, 32);
+    kp.tiles_i = p->c_in / TI;
+    kp.units = p->n * (p->w / SEG) * (p->h / kp.rows);
+    const int tiles = (p->c_out / TO) * kp.tiles_i;
+    // One workgroup per CU (profiles/r01_wrw_lab_v1.log: 256 persistent workgroups beat 512), spread over the output tiles.
+    kp.splits = std::max(1, std::min(kp.units, 256 / std::max(1, std::min(tiles, 256))));
+    const size_t dw_bytes = (size_t)p->c_out * p->c_in * 9 * sizeof(float);
+    hipError_t e = hipMemsetAsync(p->dw, 0, dw_bytes, stream);
+    if (e != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    const double elems = (double)p->n * p->h * p->w;
+    sgv_launch_scope scope(SGV_K_CONV_WRW, stream, 4.0 * elems * (p->c_out + p->c_in) + dw_bytes, 2.0 * elems * p->c_out * (double)p->c_in * 9);
+    dim3 grid((unsigned)tiles, (unsigned)kp.splits);
+    if (p->terms == 1) hipLaunchKernelGGL(wrw3x3_kernel<1>, grid, dim3(256), 0, stream, kp);
+    else hipLaunchKernelGGL(wrw3x3_kernel<3>, grid, dim3(256), 0, stream, kp);
+    return sgv_check_launch("wrw3x3_kernel");
+}

@@ -1,0 +1,239 @@
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on NCHW fp32 tensors, on the gfx950 matrix cores:
+//
+//     dw[o,i,ky,kx] = sum_{n,y,x} dy[n,o,y,x] * x[n,i,y+ky-1,x+kx-1]
+//
+// Reference: the weight gradient of the `conv2d` calls of SynthesisLayer / Conv2dLayer (src/training/networks.py:58-62,
+// layers.py:188-192 through conv2d_resample.py:40-54 and conv2d_gradfix.py:112-170 `Conv2dGradWeight`), which the reference
+// hands to cuDNN.  On gfx950 MIOpen runs it as an NHWC implicit GEMM between three layout transposes (profiles/
+// r01_bench_step_kernel_stats_v2.csv: 16 % + 5 % of the train step).  NCHW is the natural layout for this contraction: the
+// reduction index (pixels) is the contiguous one for BOTH operands, which is exactly what an MFMA wants per lane.
+//
+// Arithmetic: fp32 emulated on the bf16 matrix pipe ("bf16x3"): every fp32 value is split v = hi + lo (hi = RNE bf16(v),
+// lo = RNE bf16(v - hi)), and a*b ~= a_lo*b_hi + a_hi*b_lo + a_hi*b_hi with fp32 accumulation in the MFMA.  The dropped terms
+// are <= 2^-16 relative per product (measured against fp64 in tests/test_conv_wrw_gpu.py beside MIOpen's own fp32 error);
+// v_mfma_f32_32x32x16_bf16 runs at 16x the rate of the fp32 MFMA, so three of them are still 5.3x faster and the kernel is
+// bounded by LDS / HBM rather than by the matrix pipe.  TERMS = 1 gives the plain bf16 product.
+//
+// Work decomposition.  Output tile per workgroup: 64 o x 64 i x 9 taps (4 waves as 2x2, each 32 o x 32 i x 9 = nine 32x32
+// accumulators = 144 registers).  The reduction (n, y, x) is cut into units of (one sample, one 32-pixel column segment,
+// ROWS consecutive rows); a persistent grid of tiles x splits workgroups walks the units, keeps its accumulators in
+// registers throughout and adds them to dw with one atomicAdd per element at the very end.
+// Per row step (K = 32 pixels): dy[64 o][32 px] and ONE new x row [64 i][34 px] (32 + halo) are loaded (16-B loads, every
+// 128-B line fully used), split into hi/lo bf16 and written to LDS; the 3 x rows a step needs live in a 4-slot ring, so x is
+// read from HBM once (+2 halo rows per unit).  The nine taps are nine views of the same LDS rows: ky picks the ring slot,
+// kx = 1 is the aligned 16-B read, kx = 0 / 2 are the same dwords shifted by one bf16 with v_alignbyte_b32.  One barrier per
+// step; global loads for step y+1 are in flight during the 54 MFMAs of step y.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sgv_wrw {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TO = 64, TI = 64;   // output tile (o x i) per workgroup
+constexpr int SEG = 32;           // pixels per row step
+constexpr int RS = 40;            // LDS row stride in bf16 (80 B = 5 x 16 B: consecutive rows land in distinct 16-B bank groups)
+constexpr int XROW0 = 8;          // LDS position of the segment's first pixel inside an x row (left halo at 7, right halo at 40)
+constexpr int XS_SLOT = TI * RS + 8;
+
+struct wrw_params {
+    const float* dy;   // [n, o, h, w]
+    const float* x;    // [n, i, h, w]
+    float* dw;         // [o, i, 3, 3], accumulated with atomics
+    int n, o, i, h, w;
+    int rows;          // rows per unit
+    int tiles_i;       // i / 64
+    int splits;        // workgroups per output tile
+    int units;         // n * (w / 32) * (h / rows)
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
+}
+
+// 8 fp32 -> 8 bf16 hi (4 dwords) + 8 bf16 lo.
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const unsigned h = pack_bf16(v[2 * k], v[2 * k + 1]);
+        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        hi[k] = h;
+        lo[k] = pack_bf16(v[2 * k] - h0, v[2 * k + 1] - h1);
+    }
+}
+
+struct row_regs {
+    float main[8];   // 8 consecutive pixels of row (t / 4), starting at 8 * (t % 4)
+    float halo;      // threads < 128: column x0 - 1 (even t) or x0 + 32 (odd t) of row t / 2
+};
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 2) void wrw3x3_kernel(wrw_params p) {
+    // [hi/lo][ring slot][i][RS] and [hi/lo][buffer][o][RS]
+    __shared__ __attribute__((aligned(16))) unsigned short xs[2][4][XS_SLOT];
+    __shared__ __attribute__((aligned(16))) unsigned short ds[2][2][TO * RS];
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wo = (wave >> 1) * 32, wi = (wave & 1) * 32;
+    const int r32 = lane & 31, g = lane >> 5;
+
+    const int tile = blockIdx.x;
+    const int o0 = (tile / p.tiles_i) * TO, i0 = (tile % p.tiles_i) * TI;
+    const int segs = p.w / SEG, rblocks = p.h / p.rows;
+    const size_t plane = (size_t)p.h * p.w;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[k][e] = 0.f;
+
+    const int lr = t >> 2, lq = (t & 3) * 8;   // loader role: row (channel) and first pixel
+    const int hr = t >> 1, hside = t & 1;      // halo loader role (t < 128)
+
+    for (int u = blockIdx.y; u < p.units; u += p.splits) {
+        const int rb = u % rblocks, sg = (u / rblocks) % segs, n = u / (rblocks * segs);
+        const int y0 = rb * p.rows, x0 = sg * SEG;
+        const float* dyb = p.dy + ((size_t)n * p.o + o0) * plane + x0;
+        const float* xb = p.x + ((size_t)n * p.i + i0) * plane + x0;
+
+        auto load_x = [&](int row, row_regs& r) {
+            if (row >= 0 && row < p.h) {
+                const float* q = xb + (size_t)lr * plane + (size_t)row * p.w + lq;
+                const f32x4 a = *(const f32x4*)q, b = *(const f32x4*)(q + 4);
+#pragma unroll
+                for (int k = 0; k < 4; k++) { r.main[k] = a[k]; r.main[4 + k] = b[k]; }
+                r.halo = 0.f;
+                if (t < 128) {
+                    const int col = hside ? x0 + SEG : x0 - 1;
+                    if (col >= 0 && col < p.w) r.halo = xb[(size_t)hr * plane + (size_t)row * p.w + (col - x0)];
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) r.main[k] = 0.f;
+                r.halo = 0.f;
+            }
+        };
+        auto store_x = [&](int row, const row_regs& r) {
+            const int slot = (row + 1) & 3;
+            u32x4 hi, lo;
+            split8(r.main, hi, lo);
+            *(u32x4*)&xs[0][slot][lr * RS + XROW0 + lq] = hi;
+            *(u32x4*)&xs[1][slot][lr * RS + XROW0 + lq] = lo;
+            if (t < 128) {
+                const unsigned h = pack_bf16(r.halo, 0.f);
+                const float hf = __builtin_bit_cast(float, h << 16);
+                const unsigned l = pack_bf16(r.halo - hf, 0.f);
+                const int pos = hr * RS + (hside ? XROW0 + SEG : XROW0 - 1);
+                xs[0][slot][pos] = (unsigned short)h;
+                xs[1][slot][pos] = (unsigned short)l;
+            }
+        };
+        auto load_dy = [&](int row, float* v) {
+            const float* q = dyb + (size_t)lr * plane + (size_t)row * p.w + lq;
+            const f32x4 a = *(const f32x4*)q, b = *(const f32x4*)(q + 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = a[k]; v[4 + k] = b[k]; }
+        };
+        auto store_dy = [&](int row, const float* v) {
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            *(u32x4*)&ds[0][row & 1][lr * RS + lq] = hi;
+            *(u32x4*)&ds[1][row & 1][lr * RS + lq] = lo;
+        };
+
+        // Prologue: rows y0-1, y0, y0+1 of x and row y0 of dy (all loads in flight together).
+        {
+            row_regs ra, rb_, rc;
+            float dv[8];
+            load_x(y0 - 1, ra);
+            load_x(y0, rb_);
+            load_x(y0 + 1, rc);
+            load_dy(y0, dv);
+            __syncthreads();   // the previous unit's last step has been consumed by every wave
+            store_x(y0 - 1, ra);
+            store_x(y0, rb_);
+            store_x(y0 + 1, rc);
+            store_dy(y0, dv);
+            __syncthreads();
+        }
+
+        for (int y = y0; y < y0 + p.rows; y++) {
+            const bool more = y + 1 < y0 + p.rows;
+            row_regs rn;
+            float dn[8];
+            if (more) {   // lands during the MFMAs below
+                load_x(y + 2, rn);
+                load_dy(y + 1, dn);
+            }
+
+            const int buf = y & 1;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int pa = (wo + r32) * RS + 16 * c + 8 * g;
+                const u32x4 a_hi = *(const u32x4*)&ds[0][buf][pa];
+                u32x4 a_lo;
+                if (TERMS > 1) a_lo = *(const u32x4*)&ds[1][buf][pa];
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++) {
+                    const int slot = (y + ky) & 3;   // ring slot of row y + ky - 1
+                    const int pb = (wi + r32) * RS + XROW0 + 16 * c + 8 * g;
+                    u32x4 b[2][3];   // [hi/lo][kx]
+#pragma unroll
+                    for (int hl = 0; hl < (TERMS > 1 ? 2 : 1); hl++) {
+                        const u32x4 d = *(const u32x4*)&xs[hl][slot][pb];
+                        const unsigned dm = *(const unsigned*)&xs[hl][slot][pb - 2];
+                        const unsigned da = *(const unsigned*)&xs[hl][slot][pb + 8];
+                        const unsigned a01 = __builtin_amdgcn_alignbyte(d[1], d[0], 2), a12 = __builtin_amdgcn_alignbyte(d[2], d[1], 2),
+                                       a23 = __builtin_amdgcn_alignbyte(d[3], d[2], 2);
+                        b[hl][0] = u32x4{__builtin_amdgcn_alignbyte(d[0], dm, 2), a01, a12, a23};
+                        b[hl][1] = d;
+                        b[hl][2] = u32x4{a01, a12, a23, __builtin_amdgcn_alignbyte(da, d[3], 2)};
+                    }
+                    // small terms first; consecutive MFMAs target different accumulators
+                    if (TERMS > 1) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lo), __builtin_bit_cast(bf16x8, b[0][kx]),
+                                                                                       acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, b[1][kx]),
+                                                                                       acc[ky * 3 + kx], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++)
+                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, b[0][kx]),
+                                                                                   acc[ky * 3 + kx], 0, 0, 0);
+                }
+            }
+
+            if (more) {
+                store_x(y + 2, rn);     // slot of row y-2: its last readers (step y-1) are behind the previous barrier
+                store_dy(y + 1, dn);
+            }
+            __syncthreads();
+        }
+    }
+
+    // Flush.  C layout of the 32x32 MFMA: col (i) = lane & 31, row (o) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int o = o0 + wo + (e & 3) + 8 * (e >> 2) + 4 * g;
+            const int i = i0 + wi + r32;
+            atomicAdd(p.dw + ((size_t)o * p.i + i) * 9 + k, acc[k][e]);
+        }
+}
+
+}  // namespace sgv_wrw

@@ -142,7 +142,7 @@ def native_loaded():
 c_void_p, c_int, c_int32, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 SGV_F32, SGV_F16, SGV_BF16, SGV_F64 = 0, 1, 2, 3
-SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise']
+SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw']
 
 
 class Upfirdn2dParams(ctypes.Structure):
@@ -177,6 +177,11 @@ class PointwiseParams(ctypes.Structure):
                 ('w_stride_n', c_int64), ('kind', c_int32)]
 
 
+class ConvWrwParams(ctypes.Structure):
+    _fields_ = [('dy', c_void_p), ('x', c_void_p), ('dw', c_void_p), ('n', c_int32), ('c_out', c_int32), ('c_in', c_int32), ('h', c_int32), ('w', c_int32),
+                ('terms', c_int32)]
+
+
 class TimeEncodeParams(ctypes.Structure):
     _fields_ = [(name, c_void_p) for name in
                 ['periods', 'phases', 'al', 'ar', 'freqs', 'phase_scales', 't', 't_left', 't_right', 'alpha', 'out']] + \
@@ -209,6 +214,8 @@ ABI_SYMBOLS = {
     'sgv_scale_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_pointwise_small': (c_int, [ctypes.POINTER(PointwiseParams), c_int, c_void_p]),
     'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'sgv_conv3x3_wrw': (c_int, [ctypes.POINTER(ConvWrwParams), c_int, c_void_p]),
+    'sgv_conv3x3_wrw_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_time_encode': (c_int, [ctypes.POINTER(TimeEncodeParams), c_void_p]),
     'sgv_gemm_f32': (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
     'sgv_prof_enable': (c_int, [c_int32]),

@@ -20,8 +20,11 @@ make any order available, and ``no_weight_gradients()`` really skips the weight-
 """
 
 import contextlib
+import os
 
 import torch
+
+from .. import custom_ops
 
 enabled = True                     # False -> plain torch.nn.functional calls
 weight_gradients_disabled = False  # set inside no_weight_gradients()
@@ -104,6 +107,35 @@ class _Conv(torch.autograd.Function):
         return dx, dw, db, None
 
 
+# 3x3 / stride 1 / pad 1 weight gradients on NCHW fp32 run on the bf16 matrix pipe with fp32 emulation (csrc/wrw_kernel.h):
+# 1.5 ms where MIOpen's NHWC implicit GEMM + its three layout transposes take ~6 ms.  wrw_terms = 3 -> bf16x3 (|rel err| ~ 4e-6
+# of the result's scale, tests/test_conv_wrw_gpu.py), 1 -> plain bf16 products, 0 -> always the vendor library.
+native_wrw_terms = int(os.environ.get('SGV_WRW_TERMS', '3'))
+
+
+def _native_wrw_ok(dy, x, cfg, w_shape):
+    transposed, stride, padding, output_padding, dilation, groups = cfg
+    if native_wrw_terms not in (1, 3) or transposed or groups != 1 or stride != (1, 1) or padding != (1, 1) or dilation != (1, 1):
+        return False
+    if tuple(w_shape[2:]) != (3, 3) or not (dy.is_cuda and x.is_cuda) or dy.dtype != torch.float32 or x.dtype != torch.float32:
+        return False
+    if dy.shape[2:] != x.shape[2:]:
+        return False
+    n, ci, h, w = x.shape
+    return bool(custom_ops.get_native().sgv_conv3x3_wrw_supported(n, w_shape[0], ci, h, w, 0))
+
+
+def _native_wrw(dy, x, w_shape):
+    lib = custom_ops.get_native()
+    dyc, xc = dy.contiguous(), x.contiguous()
+    n, ci, h, w = xc.shape
+    dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, w_shape[0], ci, h, w, native_wrw_terms)
+    with custom_ops.device_guard(xc):
+        custom_ops.check(lib.sgv_conv3x3_wrw(p, 0, custom_ops.raw_stream(xc)), lib)
+    return dw
+
+
 class _ConvGradWeight(torch.autograd.Function):
     """dw = d<dy, conv(x, w)>/dw, as one backward-weight convolution; bilinear in (dy, x), so its own
     derivatives are again plain convolutions."""
@@ -113,6 +145,8 @@ class _ConvGradWeight(torch.autograd.Function):
         transposed, stride, padding, output_padding, dilation, groups = cfg
         ctx.cfg = cfg
         ctx.save_for_backward(dy, x)
+        if _native_wrw_ok(dy, x, cfg, w_shape):
+            return _native_wrw(dy, x, w_shape)
         w_like = x.new_empty(w_shape)  # only its shape/dtype are read when output_mask selects the weight gradient
         _, dw, _ = torch.ops.aten.convolution_backward(dy, x, w_like, None, stride, padding, dilation, transposed, output_padding, groups,
                                                        [False, True, False])

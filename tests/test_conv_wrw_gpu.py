@@ -1,0 +1,100 @@
+"""3x3 convolution weight gradient on the bf16 matrix pipe with fp32 emulation (csrc/wrw_kernel.h) against fp64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stylegan_v_amd.torch_utils import custom_ops
+from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _ref_dw(dy, x):
+    """fp64 on the host: dw[o,i,ky,kx] = sum dy[n,o,y,x] x[n,i,y+ky-1,x+kx-1]."""
+    xd = x.double().cpu().requires_grad_(False)
+    w = torch.zeros([dy.shape[1], x.shape[1], 3, 3], dtype=torch.float64, requires_grad=True)
+    y = F.conv2d(xd, w, padding=1)
+    return torch.autograd.grad(y, w, dy.double().cpu())[0]
+
+
+def _native(dy, x, terms):
+    old = conv2d_gradfix.native_wrw_terms
+    conv2d_gradfix.native_wrw_terms = terms
+    try:
+        assert conv2d_gradfix._native_wrw_ok(dy, x, (False, (1, 1), (1, 1), (0, 0), (1, 1), 1), (dy.shape[1], x.shape[1], 3, 3))
+        return conv2d_gradfix._native_wrw(dy, x, (dy.shape[1], x.shape[1], 3, 3))
+    finally:
+        conv2d_gradfix.native_wrw_terms = old
+
+
+def _rel(a, ref):
+    a, ref = a.double().cpu(), ref.double().cpu()
+    return ((a - ref).norm() / ref.norm()).item(), ((a - ref).abs().max() / ref.abs().max()).item()
+
+
+@pytest.mark.parametrize('n,o,i,h,w', [(2, 64, 64, 32, 32), (1, 64, 128, 64, 64), (2, 128, 64, 64, 96), (3, 64, 64, 8, 32), (1, 192, 64, 96, 32), (2, 64, 64, 1, 32)])
+def test_wrw_bf16x3_matches_fp64_as_well_as_the_vendor_fp32_kernel(n, o, i, h, w):
+    g = torch.Generator().manual_seed(n * 100 + o + i + h)
+    dy = torch.randn([n, o, h, w], generator=g).to(DEV)
+    x = (torch.randn([n, i, h, w], generator=g) * 1.5 + 0.25).to(DEV)
+    ref = _ref_dw(dy, x)
+    got = _native(dy, x, 3)
+    assert got.shape == ref.shape and got.dtype == torch.float32
+    l2, mx = _rel(got, ref)
+    # vendor fp32 kernel on the same inputs, for scale
+    w_like = x.new_empty(ref.shape)
+    _, dw_lib, _ = torch.ops.aten.convolution_backward(dy, x, w_like, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
+    l2_lib, mx_lib = _rel(dw_lib, ref)
+    print(f'bf16x3 rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
+    assert l2 < 1e-5 and mx < 1e-5, (l2, mx, l2_lib, mx_lib)   # north_star tolerance is 1e-3; fp32 round-off of this sum is ~1e-6
+    # asymmetric structure check: exact small integers survive the split exactly -> bit-exact result
+    dyi = torch.randint(-3, 4, dy.shape, generator=g).float().to(DEV)
+    xi = torch.randint(-3, 4, x.shape, generator=g).float().to(DEV)
+    assert torch.equal(_native(dyi, xi, 3).cpu().double(), _ref_dw(dyi, xi))
+
+
+def test_wrw_single_term_is_plain_bf16():
+    g = torch.Generator().manual_seed(1)
+    dy, x = torch.randn([2, 64, 32, 32], generator=g).to(DEV), torch.randn([2, 64, 32, 32], generator=g).to(DEV)
+    ref = _ref_dw(dy, x)
+    l2, _ = _rel(_native(dy, x, 1), ref)
+    assert 1e-4 < l2 < 1e-2
+    # exactly the product of bf16-rounded operands
+    l2b, _ = _rel(_native(dy, x, 1), _ref_dw(dy.bfloat16().float(), x.bfloat16().float()))
+    assert l2b < 1e-6
+
+
+def test_conv2d_gradfix_uses_it_and_stays_twice_differentiable():
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn([2, 64, 32, 32], generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn([64, 64, 3, 3], generator=g) / 24).to(DEV).requires_grad_(True)
+    custom_ops.prof_enable(64)
+    y = conv2d_gradfix.conv2d(x, w, padding=1)
+    gw, = torch.autograd.grad(y.sin().sum(), [w], create_graph=True)
+    custom_ops.prof_disable()
+    assert custom_ops.prof_collect()['conv_wrw']['launches'] == 1
+    xr, wr = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+    gwr, = torch.autograd.grad(F.conv2d(xr, wr, padding=1).sin().sum(), [wr], create_graph=True)
+    assert_close(gw, gwr, atol=2e-5 * gwr.abs().max().item(), rtol=1e-5, what='dw')
+    # second order: d/dx and d/dw of |dw|^2 (goes through _ConvGradWeight.backward -> ordinary convolutions)
+    g2 = torch.autograd.grad(gw.square().sum(), [x, w])
+    g2r = torch.autograd.grad(gwr.square().sum(), [xr, wr])
+    for a, r, name in zip(g2, g2r, 'xw'):
+        assert_close(a, r, atol=1e-4 * r.abs().max().item(), rtol=1e-3, what='d2 ' + name)
+
+
+def test_unsupported_shapes_fall_back_to_the_vendor_library():
+    lib = custom_ops.get_native()
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 16, 16, 0) == 0    # W < 32
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 3, 32, 32, 0) == 0     # fromRGB-like channel counts
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 48, 32, 0) == 0    # H > 32 and not a multiple of 32
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 32, 32, 1) == 0    # fp16
+    x = torch.randn([2, 64, 16, 16], device=DEV, requires_grad=True)
+    w = torch.randn([64, 64, 3, 3], device=DEV, requires_grad=True)
+    before = custom_ops.launch_count()
+    torch.autograd.grad(conv2d_gradfix.conv2d(x, w, padding=1).sum(), [w])
+    assert custom_ops.launch_count() == before
+    p = custom_ops.ConvWrwParams(x.data_ptr(), x.data_ptr(), w.data_ptr(), 2, 64, 64, 16, 16, 3)
+    assert lib.sgv_conv3x3_wrw(p, 0, None) == -3 and b'W % 32' in lib.sgv_last_error()

@@ -1,0 +1,107 @@
+// Lab for the 3x3 weight-gradient kernel (stylegan-v_amd/csrc/wrw_kernel.h): correctness against a naive fp32 kernel + fp64 host
+// check on a small case, then timing on the training shapes.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -Istylegan-v_amd/csrc tools/wrw_lab.hip -o tools/wrw_lab && tools/wrw_lab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+#include "wrw_kernel.h"
+
+using namespace sgv_wrw;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void fill(float* p, size_t n, unsigned seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16; p[i] = ((h & 0xffffff) / 16777216.f - 0.5f) * 2.f; }
+}
+
+// one workgroup per (o, i): fp64 accumulation of all nine taps
+__global__ void naive_wrw(const float* dy, const float* x, double* dw, int n, int o_, int i_, int h, int w) {
+    const int o = blockIdx.x / i_, i = blockIdx.x % i_;
+    double s[9] = {0};
+    for (size_t q = threadIdx.x; q < (size_t)n * h * w; q += blockDim.x) {
+        const int xx = q % w, yy = (q / w) % h, nn = q / ((size_t)w * h);
+        const double d = dy[(((size_t)nn * o_ + o) * h + yy) * w + xx];
+        for (int ky = 0; ky < 3; ky++) for (int kx = 0; kx < 3; kx++) {
+            const int sy = yy + ky - 1, sx = xx + kx - 1;
+            if (sy >= 0 && sy < h && sx >= 0 && sx < w) s[ky * 3 + kx] += d * x[(((size_t)nn * i_ + i) * h + sy) * w + sx];
+        }
+    }
+    __shared__ double red[256];
+    for (int k = 0; k < 9; k++) {
+        red[threadIdx.x] = s[k]; __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+        if (threadIdx.x == 0) dw[(size_t)blockIdx.x * 9 + k] = red[0];
+        __syncthreads();
+    }
+}
+
+static wrw_params make(const float* dy, const float* x, float* dw, int n, int o, int i, int h, int w, int rows, int wgs) {
+    wrw_params p{};
+    p.dy = dy; p.x = x; p.dw = dw; p.n = n; p.o = o; p.i = i; p.h = h; p.w = w;
+    p.rows = rows < h ? rows : h;
+    p.tiles_i = i / TI;
+    p.units = n * (w / SEG) * (h / p.rows);
+    const int tiles = (o / TO) * (i / TI);
+    int splits = wgs / tiles; if (splits < 1) splits = 1; if (splits > p.units) splits = p.units;
+    p.splits = splits;
+    return p;
+}
+
+template <int TERMS> static void launch(const wrw_params& p) {
+    dim3 grid((p.o / TO) * p.tiles_i, p.splits);
+    hipLaunchKernelGGL(wrw3x3_kernel<TERMS>, grid, dim3(256), 0, 0, p);
+}
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 5;
+    // ---- correctness ----
+    {
+        const int n = 3, o = 64, i = 128, h = 64, w = 64;
+        const size_t ndy = (size_t)n * o * h * w, nx = (size_t)n * i * h * w, ndw = (size_t)o * i * 9;
+        float *dy, *x, *dw; double* ref;
+        CK(hipMalloc(&dy, ndy * 4)); CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&dw, ndw * 4)); CK(hipMalloc(&ref, ndw * 8));
+        fill<<<(ndy + 255) / 256, 256>>>(dy, ndy, 11u); fill<<<(nx + 255) / 256, 256>>>(x, nx, 23u);
+        naive_wrw<<<o * i, 256>>>(dy, x, ref, n, o, i, h, w);
+        std::vector<double> r(ndw); std::vector<float> gpu(ndw);
+        CK(hipMemcpy(r.data(), ref, ndw * 8, hipMemcpyDeviceToHost));
+        for (int terms = 1; terms <= 3; terms += 2) for (int rows : {64, 32, 16}) {
+            CK(hipMemset(dw, 0, ndw * 4));
+            wrw_params p = make(dy, x, dw, n, o, i, h, w, rows, 8);
+            if (terms == 1) launch<1>(p); else launch<3>(p);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(gpu.data(), dw, ndw * 4, hipMemcpyDeviceToHost));
+            double maxerr = 0, maxref = 0, sq = 0, sqr = 0; size_t worst = 0;
+            for (size_t k = 0; k < ndw; k++) { double e = fabs(gpu[k] - r[k]); if (e > maxerr) { maxerr = e; worst = k; } if (fabs(r[k]) > maxref) maxref = fabs(r[k]); sq += e * e; sqr += r[k] * r[k]; }
+            printf("check terms=%d rows=%d splits=%d: max abs err %.3e (max |ref| %.3e, rel-L2 %.3e) worst at o=%zu i=%zu tap=%zu gpu=%f ref=%f\n", terms, rows, p.splits,
+                   maxerr, maxref, sqrt(sq / sqr), worst / 9 / i, (worst / 9) % i, worst % 9, gpu[worst], r[worst]);
+        }
+        CK(hipFree(dy)); CK(hipFree(x)); CK(hipFree(dw)); CK(hipFree(ref));
+    }
+    // ---- timing ----
+    struct { const char* name; int n, c, r; } shapes[] = { {"64ch 256^2", 96, 64, 256}, {"128ch 128^2", 96, 128, 128}, {"256ch 64^2", 96, 256, 64}, {"512ch 32^2", 96, 512, 32} };
+    for (auto& s : shapes) {
+        const size_t na = (size_t)s.n * s.c * s.r * s.r, ndw = (size_t)s.c * s.c * 9;
+        float *dy, *x, *dw;
+        CK(hipMalloc(&dy, na * 4)); CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&dw, ndw * 4));
+        fill<<<(na + 255) / 256, 256>>>(dy, na, 5u); fill<<<(na + 255) / 256, 256>>>(x, na, 7u);
+        const double flops = 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9;
+        for (int terms = 1; terms <= 3; terms += 2) for (int rows : {64, 32}) for (int wgs : {512, 256}) {
+            if (rows > s.r) continue;
+            wrw_params p = make(dy, x, dw, s.n, s.c, s.c, s.r, s.r, rows, wgs);
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            CK(hipMemsetAsync(dw, 0, ndw * 4)); if (terms == 1) launch<1>(p); else launch<3>(p);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; r++) { if (terms == 1) launch<1>(p); else launch<3>(p); }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            printf("%-12s terms=%d rows=%2d grid=%3dx%-3d units/wg=%5.1f  %8.3f ms  %7.1f TFLOP/s (fp32-equivalent)  %6.1f GB/s of input\n", s.name, terms, p.rows,
+                   (s.c / TO) * p.tiles_i, p.splits, (double)p.units / p.splits, ms, flops / ms / 1e9, 2.0 * na * 4 / ms / 1e6);
+            fflush(stdout);
+        }
+        CK(hipFree(dy)); CK(hipFree(x)); CK(hipFree(dw));
+    }
+    return 0;
+}
