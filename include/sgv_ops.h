@@ -28,6 +28,7 @@
  *   sgv_pointwise_small / sgv_pointwise_outer
  *                      <- the 1x1 `conv2d` of ToRGBLayer (networks.py:148-163, C_out = 3) and of the discriminator's
  *                          `fromrgb` layer (networks.py:447, C_in = 3) and their gradients, conv2d_resample.py:40-54
+ *   sgv_conv3x3        <- `conv2d` / `conv_transpose2d` of conv2d_gradfix.py:35-43,100-118 for 3x3 stride-1 layers (forward + data gradient)
  *   sgv_conv3x3_wrw    <- `Conv2dGradWeight` of conv2d_gradfix.py:140-170 (cudnn_convolution_backward_weight) for 3x3 stride-1 layers
  *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail
  *                          src/training/motion.py:201-212
@@ -195,6 +196,29 @@ int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* stream);
 int sgv_conv3x3_wrw_supported(int32_t n, int32_t c_out, int32_t c_in, int32_t h, int32_t w, int dtype);
 
 /* ---------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 convolution on dense NCHW tensors, forward and data gradient:
+ *   mode 0:  y[n,m,Y,X] = sum_{k,ky,kx} weight[m][k][ky][kx]     * x[n,k,Y+ky-1,X+kx-1]     weight: [c_out, c_in, 3, 3]
+ *   mode 1:  y[n,m,Y,X] = sum_{k,ky,kx} weight[k][m][2-ky][2-kx] * x[n,k,Y+ky-1,X+kx-1]     weight: [c_in, c_out, 3, 3]
+ *            (= conv_transpose2d(x, weight, stride 1, padding 1): the gradient w.r.t. the input of the mode-0 layer)
+ * fp32 tensors, arithmetic as sgv_conv3x3_wrw (terms = 3: bf16x3 fp32 emulation; 1: bf16 products).  `workspace` is
+ * sgv_conv3x3_workspace_bytes() of device scratch for the re-laid-out weights (owned by the caller, written per call).
+ */
+typedef struct sgv_conv3x3_params {
+    const void* x;        /* [n, c_in, h, w] */
+    const float* weight;  /* fp32, contiguous */
+    void* y;              /* [n, c_out, h, w] */
+    void* workspace;
+    int64_t workspace_bytes;
+    int32_t n, c_in, c_out, h, w;
+    int32_t mode;
+    int32_t terms;
+} sgv_conv3x3_params;
+
+int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream);
+int sgv_conv3x3_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);
+int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out);
+
+/* ---------------------------------------------------------------------------------------
  * AlignedTimeEncoder element-wise tail (motion.py:201-212), fp32:
  *   raw(tau) = freqs[j]*periods[r,j]*tau + phases[r,j]*phase_scales[j]
  *   pos(tau) = [sin raw(tau) | cos raw(tau)]                       (2*nf wide)
@@ -260,7 +284,8 @@ enum sgv_kernel_family {
     SGV_K_UPFIRDN2D_LANES = 6,
     SGV_K_POINTWISE = 7,
     SGV_K_CONV_WRW = 8,
-    SGV_K_COUNT = 9
+    SGV_K_CONV3X3 = 9,
+    SGV_K_COUNT = 10
 };
 typedef struct sgv_prof_entry {
     int64_t launches;

@@ -1,0 +1,74 @@
+// C ABI entry of the 3x3 / stride-1 / pad-1 convolution and its data gradient (kernel: conv3x3_kernel.h).
+//
+// Replaces, for the shapes it supports, `torch.nn.functional.conv2d` / `conv_transpose2d` as called by the reference's
+// conv2d_gradfix (src/torch_utils/ops/conv2d_gradfix.py:35-43, 100-118) for the 3x3 layers of networks.py / layers.py.
+
+#include "sgv_common.h"
+#include "conv3x3_kernel.h"
+
+#include <algorithm>
+#include <mutex>
+
+using namespace sgv_conv;
+
+namespace {
+
+bool supported(int n, int k, int m, int h, int w, int dtype) {
+    return dtype == SGV_F32 && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0 &&
+           (int64_t)n * std::max(k, m) * h * w <= INT32_MAX;
+}
+
+std::once_flag g_attr_once;
+int g_cus = 256;
+hipError_t g_attr_err = hipSuccess;
+
+void init_once() {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    g_attr_err = e;
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
+}
+
+}  // namespace
+
+extern "C" int sgv_conv3x3_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {
+    return supported(n, c_in, c_out, h, w, dtype) ? 1 : 0;
+}
+
+extern "C" int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out) {
+    return (int64_t)c_in * c_out * 9 * 4;   // bf16 hi + lo per weight
+}
+
+extern "C" int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream_) {
+    if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: params is NULL");
+    if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: NULL pointer");
+    if (!supported(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, W %% 32 == 0, H %% 16 == 0 (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
+                        p->n, p->c_in, p->c_out, p->h, p->w, dtype);
+    if (p->mode != 0 && p->mode != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: mode must be 0 (forward) or 1 (data gradient)");
+    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: terms must be 1 or 3");
+    if (p->workspace_bytes < sgv_conv3x3_workspace_bytes(p->c_in, p->c_out)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: workspace is too small");
+    if ((((uintptr_t)p->x) | ((uintptr_t)p->y) | ((uintptr_t)p->workspace)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: x, y and workspace must be 16-byte aligned");
+    std::call_once(g_attr_once, init_once);
+    if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
+    hipStream_t stream = (hipStream_t)stream_;
+
+    const int words = (p->c_out / TM) * (p->c_in / KC) * 9 * 2 * TM;
+    hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
+                       p->terms);
+    int rc = sgv_check_launch("conv3x3_prep_weights");
+    if (rc != SGV_OK) return rc;
+
+    conv_params kp{};
+    kp.x = (const float*)p->x; kp.wprep = (const u32x4*)p->workspace; kp.y = (float*)p->y;
+    kp.n = p->n; kp.k = p->c_in; kp.m = p->c_out; kp.h = p->h; kp.w = p->w;
+    kp.tiles = p->n * (p->h / TROWS) * (p->w / SEG) * (p->c_out / TM);
+    kp.grid = std::min(kp.tiles, g_cus);
+    const double elems = (double)p->n * p->h * p->w;
+    sgv_launch_scope scope(SGV_K_CONV3X3, stream, 4.0 * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9);
+    if (p->terms == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
+    else hipLaunchKernelGGL(conv3x3_kernel<3>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
+    return sgv_check_launch("conv3x3_kernel");
+}

@@ -1,0 +1,283 @@
+// 3x3 / stride 1 / pad 1 convolution (forward, and data gradient with re-indexed weights) on NCHW fp32 tensors, on the gfx950
+// matrix cores with bf16x3 fp32 emulation (see wrw_kernel.h for the arithmetic).
+//
+//     y[n,m,Y,X] = sum_{k,ky,kx} wgt(m,k,ky,kx) * x[n,k,Y+ky-1,X+kx-1]
+//
+// Reference: the `conv2d` of SynthesisLayer / Conv2dLayer (src/training/networks.py:58-62 via conv2d_resample.py:40-54) and its
+// data gradient (conv2d_gradfix.py:100-118 `conv_transpose2d`), cuDNN in the reference, MIOpen's fp32 Winograd here
+// (profiles/r01_bench_step_kernel_stats_v2.csv: 37 % of the train step at ~100 TFLOP/s effective).
+//
+// MFMA mapping (v_mfma_f32_32x32x16_bf16): rows = 32 output channels, columns = 32 consecutive pixels of one image row,
+// k = 16 input channels of one tap.  NCHW makes k the strided index, so the x tile is transposed on its way into LDS: a thread
+// loads 8 channels x 4 pixels (eight 16-B loads; every 128-B line is consumed whole by one instruction) and writes, per pixel,
+// the 8 channels as one 16-B bf16 vector.  LDS layout x: [hi/lo][channel octet][row][pixel][8 ch] -> the B operand of tap
+// (ky,kx) for pixel p is the 16-B word at [row + ky][p + kx]: a conflict-free ds_read_b128, the nine taps are nine addresses.
+// Weights are pre-arranged (prep kernel below) as [m tile][k chunk][hi/lo][tap][octet][64 m][8 k] bf16 and copied verbatim.
+//
+// Workgroup = 4 waves, output tile 64 m x 16 rows x 32 px; a wave owns 4 rows x 64 m = 8 accumulator tiles (128 registers).
+// Per 16-channel chunk a wave issues 9 taps x (4 A reads + 4 x (2 B reads + 6 MFMAs)) = 216 MFMAs; the next chunk's global
+// loads (x and weights) are in flight meanwhile, held in registers, split into hi/lo and written to LDS between two barriers.
+// One workgroup per CU (75 KB LDS, ~300 registers), persistent over (sample, row block, column segment, m tile).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sgv_conv {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TM = 64;            // output channels per workgroup
+constexpr int TROWS = 16;         // output rows per workgroup (4 per wave)
+constexpr int SEG = 32;           // output pixels per row
+constexpr int KC = 16;            // input channels per chunk (= MFMA k)
+constexpr int RIN = TROWS + 2;    // input rows per tile
+constexpr int PIN = SEG + 2;      // input pixels per row
+constexpr int XS_PLANE = RIN * PIN;             // 16-B words per (hi/lo, octet) plane
+constexpr int XS_WORDS = 2 * 2 * XS_PLANE;      // u32x4 words
+constexpr int WS_WORDS = 2 * 9 * 2 * TM;        // [hl][tap][octet][64 m] u32x4 words
+constexpr int LDS_BYTES = (XS_WORDS + WS_WORDS) * 16;
+
+struct conv_params {
+    const float* x;        // [n, k, h, w]
+    const u32x4* wprep;    // [m tiles][k chunks][hl][tap][octet][64][8 bf16]
+    float* y;              // [n, m, h, w]
+    int n, k, m, h, w;
+    int tiles;             // n * (h/16) * (w/32) * (m/64)
+    int grid;              // persistent workgroups
+};
+
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    f32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+
+// 8 channel values of one pixel -> hi and lo bf16x8
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const unsigned h = pack_bf16(v[2 * j], v[2 * j + 1]);
+        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        hi[j] = h;
+        lo[j] = pack_bf16(v[2 * j] - h0, v[2 * j + 1] - h1);
+    }
+}
+
+struct stage_regs {
+    f32x4 xa[8];     // item t:        8 channels x 4 pixels
+    f32x4 xb[8];     // item t + 256 (threads < 32)
+    float xh[8];     // halo item (threads < 72): 8 channels of one (row, side)
+    u32x4 wv[9];     // 9 x 16 B of the 36-KiB weight chunk
+};
+
+struct tile_pos { int n, y0, x0, mt; };
+
+__device__ __forceinline__ tile_pos decode_tile(const conv_params& p, int tile) {
+    const int mts = p.m / TM, segs = p.w / SEG, rbs = p.h / TROWS;
+    tile_pos tp;
+    tp.mt = tile % mts;
+    int r = tile / mts;
+    tp.x0 = (r % segs) * SEG;
+    r /= segs;
+    tp.y0 = (r % rbs) * TROWS;
+    tp.n = r / rbs;
+    return tp;
+}
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    u32x4* xs = lds;                // [hl][octet][row][px]
+    u32x4* ws = lds + XS_WORDS;     // [hl][tap][octet][m]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int l32 = lane & 31, g = lane >> 5;
+    const int chunks = p.k / KC;
+    const size_t plane = (size_t)p.h * p.w;
+
+    // loader roles
+    const int a_oct = t & 1, a_quad = (t >> 1) & 7, a_row = t >> 4;            // item t: rows 0..15
+    const int b_row = 16 + (t >> 4);                                           // item t + 256 (t < 32): rows 16, 17
+    const int h_oct = t & 1, h_side = (t >> 1) & 1, h_row = t >> 2;            // halo item (t < 72)
+
+    auto load_chunk = [&](const tile_pos& tp, int c, stage_regs& s) {
+        const float* xb = p.x + ((size_t)tp.n * p.k + c * KC) * plane + tp.x0;
+        {
+            const int gy = tp.y0 - 1 + a_row;
+            const bool ok = gy >= 0 && gy < p.h;
+            const float* q = xb + (size_t)(8 * a_oct) * plane + (size_t)gy * p.w + 4 * a_quad;
+#pragma unroll
+            for (int j = 0; j < 8; j++) s.xa[j] = ok ? *(const f32x4*)(q + j * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (t < 32) {
+            const int gy = tp.y0 - 1 + b_row;
+            const bool ok = gy < p.h;
+            const float* q = xb + (size_t)(8 * a_oct) * plane + (size_t)gy * p.w + 4 * a_quad;
+#pragma unroll
+            for (int j = 0; j < 8; j++) s.xb[j] = ok ? *(const f32x4*)(q + j * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (t < 72) {
+            const int gy = tp.y0 - 1 + h_row;
+            const int gx = h_side ? tp.x0 + SEG : tp.x0 - 1;
+            const bool ok = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
+            const float* q = xb + (size_t)(8 * h_oct) * plane + (size_t)gy * p.w + (gx - tp.x0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) s.xh[j] = ok ? q[j * plane] : 0.f;
+        }
+        const u32x4* wq = p.wprep + ((size_t)tp.mt * chunks + c) * WS_WORDS + t;
+#pragma unroll
+        for (int j = 0; j < 9; j++) s.wv[j] = wq[j * 256];
+    };
+
+    auto store_chunk = [&](const stage_regs& s) {
+        {
+            const int base = (a_oct * RIN + a_row) * PIN + 1 + 4 * a_quad;
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = s.xa[j][px];
+                u32x4 hi, lo;
+                split8(v, hi, lo);
+                xs[base + px] = hi;
+                if (TERMS > 1) xs[2 * XS_PLANE + base + px] = lo;
+            }
+        }
+        if (t < 32) {
+            const int base = (a_oct * RIN + b_row) * PIN + 1 + 4 * a_quad;
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = s.xb[j][px];
+                u32x4 hi, lo;
+                split8(v, hi, lo);
+                xs[base + px] = hi;
+                if (TERMS > 1) xs[2 * XS_PLANE + base + px] = lo;
+            }
+        }
+        if (t < 72) {
+            u32x4 hi, lo;
+            split8(s.xh, hi, lo);
+            const int pos = (h_oct * RIN + h_row) * PIN + (h_side ? SEG + 1 : 0);
+            xs[pos] = hi;
+            if (TERMS > 1) xs[2 * XS_PLANE + pos] = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) ws[t + j * 256] = s.wv[j];
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[r][hf][e] = 0.f;
+
+    int tile = blockIdx.x;
+    if (tile >= p.tiles) return;
+    tile_pos tp = decode_tile(p, tile);
+    int c = 0;
+    {
+        stage_regs s;
+        load_chunk(tp, 0, s);
+        store_chunk(s);
+        __syncthreads();
+    }
+
+    while (true) {
+        // what comes after (tile, c)
+        int ntile = tile, nc = c + 1;
+        if (nc == chunks) { nc = 0; ntile = tile + p.grid; }
+        const bool more = ntile < p.tiles;
+        tile_pos ntp = tp;
+        if (more && nc == 0) ntp = decode_tile(p, ntile);
+        stage_regs s;
+        if (more) load_chunk(ntp, nc, s);
+
+        // ---- 216 MFMAs on chunk c ----
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+            u32x4 a[2][2];   // [half][hl]
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                a[hf][0] = ws[((0 * 9 + tap) * 2 + g) * TM + hf * 32 + l32];
+                if (TERMS > 1) a[hf][1] = ws[((1 * 9 + tap) * 2 + g) * TM + hf * 32 + l32];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pos = (g * RIN + 4 * wave + r + ky) * PIN + l32 + kx;
+                const u32x4 b_hi = xs[pos];
+                u32x4 b_lo;
+                if (TERMS > 1) b_lo = xs[2 * XS_PLANE + pos];
+                if (TERMS > 1) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++)
+                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][1]), __builtin_bit_cast(bf16x8, b_hi), acc[r][hf], 0, 0, 0);
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++)
+                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_lo), acc[r][hf], 0, 0, 0);
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++)
+                    acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_hi), acc[r][hf], 0, 0, 0);
+            }
+        }
+
+        if (c == chunks - 1) {
+            // C layout: col (pixel) = lane & 31, row (m) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): 128-B contiguous stores
+            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane + (size_t)(tp.y0 + 4 * wave) * p.w + tp.x0 + l32;
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+                        yb[(size_t)m * plane + (size_t)r * p.w] = acc[r][hf][e];
+                        acc[r][hf][e] = 0.f;
+                    }
+        }
+        if (!more) break;
+        __syncthreads();      // every wave is done reading chunk c
+        store_chunk(s);
+        __syncthreads();
+        tile = ntile; c = nc; tp = ntp;
+    }
+}
+
+// Weight re-layout: fp32 -> bf16 hi/lo in [m tile][k chunk][hl][tap][octet][64 m][8 k].
+// mode 0: wgt(m,k,ky,kx) = w[m][k][ky][kx]            (forward;  w is [M, K, 3, 3])
+// mode 1: wgt(m,k,ky,kx) = w[k][m][2-ky][2-kx]        (data gradient of the same layer; w is [K, M, 3, 3])
+__global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x4* out, int m_total, int k_total, int mode, int terms) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;   // one 16-B output word (8 k) of the hi plane
+    const int chunks = k_total / KC;
+    const int total = (m_total / TM) * chunks * 9 * 2 * TM;
+    if (idx >= total) return;
+    int r = idx;
+    const int mi = r % TM; r /= TM;
+    const int oct = r % 2; r /= 2;
+    const int tap = r % 9; r /= 9;
+    const int c = r % chunks;
+    const int mt = r / chunks;
+    const int m = mt * TM + mi, k0 = c * KC + 8 * oct, ky = tap / 3, kx = tap % 3;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        v[j] = mode == 0 ? w[(((size_t)m * k_total + k0 + j) * 3 + ky) * 3 + kx] : w[(((size_t)(k0 + j) * m_total + m) * 3 + (2 - ky)) * 3 + (2 - kx)];
+    u32x4 hi, lo;
+    split8(v, hi, lo);
+    const size_t base = ((size_t)mt * chunks + c) * WS_WORDS;
+    out[base + ((0 * 9 + tap) * 2 + oct) * TM + mi] = hi;
+    if (terms > 1) out[base + ((1 * 9 + tap) * 2 + oct) * TM + mi] = lo;
+}
+
+}  // namespace sgv_conv

@@ -142,7 +142,7 @@ def native_loaded():
 c_void_p, c_int, c_int32, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 SGV_F32, SGV_F16, SGV_BF16, SGV_F64 = 0, 1, 2, 3
-SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw']
+SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw', 'conv3x3']
 
 
 class Upfirdn2dParams(ctypes.Structure):
@@ -182,6 +182,11 @@ class ConvWrwParams(ctypes.Structure):
                 ('terms', c_int32)]
 
 
+class Conv3x3Params(ctypes.Structure):
+    _fields_ = [('x', c_void_p), ('weight', c_void_p), ('y', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('n', c_int32), ('c_in', c_int32),
+                ('c_out', c_int32), ('h', c_int32), ('w', c_int32), ('mode', c_int32), ('terms', c_int32)]
+
+
 class TimeEncodeParams(ctypes.Structure):
     _fields_ = [(name, c_void_p) for name in
                 ['periods', 'phases', 'al', 'ar', 'freqs', 'phase_scales', 't', 't_left', 't_right', 'alpha', 'out']] + \
@@ -214,6 +219,9 @@ ABI_SYMBOLS = {
     'sgv_scale_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_pointwise_small': (c_int, [ctypes.POINTER(PointwiseParams), c_int, c_void_p]),
     'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'sgv_conv3x3': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
+    'sgv_conv3x3_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
+    'sgv_conv3x3_workspace_bytes': (c_int64, [c_int32, c_int32]),
     'sgv_conv3x3_wrw': (c_int, [ctypes.POINTER(ConvWrwParams), c_int, c_void_p]),
     'sgv_conv3x3_wrw_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_time_encode': (c_int, [ctypes.POINTER(TimeEncodeParams), c_void_p]),

@@ -90,6 +90,8 @@ class _Conv(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w)
+        if b is None and _native_conv_ok(x, w, cfg):
+            return _native_conv(x, w, 1 if cfg[0] else 0)
         return _aten_conv(x, w, b, cfg)
 
     @staticmethod
@@ -111,6 +113,35 @@ class _Conv(torch.autograd.Function):
 # 1.5 ms where MIOpen's NHWC implicit GEMM + its three layout transposes take ~6 ms.  wrw_terms = 3 -> bf16x3 (|rel err| ~ 4e-6
 # of the result's scale, tests/test_conv_wrw_gpu.py), 1 -> plain bf16 products, 0 -> always the vendor library.
 native_wrw_terms = int(os.environ.get('SGV_WRW_TERMS', '3'))
+native_conv_terms = int(os.environ.get('SGV_CONV_TERMS', '3'))   # same switch for the forward / data-gradient kernel (csrc/conv3x3_kernel.h)
+
+
+def _native_conv_ok(x, w, cfg):
+    """3x3 / stride 1 / pad 1 forward (cfg[0] False) or data gradient (cfg[0] True: conv_transpose2d) served by csrc/conv3x3_kernel.h."""
+    transposed, stride, padding, output_padding, dilation, groups = cfg
+    if native_conv_terms not in (1, 3) or groups != 1 or stride != (1, 1) or padding != (1, 1) or dilation != (1, 1) or output_padding != (0, 0):
+        return False
+    if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3) or not (x.is_cuda and w.is_cuda) or x.dtype != torch.float32 or w.dtype != torch.float32:
+        return False
+    n, ci, h, wd = x.shape
+    co = w.shape[1] if transposed else w.shape[0]
+    if (w.shape[0] if transposed else w.shape[1]) != ci:
+        return False
+    return bool(custom_ops.get_native().sgv_conv3x3_supported(n, ci, co, h, wd, 0))
+
+
+def _native_conv(x, w, mode):
+    lib = custom_ops.get_native()
+    xc, wc = x.contiguous(), w.contiguous()
+    n, ci, h, wd = xc.shape
+    co = wc.shape[1] if mode else wc.shape[0]
+    y = torch.empty([n, co, h, wd], dtype=torch.float32, device=x.device)
+    ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
+    ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
+    p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, wd, mode, native_conv_terms)
+    with custom_ops.device_guard(xc):
+        custom_ops.check(lib.sgv_conv3x3(p, 0, custom_ops.raw_stream(xc)), lib)
+    return y
 
 
 def _native_wrw_ok(dy, x, cfg, w_shape):

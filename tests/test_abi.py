@@ -65,3 +65,4 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(custom_ops.ProfEntry) == 32
     assert ctypes.sizeof(custom_ops.PointwiseParams) == 56
     assert ctypes.sizeof(custom_ops.ConvWrwParams) == 48
+    assert ctypes.sizeof(custom_ops.Conv3x3Params) == 72

@@ -1,0 +1,80 @@
+"""3x3 stride-1 convolution forward / data gradient on the bf16 matrix pipe with fp32 emulation (csrc/conv3x3_kernel.h) vs fp64."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from stylegan_v_amd.torch_utils import custom_ops
+from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
+from util import assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rel(a, ref):
+    a, ref = a.double().cpu(), ref.double().cpu()
+    return ((a - ref).norm() / ref.norm()).item(), ((a - ref).abs().max() / ref.abs().max()).item()
+
+
+@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (1, 16, 128, 16, 64), (3, 128, 64, 48, 32), (1, 80, 192, 32, 96), (5, 32, 64, 16, 32)])
+@pytest.mark.parametrize('transposed', [False, True])
+def test_conv3x3_matches_fp64(n, ci, co, h, w, transposed):
+    g = torch.Generator().manual_seed(n + ci + co + h)
+    x = (torch.randn([n, ci, h, w], generator=g) + 0.3).to(DEV)
+    wt = (torch.randn([ci, co, 3, 3] if transposed else [co, ci, 3, 3], generator=g) / (3 * ci ** 0.5)).to(DEV)
+    cfg = (transposed, (1, 1), (1, 1), (0, 0), (1, 1), 1)
+    assert conv2d_gradfix._native_conv_ok(x, wt, cfg)
+    custom_ops.prof_enable(16)
+    y = (conv2d_gradfix.conv_transpose2d if transposed else conv2d_gradfix.conv2d)(x.requires_grad_(True), wt, padding=1)
+    custom_ops.prof_disable()
+    assert custom_ops.prof_collect()['conv3x3']['launches'] == 1
+    ref = (F.conv_transpose2d if transposed else F.conv2d)(x.detach().double().cpu(), wt.double().cpu(), padding=1)
+    lib = (F.conv_transpose2d if transposed else F.conv2d)(x.detach(), wt, padding=1)
+    l2, mx = _rel(y, ref)
+    l2_lib, mx_lib = _rel(lib, ref)
+    print(f'bf16x3 rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
+    assert l2 < 1e-5 and mx < 1e-5
+    # exact on small integers (hi/lo split is exact, products and sums fit fp32): catches any tap / channel / pixel mix-up
+    xi = torch.randint(-3, 4, x.shape, generator=g).float().to(DEV)
+    wi = torch.randint(-2, 3, wt.shape, generator=g).float().to(DEV)
+    yi = conv2d_gradfix._native_conv(xi, wi, 1 if transposed else 0)
+    assert torch.equal(yi.cpu().double(), (F.conv_transpose2d if transposed else F.conv2d)(xi.double().cpu(), wi.double().cpu(), padding=1))
+
+
+def test_conv3x3_gradients_first_and_second_order():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn([2, 64, 16, 32], generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn([64, 64, 3, 3], generator=g) / 24).to(DEV).requires_grad_(True)
+    xr, wr = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+
+    def run(conv, xx, ww):
+        y = conv(xx, ww, padding=1)
+        gx, gw = torch.autograd.grad(y.tanh().sum(), [xx, ww], create_graph=True)
+        g2 = torch.autograd.grad(gx.square().sum() + gw.square().sum(), [xx, ww])
+        return y, gx, gw, g2[0], g2[1]
+    custom_ops.prof_enable(256)
+    got = run(conv2d_gradfix.conv2d, x, w)
+    custom_ops.prof_disable()
+    prof = custom_ops.prof_collect()
+    assert prof['conv3x3']['launches'] >= 4   # forward, dx, and the convolutions inside the double backward
+    want = run(F.conv2d, xr, wr)
+    for a, r, name in zip(got, want, ['y', 'dx', 'dw', 'd2x', 'd2w']):
+        assert_close(a, r, atol=3e-5 * r.abs().max().item(), rtol=1e-4, what=name)
+
+
+def test_conv3x3_unsupported_shapes_use_the_vendor_library():
+    lib = custom_ops.get_native()
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 16, 16, 0) == 0   # W < 32
+    assert lib.sgv_conv3x3_supported(4, 3, 64, 32, 32, 0) == 0    # c_in % 16
+    assert lib.sgv_conv3x3_supported(4, 64, 48, 32, 32, 0) == 0   # c_out % 64
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 24, 32, 0) == 0   # H % 16
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 32, 32, 2) == 0   # bf16 tensors
+    x = torch.randn([2, 64, 16, 16], device=DEV)
+    w = torch.randn([64, 64, 3, 3], device=DEV, requires_grad=True)
+    before = custom_ops.launch_count()
+    y = conv2d_gradfix.conv2d(x, w, padding=1)
+    assert custom_ops.launch_count() == before
+    assert_close(y, F.conv2d(x, w, padding=1), atol=1e-4, rtol=1e-4)
+    # strided / padded variants never take the native path
+    assert not conv2d_gradfix._native_conv_ok(torch.randn([2, 64, 32, 32], device=DEV), w, (False, (2, 2), (1, 1), (0, 0), (1, 1), 1))
+    assert not conv2d_gradfix._native_conv_ok(torch.randn([2, 64, 32, 32], device=DEV), w, (False, (1, 1), (0, 0), (0, 0), (1, 1), 1))

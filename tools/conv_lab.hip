@@ -1,0 +1,90 @@
+// Lab for the 3x3 forward convolution kernel (stylegan-v_amd/csrc/conv3x3_kernel.h): check against a naive fp64 kernel, then time.
+// hipcc --offload-arch=gfx950 -O3 -std=c++17 -Istylegan-v_amd/csrc tools/conv_lab.hip -o tools/conv_lab && tools/conv_lab
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <math.h>
+#include <vector>
+#include "conv3x3_kernel.h"
+
+using namespace sgv_conv;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void fill(float* p, size_t n, unsigned seed, float scale) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { unsigned h = (unsigned)i * 2654435761u ^ seed; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16; p[i] = ((h & 0xffffff) / 16777216.f - 0.5f) * 2.f * scale; }
+}
+
+__global__ void naive_conv(const float* x, const float* w, double* y, int n, int k, int m, int h, int wd, int mode) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)n * m * h * wd) return;
+    const int X = idx % wd, Y = (idx / wd) % h, mm = (idx / ((size_t)wd * h)) % m, nn = idx / ((size_t)wd * h * m);
+    double s = 0;
+    for (int kk = 0; kk < k; kk++) for (int ky = 0; ky < 3; ky++) for (int kx = 0; kx < 3; kx++) {
+        const int sy = Y + ky - 1, sx = X + kx - 1;
+        if (sy < 0 || sy >= h || sx < 0 || sx >= wd) continue;
+        const float wv = mode == 0 ? w[(((size_t)mm * k + kk) * 3 + ky) * 3 + kx] : w[(((size_t)kk * m + mm) * 3 + (2 - ky)) * 3 + (2 - kx)];
+        s += (double)wv * x[(((size_t)nn * k + kk) * h + sy) * wd + sx];
+    }
+    y[idx] = s;
+}
+
+template <int TERMS> static void launch(const float* x, const float* w, float* y, u32x4* wprep, int n, int k, int m, int h, int wd, int mode, int grid) {
+    const int total = (m / TM) * (k / KC) * 9 * 2 * TM;
+    hipLaunchKernelGGL(conv3x3_prep_weights, dim3((total + 255) / 256), dim3(256), 0, 0, w, wprep, m, k, mode, TERMS);
+    conv_params p{};
+    p.x = x; p.wprep = wprep; p.y = y; p.n = n; p.k = k; p.m = m; p.h = h; p.w = wd;
+    p.tiles = n * (h / TROWS) * (wd / SEG) * (m / TM);
+    p.grid = grid < p.tiles ? grid : p.tiles;
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+                 CK(hipFuncSetAttribute((const void*)conv3x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)); attr = true; }
+    hipLaunchKernelGGL(conv3x3_kernel<TERMS>, dim3(p.grid), dim3(256), LDS_BYTES, 0, p);
+}
+
+int main(int argc, char** argv) {
+    const int reps = argc > 1 ? atoi(argv[1]) : 5;
+    {   // ---- correctness ----
+        for (int mode = 0; mode < 2; mode++) {
+            const int n = 2, k = 32, m = 128, h = 32, wd = 64;
+            const size_t nx = (size_t)n * k * h * wd, ny = (size_t)n * m * h * wd, nw = (size_t)m * k * 9;
+            float *x, *w, *y; double* ref; u32x4* wprep;
+            CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&y, ny * 4)); CK(hipMalloc(&ref, ny * 8)); CK(hipMalloc(&wprep, nw * 4));
+            fill<<<(nx + 255) / 256, 256>>>(x, nx, 11u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 23u, 0.1f);
+            naive_conv<<<(ny + 255) / 256, 256>>>(x, w, ref, n, k, m, h, wd, mode);
+            std::vector<double> r(ny); std::vector<float> gpu(ny);
+            CK(hipMemcpy(r.data(), ref, ny * 8, hipMemcpyDeviceToHost));
+            for (int terms = 1; terms <= 3; terms += 2) for (int grid : {256, 3}) {
+                CK(hipMemset(y, 0xff, ny * 4));
+                if (terms == 1) launch<1>(x, w, y, wprep, n, k, m, h, wd, mode, grid); else launch<3>(x, w, y, wprep, n, k, m, h, wd, mode, grid);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(gpu.data(), y, ny * 4, hipMemcpyDeviceToHost));
+                double maxerr = 0, maxref = 0, sq = 0, sqr = 0; size_t worst = 0;
+                for (size_t q = 0; q < ny; q++) { double e = fabs(gpu[q] - r[q]); if (!(e <= maxerr)) { maxerr = e; worst = q; } if (fabs(r[q]) > maxref) maxref = fabs(r[q]); sq += e * e; sqr += r[q] * r[q]; }
+                printf("check mode=%d terms=%d grid=%d: max abs err %.3e (max |ref| %.3e, rel-L2 %.3e) worst idx %zu gpu=%f ref=%f\n", mode, terms, grid, maxerr, maxref, sqrt(sq / sqr), worst, gpu[worst], r[worst]);
+            }
+            CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(ref)); CK(hipFree(wprep));
+        }
+    }
+    struct { const char* name; int n, c, r; } shapes[] = { {"64ch 256^2", 96, 64, 256}, {"128ch 128^2", 96, 128, 128}, {"256ch 64^2", 96, 256, 64}, {"512ch 32^2", 96, 512, 32} };
+    for (auto& s : shapes) {
+        const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
+        float *x, *w, *y; u32x4* wprep;
+        CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
+        fill<<<(na + 255) / 256, 256>>>(x, na, 5u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 7u, 0.1f);
+        const double flops = 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9;
+        for (int terms = 1; terms <= 3; terms += 2) for (int grid : {256, 512}) {
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            if (terms == 1) launch<1>(x, w, y, wprep, s.n, s.c, s.c, s.r, s.r, 0, grid); else launch<3>(x, w, y, wprep, s.n, s.c, s.c, s.r, s.r, 0, grid);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; r++) { if (terms == 1) launch<1>(x, w, y, wprep, s.n, s.c, s.c, s.r, s.r, 0, grid); else launch<3>(x, w, y, wprep, s.n, s.c, s.c, s.r, s.r, 0, grid); }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            printf("%-12s terms=%d grid=%3d  %8.3f ms  %7.1f TFLOP/s (fp32-equivalent)  %6.1f GB/s in+out\n", s.name, terms, grid, ms, flops / ms / 1e9, 2.0 * na * 4 / ms / 1e6);
+            fflush(stdout);
+        }
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep));
+    }
+    return 0;
+}
