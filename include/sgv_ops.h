@@ -214,7 +214,17 @@ typedef struct sgv_conv3x3_params {
     int32_t terms;
 } sgv_conv3x3_params;
 
+/*
+ * Stride-2 members (sgv_conv3x3_s2; h, w name the SMALL H x W grid, the big tensor is (2h+1) x (2w+1), no padding):
+ *   mode 0:  y[n,m,Y,X]        = sum_{k,ky,kx} weight[m][k][ky][kx] * x[n,k,2Y+ky,2X+kx]      x big -> y small (conv2d, stride 2)
+ *   mode 2:  y[n,m,2Y+ky,2X+kx] += weight[k][m][ky][kx] * x[n,k,Y,X]                          x small -> y big (conv_transpose2d, stride 2)
+ * These are the convolutions either side of the FIR in the reference's down- and up-sampling layers
+ * (conv2d_resample.py:113-137) and each other's data gradients.
+ */
 int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream);
+int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream);
+int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);
+int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode);
 int sgv_conv3x3_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);
 int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out);
 

@@ -5,6 +5,7 @@
 
 #include "sgv_common.h"
 #include "conv3x3_kernel.h"
+#include "conv3x3s2_kernel.h"
 
 #include <algorithm>
 #include <mutex>
@@ -25,10 +26,19 @@ hipError_t g_attr_err = hipSuccess;
 void init_once() {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     g_attr_err = e;
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
+}
+
+bool supported_s2(int n, int k, int m, int h, int w, int dtype) {   // h, w: the small (H x W) grid
+    return dtype == SGV_F32 && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && w >= SEG && w % SEG == 0 && h >= S_ROWS && h % S_ROWS == 0 &&
+           (int64_t)n * std::max(k, m) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
 }
 
 }  // namespace
@@ -71,4 +81,61 @@ extern "C" int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream_
     if (p->terms == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     else hipLaunchKernelGGL(conv3x3_kernel<3>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     return sgv_check_launch("conv3x3_kernel");
+}
+
+extern "C" int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {
+    return supported_s2(n, c_in, c_out, h, w, dtype) ? 1 : 0;
+}
+
+extern "C" int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode) {
+    int64_t bytes = (int64_t)c_in * c_out * 9 * 4;
+    if (mode == 2) bytes += (int64_t)convT3x3_s2_edge_floats(n, c_in, c_out, h, w) * 4;
+    return bytes;
+}
+
+extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream_) {
+    if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: params is NULL");
+    if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: NULL pointer");
+    if (!supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, W %% 32 == 0, H %% 8 == 0 on the HxW grid (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
+                        p->n, p->c_in, p->c_out, p->h, p->w, dtype);
+    if (p->mode != 0 && p->mode != 2) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: mode must be 0 (strided convolution) or 2 (transposed convolution)");
+    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms must be 1 or 3");
+    if (p->workspace_bytes < sgv_conv3x3_s2_workspace_bytes(p->n, p->c_in, p->c_out, p->h, p->w, p->mode)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: workspace is too small");
+    if ((((uintptr_t)p->workspace) & 15) || (p->mode == 2 && (((uintptr_t)p->x) & 15))) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: workspace (and x of the transposed form) must be 16-byte aligned");
+    std::call_once(g_attr_once, init_once);
+    if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
+    hipStream_t stream = (hipStream_t)stream_;
+
+    const int words = (p->c_out / TM) * (p->c_in / KC) * 9 * 2 * TM;
+    hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
+                       p->terms);
+    int rc = sgv_check_launch("conv3x3_prep_weights");
+    if (rc != SGV_OK) return rc;
+
+    s2_params kp{};
+    kp.x = (const float*)p->x; kp.wprep = (const u32x4*)p->workspace; kp.y = (float*)p->y;
+    kp.n = p->n; kp.k = p->c_in; kp.m = p->c_out; kp.h = p->h; kp.w = p->w;
+    kp.tiles = p->n * (p->h / S_ROWS) * (p->w / SEG) * (p->c_out / TM);
+    kp.grid = std::min(kp.tiles, g_cus);
+    const double small_px = (double)p->n * p->h * p->w, big_px = (double)p->n * (2 * p->h + 1) * (2 * p->w + 1);
+    const double bytes = 4.0 * (p->mode == 0 ? big_px * p->c_in + small_px * p->c_out : small_px * p->c_in + big_px * p->c_out) + 4.0 * p->c_in * p->c_out * 9;
+    sgv_launch_scope scope(SGV_K_CONV3X3, stream, bytes, 2.0 * small_px * p->c_in * (double)p->c_out * 9);
+    if (p->mode == 0) {
+        if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(256), S_LDS_BYTES, stream, kp);
+        else hipLaunchKernelGGL(conv3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(256), S_LDS_BYTES, stream, kp);
+        return sgv_check_launch("conv3x3_s2_kernel");
+    }
+    if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
+    else hipLaunchKernelGGL(convT3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
+    rc = sgv_check_launch("convT3x3_s2_kernel");
+    if (rc != SGV_OK) return rc;
+    float* edge = (float*)((char*)p->workspace + (size_t)p->c_in * p->c_out * 9 * 4);
+    const size_t edge_floats = convT3x3_s2_edge_floats(p->n, p->c_in, p->c_out, p->h, p->w);
+    hipLaunchKernelGGL(convT3x3_s2_edge_gather, dim3((unsigned)((edge_floats + 255) / 256)), dim3(256), 0, stream, (const float*)p->x, p->weight, edge, p->n, p->c_in, p->c_out,
+                       p->h, p->w);
+    const int lmax = std::max(2 * p->w + 1, 2 * p->h);
+    hipLaunchKernelGGL(convT3x3_s2_edge_kernel, dim3((unsigned)((lmax + 127) / 128), (unsigned)(p->n * (p->c_out / EDGE_MC)), 2), dim3(128), 0, stream, edge, (float*)p->y, p->n,
+                       p->c_in, p->c_out, p->h, p->w);
+    return sgv_check_launch("convT3x3_s2_edge_kernel");
 }

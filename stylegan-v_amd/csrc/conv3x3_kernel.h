@@ -257,6 +257,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
 // Weight re-layout: fp32 -> bf16 hi/lo in [m tile][k chunk][hl][tap][octet][64 m][8 k].
 // mode 0: wgt(m,k,ky,kx) = w[m][k][ky][kx]            (forward;  w is [M, K, 3, 3])
 // mode 1: wgt(m,k,ky,kx) = w[k][m][2-ky][2-kx]        (data gradient of the same layer; w is [K, M, 3, 3])
+// mode 2: wgt(m,k,ky,kx) = w[k][m][ky][kx]            (transposed convolution;         w is [K, M, 3, 3])
 __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x4* out, int m_total, int k_total, int mode, int terms) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // one 16-B output word (8 k) of the hi plane
     const int chunks = k_total / KC;
@@ -272,7 +273,9 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++)
-        v[j] = mode == 0 ? w[(((size_t)m * k_total + k0 + j) * 3 + ky) * 3 + kx] : w[(((size_t)(k0 + j) * m_total + m) * 3 + (2 - ky)) * 3 + (2 - kx)];
+        v[j] = mode == 0 ? w[(((size_t)m * k_total + k0 + j) * 3 + ky) * 3 + kx]
+             : mode == 1 ? w[(((size_t)(k0 + j) * m_total + m) * 3 + (2 - ky)) * 3 + (2 - kx)]
+                         : w[(((size_t)(k0 + j) * m_total + m) * 3 + ky) * 3 + kx];
     u32x4 hi, lo;
     split8(v, hi, lo);
     const size_t base = ((size_t)mt * chunks + c) * WS_WORDS;

@@ -220,6 +220,9 @@ ABI_SYMBOLS = {
     'sgv_pointwise_small': (c_int, [ctypes.POINTER(PointwiseParams), c_int, c_void_p]),
     'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_conv3x3': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
+    'sgv_conv3x3_s2': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
+    'sgv_conv3x3_s2_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
+    'sgv_conv3x3_s2_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'sgv_conv3x3_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_workspace_bytes': (c_int64, [c_int32, c_int32]),
     'sgv_conv3x3_wrw': (c_int, [ctypes.POINTER(ConvWrwParams), c_int, c_void_p]),

@@ -91,7 +91,7 @@ class _Conv(torch.autograd.Function):
         ctx.has_bias = b is not None
         ctx.save_for_backward(x, w)
         if b is None and _native_conv_ok(x, w, cfg):
-            return _native_conv(x, w, 1 if cfg[0] else 0)
+            return _native_conv(x, w, cfg)
         return _aten_conv(x, w, b, cfg)
 
     @staticmethod
@@ -113,34 +113,61 @@ class _Conv(torch.autograd.Function):
 # 1.5 ms where MIOpen's NHWC implicit GEMM + its three layout transposes take ~6 ms.  wrw_terms = 3 -> bf16x3 (|rel err| ~ 4e-6
 # of the result's scale, tests/test_conv_wrw_gpu.py), 1 -> plain bf16 products, 0 -> always the vendor library.
 native_wrw_terms = int(os.environ.get('SGV_WRW_TERMS', '3'))
-native_conv_terms = int(os.environ.get('SGV_CONV_TERMS', '3'))   # same switch for the forward / data-gradient kernel (csrc/conv3x3_kernel.h)
+native_conv_terms = int(os.environ.get('SGV_CONV_TERMS', '3'))
+native_conv_s2 = os.environ.get('SGV_CONV_S2', '1') != '0'         # stride-2 / transposed members (csrc/conv3x3s2_kernel.h)   # same switch for the forward / data-gradient kernel (csrc/conv3x3_kernel.h)
 
 
-def _native_conv_ok(x, w, cfg):
-    """3x3 / stride 1 / pad 1 forward (cfg[0] False) or data gradient (cfg[0] True: conv_transpose2d) served by csrc/conv3x3_kernel.h."""
+def _native_conv_kind(x, w, cfg):
+    """Which hand-written kernel serves this convolution: 's1' (3x3 / stride 1 / pad 1, forward or data gradient,
+    csrc/conv3x3_kernel.h), 's2' (3x3 / stride 2 / pad 0 between a (2H+1)x(2W+1) and an HxW tensor, strided or transposed,
+    csrc/conv3x3s2_kernel.h) or None (vendor library)."""
     transposed, stride, padding, output_padding, dilation, groups = cfg
-    if native_conv_terms not in (1, 3) or groups != 1 or stride != (1, 1) or padding != (1, 1) or dilation != (1, 1) or output_padding != (0, 0):
-        return False
+    if native_conv_terms not in (1, 3) or groups != 1 or dilation != (1, 1) or output_padding != (0, 0):
+        return None
     if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3) or not (x.is_cuda and w.is_cuda) or x.dtype != torch.float32 or w.dtype != torch.float32:
-        return False
+        return None
     n, ci, h, wd = x.shape
     co = w.shape[1] if transposed else w.shape[0]
     if (w.shape[0] if transposed else w.shape[1]) != ci:
-        return False
-    return bool(custom_ops.get_native().sgv_conv3x3_supported(n, ci, co, h, wd, 0))
-
-
-def _native_conv(x, w, mode):
+        return None
     lib = custom_ops.get_native()
+    if stride == (1, 1) and padding == (1, 1):
+        return 's1' if lib.sgv_conv3x3_supported(n, ci, co, h, wd, 0) else None
+    if stride == (2, 2) and padding == (0, 0) and native_conv_s2:
+        if transposed:
+            return 's2' if lib.sgv_conv3x3_s2_supported(n, ci, co, h, wd, 0) else None
+        if h % 2 == 1 and wd % 2 == 1 and h >= 3 and wd >= 3:
+            return 's2' if lib.sgv_conv3x3_s2_supported(n, ci, co, (h - 1) // 2, (wd - 1) // 2, 0) else None
+    return None
+
+
+def _native_conv_ok(x, w, cfg):
+    return _native_conv_kind(x, w, cfg) is not None
+
+
+def _native_conv(x, w, cfg):
+    lib = custom_ops.get_native()
+    kind = _native_conv_kind(x, w, cfg)
+    transposed = cfg[0]
     xc, wc = x.contiguous(), w.contiguous()
     n, ci, h, wd = xc.shape
-    co = wc.shape[1] if mode else wc.shape[0]
-    y = torch.empty([n, co, h, wd], dtype=torch.float32, device=x.device)
-    ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
-    ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
-    p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, wd, mode, native_conv_terms)
+    co = wc.shape[1] if transposed else wc.shape[0]
+    if kind == 's1':
+        y = torch.empty([n, co, h, wd], dtype=torch.float32, device=x.device)
+        ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
+        ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
+        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, wd, 1 if transposed else 0, native_conv_terms)
+        fn = lib.sgv_conv3x3
+    else:
+        hs, wsm = (h, wd) if transposed else ((h - 1) // 2, (wd - 1) // 2)   # the small grid
+        y = torch.empty([n, co, 2 * hs + 1, 2 * wsm + 1] if transposed else [n, co, hs, wsm], dtype=torch.float32, device=x.device)
+        mode = 2 if transposed else 0
+        ws_bytes = int(lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, wsm, mode))
+        ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
+        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, hs, wsm, mode, native_conv_terms)
+        fn = lib.sgv_conv3x3_s2
     with custom_ops.device_guard(xc):
-        custom_ops.check(lib.sgv_conv3x3(p, 0, custom_ops.raw_stream(xc)), lib)
+        custom_ops.check(fn(p, 0, custom_ops.raw_stream(xc)), lib)
     return y
 
 

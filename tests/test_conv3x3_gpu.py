@@ -37,7 +37,7 @@ def test_conv3x3_matches_fp64(n, ci, co, h, w, transposed):
     # exact on small integers (hi/lo split is exact, products and sums fit fp32): catches any tap / channel / pixel mix-up
     xi = torch.randint(-3, 4, x.shape, generator=g).float().to(DEV)
     wi = torch.randint(-2, 3, wt.shape, generator=g).float().to(DEV)
-    yi = conv2d_gradfix._native_conv(xi, wi, 1 if transposed else 0)
+    yi = conv2d_gradfix._native_conv(xi, wi, cfg)
     assert torch.equal(yi.cpu().double(), (F.conv_transpose2d if transposed else F.conv2d)(xi.double().cpu(), wi.double().cpu(), padding=1))
 
 
@@ -78,3 +78,57 @@ def test_conv3x3_unsupported_shapes_use_the_vendor_library():
     # strided / padded variants never take the native path
     assert not conv2d_gradfix._native_conv_ok(torch.randn([2, 64, 32, 32], device=DEV), w, (False, (2, 2), (1, 1), (0, 0), (1, 1), 1))
     assert not conv2d_gradfix._native_conv_ok(torch.randn([2, 64, 32, 32], device=DEV), w, (False, (1, 1), (0, 0), (0, 0), (1, 1), 1))
+
+
+@pytest.mark.parametrize('n,cb,cs,h,w', [(2, 64, 64, 8, 32), (1, 16, 128, 16, 64), (3, 128, 64, 24, 32), (1, 32, 64, 8, 96)])
+@pytest.mark.parametrize('transposed', [False, True])
+def test_conv3x3_stride2_family_matches_fp64(n, cb, cs, h, w, transposed):
+    """cb channels on the (2h+1)x(2w+1) side, cs on the h x w side: strided maps big -> small, transposed small -> big."""
+    g = torch.Generator().manual_seed(n + cb + cs + h)
+    hb, wb = 2 * h + 1, 2 * w + 1
+    if transposed:
+        x = (torch.randn([n, cs, h, w], generator=g) + 0.3).to(DEV)
+        wt = (torch.randn([cs, cb, 3, 3], generator=g) / (3 * cs ** 0.5)).to(DEV)
+        if cb % 64:
+            pytest.skip('c_out % 64')
+    else:
+        x = (torch.randn([n, cb, hb, wb], generator=g) + 0.3).to(DEV)
+        wt = (torch.randn([cs, cb, 3, 3], generator=g) / (3 * cb ** 0.5)).to(DEV)
+        if cs % 64:
+            pytest.skip('c_out % 64')
+    cfg = (transposed, (2, 2), (0, 0), (0, 0), (1, 1), 1)
+    assert conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2'
+    op, ref_op = (conv2d_gradfix.conv_transpose2d, F.conv_transpose2d) if transposed else (conv2d_gradfix.conv2d, F.conv2d)
+    custom_ops.prof_enable(16)
+    y = op(x.requires_grad_(True), wt, stride=2)
+    custom_ops.prof_disable()
+    assert custom_ops.prof_collect()['conv3x3']['launches'] == 1
+    ref = ref_op(x.detach().double().cpu(), wt.double().cpu(), stride=2)
+    assert y.shape == ref.shape
+    l2, mx = _rel(y, ref)
+    l2_lib, mx_lib = _rel(ref_op(x.detach(), wt, stride=2), ref)
+    print(f'bf16x3 s2 rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
+    assert l2 < 1e-5 and mx < 1e-5
+    xi = torch.randint(-3, 4, x.shape, generator=g).float().to(DEV)
+    wi = torch.randint(-2, 3, wt.shape, generator=g).float().to(DEV)
+    assert torch.equal(conv2d_gradfix._native_conv(xi, wi, cfg).cpu().double(), ref_op(xi.double().cpu(), wi.double().cpu(), stride=2))
+
+
+def test_conv3x3_stride2_gradients_first_and_second_order():
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn([2, 64, 17, 65], generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn([64, 64, 3, 3], generator=g) / 24).to(DEV).requires_grad_(True)
+    xr, wr = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+
+    def run(conv, xx, ww):
+        y = conv(xx, ww, stride=2)
+        gx, gw = torch.autograd.grad(y.tanh().sum(), [xx, ww], create_graph=True)
+        g2 = torch.autograd.grad(gx.square().sum() + gw.square().sum(), [xx, ww])
+        return y, gx, gw, g2[0], g2[1]
+    custom_ops.prof_enable(256)
+    got = run(conv2d_gradfix.conv2d, x, w)
+    custom_ops.prof_disable()
+    assert custom_ops.prof_collect()['conv3x3']['launches'] >= 4
+    want = run(F.conv2d, xr, wr)
+    for a, r, name in zip(got, want, ['y', 'dx', 'dw', 'd2x', 'd2w']):
+        assert_close(a, r, atol=3e-5 * r.abs().max().item(), rtol=1e-4, what=name)
