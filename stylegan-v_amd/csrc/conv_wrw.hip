@@ -7,6 +7,7 @@
 #include "wrw_kernel.h"
 
 #include <algorithm>
+#include <mutex>
 
 using namespace sgv_wrw;
 
@@ -16,6 +17,14 @@ bool supported(int n, int o, int i, int h, int w, int dtype) {
     return dtype == SGV_F32 && n >= 1 && o >= TO && i >= TI && o % TO == 0 && i % TI == 0 && w >= SEG && w % SEG == 0 && h >= 1 &&
            (h <= 32 || h % 32 == 0) && (int64_t)n * std::max(o, i) * h * w <= INT32_MAX;
 }
+
+bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {
+    return dtype == SGV_F32 && n >= 1 && cs >= TO && cb >= TI && cs % TO == 0 && cb % TI == 0 && w >= SEG && w % SEG == 0 && h >= 1 && (h <= 32 || h % 32 == 0) &&
+           (int64_t)n * std::max(cs, cb) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
+}
+
+std::once_flag g_once;
+hipError_t g_attr_err = hipSuccess;
 
 }  // namespace
 
@@ -50,4 +59,43 @@ extern "C" int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* st
     if (p->terms == 1) hipLaunchKernelGGL(wrw3x3_kernel<1>, grid, dim3(256), 0, stream, kp);
     else hipLaunchKernelGGL(wrw3x3_kernel<3>, grid, dim3(256), 0, stream, kp);
     return sgv_check_launch("wrw3x3_kernel");
+}
+
+extern "C" int sgv_conv3x3_wrw_s2_supported(int32_t n, int32_t c_small, int32_t c_big, int32_t h, int32_t w, int dtype) {
+    return supported_s2(n, c_small, c_big, h, w, dtype) ? 1 : 0;
+}
+
+// Stride-2 member: p->dy is the SMALL tensor [n, c_out, h, w], p->x the BIG one [n, c_in, 2h+1, 2w+1]; dw is [c_out, c_in, 3, 3].
+extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void* stream_) {
+    if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: params is NULL");
+    if (!p->dy || !p->x || !p->dw) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: NULL pointer");
+    if (!supported_s2(p->n, p->c_out, p->c_in, p->h, p->w, dtype))
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_s2: needs fp32, channels %% 64 == 0, W %% 32 == 0, H <= 32 or H %% 32 == 0 on the HxW grid (got n=%d cs=%d cb=%d h=%d w=%d dtype=%d)",
+                        p->n, p->c_out, p->c_in, p->h, p->w, dtype);
+    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms must be 1 or 3");
+    if (((uintptr_t)p->dy) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: the small tensor must be 16-byte aligned");
+    std::call_once(g_once, [] {
+        hipError_t e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        g_attr_err = e;
+    });
+    if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
+    hipStream_t stream = (hipStream_t)stream_;
+    wrw_s2_params kp{};
+    kp.small = (const float*)p->dy; kp.big = (const float*)p->x; kp.dw = p->dw;
+    kp.n = p->n; kp.cs = p->c_out; kp.cb = p->c_in; kp.h = p->h; kp.w = p->w;
+    kp.rows = std::min(p->h, 32);
+    kp.tiles_b = p->c_in / TI;
+    kp.units = p->n * (p->w / SEG) * (p->h / kp.rows);
+    const int tiles = (p->c_out / TO) * kp.tiles_b;
+    kp.splits = std::max(1, std::min(kp.units, 256 / std::max(1, std::min(tiles, 256))));
+    const size_t dw_bytes = (size_t)p->c_out * p->c_in * 9 * sizeof(float);
+    hipError_t e = hipMemsetAsync(p->dw, 0, dw_bytes, stream);
+    if (e != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw_s2: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    const double small_px = (double)p->n * p->h * p->w, big_px = (double)p->n * (2 * p->h + 1) * (2 * p->w + 1);
+    sgv_launch_scope scope(SGV_K_CONV_WRW, stream, 4.0 * (small_px * p->c_out + big_px * p->c_in) + dw_bytes, 2.0 * small_px * p->c_out * (double)p->c_in * 9);
+    dim3 grid((unsigned)tiles, (unsigned)kp.splits);
+    if (p->terms == 1) hipLaunchKernelGGL(wrw3x3_s2_kernel<1>, grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
+    else hipLaunchKernelGGL(wrw3x3_s2_kernel<3>, grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
+    return sgv_check_launch("wrw3x3_s2_kernel");
 }

@@ -236,4 +236,184 @@ __global__ __launch_bounds__(256, 2) void wrw3x3_kernel(wrw_params p) {
         }
 }
 
+// ----------------------------------------------------------------------------------------------------------------------
+// Stride-2 member: weight gradient of the strided (and, by symmetry, of the transposed) 3x3 convolution that connects a
+// "big" tensor [n, cb, 2H+1, 2W+1] with a "small" one [n, cs, H, W] (conv3x3s2_kernel.h):
+//
+//     dw[cs, cb, ky, kx] = sum_{n,Y,X} small[n,cs,Y,X] * big[n,cb,2Y+ky,2X+kx]
+//
+// (strided layer: small = dy, big = x, dw has the weight's [c_out, c_in, 3, 3] layout; transposed layer: small = x, big = dy,
+// dw has the weight's [c_in, c_out, 3, 3] layout -- the same formula.)  Same structure as wrw3x3_kernel; differences: a step
+// consumes two new big rows (ring of 5 row slots), big rows have no 16-B alignment (4-B aligned dwordx4 loads), and the
+// columns are de-interleaved into even / odd planes on the way into LDS so that kx = 0 / 1 are aligned 16-B reads of the
+// even / odd plane and kx = 2 is the even plane shifted by one bf16 (v_alignbyte_b32).
+typedef float f32x4_u __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int BIG_CH = 2 * RS + 8;           // bf16 per channel row in a ring slot: even plane [RS] + odd plane [RS] + pad (176 B = 11 x 16 B)
+constexpr int BIG_SLOT = TI * BIG_CH;        // bf16 per ring slot
+
+struct wrw_s2_params {
+    const float* small;   // [n, cs, h, w]
+    const float* big;     // [n, cb, 2h+1, 2w+1]
+    float* dw;            // [cs, cb, 3, 3]
+    int n, cs, cb, h, w;
+    int rows, tiles_b, splits, units;
+};
+
+template <int TERMS>
+__global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds_s2[];
+    unsigned short* bs = lds_s2;                          // [hl][5 slots][64 cb][even RS | odd RS]
+    unsigned short* as = lds_s2 + 2 * 5 * BIG_SLOT;       // [hl][2 bufs][64 cs][RS]
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wo = (wave >> 1) * 32, wi = (wave & 1) * 32;
+    const int r32 = lane & 31, g = lane >> 5;
+    const int tile = blockIdx.x;
+    const int s0 = (tile / p.tiles_b) * TO, b0 = (tile % p.tiles_b) * TI;
+    const int segs = p.w / SEG, rblocks = p.h / p.rows;
+    const int hb = 2 * p.h + 1, wb = 2 * p.w + 1;
+    const size_t plane_s = (size_t)p.h * p.w, plane_b = (size_t)hb * wb;
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[k][e] = 0.f;
+
+    const int lr = t >> 2, lq = (t & 3) * 8;   // small-row loader: channel, first pixel
+
+    struct big_regs { f32x4 v[4]; float edge; };
+
+    for (int u = blockIdx.y; u < p.units; u += p.splits) {
+        const int rb = u % rblocks, sg = (u / rblocks) % segs, n = u / (rblocks * segs);
+        const int y0 = rb * p.rows, x0 = sg * SEG;
+        const float* sb = p.small + ((size_t)n * p.cs + s0) * plane_s + x0;
+        const float* bb = p.big + ((size_t)n * p.cb + b0) * plane_b + (size_t)(2 * y0) * wb + 2 * x0;
+
+        auto load_big = [&](int b, big_regs& r) {   // local big row b = 0 .. 2 * rows
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int it = t + 256 * j, quad = it & 15, ch = it >> 4;
+                r.v[j] = *(const f32x4_u*)(bb + (size_t)ch * plane_b + (size_t)b * wb + 4 * quad);
+            }
+            r.edge = t < TI ? bb[(size_t)t * plane_b + (size_t)b * wb + 64] : 0.f;
+        };
+        auto store_big = [&](int b, const big_regs& r) {
+            const int slot = b - 5 * ((b * 205) >> 10);   // b % 5
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int it = t + 256 * j, quad = it & 15, ch = it >> 4;
+                const unsigned he = pack_bf16(r.v[j][0], r.v[j][2]), ho = pack_bf16(r.v[j][1], r.v[j][3]);
+                const int pos = slot * BIG_SLOT + ch * BIG_CH + 2 * quad;
+                *(unsigned*)&bs[pos] = he;
+                *(unsigned*)&bs[pos + RS] = ho;
+                if (TERMS > 1) {
+                    const unsigned le = pack_bf16(r.v[j][0] - __builtin_bit_cast(float, he << 16), r.v[j][2] - __builtin_bit_cast(float, he & 0xffff0000u));
+                    const unsigned lo = pack_bf16(r.v[j][1] - __builtin_bit_cast(float, ho << 16), r.v[j][3] - __builtin_bit_cast(float, ho & 0xffff0000u));
+                    *(unsigned*)&bs[5 * BIG_SLOT + pos] = le;
+                    *(unsigned*)&bs[5 * BIG_SLOT + pos + RS] = lo;
+                }
+            }
+            if (t < TI) {
+                const unsigned h = pack_bf16(r.edge, 0.f);
+                const int pos = slot * BIG_SLOT + t * BIG_CH + 32;
+                bs[pos] = (unsigned short)h;
+                if (TERMS > 1) bs[5 * BIG_SLOT + pos] = (unsigned short)pack_bf16(r.edge - __builtin_bit_cast(float, h << 16), 0.f);
+            }
+        };
+        auto load_small = [&](int row, float* v) {
+            const float* q = sb + (size_t)lr * plane_s + (size_t)(y0 + row) * p.w + lq;
+            const f32x4 a = *(const f32x4*)q, b = *(const f32x4*)(q + 4);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { v[k] = a[k]; v[4 + k] = b[k]; }
+        };
+        auto store_small = [&](int row, const float* v) {
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            *(u32x4*)&as[(row & 1) * (TO * RS) + lr * RS + lq] = hi;
+            if (TERMS > 1) *(u32x4*)&as[2 * TO * RS + (row & 1) * (TO * RS) + lr * RS + lq] = lo;
+        };
+
+        {
+            big_regs r0, r1, r2;
+            float sv[8];
+            load_big(0, r0);
+            load_big(1, r1);
+            load_big(2, r2);
+            load_small(0, sv);
+            __syncthreads();
+            store_big(0, r0);
+            store_big(1, r1);
+            store_big(2, r2);
+            store_small(0, sv);
+            __syncthreads();
+        }
+
+        for (int i = 0; i < p.rows; i++) {
+            const bool more = i + 1 < p.rows;
+            big_regs rn0, rn1;
+            float sn[8];
+            if (more) {
+                load_big(2 * i + 3, rn0);
+                load_big(2 * i + 4, rn1);
+                load_small(i + 1, sn);
+            }
+            const int buf = i & 1;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int pa = buf * (TO * RS) + (wo + r32) * RS + 16 * c + 8 * g;
+                const u32x4 a_hi = *(const u32x4*)&as[pa];
+                u32x4 a_lo;
+                if (TERMS > 1) a_lo = *(const u32x4*)&as[2 * TO * RS + pa];
+#pragma unroll
+                for (int ky = 0; ky < 3; ky++) {
+                    const int b = 2 * i + ky;
+                    const int slot = b - 5 * ((b * 205) >> 10);
+                    const int pb = slot * BIG_SLOT + (wi + r32) * BIG_CH + 16 * c + 8 * g;
+                    u32x4 bv[2][3];
+#pragma unroll
+                    for (int hl = 0; hl < (TERMS > 1 ? 2 : 1); hl++) {
+                        const u32x4 e = *(const u32x4*)&bs[hl * 5 * BIG_SLOT + pb];
+                        const unsigned ea = *(const unsigned*)&bs[hl * 5 * BIG_SLOT + pb + 8];
+                        bv[hl][0] = e;
+                        bv[hl][1] = *(const u32x4*)&bs[hl * 5 * BIG_SLOT + pb + RS];
+                        bv[hl][2] = u32x4{__builtin_amdgcn_alignbyte(e[1], e[0], 2), __builtin_amdgcn_alignbyte(e[2], e[1], 2), __builtin_amdgcn_alignbyte(e[3], e[2], 2),
+                                          __builtin_amdgcn_alignbyte(ea, e[3], 2)};
+                    }
+                    if (TERMS > 1) {
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lo), __builtin_bit_cast(bf16x8, bv[0][kx]), acc[ky * 3 + kx], 0, 0, 0);
+#pragma unroll
+                        for (int kx = 0; kx < 3; kx++)
+                            acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bv[1][kx]), acc[ky * 3 + kx], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++)
+                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bv[0][kx]), acc[ky * 3 + kx], 0, 0, 0);
+                }
+            }
+            if (more) {
+                store_big(2 * i + 3, rn0);
+                store_big(2 * i + 4, rn1);
+                store_small(i + 1, sn);
+            }
+            __syncthreads();
+        }
+    }
+
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int cs = s0 + wo + (e & 3) + 8 * (e >> 2) + 4 * g;
+            const int cb = b0 + wi + r32;
+            atomicAdd(p.dw + ((size_t)cs * p.cb + cb) * 9 + k, acc[k][e]);
+        }
+}
+
+constexpr int WRW_S2_LDS_BYTES = (2 * 5 * BIG_SLOT + 2 * 2 * TO * RS) * 2;
+
 }  // namespace sgv_wrw

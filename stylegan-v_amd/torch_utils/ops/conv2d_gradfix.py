@@ -171,26 +171,50 @@ def _native_conv(x, w, cfg):
     return y
 
 
-def _native_wrw_ok(dy, x, cfg, w_shape):
+def _native_wrw_kind(dy, x, cfg, w_shape):
+    """'s1': 3x3 / stride 1 / pad 1; 's2': 3x3 / stride 2 / pad 0 (strided or transposed layer); None: vendor library."""
     transposed, stride, padding, output_padding, dilation, groups = cfg
-    if native_wrw_terms not in (1, 3) or transposed or groups != 1 or stride != (1, 1) or padding != (1, 1) or dilation != (1, 1):
-        return False
+    if native_wrw_terms not in (1, 3) or groups != 1 or dilation != (1, 1) or output_padding != (0, 0):
+        return None
     if tuple(w_shape[2:]) != (3, 3) or not (dy.is_cuda and x.is_cuda) or dy.dtype != torch.float32 or x.dtype != torch.float32:
-        return False
-    if dy.shape[2:] != x.shape[2:]:
-        return False
-    n, ci, h, w = x.shape
-    return bool(custom_ops.get_native().sgv_conv3x3_wrw_supported(n, w_shape[0], ci, h, w, 0))
-
-
-def _native_wrw(dy, x, w_shape):
+        return None
     lib = custom_ops.get_native()
-    dyc, xc = dy.contiguous(), x.contiguous()
-    n, ci, h, w = xc.shape
+    n, ci, h, w = x.shape
+    if stride == (1, 1) and padding == (1, 1) and not transposed:
+        if dy.shape[2:] != x.shape[2:]:
+            return None
+        return 's1' if lib.sgv_conv3x3_wrw_supported(n, w_shape[0], ci, h, w, 0) else None
+    if stride == (2, 2) and padding == (0, 0) and native_conv_s2:
+        small, big = (x, dy) if transposed else (dy, x)
+        hs, ws = small.shape[2:]
+        if tuple(big.shape[2:]) != (2 * hs + 1, 2 * ws + 1):
+            return None
+        return 's2' if lib.sgv_conv3x3_wrw_s2_supported(n, small.shape[1], big.shape[1], hs, ws, 0) else None
+    return None
+
+
+def _native_wrw_ok(dy, x, cfg, w_shape):
+    return _native_wrw_kind(dy, x, cfg, w_shape) is not None
+
+
+def _native_wrw(dy, x, cfg, w_shape):
+    lib = custom_ops.get_native()
+    kind = _native_wrw_kind(dy, x, cfg, w_shape)
     dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
-    p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, w_shape[0], ci, h, w, native_wrw_terms)
+    if kind == 's1':
+        dyc, xc = dy.contiguous(), x.contiguous()
+        n, ci, h, w = xc.shape
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, w_shape[0], ci, h, w, native_wrw_terms)
+        fn = lib.sgv_conv3x3_wrw
+    else:   # the weight is [c_small, c_big, 3, 3] for both the strided ([c_out, c_in]) and the transposed ([c_in, c_out]) layer
+        small, big = ((x, dy) if cfg[0] else (dy, x))
+        dyc, xc = small.contiguous(), big.contiguous()
+        n, cs, hs, ws = dyc.shape
+        assert tuple(w_shape[:2]) == (cs, xc.shape[1])
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, cs, xc.shape[1], hs, ws, native_wrw_terms)
+        fn = lib.sgv_conv3x3_wrw_s2
     with custom_ops.device_guard(xc):
-        custom_ops.check(lib.sgv_conv3x3_wrw(p, 0, custom_ops.raw_stream(xc)), lib)
+        custom_ops.check(fn(p, 0, custom_ops.raw_stream(xc)), lib)
     return dw
 
 
@@ -204,7 +228,7 @@ class _ConvGradWeight(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.save_for_backward(dy, x)
         if _native_wrw_ok(dy, x, cfg, w_shape):
-            return _native_wrw(dy, x, w_shape)
+            return _native_wrw(dy, x, cfg, w_shape)
         w_like = x.new_empty(w_shape)  # only its shape/dtype are read when output_mask selects the weight gradient
         _, dw, _ = torch.ops.aten.convolution_backward(dy, x, w_like, None, stride, padding, dilation, transposed, output_padding, groups,
                                                        [False, True, False])

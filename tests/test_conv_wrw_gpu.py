@@ -24,7 +24,7 @@ def _native(dy, x, terms):
     conv2d_gradfix.native_wrw_terms = terms
     try:
         assert conv2d_gradfix._native_wrw_ok(dy, x, (False, (1, 1), (1, 1), (0, 0), (1, 1), 1), (dy.shape[1], x.shape[1], 3, 3))
-        return conv2d_gradfix._native_wrw(dy, x, (dy.shape[1], x.shape[1], 3, 3))
+        return conv2d_gradfix._native_wrw(dy, x, (False, (1, 1), (1, 1), (0, 0), (1, 1), 1), (dy.shape[1], x.shape[1], 3, 3))
     finally:
         conv2d_gradfix.native_wrw_terms = old
 
@@ -98,3 +98,28 @@ def test_unsupported_shapes_fall_back_to_the_vendor_library():
     assert custom_ops.launch_count() == before
     p = custom_ops.ConvWrwParams(x.data_ptr(), x.data_ptr(), w.data_ptr(), 2, 64, 64, 16, 16, 3)
     assert lib.sgv_conv3x3_wrw(p, 0, None) == -3 and b'W % 32' in lib.sgv_last_error()
+
+
+@pytest.mark.parametrize('n,cs,cb,h,w', [(2, 64, 64, 8, 32), (1, 128, 64, 32, 64), (3, 64, 128, 64, 32), (2, 64, 64, 1, 96)])
+@pytest.mark.parametrize('transposed', [False, True])
+def test_wrw_stride2_family(n, cs, cb, h, w, transposed):
+    """Weight gradient of the strided (big -> small) and of the transposed (small -> big) 3x3 layer."""
+    g = torch.Generator().manual_seed(n + cs + cb + h)
+    small = torch.randn([n, cs, h, w], generator=g).to(DEV)
+    big = (torch.randn([n, cb, 2 * h + 1, 2 * w + 1], generator=g) * 1.5 + 0.25).to(DEV)
+    cfg = (transposed, (2, 2), (0, 0), (0, 0), (1, 1), 1)
+    x, dy = (small, big) if transposed else (big, small)
+    assert conv2d_gradfix._native_wrw_kind(dy, x, cfg, (cs, cb, 3, 3)) == 's2'
+    got = conv2d_gradfix._native_wrw(dy, x, cfg, (cs, cb, 3, 3))
+    wz = torch.zeros([cs, cb, 3, 3], dtype=torch.float64, requires_grad=True)
+    xd, dyd = x.double().cpu(), dy.double().cpu()
+    y = F.conv_transpose2d(xd, wz, stride=2) if transposed else F.conv2d(xd, wz, stride=2)
+    ref = torch.autograd.grad(y, wz, dyd)[0]
+    l2, mx = _rel(got, ref)
+    print(f'bf16x3 wrw-s2 rel-L2 {l2:.2e} max {mx:.2e}')
+    assert l2 < 1e-5 and mx < 1e-5
+    si = torch.randint(-3, 4, small.shape, generator=g).float().to(DEV)
+    bi = torch.randint(-3, 4, big.shape, generator=g).float().to(DEV)
+    xi, dyi = (si, bi) if transposed else (bi, si)
+    yi = F.conv_transpose2d(xi.double().cpu(), wz, stride=2) if transposed else F.conv2d(xi.double().cpu(), wz, stride=2)
+    assert torch.equal(conv2d_gradfix._native_wrw(dyi, xi, cfg, (cs, cb, 3, 3)).cpu().double(), torch.autograd.grad(yi, wz, dyi.double().cpu())[0])

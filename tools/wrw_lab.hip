@@ -54,8 +54,86 @@ template <int TERMS> static void launch(const wrw_params& p) {
     hipLaunchKernelGGL(wrw3x3_kernel<TERMS>, grid, dim3(256), 0, 0, p);
 }
 
+__global__ void naive_wrw_s2(const float* sm, const float* big, double* dw, int n, int cs, int cb, int h, int w) {
+    const int o = blockIdx.x / cb, i = blockIdx.x % cb;
+    const int hb = 2 * h + 1, wb = 2 * w + 1;
+    double s[9] = {0};
+    for (size_t q = threadIdx.x; q < (size_t)n * h * w; q += blockDim.x) {
+        const int xx = q % w, yy = (q / w) % h, nn = q / ((size_t)w * h);
+        const double d = sm[(((size_t)nn * cs + o) * h + yy) * w + xx];
+        for (int ky = 0; ky < 3; ky++) for (int kx = 0; kx < 3; kx++) s[ky * 3 + kx] += d * big[(((size_t)nn * cb + i) * hb + 2 * yy + ky) * wb + 2 * xx + kx];
+    }
+    __shared__ double red[256];
+    for (int k = 0; k < 9; k++) {
+        red[threadIdx.x] = s[k]; __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) { if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st]; __syncthreads(); }
+        if (threadIdx.x == 0) dw[(size_t)blockIdx.x * 9 + k] = red[0];
+        __syncthreads();
+    }
+}
+
+template <int TERMS> static wrw_s2_params launch_s2(const float* sm, const float* big, float* dw, int n, int cs, int cb, int h, int w, int wgs) {
+    wrw_s2_params p{};
+    p.small = sm; p.big = big; p.dw = dw; p.n = n; p.cs = cs; p.cb = cb; p.h = h; p.w = w;
+    p.rows = h < 32 ? h : 32;
+    p.tiles_b = cb / TI;
+    p.units = n * (w / SEG) * (h / p.rows);
+    const int tiles = (cs / TO) * p.tiles_b;
+    int splits = wgs / tiles; if (splits < 1) splits = 1; if (splits > p.units) splits = p.units;
+    p.splits = splits;
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES));
+                 CK(hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES)); attr = true; }
+    hipLaunchKernelGGL(wrw3x3_s2_kernel<TERMS>, dim3(tiles, p.splits), dim3(256), WRW_S2_LDS_BYTES, 0, p);
+    return p;
+}
+
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 5;
+    if (argc > 2) {   // ---- stride-2 member only ----
+        {
+            const int n = 3, cs = 128, cb = 64, h = 16, w = 64, hb = 2 * h + 1, wb = 2 * w + 1;
+            const size_t ns = (size_t)n * cs * h * w, nb = (size_t)n * cb * hb * wb, ndw = (size_t)cs * cb * 9;
+            float *sm, *big, *dw; double* ref;
+            CK(hipMalloc(&sm, ns * 4)); CK(hipMalloc(&big, nb * 4)); CK(hipMalloc(&dw, ndw * 4)); CK(hipMalloc(&ref, ndw * 8));
+            fill<<<(ns + 255) / 256, 256>>>(sm, ns, 11u); fill<<<(nb + 255) / 256, 256>>>(big, nb, 23u);
+            naive_wrw_s2<<<cs * cb, 256>>>(sm, big, ref, n, cs, cb, h, w);
+            std::vector<double> r(ndw); std::vector<float> gpu(ndw);
+            CK(hipMemcpy(r.data(), ref, ndw * 8, hipMemcpyDeviceToHost));
+            for (int terms = 1; terms <= 3; terms += 2) for (int wgs : {256, 4}) {
+                CK(hipMemset(dw, 0, ndw * 4));
+                wrw_s2_params p = terms == 1 ? launch_s2<1>(sm, big, dw, n, cs, cb, h, w, wgs) : launch_s2<3>(sm, big, dw, n, cs, cb, h, w, wgs);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(gpu.data(), dw, ndw * 4, hipMemcpyDeviceToHost));
+                double maxerr = 0, maxref = 0, sq = 0, sqr = 0; size_t worst = 0;
+                for (size_t k = 0; k < ndw; k++) { double e = fabs(gpu[k] - r[k]); if (!(e <= maxerr)) { maxerr = e; worst = k; } if (fabs(r[k]) > maxref) maxref = fabs(r[k]); sq += e * e; sqr += r[k] * r[k]; }
+                printf("check s2 terms=%d splits=%d: max abs err %.3e (max |ref| %.3e, rel-L2 %.3e) worst at cs=%zu cb=%zu tap=%zu gpu=%f ref=%f\n", terms, p.splits, maxerr, maxref,
+                       sqrt(sq / sqr), worst / 9 / cb, (worst / 9) % cb, worst % 9, gpu[worst], r[worst]);
+            }
+            CK(hipFree(sm)); CK(hipFree(big)); CK(hipFree(dw)); CK(hipFree(ref));
+        }
+        struct { const char* name; int n, cb, cs, r; } sh[] = { {"big 64ch 257^2 | small 128ch 128^2", 96, 64, 128, 128}, {"big 128ch 129^2 | small 256ch 64^2", 96, 128, 256, 64}, {"big 256ch 65^2 | small 512ch 32^2", 96, 256, 512, 32} };
+        for (auto& s : sh) {
+            const int hb = 2 * s.r + 1;
+            const size_t ns = (size_t)s.n * s.cs * s.r * s.r, nb = (size_t)s.n * s.cb * hb * hb, ndw = (size_t)s.cs * s.cb * 9;
+            float *sm, *big, *dw;
+            CK(hipMalloc(&sm, ns * 4)); CK(hipMalloc(&big, nb * 4)); CK(hipMalloc(&dw, ndw * 4));
+            fill<<<(ns + 255) / 256, 256>>>(sm, ns, 5u); fill<<<(nb + 255) / 256, 256>>>(big, nb, 7u);
+            const double flops = 2.0 * s.n * s.r * s.r * (double)s.cs * s.cb * 9;
+            for (int terms = 1; terms <= 3; terms += 2) {
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                if (terms == 1) launch_s2<1>(sm, big, dw, s.n, s.cs, s.cb, s.r, s.r, 256); else launch_s2<3>(sm, big, dw, s.n, s.cs, s.cb, s.r, s.r, 256);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0));
+                for (int r = 0; r < reps; r++) { if (terms == 1) launch_s2<1>(sm, big, dw, s.n, s.cs, s.cb, s.r, s.r, 256); else launch_s2<3>(sm, big, dw, s.n, s.cs, s.cb, s.r, s.r, 256); }
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+                printf("%-38s terms=%d  %8.3f ms  %7.1f TFLOP/s (fp32-equivalent)  %6.1f GB/s of input\n", s.name, terms, ms, flops / ms / 1e9, (ns + nb) * 4.0 / ms / 1e6);
+            }
+            CK(hipFree(sm)); CK(hipFree(big)); CK(hipFree(dw));
+        }
+        return 0;
+    }
     // ---- correctness ----
     {
         const int n = 3, o = 64, i = 128, h = 64, w = 64;
