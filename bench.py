@@ -15,8 +15,9 @@ every 16th, each followed by nan_to_num + Adam, then the G_ema update.  Per-GPU 
 (weak scaling): `--batch-gpu` videos x 3 frames per rank; DDP all-reduces G/D gradients over RCCL.
 
 The single JSON line carries, besides the contract fields:
-  roofline      the hand-written upfirdn2d lane-exchange kernel (every upfirdn2d call of the step selects it): algorithmic bytes / HIP-event time summed over
-                every launch inside the timed steps (events recorded by the C ABI on the launch stream)
+  roofline      the dominant hand-written kernel family of the step (largest summed time; the 3x3 convolution kernels): algorithmic flops (or bytes) /
+                HIP-event time summed over every launch inside the timed steps (events recorded by the C ABI on the launch stream)
+  roofline_upfirdn2d  the same for the upfirdn2d lane-exchange kernel against the HBM roofline (second half of BASELINE.json's metric)
   kernels       the same accounting for every native kernel family
   cpu_baseline  the same training step on the host CPU through the plain-PyTorch op path (a restatement
                 of the reference's CPU fallback ops), on a bounded sample (1 video = 3 frames per step)
@@ -35,6 +36,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling 6290 GB/s
 HBM_COPY_GBPS = 6290.0
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md); the fp32-input MFMA peaks at 157.3
 
 
 def log(*a):
@@ -121,6 +123,7 @@ def main():
         torch.distributed.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     from stylegan_v_amd.torch_utils import custom_ops
+    from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
     from stylegan_v_amd.training import config as cfgs
     from stylegan_v_amd.training.train_step import TrainStep
     custom_ops.verbosity = 'none' if rank else 'brief'
@@ -178,9 +181,12 @@ def main():
     frames_total = global_batch * args.frames * args.steps
     value = frames_total / elapsed
 
+    F32_LABEL = 'f32' if conv2d_gradfix.native_conv_terms == 0 and conv2d_gradfix.native_wrw_terms == 0 else \
+        'f32 tensors, f32 accumulation; 3x3 convolutions multiply on the bf16 matrix pipe with hi/lo operand splitting (bf16x3 fp32 emulation, 4e-6 rel. error vs fp64)'
     if rank == 0:
         kernels = {}
         roofline = None
+        roofline_ufd = None
         if prof is not None:
             for name, e in prof.items():
                 if e['launches'] == 0:
@@ -195,24 +201,47 @@ def main():
             r = prof['upfirdn2d_lanes']
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-                roofline = dict(kernel='upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
-                                frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch(), launches=r['launches'],
-                                traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, profiles/r01_pmc_bench_step_FETCH_WRITE.json (reads x2, gfx950 correction)',
-                                avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
-                                note='all launches inside the timed steps (every layer size, fwd+bwd+double-bwd), size-weighted')
+                roofline_ufd = dict(kernel='upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
+                                    frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch(), launches=r['launches'],
+                                    traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, profiles/r01_pmc_bench_step_FETCH_WRITE.json (reads x2, gfx950 correction)',
+                                    avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
+                                    note='all launches inside the timed steps (every layer size, fwd+bwd+double-bwd), size-weighted')
+            # The contract's `roofline` is the dominant hand-written kernel family of the step (largest summed HIP-event time).
+            dom = max((n for n in prof if prof[n]['launches']), key=lambda n: prof[n]['ms'], default=None)
+            if dom in ('conv3x3', 'conv_wrw'):
+                e = prof[dom]
+                terms = conv2d_gradfix.native_conv_terms if dom == 'conv3x3' else conv2d_gradfix.native_wrw_terms
+                achieved = e['flops'] / (e['ms'] * 1e-3) / 1e12
+                peak = MFMA_BF16_PEAK_TFLOPS / terms
+                roofline = dict(kernel={'conv3x3': 'conv3x3_kernel / conv3x3_s2_kernel / convT3x3_s2_kernel', 'conv_wrw': 'wrw3x3_kernel / wrw3x3_s2_kernel'}[dom], bound='mfma',
+                                achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=None, launches=e['launches'],
+                                avg_launch_us=1e3 * e['ms'] / e['launches'], algorithmic_flops_per_launch=e['flops'] / e['launches'],
+                                executed_bf16_TFLOPs=achieved * terms, bf16_dense_peak_TFLOPs=MFMA_BF16_PEAK_TFLOPS, fp32_mfma_peak_TFLOPs=157.3,
+                                note=f'algorithmic flops = 2*N*H*W*Cin*Cout*9 (fp32-equivalent); the kernel issues {terms} bf16 MFMAs per product (hi/lo split, fp32 accumulate), '
+                                     f'so its ceiling is the bf16 dense peak / {terms}; all launches of the family inside the timed steps, flop-weighted')
+            elif dom == 'gemm':
+                e = prof[dom]
+                achieved = e['flops'] / (e['ms'] * 1e-3) / 1e12
+                roofline = dict(kernel='gemm_f32_kernel', bound='mfma', achieved=achieved, peak=157.3, unit='TFLOP/s', frac=achieved / 157.3, traffic=None, launches=e['launches'])
+            elif dom is not None and dom != 'upfirdn2d_lanes':
+                e = prof[dom]
+                achieved = e['bytes'] / (e['ms'] * 1e-3) / 1e9
+                roofline = dict(kernel=dom, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS, traffic=None, launches=e['launches'])
+            else:
+                roofline = roofline_ufd
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             log('[bench] timing the CPU baseline leg ...')
             cpu = cpu_baseline(args.res, args.frames, args.cpu_seconds)
         out = dict(metric='G+D train-step images/sec at 256^2', value=value, unit='img/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype={'none': 'f32', 'fp16': 'f16 (blocks >= 32^2; f32 accumulate, f32 master weights)', 'bf16': 'bf16 (blocks >= 32^2; f32 accumulate, f32 master weights)'}[args.lowp], data='synthetic',
+                   dtype={'none': F32_LABEL, 'fp16': 'f16 (blocks >= 32^2; f32 accumulate, f32 master weights)', 'bf16': 'bf16 (blocks >= 32^2; f32 accumulate, f32 master weights)'}[args.lowp], data='synthetic',
                    config=dict(workload=f'FFS {args.res}x{args.res} full G+D train step (Gmain+Greg+Dmain+Dreg/R1), cfg=auto fmaps 0.5, ' + ('fp32' if lowp is None else args.lowp + ' mixed precision') + ', aug=noaug',
                                videos_per_gpu=args.batch_gpu, frames_per_video=args.frames, frames_per_gpu=args.batch_gpu * args.frames,
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
                                native_launches_per_step=launches / args.steps),
-                   roofline=roofline, kernels=kernels, cpu_baseline=cpu)
+                   roofline=roofline, roofline_upfirdn2d=roofline_ufd, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -212,24 +212,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
                 a[hf][0] = ws[((0 * 9 + tap) * 2 + g) * TM + hf * 32 + l32];
                 if (TERMS > 1) a[hf][1] = ws[((1 * 9 + tap) * 2 + g) * TM + hf * 32 + l32];
             }
+            // B operands of the wave's 4 rows first, then three passes over the 8 accumulators: an MFMA never waits for the
+            // accumulator written by the one just before it.
+            u32x4 b_hi[4], b_lo[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int pos = (g * RIN + 4 * wave + r + ky) * PIN + l32 + kx;
-                const u32x4 b_hi = xs[pos];
-                u32x4 b_lo;
-                if (TERMS > 1) b_lo = xs[2 * XS_PLANE + pos];
-                if (TERMS > 1) {
+                b_hi[r] = xs[pos];
+                if (TERMS > 1) b_lo[r] = xs[2 * XS_PLANE + pos];
+            }
+            if (TERMS > 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][1]), __builtin_bit_cast(bf16x8, b_hi), acc[r][hf], 0, 0, 0);
+                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][1]), __builtin_bit_cast(bf16x8, b_hi[r]), acc[r][hf], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_lo), acc[r][hf], 0, 0, 0);
-                }
+                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_lo[r]), acc[r][hf], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
-                    acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_hi), acc[r][hf], 0, 0, 0);
-            }
+                    acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_hi[r]), acc[r][hf], 0, 0, 0);
         }
 
         if (c == chunks - 1) {
