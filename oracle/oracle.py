@@ -160,3 +160,56 @@ def time_encode(periods, phases, al, ar, freqs, phase_scales, t, t_left, t_right
     rem = pos(t_left) * (1 - a) + pos(t_right) * a
     add = al.double().numpy() * (1 - a) + ar.double().numpy() * a
     return torch.from_numpy(pos(t) - rem + add)
+
+
+# ----------------------------------------------------------------------------------------------
+# 3x3 convolutions.  The reference leaves them to ATen / cuDNN (call sites: conv2d_gradfix.py:35-43 `conv2d` /
+# `conv_transpose2d`, :100-118 data gradient, :140-170 weight gradient; conv2d_resample.py:113-137 for the stride-2 forms) --
+# third-party arithmetic pinned by the reference only as "pytorch 1.7.1 / 1.9" (environment.yaml:9-11), no tests or golden
+# vectors at that boundary: parity there is UNPINNED against the reference itself.  The restatement below is the textbook
+# definition in float64 (tap loop + channel contraction); tests/test_oracle.py checks it against torch's CPU float64
+# `F.conv2d` / `F.conv_transpose2d`, the same ATen entry points the reference calls.
+
+def conv3x3(x, w, stride=1, transposed=False):
+    """float64 direct 3x3 convolution on NCHW.
+    stride 1: padding 1.  `transposed=False`: y[n,m,Y,X] = sum w[m,k,ky,kx] x[n,k,s*Y+ky-p,s*X+kx-p];  stride 2: padding 0.
+    `transposed=True` (w is [K, M, 3, 3], conv_transpose2d semantics): y[n,m,s*Y+ky-p,s*X+kx-p] += w[k,m,ky,kx] x[n,k,Y,X]."""
+    x = np.asarray(x, dtype=np.float64)
+    w = np.asarray(w, dtype=np.float64)
+    assert stride in (1, 2) and x.ndim == 4 and w.shape[2:] == (3, 3)
+    pad = 1 if stride == 1 else 0
+    n, k, h, wd = x.shape
+    if not transposed:
+        assert w.shape[1] == k
+        ho, wo = (h + 2 * pad - 3) // stride + 1, (wd + 2 * pad - 3) // stride + 1
+        xp = np.pad(x, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+        y = np.zeros([n, w.shape[0], ho, wo])
+        for ky in range(3):
+            for kx in range(3):
+                y += np.einsum('mk,nkhw->nmhw', w[:, :, ky, kx], xp[:, :, ky:ky + stride * (ho - 1) + 1:stride, kx:kx + stride * (wo - 1) + 1:stride])
+        return y
+    assert w.shape[0] == k
+    ho, wo = (h - 1) * stride - 2 * pad + 3, (wd - 1) * stride - 2 * pad + 3
+    full = np.zeros([n, w.shape[1], (h - 1) * stride + 3, (wd - 1) * stride + 3])
+    for ky in range(3):
+        for kx in range(3):
+            full[:, :, ky:ky + stride * (h - 1) + 1:stride, kx:kx + stride * (wd - 1) + 1:stride] += np.einsum('km,nkhw->nmhw', w[:, :, ky, kx], x)
+    return full[:, :, pad:pad + ho, pad:pad + wo]
+
+
+def conv3x3_weight_grad(dy, x, stride=1, transposed=False):
+    """float64 gradient of <dy, conv3x3(x, w)> with respect to w (same layout as w)."""
+    dy = np.asarray(dy, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    pad = 1 if stride == 1 else 0
+    if transposed:   # y[.., s*Y+ky-p, ..] += w[k,m] x[k,Y]  ->  dw[k,m,ky,kx] = sum x[n,k,Y,X] dy[n,m,s*Y+ky-p,s*X+kx-p]
+        small, big = x, dy
+    else:            # dw[m,k,ky,kx] = sum dy[n,m,Y,X] x[n,k,s*Y+ky-p,s*X+kx-p]
+        small, big = dy, x
+    hs, ws = small.shape[2:]
+    bp = np.pad(big, ((0, 0), (0, 0), (pad, pad), (pad, pad)))
+    dw = np.zeros([small.shape[1], big.shape[1], 3, 3])
+    for ky in range(3):
+        for kx in range(3):
+            dw[:, :, ky, kx] = np.einsum('nshw,nbhw->sb', small, bp[:, :, ky:ky + stride * (hs - 1) + 1:stride, kx:kx + stride * (ws - 1) + 1:stride])
+    return dw

@@ -33,7 +33,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TM = 64;            // output channels per workgroup
-constexpr int TROWS = 16;         // output rows per workgroup (4 per wave)
+constexpr int TROWS = 16;         // output rows per workgroup in the default configuration (RW = 4 rows per wave)
 constexpr int SEG = 32;           // output pixels per row
 constexpr int KC = 16;            // input channels per chunk (= MFMA k)
 constexpr int RIN = TROWS + 2;    // input rows per tile
@@ -42,6 +42,7 @@ constexpr int XS_PLANE = RIN * PIN;             // 16-B words per (hi/lo, octet)
 constexpr int XS_WORDS = 2 * 2 * XS_PLANE;      // u32x4 words
 constexpr int WS_WORDS = 2 * 9 * 2 * TM;        // [hl][tap][octet][64 m] u32x4 words
 constexpr int LDS_BYTES = (XS_WORDS + WS_WORDS) * 16;
+constexpr int lds_bytes_rw(int rw) { return (4 * (4 * rw + 2) * PIN + WS_WORDS) * 16; }
 
 struct conv_params {
     const float* x;        // [n, k, h, w]
@@ -77,20 +78,24 @@ struct stage_regs {
 
 struct tile_pos { int n, y0, x0, mt; };
 
-__device__ __forceinline__ tile_pos decode_tile(const conv_params& p, int tile) {
-    const int mts = p.m / TM, segs = p.w / SEG, rbs = p.h / TROWS;
+__device__ __forceinline__ tile_pos decode_tile(const conv_params& p, int tile, int trows = TROWS) {
+    const int mts = p.m / TM, segs = p.w / SEG, rbs = p.h / trows;
     tile_pos tp;
     tp.mt = tile % mts;
     int r = tile / mts;
     tp.x0 = (r % segs) * SEG;
     r /= segs;
-    tp.y0 = (r % rbs) * TROWS;
+    tp.y0 = (r % rbs) * trows;
     tp.n = r / rbs;
     return tp;
 }
 
-template <int TERMS>
-__global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
+// ABL (tools/conv_lab.hip only): 1 = skip the weight copy, 2 = skip the x split + LDS fill, 3 = skip the global loads, 4 = skip the MFMAs.
+// RW = output rows per wave: 4 (tile 16 rows, one workgroup per CU) or 2 (tile 8 rows, <= 256 registers and 59 KiB LDS: two workgroups per
+// CU, so that one's LDS fill overlaps the other's MFMAs).
+template <int TERMS, int ABL = 0, int RW = 4>
+__global__ __launch_bounds__(256, RW == 4 ? 1 : 2) void conv3x3_kernel(conv_params p) {
+    constexpr int TROWS = 4 * RW, RIN = TROWS + 2, XS_PLANE = RIN * PIN, XS_WORDS = 4 * XS_PLANE, ITEMS = 16 * RIN;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     u32x4* xs = lds;                // [hl][octet][row][px]
     u32x4* ws = lds + XS_WORDS;     // [hl][tap][octet][m]
@@ -102,27 +107,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
     const size_t plane = (size_t)p.h * p.w;
 
     // loader roles
-    const int a_oct = t & 1, a_quad = (t >> 1) & 7, a_row = t >> 4;            // item t: rows 0..15
-    const int b_row = 16 + (t >> 4);                                           // item t + 256 (t < 32): rows 16, 17
-    const int h_oct = t & 1, h_side = (t >> 1) & 1, h_row = t >> 2;            // halo item (t < 72)
+    const int a_oct = t & 1, a_quad = (t >> 1) & 7, a_row = t >> 4;            // item t (< ITEMS): rows 0..15
+    const int b_row = 16 + (t >> 4);                                           // item t + 256 (< ITEMS): rows 16, 17
+    const int h_oct = t & 1, h_side = (t >> 1) & 1, h_row = t >> 2;            // halo item (t < 4 * RIN)
 
     auto load_chunk = [&](const tile_pos& tp, int c, stage_regs& s) {
         const float* xb = p.x + ((size_t)tp.n * p.k + c * KC) * plane + tp.x0;
-        {
+        if (t < ITEMS) {
             const int gy = tp.y0 - 1 + a_row;
             const bool ok = gy >= 0 && gy < p.h;
             const float* q = xb + (size_t)(8 * a_oct) * plane + (size_t)gy * p.w + 4 * a_quad;
 #pragma unroll
             for (int j = 0; j < 8; j++) s.xa[j] = ok ? *(const f32x4*)(q + j * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (t < 32) {
+        if (t + 256 < ITEMS) {
             const int gy = tp.y0 - 1 + b_row;
             const bool ok = gy < p.h;
             const float* q = xb + (size_t)(8 * a_oct) * plane + (size_t)gy * p.w + 4 * a_quad;
 #pragma unroll
             for (int j = 0; j < 8; j++) s.xb[j] = ok ? *(const f32x4*)(q + j * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        if (t < 72) {
+        if (t < 4 * RIN) {
             const int gy = tp.y0 - 1 + h_row;
             const int gx = h_side ? tp.x0 + SEG : tp.x0 - 1;
             const bool ok = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
@@ -136,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
     };
 
     auto store_chunk = [&](const stage_regs& s) {
-        {
+        if (ABL != 2 && t < ITEMS) {
             const int base = (a_oct * RIN + a_row) * PIN + 1 + 4 * a_quad;
 #pragma unroll
             for (int px = 0; px < 4; px++) {
@@ -149,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
                 if (TERMS > 1) xs[2 * XS_PLANE + base + px] = lo;
             }
         }
-        if (t < 32) {
+        if (t + 256 < ITEMS && ABL != 2) {
             const int base = (a_oct * RIN + b_row) * PIN + 1 + 4 * a_quad;
 #pragma unroll
             for (int px = 0; px < 4; px++) {
@@ -162,20 +167,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
                 if (TERMS > 1) xs[2 * XS_PLANE + base + px] = lo;
             }
         }
-        if (t < 72) {
+        if (t < 4 * RIN && ABL != 2) {
             u32x4 hi, lo;
             split8(s.xh, hi, lo);
             const int pos = (h_oct * RIN + h_row) * PIN + (h_side ? SEG + 1 : 0);
             xs[pos] = hi;
             if (TERMS > 1) xs[2 * XS_PLANE + pos] = lo;
         }
+        if (ABL != 1) {
 #pragma unroll
-        for (int j = 0; j < 9; j++) ws[t + j * 256] = s.wv[j];
+            for (int j = 0; j < 9; j++) ws[t + j * 256] = s.wv[j];
+        }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[RW][2];
 #pragma unroll
-    for (int r = 0; r < 4; r++)
+    for (int r = 0; r < RW; r++)
 #pragma unroll
         for (int hf = 0; hf < 2; hf++)
 #pragma unroll
@@ -183,7 +190,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
 
     int tile = blockIdx.x;
     if (tile >= p.tiles) return;
-    tile_pos tp = decode_tile(p, tile);
+    tile_pos tp = decode_tile(p, tile, TROWS);
     int c = 0;
     {
         stage_regs s;
@@ -198,13 +205,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
         if (nc == chunks) { nc = 0; ntile = tile + p.grid; }
         const bool more = ntile < p.tiles;
         tile_pos ntp = tp;
-        if (more && nc == 0) ntp = decode_tile(p, ntile);
+        if (more && nc == 0) ntp = decode_tile(p, ntile, TROWS);
         stage_regs s;
-        if (more) load_chunk(ntp, nc, s);
+        if (more && ABL != 3) load_chunk(ntp, nc, s);
 
         // ---- 216 MFMAs on chunk c ----
 #pragma unroll
-        for (int tap = 0; tap < 9; tap++) {
+        for (int tap = 0; tap < (ABL == 4 ? 0 : 9); tap++) {
             const int ky = tap / 3, kx = tap % 3;
             u32x4 a[2][2];   // [half][hl]
 #pragma unroll
@@ -214,27 +221,27 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
             }
             // B operands of the wave's 4 rows first, then three passes over the 8 accumulators: an MFMA never waits for the
             // accumulator written by the one just before it.
-            u32x4 b_hi[4], b_lo[4];
+            u32x4 b_hi[RW], b_lo[RW];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int pos = (g * RIN + 4 * wave + r + ky) * PIN + l32 + kx;
+            for (int r = 0; r < RW; r++) {
+                const int pos = (g * RIN + RW * wave + r + ky) * PIN + l32 + kx;
                 b_hi[r] = xs[pos];
                 if (TERMS > 1) b_lo[r] = xs[2 * XS_PLANE + pos];
             }
             if (TERMS > 1) {
 #pragma unroll
-                for (int r = 0; r < 4; r++)
+                for (int r = 0; r < RW; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
                         acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][1]), __builtin_bit_cast(bf16x8, b_hi[r]), acc[r][hf], 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 4; r++)
+                for (int r = 0; r < RW; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
                         acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_lo[r]), acc[r][hf], 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < RW; r++)
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
                     acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_hi[r]), acc[r][hf], 0, 0, 0);
@@ -242,9 +249,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
 
         if (c == chunks - 1) {
             // C layout: col (pixel) = lane & 31, row (m) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): 128-B contiguous stores
-            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane + (size_t)(tp.y0 + 4 * wave) * p.w + tp.x0 + l32;
+            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane + (size_t)(tp.y0 + RW * wave) * p.w + tp.x0 + l32;
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < RW; r++)
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
 #pragma unroll
@@ -256,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_kernel(conv_params p) {
         }
         if (!more) break;
         __syncthreads();      // every wave is done reading chunk c
-        store_chunk(s);
+        if (ABL != 3) store_chunk(s);
         __syncthreads();
         tile = ntile; c = nc; tp = ntp;
     }

@@ -132,3 +132,26 @@ def test_conv3x3_stride2_gradients_first_and_second_order():
     want = run(F.conv2d, xr, wr)
     for a, r, name in zip(got, want, ['y', 'dx', 'dw', 'd2x', 'd2w']):
         assert_close(a, r, atol=3e-5 * r.abs().max().item(), rtol=1e-4, what=name)
+
+
+@pytest.mark.parametrize('stride,transposed', [(1, False), (1, True), (2, False), (2, True)])
+def test_conv3x3_family_vs_oracle(stride, transposed):
+    """All four geometries and their weight gradients against oracle/oracle.py (float64 textbook definition)."""
+    import oracle
+    g = torch.Generator().manual_seed(10 + stride * 2 + transposed)
+    h, w = (17, 65) if (stride == 2 and not transposed) else (16, 32) if stride == 1 else (8, 32)
+    x = torch.randn([2, 64, h, w], generator=g)
+    wt = torch.randn([64, 64, 3, 3], generator=g) / 24
+    xg, wg = x.to(DEV), wt.to(DEV).requires_grad_(True)
+    op = conv2d_gradfix.conv_transpose2d if transposed else conv2d_gradfix.conv2d
+    custom_ops.prof_enable(64)
+    y = op(xg, wg, stride=stride, padding=1 if stride == 1 else 0)
+    dy = torch.randn(y.shape, generator=g)
+    gw, = torch.autograd.grad(y, [wg], dy.to(DEV))
+    custom_ops.prof_disable()
+    prof = custom_ops.prof_collect()
+    assert prof['conv3x3']['launches'] == 1 and prof['conv_wrw']['launches'] == 1
+    for got, ref, what in ((y, oracle.conv3x3(x.numpy(), wt.numpy(), stride=stride, transposed=transposed), 'y'),
+                           (gw, oracle.conv3x3_weight_grad(dy.numpy(), x.numpy(), stride=stride, transposed=transposed), 'dw')):
+        l2, mx = _rel(got.detach(), torch.as_tensor(ref))
+        assert l2 < 1e-5 and mx < 1e-5, (what, l2, mx)

@@ -1,5 +1,6 @@
 """Pins the CPU oracle (oracle/) against golden vectors produced by the reference's own Python
 implementations (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
 import pytest
 import torch
 
@@ -122,3 +123,24 @@ def test_bias_act_16bit_rounding():
         y = oracle.bias_act(x.to(dt), b.to(dt), act='lrelu')
         exact = oracle.bias_act(x.to(dt).float(), b.to(dt).float(), act='lrelu')
         assert torch.equal(y, exact.to(dt))
+
+
+@pytest.mark.parametrize('stride,transposed', [(1, False), (1, True), (2, False), (2, True)])
+def test_conv3x3_oracle_vs_aten_float64(stride, transposed):
+    """The reference's convolutions are ATen calls (conv2d_gradfix.py:35-43); the oracle's textbook restatement must agree with
+    torch's CPU float64 kernels for the four geometries of the hot path, values and weight gradients."""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(stride * 2 + transposed)
+    n, k, m = 2, 5, 7
+    h, w = (9, 11) if not (stride == 2 and not transposed) else (9, 13)
+    x = torch.randn([n, k, h, w], generator=g, dtype=torch.float64)
+    wt = torch.randn([k, m, 3, 3] if transposed else [m, k, 3, 3], generator=g, dtype=torch.float64, requires_grad=True)
+    pad = 1 if stride == 1 else 0
+    y = (F.conv_transpose2d if transposed else F.conv2d)(x, wt, stride=stride, padding=pad)
+    got = oracle.conv3x3(x.numpy(), wt.detach().numpy(), stride=stride, transposed=transposed)
+    assert got.shape == tuple(y.shape)
+    assert np.abs(got - y.detach().numpy()).max() < 1e-12
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    dw, = torch.autograd.grad(y, wt, dy)
+    got_dw = oracle.conv3x3_weight_grad(dy.numpy(), x.numpy(), stride=stride, transposed=transposed)
+    assert np.abs(got_dw - dw.numpy()).max() < 1e-11

@@ -86,5 +86,58 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep));
     }
+    for (auto& s : shapes) {   // ---- RW = 2 variant: 8-row tiles, two workgroups per CU ----
+        const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
+        float *x, *w, *y; u32x4* wprep; double* ref = nullptr;
+        CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
+        fill<<<(na + 255) / 256, 256>>>(x, na, 5u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 7u, 0.1f);
+        launch<3>(x, w, y, wprep, s.n, s.c, s.c, s.r, s.r, 0, 256);   // reference result + prepared weights
+        std::vector<float> a(1 << 20), b(1 << 20);
+        CK(hipMemcpy(a.data(), y + na / 2, a.size() * 4, hipMemcpyDeviceToHost));
+        conv_params p{};
+        p.x = x; p.wprep = wprep; p.y = y; p.n = s.n; p.k = s.c; p.m = s.c; p.h = s.r; p.w = s.r;
+        p.tiles = s.n * (s.r / 8) * (s.r / SEG) * (s.c / TM);
+        CK(hipFuncSetAttribute((const void*)conv3x3_kernel<3, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes_rw(2)));
+        for (int grid : {512, 768}) {
+            p.grid = grid;
+            CK(hipMemset(y, 0, na * 4));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            hipLaunchKernelGGL((conv3x3_kernel<3, 0, 2>), dim3(grid), dim3(256), lds_bytes_rw(2), 0, p);
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(b.data(), y + na / 2, b.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0; for (size_t i = 0; i < a.size(); i++) md = fmax(md, fabs((double)a[i] - b[i]));
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; r++) hipLaunchKernelGGL((conv3x3_kernel<3, 0, 2>), dim3(grid), dim3(256), lds_bytes_rw(2), 0, p);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            printf("%-12s RW=2 terms=3 grid=%3d  %8.3f ms  %7.1f TFLOP/s   max |diff| vs RW=4: %.2e\n", s.name, grid, ms, 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9 / ms / 1e9, md);
+        }
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep)); (void)ref;
+    }
+    {   // ---- ablations on the 128ch 128^2 layer (timing only; results are wrong by construction) ----
+        const int n = 96, c = 128, r = 128;
+        const size_t na = (size_t)n * c * r * r, nw = (size_t)c * c * 9;
+        float *x, *w, *y; u32x4* wprep;
+        CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
+        fill<<<(na + 255) / 256, 256>>>(x, na, 5u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 7u, 0.1f);
+        launch<3>(x, w, y, wprep, n, c, c, r, r, 0, 256);
+        conv_params p{};
+        p.x = x; p.wprep = wprep; p.y = y; p.n = n; p.k = c; p.m = c; p.h = r; p.w = r;
+        p.tiles = n * (r / TROWS) * (r / SEG) * (c / TM); p.grid = 256;
+        typedef void (*kern_t)(conv_params);
+        struct { const char* name; kern_t k; } abl[] = { {"full", conv3x3_kernel<3, 0>}, {"no weight LDS copy", conv3x3_kernel<3, 1>}, {"no x split + LDS fill", conv3x3_kernel<3, 2>},
+                                                         {"no global loads / fill", conv3x3_kernel<3, 3>}, {"no MFMAs / LDS reads", conv3x3_kernel<3, 4>} };
+        for (auto& a : abl) {
+            CK(hipFuncSetAttribute((const void*)a.k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            hipLaunchKernelGGL(a.k, dim3(256), dim3(256), LDS_BYTES, 0, p);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int i = 0; i < reps; i++) hipLaunchKernelGGL(a.k, dim3(256), dim3(256), LDS_BYTES, 0, p);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            printf("ablation 128ch 128^2 terms=3: %-26s %8.3f ms\n", a.name, ms);
+        }
+    }
     return 0;
 }
