@@ -140,6 +140,10 @@ typedef struct sgv_bias_act_params {
 } sgv_bias_act_params;
 
 int sgv_bias_act(const sgv_bias_act_params* p, int dtype, void* stream);
+/* grad = 1 form that also accumulates the bias gradient: db[slot][c] += partial sums of the result over channel c (fp32 atomics,
+ * spread over db_slots (a power of two) copies to avoid same-address contention; the caller zero-initialises db[db_slots][size_b]
+ * and adds the slots up).  Replaces `dx.sum([0, 2, 3])` of bias_act.py:185; needs step_b % (16 / sizeof(T)) == 0. */
+int sgv_bias_act_db(const sgv_bias_act_params* p, float* db, int db_slots, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Weight (de)modulation of modulated_conv2d (networks.py:57-62) without the [N,O,I,kh,kw]

@@ -28,6 +28,9 @@ struct ba_params {
     void* y;
     float alpha, gain, clamp;
     int size_x, size_b, step_b;
+    float* db;     // optional: db[channel] += sum of the outputs (bias gradient), fp32 atomics
+    int db_mode;   // 1: every wave lies inside one channel plane (one atomic per wave), 2: one atomic per lane
+    int db_slots;  // db is [db_slots][size_b]: waves spread their atomics over the slots (power of two), the caller adds the slots up
 };
 
 template <typename S> __device__ __forceinline__ S s_exp(S v);
@@ -157,6 +160,19 @@ __global__ __launch_bounds__(256) void bias_act_kernel(ba_params p, int bmode, i
         } else {
             yv[vi] = vo;
         }
+        if (p.db) {   // bias gradient = per-channel sum of what was just written (bias_act.py:185 `dx.sum(...)` of the reference)
+            float part = 0.f;
+#pragma unroll
+            for (int k = 0; k < N; k++) part += (float)sgv_traits<T>::load(&vo.e[k]);
+            const int ch = (xi / p.step_b) % p.size_b + ((vi >> 6) & (p.db_slots - 1)) * p.size_b;
+            if (p.db_mode == 1) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off, 64);
+                if ((threadIdx.x & 63) == 0) atomicAdd(p.db + ch, part);
+            } else {
+                atomicAdd(p.db + ch, part);
+            }
+        }
     }
 
     // Tail (size_x not a multiple of the vector length): handled by the first lanes of block 0.
@@ -199,7 +215,7 @@ ba_fn pick_act(int act, int grad) {
 
 }  // namespace
 
-extern "C" int sgv_bias_act(const sgv_bias_act_params* p, int dtype, void* stream_) {
+static int bias_act_launch(const sgv_bias_act_params* p, float* db, int db_slots, int dtype, void* stream_) {
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "bias_act: params is NULL");
     const size_t es = sgv_dtype_size(dtype);
     if (es == 0) return sgv_fail(SGV_ERR_UNSUPPORTED, "bias_act: unknown dtype %d", dtype);
@@ -238,6 +254,13 @@ extern "C" int sgv_bias_act(const sgv_bias_act_params* p, int dtype, void* strea
     kp.x = p->x; kp.b = p->b; kp.xref = p->xref; kp.yref = p->yref; kp.dy = p->dy; kp.y = p->y;
     kp.alpha = p->alpha; kp.gain = p->gain; kp.clamp = p->clamp;
     kp.size_x = p->size_x; kp.size_b = p->b ? p->size_b : 1; kp.step_b = p->b ? p->step_b : 1;
+    kp.db = db; kp.db_mode = 0; kp.db_slots = db_slots;
+    if (db) {
+        // the fused bias gradient needs one channel per 16-B vector and no scalar tail
+        if (!p->b || bmode != 1 || p->size_x % nvecel != 0) return sgv_fail(SGV_ERR_UNSUPPORTED, "bias_act_db: needs a bias with step_b %% %d == 0 and size_x %% %d == 0", nvecel, nvecel);
+        if (p->grad != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "bias_act_db: only the grad = 1 form produces a bias gradient");
+        kp.db_mode = (p->step_b % (64 * nvecel) == 0) ? 1 : 2;
+    }
 
     const int nvec = p->size_x / nvecel;
     int blocks = (nvec + 255) / 256;
@@ -249,4 +272,14 @@ extern "C" int sgv_bias_act(const sgv_bias_act_params* p, int dtype, void* strea
     sgv_launch_scope scope(SGV_K_BIAS_ACT, stream, bytes);
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, stream, kp, bmode, nt_store);
     return sgv_check_launch("bias_act_kernel");
+}
+
+extern "C" int sgv_bias_act(const sgv_bias_act_params* p, int dtype, void* stream) { return bias_act_launch(p, nullptr, 1, dtype, stream); }
+
+// grad = 1 form that also accumulates the bias gradient: db[slot][c] += partial sums of the result over channel c (fp32 atomics spread over
+// `db_slots` copies to keep same-address contention low; the caller zero-initialises db[db_slots][size_b] and adds the slots up).
+extern "C" int sgv_bias_act_db(const sgv_bias_act_params* p, float* db, int db_slots, int dtype, void* stream) {
+    if (!db) return sgv_fail(SGV_ERR_INVALID_ARG, "bias_act_db: db is NULL");
+    if (db_slots < 1 || (db_slots & (db_slots - 1))) return sgv_fail(SGV_ERR_INVALID_ARG, "bias_act_db: db_slots must be a power of two");
+    return bias_act_launch(p, db, db_slots, dtype, stream);
 }

@@ -78,6 +78,12 @@ struct stage_regs {
 
 struct tile_pos { int n, y0, x0, mt; };
 
+// Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  Consecutive tile indices differ in the output-channel
+// tile and read the same x tile, so workgroup i takes the i-th entry of a per-XCD contiguous range: neighbours in tile order share an L2.
+__device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
+    return (nblocks & 7) == 0 ? (bid & 7) * (nblocks >> 3) + (bid >> 3) : bid;
+}
+
 __device__ __forceinline__ tile_pos decode_tile(const conv_params& p, int tile, int trows = TROWS) {
     const int mts = p.m / TM, segs = p.w / SEG, rbs = p.h / trows;
     tile_pos tp;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256, RW == 4 ? 1 : 2) void conv3x3_kernel(conv_para
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[r][hf][e] = 0.f;
 
-    int tile = blockIdx.x;
+    int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     if (tile >= p.tiles) return;
     tile_pos tp = decode_tile(p, tile, TROWS);
     int c = 0;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_s2_kernel(s2_params p) {
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[r][hf][e] = 0.f;
 
-    int tile = blockIdx.x;
+    int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     if (tile >= p.tiles) return;
     tile_pos tp = decode_tile_s2(p, tile, S_ROWS);
     int c = 0;
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(512, 1) void convT3x3_s2_kernel(s2_params p) {
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[cl][hf][e] = 0.f;
 
-    int tile = blockIdx.x;
+    int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     if (tile >= p.tiles) return;
     tile_pos tp = decode_tile_s2(p, tile, T_ROWS);
     int c = 0;

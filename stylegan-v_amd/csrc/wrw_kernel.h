@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256, 2) void wrw3x3_kernel(wrw_params p) {
     const int wo = (wave >> 1) * 32, wi = (wave & 1) * 32;
     const int r32 = lane & 31, g = lane >> 5;
 
-    const int tile = blockIdx.x;
+    // XCD-aware: workgroups that walk the same units (same split) on different output tiles share one L2
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int vid = (nwg & 7) == 0 ? (lin & 7) * (nwg >> 3) + (lin >> 3) : lin;
+    const int tile = vid % (int)gridDim.x, split = vid / (int)gridDim.x;
     const int o0 = (tile / p.tiles_i) * TO, i0 = (tile % p.tiles_i) * TI;
     const int segs = p.w / SEG, rblocks = p.h / p.rows;
     const size_t plane = (size_t)p.h * p.w;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256, 2) void wrw3x3_kernel(wrw_params p) {
     const int lr = t >> 2, lq = (t & 3) * 8;   // loader role: row (channel) and first pixel
     const int hr = t >> 1, hside = t & 1;      // halo loader role (t < 128)
 
-    for (int u = blockIdx.y; u < p.units; u += p.splits) {
+    for (int u = split; u < p.units; u += p.splits) {
         const int rb = u % rblocks, sg = (u / rblocks) % segs, n = u / (rblocks * segs);
         const int y0 = rb * p.rows, x0 = sg * SEG;
         const float* dyb = p.dy + ((size_t)n * p.o + o0) * plane + x0;
@@ -270,7 +273,9 @@ __global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
     const int lane = t & 63, wave = t >> 6;
     const int wo = (wave >> 1) * 32, wi = (wave & 1) * 32;
     const int r32 = lane & 31, g = lane >> 5;
-    const int tile = blockIdx.x;
+    const int nwg = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const int vid = (nwg & 7) == 0 ? (lin & 7) * (nwg >> 3) + (lin >> 3) : lin;
+    const int tile = vid % (int)gridDim.x, split = vid / (int)gridDim.x;
     const int s0 = (tile / p.tiles_b) * TO, b0 = (tile % p.tiles_b) * TI;
     const int segs = p.w / SEG, rblocks = p.h / p.rows;
     const int hb = 2 * p.h + 1, wb = 2 * p.w + 1;
@@ -286,7 +291,7 @@ __global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
 
     struct big_regs { f32x4 v[4]; float edge; };
 
-    for (int u = blockIdx.y; u < p.units; u += p.splits) {
+    for (int u = split; u < p.units; u += p.splits) {
         const int rb = u % rblocks, sg = (u / rblocks) % segs, n = u / (rblocks * segs);
         const int y0 = rb * p.rows, x0 = sg * SEG;
         const float* sb = p.small + ((size_t)n * p.cs + s0) * plane_s + x0;

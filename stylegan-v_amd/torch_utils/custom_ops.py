@@ -214,6 +214,7 @@ ABI_SYMBOLS = {
     'sgv_upfirdn2d_kernel_kind': (c_int, [ctypes.POINTER(Upfirdn2dParams), c_int]),
     'sgv_upfirdn2d_fused': (c_int, [ctypes.POINTER(Upfirdn2dParams), ctypes.POINTER(FirEpilogue), c_int, c_void_p]),
     'sgv_bias_act': (c_int, [ctypes.POINTER(BiasActParams), c_int, c_void_p]),
+    'sgv_bias_act_db': (c_int, [ctypes.POINTER(BiasActParams), c_void_p, c_int, c_int, c_void_p]),
     'sgv_weight_sqsum': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_demod_coefs': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
     'sgv_scale_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),

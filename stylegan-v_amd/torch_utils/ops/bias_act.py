@@ -85,8 +85,9 @@ def _same_layout(a, b):
     return all(sa == sb and (sa < 2 or ta == tb) for sa, sb, ta, tb in zip(a.shape, b.shape, a.stride(), b.stride()))
 
 
-def _native_call(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp):
-    """One ``sgv_bias_act`` launch on x's current stream; ``None`` marks an absent stream."""
+def _native_call(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp, db=None):
+    """One ``sgv_bias_act`` launch on x's current stream; ``None`` marks an absent stream.  ``db`` (fp32, zero-initialised,
+    one entry per bias element) additionally receives the per-channel sum of the result (``sgv_bias_act_db``)."""
     lib = custom_ops.get_native()
     if x.dtype not in _DTYPE_CODES:
         raise RuntimeError(f'bias_act: unsupported dtype {x.dtype}')
@@ -121,7 +122,10 @@ def _native_call(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp):
                                  grad, act_idx, alpha, gain, clamp, x.numel(), b.numel() if b is not None else 0,
                                  x.stride(dim) if b is not None else 1)
     with custom_ops.device_guard(x):
-        custom_ops.check(lib.sgv_bias_act(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
+        if db is None:
+            custom_ops.check(lib.sgv_bias_act(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
+        else:
+            custom_ops.check(lib.sgv_bias_act_db(p, db.data_ptr(), db.shape[0], _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
     return y
 
 
@@ -145,6 +149,8 @@ class _BiasActFn(torch.autograd.Function):
         keep_x = 'x' in spec.ref or spec.has_2nd_grad
         ctx.cfg = cfg
         ctx.has_b = b is not None
+        ctx.b_shape = tuple(b.shape) if b is not None else None
+        ctx.b_dtype = b.dtype if b is not None else None
         ctx.save_for_backward(x if keep_x else None, b if keep_x else None, y if 'y' in spec.ref else None)
         return y
 
@@ -157,10 +163,71 @@ class _BiasActFn(torch.autograd.Function):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             dx = dy
             if act != 'linear' or gain != 1 or clamp >= 0:
-                dx = _BiasActGradFn.apply(dy, x, b, y, ctx.cfg)
-        if ctx.has_b and ctx.needs_input_grad[1]:
+                if ctx.has_b and ctx.needs_input_grad[1] and _fused_db_ok(dy, ctx.b_shape, dim):
+                    dx, db = _BiasActGradDbFn.apply(dy, x, b, y, ctx.cfg, ctx.b_shape[0], ctx.b_dtype)
+                else:
+                    dx = _BiasActGradFn.apply(dy, x, b, y, ctx.cfg)
+        if ctx.has_b and ctx.needs_input_grad[1] and db is None:
             db = dx.sum([i for i in range(dx.ndim) if i != dim])
         return dx, db, None
+
+
+fused_bias_grad = True   # bias gradient accumulated inside the grad = 1 kernel (one pass over dy less per layer)
+
+
+def _fused_db_ok(dy, b_shape, dim):
+    """The in-kernel bias-gradient sum needs dense NCHW-like storage: a whole 16-byte vector inside one bias element."""
+    if not (fused_bias_grad and dy.is_cuda and dy.is_contiguous() and dy.dtype in (torch.float32, torch.float16, torch.bfloat16)):
+        return False
+    nvec = 16 // dy.element_size()
+    return dy.numel() > 0 and dy.stride(dim) % nvec == 0 and dy.numel() % nvec == 0
+
+
+def _grad_fn_backward(ctx, d_dx):
+    """Shared second-order logic of _BiasActGradFn / _BiasActGradDbFn (the structure of bias_act.py:188-206)."""
+    dim, act, alpha, gain, clamp = ctx.cfg
+    spec = activation_funcs[act]
+    d_dx = _dense_like(d_dx, ctx.memory_format)
+    dy, x, b, y = ctx.saved_tensors
+    d_dy = d_x = d_b = None
+    if ctx.needs_input_grad[0]:
+        d_dy = _BiasActGradFn.apply(d_dx, x, b, y, ctx.cfg)
+    if spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+        d_x = _native_call(d_dx, b, x, y, dy, 2, dim, spec.cuda_idx, alpha, gain, clamp)
+    if spec.has_2nd_grad and b is not None and ctx.needs_input_grad[2]:
+        d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+    return d_dy, d_x, d_b
+
+
+class _BiasActGradDbFn(torch.autograd.Function):
+    """(dx, db) = (d(bias_act)/dx * dy, sum of dx over everything but `dim`) in ONE kernel.  Differentiable like _BiasActGradFn:
+    db = sum(dx), so an incoming d_db is broadcast onto d_dx."""
+
+    @staticmethod
+    def forward(ctx, dy, x, b, y, cfg, nb, b_dtype):
+        dim, act, alpha, gain, clamp = cfg
+        spec = activation_funcs[act]
+        ctx.memory_format = _memory_format_of(dy)
+        slots = 64 if dy.numel() >= (1 << 22) else 1   # big tensors: spread the per-channel atomics over 64 partial rows
+        db32 = torch.zeros([slots, nb], dtype=torch.float32, device=dy.device)
+        bb = b if b is not None else torch.zeros([nb], dtype=dy.dtype, device=dy.device)   # carries size_b / step_b; its values are only read by 'x'-referencing activations
+        dx = _native_call(dy, bb, x, y, None, 1, dim, spec.cuda_idx, alpha, gain, clamp, db=db32)
+        ctx.cfg = cfg
+        ctx.dim = dim
+        ctx.save_for_backward(dy if spec.has_2nd_grad else None, x, b, y)
+        return dx, (db32.sum(0) if slots > 1 else db32[0]).to(b_dtype)
+
+    @staticmethod
+    def backward(ctx, d_dx, d_db):
+        ref = next(t for t in (ctx.saved_tensors[3], ctx.saved_tensors[1], ctx.saved_tensors[0]) if t is not None)   # y, x or dy: same shape as dx
+        if d_dx is None:
+            d_dx = torch.zeros_like(ref)
+        if d_db is not None:
+            view = [1] * ref.ndim
+            view[ctx.dim] = -1
+            d_dx = d_dx + d_db.reshape(view).to(d_dx.dtype)
+        d_dy, d_x, d_b = _grad_fn_backward(ctx, d_dx)
+        return d_dy, d_x, d_b, None, None, None, None
 
 
 class _BiasActGradFn(torch.autograd.Function):
@@ -178,17 +245,7 @@ class _BiasActGradFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_dx):
-        dim, act, alpha, gain, clamp = ctx.cfg
-        spec = activation_funcs[act]
-        d_dx = _dense_like(d_dx, ctx.memory_format)
-        dy, x, b, y = ctx.saved_tensors
-        d_dy = d_x = d_b = None
-        if ctx.needs_input_grad[0]:
-            d_dy = _BiasActGradFn.apply(d_dx, x, b, y, ctx.cfg)
-        if spec.has_2nd_grad and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
-            d_x = _native_call(d_dx, b, x, y, dy, 2, dim, spec.cuda_idx, alpha, gain, clamp)
-        if spec.has_2nd_grad and b is not None and ctx.needs_input_grad[2]:
-            d_b = d_x.sum([i for i in range(d_x.ndim) if i != dim])
+        d_dy, d_x, d_b = _grad_fn_backward(ctx, d_dx)
         return d_dy, d_x, d_b, None, None
 
 

@@ -180,10 +180,11 @@ def _native_wrw_kind(dy, x, cfg, w_shape):
         return None
     lib = custom_ops.get_native()
     n, ci, h, w = x.shape
-    if stride == (1, 1) and padding == (1, 1) and not transposed:
+    if stride == (1, 1) and padding == (1, 1):
         if dy.shape[2:] != x.shape[2:]:
             return None
-        return 's1' if lib.sgv_conv3x3_wrw_supported(n, w_shape[0], ci, h, w, 0) else None
+        # a transposed stride-1 layer (only met as a derivative of a convolution) has the same formula with x and dy swapped
+        return 's1' if lib.sgv_conv3x3_wrw_supported(n, dy.shape[1] if not transposed else ci, ci if not transposed else dy.shape[1], h, w, 0) else None
     if stride == (2, 2) and padding == (0, 0) and native_conv_s2:
         small, big = (x, dy) if transposed else (dy, x)
         hs, ws = small.shape[2:]
@@ -202,9 +203,10 @@ def _native_wrw(dy, x, cfg, w_shape):
     kind = _native_wrw_kind(dy, x, cfg, w_shape)
     dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
     if kind == 's1':
-        dyc, xc = dy.contiguous(), x.contiguous()
+        dyc, xc = (x.contiguous(), dy.contiguous()) if cfg[0] else (dy.contiguous(), x.contiguous())   # weight is [dyc channels, xc channels, 3, 3]
         n, ci, h, w = xc.shape
-        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, w_shape[0], ci, h, w, native_wrw_terms)
+        assert tuple(w_shape[:2]) == (dyc.shape[1], ci)
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, native_wrw_terms)
         fn = lib.sgv_conv3x3_wrw
     else:   # the weight is [c_small, c_big, 3, 3] for both the strided ([c_out, c_in]) and the transposed ([c_in, c_out]) layer
         small, big = ((x, dy) if cfg[0] else (dy, x))

@@ -220,3 +220,53 @@ def test_reference_time_encoder_golden_on_gpu():
     t = G.t('t', torch.float32, DEV)
     out = enc(torch.zeros([t.shape[0], 0], device=DEV), t, motion_z=G.t('motion_z', torch.float32, DEV))
     assert_close(out['motion_v'], G.t('motion_v'), atol=1e-3, rtol=1e-3, what='motion_v')
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(4, 8, 16, 16), (3, 5, 6, 6), (2, 64, 64, 64), (5, 7)])
+def test_bias_act_fused_bias_gradient(dtype, shape):
+    """db accumulated inside the grad = 1 kernel (sgv_bias_act_db) equals the reference's dx.sum(...), incl. its own derivative."""
+    from stylegan_v_amd.torch_utils.ops import bias_act
+    g = torch.Generator().manual_seed(len(shape) + shape[1])
+    x = torch.randn(shape, generator=g).to(DEV).to(dtype).requires_grad_(True)
+    b = torch.randn([shape[1]], generator=g).to(DEV).to(dtype).requires_grad_(True)
+    dy = torch.randn(shape, generator=g).to(DEV).to(dtype)
+
+    def grads(fused):
+        bias_act.fused_bias_grad = fused
+        try:
+            y = bias_act.bias_act(x, b, act='lrelu', clamp=1.5)
+            gx, gb = torch.autograd.grad(y, [x, b], dy, create_graph=True)
+            # second order through BOTH outputs of the fused node (d/d(dy) of <gx, u> + <gb, v>)
+            return gx, gb
+        finally:
+            bias_act.fused_bias_grad = True
+    before = custom_ops.launch_count()
+    gx1, gb1 = grads(True)
+    n_fused = custom_ops.launch_count() - before
+    gx0, gb0 = grads(False)
+    assert torch.equal(gx1, gx0)
+    tol = {torch.float32: 1e-5, torch.float16: 2e-3, torch.bfloat16: 1.6e-2}[dtype]
+    assert_close(gb1.float(), gb0.float(), atol=tol * max(1.0, gb0.float().abs().max().item()), rtol=tol, what='db')
+    if len(shape) == 4 and (shape[2] * shape[3]) % (16 // x.element_size()) == 0:
+        assert n_fused == 2   # forward + ONE fused backward kernel
+
+
+def test_bias_act_fused_bias_gradient_is_twice_differentiable():
+    from stylegan_v_amd.torch_utils.ops import bias_act
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn([2, 4, 8, 8], generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn([4], generator=g).to(DEV).requires_grad_(True)
+    u = torch.randn([2, 4, 8, 8], generator=g).to(DEV)
+    v = torch.randn([4], generator=g).to(DEV)
+    dy = torch.randn([2, 4, 8, 8], generator=g).to(DEV).requires_grad_(True)
+
+    def second(fused):
+        bias_act.fused_bias_grad = fused
+        try:
+            y = bias_act.bias_act(x, b, act='lrelu', gain=1.3)
+            gx, gb = torch.autograd.grad(y, [x, b], dy, create_graph=True)
+            return torch.autograd.grad((gx * u).sum() + (gb * v).sum(), [dy])[0]
+        finally:
+            bias_act.fused_bias_grad = True
+    assert_close(second(True), second(False), atol=1e-5, rtol=1e-5)
