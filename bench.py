@@ -43,6 +43,25 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def pmc_traffic_conv_family():
+    """HBM-side (L2 miss) bytes per launch of the 3x3 forward / data-gradient kernels from the committed PMC passes
+    (profiles/r01_pmc_bench_step_v2_FETCH_WRITE.json, same command, collected before the XCD-aware tile order went in).
+    FETCH_SIZE is doubled for the kernels that read with 16-B loads (gfx950 correction, see pmc_traffic_per_launch); the
+    strided kernel reads with dword loads, for which the counter is taken as is."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_bench_step_v2_FETCH_WRITE.json')
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        kb = n = 0.0
+        for name, e in d['FETCH_SIZE'].items():
+            if name.startswith(('conv3x3_kernel', 'conv3x3_small_kernel', 'convT3x3_s2_kernel', 'conv3x3_s2_kernel')):
+                kb += (1.0 if name.startswith('conv3x3_s2_kernel') else 2.0) * e['total_KB'] + d['WRITE_SIZE'][name]['total_KB']
+                n += e['launches']
+        return kb * 1024.0 / n if n else None
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def pmc_traffic_per_launch(prefix='upfirdn2d_lanes'):
     """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes over this same command
     (profiles/r01_pmc_bench_step_FETCH_WRITE.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; on gfx950 FETCH_SIZE
@@ -214,7 +233,9 @@ def main():
                 achieved = e['flops'] / (e['ms'] * 1e-3) / 1e12
                 peak = MFMA_BF16_PEAK_TFLOPS / terms
                 roofline = dict(kernel={'conv3x3': 'conv3x3_kernel / conv3x3_s2_kernel / convT3x3_s2_kernel', 'conv_wrw': 'wrw3x3_kernel / wrw3x3_s2_kernel'}[dom], bound='mfma',
-                                achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=None, launches=e['launches'],
+                                achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=pmc_traffic_conv_family() if dom == 'conv3x3' else None,
+                                traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, profiles/r01_pmc_bench_step_v2_FETCH_WRITE.json (L2-miss bytes: Infinity-Cache hits included)',
+                                algorithmic_bytes_per_launch=e['bytes'] / e['launches'], launches=e['launches'],
                                 avg_launch_us=1e3 * e['ms'] / e['launches'], algorithmic_flops_per_launch=e['flops'] / e['launches'],
                                 executed_bf16_TFLOPs=achieved * terms, bf16_dense_peak_TFLOPs=MFMA_BF16_PEAK_TFLOPS, fp32_mfma_peak_TFLOPs=157.3,
                                 note=f'algorithmic flops = 2*N*H*W*Cin*Cout*9 (fp32-equivalent); the kernel issues {terms} bf16 MFMAs per product (hi/lo split, fp32 accumulate), '

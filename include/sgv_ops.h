@@ -208,6 +208,7 @@ int sgv_conv3x3_wrw_s2_supported(int32_t n, int32_t c_small, int32_t c_big, int3
  *   mode 0:  y[n,m,Y,X] = sum_{k,ky,kx} weight[m][k][ky][kx]     * x[n,k,Y+ky-1,X+kx-1]     weight: [c_out, c_in, 3, 3]
  *   mode 1:  y[n,m,Y,X] = sum_{k,ky,kx} weight[k][m][2-ky][2-kx] * x[n,k,Y+ky-1,X+kx-1]     weight: [c_in, c_out, 3, 3]
  *            (= conv_transpose2d(x, weight, stride 1, padding 1): the gradient w.r.t. the input of the mode-0 layer)
+ * Shapes: c_in % 16 == 0, c_out % 64 == 0, and either w % 32 == 0 && h % 16 == 0 or whole 16x16 / 8x8 images (n % 2 resp. n % 8 == 0).
  * fp32 tensors, arithmetic as sgv_conv3x3_wrw (terms = 3: bf16x3 fp32 emulation; 1: bf16 products).  `workspace` is
  * sgv_conv3x3_workspace_bytes() of device scratch for the re-laid-out weights (owned by the caller, written per call).
  */

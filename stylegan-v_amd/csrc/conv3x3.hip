@@ -14,9 +14,16 @@ using namespace sgv_conv;
 
 namespace {
 
+// small square images (16x16, 8x8): conv3x3_small_kernel packs 2 resp. 8 whole samples into a tile
+int small_samples(int n, int h, int w) {
+    if (h == 16 && w == 16 && n % small_cfg<16>::S == 0) return small_cfg<16>::S;
+    if (h == 8 && w == 8 && n % small_cfg<8>::S == 0) return small_cfg<8>::S;
+    return 0;
+}
+
 bool supported(int n, int k, int m, int h, int w, int dtype) {
-    return dtype == SGV_F32 && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0 &&
-           (int64_t)n * std::max(k, m) * h * w <= INT32_MAX;
+    if (!(dtype == SGV_F32 && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && (int64_t)n * std::max(k, m) * h * w <= INT32_MAX)) return false;
+    return (w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0) || small_samples(n, h, w) > 0;
 }
 
 std::once_flag g_attr_once;
@@ -26,6 +33,10 @@ hipError_t g_attr_err = hipSuccess;
 void init_once() {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<16>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<3, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<16>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<8>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
@@ -55,7 +66,7 @@ extern "C" int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream_
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: params is NULL");
     if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: NULL pointer");
     if (!supported(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, W %% 32 == 0, H %% 16 == 0 (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, and W %% 32 == 0, H %% 16 == 0 or 16x16 / 8x8 images (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_in, p->c_out, p->h, p->w, dtype);
     if (p->mode != 0 && p->mode != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: mode must be 0 (forward) or 1 (data gradient)");
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: terms must be 1 or 3");
@@ -74,10 +85,21 @@ extern "C" int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream_
     conv_params kp{};
     kp.x = (const float*)p->x; kp.wprep = (const u32x4*)p->workspace; kp.y = (float*)p->y;
     kp.n = p->n; kp.k = p->c_in; kp.m = p->c_out; kp.h = p->h; kp.w = p->w;
-    kp.tiles = p->n * (p->h / TROWS) * (p->w / SEG) * (p->c_out / TM);
+    const int small = (p->w >= SEG && p->w % SEG == 0 && p->h % TROWS == 0) ? 0 : small_samples(p->n, p->h, p->w);
+    kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * (p->c_out / TM);
     kp.grid = std::min(kp.tiles, g_cus);
     const double elems = (double)p->n * p->h * p->w;
     sgv_launch_scope scope(SGV_K_CONV3X3, stream, 4.0 * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9);
+    if (small) {
+        if (p->w == 16) {
+            if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
+            else hipLaunchKernelGGL((conv3x3_small_kernel<3, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
+        } else {
+            if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
+            else hipLaunchKernelGGL((conv3x3_small_kernel<3, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
+        }
+        return sgv_check_launch("conv3x3_small_kernel");
+    }
     if (p->terms == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     else hipLaunchKernelGGL(conv3x3_kernel<3>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     return sgv_check_launch("conv3x3_kernel");

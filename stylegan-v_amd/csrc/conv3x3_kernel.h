@@ -275,6 +275,158 @@ __global__ __launch_bounds__(256, RW == 4 ? 1 : 2) void conv3x3_kernel(conv_para
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Small square images (SW x SW, SW = 16 or 8: the 16^2 / 8^2 blocks).  Same MFMA mapping, but the 512 pixels of a workgroup
+// tile are S = 512 / SW^2 WHOLE images (2 at 16^2, 8 at 8^2): a 32-pixel MFMA column block is 32 / SW consecutive image rows.
+// Every halo position of the LDS image (row -1, row SW, column -1, column SW of each sample) is zero padding: it is cleared
+// once at kernel start and never written again; per 16-channel chunk each thread loads exactly one (8 channels x 4 pixels) item.
+template <int SW> struct small_cfg {
+    static constexpr int S = 512 / (SW * SW);        // samples per tile
+    static constexpr int RINS = S * (SW + 2);        // LDS rows
+    static constexpr int PINS = SW + 2;              // LDS columns
+    static constexpr int PLANE = RINS * PINS;        // words per (hl, octet)
+    static constexpr int XS = 4 * PLANE;
+    static constexpr int QPR = SW / 4;               // 4-pixel quads per image row
+    static constexpr int LDS = (XS + WS_WORDS) * 16;
+};
+
+struct small_stage { f32x4 xa[8]; u32x4 wv[9]; };
+
+template <int TERMS, int SW>
+__global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
+    typedef small_cfg<SW> C;
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    u32x4* xs = lds;
+    u32x4* ws = lds + C::XS;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l32 = lane & 31, g = lane >> 5;
+    const int chunks = p.k / KC, mts = p.m / TM;
+    constexpr int PLANE_PX = SW * SW;
+    const size_t plane = PLANE_PX;
+
+    for (int i = t; i < C::XS; i += 256) xs[i] = u32x4{0u, 0u, 0u, 0u};   // zero padding (and everything else, once)
+
+    // loader role: 8 channels (octet) x 4 pixels of image row R of the tile (R = sample * SW + y)
+    const int a_oct = t & 1, a_quad = (t >> 1) % C::QPR, a_R = (t >> 1) / C::QPR;
+    const int a_s = a_R / SW, a_y = a_R % SW;
+    const int a_pos = (a_oct * C::RINS + a_s * (SW + 2) + a_y + 1) * C::PINS + 1 + 4 * a_quad;
+
+    auto load_chunk = [&](int n0, int mt, int c, small_stage& s) {
+        const float* q = p.x + ((size_t)(n0 + a_s) * p.k + c * KC + 8 * a_oct) * plane + a_y * SW + 4 * a_quad;
+#pragma unroll
+        for (int j = 0; j < 8; j++) s.xa[j] = *(const f32x4*)(q + j * plane);
+        const u32x4* wq = p.wprep + ((size_t)mt * chunks + c) * WS_WORDS + t;
+#pragma unroll
+        for (int j = 0; j < 9; j++) s.wv[j] = wq[j * 256];
+    };
+    auto store_chunk = [&](const small_stage& s) {
+#pragma unroll
+        for (int px = 0; px < 4; px++) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = s.xa[j][px];
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            xs[a_pos + px] = hi;
+            if (TERMS > 1) xs[2 * C::PLANE + a_pos + px] = lo;
+        }
+#pragma unroll
+        for (int j = 0; j < 9; j++) ws[t + j * 256] = s.wv[j];
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[r][hf][e] = 0.f;
+
+    // B-operand position of this lane in each of the wave's 4 column blocks (pixels 32 * slot + l32 of the tile)
+    int bpos[4], ypix[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int q = 32 * (4 * wave + r) + l32;
+        const int R = q / SW, px = q % SW, sidx = R / SW, yy = R % SW;
+        bpos[r] = (g * C::RINS + sidx * (SW + 2) + yy) * C::PINS + px;
+        ypix[r] = q;   // pixel index inside the tile: sample = q / SW^2, offset inside the sample plane = q % SW^2
+    }
+
+    int tile = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (tile >= p.tiles) return;
+    int mt = tile % mts, n0 = (tile / mts) * C::S;
+    int c = 0;
+    __syncthreads();   // zero fill complete
+    {
+        small_stage s;
+        load_chunk(n0, mt, 0, s);
+        store_chunk(s);
+        __syncthreads();
+    }
+    while (true) {
+        int ntile = tile, nc = c + 1;
+        if (nc == chunks) { nc = 0; ntile = tile + p.grid; }
+        const bool more = ntile < p.tiles;
+        const int nmt = ntile % mts, nn0 = (ntile / mts) * C::S;
+        small_stage s;
+        if (more) load_chunk(nn0, nmt, nc, s);
+
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+            u32x4 a[2][2];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                a[hf][0] = ws[((0 * 9 + tap) * 2 + g) * TM + hf * 32 + l32];
+                if (TERMS > 1) a[hf][1] = ws[((1 * 9 + tap) * 2 + g) * TM + hf * 32 + l32];
+            }
+            u32x4 b_hi[4], b_lo[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int pos = bpos[r] + ky * C::PINS + kx;
+                b_hi[r] = xs[pos];
+                if (TERMS > 1) b_lo[r] = xs[2 * C::PLANE + pos];
+            }
+            if (TERMS > 1) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++)
+                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][1]), __builtin_bit_cast(bf16x8, b_hi[r]), acc[r][hf], 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++)
+                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_lo[r]), acc[r][hf], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++)
+                    acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_hi[r]), acc[r][hf], 0, 0, 0);
+        }
+
+        if (c == chunks - 1) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float* yb = p.y + ((size_t)(n0 + ypix[r] / PLANE_PX) * p.m + mt * TM) * plane + ypix[r] % PLANE_PX;
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+                        yb[(size_t)m * plane] = acc[r][hf][e];
+                        acc[r][hf][e] = 0.f;
+                    }
+            }
+        }
+        if (!more) break;
+        __syncthreads();
+        store_chunk(s);
+        __syncthreads();
+        tile = ntile; c = nc; mt = nmt; n0 = nn0;
+    }
+}
+
 // Weight re-layout: fp32 -> bf16 hi/lo in [m tile][k chunk][hl][tap][octet][64 m][8 k].
 // mode 0: wgt(m,k,ky,kx) = w[m][k][ky][kx]            (forward;  w is [M, K, 3, 3])
 // mode 1: wgt(m,k,ky,kx) = w[k][m][2-ky][2-kx]        (data gradient of the same layer; w is [K, M, 3, 3])

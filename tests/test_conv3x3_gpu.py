@@ -16,7 +16,8 @@ def _rel(a, ref):
     return ((a - ref).norm() / ref.norm()).item(), ((a - ref).abs().max() / ref.abs().max()).item()
 
 
-@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (1, 16, 128, 16, 64), (3, 128, 64, 48, 32), (1, 80, 192, 32, 96), (5, 32, 64, 16, 32)])
+@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (1, 16, 128, 16, 64), (3, 128, 64, 48, 32), (1, 80, 192, 32, 96), (5, 32, 64, 16, 32),
+                                          (4, 64, 128, 16, 16), (6, 32, 64, 16, 16), (16, 48, 64, 8, 8), (8, 128, 192, 8, 8)])
 @pytest.mark.parametrize('transposed', [False, True])
 def test_conv3x3_matches_fp64(n, ci, co, h, w, transposed):
     g = torch.Generator().manual_seed(n + ci + co + h)
@@ -64,12 +65,14 @@ def test_conv3x3_gradients_first_and_second_order():
 
 def test_conv3x3_unsupported_shapes_use_the_vendor_library():
     lib = custom_ops.get_native()
-    assert lib.sgv_conv3x3_supported(4, 64, 64, 16, 16, 0) == 0   # W < 32
+    assert lib.sgv_conv3x3_supported(3, 64, 64, 16, 16, 0) == 0   # 16x16 images come in pairs
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 8, 8, 0) == 0     # 8x8 images in groups of 8
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 4, 4, 0) == 0
     assert lib.sgv_conv3x3_supported(4, 3, 64, 32, 32, 0) == 0    # c_in % 16
     assert lib.sgv_conv3x3_supported(4, 64, 48, 32, 32, 0) == 0   # c_out % 64
     assert lib.sgv_conv3x3_supported(4, 64, 64, 24, 32, 0) == 0   # H % 16
     assert lib.sgv_conv3x3_supported(4, 64, 64, 32, 32, 2) == 0   # bf16 tensors
-    x = torch.randn([2, 64, 16, 16], device=DEV)
+    x = torch.randn([3, 64, 16, 16], device=DEV)
     w = torch.randn([64, 64, 3, 3], device=DEV, requires_grad=True)
     before = custom_ops.launch_count()
     y = conv2d_gradfix.conv2d(x, w, padding=1)

@@ -66,6 +66,57 @@ int main(int argc, char** argv) {
             CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(ref)); CK(hipFree(wprep));
         }
     }
+    for (int sw : {16, 8}) for (int mode = 0; mode < 2; mode++) {   // ---- small-image kernel: correctness + timing ----
+        const int n = 16, k = 32, m = 128;
+        const size_t nx = (size_t)n * k * sw * sw, ny = (size_t)n * m * sw * sw, nw = (size_t)m * k * 9;
+        float *x, *w, *y; double* ref; u32x4* wprep;
+        CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&y, ny * 4)); CK(hipMalloc(&ref, ny * 8)); CK(hipMalloc(&wprep, nw * 4));
+        fill<<<(nx + 255) / 256, 256>>>(x, nx, 11u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 23u, 0.1f);
+        naive_conv<<<(ny + 255) / 256, 256>>>(x, w, ref, n, k, m, sw, sw, mode);
+        std::vector<double> r(ny); std::vector<float> gpu(ny);
+        CK(hipMemcpy(r.data(), ref, ny * 8, hipMemcpyDeviceToHost));
+        const int total = (m / TM) * (k / KC) * 9 * 2 * TM;
+        hipLaunchKernelGGL(conv3x3_prep_weights, dim3((total + 255) / 256), dim3(256), 0, 0, w, wprep, m, k, mode, 3);
+        conv_params p{};
+        p.x = x; p.wprep = wprep; p.y = y; p.n = n; p.k = k; p.m = m; p.h = sw; p.w = sw;
+        for (int grid : {256, 3}) {
+            CK(hipMemset(y, 0xff, ny * 4));
+            if (sw == 16) { p.tiles = (n / small_cfg<16>::S) * (m / TM); p.grid = grid < p.tiles ? grid : p.tiles;
+                CK(hipFuncSetAttribute((const void*)conv3x3_small_kernel<3, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<16>::LDS));
+                hipLaunchKernelGGL((conv3x3_small_kernel<3, 16>), dim3(p.grid), dim3(256), small_cfg<16>::LDS, 0, p); }
+            else { p.tiles = (n / small_cfg<8>::S) * (m / TM); p.grid = grid < p.tiles ? grid : p.tiles;
+                CK(hipFuncSetAttribute((const void*)conv3x3_small_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<8>::LDS));
+                hipLaunchKernelGGL((conv3x3_small_kernel<3, 8>), dim3(p.grid), dim3(256), small_cfg<8>::LDS, 0, p); }
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(gpu.data(), y, ny * 4, hipMemcpyDeviceToHost));
+            double maxerr = 0, maxref = 0, sq = 0, sqr = 0; size_t worst = 0;
+            for (size_t q = 0; q < ny; q++) { double e = fabs(gpu[q] - r[q]); if (!(e <= maxerr)) { maxerr = e; worst = q; } if (fabs(r[q]) > maxref) maxref = fabs(r[q]); sq += e * e; sqr += r[q] * r[q]; }
+            printf("check small %dx%d mode=%d grid=%d: max abs err %.3e (max |ref| %.3e, rel-L2 %.3e) worst idx %zu gpu=%f ref=%f\n", sw, sw, mode, grid, maxerr, maxref, sqrt(sq / sqr), worst, gpu[worst], r[worst]);
+        }
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(ref)); CK(hipFree(wprep));
+    }
+    for (int sw : {16, 8}) {   // timing at the training shapes: [96, 512, sw, sw] -> 512
+        const int n = 96, c = 512;
+        const size_t na = (size_t)n * c * sw * sw, nw = (size_t)c * c * 9;
+        float *x, *w, *y; u32x4* wprep;
+        CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
+        fill<<<(na + 255) / 256, 256>>>(x, na, 5u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 7u, 0.1f);
+        const int total = (c / TM) * (c / KC) * 9 * 2 * TM;
+        hipLaunchKernelGGL(conv3x3_prep_weights, dim3((total + 255) / 256), dim3(256), 0, 0, w, wprep, c, c, 0, 3);
+        conv_params p{};
+        p.x = x; p.wprep = wprep; p.y = y; p.n = n; p.k = c; p.m = c; p.h = sw; p.w = sw;
+        p.tiles = (n / (512 / (sw * sw))) * (c / TM); p.grid = p.tiles < 256 ? p.tiles : 256;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int it = 0; it < reps + 1; it++) {
+            if (it == 1) CK(hipEventRecord(e0));
+            if (sw == 16) hipLaunchKernelGGL((conv3x3_small_kernel<3, 16>), dim3(p.grid), dim3(256), small_cfg<16>::LDS, 0, p);
+            else hipLaunchKernelGGL((conv3x3_small_kernel<3, 8>), dim3(p.grid), dim3(256), small_cfg<8>::LDS, 0, p);
+        }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        printf("small 512ch %dx%d n=96 terms=3: %8.3f ms  %7.1f TFLOP/s (fp32-equivalent), %d tiles\n", sw, sw, ms, 2.0 * n * sw * sw * (double)c * c * 9 / ms / 1e9, p.tiles);
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep));
+    }
     struct { const char* name; int n, c, r; } shapes[] = { {"64ch 256^2", 96, 64, 256}, {"128ch 128^2", 96, 128, 128}, {"256ch 64^2", 96, 256, 64}, {"512ch 32^2", 96, 512, 32} };
     for (auto& s : shapes) {
         const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
