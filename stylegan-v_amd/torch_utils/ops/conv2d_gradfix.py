@@ -49,6 +49,10 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
     if _use_custom(input):
         cfg = (False, _pair(stride), _pair(padding), (0, 0), _pair(dilation), int(groups))
         return _Conv.apply(input, weight, bias, cfg)
+    if enabled and input.ndim == 4 and bias is None and not torch.is_grad_enabled():   # e.g. the generator pass of the D phase (loss.py:123)
+        cfg = (False, _pair(stride), _pair(padding), (0, 0), _pair(dilation), int(groups))
+        if _native_conv_ok(input, weight, cfg):
+            return _native_conv(input, weight, cfg)
     return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
 
 
@@ -56,6 +60,10 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
     if _use_custom(input):
         cfg = (True, _pair(stride), _pair(padding), _pair(output_padding), _pair(dilation), int(groups))
         return _Conv.apply(input, weight, bias, cfg)
+    if enabled and input.ndim == 4 and bias is None and not torch.is_grad_enabled():
+        cfg = (True, _pair(stride), _pair(padding), _pair(output_padding), _pair(dilation), int(groups))
+        if _native_conv_ok(input, weight, cfg):
+            return _native_conv(input, weight, cfg)
     return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
 

@@ -158,3 +158,17 @@ def test_conv3x3_family_vs_oracle(stride, transposed):
                            (gw, oracle.conv3x3_weight_grad(dy.numpy(), x.numpy(), stride=stride, transposed=transposed), 'dw')):
         l2, mx = _rel(got.detach(), torch.as_tensor(ref))
         assert l2 < 1e-5 and mx < 1e-5, (what, l2, mx)
+
+
+def test_native_kernels_also_serve_no_grad_passes():
+    """The D phase runs the generator under torch.no_grad() (loss.py:123 of the reference): those convolutions must not fall back."""
+    x = torch.randn([2, 64, 16, 32], device=DEV)
+    w = torch.randn([64, 64, 3, 3], device=DEV) / 24
+    custom_ops.prof_enable(16)
+    with torch.no_grad():
+        y = conv2d_gradfix.conv2d(x, w, padding=1)
+        yt = conv2d_gradfix.conv_transpose2d(x, w, stride=2)
+    custom_ops.prof_disable()
+    assert custom_ops.prof_collect()['conv3x3']['launches'] == 2
+    assert_close(y, F.conv2d(x.double(), w.double(), padding=1), atol=2e-5 * 3, rtol=1e-4)
+    assert_close(yt, F.conv_transpose2d(x.double(), w.double(), stride=2), atol=2e-5 * 3, rtol=1e-4)
