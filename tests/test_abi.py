@@ -66,3 +66,59 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(custom_ops.PointwiseParams) == 56
     assert ctypes.sizeof(custom_ops.ConvWrwParams) == 48
     assert ctypes.sizeof(custom_ops.Conv3x3Params) == 72
+
+
+def test_convolution_family_shape_rules_and_validation_without_gpu():
+    """Eligibility predicates, workspace sizes and precondition errors of the 3x3 convolution entry points are host-side."""
+    lib = custom_ops.get_native()
+    F32, F16 = custom_ops.SGV_F32, custom_ops.SGV_F16
+    # stride 1: c_in % 16, c_out % 64, (W % 32 and H % 16) or whole 16x16 / 8x8 images in pairs / octets
+    assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, F32) == 1
+    assert lib.sgv_conv3x3_supported(96, 16, 512, 32, 32, F32) == 1
+    assert lib.sgv_conv3x3_supported(96, 512, 512, 16, 16, F32) == 1
+    assert lib.sgv_conv3x3_supported(32, 512, 512, 8, 8, F32) == 1
+    assert lib.sgv_conv3x3_supported(31, 512, 512, 16, 16, F32) == 0
+    assert lib.sgv_conv3x3_supported(96, 512, 512, 4, 4, F32) == 0
+    assert lib.sgv_conv3x3_supported(96, 3, 64, 256, 256, F32) == 0
+    assert lib.sgv_conv3x3_supported(96, 64, 32, 256, 256, F32) == 0
+    assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, F16) == 0
+    assert lib.sgv_conv3x3_workspace_bytes(64, 128) == 64 * 128 * 9 * 4
+    # stride 2 (h, w = the small grid): W % 32, H % 8
+    assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 128, 128, F32) == 1
+    assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 8, 32, F32) == 1
+    assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 16, 16, F32) == 0
+    assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 12, 32, F32) == 0
+    ws_strided = lib.sgv_conv3x3_s2_workspace_bytes(4, 64, 128, 16, 32, 0)
+    ws_transposed = lib.sgv_conv3x3_s2_workspace_bytes(4, 64, 128, 16, 32, 2)
+    assert ws_strided == 64 * 128 * 9 * 4
+    assert ws_transposed == ws_strided + 4 * (4 * 64 * (16 + 32) + 2 * 64 * 3 * 128)   # + edge lines + edge weights
+    # weight gradients: channels % 64
+    assert lib.sgv_conv3x3_wrw_supported(96, 64, 64, 256, 256, F32) == 1
+    assert lib.sgv_conv3x3_wrw_supported(96, 64, 16, 256, 256, F32) == 0
+    assert lib.sgv_conv3x3_wrw_supported(96, 64, 64, 48, 32, F32) == 0
+    assert lib.sgv_conv3x3_wrw_s2_supported(96, 128, 64, 128, 128, F32) == 1
+    assert lib.sgv_conv3x3_wrw_s2_supported(96, 128, 64, 128, 16, F32) == 0
+    # preconditions are reported before anything is launched
+    p = custom_ops.Conv3x3Params()
+    assert lib.sgv_conv3x3(p, F32, None) == -1 and b'NULL' in lib.sgv_last_error()
+    buf = (ctypes.c_float * 64)()
+    addr = ctypes.addressof(buf)
+    p.x = p.weight = p.y = p.workspace = addr
+    p.n, p.c_in, p.c_out, p.h, p.w, p.mode, p.terms = 2, 64, 64, 20, 32, 0, 3
+    assert lib.sgv_conv3x3(p, F32, None) == -3 and b'H % 16' in lib.sgv_last_error()
+    p.h = 16
+    p.terms = 2
+    assert lib.sgv_conv3x3(p, F32, None) == -1 and b'terms' in lib.sgv_last_error()
+    p.terms, p.workspace_bytes = 3, 16
+    assert lib.sgv_conv3x3(p, F32, None) == -1 and b'workspace' in lib.sgv_last_error()
+    p.mode, p.workspace_bytes = 1, 1 << 30
+    assert lib.sgv_conv3x3_s2(p, F32, None) == -3 or b'mode' in lib.sgv_last_error()
+    q = custom_ops.ConvWrwParams()
+    assert lib.sgv_conv3x3_wrw(q, F32, None) == -1
+    q.dy = q.x = q.dw = addr
+    q.n, q.c_out, q.c_in, q.h, q.w, q.terms = 2, 64, 64, 32, 16, 3
+    assert lib.sgv_conv3x3_wrw(q, F32, None) == -3 and b'W % 32' in lib.sgv_last_error()
+    assert lib.sgv_conv3x3_wrw_s2(q, F32, None) == -3
+    r = custom_ops.PointwiseParams()
+    assert lib.sgv_pointwise_small(r, F32, None) == -1
+    assert lib.sgv_bias_act_db(custom_ops.BiasActParams(), None, 1, F32, None) == -1 and b'db is NULL' in lib.sgv_last_error()
