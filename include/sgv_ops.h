@@ -157,6 +157,9 @@ int sgv_demod_coefs(const float* styles, const float* wsq, float* dcoefs, int32_
                     int32_t ic, float eps, void* stream);
 /* y[n,c,hw] = x[n,c,hw] * s[n*C + c] (+ optional per-[n,hw] noise), contiguous NCHW,
  * x/y of dtype `dtype`, s fp32.  Used for x*styles and x*dcoefs (networks.py:66,70-71). */
+/* out[p] += sum_i a[p,i] * b[p,i] over `planes` planes of hw elements (fp32 accumulate, atomics; the caller zero-initialises out):
+ * the styles gradient of x * s[n,c] (`networks.py:66,70`) without materialising a * b. */
+int sgv_plane_dot(const void* a, const void* b, float* out, int32_t planes, int32_t hw, int dtype, void* stream);
 int sgv_scale_channels(const void* x, const float* s, void* y, int32_t n, int32_t c, int32_t hw,
                        int dtype, void* stream);
 

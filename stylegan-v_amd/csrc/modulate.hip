@@ -14,6 +14,8 @@
 
 #include "sgv_common.h"
 
+#include <algorithm>
+
 #pragma clang fp contract(off)
 
 namespace {
@@ -92,7 +94,67 @@ void launch_scale(const void* x, const float* s, void* y, int total, int hw, hip
         hipLaunchKernelGGL(scale_channels_scalar_kernel<T>, dim3(blocks), dim3(256), 0, stream, (const T*)x, s, (T*)y, total, hw);
 }
 
+// out[p] += sum over the plane's pixels of a[p,:] * b[p,:] (fp32): the styles gradient of x * s[n,c] without materialising a * b.
+// grid = (chunks per plane, planes); a workgroup reduces CHUNK = 4096 elements (wave shuffle, LDS across the 4 waves) and issues ONE atomic.
+constexpr int PD_CHUNK = 4096;
+
+template <typename T>
+__global__ __launch_bounds__(256) void plane_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ out, int hw, int vec_ok) {
+    constexpr int N = vec16<T>::N;
+    const int plane = blockIdx.y;
+    const int p0 = blockIdx.x * PD_CHUNK, p1 = min(hw, p0 + PD_CHUNK);
+    const T* ap = a + (size_t)plane * hw;
+    const T* bp = b + (size_t)plane * hw;
+    float acc = 0.f;
+    if (vec_ok) {
+        for (int i = p0 + threadIdx.x * N; i < p1; i += 256 * N) {
+            const vec16<T> va = *(const vec16<T>*)(ap + i), vb = *(const vec16<T>*)(bp + i);
+#pragma unroll
+            for (int k = 0; k < N; k++) acc = __builtin_fmaf((float)sgv_traits<T>::load(&va.e[k]), (float)sgv_traits<T>::load(&vb.e[k]), acc);
+        }
+    } else {
+        for (int i = p0 + threadIdx.x; i < p1; i += 256) acc = __builtin_fmaf((float)sgv_traits<T>::load(ap + i), (float)sgv_traits<T>::load(bp + i), acc);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + plane, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+template <typename T>
+void launch_plane_dot(const void* a, const void* b, float* out, int planes, int hw, hipStream_t stream) {
+    constexpr int N = vec16<T>::N;
+    const int vec_ok = (hw % N == 0) && (((uintptr_t)a | (uintptr_t)b) % 16 == 0);
+    dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)planes);
+    hipLaunchKernelGGL(plane_dot_kernel<T>, grid, dim3(256), 0, stream, (const T*)a, (const T*)b, out, hw, vec_ok);
+}
+
 }  // namespace
+
+extern "C" int sgv_plane_dot(const void* a, const void* b, float* out, int32_t planes, int32_t hw, int dtype, void* stream_) {
+    if (!a || !b || !out) return sgv_fail(SGV_ERR_INVALID_ARG, "plane_dot: NULL pointer");
+    if (planes < 1 || hw < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "plane_dot: sizes must be positive");
+    if (planes > 65535 * 16) return sgv_fail(SGV_ERR_TOO_LARGE, "plane_dot: too many planes");
+    if ((int64_t)planes * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "plane_dot: tensors are too large");
+    const size_t es = sgv_dtype_size(dtype);
+    if (es == 0 || dtype == SGV_F64) return sgv_fail(SGV_ERR_UNSUPPORTED, "plane_dot: unsupported dtype %d", dtype);
+    hipStream_t stream = (hipStream_t)stream_;
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, 2.0 * planes * (double)hw * es + planes * 4.0);
+    // blockIdx.y is limited to 65535: fold the planes in slabs
+    for (int p0 = 0; p0 < planes; p0 += 65535) {
+        const int np = std::min(65535, planes - p0);
+        const char* ap = (const char*)a + (size_t)p0 * hw * es;
+        const char* bp = (const char*)b + (size_t)p0 * hw * es;
+        switch (dtype) {
+            case SGV_F32: launch_plane_dot<float>(ap, bp, out + p0, np, hw, stream); break;
+            case SGV_F16: launch_plane_dot<sgv_half_t>(ap, bp, out + p0, np, hw, stream); break;
+            default: launch_plane_dot<sgv_bf16_t>(ap, bp, out + p0, np, hw, stream); break;
+        }
+    }
+    return sgv_check_launch("plane_dot_kernel");
+}
 
 extern "C" int sgv_weight_sqsum(const float* w, float* wsq, int32_t oc, int32_t ic, int32_t kk, void* stream_) {
     if (!w || !wsq) return sgv_fail(SGV_ERR_INVALID_ARG, "weight_sqsum: NULL pointer");

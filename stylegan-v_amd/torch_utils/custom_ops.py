@@ -218,6 +218,7 @@ ABI_SYMBOLS = {
     'sgv_weight_sqsum': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_demod_coefs': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
     'sgv_scale_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'sgv_plane_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int, c_void_p]),
     'sgv_pointwise_small': (c_int, [ctypes.POINTER(PointwiseParams), c_int, c_void_p]),
     'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_conv3x3': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),

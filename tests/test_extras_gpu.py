@@ -270,3 +270,26 @@ def test_bias_act_fused_bias_gradient_is_twice_differentiable():
         finally:
             bias_act.fused_bias_grad = True
     assert_close(second(True), second(False), atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize('shape', [(3, 5, 64, 64), (2, 7, 9, 9), (4, 16, 4, 4), (1, 3, 130, 100)])
+def test_plane_dot_and_scale_channels_style_gradient(dtype, shape):
+    g = torch.Generator().manual_seed(shape[1])
+    a = torch.randn(shape, generator=g).to(DEV).to(dtype)
+    b = torch.randn(shape, generator=g).to(DEV).to(dtype)
+    out = modulation.plane_dot(a, b)
+    ref = (a.double() * b.double()).sum(dim=[2, 3])
+    assert out.dtype == torch.float32
+    hw = shape[2] * shape[3]
+    assert_close(out, ref, atol=2e-6 * hw ** 0.5 * 4, rtol=2e-6)
+    # through scale_channels: ds and the second-order terms d(ds)/d(dy), d(ds)/dx
+    x = a.float().requires_grad_(True)
+    s = torch.randn(shape[:2], generator=g).to(DEV).requires_grad_(True)
+    dy = b.float().requires_grad_(True)
+    ds, = torch.autograd.grad(modulation.scale_channels(x, s), [s], dy, create_graph=True)
+    assert_close(ds, (dy * x).sum(dim=[2, 3]), atol=1e-4 * hw ** 0.5, rtol=1e-5)
+    u = torch.randn(shape[:2], generator=g).to(DEV)
+    g_dy, g_x = torch.autograd.grad((ds * u).sum(), [dy, x])
+    assert_close(g_dy, x.detach() * u[:, :, None, None], atol=1e-5, rtol=1e-5)
+    assert_close(g_x, dy.detach() * u[:, :, None, None], atol=1e-5, rtol=1e-5)
