@@ -6,6 +6,7 @@
 #include <math.h>
 #include <vector>
 #include "conv3x3_kernel.h"
+#include "../tools/experimental_conv3x3_ws.h"
 
 using namespace sgv_conv;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -164,6 +165,31 @@ int main(int argc, char** argv) {
             printf("%-12s RW=2 terms=3 grid=%3d  %8.3f ms  %7.1f TFLOP/s   max |diff| vs RW=4: %.2e\n", s.name, grid, ms, 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9 / ms / 1e9, md);
         }
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep)); (void)ref;
+    }
+    for (auto& s : shapes) {   // ---- EXPERIMENTAL producer/consumer variant (tools/experimental_conv3x3_ws.h): check vs the product kernel, then time ----
+        const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
+        float *x, *w, *y; u32x4* wprep;
+        CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
+        fill<<<(na + 255) / 256, 256>>>(x, na, 5u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 7u, 0.1f);
+        launch<3>(x, w, y, wprep, s.n, s.c, s.c, s.r, s.r, 0, 256);
+        std::vector<float> a(1 << 20), b(1 << 20);
+        CK(hipMemcpy(a.data(), y + na / 2, a.size() * 4, hipMemcpyDeviceToHost));
+        conv_params p{};
+        p.x = x; p.wprep = wprep; p.y = y; p.n = s.n; p.k = s.c; p.m = s.c; p.h = s.r; p.w = s.r;
+        p.tiles = s.n * (s.r / TROWS) * (s.r / SEG) * (s.c / TM); p.grid = 256;
+        CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+        CK(hipMemset(y, 0, na * 4));
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        hipLaunchKernelGGL((conv3x3_ws_kernel<3>), dim3(256), dim3(512), WS_LDS_BYTES, 0, p);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(b.data(), y + na / 2, b.size() * 4, hipMemcpyDeviceToHost));
+        double md = 0; for (size_t i = 0; i < a.size(); i++) md = fmax(md, fabs((double)a[i] - b[i]));
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; r++) hipLaunchKernelGGL((conv3x3_ws_kernel<3>), dim3(256), dim3(512), WS_LDS_BYTES, 0, p);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        printf("%-12s ws (producer/consumer, EXPERIMENTAL) terms=3  %8.3f ms  %7.1f TFLOP/s   max |diff| vs product kernel: %.2e\n", s.name, ms, 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9 / ms / 1e9, md);
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep));
     }
     {   // ---- ablations on the 128ch 128^2 layer (timing only; results are wrong by construction) ----
         const int n = 96, c = 128, r = 128;
