@@ -166,7 +166,7 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep)); (void)ref;
     }
-    for (auto& s : shapes) {   // ---- EXPERIMENTAL producer/consumer variant (tools/experimental_conv3x3_ws.h): check vs the product kernel, then time ----
+    if (getenv("SGV_LAB_WS")) for (auto& s : shapes) {   // ---- EXPERIMENTAL producer/consumer variant (tools/experimental_conv3x3_ws.h), opt-in: never run on hardware yet -- run it under `timeout` ----
         const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
         float *x, *w, *y; u32x4* wprep;
         CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
