@@ -214,16 +214,17 @@ class _BiasActGradDbFn(torch.autograd.Function):
         dx = _native_call(dy, bb, x, y, None, 1, dim, spec.cuda_idx, alpha, gain, clamp, db=db32)
         ctx.cfg = cfg
         ctx.dim = dim
+        ctx.dx_meta = (tuple(dx.shape), dx.dtype, dx.device)   # 'linear' + gain/clamp saves no tensor at all: the shape comes from here
         ctx.save_for_backward(dy if spec.has_2nd_grad else None, x, b, y)
         return dx, (db32.sum(0) if slots > 1 else db32[0]).to(b_dtype)
 
     @staticmethod
     def backward(ctx, d_dx, d_db):
-        ref = next(t for t in (ctx.saved_tensors[3], ctx.saved_tensors[1], ctx.saved_tensors[0]) if t is not None)   # y, x or dy: same shape as dx
+        shape, dtype, device = ctx.dx_meta
         if d_dx is None:
-            d_dx = torch.zeros_like(ref)
+            d_dx = torch.zeros(shape, dtype=dtype, device=device)
         if d_db is not None:
-            view = [1] * ref.ndim
+            view = [1] * len(shape)
             view[ctx.dim] = -1
             d_dx = d_dx + d_db.reshape(view).to(d_dx.dtype)
         d_dy, d_x, d_b = _grad_fn_backward(ctx, d_dx)

@@ -42,12 +42,18 @@ class _DemodCoefsFn(torch.autograd.Function):
         with custom_ops.device_guard(w):
             custom_ops.check(lib.sgv_weight_sqsum(w.data_ptr(), q.data_ptr(), oc, ic, kh * kw, _stream(w)), lib)
             custom_ops.check(lib.sgv_demod_coefs(s.data_ptr(), q.data_ptr(), d.data_ptr(), n, oc, ic, float(eps), _stream(w)), lib)
-        ctx.save_for_backward(weight, styles, q, d)
+        ctx.eps = eps
+        ctx.save_for_backward(weight, styles)
         return d
 
     @staticmethod
     def backward(ctx, grad_d):
-        weight, styles, q, d = ctx.saved_tensors
+        weight, styles = ctx.saved_tensors
+        # Everything below is rebuilt from the INPUTS with differentiable tensor ops (q and d are [O,I] / [N,O]: negligible work),
+        # so that a create_graph pass (path-length regularisation differentiates G twice) sees the dependence of both gradients
+        # on weight and styles.  Saved intermediates would come back as constants and silently drop those terms.
+        q = weight.square().sum(dim=[2, 3])                              # [O, I]
+        d = (styles.square() @ q.t() + ctx.eps).rsqrt()                  # [N, O]
         # d = (s^2 q^T + eps)^(-1/2)  =>  dd/d(s^2 q^T) = -d^3 / 2
         g = grad_d * (-0.5) * d.pow(3)  # [N, O]
         grad_w = grad_s = None

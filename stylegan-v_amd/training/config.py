@@ -102,3 +102,24 @@ def small_test_model_kwargs(res=32):
     d_kwargs = dict(c_dim=0, img_resolution=res, img_channels=3, channel_base=res * 16, channel_max=32, num_fp16_res=0, conv_clamp=None,
                     mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2), cfg=dcfg)
     return g_kwargs, d_kwargs
+
+
+def mid_test_configs():
+    """Hyper-parameters of the mid-size golden (tests/golden/networks_mid.npz): every conv has 64 output channels and
+    the network reaches 128^2, so that G / D / R1 parity on the GPU runs THROUGH the MFMA convolution kernels, the
+    whole-tile GEMM and the wide (>= 129 column) upfirdn2d kernels instead of their small-shape fallbacks."""
+    samp = Config(type='random', num_frames_per_video=3, max_num_frames=64, total_dists=[1, 2, 4, 8, 16, 32], max_dist=32)
+    gcfg = Config(sampling=samp, use_noise=False, input=dict(type='temporal'), w_dim=64, z_dim=64, c_dim=0,
+                  motion=dict(z_dim=24, v_dim=24, motion_z_distance=4, gen_strategy='conv', kernel_size=5, use_fractional_t=True, fourier=True),
+                  time_enc=dict(cond_type='concat_const', dim=8, min_period_len=4, max_period_len=64, phase_dropout_std=1.0))
+    dcfg = Config(sampling=samp, concat_res=16, num_frames_div_factor=2, dummy_c=False)
+    return gcfg, dcfg
+
+
+def mid_test_model_kwargs(res=128, channels=64):
+    gcfg, dcfg = mid_test_configs()
+    g_kwargs = dict(c_dim=0, w_dim=64, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=2, cfg=gcfg),
+                    synthesis_kwargs=dict(channel_base=res * channels, channel_max=channels, num_fp16_res=0, conv_clamp=None), cfg=gcfg)
+    d_kwargs = dict(c_dim=0, img_resolution=res, img_channels=3, channel_base=res * channels, channel_max=channels, num_fp16_res=0, conv_clamp=None,
+                    mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2), cfg=dcfg)
+    return g_kwargs, d_kwargs

@@ -27,7 +27,9 @@ class StyleGAN2Loss:
         self.style_mixing_prob, self.r1_gamma = style_mixing_prob, r1_gamma
         self.pl_batch_shrink, self.pl_decay, self.pl_weight = pl_batch_shrink, pl_decay, pl_weight
         self.pl_mean = torch.zeros([], device=device)
-        self.video_consistent_aug = bool(cfg.get('video_consistent_aug', True)) if hasattr(cfg, 'get') else True
+        # same key, same place, same default as the reference (loss.py:58: cfg.model.loss_kwargs.get('video_consistent_aug', False))
+        loss_kwargs = getattr(getattr(cfg, 'model', None), 'loss_kwargs', None)
+        self.video_consistent_aug = bool(loss_kwargs.get('video_consistent_aug', False)) if hasattr(loss_kwargs, 'get') else False
         self.frames = cfg.sampling.num_frames_per_video
 
     def run_G(self, z, c, t, sync):

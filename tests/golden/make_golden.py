@@ -264,6 +264,67 @@ def gen_networks():
     save('networks', arrays, json.loads(json.dumps(meta, default=lambda o: dict(o))))
 
 
+def gen_networks_mid():
+    """Second module golden: 64 channels everywhere, 128^2, 2 videos x 3 frames.  Parameters are NOT stored: both sides
+    draw them with tests/util.py:seeded_parameters_ (keyed by parameter name).  Gradients are stored as strided samples."""
+    from omegaconf import OmegaConf
+    from training.networks import Generator, Discriminator
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import seeded_parameters_, sample_flat
+    RES, CH = 128, 64
+    sampling = dict(type='random', num_frames_per_video=3, max_num_frames=64, total_dists=[1, 2, 4, 8, 16, 32], max_dist=32, name='random3_max32')
+    gcfg = OmegaConf.create(dict(sampling=sampling, use_noise=False, input=dict(type='temporal'), w_dim=64, z_dim=64, c_dim=0,
+                                 motion=dict(z_dim=24, v_dim=24, motion_z_distance=4, gen_strategy='conv', kernel_size=5, use_fractional_t=True, fourier=True),
+                                 time_enc=dict(cond_type='concat_const', dim=8, min_period_len=4, max_period_len=64, phase_dropout_std=1.0)))
+    dcfg = OmegaConf.create(dict(sampling=sampling, concat_res=16, num_frames_div_factor=2, dummy_c=False))
+    torch.manual_seed(4048)
+    G = Generator(c_dim=0, w_dim=64, img_resolution=RES, img_channels=3, mapping_kwargs=dict(num_layers=2, cfg=gcfg),
+                  synthesis_kwargs=dict(channel_base=RES * CH, channel_max=CH, num_fp16_res=0, conv_clamp=None), cfg=gcfg)
+    D = Discriminator(c_dim=0, img_resolution=RES, img_channels=3, channel_base=RES * CH, channel_max=CH, num_fp16_res=0, conv_clamp=None,
+                      mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2), cfg=dcfg)
+    seeded_parameters_(G, 101)
+    seeded_parameters_(D, 202)
+    g = torch.Generator().manual_seed(78)
+    B, F = 2, 3
+    z = torch.randn([B, 64], generator=g)
+    c = torch.zeros([B, 0])
+    t = torch.sort(torch.rand([B, F], generator=g) * 40, dim=1).values
+    traj_len = G.synthesis.motion_encoder.get_max_traj_len(t) + G.synthesis.motion_encoder.num_additional_codes
+    motion_z = torch.randn([B, traj_len, 24], generator=g)
+    arrays = {'z': z, 't': t, 'motion_z': motion_z}
+    G.train(); D.train()
+    ws = G.mapping(z, c, skip_w_avg_update=True)
+    arrays['ws'] = ws
+    img_train = G.synthesis(ws, t=t, c=c, motion_z=motion_z)
+    arrays['img_train'] = img_train
+    real = torch.rand([B * F, 3, RES, RES], generator=g) * 2 - 1
+    arrays['real'] = real.half()      # exactly representable on both sides: the test reads it back as float32
+    real = real.half().float()
+    arrays['logits_fake'] = D(img_train.detach(), c, t)['image_logits']
+    G.zero_grad(); D.zero_grad()
+    img = G.synthesis(G.mapping(z, c, skip_w_avg_update=True), t=t, c=c, motion_z=motion_z)
+    loss_g = torch.nn.functional.softplus(-D(img, c, t)['image_logits']).mean()
+    loss_g.backward()
+    arrays['loss_Gmain'] = loss_g
+    for name, p in G.named_parameters():
+        arrays['gradG.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p))
+    G.zero_grad(); D.zero_grad()
+    real_tmp = real.clone().requires_grad_(True)
+    logits_real = D(real_tmp, c, t)['image_logits']
+    (r1_grads,) = torch.autograd.grad(logits_real.sum(), real_tmp, create_graph=True)
+    r1 = r1_grads.square().sum([1, 2, 3])
+    loss_d = (torch.nn.functional.softplus(-logits_real) + (r1 * 0.5).view(-1, F).mean(dim=1)).mean()
+    loss_d.backward()
+    arrays['logits_real'] = logits_real
+    arrays['r1_penalty'] = r1
+    arrays['loss_Dreal_r1'] = loss_d
+    for name, p in D.named_parameters():
+        arrays['gradD.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p))
+    meta = dict(B=B, F=F, res=RES, channels=CH, w_dim=64, z_dim=64, seed_G=101, seed_D=202,
+                G_params=sum(p.numel() for p in G.parameters()), D_params=sum(p.numel() for p in D.parameters()))
+    save('networks_mid', arrays, meta)
+
+
 def gen_time_encoder():
     """AlignedTimeEncoder + motion-code gather in float64 for a tight kernel tolerance."""
     from training.motion import MotionMappingNetwork
@@ -285,8 +346,13 @@ def gen_time_encoder():
 
 if __name__ == '__main__':
     torch.set_num_threads(4)
+    if len(sys.argv) > 1:            # e.g. `make_golden.py networks_mid`: regenerate only the named fixtures
+        for name in sys.argv[1:]:
+            globals()['gen_' + name]()
+        sys.exit(0)
     gen_upfirdn2d()
     gen_bias_act()
     gen_conv_ops()
     gen_networks()
+    gen_networks_mid()
     gen_time_encoder()

@@ -5,7 +5,7 @@ import torch
 import oracle
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import gemm, modulation, time_encode
-from util import Golden, assert_close
+from util import Golden, assert_close, assert_bit_equal
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -195,6 +195,43 @@ def test_fused_fir_bias_act_matches_three_op_composition(dtype, shape):
                                         ('dscale', ds1, ds2, dsr, lim_sum), ('dbias', db1, db2, dbr, lim_sum)):
         assert rel(fused, ref) < lim, f'{name}: fused path off by {rel(fused, ref):.3f} (relative L2) from the fp32 composition'
         assert rel(fused, ref) < 3.0 * rel(comp, ref) + lim / 2, f'{name}: fused path much less accurate than the 16-bit composition'
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 9, 9), (3, 5, 17, 17), (2, 4, 33, 33), (1, 2, 65, 65), (2, 2, 129, 129), (1, 2, 257, 257), (1, 1, 300, 300)])
+@pytest.mark.parametrize('act,clamp', [('lrelu', 1.5), ('lrelu', None), ('linear', 2.0)])
+def test_fused_fir_bias_act_vs_oracle_composition(shape, act, clamp):
+    """The fused kernel against the ORACLE's composition (oracle.upfirdn2d -> fp32 multiply by the per-sample scale ->
+    oracle.bias_act), not against this repo's own kernels: forward and data gradient bit-exact in fp32 (the same fp32
+    operations in the same order), bias / scale gradients against float64 sums of oracle terms."""
+    import oracle
+    from stylegan_v_amd.torch_utils.ops import fused_fir_act, upfirdn2d
+    g = torch.Generator().manual_seed(sum(shape) + len(act))
+    n, c = shape[:2]
+    f = upfirdn2d.setup_filter([1, 3, 3, 1])
+    x = torch.randn(shape, generator=g)
+    s = torch.rand([n, c], generator=g) + 0.5
+    b = torch.randn([c], generator=g)
+    gain = 1.2
+    xg, sg, bg = x.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    before = custom_ops.launch_count()
+    y = fused_fir_act.fir_bias_act(xg, f.to(DEV), scale=sg, bias=bg, padding=1, fir_gain=4, act=act, gain=gain, clamp=clamp)
+    assert custom_ops.launch_count() - before == 1
+    dy = torch.randn(y.shape, generator=g)
+    dx, ds, db = torch.autograd.grad(y, [xg, sg, bg], dy.to(DEV))
+    # oracle forward
+    u = oracle.upfirdn2d(x, f, padding=1, gain=4)                       # [n, c, h-1, w-1]
+    v = u * s.reshape(n, c, 1, 1)                                      # one fp32 multiply per element, as networks.py:70-71
+    y_ref = oracle.bias_act(v, b, act=act, gain=gain, clamp=clamp)
+    assert_bit_equal(y.detach().cpu(), y_ref, 'fused forward vs oracle composition')
+    # oracle backward: bias_act grad 1 (bias_act.cu:39-146 with grad = 1), times scale, then the adjoint FIR (upfirdn2d.py:251-261)
+    dv = oracle.bias_act(dy, b, act=act, gain=gain, clamp=clamp, grad=1, xref=v, yref=y_ref)
+    du = dv * s.reshape(n, c, 1, 1)
+    dx_ref = oracle.upfirdn2d(du, f, padding=2, gain=4, flip_filter=True)
+    assert_bit_equal(dx.cpu(), dx_ref, 'fused data gradient vs oracle composition')
+    db_ref = dv.double().sum([0, 2, 3])
+    ds_ref = (dv.double() * u.double()).sum([2, 3])
+    assert_close(db, db_ref, atol=2e-4 * max(1.0, db_ref.abs().max().item()), rtol=2e-4, what='dbias')
+    assert_close(ds, ds_ref, atol=2e-4 * max(1.0, ds_ref.abs().max().item()), rtol=2e-4, what='dscale')
 
 
 def test_fused_fir_bias_act_double_backward_is_refused():

@@ -47,3 +47,31 @@ def assert_bit_equal(a, b, what=''):
     # compare numerically so +0 == -0, but NaN must match NaN
     same = (a == b) | (a.isnan() & b.isnan())
     assert same.all(), f'{what}: {int((~same).sum())} / {same.numel()} elements differ, max abs {max_abs(a, b):.3e}'
+
+
+def seeded_parameters_(module, seed):
+    """Deterministic, construction-order-independent parameter values: every tensor is drawn from its own generator
+    keyed by (seed, parameter name).  Used on BOTH sides of a module golden (tests/golden/make_golden.py applies it
+    to the reference's modules, the tests to this repo's mirrors), so fixtures need not carry the parameters.
+    Weights keep the decade of their init scale (1, or 100 for lr_multiplier 0.01 layers); biases are perturbed
+    around their init value (0 or 1) so that every bias path is exercised."""
+    import math
+    import zlib
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            g = torch.Generator().manual_seed((zlib.crc32(name.encode()) ^ seed) & 0x7fffffff)
+            r = torch.randn(p.shape, generator=g, dtype=torch.float32)
+            if name.endswith('bias'):
+                p.add_((r * 0.1).to(p.device, p.dtype))
+            else:
+                std = float(p.detach().float().std()) if p.numel() > 1 else 1.0
+                scale = 10.0 ** round(math.log10(max(std, 1e-3)))
+                p.copy_((r * scale).to(p.device, p.dtype))
+    return module
+
+
+def sample_flat(t, limit=4096):
+    """Strided subsample of a tensor (whole tensor if it has <= limit elements): what the mid-size golden stores per gradient."""
+    flat = t.detach().reshape(-1)
+    stride = max(1, -(-flat.numel() // limit))
+    return flat[::stride]
