@@ -43,42 +43,40 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+PMC_FILES = ['r02_pmc_bench_step_FETCH_WRITE.json', 'r01_pmc_bench_step_v2_FETCH_WRITE.json']   # newest first
+
+
+def pmc_traffic(prefixes, dword_read_prefixes=()):
+    """HBM-side (L2 miss) bytes per launch of a kernel family from the newest committed rocprofv3 PMC summary
+    (tools/pmc_summary.py over separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command: bench.py cannot
+    collect counters on itself).  gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced read,
+    so reads are doubled for kernels that read with 16-B loads (calibrated on a float4 copy,
+    profiles/r01_pmc_headline_call_FETCH_WRITE.json); kernels reading with dword loads are taken as is; WRITE_SIZE is exact.
+    Returns (bytes per launch or None, description of the source incl. the commit the counters were collected on)."""
+    for fname in PMC_FILES:
+        path = os.path.join(ROOT, 'profiles', fname)
+        try:
+            with open(path) as fh:
+                d = json.load(fh)
+            kb = n = 0.0
+            for name, e in d['FETCH_SIZE'].items():
+                if name.startswith(tuple(prefixes)):
+                    kb += (1.0 if name.startswith(tuple(dword_read_prefixes)) and dword_read_prefixes else 2.0) * e['total_KB'] + d['WRITE_SIZE'][name]['total_KB']
+                    n += e['launches']
+            if n:
+                src = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, profiles/{fname}, collected on commit {d.get('commit', 'of round 1 (before the XCD-aware tile order)')}"
+                return kb * 1024.0 / n, src
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, 'no PMC summary committed'
+
+
 def pmc_traffic_conv_family():
-    """HBM-side (L2 miss) bytes per launch of the 3x3 forward / data-gradient kernels from the committed PMC passes
-    (profiles/r01_pmc_bench_step_v2_FETCH_WRITE.json, same command, collected before the XCD-aware tile order went in).
-    FETCH_SIZE is doubled for the kernels that read with 16-B loads (gfx950 correction, see pmc_traffic_per_launch); the
-    strided kernel reads with dword loads, for which the counter is taken as is."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_bench_step_v2_FETCH_WRITE.json')
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-        kb = n = 0.0
-        for name, e in d['FETCH_SIZE'].items():
-            if name.startswith(('conv3x3_kernel', 'conv3x3_small_kernel', 'convT3x3_s2_kernel', 'conv3x3_s2_kernel')):
-                kb += (1.0 if name.startswith('conv3x3_s2_kernel') else 2.0) * e['total_KB'] + d['WRITE_SIZE'][name]['total_KB']
-                n += e['launches']
-        return kb * 1024.0 / n if n else None
-    except (OSError, KeyError, ValueError):
-        return None
+    return pmc_traffic(('conv3x3_kernel', 'conv3x3_small_kernel', 'convT3x3_s2_kernel', 'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
 
 
 def pmc_traffic_per_launch(prefix='upfirdn2d_lanes'):
-    """HBM bytes per launch of the kernel family from the committed rocprofv3 PMC passes over this same command
-    (profiles/r01_pmc_bench_step_FETCH_WRITE.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; on gfx950 FETCH_SIZE
-    counts half of a wide coalesced read -- calibrated on a float4 copy in profiles/r01_pmc_headline_call_FETCH_WRITE.json --
-    so reads are doubled; WRITE_SIZE is exact).  bench.py cannot collect counters on itself; None if the file is absent."""
-    path = os.path.join(ROOT, 'profiles', 'r01_pmc_bench_step_FETCH_WRITE.json')
-    try:
-        with open(path) as fh:
-            d = json.load(fh)
-        kb = n = 0.0
-        for name, e in d['FETCH_SIZE'].items():
-            if name.startswith(prefix):
-                kb += 2.0 * e['total_KB'] + d['WRITE_SIZE'][name]['total_KB']
-                n += e['launches']
-        return kb * 1024.0 / n if n else None
-    except (OSError, KeyError, ValueError):
-        return None
+    return pmc_traffic((prefix,))
 
 
 def cpu_baseline(res, frames, seconds_cap):
@@ -112,7 +110,7 @@ def cpu_baseline(res, frames, seconds_cap):
                     break
     except OSError:
         pass
-    return dict(value=done * frames / spent, unit='img/s', cores=threads, kind='port', cpu=model,
+    return dict(value=done * frames / spent, unit='img/s', cores=threads, host_cores=cores, host_logical_cpus=os.cpu_count(), kind='port', cpu=model,
                 sample=f'{done} training iteration(s) at batch 1 video x {frames} frames, {res}x{res}, fp32 (iteration 0 includes Greg+Dreg), {spent:.1f} s')
 
 
@@ -126,10 +124,21 @@ def main():
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline leg; 0 disables it')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
+    ap.add_argument('--strict-steps', type=int, default=8, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
     ap.add_argument('--lowp', choices=['none', 'fp16', 'bf16'], default='none',
                     help='mixed precision in the 4 highest resolutions (reference: fp16; BASELINE config 4: bf16). Default: full fp32')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # plain `python bench.py --gpus N`: re-launch as N ranks (one per GPU) under torch.distributed.run; rank 0 prints the line
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+               '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log('[bench] spawning', ' '.join(cmd))
+        os.execvp(sys.executable, cmd)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -200,8 +209,41 @@ def main():
     frames_total = global_batch * args.frames * args.steps
     value = frames_total / elapsed
 
+    # Strict-fp32 companion (the reference's fp32 mode is allow_tf32=False, training_loop.py:129,141-142): the same step with every
+    # 3x3 convolution on the vendor library's fp32 kernels instead of the split-bf16 matrix-pipe kernels.  Same schedule start
+    # (iteration 0 runs all four phases), same barrier / synchronize bracket, MAX over ranks.
+    strict = None
+    default_terms = (conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms)
+    if args.strict_steps > 0 and lowp is None and default_terms != (0, 0):
+        conv2d_gradfix.native_conv_terms = conv2d_gradfix.native_wrw_terms = 0
+        try:
+            tw = time.perf_counter()
+            ts.batch_idx = 1
+            ts.step()                      # MIOpen kernel selection / compilation for the shapes that were on the native path
+            ts.batch_idx = 0
+            ts.step()                      # ... and for the R1 shapes
+            torch.cuda.synchronize()
+            if rank == 0:
+                log(f'[bench] strict-fp32 companion: warm-up {time.perf_counter() - tw:.1f} s')
+            ts.batch_idx = 0
+            barrier()
+            t1 = time.perf_counter()
+            strict_phases = {}
+            for _ in range(args.strict_steps):
+                for name in ts.step():
+                    strict_phases[name] = strict_phases.get(name, 0) + 1
+            barrier()
+            t_s = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            if world > 1:
+                torch.distributed.all_reduce(t_s, op=torch.distributed.ReduceOp.MAX)
+            strict = dict(value=global_batch * args.frames * args.strict_steps / float(t_s.item()), ms_per_step=1e3 * float(t_s.item()) / args.strict_steps,
+                          steps=args.strict_steps, phases_run=strict_phases,
+                          what='same step, SGV_CONV_TERMS=0 SGV_WRW_TERMS=0: every 3x3 convolution and weight gradient on MIOpen fp32 (no bf16 products anywhere)')
+        finally:
+            conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms = default_terms
+
     F32_LABEL = 'f32' if conv2d_gradfix.native_conv_terms == 0 and conv2d_gradfix.native_wrw_terms == 0 else \
-        'f32 tensors, f32 accumulation; 3x3 convolutions multiply on the bf16 matrix pipe with hi/lo operand splitting (bf16x3 fp32 emulation, 4e-6 rel. error vs fp64)'
+        'fp32 I/O + fp32 accumulate everywhere; 3x3 convolution products are 2-way-bf16-split (hi/lo, 3 MFMAs per product: 16-bit mantissa operands, 4e-6 rel. error vs fp64; NOT strict fp32 -- see value_strict_fp32)'
     if rank == 0:
         kernels = {}
         roofline = None
@@ -221,8 +263,8 @@ def main():
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
                 roofline_ufd = dict(kernel='upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
-                                    frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch(), launches=r['launches'],
-                                    traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, profiles/r01_pmc_bench_step_FETCH_WRITE.json (reads x2, gfx950 correction)',
+                                    frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch()[0], launches=r['launches'],
+                                    traffic_source=pmc_traffic_per_launch()[1] + ' (reads x2, gfx950 correction)',
                                     avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
                                     note='all launches inside the timed steps (every layer size, fwd+bwd+double-bwd), size-weighted')
             # The contract's `roofline` is the dominant hand-written kernel family of the step (largest summed HIP-event time).
@@ -233,8 +275,8 @@ def main():
                 achieved = e['flops'] / (e['ms'] * 1e-3) / 1e12
                 peak = MFMA_BF16_PEAK_TFLOPS / terms
                 roofline = dict(kernel={'conv3x3': 'conv3x3_kernel / conv3x3_s2_kernel / convT3x3_s2_kernel', 'conv_wrw': 'wrw3x3_kernel / wrw3x3_s2_kernel'}[dom], bound='mfma',
-                                achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=pmc_traffic_conv_family() if dom == 'conv3x3' else None,
-                                traffic_source='rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, profiles/r01_pmc_bench_step_v2_FETCH_WRITE.json (L2-miss bytes: Infinity-Cache hits included)',
+                                achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=pmc_traffic_conv_family()[0] if dom == 'conv3x3' else pmc_traffic(('wrw3x3',))[0],
+                                traffic_source=(pmc_traffic_conv_family()[1] if dom == 'conv3x3' else pmc_traffic(('wrw3x3',))[1]) + ' (L2-miss bytes: Infinity-Cache hits included)',
                                 algorithmic_bytes_per_launch=e['bytes'] / e['launches'], launches=e['launches'],
                                 avg_launch_us=1e3 * e['ms'] / e['launches'], algorithmic_flops_per_launch=e['flops'] / e['launches'],
                                 executed_bf16_TFLOPs=achieved * terms, bf16_dense_peak_TFLOPs=MFMA_BF16_PEAK_TFLOPS, fp32_mfma_peak_TFLOPs=157.3,
@@ -262,6 +304,7 @@ def main():
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
                                native_launches_per_step=launches / args.steps),
+                   value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict,
                    roofline=roofline, roofline_upfirdn2d=roofline_ufd, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -23,6 +23,28 @@ def test_demod_coefs_vs_reference_formula(shape):
     assert_close(d, oracle.modulated_demod_coefs(w, s), atol=0, rtol=2e-5, what='dcoefs')
 
 
+def test_demod_coefs_second_order_gradients_match_plain_autograd():
+    """Path-length regularisation differentiates G twice: the custom node's backward must keep its dependence on BOTH inputs
+    (a saved intermediate q = sum W^2 would come back as a constant and drop d(grad_s)/d(weight))."""
+    g = torch.Generator().manual_seed(12)
+    w0 = torch.randn([6, 5, 3, 3], generator=g)
+    s0 = torch.randn([4, 5], generator=g) + 1
+    v = torch.randn([4, 6], generator=g)
+
+    def second_order(fn, w, s):
+        d = fn(w, s)
+        gw, gs = torch.autograd.grad((d * v.to(d.device, d.dtype)).sum(), [w, s], create_graph=True)
+        return torch.autograd.grad(gw.square().sum() + gs.square().sum(), [w, s])
+    wg, sg = w0.to(DEV).requires_grad_(True), s0.to(DEV).requires_grad_(True)
+    before = custom_ops.launch_count()
+    got = second_order(modulation.demod_coefs, wg, sg)
+    assert custom_ops.launch_count() - before == 2, 'native demodulation kernels did not run'
+    wr, sr = w0.double().requires_grad_(True), s0.double().requires_grad_(True)
+    want = second_order(modulation.demod_coefs_ref, wr, sr)
+    for a, r, name in zip(got, want, ['d2/dweight', 'd2/dstyles']):
+        assert_close(a, r, atol=1e-4 * max(1.0, r.abs().max().item()), rtol=1e-3, what=name)
+
+
 def test_demod_coefs_gradients():
     g = torch.Generator().manual_seed(2)
     w = torch.randn([6, 5, 3, 3], generator=g, dtype=torch.float64).to(DEV).requires_grad_(True)
@@ -330,3 +352,24 @@ def test_plane_dot_and_scale_channels_style_gradient(dtype, shape):
     g_dy, g_x = torch.autograd.grad((ds * u).sum(), [dy, x])
     assert_close(g_dy, x.detach() * u[:, :, None, None], atol=1e-5, rtol=1e-5)
     assert_close(g_x, dy.detach() * u[:, :, None, None], atol=1e-5, rtol=1e-5)
+
+
+def test_grid_sample_gradfix_first_and_second_order_on_gpu():
+    """ADA geometric path (augment.py:300): R1 differentiates the resampler's input gradient again.  Values against the CPU
+    float64 evaluation of the same graph; the stock op would raise in the second backward."""
+    from stylegan_v_amd.torch_utils.ops import grid_sample_gradfix
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn([4, 3, 32, 32], generator=g)
+    theta = torch.tensor([[0.9, 0.15, 0.05], [-0.1, 1.1, -0.2]]).repeat(4, 1, 1) + 0.05 * torch.randn([4, 2, 3], generator=g)
+    v = torch.randn([4, 3, 40, 40], generator=g)
+
+    def run(x, th, vv):
+        grid = torch.nn.functional.affine_grid(th, [4, 3, 40, 40], align_corners=False)
+        y = grid_sample_gradfix.grid_sample(x, grid)
+        (gx,) = torch.autograd.grad((y * vv).sum() + y.square().sum(), x, create_graph=True)
+        (g2,) = torch.autograd.grad(gx.square().sum(), x)
+        return y, gx, g2
+    got = run(x0.to(DEV).requires_grad_(True), theta.to(DEV), v.to(DEV))
+    want = run(x0.double().requires_grad_(True), theta.double(), v.double())
+    for a, r, name in zip(got, want, ['y', 'dx', 'd2x']):
+        assert_close(a, r, atol=2e-4 * max(1.0, r.abs().max().item()), rtol=1e-4, what=name)

@@ -297,6 +297,30 @@ def test_bias_act_gradgradcheck():
         assert torch.autograd.gradgradcheck(fn, (x, b))
 
 
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_bias_act_linear_gain_clamp_is_twice_differentiable_through_the_fused_bias_gradient(dtype):
+    """ToRGB with conv_clamp / linear Conv2dLayer: act='linear' + bias + gain/clamp saves no tensor at all, and the fused
+    dx+db node is picked whenever the bias requires grad.  A create_graph pass (R1, path-length) used to die in its backward."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn([2, 8, 6, 6], generator=g).to(dtype).to(DEV).requires_grad_(True)
+    b = torch.randn([8], generator=g).to(dtype).to(DEV).requires_grad_(True)
+    for gain, clamp in ((1.7, None), (1.0, 0.8), (0.5, 1.2)):
+        y = ba.bias_act(x, b, act='linear', gain=gain, clamp=clamp)
+        (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)       # needs_input_grad is (True, True): fused-db node
+        pen = gx.square().sum() + (y * y).sum()
+        dx2, db2 = torch.autograd.grad(pen, [x, b], allow_unused=True)
+        yr = ba.bias_act(x.detach().double().cpu().requires_grad_(True), b.detach().double().cpu(), act='linear', gain=gain, clamp=clamp, impl='ref')
+        assert_close(y, yr, atol=1e-5, rtol=1e-5, what='y')
+        assert dx2 is not None and torch.isfinite(dx2).all()
+    # explicit second-order value: d/d(dy) of <dx, v> = gain * v where the (native, unmasked) linear gradient applies
+    dy = torch.randn(x.shape, generator=g).to(dtype).to(DEV).requires_grad_(True)
+    y = ba.bias_act(x, b, act='linear', gain=1.7)
+    gx, gb = torch.autograd.grad(y, [x, b], dy, create_graph=True)
+    v = torch.randn(x.shape, generator=g).to(dtype).to(DEV)
+    (ddy,) = torch.autograd.grad((gx * v).sum() + gb.sum(), dy)
+    assert_close(ddy, 1.7 * v + 1.7, atol=1e-5, rtol=1e-5, what='ddy')
+
+
 def test_bias_act_errors():
     x = torch.randn([2, 4, 3, 3], device=DEV)
     with pytest.raises(RuntimeError, match='wrong number of elements'):
