@@ -162,6 +162,14 @@ int sgv_demod_coefs(const float* styles, const float* wsq, float* dcoefs, int32_
 int sgv_plane_dot(const void* a, const void* b, float* out, int32_t planes, int32_t hw, int dtype, void* stream);
 int sgv_scale_channels(const void* x, const float* s, void* y, int32_t n, int32_t c, int32_t hw,
                        int dtype, void* stream);
+/* Backward helpers of the fused convolution layer (sgv_conv3x3_fused), fp32, dense [planes = n*c, hw]:
+ * sgv_act_grad_scale: out = dz * d[plane] with dz = the bias_act gradient (grad 1, act 1 linear / 3 lrelu) of dy evaluated from the saved
+ *   output y; sums (NULL or [2][planes], zero-initialised by the caller) += per-plane sum of dz and of dz * pre-activation
+ *   (-> bias and demodulation-coefficient gradients).  d may be NULL (factor 1).
+ * sgv_scale_dot: out = a * s[plane], dot[plane] += sum a * b  (input gradient and styles gradient of x * styles in one pass). */
+int sgv_act_grad_scale(const float* dy, const float* y, const float* d, float* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
+                       float gain, float clamp, void* stream);
+int sgv_scale_dot(const float* a, const float* b, const float* s, float* out, float* dot, int32_t planes, int32_t hw, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * 1x1 convolutions with <= 4 channels on one side, as HBM streams (ToRGB Cin->3, fromRGB 3->C; NCHW, fp32 accumulate):
@@ -235,6 +243,28 @@ typedef struct sgv_conv3x3_params {
  */
 int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream);
 int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream);
+
+/*
+ * sgv_conv3x3 with the element-wise steps that surround the convolution of a stride-1 SynthesisLayer / Conv2dLayer folded in
+ * (modulated_conv2d training path networks.py:65-74 + `bias_act` networks.py:141-143, layers.py Conv2dLayer.forward):
+ *
+ *     y[n,m] = clamp( act( out_scale[n,m] * conv3x3( x[n,k] * x_scale[n,k] , weight )[n,m] + bias[m] ) * gain )
+ *
+ * x_scale (styles) multiplies the activations on their way into the matrix-core operand tiles; out_scale (demodulation
+ * coefficients), bias, activation (1 = linear, 3 = lrelu with `alpha`), gain and clamp (< 0: none) are applied to the fp32
+ * accumulators before the only store.  Any of the three pointers may be NULL (factor 1 / no bias).  Needs gain > 0 and
+ * 0 <= alpha <= 1.  Result equals the three-pass composition up to fused-multiply-add rounding of the epilogue.
+ * Served for the shapes of sgv_conv3x3_fused_supported() (the big-image kernel: W % 32 == 0, H % 16 == 0).
+ */
+typedef struct sgv_conv3x3_epilogue {
+    const float* x_scale;    /* [n, c_in]  or NULL */
+    const float* out_scale;  /* [n, c_out] or NULL */
+    const float* bias;       /* [c_out]    or NULL */
+    int32_t act;             /* 1 linear, 3 lrelu */
+    float alpha, gain, clamp;
+} sgv_conv3x3_epilogue;
+int sgv_conv3x3_fused(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* e, int dtype, void* stream);
+int sgv_conv3x3_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);
 int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);
 int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode);
 int sgv_conv3x3_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);

@@ -5,10 +5,12 @@
 
 #include "sgv_common.h"
 #include "conv3x3_kernel.h"
+#include "conv3x3_ws_kernel.h"
 #include "conv3x3s2_kernel.h"
 
 #include <algorithm>
 #include <mutex>
+#include <stdlib.h>
 
 using namespace sgv_conv;
 
@@ -29,6 +31,15 @@ bool supported(int n, int k, int m, int h, int w, int dtype) {
 std::once_flag g_attr_once;
 int g_cus = 256;
 hipError_t g_attr_err = hipSuccess;
+bool g_use_ws = true;   // SGV_CONV_WS=0: the 4-wave kernel of conv3x3_kernel.h instead of the producer / consumer form
+
+bool big_image(int h, int w) { return w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0; }
+
+typedef void (*ws_kernel_t)(conv_ws_params);
+// [terms == 3][PRO][EPI]
+const ws_kernel_t g_ws_kernels[2][2][2] = {
+    {{conv3x3_ws_kernel<1, 0, 0>, conv3x3_ws_kernel<1, 0, 1>}, {conv3x3_ws_kernel<1, 1, 0>, conv3x3_ws_kernel<1, 1, 1>}},
+    {{conv3x3_ws_kernel<3, 0, 0>, conv3x3_ws_kernel<3, 0, 1>}, {conv3x3_ws_kernel<3, 1, 0>, conv3x3_ws_kernel<3, 1, 1>}}};
 
 void init_once() {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -41,7 +52,11 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    for (int t = 0; t < 2; t++) for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++)
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)g_ws_kernels[t][a][b], hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
     g_attr_err = e;
+    const char* env = getenv("SGV_CONV_WS");
+    g_use_ws = !(env && env[0] == '0');
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
@@ -62,18 +77,24 @@ extern "C" int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out) {
     return (int64_t)c_in * c_out * 9 * 4;   // bf16 hi + lo per weight
 }
 
-extern "C" int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream_) {
-    if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: params is NULL");
-    if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: NULL pointer");
+namespace {
+
+int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, int dtype, void* stream_, const char* who) {
+    if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: params is NULL", who);
+    if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: NULL pointer", who);
     if (!supported(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, and W %% 32 == 0, H %% 16 == 0 or 16x16 / 8x8 images (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
-                        p->n, p->c_in, p->c_out, p->h, p->w, dtype);
-    if (p->mode != 0 && p->mode != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: mode must be 0 (forward) or 1 (data gradient)");
-    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: terms must be 1 or 3");
-    if (p->workspace_bytes < sgv_conv3x3_workspace_bytes(p->c_in, p->c_out)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: workspace is too small");
-    if ((((uintptr_t)p->x) | ((uintptr_t)p->y) | ((uintptr_t)p->workspace)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3: x, y and workspace must be 16-byte aligned");
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, and W %% 32 == 0, H %% 16 == 0 or 16x16 / 8x8 images (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
+                        who, p->n, p->c_in, p->c_out, p->h, p->w, dtype);
+    if (ep && !big_image(p->h, p->w)) return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: the fused form needs W %% 32 == 0 and H %% 16 == 0 (got h=%d w=%d)", who, p->h, p->w);
+    if (ep && (ep->act != 1 && ep->act != 3)) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: act must be 1 (linear) or 3 (lrelu)", who);
+    if (ep && (!(ep->gain > 0.f) || (ep->act == 3 && !(ep->alpha >= 0.f && ep->alpha <= 1.f)))) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: needs gain > 0 and 0 <= alpha <= 1", who);
+    if (p->mode != 0 && p->mode != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: mode must be 0 (forward) or 1 (data gradient)", who);
+    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: terms must be 1 or 3", who);
+    if (p->workspace_bytes < sgv_conv3x3_workspace_bytes(p->c_in, p->c_out)) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: workspace is too small", who);
+    if ((((uintptr_t)p->x) | ((uintptr_t)p->y) | ((uintptr_t)p->workspace)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: x, y and workspace must be 16-byte aligned", who);
+    if (ep && ep->x_scale && (((uintptr_t)ep->x_scale) & 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: x_scale must be 16-byte aligned", who);
     std::call_once(g_attr_once, init_once);
-    if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
+    if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(g_attr_err));
     hipStream_t stream = (hipStream_t)stream_;
 
     const int words = (p->c_out / TM) * (p->c_in / KC) * 9 * 2 * TM;
@@ -85,7 +106,7 @@ extern "C" int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream_
     conv_params kp{};
     kp.x = (const float*)p->x; kp.wprep = (const u32x4*)p->workspace; kp.y = (float*)p->y;
     kp.n = p->n; kp.k = p->c_in; kp.m = p->c_out; kp.h = p->h; kp.w = p->w;
-    const int small = (p->w >= SEG && p->w % SEG == 0 && p->h % TROWS == 0) ? 0 : small_samples(p->n, p->h, p->w);
+    const int small = big_image(p->h, p->w) ? 0 : small_samples(p->n, p->h, p->w);
     kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * (p->c_out / TM);
     kp.grid = std::min(kp.tiles, g_cus);
     const double elems = (double)p->n * p->h * p->w;
@@ -100,9 +121,35 @@ extern "C" int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream_
         }
         return sgv_check_launch("conv3x3_small_kernel");
     }
+    if (ep || g_use_ws) {
+        conv_ws_params wp{};
+        wp.c = kp;
+        int pro = 0, epi = 0;
+        if (ep) {
+            wp.xscale = ep->x_scale; wp.oscale = ep->out_scale; wp.bias = ep->bias;
+            wp.act = ep->act; wp.alpha = ep->alpha; wp.gain = ep->gain; wp.clamp = ep->clamp;
+            pro = ep->x_scale ? 1 : 0;
+            epi = 1;
+        }
+        hipLaunchKernelGGL(g_ws_kernels[p->terms == 3][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
+        return sgv_check_launch("conv3x3_ws_kernel");
+    }
     if (p->terms == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     else hipLaunchKernelGGL(conv3x3_kernel<3>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     return sgv_check_launch("conv3x3_kernel");
+}
+
+}  // namespace
+
+extern "C" int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream_) { return conv3x3_impl(p, nullptr, dtype, stream_, "conv3x3"); }
+
+extern "C" int sgv_conv3x3_fused(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* e, int dtype, void* stream_) {
+    if (!e) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_fused: epilogue is NULL");
+    return conv3x3_impl(p, e, dtype, stream_, "conv3x3_fused");
+}
+
+extern "C" int sgv_conv3x3_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {
+    return supported(n, c_in, c_out, h, w, dtype) && big_image(h, w) ? 1 : 0;
 }
 
 extern "C" int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {

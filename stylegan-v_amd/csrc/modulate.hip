@@ -131,7 +131,105 @@ void launch_plane_dot(const void* a, const void* b, float* out, int planes, int 
     hipLaunchKernelGGL(plane_dot_kernel<T>, grid, dim3(256), 0, stream, (const T*)a, (const T*)b, out, hw, vec_ok);
 }
 
+// Backward prologue of a fused "conv -> * d[n,c] -> + bias -> lrelu/linear -> * gain -> clamp" layer (csrc/conv3x3_ws_kernel.h, EPI = 1), one pass:
+//   dz    = bias_act gradient (bias_act.cu:39-146, grad = 1) of the incoming dy, from the saved OUTPUT y: ((y > 0) ? dy : dy * alpha) * gain, 0 where clamped
+//   out   = dz * d[plane]                               gradient w.r.t. the convolution result
+//   sums[0][plane] += sum dz                            -> bias gradient (summed over samples by the caller)
+//   sums[1][plane] += sum dz * v,  v = pre-activation   -> demodulation-coefficient gradient: (sums[1] - bias * sums[0]) / d
+// dz * v needs no inverse activation: dz = dy * gain * slope and v = y / (gain * slope), so dz * v = dy * y wherever dz != 0.
+__global__ __launch_bounds__(256) void act_grad_scale_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ d,
+                                                             float* __restrict__ out, float* __restrict__ sums, int planes, int hw, int act, float alpha, float gain,
+                                                             float clamp, int vec_ok) {
+    const int plane = blockIdx.y;
+    const int p0 = blockIdx.x * PD_CHUNK, p1 = min(hw, p0 + PD_CHUNK);
+    const float* gp = dy + (size_t)plane * hw;
+    const float* yp = y + (size_t)plane * hw;
+    float* op = out + (size_t)plane * hw;
+    const float dsc = d ? d[plane] : 1.f;
+    float sg = 0.f, sgv = 0.f;
+    auto one = [&](float g, float yy) {
+        float dz = ((act == 3 && !(yy > 0.f)) ? g * alpha : g) * gain;
+        float gv = g * yy;
+        if (clamp >= 0.f && !(yy > -clamp & yy < clamp)) { dz = 0.f; gv = 0.f; }
+        sg += dz;
+        sgv += gv;
+        return dz * dsc;
+    };
+    if (vec_ok) {
+        for (int i = p0 + threadIdx.x * 4; i < p1; i += 256 * 4) {
+            const float4 g = *(const float4*)(gp + i), yy = *(const float4*)(yp + i);
+            float4 o;
+            o.x = one(g.x, yy.x); o.y = one(g.y, yy.y); o.z = one(g.z, yy.z); o.w = one(g.w, yy.w);
+            *(float4*)(op + i) = o;
+        }
+    } else {
+        for (int i = p0 + threadIdx.x; i < p1; i += 256) op[i] = one(gp[i], yp[i]);
+    }
+    if (!sums) return;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgv += __shfl_xor(sgv, off, 64); }
+    __shared__ float part[8];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = sg; part[4 + (threadIdx.x >> 6)] = sgv; }
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(sums + plane, (part[0] + part[1]) + (part[2] + part[3]));
+    if (threadIdx.x == 64) atomicAdd(sums + planes + plane, (part[4] + part[5]) + (part[6] + part[7]));
+}
+
+// out = a * s[plane] and dot[plane] += sum a * b in one pass: the input gradient dx = dxs * styles of a modulated layer together with the
+// styles gradient sum_px dxs * x (networks.py:66), instead of plane_dot + scale_channels (5 tensor passes -> 3).
+__global__ __launch_bounds__(256) void scale_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ s, float* __restrict__ out,
+                                                        float* __restrict__ dot, int hw, int vec_ok) {
+    const int plane = blockIdx.y;
+    const int p0 = blockIdx.x * PD_CHUNK, p1 = min(hw, p0 + PD_CHUNK);
+    const float* ap = a + (size_t)plane * hw;
+    const float* bp = b + (size_t)plane * hw;
+    float* op = out + (size_t)plane * hw;
+    const float sc = s[plane];
+    float acc = 0.f;
+    if (vec_ok) {
+        for (int i = p0 + threadIdx.x * 4; i < p1; i += 256 * 4) {
+            const float4 va = *(const float4*)(ap + i), vb = *(const float4*)(bp + i);
+            acc = __builtin_fmaf(va.x, vb.x, acc); acc = __builtin_fmaf(va.y, vb.y, acc); acc = __builtin_fmaf(va.z, vb.z, acc); acc = __builtin_fmaf(va.w, vb.w, acc);
+            *(float4*)(op + i) = float4{va.x * sc, va.y * sc, va.z * sc, va.w * sc};
+        }
+    } else {
+        for (int i = p0 + threadIdx.x; i < p1; i += 256) { const float va = ap[i]; acc = __builtin_fmaf(va, bp[i], acc); op[i] = va * sc; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dot + plane, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
 }  // namespace
+
+extern "C" int sgv_act_grad_scale(const float* dy, const float* y, const float* d, float* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
+                                  float gain, float clamp, void* stream_) {
+    if (!dy || !y || !out) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: NULL pointer");
+    if (planes < 1 || hw < 1 || planes > 65535) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: needs 1 <= planes <= 65535, hw >= 1");
+    if ((int64_t)planes * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "act_grad_scale: tensors are too large");
+    if (act != 1 && act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: act must be 1 (linear) or 3 (lrelu)");
+    hipStream_t stream = (hipStream_t)stream_;
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * 4.0);
+    const int vec_ok = (hw % 4 == 0) && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
+    dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)planes);
+    hipLaunchKernelGGL(act_grad_scale_kernel, grid, dim3(256), 0, stream, dy, y, d, out, sums, planes, hw, act, alpha, gain, clamp, vec_ok);
+    return sgv_check_launch("act_grad_scale_kernel");
+}
+
+extern "C" int sgv_scale_dot(const float* a, const float* b, const float* s, float* out, float* dot, int32_t planes, int32_t hw, void* stream_) {
+    if (!a || !b || !s || !out || !dot) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: NULL pointer");
+    if (planes < 1 || hw < 1 || planes > 65535) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: needs 1 <= planes <= 65535, hw >= 1");
+    if ((int64_t)planes * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "scale_dot: tensors are too large");
+    hipStream_t stream = (hipStream_t)stream_;
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * 4.0);
+    const int vec_ok = (hw % 4 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0);
+    dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)planes);
+    hipLaunchKernelGGL(scale_dot_kernel, grid, dim3(256), 0, stream, a, b, s, out, dot, hw, vec_ok);
+    return sgv_check_launch("scale_dot_kernel");
+}
 
 extern "C" int sgv_plane_dot(const void* a, const void* b, float* out, int32_t planes, int32_t hw, int dtype, void* stream_) {
     if (!a || !b || !out) return sgv_fail(SGV_ERR_INVALID_ARG, "plane_dot: NULL pointer");

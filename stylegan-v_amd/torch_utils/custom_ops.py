@@ -187,6 +187,10 @@ class Conv3x3Params(ctypes.Structure):
                 ('c_out', c_int32), ('h', c_int32), ('w', c_int32), ('mode', c_int32), ('terms', c_int32)]
 
 
+class Conv3x3Epilogue(ctypes.Structure):
+    _fields_ = [('x_scale', c_void_p), ('out_scale', c_void_p), ('bias', c_void_p), ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
+
+
 class TimeEncodeParams(ctypes.Structure):
     _fields_ = [(name, c_void_p) for name in
                 ['periods', 'phases', 'al', 'ar', 'freqs', 'phase_scales', 't', 't_left', 't_right', 'alpha', 'out']] + \
@@ -219,10 +223,14 @@ ABI_SYMBOLS = {
     'sgv_demod_coefs': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
     'sgv_scale_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_plane_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int, c_void_p]),
+    'sgv_act_grad_scale': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p]),
+    'sgv_scale_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'sgv_pointwise_small': (c_int, [ctypes.POINTER(PointwiseParams), c_int, c_void_p]),
     'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_conv3x3': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
     'sgv_conv3x3_s2': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
+    'sgv_conv3x3_fused': (c_int, [ctypes.POINTER(Conv3x3Params), ctypes.POINTER(Conv3x3Epilogue), c_int, c_void_p]),
+    'sgv_conv3x3_fused_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_s2_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_s2_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'sgv_conv3x3_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),

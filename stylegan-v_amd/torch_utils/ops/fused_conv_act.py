@@ -1,0 +1,170 @@
+"""Fused stride-1 3x3 layer:  y = clamp(act(dcoefs[n,o] * conv3x3(x * styles[n,i], W) + bias[o]) * gain).
+
+The reference evaluates this as four separate full-tensor operations on the training path -- ``x * styles`` (networks.py:66),
+the convolution (conv2d_resample.py:40-54 -> conv2d_gradfix.py:35), ``x * dcoefs`` (networks.py:70-71) and ``bias_act``
+(networks.py:141-143; layers.py ``Conv2dLayer.forward`` for the un-modulated discriminator layers).  There is no single
+reference op to mirror, so -- like ``fused_fir_act`` -- this is an internal fusion of that sequence:
+``conv3x3_bias_act`` is DEFINED as the composition (`conv3x3_bias_act_composed`), and on the GPU it runs as
+
+  forward   ONE kernel (``sgv_conv3x3_fused``, csrc/conv3x3_ws_kernel.h): the styles multiply the activations on their way into
+            the matrix-core operand tiles, dcoefs / bias / activation / gain / clamp are applied to the accumulators before the
+            only store.  Six full-tensor passes of the composition disappear.
+  backward  ``sgv_act_grad_scale`` (activation gradient from the saved OUTPUT, times dcoefs, with the per-plane sums that give
+            the bias and dcoefs gradients) -> data-gradient convolution -> ``sgv_scale_dot`` (input gradient and styles gradient
+            in one pass) -> weight-gradient convolution on the re-scaled input.
+
+Second order: when the node's gradient is itself differentiated (``create_graph=True``) its backward switches to differentiating
+the composition on the saved inputs (one extra forward), so gradients of any order exist.  Passes that are known to be
+differentiated twice (R1, path-length regularisation; training/loss.py) run under ``composition_only()`` and skip the fused
+forward altogether; so do CPU tensors, 16-bit tensors and shapes the kernel does not serve.  Parity: forward within fused-multiply-add rounding of the composition (1e-6),
+tests/test_fused_conv_gpu.py against the oracle composition.
+"""
+
+import contextlib
+import os
+
+import torch
+
+from .. import custom_ops
+from . import bias_act as _ba
+from . import conv2d_gradfix as _cg
+from . import modulation as _mod
+
+# 0: never fuse; 1: only passes that record no autograd graph (the generator pass of the D phase, inference); 2: training too
+mode = int(os.environ.get('SGV_FUSED_CONV', '2'))
+_composition_depth = 0
+
+
+@contextlib.contextmanager
+def composition_only():
+    """Inside this context the layer is evaluated as its composition (needed wherever the result is differentiated twice)."""
+    global _composition_depth
+    _composition_depth += 1
+    try:
+        yield
+    finally:
+        _composition_depth -= 1
+
+
+def conv3x3_bias_act_composed(x, weight, styles=None, dcoefs=None, bias=None, act='lrelu', alpha=None, gain=None, clamp=None):
+    """The definition: scale -> conv -> scale -> bias_act, each differentiable to any order."""
+    if styles is not None:
+        x = _mod.scale_channels(x, styles)
+    y = _cg.conv2d(x, weight.to(x.dtype), padding=1)
+    if dcoefs is not None:
+        y = _mod.scale_channels(y, dcoefs)
+    return _ba.bias_act(y, bias.to(y.dtype) if bias is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)
+
+
+def _launch_fused(x, weight, styles, dcoefs, bias, act_idx, alpha, gain, clamp):
+    lib = custom_ops.get_native()
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    y = torch.empty([n, co, h, w], dtype=torch.float32, device=x.device)
+    ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
+    ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
+    p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, 0, _cg.native_conv_terms)
+    e = custom_ops.Conv3x3Epilogue(styles.data_ptr() if styles is not None else None, dcoefs.data_ptr() if dcoefs is not None else None,
+                                   bias.data_ptr() if bias is not None else None, act_idx, alpha, gain, clamp)
+    with custom_ops.device_guard(x):
+        custom_ops.check(lib.sgv_conv3x3_fused(p, e, 0, custom_ops.raw_stream(x)), lib)
+    return y
+
+
+class _FusedConvBiasActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, styles, dcoefs, bias, cfg):
+        act, alpha, gain, clamp = cfg
+        s = styles.contiguous() if styles is not None else None
+        d = dcoefs.contiguous() if dcoefs is not None else None
+        b = bias.contiguous().float() if bias is not None else None
+        y = _launch_fused(x.contiguous(), weight.contiguous(), s, d, b, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
+        ctx.cfg = cfg
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        ctx.save_for_backward(x, weight, styles, dcoefs, bias, y)   # the inputs themselves: the create_graph path below needs their history
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        act, alpha, gain, clamp = ctx.cfg
+        x, weight, s, d, b, y = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # create_graph=True (somebody differentiates this gradient again, e.g. R1 without `composition_only()`): differentiate the
+            # composition on the saved inputs instead -- one extra forward, gradients of any order.
+            ins = [t for t, need in zip((x, weight, s, d, b), ctx.needs_input_grad[:5]) if need and t is not None]
+            with torch.enable_grad():
+                y2 = conv3x3_bias_act_composed(x, weight, styles=s, dcoefs=d, bias=b, act=act, alpha=alpha, gain=gain, clamp=(clamp if clamp >= 0 else None))
+                grads = iter(torch.autograd.grad(y2, ins, dy, create_graph=True, allow_unused=True))
+            return tuple(next(grads) if (need and t is not None) else None for t, need in zip((x, weight, s, d, b), ctx.needs_input_grad[:5])) + (None,)
+        lib = custom_ops.get_native()
+        dy, x, weight = dy.contiguous(), x.contiguous(), weight.contiguous()
+        s = s.contiguous() if s is not None else None
+        d = d.contiguous() if d is not None else None
+        b = b.contiguous().float() if b is not None else None
+        n, co, h, w = y.shape
+        ci = x.shape[1]
+        stream = custom_ops.raw_stream(dy)
+        need_sums = (b is not None and ctx.needs_input_grad[4]) or (d is not None and ctx.needs_input_grad[3])
+        sums = torch.zeros([2, n * co], dtype=torch.float32, device=dy.device) if need_sums else None
+        dzd = torch.empty_like(y)     # gradient w.r.t. the convolution result: bias_act gradient times dcoefs
+        with custom_ops.device_guard(dy):
+            custom_ops.check(lib.sgv_act_grad_scale(dy.data_ptr(), y.data_ptr(), d.data_ptr() if d is not None else None, dzd.data_ptr(),
+                                                    sums.data_ptr() if sums is not None else None, n * co, h * w,
+                                                    _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, stream), lib)
+        d_x = d_w = d_s = d_d = d_b = None
+        if b is not None and ctx.needs_input_grad[4]:
+            d_b = sums[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
+        if d is not None and ctx.needs_input_grad[3]:
+            sg, sgv = sums[0].reshape(n, co), sums[1].reshape(n, co)
+            d_d = (sgv - (b.reshape(1, co) * sg if b is not None else 0.0)) / d
+        cfg = (False, (1, 1), (1, 1), (0, 0), (1, 1), 1)
+        if ctx.needs_input_grad[0] or (s is not None and ctx.needs_input_grad[2]):
+            dxs = _cg._native_conv(dzd, weight, (True, (1, 1), (1, 1), (0, 0), (1, 1), 1))    # data gradient: transposed form, same kernel family
+            if s is not None:
+                d_x = torch.empty_like(dxs)
+                dot = torch.zeros([n * ci], dtype=torch.float32, device=dy.device)
+                with custom_ops.device_guard(dy):
+                    custom_ops.check(lib.sgv_scale_dot(dxs.data_ptr(), x.data_ptr(), s.data_ptr(), d_x.data_ptr(), dot.data_ptr(), n * ci, h * w, stream), lib)
+                d_s = dot.reshape(n, ci)
+            else:
+                d_x = dxs
+        if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
+            xs = _mod.scale_channels(x, s) if s is not None else x
+            if _cg._native_wrw_ok(dzd, xs, cfg, tuple(weight.shape)):
+                d_w = _cg._native_wrw(dzd, xs, cfg, tuple(weight.shape))
+            else:
+                _, d_w, _ = torch.ops.aten.convolution_backward(dzd, xs, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
+        return d_x, d_w, d_s, d_d, d_b, None
+
+
+def _fusable(x, weight, styles, dcoefs, bias, act, alpha, gain, clamp):
+    if act == 'linear' and clamp >= 0:   # the reference's linear + clamp gradient is NOT masked where the output saturated (bias_act.py:24 saves no y); keep that
+        return False
+    if mode == 0 or _composition_depth > 0 or _cg.native_conv_terms not in (1, 3) or not _cg.enabled:
+        return False
+    if not (x.is_cuda and x.ndim == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    if act not in ('linear', 'lrelu') or not gain > 0 or (act == 'lrelu' and not 0 <= alpha <= 1):
+        return False
+    n, ci, h, w = x.shape
+    co = weight.shape[0]
+    if weight.shape[1] != ci or n * max(ci, co) > 65535:
+        return False
+    for t, c in ((styles, ci), (dcoefs, co)):
+        if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (n, c)):
+            return False
+    if bias is not None and tuple(bias.shape) != (co,):
+        return False
+    needs_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, styles, dcoefs, bias))
+    if needs_graph and mode < 2:
+        return False
+    return bool(custom_ops.get_native().sgv_conv3x3_fused_supported(n, ci, co, h, w, 0))
+
+
+def conv3x3_bias_act(x, weight, styles=None, dcoefs=None, bias=None, act='lrelu', alpha=None, gain=None, clamp=None):
+    """x [N,I,H,W]; weight [O,I,3,3] (correlation, padding 1); styles [N,I] / dcoefs [N,O] fp32 or None; bias [O] or None;
+    act / alpha / gain / clamp as ``bias_act``."""
+    _, alpha_f, gain_f, clamp_f = _ba._resolve(act, alpha, gain, clamp)
+    if _fusable(x, weight, styles, dcoefs, bias, act, alpha_f, gain_f, clamp_f):
+        return _FusedConvBiasActFn.apply(x, weight, styles, dcoefs, bias, (act, alpha_f, gain_f, clamp_f))
+    return conv3x3_bias_act_composed(x, weight, styles=styles, dcoefs=dcoefs, bias=bias, act=act, alpha=alpha, gain=gain, clamp=clamp)

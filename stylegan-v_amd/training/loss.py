@@ -10,12 +10,14 @@ frame per video -- with F > 1 the reference's penalty shapes do not broadcast (l
 StyleGAN-V config disables it (``pl_weight: 0``).  The same ``RuntimeError`` surfaces here.
 """
 
+import contextlib
+
 import numpy as np
 import torch
 import torch.nn.functional as F
 
 from ..torch_utils import misc
-from ..torch_utils.ops import conv2d_gradfix
+from ..torch_utils.ops import conv2d_gradfix, fused_conv_act
 
 
 class StyleGAN2Loss:
@@ -72,7 +74,8 @@ class StyleGAN2Loss:
 
         if do_Gpl:  # path-length regularisation (second-order through G)
             bs = gen_z.shape[0] // self.pl_batch_shrink
-            gen_img, gen_ws = self.run_G(gen_z[:bs], gen_c[:bs], gen_t[:bs], sync=sync)
+            with fused_conv_act.composition_only():   # differentiated twice below
+                gen_img, gen_ws = self.run_G(gen_z[:bs], gen_c[:bs], gen_t[:bs], sync=sync)
             pl_noise = torch.randn_like(gen_img) / np.sqrt(gen_img.shape[2] * gen_img.shape[3])
             with conv2d_gradfix.no_weight_gradients():
                 (pl_grads,) = torch.autograd.grad(outputs=[(gen_img * pl_noise).sum()], inputs=[gen_ws], create_graph=True, only_inputs=True)
@@ -93,7 +96,8 @@ class StyleGAN2Loss:
 
         if do_Dmain or do_Dr1:  # maximise logits of real clips and/or R1 penalty on them
             real_tmp = real_img.detach().requires_grad_(do_Dr1)
-            logits = self.run_D(real_tmp, real_c, real_t, sync=sync)['image_logits']
+            with (fused_conv_act.composition_only() if do_Dr1 else contextlib.nullcontext()):   # R1 differentiates this pass twice
+                logits = self.run_D(real_tmp, real_c, real_t, sync=sync)['image_logits']
             loss_Dreal = 0
             if do_Dmain:
                 loss_Dreal = F.softplus(-logits)

@@ -12,7 +12,14 @@ What is different underneath (MI355X-first, same results to fp32 round-off):
   * the per-sample channel scalings x*s and y*d are single streaming kernels (``scale_channels``);
   * every FIR resampling / bias+activation step is a hand-written gfx950 kernel (upfirdn2d, bias_act);
   * low-precision blocks can run bf16 as well as the reference's fp16 (``lowp_dtype``).
-3x3 convolutions stay on MIOpen, as the reference leaves them to cuDNN.
+  * 3x3 convolutions (forward, data and weight gradients, stride 1 and the stride-2 pairs around the FIR) run on the
+    hand-written matrix-core kernels of csrc/conv3x3*.h / wrw_kernel.h; a stride-1 SynthesisLayer is ONE kernel forward
+    (``ops.fused_conv_act``: styles in the operand load, dcoefs / bias / lrelu / gain / clamp in the accumulator store), an
+    up-sampling one is transposed convolution + one FIR kernel with the same epilogue (``ops.fused_fir_act``);
+  * on the GPU, eval-mode synthesis uses the same activation-scaling formulation as training (``prefer_native_inference``)
+    instead of the reference's per-sample grouped convolution -- the same function, without per-sample weight tensors.
+Shapes the kernels do not serve (4x4 layers, odd channel counts, 16-bit tensors) fall back to MIOpen, as the reference leaves
+every convolution to cuDNN.
 """
 
 import math
@@ -21,9 +28,12 @@ import numpy as np
 import torch
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, fma, fused_fir_act, modulation, pointwise, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_resample, fma, fused_conv_act, fused_fir_act, modulation, pointwise, upfirdn2d
 from .layers import Conv2dLayer, FullyConnectedLayer, GenInput, MappingNetwork, TemporalDifferenceEncoder
 from .motion import MotionMappingNetwork
+
+
+prefer_native_inference = True   # GPU eval-mode synthesis: scale-conv-scale through the native kernels instead of the grouped convolution
 
 
 @misc.profiled_function
@@ -113,6 +123,13 @@ class SynthesisLayer(torch.nn.Module):
                                                                flip_weight=False)
             return fused_fir_act.fir_bias_act(x, self.resample_filter, scale=dcoefs, bias=self.bias, padding=fir_pad, fir_gain=self.up ** 2,
                                               act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        if self.up == 1 and not fused_modconv and noise is None and fused_conv_act.mode and x.is_cuda and x.dtype == torch.float32 \
+                and self.activation in ('linear', 'lrelu') and tuple(self.weight.shape[2:]) == (3, 3) and self.padding == 1:
+            # Stride-1 layer, training formulation: [x*s -> conv3x3 -> *dcoefs + bias -> act -> clamp] as one kernel where the shape is
+            # served (ops/fused_conv_act.py), as the four-op composition otherwise.
+            dcoefs = modulation.demod_coefs(self.weight, styles)
+            return fused_conv_act.conv3x3_bias_act(x, self.weight, styles=styles, dcoefs=dcoefs, bias=self.bias, act=self.activation,
+                                                   gain=self.act_gain * gain, clamp=clamp)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)
         return bias_act.bias_act(x, self.bias.to(x.dtype), act=self.activation, gain=self.act_gain * gain, clamp=clamp)
@@ -178,6 +195,8 @@ class SynthesisBlock(torch.nn.Module):
         fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
         if fused_modconv is None:  # reference policy (networks.py:230-232)
             fused_modconv = (not self.training) and (dtype == torch.float32 or (isinstance(x, torch.Tensor) and int(x.shape[0]) == 1))
+            if fused_modconv and prefer_native_inference and ws.is_cuda and dtype == torch.float32:
+                fused_modconv = False
 
         if self.in_channels == 0:
             x = self.input(ws.shape[0], motion_v=motion_v, dtype=dtype, memory_format=fmt)

@@ -6,7 +6,7 @@
 #include <math.h>
 #include <vector>
 #include "conv3x3_kernel.h"
-#include "../tools/experimental_conv3x3_ws.h"
+#include "conv3x3_ws_kernel.h"
 
 using namespace sgv_conv;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -45,6 +45,7 @@ template <int TERMS> static void launch(const float* x, const float* w, float* y
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 5;
+    const bool legacy = argc <= 2;   // `conv_lab 5 ws`: only the producer / consumer sections
     {   // ---- correctness ----
         for (int mode = 0; mode < 2; mode++) {
             const int n = 2, k = 32, m = 128, h = 32, wd = 64;
@@ -67,7 +68,7 @@ int main(int argc, char** argv) {
             CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(ref)); CK(hipFree(wprep));
         }
     }
-    for (int sw : {16, 8}) for (int mode = 0; mode < 2; mode++) {   // ---- small-image kernel: correctness + timing ----
+    if (legacy) for (int sw : {16, 8}) for (int mode = 0; mode < 2; mode++) {   // ---- small-image kernel: correctness + timing ----
         const int n = 16, k = 32, m = 128;
         const size_t nx = (size_t)n * k * sw * sw, ny = (size_t)n * m * sw * sw, nw = (size_t)m * k * 9;
         float *x, *w, *y; double* ref; u32x4* wprep;
@@ -96,7 +97,7 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(ref)); CK(hipFree(wprep));
     }
-    for (int sw : {16, 8}) {   // timing at the training shapes: [96, 512, sw, sw] -> 512
+    if (legacy) for (int sw : {16, 8}) {   // timing at the training shapes: [96, 512, sw, sw] -> 512
         const int n = 96, c = 512;
         const size_t na = (size_t)n * c * sw * sw, nw = (size_t)c * c * 9;
         float *x, *w, *y; u32x4* wprep;
@@ -119,7 +120,7 @@ int main(int argc, char** argv) {
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep));
     }
     struct { const char* name; int n, c, r; } shapes[] = { {"64ch 256^2", 96, 64, 256}, {"128ch 128^2", 96, 128, 128}, {"256ch 64^2", 96, 256, 64}, {"512ch 32^2", 96, 512, 32} };
-    for (auto& s : shapes) {
+    if (legacy) for (auto& s : shapes) {
         const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
         float *x, *w, *y; u32x4* wprep;
         CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
@@ -138,7 +139,7 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep));
     }
-    for (auto& s : shapes) {   // ---- RW = 2 variant: 8-row tiles, two workgroups per CU ----
+    if (legacy) for (auto& s : shapes) {   // ---- RW = 2 variant: 8-row tiles, two workgroups per CU ----
         const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
         float *x, *w, *y; u32x4* wprep; double* ref = nullptr;
         CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
@@ -166,32 +167,103 @@ int main(int argc, char** argv) {
         }
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep)); (void)ref;
     }
-    if (getenv("SGV_LAB_WS")) for (auto& s : shapes) {   // ---- EXPERIMENTAL producer/consumer variant (tools/experimental_conv3x3_ws.h), opt-in: never run on hardware yet -- run it under `timeout` ----
+    {   // ---- producer / consumer kernel (conv3x3_ws_kernel.h): correctness vs the naive fp64 kernel, plain and with prologue / epilogue ----
+        CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+        CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+        CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+        for (int mode = 0; mode < 2; mode++) {
+            const int n = 3, k = 48, m = 128, h = 32, wd = 64;
+            const size_t nx = (size_t)n * k * h * wd, ny = (size_t)n * m * h * wd, nw = (size_t)m * k * 9;
+            float *x, *w, *y, *xsc, *osc, *bias; double* ref; u32x4* wprep;
+            CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&y, ny * 4)); CK(hipMalloc(&ref, ny * 8)); CK(hipMalloc(&wprep, nw * 4));
+            CK(hipMalloc(&xsc, n * k * 4)); CK(hipMalloc(&osc, n * m * 4)); CK(hipMalloc(&bias, m * 4));
+            fill<<<(nx + 255) / 256, 256>>>(x, nx, 11u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 23u, 0.1f);
+            fill<<<1, 256>>>(xsc, n * k, 31u, 1.f); fill<<<2, 256>>>(osc, n * m, 37u, 1.f); fill<<<1, 256>>>(bias, m, 41u, 0.5f);
+            naive_conv<<<(ny + 255) / 256, 256>>>(x, w, ref, n, k, m, h, wd, mode);
+            std::vector<double> r(ny); std::vector<float> gpu(ny), hx(n * k), ho(n * m), hb(m), old(ny);
+            CK(hipMemcpy(r.data(), ref, ny * 8, hipMemcpyDeviceToHost));
+            launch<3>(x, w, y, wprep, n, k, m, h, wd, mode, 256);   // product kernel (also prepares the weights)
+            CK(hipMemcpy(old.data(), y, ny * 4, hipMemcpyDeviceToHost));
+            conv_ws_params pp{};
+            pp.c.x = x; pp.c.wprep = wprep; pp.c.y = y; pp.c.n = n; pp.c.k = k; pp.c.m = m; pp.c.h = h; pp.c.w = wd;
+            pp.c.tiles = n * (h / TROWS) * (wd / SEG) * (m / TM);
+            for (int grid : {256, 5, 1}) {
+                pp.c.grid = grid < pp.c.tiles ? grid : pp.c.tiles;
+                CK(hipMemset(y, 0xff, ny * 4));
+                hipLaunchKernelGGL((conv3x3_ws_kernel<3, 0, 0>), dim3(pp.c.grid), dim3(512), WS_LDS_BYTES, 0, pp);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(gpu.data(), y, ny * 4, hipMemcpyDeviceToHost));
+                double maxerr = 0, maxref = 0; size_t diff = 0;
+                for (size_t q = 0; q < ny; q++) { double e = fabs(gpu[q] - r[q]); if (!(e <= maxerr)) maxerr = e; if (fabs(r[q]) > maxref) maxref = fabs(r[q]); if (gpu[q] != old[q]) diff++; }
+                printf("check ws mode=%d grid=%d: max abs err %.3e (max |ref| %.3e); %zu of %zu outputs differ bitwise from the 4-wave kernel\n", mode, pp.c.grid, maxerr, maxref, diff, ny);
+            }
+            // prologue + epilogue: y = lrelu((conv(x * xs) * os + b)) * gain with the naive kernel on pre-scaled x as reference
+            CK(hipMemcpy(hx.data(), xsc, n * k * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ho.data(), osc, n * m * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), bias, m * 4, hipMemcpyDeviceToHost));
+            float* x2; CK(hipMalloc(&x2, nx * 4));
+            { std::vector<float> hx0(nx); CK(hipMemcpy(hx0.data(), x, nx * 4, hipMemcpyDeviceToHost));
+              for (size_t q = 0; q < nx; q++) hx0[q] *= hx[q / ((size_t)h * wd)];
+              CK(hipMemcpy(x2, hx0.data(), nx * 4, hipMemcpyHostToDevice)); }
+            naive_conv<<<(ny + 255) / 256, 256>>>(x2, w, ref, n, k, m, h, wd, mode);
+            CK(hipMemcpy(r.data(), ref, ny * 8, hipMemcpyDeviceToHost));
+            pp.xscale = xsc; pp.oscale = osc; pp.bias = bias; pp.act = 3; pp.alpha = 0.2f; pp.gain = 1.41421356f; pp.clamp = -1.f;
+            for (int grid : {256, 5}) {
+                pp.c.grid = grid < pp.c.tiles ? grid : pp.c.tiles;
+                CK(hipMemset(y, 0xff, ny * 4));
+                hipLaunchKernelGGL((conv3x3_ws_kernel<3, 1, 1>), dim3(pp.c.grid), dim3(512), WS_LDS_BYTES, 0, pp);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(gpu.data(), y, ny * 4, hipMemcpyDeviceToHost));
+                double maxerr = 0, maxref = 0;
+                for (size_t q = 0; q < ny; q++) {
+                    const size_t pl = q / ((size_t)h * wd);   // n * m + mm
+                    double v = r[q] * ho[pl] + hb[pl % m]; v = (v > 0 ? v : 0.2 * v) * 1.41421356;
+                    double e = fabs(gpu[q] - v); if (!(e <= maxerr)) maxerr = e; if (fabs(v) > maxref) maxref = fabs(v);
+                }
+                printf("check ws PRO=1 EPI=1 mode=%d grid=%d: max abs err %.3e (max |ref| %.3e)\n", mode, pp.c.grid, maxerr, maxref);
+            }
+            CK(hipFree(x)); CK(hipFree(x2)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(ref)); CK(hipFree(wprep)); CK(hipFree(xsc)); CK(hipFree(osc)); CK(hipFree(bias));
+        }
+    }
+    for (auto& s : shapes) {   // ---- producer / consumer kernel: timing at the training shapes, interleaved with the 4-wave kernel ----
         const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
-        float *x, *w, *y; u32x4* wprep;
+        float *x, *w, *y, *xsc, *osc, *bias; u32x4* wprep;
         CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
+        CK(hipMalloc(&xsc, s.n * s.c * 4)); CK(hipMalloc(&osc, s.n * s.c * 4)); CK(hipMalloc(&bias, s.c * 4));
         fill<<<(na + 255) / 256, 256>>>(x, na, 5u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 7u, 0.1f);
+        fill<<<(s.n * s.c + 255) / 256, 256>>>(xsc, s.n * s.c, 31u, 1.f); fill<<<(s.n * s.c + 255) / 256, 256>>>(osc, s.n * s.c, 37u, 1.f); fill<<<(s.c + 255) / 256, 256>>>(bias, s.c, 41u, 0.5f);
         launch<3>(x, w, y, wprep, s.n, s.c, s.c, s.r, s.r, 0, 256);
         std::vector<float> a(1 << 20), b(1 << 20);
         CK(hipMemcpy(a.data(), y + na / 2, a.size() * 4, hipMemcpyDeviceToHost));
-        conv_params p{};
-        p.x = x; p.wprep = wprep; p.y = y; p.n = s.n; p.k = s.c; p.m = s.c; p.h = s.r; p.w = s.r;
-        p.tiles = s.n * (s.r / TROWS) * (s.r / SEG) * (s.c / TM); p.grid = 256;
-        CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+        conv_ws_params pp{};
+        pp.c.x = x; pp.c.wprep = wprep; pp.c.y = y; pp.c.n = s.n; pp.c.k = s.c; pp.c.m = s.c; pp.c.h = s.r; pp.c.w = s.r;
+        pp.c.tiles = s.n * (s.r / TROWS) * (s.r / SEG) * (s.c / TM); pp.c.grid = 256;
+        pp.xscale = xsc; pp.oscale = osc; pp.bias = bias; pp.act = 3; pp.alpha = 0.2f; pp.gain = 1.41421356f; pp.clamp = -1.f;
+        conv_params p0 = pp.c;
         CK(hipMemset(y, 0, na * 4));
-        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        hipLaunchKernelGGL((conv3x3_ws_kernel<3>), dim3(256), dim3(512), WS_LDS_BYTES, 0, p);
+        hipLaunchKernelGGL((conv3x3_ws_kernel<3, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(b.data(), y + na / 2, b.size() * 4, hipMemcpyDeviceToHost));
         double md = 0; for (size_t i = 0; i < a.size(); i++) md = fmax(md, fabs((double)a[i] - b[i]));
-        CK(hipEventRecord(e0));
-        for (int r = 0; r < reps; r++) hipLaunchKernelGGL((conv3x3_ws_kernel<3>), dim3(256), dim3(512), WS_LDS_BYTES, 0, p);
-        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        printf("%-12s ws (producer/consumer, EXPERIMENTAL) terms=3  %8.3f ms  %7.1f TFLOP/s   max |diff| vs product kernel: %.2e\n", s.name, ms, 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9 / ms / 1e9, md);
-        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep));
+        const double flops = 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9;
+        float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
+        for (int round = 0; round < 3; round++) for (int v = 0; v < 4; v++) {
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; r++) {
+                if (v == 0) hipLaunchKernelGGL(conv3x3_kernel<3>, dim3(256), dim3(256), LDS_BYTES, 0, p0);
+                else if (v == 1) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+                else if (v == 2) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 1, 1>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+                else hipLaunchKernelGGL((conv3x3_ws_kernel<1, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+            }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            best[v] = fminf(best[v], ms);
+        }
+        printf("%-12s 4-wave %7.3f ms %6.1f TF | ws %7.3f ms %6.1f TF | ws+PRO+EPI %7.3f ms | ws terms=1 %7.3f ms %6.1f TF   (max |diff| ws vs 4-wave %.2e)\n", s.name,
+               best[0], flops / best[0] / 1e9, best[1], flops / best[1] / 1e9, best[2], best[3], flops / best[3] / 1e9, md);
+        fflush(stdout);
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep)); CK(hipFree(xsc)); CK(hipFree(osc)); CK(hipFree(bias));
     }
-    {   // ---- ablations on the 128ch 128^2 layer (timing only; results are wrong by construction) ----
+    if (legacy) {   // ---- ablations on the 128ch 128^2 layer (timing only; results are wrong by construction) ----
         const int n = 96, c = 128, r = 128;
         const size_t na = (size_t)n * c * r * r, nw = (size_t)c * c * 9;
         float *x, *w, *y; u32x4* wprep;
