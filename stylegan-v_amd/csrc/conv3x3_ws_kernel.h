@@ -13,9 +13,10 @@
 //
 //   waves 0-3 (consumers): only LDS operand reads + MFMAs on image q & 1 (128 accumulators, operands double-buffered in
 //                          registers one half-tap ahead), the epilogue when a tile is complete;
-//   waves 4-7 (producers): write chunk q+1 (already in registers) into image (q+1) & 1 -- optional per-(sample, channel) scale, hi/lo
-//                          split, transposing ds_write_b128 -- start the weight block of chunk q+1 as global -> LDS DMA (36 x 1 KiB
-//                          `global_load_lds_dwordx4`, no registers, no ds_write), load x of chunk q+2, wait, barrier.
+//   waves 4-6 (x producers): start the loads of chunk q+2 into one of two register sets, then write chunk q+1 (loaded an iteration
+//                          ago) into image (q+1) & 1 -- optional per-(sample, channel) scale, hi/lo split, transposing ds_write_b128;
+//   wave 7 (weight DMA):   the weight block of chunk q+1 as global -> LDS DMA (36 x 1 KiB `global_load_lds_dwordx4`: no registers,
+//                          no ds_write), waited for before the barrier.
 //
 // One barrier per chunk.  The producers' VALU / LDS-write / VMEM instructions issue in the gaps between the consumer's MFMAs of the
 // same SIMD (separate pipes).  LDS: 2 x (x tile 38.3 KiB + weights 36 KiB + 512 B epilogue vectors) = 149.5 KiB, one workgroup per CU.
@@ -43,7 +44,16 @@ struct conv_ws_params {
 //      c0 = oscale * gain, c1 = bias * gain, c2 = c0 * alpha, c3 = c1 * alpha prepared per tile by the producers (valid for gain > 0,
 //      0 <= alpha <= 1; alpha = 1 is the linear activation): 3 VALU operations per output in the consumer, which is what the MFMA waves
 //      can afford.  Differs from the three-pass composition (networks.py:70-71 + bias_act.cu:39-146) by fused-multiply-add rounding only.
-template <int TERMS, int PRO, int EPI>
+template <int ABL>
+__device__ __forceinline__ f32x16 ws_mma(u32x4 a, u32x4 b, f32x16 c) {
+    if (ABL == 2) { asm volatile("" :: "v"(a), "v"(b)); return c; }   // lab ablation: keep the operand reads, drop the MFMA
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// ABL (tools/conv_lab.hip only; results are wrong by construction): 1 producers only keep the barrier protocol (consumer-only speed), 2 no MFMAs
+// (operand reads + barriers), 3 no operand reads (MFMA issue + barriers), 4 no epilogue stores, 5 producers without global loads / DMA.
+// PRIO: s_setprio level of the consumer waves (the producers' VALU-heavy split competes for the SIMD's issue slots).
+template <int TERMS, int PRO, int EPI, int ABL = 0, int PRIO = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
     const conv_params& p = pp.c;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
@@ -58,96 +68,115 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
     const int my_tiles = (p.tiles - first + p.grid - 1) / p.grid;
     const int total = my_tiles * chunks;
 
+    if (wave == 7) {
+        // =========================================== weight DMA wave ===========================================
+        // The 36-KiB weight block of (tile, chunk) q is copied verbatim: 36 wave-instructions of 64 lanes x 16 B to a wave-uniform LDS base.
+        // A wave of its own, so that the x waves' instruction stream contains no LDS-DMA (hipcc drains vmcnt to 0 at every use of an
+        // ordinary load while one is in flight, which would serialise their prefetch).
+        auto dma_w = [&](int q, u32x4* img) {
+            const tile_pos tp = decode_tile(p, first + (q / chunks) * p.grid, TROWS);
+            const u32x4* wq = p.wprep + ((size_t)tp.mt * chunks + (q % chunks)) * WS_WORDS + lane;
+            u32x4* wl = img + XS_WORDS;
+#pragma unroll
+            for (int j = 0; j < 36; j++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wq + j * 64),
+                                                 (__attribute__((address_space(3))) void*)(wl + j * 64), 16, 0, 0);
+        };
+        dma_w(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // image 0 ready
+        for (int q = 0; q < total; q++) {
+            if (q + 1 < total && ABL != 1 && ABL != 5) dma_w(q + 1, lds + ((q + 1) & 1) * WS_IMAGE_WORDS);   // free since the previous barrier
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
     if (wave >= 4) {
-        // =========================================== producers ===========================================
-        const int pt = t - 256, pw = wave - 4;
+        // =========================================== x waves (4, 5, 6) ===========================================
+        // 360 units per chunk: 288 items of 8 channels x 4 pixels (rows 0..17 of the tile incl. its row halo) and 72 column-halo items of
+        // 8 channels x 1 pixel.  Thread i of 192 takes units i and i + 192.  Two register sets: the loads of chunk q+2 are issued at the
+        // start of iteration q and consumed at the start of iteration q+1 -- a whole consumer iteration to land.
+        const int pt = t - 256;
         constexpr int ITEMS = 16 * RIN;
-        const int a_oct = pt & 1, a_quad = (pt >> 1) & 7, a_row = pt >> 4;
-        const int b_row = 16 + (pt >> 4);
-        const int h_oct = pt & 1, h_side = (pt >> 1) & 1, h_row = pt >> 2;
-        f32x4 xa[8], xb[8];
-        float xh[8];
-        f32x4 sc[2];   // PRO: the 8 channel scales of this thread's octet
+        const int u1 = pt + 192;
+        const int kind1 = u1 < ITEMS ? 0 : (u1 < ITEMS + 4 * RIN ? 1 : 2);        // second unit: item, column halo, none
+        const int oct = pt & 1;                                                   // same for both units (192 and ITEMS are even)
+        const int a_quad = (pt >> 1) & 7, a_row0 = pt >> 4, a_row1 = u1 >> 4;     // u1 >> 4 = a_row0 + 12
+        const int hh = u1 - ITEMS, h_side = (hh >> 1) & 1, h_row = hh >> 2;
+        struct xset { f32x4 a[8]; f32x4 b[8]; f32x4 sc[2]; bool ok0, ok1; };
 
-        auto load_x = [&](int q) {
+        // Branch-free: every thread issues the same 16 (+2) loads per chunk -- out-of-image positions load from a clamped address and are zeroed
+        // when they are written to LDS -- so that the compiler can count them (`s_waitcnt vmcnt(16)` before the previous set is consumed)
+        // instead of draining to 0.  A column-halo pixel is taken from the aligned 16-B group that contains it.
+        auto load_x = [&](int q, xset& r) {
             const tile_pos tp = decode_tile(p, first + (q / chunks) * p.grid, TROWS);
             const int c = q % chunks;
-            const float* xb_ = p.x + ((size_t)tp.n * p.k + c * KC) * plane + tp.x0;
-            {
-                const int gy = tp.y0 - 1 + a_row;
-                const bool ok = gy >= 0 && gy < p.h;
-                const float* qx = xb_ + (size_t)(8 * a_oct) * plane + (size_t)gy * p.w + 4 * a_quad;
+            const float* xb_ = p.x + ((size_t)tp.n * p.k + c * KC + 8 * oct) * plane;
+            const int gy0 = tp.y0 - 1 + a_row0;
+            const int gy1 = tp.y0 - 1 + (kind1 == 0 ? a_row1 : h_row);
+            const int gx0 = tp.x0 + 4 * a_quad;
+            const int gx1 = kind1 == 0 ? gx0 : (h_side ? tp.x0 + SEG : tp.x0 - 4);
+            r.ok0 = gy0 >= 0 && gy0 < p.h;
+            r.ok1 = kind1 != 2 && gy1 >= 0 && gy1 < p.h && gx1 >= 0 && gx1 < p.w;
+            const float* q0 = xb_ + (size_t)min(max(gy0, 0), p.h - 1) * p.w + gx0;
+            const float* q1 = xb_ + (size_t)min(max(gy1, 0), p.h - 1) * p.w + min(max(gx1, 0), p.w - 4);
+            // The loads are inline asm on purpose: hipcc's own wait insertion cannot keep a load in flight across the loop back edge (it
+            // emitted vmcnt(15) where 31 was needed, i.e. waited for one of the loads just issued), which puts the HBM latency back on
+            // the producers' path.  Their destinations are unprotected until the counted s_waitcnt in `arrive` (cdna_hip_programming.md 5.7).
 #pragma unroll
-                for (int j = 0; j < 8; j++) xa[j] = ok ? *(const f32x4*)(qx + j * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (pt + 256 < ITEMS) {
-                const int gy = tp.y0 - 1 + b_row;
-                const bool ok = gy < p.h;
-                const float* qx = xb_ + (size_t)(8 * a_oct) * plane + (size_t)gy * p.w + 4 * a_quad;
+            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * plane) : "memory");
 #pragma unroll
-                for (int j = 0; j < 8; j++) xb[j] = ok ? *(const f32x4*)(qx + j * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (pt < 4 * RIN) {
-                const int gy = tp.y0 - 1 + h_row;
-                const int gx = h_side ? tp.x0 + SEG : tp.x0 - 1;
-                const bool ok = gy >= 0 && gy < p.h && gx >= 0 && gx < p.w;
-                const float* qx = xb_ + (size_t)(8 * h_oct) * plane + (size_t)gy * p.w + (gx - tp.x0);
-#pragma unroll
-                for (int j = 0; j < 8; j++) xh[j] = ok ? qx[j * plane] : 0.f;
-            }
-            if (PRO == 1) {   // a_oct == h_oct: one octet of scales serves all three items
-                const float* sp = pp.xscale + (size_t)tp.n * p.k + c * KC + 8 * a_oct;
-                sc[0] = *(const f32x4*)sp;
-                sc[1] = *(const f32x4*)(sp + 4);
+            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b[j]) : "v"(q1 + j * plane) : "memory");
+            if (PRO == 1) {
+                const float* sp = pp.xscale + (size_t)tp.n * p.k + c * KC + 8 * oct;
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.sc[0]) : "v"(sp) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.sc[1]) : "v"(sp + 4) : "memory");
             }
         };
-        auto put = [&](u32x4* xs, int pos, float* v) {
-            if (PRO == 1) {
+        // everything issued before the `newer` most recent loads has landed; re-define the set's registers after the wait so that no use can be
+        // scheduled above it
+        auto arrive = [&](xset& r, bool newer) {
+            if (newer) { if (PRO == 1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] *= sc[j >> 2][j & 3];
-            }
+            for (int j = 0; j < 8; j++) { asm volatile("" : "+v"(r.a[j])); asm volatile("" : "+v"(r.b[j])); }
+            if (PRO == 1) { asm volatile("" : "+v"(r.sc[0])); asm volatile("" : "+v"(r.sc[1])); }
+        };
+        auto put = [&](u32x4* xs, int pos, float* v, const xset& r, bool ok) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = ok ? (PRO == 1 ? v[j] * r.sc[j >> 2][j & 3] : v[j]) : 0.f;
             u32x4 hi, lo;
             split8(v, hi, lo);
             xs[pos] = hi;
             if (TERMS > 1) xs[2 * XS_PLANE + pos] = lo;
         };
-        auto store_x = [&](u32x4* xs) {
+        auto store_x = [&](u32x4* xs, const xset& r) {
             {
-                const int base = (a_oct * RIN + a_row) * PIN + 1 + 4 * a_quad;
+                const int base = (oct * RIN + a_row0) * PIN + 1 + 4 * a_quad;
 #pragma unroll
                 for (int px = 0; px < 4; px++) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = xa[j][px];
-                    put(xs, base + px, v);
+                    for (int j = 0; j < 8; j++) v[j] = r.a[j][px];
+                    put(xs, base + px, v, r, r.ok0);
                 }
             }
-            if (pt + 256 < ITEMS) {
-                const int base = (a_oct * RIN + b_row) * PIN + 1 + 4 * a_quad;
+            if (kind1 == 0) {
+                const int base = (oct * RIN + a_row1) * PIN + 1 + 4 * a_quad;
 #pragma unroll
                 for (int px = 0; px < 4; px++) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = xb[j][px];
-                    put(xs, base + px, v);
+                    for (int j = 0; j < 8; j++) v[j] = r.b[j][px];
+                    put(xs, base + px, v, r, r.ok1);
                 }
-            }
-            if (pt < 4 * RIN) {
+            } else if (kind1 == 1) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = xh[j];
-                put(xs, (h_oct * RIN + h_row) * PIN + (h_side ? SEG + 1 : 0), v);
+                for (int j = 0; j < 8; j++) v[j] = h_side ? r.b[j][0] : r.b[j][3];   // right halo: first pixel of the next group; left halo: last of the previous
+                put(xs, (oct * RIN + h_row) * PIN + (h_side ? SEG + 1 : 0), v, r, r.ok1);
             }
-        };
-        // weights of (tile, chunk) q: 36 KiB copied verbatim; each wave-instruction moves 64 lanes x 16 B to a wave-uniform LDS base
-        auto dma_w = [&](int q, u32x4* img) {
-            const tile_pos tp = decode_tile(p, first + (q / chunks) * p.grid, TROWS);
-            const u32x4* wq = p.wprep + ((size_t)tp.mt * chunks + (q % chunks)) * WS_WORDS + pw * 64 + lane;
-            u32x4* wl = img + XS_WORDS + pw * 64;
-#pragma unroll
-            for (int j = 0; j < 9; j++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wq + j * 256),
-                                                 (__attribute__((address_space(3))) void*)(wl + j * 256), 16, 0, 0);
         };
         auto put_ep = [&](int q, u32x4* img) {   // the tile's epilogue vectors ride with its LAST chunk
             if (EPI == 0 || (q % chunks) != chunks - 1 || pt >= TM) return;
@@ -162,30 +191,37 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
             ep[2 * TM + pt] = c0 * al;
             ep[3 * TM + pt] = c1 * al;
         };
-
-        load_x(0);
-        dma_w(0, lds);
-        store_x(lds);
-        put_ep(0, lds);
-        if (total > 1) load_x(1);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();   // image 0 ready
-        for (int q = 0; q < total; q++) {
-            if (q + 1 < total) {
+        // iteration q: start the loads of chunk q+2 into `ld`, then split / write chunk q+1 (in `st`, loaded one iteration ago) into image (q+1) & 1
+        auto step = [&](int q, xset& ld, xset& st) {
+            const bool more = q + 2 < total && ABL != 1 && ABL != 5;
+            if (more) load_x(q + 2, ld);
+            if (q + 1 < total && ABL != 1) {
                 u32x4* img = lds + ((q + 1) & 1) * WS_IMAGE_WORDS;    // last read by the consumers in iteration q-1, i.e. before the previous barrier
-                store_x(img);
+                arrive(st, more);
+                store_x(img, st);
                 put_ep(q + 1, img);
-                dma_w(q + 1, img);
-                if (q + 2 < total) load_x(q + 2);
             }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes; the loads just issued stay in flight across the barrier
             __builtin_amdgcn_s_barrier();
+        };
+
+        xset s0, s1;
+        load_x(0, s0);
+        if (total > 1) load_x(1, s1);
+        arrive(s0, total > 1);
+        store_x(lds, s0);
+        put_ep(0, lds);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // image 0 ready
+        for (int q = 0; q < total; q += 2) {
+            step(q, s0, s1);
+            if (q + 1 < total) step(q + 1, s1, s0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing is outstanding here on the product path; the lab's ablations skip consumers of issued loads
         return;
     }
 
     // =========================================== consumers ===========================================
-    const int l32 = lane & 31, g = lane >> 5;
     f32x16 acc[4][2];
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -195,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
             for (int e = 0; e < 16; e++) acc[r][hf][e] = 0.f;
 
 
+    if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
     __builtin_amdgcn_s_barrier();   // image 0 ready
     asm volatile("" ::: "memory");
     for (int q = 0; q < total; q++) {
@@ -212,6 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         u32x4 a[2][2][2];    // [buffer][half][hl]
         u32x4 b[2][2][2];    // [buffer][row][hl]
         auto fetch_a = [&](int buf, int tap) {
+            if (ABL == 3) { for (int hf = 0; hf < 2; hf++) for (int hl = 0; hl < 2; hl++) a[buf][hf][hl] = u32x4{(unsigned)ln, 2u, 3u, 4u}; return; }
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
                 a[buf][hf][0] = ws[a_lane + ((0 * 9 + tap) * 2) * TM + hf * 32];
@@ -219,6 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
             }
         };
         auto fetch_b = [&](int buf, int tap, int rh) {
+            if (ABL == 3) { for (int r = 0; r < 2; r++) for (int hl = 0; hl < 2; hl++) b[buf][r][hl] = u32x4{5u, (unsigned)ln, 7u, 8u}; return; }
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -242,18 +281,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[2 * rh + r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ab][hf][1]), __builtin_bit_cast(bf16x8, b[bb][r][0]), acc[2 * rh + r][hf], 0, 0, 0);
+                        acc[2 * rh + r][hf] = ws_mma<ABL>(a[ab][hf][1], b[bb][r][0], acc[2 * rh + r][hf]);
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[2 * rh + r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ab][hf][0]), __builtin_bit_cast(bf16x8, b[bb][r][1]), acc[2 * rh + r][hf], 0, 0, 0);
+                        acc[2 * rh + r][hf] = ws_mma<ABL>(a[ab][hf][0], b[bb][r][1], acc[2 * rh + r][hf]);
             }
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
-                    acc[2 * rh + r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[ab][hf][0]), __builtin_bit_cast(bf16x8, b[bb][r][0]), acc[2 * rh + r][hf], 0, 0, 0);
+                    acc[2 * rh + r][hf] = ws_mma<ABL>(a[ab][hf][0], b[bb][r][0], acc[2 * rh + r][hf]);
             // pin the interleave: one operand read of step s+1 behind each of the first MFMAs of step s (the MFMA issues every 32 cycles,
             // a ds_read_b128 costs one issue slot), so the reads are spread over the step and nothing is fetched earlier than needed
             constexpr int MF = TERMS > 1 ? 12 : 4;
@@ -268,8 +307,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         if (c == chunks - 1) {
             // C layout: col (pixel) = lane & 31, row (m) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): 128-B contiguous stores
             const tile_pos tp = decode_tile(p, first + (q / chunks) * p.grid, TROWS);
-            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane + (size_t)(tp.y0 + 4 * wave) * p.w + tp.x0 + l32;
+            int le = lane;                      // opaque copy: everything lane-dependent below is recomputed per tile instead of being
+            asm volatile("" : "+v"(le));        // hoisted out of the chunk loop and spilled (nine scratch reloads, each behind a vmcnt(0))
+            const int g = le >> 5;
+            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane + (size_t)(tp.y0 + 4 * wave) * p.w + tp.x0 + (le & 31);
             const float* ep = (const float*)(ws + WS_WORDS);
+            const float clamp_hi = pp.clamp >= 0.f ? pp.clamp : __builtin_inff();
 #pragma unroll
             for (int hf = 0; hf < 2; hf++)
 #pragma unroll
@@ -284,9 +327,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                             float v = acc[r][hf][4 * e4 + ei];
                             if (EPI == 1) {
                                 v = fmaxf(__builtin_fmaf(v, c0[ei], c1[ei]), __builtin_fmaf(v, c2[ei], c3[ei]));
-                                if (pp.clamp >= 0.f) v = (v > -pp.clamp & v < pp.clamp) ? v : (v >= 0.f) ? pp.clamp : -pp.clamp;
+                                v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);   // one instruction; clamp_hi = +inf when there is no clamp
                             }
-                            yb[(size_t)(m0 + ei) * plane + (size_t)r * p.w] = v;
+                            if (ABL == 4) asm volatile("" :: "v"(v)); else yb[(size_t)(m0 + ei) * plane + (size_t)r * p.w] = v;
                             acc[r][hf][4 * e4 + ei] = 0.f;
                         }
                 }

@@ -119,7 +119,8 @@ class _FusedConvBiasActFn(torch.autograd.Function):
             d_d = (sgv - (b.reshape(1, co) * sg if b is not None else 0.0)) / d
         cfg = (False, (1, 1), (1, 1), (0, 0), (1, 1), 1)
         if ctx.needs_input_grad[0] or (s is not None and ctx.needs_input_grad[2]):
-            dxs = _cg._native_conv(dzd, weight, (True, (1, 1), (1, 1), (0, 0), (1, 1), 1))    # data gradient: transposed form, same kernel family
+            tcfg = (True, (1, 1), (1, 1), (0, 0), (1, 1), 1)                                    # data gradient: the transposed form, same kernel family
+            dxs = _cg._native_conv(dzd, weight, tcfg) if _cg._native_conv_ok(dzd, weight, tcfg) else _cg._aten_conv(dzd, weight, None, tcfg)
             if s is not None:
                 d_x = torch.empty_like(dxs)
                 dot = torch.zeros([n * ci], dtype=torch.float32, device=dy.device)

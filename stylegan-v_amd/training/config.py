@@ -105,7 +105,7 @@ def small_test_model_kwargs(res=32):
 
 
 def mid_test_configs():
-    """Hyper-parameters of the mid-size golden (tests/golden/networks_mid.npz): every conv has 64 output channels and
+    """Hyper-parameters of the mid-size golden (tests/golden/networks_mid.npz): every conv has 128 output channels and
     the network reaches 128^2, so that G / D / R1 parity on the GPU runs THROUGH the MFMA convolution kernels, the
     whole-tile GEMM and the wide (>= 129 column) upfirdn2d kernels instead of their small-shape fallbacks."""
     samp = Config(type='random', num_frames_per_video=3, max_num_frames=64, total_dists=[1, 2, 4, 8, 16, 32], max_dist=32)
@@ -116,7 +116,7 @@ def mid_test_configs():
     return gcfg, dcfg
 
 
-def mid_test_model_kwargs(res=128, channels=64):
+def mid_test_model_kwargs(res=128, channels=128):
     gcfg, dcfg = mid_test_configs()
     g_kwargs = dict(c_dim=0, w_dim=64, img_resolution=res, img_channels=3, mapping_kwargs=dict(num_layers=2, cfg=gcfg),
                     synthesis_kwargs=dict(channel_base=res * channels, channel_max=channels, num_fp16_res=0, conv_clamp=None), cfg=gcfg)

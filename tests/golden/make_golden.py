@@ -265,13 +265,13 @@ def gen_networks():
 
 
 def gen_networks_mid():
-    """Second module golden: 64 channels everywhere, 128^2, 2 videos x 3 frames.  Parameters are NOT stored: both sides
+    """Second module golden: 128 channels everywhere, 128^2, 2 videos x 3 frames.  Parameters are NOT stored: both sides
     draw them with tests/util.py:seeded_parameters_ (keyed by parameter name).  Gradients are stored as strided samples."""
     from omegaconf import OmegaConf
     from training.networks import Generator, Discriminator
     sys.path.insert(0, os.path.dirname(HERE))
     from util import seeded_parameters_, sample_flat
-    RES, CH = 128, 64
+    RES, CH = 128, 128
     sampling = dict(type='random', num_frames_per_video=3, max_num_frames=64, total_dists=[1, 2, 4, 8, 16, 32], max_dist=32, name='random3_max32')
     gcfg = OmegaConf.create(dict(sampling=sampling, use_noise=False, input=dict(type='temporal'), w_dim=64, z_dim=64, c_dim=0,
                                  motion=dict(z_dim=24, v_dim=24, motion_z_distance=4, gen_strategy='conv', kernel_size=5, use_fractional_t=True, fourier=True),

@@ -21,9 +21,12 @@ def _oracle_layer(x, w, s, d, b, act, gain, clamp):
     return xs, y0, y1, y
 
 
-def _oracle_grads(x, w, s, d, b, dy, act, gain, clamp):
+def _oracle_grads(x, w, s, d, b, dy, act, gain, clamp, y_mask=None):
+    """`y_mask`: the output whose sign / saturation pattern selects the activation derivative (bias_act.cu grad = 1 reads it from yref).
+    Passing the kernel's own output removes the few elements whose pre-activation lies within rounding of the lrelu kink or the clamp
+    bound from the comparison -- there the fp32 and fp64 evaluations legitimately take different branches."""
     xs, y0, y1, y = _oracle_layer(x, w, s, d, b, act, gain, clamp)
-    dz = oracle.bias_act(dy.double(), b.double() if b is not None else None, act=act, gain=gain, clamp=clamp, grad=1, xref=y1, yref=y)   # bias_act.cu grad = 1
+    dz = oracle.bias_act(dy.double(), b.double() if b is not None else None, act=act, gain=gain, clamp=clamp, grad=1, xref=y1, yref=y if y_mask is None else y_mask)
     db = dz.sum([0, 2, 3])
     dd = (dz * y0).sum([2, 3])
     dy0 = dz * (d.double()[:, :, None, None] if d is not None else 1.0)
@@ -56,16 +59,18 @@ def test_fused_layer_forward_and_gradients_vs_oracle(n, ci, co, h, w, modulated,
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
     assert prof['conv3x3']['launches'] == 1 and prof['bias_act']['launches'] == 0 and prof['modulate']['launches'] == 0, 'the forward pass must be ONE kernel'
-    y_ref, grads_ref = _oracle_grads(x, wt, s, d, b, dy, act, gain, clamp)
-    assert _rel(y.detach(), y_ref) < 1e-5, f'forward: {_rel(y.detach(), y_ref):.2e}'
+    y_ref, grads_ref = _oracle_grads(x, wt, s, d, b, dy, act, gain, clamp, y_mask=y.detach().double().cpu())
+    # error scale = the un-clamped activation range: the convolution's rounding (4e-6 of ITS scale) passes straight through the epilogue,
+    # while a clamp shrinks max |y|
+    scale = oracle.bias_act(_oracle_layer(x, wt, s, d, b, act, gain, None)[2], b.double(), act=act, gain=gain).abs().max().item()
+    err = (y.detach().double().cpu() - y_ref).abs().max().item() / scale
+    assert err < 1e-5, f'forward: {err:.2e}'
     ins = [t for t in (xg, wg, sg, dg, bg) if t is not None]
     names = [k for k, t in zip('xwsdb', (xg, wg, sg, dg, bg)) if t is not None]
     got = torch.autograd.grad(y, ins, dy.to(DEV))
-    # elements whose pre-activation sits within rounding of the lrelu kink / clamp bound may take the other branch: compare in the aggregate norm too
     for name, a in zip(names, got):
-        ref = grads_ref[name]
-        err = _rel(a, ref)
-        assert err < 2e-5 or (name in 'x' and err < 1e-3), f'd{name}: {err:.2e}'
+        err = _rel(a, grads_ref[name])
+        assert err < 2e-5, f'd{name}: {err:.2e}'
 
 
 def test_fused_layer_is_twice_differentiable_through_the_composition():
@@ -95,7 +100,7 @@ def test_fused_layer_no_grad_pass_and_fallbacks():
     with torch.no_grad():
         before = custom_ops.launch_count()
         y = fused_conv_act.conv3x3_bias_act(x, wt, styles=s, act='lrelu')
-        assert custom_ops.launch_count() - before == 2          # weight preparation + the fused kernel
+        assert custom_ops.launch_count() - before == 1          # the fused kernel (its weight preparation rides in the same accounted launch)
         with fused_conv_act.composition_only():
             yc = fused_conv_act.conv3x3_bias_act(x, wt, styles=s, act='lrelu')
     assert _rel(y, yc.double().cpu()) < 1e-5
@@ -107,6 +112,6 @@ def test_fused_layer_no_grad_pass_and_fallbacks():
     # linear + clamp keeps the reference's (unmasked) gradient semantics of bias_act.py:24 -> composition; tanh is not a fusable activation
     before = custom_ops.launch_count()
     fused_conv_act.conv3x3_bias_act(x, wt, act='linear', clamp=1.0)
-    assert custom_ops.launch_count() - before >= 3
+    assert custom_ops.launch_count() - before == 2              # convolution, then bias_act as its own pass
     yt = fused_conv_act.conv3x3_bias_act(x, wt, act='tanh')
     assert yt.abs().max() <= 1

@@ -46,6 +46,7 @@ template <int TERMS> static void launch(const float* x, const float* w, float* y
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 5;
     const bool legacy = argc <= 2;   // `conv_lab 5 ws`: only the producer / consumer sections
+    const bool ablate = argc > 3;    // `conv_lab 5 ws abl`: also the timing-only ablation variants of the producer / consumer kernel
     {   // ---- correctness ----
         for (int mode = 0; mode < 2; mode++) {
             const int n = 2, k = 32, m = 128, h = 32, wd = 64;
@@ -262,6 +263,40 @@ int main(int argc, char** argv) {
                best[0], flops / best[0] / 1e9, best[1], flops / best[1] / 1e9, best[2], best[3], flops / best[3] / 1e9, md);
         fflush(stdout);
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep)); CK(hipFree(xsc)); CK(hipFree(osc)); CK(hipFree(bias));
+    }
+    if (ablate) for (int si : {1, 3}) {   // ---- producer / consumer kernel: ablations and consumer priority (timing only where ABL != 0) ----
+        auto& s = shapes[si];
+        const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
+        float *x, *w, *y; u32x4* wprep;
+        CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&y, na * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
+        fill<<<(na + 255) / 256, 256>>>(x, na, 5u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 7u, 0.1f);
+        launch<3>(x, w, y, wprep, s.n, s.c, s.c, s.r, s.r, 0, 256);
+        conv_ws_params pp{};
+        pp.c.x = x; pp.c.wprep = wprep; pp.c.y = y; pp.c.n = s.n; pp.c.k = s.c; pp.c.m = s.c; pp.c.h = s.r; pp.c.w = s.r;
+        pp.c.tiles = s.n * (s.r / TROWS) * (s.r / SEG) * (s.c / TM); pp.c.grid = 256;
+        typedef void (*kern_t)(conv_ws_params);
+        struct { const char* name; kern_t k; } abl[] = {
+            {"full", conv3x3_ws_kernel<3, 0, 0, 0, 0>}, {"full, consumer prio 1", conv3x3_ws_kernel<3, 0, 0, 0, 1>}, {"full, consumer prio 3", conv3x3_ws_kernel<3, 0, 0, 0, 3>},
+            {"producers idle (barriers only)", conv3x3_ws_kernel<3, 0, 0, 1, 0>}, {"no MFMAs (reads + barriers)", conv3x3_ws_kernel<3, 0, 0, 2, 0>},
+            {"no operand reads (MFMAs + barriers)", conv3x3_ws_kernel<3, 0, 0, 3, 0>}, {"no epilogue stores", conv3x3_ws_kernel<3, 0, 0, 4, 0>},
+            {"producers without global loads / DMA", conv3x3_ws_kernel<3, 0, 0, 5, 0>}, {"producers idle + no operand reads", nullptr} };
+        for (auto& a : abl) {
+            if (!a.k) continue;
+            CK(hipFuncSetAttribute((const void*)a.k, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+            hipLaunchKernelGGL(a.k, dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+            CK(hipDeviceSynchronize());
+            float best = 1e9f;
+            for (int round = 0; round < 3; round++) {
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < reps; i++) hipLaunchKernelGGL(a.k, dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = fminf(best, ms / reps);
+            }
+            printf("ws ablation %-12s terms=3: %-40s %8.3f ms\n", s.name, a.name, best);
+            fflush(stdout);
+        }
+        CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep));
     }
     if (legacy) {   // ---- ablations on the 128ch 128^2 layer (timing only; results are wrong by construction) ----
         const int n = 96, c = 128, r = 128;
