@@ -125,6 +125,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline leg; 0 disables it')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
     ap.add_argument('--strict-steps', type=int, default=8, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
+    ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs (single GPU; pays off at small per-GPU batches)')
     ap.add_argument('--lowp', choices=['none', 'fp16', 'bf16'], default='none',
                     help='mixed precision in the 4 highest resolutions (reference: fp16; BASELINE config 4: bf16). Default: full fp32')
     args = ap.parse_args()
@@ -170,7 +171,7 @@ def main():
     lowp = {'none': None, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.lowp]
     g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=(lowp is None),
                                                       num_frames_per_video=args.frames, lowp_dtype=lowp)
-    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank)
+    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=args.graphs)
 
     def barrier():
         if world > 1:
@@ -186,6 +187,8 @@ def main():
     # Start the timed window on an iteration that runs the regularisation phases, whatever the warm-up was.
     ts.batch_idx = 0
     launches0 = custom_ops.launch_count()
+    if args.graphs:
+        args.no_prof = True   # a replayed graph launches nothing from the host: there are no per-launch events to record
     if not args.no_prof:
         custom_ops.prof_enable(1 << 17)
     barrier()
@@ -303,7 +306,7 @@ def main():
                                videos_per_gpu=args.batch_gpu, frames_per_video=args.frames, frames_per_gpu=args.batch_gpu * args.frames,
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
-                               native_launches_per_step=launches / args.steps),
+                               native_launches_per_step=launches / args.steps, hip_graphs=bool(ts.use_graphs)),
                    value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict,
                    roofline=roofline, roofline_upfirdn2d=roofline_ufd, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)

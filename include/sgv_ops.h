@@ -321,6 +321,36 @@ typedef struct sgv_gemm_params {
 int sgv_gemm_f32(const sgv_gemm_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Small-M dense layer with FullyConnectedLayer's element-wise steps folded in (fp32, exact-fp32 MFMA; csrc/fc.hip).
+ *   C(m,n) = epi( sum_k A(m,k) * B(k,n) ),   A(m,k) = a[m*a_stride_m + k*a_stride_k],  B(k,n) = b[k*b_stride_k + n*b_stride_n]
+ *   epi(v) = act(v * weight_gain + bias[n] * bias_gain) * gain        (act / gain only if epilogue_act)
+ * replaces `torch.addmm` / `matmul` + `bias_act` of layers.py:108-138.  Optional:
+ *   normalize_a : rows of A are scaled by rsqrt(mean_k A^2 + 1e-8) (normalize_2nd_moment of the mapping input, layers.py:22-25)
+ *   a_ref       : same indexing as a; A(m,k) becomes the bias_act gradient (grad 1) of a w.r.t. the saved OUTPUT a_ref:
+ *                 ((a_ref > 0) ? a : a * alpha) * gain  for act = 3 (lrelu), a * gain for act = 1  -- the backward forms read dy and y directly
+ *   a_rowsum    : [m] <- bias_gain * sum_k A(m,k)  (the bias gradient when A = dz^T)
+ * The three forms of a dense layer y = act(x W^T wg + b bg) * gain with x [M,K], W [N,K]:
+ *   forward     A = x (K,1)        B = W^T (1,K)      C = y [M,N]
+ *   data grad   A = dy (N,1; a_ref = y)   B = W (K,1)        C = dx [M,K]    weight_gain = wg
+ *   weight grad A = dy^T (1,N; a_ref = y) B = x (K,1)        C = dW [N,K]    weight_gain = wg, a_rowsum = db
+ */
+typedef struct sgv_fc_params {
+    const float* a; int64_t a_stride_m, a_stride_k;
+    const float* a_ref;
+    const float* b; int64_t b_stride_k, b_stride_n;
+    float* c; int64_t c_stride_m, c_stride_n;
+    const float* bias;
+    float* a_rowsum;
+    int32_t m, n, k;
+    int32_t normalize_a;
+    int32_t act;            /* 1 linear, 3 lrelu */
+    float alpha, gain;
+    float weight_gain, bias_gain;
+    int32_t epilogue_act;
+} sgv_fc_params;
+int sgv_fc(const sgv_fc_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Per-launch timing (bench.py roofline leg).  When enabled, every sgv_* launch is bracketed by
  * two HIP events on its own stream; sgv_prof_collect synchronises those events and reports, per
  * kernel family, launch count, summed milliseconds and summed algorithmic bytes

@@ -5,9 +5,11 @@
 
 #include "sgv_common.h"
 #include "wrw_kernel.h"
+#include "wrw_ws_kernel.h"
 
 #include <algorithm>
 #include <mutex>
+#include <stdlib.h>
 
 using namespace sgv_wrw;
 
@@ -23,8 +25,9 @@ bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {
            (int64_t)n * std::max(cs, cb) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
 }
 
-std::once_flag g_once;
-hipError_t g_attr_err = hipSuccess;
+std::once_flag g_once, g_ws_once;
+hipError_t g_attr_err = hipSuccess, g_ws_attr_err = hipSuccess;
+bool g_use_ws = true;   // SGV_WRW_WS=0: the 4-wave kernel of wrw_kernel.h instead of the producer / consumer form (wrw_ws_kernel.h)
 
 }  // namespace
 
@@ -44,18 +47,39 @@ extern "C" int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* st
     wrw_params kp{};
     kp.dy = (const float*)p->dy; kp.x = (const float*)p->x; kp.dw = p->dw;
     kp.n = p->n; kp.o = p->c_out; kp.i = p->c_in; kp.h = p->h; kp.w = p->w;
-    kp.rows = std::min(p->h, 32);
     kp.tiles_i = p->c_in / TI;
-    kp.units = p->n * (p->w / SEG) * (p->h / kp.rows);
     const int tiles = (p->c_out / TO) * kp.tiles_i;
     // One workgroup per CU (profiles/r01_wrw_lab_v1.log: 256 persistent workgroups beat 512), spread over the output tiles.
-    kp.splits = std::max(1, std::min(kp.units, 256 / std::max(1, std::min(tiles, 256))));
+    const int max_splits = std::max(1, 256 / std::max(1, std::min(tiles, 256)));
+    // Rows per unit: every unit pays a two-barrier prologue with exposed load latency, so take the tallest row block that still spreads evenly
+    // over the workgroups (whole column segments where the batch allows it).
+    kp.rows = std::min(p->h, 32);
+    for (int rows : {p->h, 64}) {
+        if (rows > p->h || p->h % rows) continue;
+        const int units = p->n * (p->w / SEG) * (p->h / rows), splits = std::min(units, max_splits);
+        if (units % splits == 0 || units >= 8 * splits) { kp.rows = rows; break; }
+    }
+    kp.units = p->n * (p->w / SEG) * (p->h / kp.rows);
+    kp.splits = std::max(1, std::min(kp.units, max_splits));
     const size_t dw_bytes = (size_t)p->c_out * p->c_in * 9 * sizeof(float);
     hipError_t e = hipMemsetAsync(p->dw, 0, dw_bytes, stream);
     if (e != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw: hipMemsetAsync failed: %s", hipGetErrorString(e));
     const double elems = (double)p->n * p->h * p->w;
     sgv_launch_scope scope(SGV_K_CONV_WRW, stream, 4.0 * elems * (p->c_out + p->c_in) + dw_bytes, 2.0 * elems * p->c_out * (double)p->c_in * 9);
     dim3 grid((unsigned)tiles, (unsigned)kp.splits);
+    std::call_once(g_ws_once, [] {
+        hipError_t e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
+        g_ws_attr_err = e2;
+        const char* env = getenv("SGV_WRW_WS");
+        g_use_ws = !(env && env[0] == '0');
+    });
+    if (g_ws_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw: hipFuncSetAttribute failed: %s", hipGetErrorString(g_ws_attr_err));
+    if (g_use_ws) {
+        if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        return sgv_check_launch("wrw3x3_ws_kernel");
+    }
     if (p->terms == 1) hipLaunchKernelGGL(wrw3x3_kernel<1>, grid, dim3(256), 0, stream, kp);
     else hipLaunchKernelGGL(wrw3x3_kernel<3>, grid, dim3(256), 0, stream, kp);
     return sgv_check_launch("wrw3x3_kernel");

@@ -208,6 +208,14 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class FcParams(ctypes.Structure):
+    _fields_ = [('a', c_void_p), ('a_stride_m', c_int64), ('a_stride_k', c_int64), ('a_ref', c_void_p),
+                ('b', c_void_p), ('b_stride_k', c_int64), ('b_stride_n', c_int64),
+                ('c', c_void_p), ('c_stride_m', c_int64), ('c_stride_n', c_int64), ('bias', c_void_p), ('a_rowsum', c_void_p),
+                ('m', c_int32), ('n', c_int32), ('k', c_int32), ('normalize_a', c_int32), ('act', c_int32), ('alpha', c_float), ('gain', c_float),
+                ('weight_gain', c_float), ('bias_gain', c_float), ('epilogue_act', c_int32)]
+
+
 class ProfEntry(ctypes.Structure):
     _fields_ = [('launches', c_int64), ('ms', c_double), ('bytes', c_double), ('flops', c_double)]
 
@@ -241,6 +249,7 @@ ABI_SYMBOLS = {
     'sgv_conv3x3_wrw_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_time_encode': (c_int, [ctypes.POINTER(TimeEncodeParams), c_void_p]),
     'sgv_gemm_f32': (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
+    'sgv_fc': (c_int, [ctypes.POINTER(FcParams), c_void_p]),
     'sgv_prof_enable': (c_int, [c_int32]),
     'sgv_prof_disable': (c_int, []),
     'sgv_prof_collect': (c_int, [ctypes.POINTER(ProfEntry)]),

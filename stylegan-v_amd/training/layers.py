@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, fused_conv_act, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_resample, fc, fused_conv_act, upfirdn2d
 
 
 @misc.profiled_function
@@ -35,7 +35,12 @@ class FullyConnectedLayer(torch.nn.Module):
         self.weight_gain = lr_multiplier / math.sqrt(in_features)
         self.bias_gain = lr_multiplier
 
-    def forward(self, x):
+    def forward(self, x, normalize_input=False):
+        """``normalize_input``: apply normalize_2nd_moment to x first (the mapping network's first layer; one kernel with the layer)."""
+        if x.ndim == 2:   # one kernel on the GPU (ops/fc.py -> csrc/fc.hip); the torch composition elsewhere
+            return fc.dense(x, self.weight, self.bias, weight_gain=self.weight_gain, bias_gain=self.bias_gain, act=self.activation, normalize=normalize_input)
+        if normalize_input:
+            x = normalize_2nd_moment(x)
         w = self.weight.to(x.dtype) * self.weight_gain
         b = self.bias
         if b is not None:
@@ -72,15 +77,16 @@ class MappingNetwork(torch.nn.Module):
 
     def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, skip_w_avg_update=False):
         parts = []
+        fold_norm = self.z_dim > 0 and self.c_dim == 0   # unconditional model: the input normalisation rides in fc0's kernel
         if self.z_dim > 0:
             misc.assert_shape(z, [None, self.z_dim])
-            parts.append(normalize_2nd_moment(z.to(torch.float32)))
+            parts.append(z.to(torch.float32) if fold_norm else normalize_2nd_moment(z.to(torch.float32)))
         if self.c_dim > 0:
             misc.assert_shape(c, [None, self.c_dim])
             parts.append(normalize_2nd_moment(self.embed(c.to(torch.float32))))
         x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
         for idx in range(self.num_layers):
-            x = getattr(self, f'fc{idx}')(x)
+            x = getattr(self, f'fc{idx}')(x, normalize_input=(fold_norm and idx == 0))
         if self.w_avg_beta is not None and self.training and not skip_w_avg_update:
             self.w_avg.copy_(x.detach().mean(dim=0).lerp(self.w_avg, self.w_avg_beta))
         if self.num_ws is not None:

@@ -79,8 +79,14 @@ class MotionMappingNetwork(torch.nn.Module):
         )
         self.num_additional_codes = (k - 1) * 2  # the two valid convolutions eat (k-1) codes each
 
+    t_bound = None   # if set (training loops that draw t < max_num_frames by construction): skips the device->host read of t.max() below,
+                     # a pipeline stall per generator pass and illegal under hipGraph capture
+
     def get_max_traj_len(self, t):
-        max_t = max(self.cfg.sampling.max_num_frames - 1, float(t.max().item()))
+        if self.t_bound is not None:
+            max_t = max(self.cfg.sampling.max_num_frames - 1, float(self.t_bound))
+        else:
+            max_t = max(self.cfg.sampling.max_num_frames - 1, float(t.max().item()))
         return int(math.ceil(max_t / self.cfg.motion.motion_z_distance)) + 2
 
     def get_dim(self):

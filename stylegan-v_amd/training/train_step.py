@@ -52,7 +52,7 @@ def sample_frame_times(sampling, batch, generator=None, device='cpu'):
 class TrainStep:
     """Holds G, D, G_ema, optimisers and the loss; ``step()`` runs one iteration of the phase schedule."""
 
-    def __init__(self, g_kwargs, d_kwargs, train_cfg, device, batch_gpu, world_size=1, rank=0, seed=0, ddp=None, bucket_cap_mb=25):
+    def __init__(self, g_kwargs, d_kwargs, train_cfg, device, batch_gpu, world_size=1, rank=0, seed=0, ddp=None, bucket_cap_mb=25, use_graphs=False):
         self.device, self.batch_gpu, self.world_size, self.rank = torch.device(device), batch_gpu, world_size, rank
         self.train_cfg = train_cfg
         self.G, self.D, self.G_ema = build_models(g_kwargs, d_kwargs, device, seed=seed)
@@ -94,6 +94,17 @@ class TrainStep:
         self.cur_nimg = 0
         self.batch_idx = 0
         self.last_losses = {}
+        # frame times are drawn inside [0, max_num_frames - 1) here (sample_frame_times): no need to read t.max() back from the device
+        for mod in (self.G, self.G_ema):
+            if getattr(mod.synthesis, 'motion_encoder', None) is not None:
+                mod.synthesis.motion_encoder.t_bound = self.sampling.max_num_frames - 1
+        # hipGraph replay of the two every-iteration phases (small per-GPU batches are launch-bound: ~1600 launches per iteration)
+        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda' and not self.ddp
+        self._graphs = {}
+        if self.use_graphs:
+            for phase in self.phases:
+                for group in phase['opt'].param_groups:
+                    group['capturable'] = True
 
     # -- synthetic inputs -------------------------------------------------------------------------
     def synthetic_real_batch(self):
@@ -107,6 +118,43 @@ class TrainStep:
         t = sample_frame_times(self.sampling, self.batch_gpu, generator=self.gen, device=self.device)
         return z, c, t
 
+    # -- one phase: zero_grad -> accumulate_gradients -> nan_to_num -> Adam (training_loop.py:351-389) -----------------
+    def _run_phase(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
+        phase['opt'].zero_grad(set_to_none=True)
+        phase['module'].requires_grad_(True)
+        losses = self.loss.accumulate_gradients(phase=phase['name'], real_img=real_img, real_c=real_c, real_t=real_t, gen_z=gen_z,
+                                                gen_c=gen_c, gen_t=gen_t, sync=True, gain=phase['interval'])
+        phase['module'].requires_grad_(False)
+        for p in phase['module'].parameters():
+            if p.grad is not None:
+                misc.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
+        phase['opt'].step()
+        return losses
+
+    def _run_phase_graph(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
+        """The same phase as ONE hipGraph launch: first call = two eager warm-up runs on a side stream (library initialisation, allocator
+        warm-up, Adam state) and the capture; later calls copy the inputs into the captured buffers and replay.  Every kernel of the
+        native library launches on torch's current stream without allocating or synchronising, so it is capture-safe as is."""
+        name = phase['name']
+        entry = self._graphs.get(name)
+        if entry is None:
+            static = dict(real_img=real_img.clone(), real_c=real_c.clone(), real_t=real_t.clone(), gen_z=gen_z.clone(), gen_c=gen_c.clone(), gen_t=gen_t.clone())
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self._run_phase(phase, **static)
+            torch.cuda.current_stream(self.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                out = self._run_phase(phase, **static)
+            entry = self._graphs[name] = dict(graph=graph, static=static, out=out)
+            return {k: v.clone() for k, v in out.items()}
+        for key, val in (('real_img', real_img), ('real_c', real_c), ('real_t', real_t), ('gen_z', gen_z), ('gen_c', gen_c), ('gen_t', gen_t)):
+            entry['static'][key].copy_(val)
+        entry['graph'].replay()
+        return {k: v.clone() for k, v in entry['out'].items()}
+
     # -- one iteration ----------------------------------------------------------------------------
     def step(self, real_img=None, real_t=None):
         if real_img is None:
@@ -119,15 +167,10 @@ class TrainStep:
             if self.batch_idx % phase['interval'] != 0:
                 continue
             gen_z, gen_c, gen_t = self._latents()
-            phase['opt'].zero_grad(set_to_none=True)
-            phase['module'].requires_grad_(True)
-            losses = self.loss.accumulate_gradients(phase=phase['name'], real_img=real_img, real_c=real_c, real_t=real_t, gen_z=gen_z,
-                                                    gen_c=gen_c, gen_t=gen_t, sync=True, gain=phase['interval'])
-            phase['module'].requires_grad_(False)
-            for p in phase['module'].parameters():
-                if p.grad is not None:
-                    misc.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
-            phase['opt'].step()
+            if self.use_graphs and phase['name'] in ('Gmain', 'Dmain'):
+                losses = self._run_phase_graph(phase, real_img, real_c, real_t, gen_z, gen_c, gen_t)
+            else:
+                losses = self._run_phase(phase, real_img, real_c, real_t, gen_z, gen_c, gen_t)
             self.last_losses.update(losses)
             ran.append(phase['name'])
 

@@ -1,0 +1,79 @@
+"""Small-M dense layer kernel (csrc/fc.hip via ops/fc.py) against the float64 evaluation of FullyConnectedLayer's formula
+(src/training/layers.py:22-25, 126-137): forward incl. the folded weight / bias gains, activation and input normalisation; data,
+weight and bias gradients (two launches); second order through the composition."""
+import pytest
+import torch
+
+from stylegan_v_amd.torch_utils import custom_ops
+from stylegan_v_amd.torch_utils.ops import fc
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _rel(a, ref):
+    ref = ref.double().cpu()
+    return (a.double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
+
+
+@pytest.mark.parametrize('m,k,n', [(32, 512, 512), (96, 512, 64), (96, 768, 512), (32, 8192, 512), (7, 37, 45), (96, 512, 1), (1, 24, 16)])
+@pytest.mark.parametrize('act,bias,normalize', [('lrelu', True, False), ('linear', True, False), ('linear', False, False), ('lrelu', True, True)])
+def test_dense_forward_and_gradients_vs_fp64(m, k, n, act, bias, normalize):
+    g = torch.Generator().manual_seed(m + k + n)
+    x = torch.randn([m, k], generator=g)
+    w = torch.randn([n, k], generator=g) * 100                # lr_multiplier 0.01 layers store weight / 0.01
+    b = torch.randn([n], generator=g) if bias else None
+    wg, bg = 0.01 / k ** 0.5, 0.01
+    dy = torch.randn([m, n], generator=g)
+    xg, wgt = x.to(DEV).requires_grad_(True), w.to(DEV).requires_grad_(True)
+    bgt = b.to(DEV).requires_grad_(True) if bias else None
+    before = custom_ops.launch_count()
+    y = fc.dense(xg, wgt, bgt, weight_gain=wg, bias_gain=bg, act=act, normalize=normalize)
+    assert custom_ops.launch_count() - before == 1, 'forward must be one kernel'
+    ins = [t for t in (xg, wgt, bgt) if t is not None]
+    before = custom_ops.launch_count()
+    got = torch.autograd.grad(y, ins, dy.to(DEV))
+    if not normalize:
+        assert custom_ops.launch_count() - before == 2, 'backward must be two kernels (data gradient; weight + bias gradient)'
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    b64 = b.double().requires_grad_(True) if bias else None
+    yr = fc.dense_ref(x64, w64, b64, wg, bg, act, normalize)
+    want = torch.autograd.grad(yr, [t for t in (x64, w64, b64) if t is not None], dy.double())
+    assert _rel(y.detach(), yr.detach()) < 5e-6
+    for a, r, name in zip(got, want, ['dx', 'dw', 'db'] if bias else ['dx', 'dw']):
+        assert _rel(a, r) < 2e-5, f'{name}: {_rel(a, r):.2e}'
+
+
+def test_dense_second_order_and_fallbacks():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn([16, 64], generator=g).to(DEV).requires_grad_(True)
+    w = torch.randn([32, 64], generator=g).to(DEV).requires_grad_(True)
+    b = torch.randn([32], generator=g).to(DEV).requires_grad_(True)
+
+    def r1(fn):
+        y = fn(x, w, b, 0.125, 1.0, 'lrelu')
+        (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
+        return torch.autograd.grad(gx.square().sum(), [w])
+    got, want = r1(fc.dense), r1(fc.dense_ref)
+    assert _rel(got[0], want[0]) < 1e-5
+    # 3-D inputs, 16-bit tensors and other activations take the torch composition
+    y = fc.dense(x.half(), w.half(), b.half(), act='lrelu')
+    assert y.dtype == torch.float16
+    assert fc.dense(x, w, b, act='tanh').abs().max() <= 1
+
+
+def test_mapping_network_is_two_launches_and_matches_the_composition():
+    from stylegan_v_amd.training.layers import MappingNetwork
+    torch.manual_seed(0)
+    net = MappingNetwork(z_dim=512, c_dim=0, w_dim=512, num_ws=14, num_layers=2).to(DEV)
+    z = torch.randn([32, 512], device=DEV)
+    c = torch.zeros([32, 0], device=DEV)
+    before = custom_ops.launch_count()
+    ws = net(z, c, skip_w_avg_update=True)
+    assert custom_ops.launch_count() - before == 2, 'normalize -> fc0 -> lrelu -> fc1 -> lrelu must be two kernels'
+    fc.enabled = False
+    try:
+        ref = net(z, c, skip_w_avg_update=True)
+    finally:
+        fc.enabled = True
+    assert ws.shape == (32, 14, 512) and _rel(ws, ref) < 1e-5

@@ -22,7 +22,7 @@ def main():
         for r in csv.DictReader(open(fs[0])):
             k = r['Kernel_Name']
             key = None
-            for ns in ('(anonymous namespace)::', 'sgv_conv::', 'sgv_wrw::', 'sgv_gemm::', 'sgv_fc::'):
+            for ns in ('(anonymous namespace)::', 'sgv_conv::', 'sgv_wrw::', 'sgv_gemm::', 'sgv_fck::'):
                 if ns in k:
                     key = k.split(ns)[1].split('(')[0][:80]
                     break

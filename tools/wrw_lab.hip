@@ -7,6 +7,7 @@
 #include <math.h>
 #include <vector>
 #include "wrw_kernel.h"
+#include "wrw_ws_kernel.h"
 
 using namespace sgv_wrw;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -52,6 +53,13 @@ static wrw_params make(const float* dy, const float* x, float* dw, int n, int o,
 template <int TERMS> static void launch(const wrw_params& p) {
     dim3 grid((p.o / TO) * p.tiles_i, p.splits);
     hipLaunchKernelGGL(wrw3x3_kernel<TERMS>, grid, dim3(256), 0, 0, p);
+}
+
+template <int TERMS, int VIEWS> static void launch_ws(const wrw_params& p) {   // producer / consumer form (wrw_ws_kernel.h)
+    static bool attr = false;
+    if (!attr) { CK(hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<TERMS, VIEWS>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(VIEWS))); attr = true; }
+    dim3 grid((p.o / TO) * p.tiles_i, p.splits);
+    hipLaunchKernelGGL((wrw3x3_ws_kernel<TERMS, VIEWS>), grid, dim3(512), wrw_ws_lds_bytes(VIEWS), 0, p);
 }
 
 __global__ void naive_wrw_s2(const float* sm, const float* big, double* dw, int n, int cs, int cb, int h, int w) {
@@ -155,7 +163,41 @@ int main(int argc, char** argv) {
             printf("check terms=%d rows=%d splits=%d: max abs err %.3e (max |ref| %.3e, rel-L2 %.3e) worst at o=%zu i=%zu tap=%zu gpu=%f ref=%f\n", terms, rows, p.splits,
                    maxerr, maxref, sqrt(sq / sqr), worst / 9 / i, (worst / 9) % i, worst % 9, gpu[worst], r[worst]);
         }
+        for (int views : {1, 3}) for (int terms = 1; terms <= 3; terms += 2) for (int rows : {64, 32, 16}) for (int wgs : {8, 256}) {
+            CK(hipMemset(dw, 0, ndw * 4));
+            wrw_params p = make(dy, x, dw, n, o, i, h, w, rows, wgs);
+            if (views == 1) { if (terms == 1) launch_ws<1, 1>(p); else launch_ws<3, 1>(p); } else { if (terms == 1) launch_ws<1, 3>(p); else launch_ws<3, 3>(p); }
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(gpu.data(), dw, ndw * 4, hipMemcpyDeviceToHost));
+            double maxerr = 0, maxref = 0, sq = 0, sqr = 0; size_t worst = 0;
+            for (size_t k = 0; k < ndw; k++) { double e = fabs(gpu[k] - r[k]); if (!(e <= maxerr)) { maxerr = e; worst = k; } if (fabs(r[k]) > maxref) maxref = fabs(r[k]); sq += e * e; sqr += r[k] * r[k]; }
+            printf("check ws views=%d terms=%d rows=%d splits=%d: max abs err %.3e (max |ref| %.3e, rel-L2 %.3e) worst at o=%zu i=%zu tap=%zu gpu=%f ref=%f\n", views, terms, rows, p.splits,
+                   maxerr, maxref, sqrt(sq / sqr), worst / 9 / i, (worst / 9) % i, worst % 9, gpu[worst], r[worst]);
+        }
         CK(hipFree(dy)); CK(hipFree(x)); CK(hipFree(dw)); CK(hipFree(ref));
+    }
+    {   // small heights: units of 1, 2, 3, 8 rows (the ring / dy-buffer schedule at its edges)
+        for (int h : {1, 2, 3, 8}) {
+            const int n = 5, o = 64, i = 64, w = 32;
+            const size_t ndy = (size_t)n * o * h * w, nx = (size_t)n * i * h * w, ndw = (size_t)o * i * 9;
+            float *dy, *x, *dw; double* ref;
+            CK(hipMalloc(&dy, ndy * 4)); CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&dw, ndw * 4)); CK(hipMalloc(&ref, ndw * 8));
+            fill<<<(ndy + 255) / 256, 256>>>(dy, ndy, 11u); fill<<<(nx + 255) / 256, 256>>>(x, nx, 23u);
+            naive_wrw<<<o * i, 256>>>(dy, x, ref, n, o, i, h, w);
+            std::vector<double> r(ndw); std::vector<float> gpu(ndw);
+            CK(hipMemcpy(r.data(), ref, ndw * 8, hipMemcpyDeviceToHost));
+            for (int wgs : {1, 2}) {
+                CK(hipMemset(dw, 0, ndw * 4));
+                wrw_params p = make(dy, x, dw, n, o, i, h, w, 32, wgs);
+                launch_ws<3, 1>(p);
+                CK(hipDeviceSynchronize());
+                CK(hipMemcpy(gpu.data(), dw, ndw * 4, hipMemcpyDeviceToHost));
+                double maxerr = 0, maxref = 0;
+                for (size_t k = 0; k < ndw; k++) { double e = fabs(gpu[k] - r[k]); if (!(e <= maxerr)) maxerr = e; if (fabs(r[k]) > maxref) maxref = fabs(r[k]); }
+                printf("check ws h=%d splits=%d: max abs err %.3e (max |ref| %.3e)\n", h, p.splits, maxerr, maxref);
+            }
+            CK(hipFree(dy)); CK(hipFree(x)); CK(hipFree(dw)); CK(hipFree(ref));
+        }
     }
     // ---- timing ----
     struct { const char* name; int n, c, r; } shapes[] = { {"64ch 256^2", 96, 64, 256}, {"128ch 128^2", 96, 128, 128}, {"256ch 64^2", 96, 256, 64}, {"512ch 32^2", 96, 512, 32} };
@@ -165,7 +207,21 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dy, na * 4)); CK(hipMalloc(&x, na * 4)); CK(hipMalloc(&dw, ndw * 4));
         fill<<<(na + 255) / 256, 256>>>(dy, na, 5u); fill<<<(na + 255) / 256, 256>>>(x, na, 7u);
         const double flops = 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9;
-        for (int terms = 1; terms <= 3; terms += 2) for (int rows : {64, 32}) for (int wgs : {512, 256}) {
+        for (int views : {1, 3}) for (int rows : {32, 64}) {   // producer / consumer form, one workgroup per CU
+            if (rows > s.r) continue;
+            wrw_params p = make(dy, x, dw, s.n, s.c, s.c, s.r, s.r, rows, 256);
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            if (views == 1) launch_ws<3, 1>(p); else launch_ws<3, 3>(p);
+            CK(hipDeviceSynchronize());
+            CK(hipEventRecord(e0));
+            for (int r = 0; r < reps; r++) { if (views == 1) launch_ws<3, 1>(p); else launch_ws<3, 3>(p); }
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            printf("%-12s ws views=%d terms=3 rows=%2d grid=%3dx%-3d units/wg=%5.1f  %8.3f ms  %7.1f TFLOP/s (fp32-equivalent)\n", s.name, views, p.rows, (s.c / TO) * p.tiles_i, p.splits,
+                   (double)p.units / p.splits, ms, flops / ms / 1e9);
+            fflush(stdout);
+        }
+        for (int terms = 3; terms <= 3; terms += 2) for (int rows : {32}) for (int wgs : {256}) {
             if (rows > s.r) continue;
             wrw_params p = make(dy, x, dw, s.n, s.c, s.c, s.r, s.r, rows, wgs);
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
