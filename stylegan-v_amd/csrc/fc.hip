@@ -13,8 +13,9 @@
 //            data grad dx = (dz @ W) * wg                                      A = dz, B = W       (mapping input), operand A can be
 //            weight gr dW = (dz^T @ x) * wg,  db = bg * sum_m dz               A = dz^T, B = x     "dy with the activation gradient
 //                                                                                                   applied from the saved output"
-// Tiling: a workgroup owns a 32 x 32 output tile (grid = N/32 x M/32: 16..256 workgroups for the layers above); its four waves split K
-// four ways, each accumulates a whole 32x32 MFMA tile (16 registers), partial tiles are added through LDS, then the epilogue.
+// Tiling: a workgroup owns a 32 x 32 output tile (grid = N/32 x M/32: 16..256 workgroups for the layers above); its sixteen waves split
+// K sixteen ways, each accumulates whole 32x32 MFMA tiles (two independent accumulators), partial tiles are added through LDS, then the
+// epilogue.
 // Algorithmic bytes: 4 * (M*K + N*K + M*N); flops 2*M*N*K.
 
 #include "sgv_common.h"
@@ -38,8 +39,15 @@ struct fc_params {
     int epilogue_act;                     // apply act/gain in the epilogue (forward form)
 };
 
-__global__ __launch_bounds__(256) void fc_kernel(fc_params p) {
-    __shared__ float red[3][32 * 32 + 32];
+// AK / BK: operand is contiguous along k (row-major x, W in the forward form: each lane streams its own row with 16-B loads) or along the
+// tile's row / column index (consecutive lanes read consecutive floats: scalar loads, one 128-B line per half wave).
+// WAVES split K; every wave keeps two accumulators so that consecutive MFMAs are independent (a v_mfma_f32_32x32x2_f32 takes 64 cycles
+// and a dependent one cannot start earlier): the serial chain of the K = 8192 epilogue layer is 128 MFMAs instead of 1024.
+constexpr int FC_WAVES = 16;
+
+template <int AK, int BK>
+__global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
+    __shared__ float red[FC_WAVES - 1][32 * 32];
     __shared__ float rowstat[32];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, kk = lane >> 5;
@@ -49,38 +57,63 @@ __global__ __launch_bounds__(256) void fc_kernel(fc_params p) {
     const float* ap = p.a + (size_t)(a_ok ? am : 0) * p.sam;
     const float* arp = p.aref ? p.aref + (size_t)(a_ok ? am : 0) * p.sam : nullptr;
     const float* bp = p.b + (size_t)(b_ok ? bn : 0) * p.sbn;
+    if (t < 32) rowstat[t] = 0.f;
 
-    // wave w takes k = 2 * (4 * i + w) + kk: interleaved so that the four waves stream neighbouring addresses
-    f32x16 acc;
+    f32x16 acc0, acc1;
 #pragma unroll
-    for (int e = 0; e < 16; e++) acc[e] = 0.f;
+    for (int e = 0; e < 16; e++) { acc0[e] = 0.f; acc1[e] = 0.f; }
     float a_sum = 0.f, a_sq = 0.f;
+    // a step covers 8 consecutive k: lane (r, kk) holds k = k0 + 4 * kk + j for j = 0..3, MFMA j contracts the pair (k0 + j, k0 + 4 + j)
     const int steps = (p.k + 7) / 8;
-    for (int i = 0; i < steps; i++) {
-        const int k = 2 * (4 * i + wave) + kk;
-        const bool k_ok = k < p.k;
-        float av = (a_ok && k_ok) ? ap[(size_t)k * p.sak] : 0.f;
-        if (arp) {
-            const float yv = (a_ok && k_ok) ? arp[(size_t)k * p.sak] : 0.f;
-            av = ((p.act == 3 && !(yv > 0.f)) ? av * p.alpha : av) * p.gain;
+    const bool vec_a = AK && (p.k % 4 == 0) && ((((uintptr_t)p.a) | (uintptr_t)(p.sam * 4)) % 16 == 0) && (!p.aref || ((uintptr_t)p.aref % 16 == 0));
+    const bool vec_b = BK && (p.k % 4 == 0) && ((((uintptr_t)p.b) | (uintptr_t)(p.sbn * 4)) % 16 == 0);
+    for (int i = wave; i < steps; i += FC_WAVES) {
+        const int k0 = 8 * i + 4 * kk;
+        float av[4], bv[4], yv[4];
+        if (vec_a) {
+            const bool ok = a_ok && k0 < p.k;
+            const float4 q = ok ? *(const float4*)(ap + k0) : float4{0.f, 0.f, 0.f, 0.f};
+            av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
+            if (arp) { const float4 w = ok ? *(const float4*)(arp + k0) : float4{0.f, 0.f, 0.f, 0.f}; yv[0] = w.x; yv[1] = w.y; yv[2] = w.z; yv[3] = w.w; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const bool ok = a_ok && k0 + j < p.k;
+                av[j] = ok ? ap[(size_t)(k0 + j) * p.sak] : 0.f;
+                if (arp) yv[j] = ok ? arp[(size_t)(k0 + j) * p.sak] : 0.f;
+            }
         }
-        const float bv = (b_ok && k_ok) ? bp[(size_t)k * p.sbk] : 0.f;
-        a_sum += av;
-        a_sq = __builtin_fmaf(av, av, a_sq);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        if (vec_b) {
+            const float4 q = (b_ok && k0 < p.k) ? *(const float4*)(bp + k0) : float4{0.f, 0.f, 0.f, 0.f};
+            bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) bv[j] = (b_ok && k0 + j < p.k) ? bp[(size_t)(k0 + j) * p.sbk] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (arp) av[j] = ((p.act == 3 && !(yv[j] > 0.f)) ? av[j] * p.alpha : av[j]) * p.gain;
+            a_sum += av[j];
+            a_sq = __builtin_fmaf(av[j], av[j], a_sq);
+        }
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
     }
-    // row statistics of A (sum / sum of squares over k): lanes r and r + 32 of the four waves hold the pieces of row m0 + r
+#pragma unroll
+    for (int e = 0; e < 16; e++) acc0[e] += acc1[e];
+    __syncthreads();   // rowstat zeroed
+    // row statistics of A (sum / sum of squares over k): lanes r and r + 32 of all waves hold the pieces of row m0 + r
     if (p.normalize || p.colsum) {
         float v = p.normalize ? a_sq : a_sum;
         v += __shfl_xor(v, 32, 64);
-        if (wave == 0 && lane < 32) rowstat[lane] = 0.f;
-        __syncthreads();
         if (lane < 32) atomicAdd(&rowstat[lane], v);
     }
     // C layout of the 32x32 MFMA: col (n) = lane & 31, row (m) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (wave > 0) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) red[wave - 1][((e & 3) + 8 * (e >> 2) + 4 * kk) * 32 + r] = acc[e];
+        for (int e = 0; e < 16; e++) red[wave - 1][((e & 3) + 8 * (e >> 2) + 4 * kk) * 32 + r] = acc0[e];
     }
     __syncthreads();
     if (wave != 0) return;
@@ -89,7 +122,9 @@ __global__ __launch_bounds__(256) void fc_kernel(fc_params p) {
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const int ml = (e & 3) + 8 * (e >> 2) + 4 * kk;
-        float v = acc[e] + ((red[0][ml * 32 + r] + red[1][ml * 32 + r]) + red[2][ml * 32 + r]);
+        float v = acc0[e];
+#pragma unroll
+        for (int w = 0; w < FC_WAVES - 1; w++) v += red[w][ml * 32 + r];
         if (p.normalize) v *= 1.0f / sqrtf(rowstat[ml] / (float)p.k + 1e-8f);
         v = v * p.wgain + bias;
         if (p.epilogue_act) v = ((p.act == 3 && !(v > 0.f)) ? v * p.alpha : v) * p.gain;
@@ -115,7 +150,11 @@ extern "C" int sgv_fc(const sgv_fc_params* q, void* stream_) {
     p.epilogue_act = q->epilogue_act;
     hipStream_t stream = (hipStream_t)stream_;
     sgv_launch_scope scope(SGV_K_GEMM, stream, 4.0 * ((double)q->m * q->k + (double)q->n * q->k + (double)q->m * q->n), 2.0 * q->m * (double)q->n * q->k);
-    dim3 grid((unsigned)((q->n + 31) / 32), (unsigned)((q->m + 31) / 32));
-    hipLaunchKernelGGL(sgv_fck::fc_kernel, grid, dim3(256), 0, stream, p);
+    dim3 grid((unsigned)((q->n + 31) / 32), (unsigned)((q->m + 31) / 32)), block(sgv_fck::FC_WAVES * 64);
+    const bool ak = q->a_stride_k == 1, bk = q->b_stride_k == 1;
+    if (ak && bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 1>), grid, block, 0, stream, p);
+    else if (ak) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 0>), grid, block, 0, stream, p);
+    else if (bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 1>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 0>), grid, block, 0, stream, p);
     return sgv_check_launch("fc_kernel");
 }

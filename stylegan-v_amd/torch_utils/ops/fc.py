@@ -22,8 +22,9 @@ from . import bias_act as _ba
 enabled = True
 
 
-def dense_ref(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear', normalize=False):
-    """The definition, in torch ops (layers.py:22-25, 126-137)."""
+def dense_ref(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear', normalize=False, act_gain=None):
+    """The definition, in torch ops (layers.py:22-25, 126-137).  ``act_gain``: gain of the activation (default: the activation's own,
+    sqrt(2) for lrelu; the trajectory convolutions of motion.py use a plain leaky relu, gain 1)."""
     if normalize:
         x = x * (x.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
     w = weight.to(x.dtype) * weight_gain
@@ -32,9 +33,9 @@ def dense_ref(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear'
         b = b.to(x.dtype)
         if bias_gain != 1:
             b = b * bias_gain
-    if act == 'linear' and b is not None:
+    if act == 'linear' and b is not None and act_gain in (None, 1):
         return torch.addmm(b.unsqueeze(0), x, w.t())
-    return _ba.bias_act(x.matmul(w.t()), b, act=act)
+    return _ba.bias_act(x.matmul(w.t()), b, act=act, gain=act_gain)
 
 
 def _launch(a, sam, sak, b, sbk, sbn, c, scm, scn, m, n, k, a_ref=None, bias=None, rowsum=None, normalize=False, act=1, alpha=0.0, gain=1.0, wgain=1.0,
@@ -50,14 +51,14 @@ def _launch(a, sam, sak, b, sbk, sbn, c, scm, scn, m, n, k, a_ref=None, bias=Non
 class _DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
-        wgain, bgain, act, normalize = cfg
+        wgain, bgain, act, normalize, again = cfg
         spec = _ba.activation_funcs[act]
         xc, wc = x.contiguous(), weight.contiguous()
         bc = bias.contiguous().float() if bias is not None else None
         m, k = xc.shape
         n = wc.shape[0]
         y = torch.empty([m, n], dtype=torch.float32, device=x.device)
-        _launch(xc, k, 1, wc, 1, k, y, n, 1, m, n, k, bias=bc, normalize=normalize, act=spec.cuda_idx, alpha=float(spec.def_alpha), gain=float(spec.def_gain),
+        _launch(xc, k, 1, wc, 1, k, y, n, 1, m, n, k, bias=bc, normalize=normalize, act=spec.cuda_idx, alpha=float(spec.def_alpha), gain=again,
                 wgain=wgain, bgain=bgain, epilogue_act=True)
         ctx.cfg = cfg
         ctx.save_for_backward(x, weight, bias, y)
@@ -65,7 +66,7 @@ class _DenseFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        wgain, bgain, act, normalize = ctx.cfg
+        wgain, bgain, act, normalize, again = ctx.cfg
         x, weight, bias, y = ctx.saved_tensors
         if torch.is_grad_enabled() or normalize:
             # create_graph (R1 / path length differentiate this gradient again), or the normalised mapping input (its Jacobian is not
@@ -73,14 +74,14 @@ class _DenseFn(torch.autograd.Function):
             with torch.enable_grad():
                 ins = [t for t, need in zip((x, weight, bias), ctx.needs_input_grad[:3]) if need and t is not None]
                 xin = x if ctx.needs_input_grad[0] else x.detach()
-                y2 = dense_ref(xin, weight, bias, wgain, bgain, act, normalize)
+                y2 = dense_ref(xin, weight, bias, wgain, bgain, act, normalize, again)
                 grads = iter(torch.autograd.grad(y2, ins, dy, create_graph=torch.is_grad_enabled(), allow_unused=True))
             return tuple(next(grads) if (need and t is not None) else None for t, need in zip((x, weight, bias), ctx.needs_input_grad[:3])) + (None,)
         spec = _ba.activation_funcs[act]
         dyc, xc, wc = dy.contiguous(), x.contiguous(), weight.contiguous()
         m, k = xc.shape
         n = wc.shape[0]
-        common = dict(a_ref=y, act=spec.cuda_idx, alpha=float(spec.def_alpha), gain=float(spec.def_gain), wgain=wgain)
+        common = dict(a_ref=y, act=spec.cuda_idx, alpha=float(spec.def_alpha), gain=again, wgain=wgain)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty([m, k], dtype=torch.float32, device=dy.device)
@@ -94,9 +95,10 @@ class _DenseFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
-def dense(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear', normalize=False):
+def dense(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear', normalize=False, act_gain=None):
     """x [M,K], weight [N,K], bias [N] or None -> [M,N]."""
     if enabled and x.is_cuda and x.ndim == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and act in ('linear', 'lrelu') \
-            and (bias is None or bias.dtype == torch.float32) and x.shape[0] <= 4096:
-        return _DenseFn.apply(x, weight, bias, (float(weight_gain), float(bias_gain), act, bool(normalize)))
-    return dense_ref(x, weight, bias, weight_gain, bias_gain, act, normalize)
+            and (bias is None or bias.dtype == torch.float32) and x.shape[0] <= 65535 * 32:
+        again = float(_ba.activation_funcs[act].def_gain if act_gain is None else act_gain)
+        return _DenseFn.apply(x, weight, bias, (float(weight_gain), float(bias_gain), act, bool(normalize), again))
+    return dense_ref(x, weight, bias, weight_gain, bias_gain, act, normalize, act_gain)

@@ -259,6 +259,21 @@ class EqLRConv1d(torch.nn.Module):
         # bias + leaky-relu through the fused kernel (gain 1: the reference applies F.leaky_relu without sqrt(2))
         return bias_act.bias_act(y, b, dim=1, act=self.activation, gain=1)
 
+    def forward_nlc(self, x):
+        """The same layer on a [B, L, C] trajectory (the layout the motion network holds it in, motion.py:84-110), without the two
+        permutes around F.conv1d: the valid convolution is the product of the unfolded trajectory [B * Lout, k * C] with the weight
+        re-laid as [O, k * C], i.e. ONE dense-layer kernel (ops/fc.py -> csrc/fc.hip, exact-fp32 MFMA) with the weight gain, bias gain,
+        bias and leaky relu in its epilogue; gradients through the same kernel's data- / weight-gradient forms.  Returns [B, Lout, O]."""
+        assert x.ndim == 3 and self.stride == 1 and self.padding == 0
+        bsz, length, ch = x.shape
+        o, c, k = self.weight.shape
+        assert c == ch
+        lout = length - k + 1
+        cols = x.unfold(1, k, 1).permute(0, 1, 3, 2).reshape(bsz * lout, k * ch)      # [B, Lout, C, k] view -> [B * Lout, (k, C)]
+        w2 = self.weight.permute(0, 2, 1).reshape(o, k * ch)                          # [O, (k, C)]
+        y = fc.dense(cols, w2.to(x.dtype), self.bias, weight_gain=self.weight_gain, bias_gain=self.bias_gain, act=self.activation, act_gain=1)
+        return y.reshape(bsz, lout, o)
+
 
 # ------------------------------------------------------------------------------------------------
 # Host-side frame-index sampling (layers.py:377-435 contract): which frames of a video a clip uses.

@@ -4,8 +4,9 @@ Mirrors ``src/training/motion.py`` of the reference: ``MotionMappingNetwork`` (:
 trajectory into per-frame motion codes, ``AlignedTimeEncoder`` (:160-214) turns a frame's time stamp and
 its two neighbouring trajectory codes into the 2*dim sin/cos embedding
 ``pos(t) - lerp(pos(t_l), pos(t_r), a) + lerp(A_l, A_r, a)``.  The element-wise tail (three phases, six
-sin/cos, two lerps) is one fused kernel (``csrc/time_encode.hip``); the trajectory convolutions use
-MIOpen's conv1d with the fused bias+lrelu kernel.  Only the configuration StyleGAN-V trains with is
+sin/cos, two lerps) is one fused kernel (``csrc/time_encode.hip``); on the GPU the two trajectory convolutions (k = 11, valid) run
+as dense-layer kernels on the unfolded [B, L, C] trajectory and the four prediction heads as two more (``csrc/fc.hip``: exact-fp32
+MFMA, weight / bias gains, bias and leaky relu in the epilogue) -- no vendor convolution or GEMM is left in the encoder.  Only the configuration StyleGAN-V trains with is
 built: ``gen_strategy='conv'`` and ``fourier=True`` (configs/model/stylegan-v.yaml:19-27).
 """
 
@@ -15,6 +16,7 @@ import numpy as np
 import torch
 
 from ..torch_utils import misc
+from ..torch_utils.ops import fc as _fc
 from ..torch_utils.ops import time_encode as _te
 from .layers import EqLRConv1d, FullyConnectedLayer
 
@@ -54,7 +56,7 @@ class AlignedTimeEncoder(torch.nn.Module):
         # one GEMM for the three heads that read the left code (periods | phases | aligners), one for the right aligner
         heads = torch.cat([self.periods_predictor.weight, self.phase_predictor.weight, self.aligners_predictor.weight], dim=0)
         gain = self.periods_predictor.weight_gain  # identical for the three heads: lr_mul 1, same fan-in
-        left = ul.matmul(heads.t().to(ul.dtype)) * gain
+        left = _fc.dense(ul, heads.to(ul.dtype), None, weight_gain=gain)   # one small-M MFMA kernel on the GPU (csrc/fc.hip)
         nf = self.freqs.shape[1]
         periods = left[:, :nf].tanh() + 1
         phases = left[:, nf:2 * nf]
@@ -105,7 +107,12 @@ class MotionMappingNetwork(torch.nn.Module):
         if self.cfg.c_dim > 0:
             misc.assert_shape(c, [b, None])
             x = torch.cat([x, c.unsqueeze(1).expand(-1, traj_len, -1)], dim=2)
-        trajs = self.conv(x.permute(0, 2, 1)).permute(0, 2, 1)  # [B, L - 2(k-1), v_dim]
+        if x.is_cuda and x.dtype == torch.float32 and _fc.enabled:
+            trajs = x                          # [B, L, C] throughout: each valid conv1d + bias + lrelu is one dense-layer kernel on the unfolded trajectory
+            for layer in self.conv:
+                trajs = layer.forward_nlc(trajs)
+        else:
+            trajs = self.conv(x.permute(0, 2, 1)).permute(0, 2, 1)  # [B, L - 2(k-1), v_dim]
 
         left_idx = (t / dist).floor().long()
         rows = torch.arange(b, device=c.device).unsqueeze(1).expand(-1, f)
