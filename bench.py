@@ -124,7 +124,9 @@ def main():
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline leg; 0 disables it')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
+    ap.add_argument('--ada-steps', type=int, default=8, help="steps of the aug=ada companion measurement (the reference's default augmentation, bgc pipeline); 0 disables it")
     ap.add_argument('--strict-steps', type=int, default=8, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
+    ap.add_argument('--aug', choices=['noaug', 'ada'], default='noaug', help="discriminator augmentation: the reference's default is ada (bgc pipeline, adaptive p)")
     ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs (single GPU; pays off at small per-GPU batches)')
     ap.add_argument('--lowp', choices=['none', 'fp16', 'bf16'], default='none',
                     help='mixed precision in the 4 highest resolutions (reference: fp16; BASELINE config 4: bf16). Default: full fp32')
@@ -171,7 +173,7 @@ def main():
     lowp = {'none': None, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.lowp]
     g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=(lowp is None),
                                                       num_frames_per_video=args.frames, lowp_dtype=lowp)
-    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=args.graphs)
+    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=args.graphs, augment=args.aug)
 
     def barrier():
         if world > 1:
@@ -245,6 +247,28 @@ def main():
         finally:
             conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms = default_terms
 
+    # aug=ada companion: the reference's default discriminator augmentation (bgc pipeline: reflect-pad -> 2x up -> affine resample -> 2x down +
+    # colour matrix on every D input, adaptive p) on the same models; same bracket, schedule restarted at iteration 0.
+    ada = None
+    if args.ada_steps > 0 and args.aug == 'noaug' and not args.graphs:
+        ts.set_augment('ada')
+        try:
+            ts.batch_idx = 0
+            ts.step(); ts.step()
+            ts.batch_idx = 0
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.ada_steps):
+                ts.step()
+            barrier()
+            t_a = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            if world > 1:
+                torch.distributed.all_reduce(t_a, op=torch.distributed.ReduceOp.MAX)
+            ada = dict(value=global_batch * args.frames * args.ada_steps / float(t_a.item()), ms_per_step=1e3 * float(t_a.item()) / args.ada_steps, steps=args.ada_steps,
+                       p_final=float(ts.augment_pipe.p), what='same step with aug=ada (augpipe bgc, one transform per video, ADA target 0.6 / interval 4 / 500 kimg)')
+        finally:
+            ts.set_augment('noaug')
+
     F32_LABEL = 'f32' if conv2d_gradfix.native_conv_terms == 0 and conv2d_gradfix.native_wrw_terms == 0 else \
         'fp32 I/O + fp32 accumulate everywhere; 3x3 convolution products are 2-way-bf16-split (hi/lo, 3 MFMAs per product: 16-bit mantissa operands, 4e-6 rel. error vs fp64; NOT strict fp32 -- see value_strict_fp32)'
     if rank == 0:
@@ -302,12 +326,12 @@ def main():
         out = dict(metric='G+D train-step images/sec at 256^2', value=value, unit='img/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
                    dtype={'none': F32_LABEL, 'fp16': 'f16 (blocks >= 32^2; f32 accumulate, f32 master weights)', 'bf16': 'bf16 (blocks >= 32^2; f32 accumulate, f32 master weights)'}[args.lowp], data='synthetic',
-                   config=dict(workload=f'FFS {args.res}x{args.res} full G+D train step (Gmain+Greg+Dmain+Dreg/R1), cfg=auto fmaps 0.5, ' + ('fp32' if lowp is None else args.lowp + ' mixed precision') + ', aug=noaug',
+                   config=dict(workload=f'FFS {args.res}x{args.res} full G+D train step (Gmain+Greg+Dmain+Dreg/R1), cfg=auto fmaps 0.5, ' + ('fp32' if lowp is None else args.lowp + ' mixed precision') + ', aug=' + args.aug,
                                videos_per_gpu=args.batch_gpu, frames_per_video=args.frames, frames_per_gpu=args.batch_gpu * args.frames,
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
                                native_launches_per_step=launches / args.steps, hip_graphs=bool(ts.use_graphs)),
-                   value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict,
+                   value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada,
                    roofline=roofline, roofline_upfirdn2d=roofline_ufd, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -271,6 +271,15 @@ int sgv_conv3x3_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int
 int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out);
 
 /* ---------------------------------------------------------------------------------------
+ * Bilinear resampling under one affine map per sample (ADA geometric execution: `affine_grid(theta, size, align_corners=False)` +
+ * `grid_sample(bilinear, zeros)` of augment.py:297-300, without materialising the grid), fp32 NCHW:
+ *   adjoint = 0:  dst[n,c,Y,X] = bilinear sample of src[n,c] at theta[n] @ (xn, yn, 1)     src [n,c,h,w] -> dst [n,c,ho,wo]
+ *   adjoint = 1:  the transposed map (gradient w.r.t. the image): src [n,c,ho,wo] -> dst [n,c,h,w], dst zero-initialised by the caller
+ * theta is [n, 2, 3] in affine_grid's normalised coordinates. */
+int sgv_affine_resample(const float* src, float* dst, const float* theta, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho, int32_t wo,
+                        int32_t adjoint, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * AlignedTimeEncoder element-wise tail (motion.py:201-212), fp32:
  *   raw(tau) = freqs[j]*periods[r,j]*tau + phases[r,j]*phase_scales[j]
  *   pos(tau) = [sin raw(tau) | cos raw(tau)]                       (2*nf wide)

@@ -1,0 +1,57 @@
+"""Affine bilinear resampling of an image batch: ``affine_resample(x, theta, (Ho, Wo))`` ==
+``grid_sample(x, affine_grid(theta, [N, C, Ho, Wo], align_corners=False), bilinear, zeros, align_corners=False)``.
+
+This is the geometric execution step of the ADA augmentation pipeline (reference: src/training/augment.py:297-300 through
+src/torch_utils/ops/grid_sample_gradfix.py).  On the GPU it is one gather kernel that evaluates the sampling grid in registers
+(csrc/resample.hip) instead of materialising it; the gradient w.r.t. the image is the adjoint scatter kernel, and since both maps are
+linear in the image one autograd node serves either direction -- differentiating it gives the other -- so the R1 penalty (a gradient of
+a gradient through augmented real images, loss.py:144-164) works.  ``theta`` (built from random augmentation parameters) gets no
+gradient.  CPU / non-fp32 tensors take the two-op formulation through ``grid_sample_gradfix``.
+"""
+
+import torch
+
+from .. import custom_ops
+from . import grid_sample_gradfix
+
+enabled = True
+
+
+def affine_resample_ref(x, theta, out_hw):
+    grid = torch.nn.functional.affine_grid(theta, [x.shape[0], x.shape[1], out_hw[0], out_hw[1]], align_corners=False)
+    return grid_sample_gradfix.grid_sample(x, grid)
+
+
+class _AffineMap(torch.autograd.Function):
+    """``src_hw is None``: y = S(t), t the image [N,C,H,W] -> [N,C,Ho,Wo].  ``src_hw = (H, W)``: y = S^T(t), t [N,C,Ho,Wo] -> [N,C,H,W]."""
+
+    @staticmethod
+    def forward(ctx, t, theta, out_hw, src_hw):
+        lib = custom_ops.get_native()
+        t, th = t.contiguous(), theta.detach().contiguous().float()
+        n, c = t.shape[:2]
+        adjoint = src_hw is not None
+        h, w = src_hw if adjoint else t.shape[2:]
+        ho, wo = out_hw
+        dst = torch.zeros([n, c, h, w], dtype=torch.float32, device=t.device) if adjoint else torch.empty([n, c, ho, wo], dtype=torch.float32, device=t.device)
+        with custom_ops.device_guard(t):
+            custom_ops.check(lib.sgv_affine_resample(t.data_ptr(), dst.data_ptr(), th.data_ptr(), n, c, h, w, ho, wo, int(adjoint), custom_ops.raw_stream(t)), lib)
+        ctx.adjoint, ctx.out_hw, ctx.img_hw = adjoint, (ho, wo), (h, w)
+        ctx.save_for_backward(th)
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        (th,) = ctx.saved_tensors
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError('affine_resample: no gradient w.r.t. theta (augmentation parameters are constants)')
+        d_t = _AffineMap.apply(g, th, ctx.out_hw, None if ctx.adjoint else ctx.img_hw) if ctx.needs_input_grad[0] else None
+        return d_t, None, None, None
+
+
+def affine_resample(x, theta, out_hw):
+    """x [N,C,H,W], theta [N,2,3] (normalised coordinates, as ``affine_grid``), out_hw = (Ho, Wo)."""
+    out_hw = (int(out_hw[0]), int(out_hw[1]))
+    if enabled and x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and not theta.requires_grad:
+        return _AffineMap.apply(x, theta, out_hw, None)
+    return affine_resample_ref(x, theta.to(x.dtype), out_hw)

@@ -1,0 +1,195 @@
+"""Adaptive discriminator augmentation: the `bgc` pipeline (pixel blitting + general geometric + colour transforms) the reference
+trains with by default (`aug=ada`, `augpipe=bgc`: src/train.py:44,238-277).
+
+Function mirrored: ``AugmentPipe.forward`` of src/training/augment.py:172-375 -- same parameter distributions, same order of
+composition, same execution: ONE inverse homogeneous 2-D transform per sample (x-flip, 90-degree rotation, integer translation,
+isotropic scale, pre-rotation, anisotropic scale, post-rotation, fractional translation; :185-268) applied as reflect-pad ->
+2x up-sampling with the 12-tap `sym6` low-pass -> bilinear resampling -> 2x down-sampling (:270-300), then ONE 4x4 colour matrix
+per sample (brightness, contrast, luma flip, hue, saturation; :306-368).  Like the reference, the geometric path runs whenever any
+geometric augmentation is configured, even at p = 0.  The image-space filter / noise / cutout stages of the larger
+pipelines (`bgcf...`) are not part of `bgc` and are not built.
+
+Organisation (not the reference's): every augmentation is one row of a table -- (probability multiplier, how to draw its parameter,
+how the parameter becomes a matrix) -- and ``forward`` folds the rows; the resampling step goes through ``affine_resample`` below,
+which on the GPU is a hand-written gather kernel with its adjoint (csrc/resample.hip) instead of affine_grid + grid_sample, and stays
+differentiable to any order (R1 runs through this path on real images).
+"""
+
+import math
+
+import numpy as np
+import torch
+
+from ..torch_utils.ops import resample, upfirdn2d
+
+SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466, 0.787641141030194,
+        0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578, 0.0017677118642428036, -0.007800708325034148]
+
+BGC = dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1)
+
+
+def _mat(rows, like):
+    """[B, r, c] matrix from a nested list whose entries are python numbers or [B] tensors."""
+    flat = [e for row in rows for e in row]
+    ref = next((e for e in flat if isinstance(e, torch.Tensor)), None)
+    b = ref.shape[0] if ref is not None else 1
+    cols = [e if isinstance(e, torch.Tensor) else torch.full([b], float(e), device=like.device, dtype=torch.float32) for e in flat]
+    return torch.stack(cols, dim=-1).reshape(b, len(rows), len(rows[0]))
+
+
+def _translate(tx, ty, like):
+    return _mat([[1, 0, tx], [0, 1, ty], [0, 0, 1]], like)
+
+
+def _scale(sx, sy, like):
+    return _mat([[sx, 0, 0], [0, sy, 0], [0, 0, 1]], like)
+
+
+def _rotate(theta, like):
+    c, s = torch.cos(theta), torch.sin(theta)
+    return _mat([[c, -s, 0], [s, c, 0], [0, 0, 1]], like)
+
+
+class AugmentPipe(torch.nn.Module):
+    def __init__(self, xflip=0, rotate90=0, xint=0, xint_max=0.125, scale=0, rotate=0, aniso=0, xfrac=0, scale_std=0.2, rotate_max=1,
+                 aniso_std=0.2, xfrac_std=0.125, brightness=0, contrast=0, lumaflip=0, hue=0, saturation=0, brightness_std=0.2,
+                 contrast_std=0.5, hue_max=1, saturation_std=1, imgfilter=0, noise=0, cutout=0, **_unused):
+        super().__init__()
+        if imgfilter or noise or cutout:
+            raise NotImplementedError('image-space filtering / noise / cutout are outside the bgc pipeline built here')
+        self.register_buffer('p', torch.ones([]))   # overall probability multiplier, adapted by ADA (training_loop.py:407-410)
+        self.mult = dict(xflip=float(xflip), rotate90=float(rotate90), xint=float(xint), scale=float(scale), rotate=float(rotate), aniso=float(aniso),
+                         xfrac=float(xfrac), brightness=float(brightness), contrast=float(contrast), lumaflip=float(lumaflip), hue=float(hue),
+                         saturation=float(saturation))
+        self.xint_max, self.scale_std, self.rotate_max, self.aniso_std, self.xfrac_std = xint_max, scale_std, rotate_max, aniso_std, xfrac_std
+        self.brightness_std, self.contrast_std, self.hue_max, self.saturation_std = brightness_std, contrast_std, hue_max, saturation_std
+        self.register_buffer('Hz_geom', upfirdn2d.setup_filter(SYM6))
+
+    # -- parameter draws ------------------------------------------------------------------------------------------------------
+    def _draw(self, name, shape, kind, neutral, device, pct, prob=None):
+        """One augmentation parameter per sample: drawn from `kind`, replaced by `neutral` with probability 1 - mult * p
+        (or 1 - prob); with `pct` (the reference's debug_percentile) the draw is the given percentile for every sample."""
+        if kind == 'flip':        # uniform over {0, 1}
+            v = torch.floor(torch.rand(shape, device=device) * 2) if pct is None else torch.full(shape, math.floor(pct * 2), device=device, dtype=torch.float32)
+        elif kind == 'quarter':   # uniform over {0, 1, 2, 3}
+            v = torch.floor(torch.rand(shape, device=device) * 4) if pct is None else torch.full(shape, math.floor(pct * 4), device=device, dtype=torch.float32)
+        elif kind == 'uniform':   # uniform over [-1, 1]
+            v = torch.rand(shape, device=device) * 2 - 1 if pct is None else torch.full(shape, pct * 2 - 1, device=device, dtype=torch.float32)
+        else:                     # standard normal
+            v = torch.randn(shape, device=device) if pct is None else torch.full(shape, float(torch.erfinv(torch.tensor(pct * 2 - 1.0))), device=device)
+        if pct is not None:
+            return v
+        gate_shape = [shape[0]] + [1] * (len(shape) - 1)
+        keep = torch.rand(gate_shape, device=device) < (self.mult[name] * self.p if prob is None else prob)
+        return torch.where(keep, v, torch.full_like(v, neutral))
+
+    def forward(self, images, debug_percentile=None):
+        assert isinstance(images, torch.Tensor) and images.ndim == 4
+        n, ch, h, w = images.shape
+        dev, pct, on = images.device, debug_percentile, self.mult
+        like = images
+
+        # ---- inverse geometric transform G_inv (maps output pixels to input pixels), composed left to right (augment.py:185-268) ----
+        g_inv, geometric = None, False
+
+        def push(m):
+            nonlocal g_inv, geometric
+            g_inv = m if g_inv is None else g_inv @ m
+            geometric = True
+        if on['xflip'] > 0:
+            i = self._draw('xflip', [n], 'flip', 0, dev, pct)
+            push(_scale(1 / (1 - 2 * i), 1, like))
+        if on['rotate90'] > 0:
+            i = self._draw('rotate90', [n], 'quarter', 0, dev, pct)
+            push(_rotate(math.pi / 2 * i, like))                       # inverse of a rotation by -pi/2 * i
+        if on['xint'] > 0:
+            t = self._draw('xint', [n, 2], 'uniform', 0, dev, pct) * self.xint_max
+            push(_translate(-torch.round(t[:, 0] * w), -torch.round(t[:, 1] * h), like))
+        if on['scale'] > 0:
+            s = torch.exp2(self._draw('scale', [n], 'normal', 0, dev, pct) * self.scale_std)
+            push(_scale(1 / s, 1 / s, like))
+        p_rot = 1 - torch.sqrt((1 - on['rotate'] * self.p).clamp(0, 1))   # P(pre OR post) = p
+        if on['rotate'] > 0:
+            th = self._draw('rotate', [n], 'uniform', 0, dev, pct, prob=p_rot) * math.pi * self.rotate_max
+            push(_rotate(th, like))                                    # inverse of a rotation by -theta
+        if on['aniso'] > 0:
+            s = torch.exp2(self._draw('aniso', [n], 'normal', 0, dev, pct) * self.aniso_std)
+            push(_scale(1 / s, s, like))
+        if on['rotate'] > 0:
+            th = self._draw('rotate', [n], 'uniform', 0, dev, None if pct is None else 0.5, prob=p_rot) * math.pi * self.rotate_max   # debug mode: no post-rotation
+            push(_rotate(th, like))
+        if on['xfrac'] > 0:
+            t = self._draw('xfrac', [n, 2], 'normal', 0, dev, pct) * self.xfrac_std
+            push(_translate(-t[:, 0] * w, -t[:, 1] * h, like))
+
+        if geometric:
+            images = self._resample(images, g_inv)
+
+        # ---- colour transform C (augment.py:306-368) ----
+        c_mat, coloured = torch.eye(4, device=dev).unsqueeze(0), False
+        luma = torch.tensor([1, 1, 1, 0], device=dev, dtype=torch.float32) / math.sqrt(3)
+        vv = luma.outer(luma)
+        eye4 = torch.eye(4, device=dev)
+        if on['brightness'] > 0:
+            b = self._draw('brightness', [n], 'normal', 0, dev, pct) * self.brightness_std
+            c_mat, coloured = _mat([[1, 0, 0, b], [0, 1, 0, b], [0, 0, 1, b], [0, 0, 0, 1]], like) @ c_mat, True
+        if on['contrast'] > 0:
+            c = torch.exp2(self._draw('contrast', [n], 'normal', 0, dev, pct) * self.contrast_std)
+            c_mat, coloured = _mat([[c, 0, 0, 0], [0, c, 0, 0], [0, 0, c, 0], [0, 0, 0, 1]], like) @ c_mat, True
+        if on['lumaflip'] > 0:
+            i = self._draw('lumaflip', [n, 1, 1], 'flip', 0, dev, pct)
+            c_mat, coloured = (eye4 - 2 * vv * i) @ c_mat, True          # Householder reflection about the luma axis
+        if on['hue'] > 0 and ch > 1:
+            th = self._draw('hue', [n], 'uniform', 0, dev, pct) * math.pi * self.hue_max
+            k = torch.tensor([[0, -1, 1, 0], [1, 0, -1, 0], [-1, 1, 0, 0], [0, 0, 0, 0]], device=dev, dtype=torch.float32) / math.sqrt(3)   # cross-product matrix of the luma axis
+            cth, sth = torch.cos(th).reshape(n, 1, 1), torch.sin(th).reshape(n, 1, 1)
+            rot = vv * (1 - cth) + torch.diag(torch.tensor([1., 1., 1., 0.], device=dev)) * cth + k * sth     # Rodrigues about v
+            rot = rot + torch.diag(torch.tensor([0., 0., 0., 1.], device=dev))
+            c_mat, coloured = rot @ c_mat, True
+        if on['saturation'] > 0 and ch > 1:
+            s = torch.exp2(self._draw('saturation', [n, 1, 1], 'normal', 0, dev, pct) * self.saturation_std)
+            c_mat, coloured = (vv + (eye4 - vv) * s) @ c_mat, True
+        if coloured:
+            c_mat = c_mat.expand(n, 4, 4)
+            flat = images.reshape(n, ch, h * w)
+            if ch % 3 == 0:                       # RGB, or F frames of one video folded into 3F channels (loss.py:58-66): the same matrix for every frame
+                f = ch // 3
+                cm = c_mat.repeat_interleave(f, dim=0) if f > 1 else c_mat
+                flat = (cm[:, :3, :3] @ flat.reshape(n * f, 3, h * w) + cm[:, :3, 3:]).reshape(n, ch, h * w)
+            elif ch == 1:
+                cm = c_mat[:, :3, :].mean(dim=1, keepdim=True)
+                flat = flat * cm[:, :, :3].sum(dim=2, keepdim=True) + cm[:, :, 3:]
+            else:
+                raise ValueError('Image must be RGB (3 channels) or L (1 channel)')
+            images = flat.reshape(n, ch, h, w)
+        return images
+
+    # -- geometric execution (augment.py:270-300) -----------------------------------------------------------------------------------
+    def _resample(self, images, g_inv):
+        n, ch, h, w = images.shape
+        dev = images.device
+        cx, cy = (w - 1) / 2, (h - 1) / 2
+        corners = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], device=dev, dtype=torch.float32)
+        cp = g_inv @ corners.t()                                          # [n, 3, 4]: where the output corners come from
+        pad = self.Hz_geom.shape[0] // 4
+        ext = cp[:, :2, :].permute(1, 0, 2).flatten(1)                    # [2, n * 4]
+        margin = torch.cat([-ext, ext]).max(dim=1).values                 # [x0, y0, x1, y1]
+        margin = margin + torch.tensor([pad * 2 - cx, pad * 2 - cy] * 2, device=dev)
+        margin = margin.clamp(min=0).minimum(torch.tensor([w - 1, h - 1] * 2, device=dev, dtype=torch.float32))
+        mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().tolist())     # one device -> host read per call, as in the reference (:283)
+        images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
+        g_inv = _translate((mx0 - mx1) / 2, (my0 - my1) / 2, images) @ g_inv
+        images = upfirdn2d.upsample2d(images, self.Hz_geom, up=2)
+        s2, s2i = _scale(2, 2, images), _scale(0.5, 0.5, images)
+        g_inv = s2 @ g_inv @ s2i
+        g_inv = _translate(-0.5, -0.5, images) @ g_inv @ _translate(0.5, 0.5, images)
+        out_h, out_w = (h + pad * 2) * 2, (w + pad * 2) * 2
+        g_inv = _scale(2 / images.shape[3], 2 / images.shape[2], images) @ g_inv @ _scale(out_w / 2, out_h / 2, images)
+        images = resample.affine_resample(images, g_inv[:, :2, :], (out_h, out_w))
+        return upfirdn2d.downsample2d(images, self.Hz_geom, down=2, padding=-pad * 2, flip_filter=True)
+
+
+def ada_update(augment_pipe, sign_real_mean, batch_size, interval=4, target=0.6, kimg=500):
+    """p <- max(p + sign(E[sign(D(real))] - target) * batch * interval / (kimg * 1000), 0), all on the device (training_loop.py:407-410)."""
+    step = torch.sign(sign_real_mean - target) * (batch_size * interval) / (kimg * 1000)
+    augment_pipe.p.copy_((augment_pipe.p + step).clamp(min=0))

@@ -99,6 +99,7 @@ class StyleGAN2Loss:
             with (fused_conv_act.composition_only() if do_Dr1 else contextlib.nullcontext()):   # R1 differentiates this pass twice
                 logits = self.run_D(real_tmp, real_c, real_t, sync=sync)['image_logits']
             loss_Dreal = 0
+            out['signs_real'] = logits.detach().sign().mean()   # what the reference reports as 'Loss/signs/real' (loss.py:147): the ADA feedback signal
             if do_Dmain:
                 loss_Dreal = F.softplus(-logits)
                 out['D/loss'] = (loss_Dgen + loss_Dreal).detach().mean()

@@ -52,7 +52,8 @@ def sample_frame_times(sampling, batch, generator=None, device='cpu'):
 class TrainStep:
     """Holds G, D, G_ema, optimisers and the loss; ``step()`` runs one iteration of the phase schedule."""
 
-    def __init__(self, g_kwargs, d_kwargs, train_cfg, device, batch_gpu, world_size=1, rank=0, seed=0, ddp=None, bucket_cap_mb=25, use_graphs=False):
+    def __init__(self, g_kwargs, d_kwargs, train_cfg, device, batch_gpu, world_size=1, rank=0, seed=0, ddp=None, bucket_cap_mb=25, use_graphs=False, augment='noaug',
+                 ada_target=0.6, ada_interval=4, ada_kimg=500):
         self.device, self.batch_gpu, self.world_size, self.rank = torch.device(device), batch_gpu, world_size, rank
         self.train_cfg = train_cfg
         self.G, self.D, self.G_ema = build_models(g_kwargs, d_kwargs, device, seed=seed)
@@ -77,7 +78,12 @@ class TrainStep:
         if train_cfg.pl_weight != 0:  # path-length regularisation differentiates G twice: the fused epilogue node is first-order only
             from ..torch_utils.ops import fused_fir_act
             fused_fir_act.enabled = False
+        # Discriminator augmentation (train.py:238-277, training_loop.py:197-205): 'ada' = the bgc pipeline with p starting at 0 and adapted
+        # every `ada_interval` iterations from the sign of D's outputs on real clips; one transform per video (configs/model/stylegan-v.yaml:58).
+        self.augment_pipe, self.ada = None, None
+        self._ada_cfg = dict(target=ada_target, interval=ada_interval, kimg=ada_kimg)
         self.loss = StyleGAN2Loss(cfg=g_kwargs['cfg'], device=self.device, r1_gamma=train_cfg.r1_gamma, pl_weight=train_cfg.pl_weight, **modules)
+        self.set_augment(augment)
 
         # Phase list with lazy regularisation (training_loop.py:238-252): reg every `interval` iterations with
         # lr and betas rescaled by c = interval / (interval + 1).
@@ -99,12 +105,26 @@ class TrainStep:
             if getattr(mod.synthesis, 'motion_encoder', None) is not None:
                 mod.synthesis.motion_encoder.t_bound = self.sampling.max_num_frames - 1
         # hipGraph replay of the two every-iteration phases (small per-GPU batches are launch-bound: ~1600 launches per iteration)
-        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda' and not self.ddp
+        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda' and not self.ddp and self.augment_pipe is None
         self._graphs = {}
         if self.use_graphs:
             for phase in self.phases:
                 for group in phase['opt'].param_groups:
                     group['capturable'] = True
+
+    def set_augment(self, augment):
+        """'noaug' or 'ada' (see __init__); can be switched on an existing instance (bench.py times both on the same models)."""
+        assert augment in ('noaug', 'ada')
+        if augment == 'ada':
+            from .augment import AugmentPipe, BGC
+            self.augment_pipe = AugmentPipe(**BGC).train().requires_grad_(False).to(self.device)
+            self.augment_pipe.p.copy_(torch.zeros([]))
+            self.ada = dict(self._ada_cfg, acc=torch.zeros([2], device=self.device))
+            self.use_graphs = False   # the ADA pipe reads its padding back to the host
+        else:
+            self.augment_pipe, self.ada = None, None
+        self.loss.augment_pipe = self.augment_pipe
+        self.loss.video_consistent_aug = augment == 'ada'
 
     # -- synthetic inputs -------------------------------------------------------------------------
     def synthetic_real_batch(self):
@@ -173,6 +193,16 @@ class TrainStep:
                 losses = self._run_phase(phase, real_img, real_c, real_t, gen_z, gen_c, gen_t)
             self.last_losses.update(losses)
             ran.append(phase['name'])
+            if self.ada is not None and 'signs_real' in losses:
+                self.ada['acc'] += torch.stack([losses['signs_real'], torch.ones_like(losses['signs_real'])])
+        if self.ada is not None and self.batch_idx % self.ada['interval'] == 0:   # training_loop.py:407-410, entirely on the device
+            from .augment import ada_update
+            mean_sign = self.ada['acc'][0] / self.ada['acc'][1].clamp(min=1)
+            if self.ddp:
+                torch.distributed.all_reduce(mean_sign)
+                mean_sign = mean_sign / self.world_size
+            ada_update(self.augment_pipe, mean_sign, self.batch_size, self.ada['interval'], self.ada['target'], self.ada['kimg'])
+            self.ada['acc'].zero_()
 
         # G_ema (training_loop.py:392-400)
         ema_nimg = self.train_cfg.ema_kimg * 1000

@@ -325,6 +325,25 @@ def gen_networks_mid():
     save('networks_mid', arrays, meta)
 
 
+def gen_augment():
+    """ADA `bgc` pipeline (src/training/augment.py) at fixed percentiles of every augmentation parameter (the reference's own
+    `debug_percentile` hook makes the transform deterministic), on 3-frame clips folded into 9 channels (loss.py:58-66)."""
+    from training.augment import AugmentPipe
+    bgc = dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1)
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand([2, 9, 32, 32], generator=g) * 2 - 1
+    pcts = [0.1, 0.35, 0.5, 0.8, 0.93]
+    arrays = {'x': x}
+    pipe = AugmentPipe(**bgc)
+    for i, pct in enumerate(pcts):
+        xi = x.clone().requires_grad_(True)
+        y = pipe(xi, debug_percentile=pct)
+        v = torch.randn(y.shape, generator=g)
+        (dx,) = torch.autograd.grad((y * v).sum(), xi)
+        arrays.update({f'y{i}': y, f'v{i}': v, f'dx{i}': dx})
+    save('augment', arrays, dict(percentiles=pcts, pipe='bgc'))
+
+
 def gen_time_encoder():
     """AlignedTimeEncoder + motion-code gather in float64 for a tight kernel tolerance."""
     from training.motion import MotionMappingNetwork
@@ -355,4 +374,5 @@ if __name__ == '__main__':
     gen_conv_ops()
     gen_networks()
     gen_networks_mid()
+    gen_augment()
     gen_time_encoder()

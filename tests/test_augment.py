@@ -1,0 +1,69 @@
+"""ADA `bgc` augmentation pipeline (training/augment.py) and its resampling kernel against the reference's AugmentPipe
+(tests/golden/augment.npz: reference outputs + input gradients at fixed percentiles of every augmentation parameter)."""
+import pytest
+import torch
+
+from stylegan_v_amd.torch_utils import custom_ops
+from stylegan_v_amd.torch_utils.ops import resample
+from stylegan_v_amd.training.augment import AugmentPipe, BGC, ada_update
+from util import Golden, assert_close
+
+AUG = Golden('augment')
+
+
+def _check_pipe(device, tol):
+    pipe = AugmentPipe(**BGC).to(device)
+    x0 = AUG.t('x', device=device)
+    for i, pct in enumerate(AUG.meta['percentiles']):
+        x = x0.clone().requires_grad_(True)
+        y = pipe(x, debug_percentile=pct)
+        assert_close(y, AUG.t(f'y{i}'), atol=tol, rtol=tol, what=f'augmented clip at percentile {pct}')
+        (dx,) = torch.autograd.grad((y * AUG.t(f'v{i}', device=device)).sum(), x)
+        assert_close(dx, AUG.t(f'dx{i}'), atol=tol * 10, rtol=tol * 10, what=f'input gradient at percentile {pct}')
+
+
+def test_augment_pipe_matches_reference_cpu():
+    _check_pipe('cpu', 2e-5)
+
+
+def test_augment_pipe_identity_at_p0_and_ada_update():
+    pipe = AugmentPipe(**BGC)
+    pipe.p.copy_(torch.zeros([]))
+    x = torch.rand([2, 9, 32, 32]) * 2 - 1
+    assert (pipe(x) - x).abs().max() < 5e-5          # the geometric path still runs (up-sample, resample, down-sample) and reproduces the input
+    ada_update(pipe, torch.tensor(0.9), batch_size=32, interval=4, target=0.6, kimg=500)
+    assert abs(float(pipe.p) - 32 * 4 / 500000) < 1e-9
+    ada_update(pipe, torch.tensor(0.1), batch_size=32, interval=4, target=0.6, kimg=500)
+    assert float(pipe.p) == 0
+    with pytest.raises(NotImplementedError):
+        AugmentPipe(noise=1)
+
+
+@pytest.mark.gpu
+def test_augment_pipe_matches_reference_gpu():
+    before = custom_ops.launch_count()
+    _check_pipe('cuda', 1e-4)
+    assert custom_ops.launch_count() - before >= 5 * 6, 'upfirdn2d / resample kernels did not run'
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,out', [((2, 9, 40, 40), (52, 52)), ((3, 3, 17, 33), (64, 20)), ((1, 1, 8, 8), (8, 8))])
+def test_affine_resample_kernel_vs_two_op_formulation(shape, out):
+    """Gather, adjoint (first-order gradient) and the second-order term against affine_grid + grid_sample in float64 on the CPU."""
+    g = torch.Generator().manual_seed(sum(shape))
+    n = shape[0]
+    x0 = torch.randn(shape, generator=g)
+    theta = torch.tensor([[0.9, 0.2, 0.05], [-0.15, 1.1, -0.1]]).repeat(n, 1, 1) + 0.1 * torch.randn([n, 2, 3], generator=g)
+    v = torch.randn([n, shape[1], *out], generator=g)
+
+    def run(x, th, vv, fn):
+        y = fn(x, th, out)
+        (gx,) = torch.autograd.grad((y * vv).sum() + y.square().sum(), x, create_graph=True)
+        (g2,) = torch.autograd.grad(gx.square().sum(), x)
+        return y, gx, g2
+    before = custom_ops.launch_count()
+    got = run(x0.cuda().requires_grad_(True), theta.cuda(), v.cuda(), resample.affine_resample)
+    assert custom_ops.launch_count() - before >= 3
+    want = run(x0.double().requires_grad_(True), theta.double(), v.double(), resample.affine_resample_ref)
+    for a, r, name in zip(got, want, ['y', 'dx', 'd2x']):
+        assert_close(a, r, atol=2e-4 * max(1.0, r.abs().max().item()), rtol=1e-4, what=name)
