@@ -72,7 +72,7 @@ def pmc_traffic(prefixes, dword_read_prefixes=()):
 
 
 def pmc_traffic_conv_family():
-    return pmc_traffic(('conv3x3_kernel', 'conv3x3_small_kernel', 'convT3x3_s2_kernel', 'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
+    return pmc_traffic(('conv3x3_ws_kernel', 'conv3x3_kernel', 'conv3x3_small_kernel', 'convT3x3_s2_kernel', 'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
 
 
 def pmc_traffic_per_launch(prefix='upfirdn2d_lanes'):
