@@ -356,6 +356,9 @@ typedef struct sgv_fc_params {
     float alpha, gain;
     float weight_gain, bias_gain;
     int32_t epilogue_act;
+    int32_t batch;          /* >= 1 independent problems: pointers advance by the *_stride_batch elements (0 = shared operand); batch == 0 means 1 */
+    int64_t a_stride_batch, b_stride_batch, c_stride_batch;
+    int32_t accumulate;     /* C += epi(...) instead of C = epi(...) */
 } sgv_fc_params;
 int sgv_fc(const sgv_fc_params* p, void* stream);
 

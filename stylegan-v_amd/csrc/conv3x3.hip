@@ -7,6 +7,7 @@
 #include "conv3x3_kernel.h"
 #include "conv3x3_ws_kernel.h"
 #include "conv3x3s2_kernel.h"
+#include "conv3x3s2_ws_kernel.h"
 
 #include <algorithm>
 #include <mutex>
@@ -31,6 +32,8 @@ bool supported(int n, int k, int m, int h, int w, int dtype) {
 std::once_flag g_attr_once;
 int g_cus = 256;
 hipError_t g_attr_err = hipSuccess;
+bool g_edge_fc = true;  // SGV_CONVT_EDGE_FC=0: the gather + FMA edge kernels instead of the strided fc products
+bool g_s2_ws = true;    // SGV_S2_WS=0: the one-role-per-wave stride-2 kernels of conv3x3s2_kernel.h
 bool g_use_ws = true;   // SGV_CONV_WS=0: the 4-wave kernel of conv3x3_kernel.h instead of the producer / consumer form
 
 bool big_image(int h, int w) { return w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0; }
@@ -57,6 +60,15 @@ void init_once() {
     g_attr_err = e;
     const char* env = getenv("SGV_CONV_WS");
     g_use_ws = !(env && env[0] == '0');
+    env = getenv("SGV_S2_WS");
+    g_s2_ws = !(env && env[0] == '0');
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+    g_attr_err = e;
+    env = getenv("SGV_CONVT_EDGE_FC");
+    g_edge_fc = !(env && env[0] == '0');
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
@@ -157,7 +169,7 @@ extern "C" int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, 
 }
 
 extern "C" int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode) {
-    int64_t bytes = (int64_t)c_in * c_out * 9 * 4;
+    int64_t bytes = (int64_t)c_in * c_out * 10 * 4;   // nine taps, ten in the tap-pair layout of conv3x3_s2_pairs_kernel
     if (mode == 2) bytes += (int64_t)convT3x3_s2_edge_floats(n, c_in, c_out, h, w) * 4;
     return bytes;
 }
@@ -176,10 +188,18 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
     hipStream_t stream = (hipStream_t)stream_;
 
-    const int words = (p->c_out / TM) * (p->c_in / KC) * 9 * 2 * TM;
-    hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
-                       p->terms);
-    int rc = sgv_check_launch("conv3x3_prep_weights");
+    const bool pairs = p->mode == 0 && g_s2_ws && p->c_out % P2_TM == 0 && p->h % P2_ROWS == 0;
+    int rc;
+    if (pairs) {
+        const int words = (p->c_out / P2_TM) * (p->c_in / P2_KC) * 10 * P2_TM;
+        hipLaunchKernelGGL(conv3x3_prep_weights_pairs, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->terms);
+        rc = sgv_check_launch("conv3x3_prep_weights_pairs");
+    } else {
+        const int words = (p->c_out / TM) * (p->c_in / KC) * 9 * 2 * TM;
+        hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
+                           p->terms);
+        rc = sgv_check_launch("conv3x3_prep_weights");
+    }
     if (rc != SGV_OK) return rc;
 
     s2_params kp{};
@@ -190,6 +210,20 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
     const double small_px = (double)p->n * p->h * p->w, big_px = (double)p->n * (2 * p->h + 1) * (2 * p->w + 1);
     const double bytes = 4.0 * (p->mode == 0 ? big_px * p->c_in + small_px * p->c_out : small_px * p->c_in + big_px * p->c_out) + 4.0 * p->c_in * p->c_out * 9;
     sgv_launch_scope scope(SGV_K_CONV3X3, stream, bytes, 2.0 * small_px * p->c_in * (double)p->c_out * 9);
+    if (pairs) {
+        kp.tiles = p->n * (p->h / P2_ROWS) * (p->w / SEG) * (p->c_out / P2_TM);
+        kp.grid = std::min(kp.tiles, g_cus);
+        if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_pairs_kernel<1>, dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp);
+        else hipLaunchKernelGGL(conv3x3_s2_pairs_kernel<3>, dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp);
+        return sgv_check_launch("conv3x3_s2_pairs_kernel");
+    }
+    if (p->mode == 0 && g_s2_ws) {
+        kp.tiles = p->n * (p->h / S2W_ROWS) * (p->w / SEG) * (p->c_out / TM);
+        kp.grid = std::min(kp.tiles, g_cus);
+        if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_ws_kernel<1>, dim3((unsigned)kp.grid), dim3(512), S2W_LDS_BYTES, stream, kp);
+        else hipLaunchKernelGGL(conv3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(512), S2W_LDS_BYTES, stream, kp);
+        return sgv_check_launch("conv3x3_s2_ws_kernel");
+    }
     if (p->mode == 0) {
         if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(256), S_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL(conv3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(256), S_LDS_BYTES, stream, kp);
@@ -199,12 +233,44 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
     else hipLaunchKernelGGL(convT3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
     rc = sgv_check_launch("convT3x3_s2_kernel");
     if (rc != SGV_OK) return rc;
-    float* edge = (float*)((char*)p->workspace + (size_t)p->c_in * p->c_out * 9 * 4);
-    const size_t edge_floats = convT3x3_s2_edge_floats(p->n, p->c_in, p->c_out, p->h, p->w);
-    hipLaunchKernelGGL(convT3x3_s2_edge_gather, dim3((unsigned)((edge_floats + 255) / 256)), dim3(256), 0, stream, (const float*)p->x, p->weight, edge, p->n, p->c_in, p->c_out,
-                       p->h, p->w);
-    const int lmax = std::max(2 * p->w + 1, 2 * p->h);
-    hipLaunchKernelGGL(convT3x3_s2_edge_kernel, dim3((unsigned)((lmax + 127) / 128), (unsigned)(p->n * (p->c_out / EDGE_MC)), 2), dim3(128), 0, stream, edge, (float*)p->y, p->n,
-                       p->c_in, p->c_out, p->h, p->w);
-    return sgv_check_launch("convT3x3_s2_edge_kernel");
+    if (!g_edge_fc || p->n > 65535) {
+        float* edge = (float*)((char*)p->workspace + (size_t)p->c_in * p->c_out * 9 * 4);
+        const size_t edge_floats = convT3x3_s2_edge_floats(p->n, p->c_in, p->c_out, p->h, p->w);
+        hipLaunchKernelGGL(convT3x3_s2_edge_gather, dim3((unsigned)((edge_floats + 255) / 256)), dim3(256), 0, stream, (const float*)p->x, p->weight, edge, p->n, p->c_in, p->c_out,
+                           p->h, p->w);
+        const int lmax = std::max(2 * p->w + 1, 2 * p->h);
+        hipLaunchKernelGGL(convT3x3_s2_edge_kernel, dim3((unsigned)((lmax + 127) / 128), (unsigned)(p->n * (p->c_out / EDGE_MC)), 2), dim3(128), 0, stream, edge, (float*)p->y, p->n,
+                           p->c_in, p->c_out, p->h, p->w);
+        return sgv_check_launch("convT3x3_s2_edge_kernel");
+    }
+    // Last output column (ox = 2W: tap kx = 2 of input column W-1) and last output row (oy = 2H: tap ky = 2 of input row H-1):
+    // per sample, seven [c_out x c_in] x [c_in x line] products of one weight tap with one input line, read and written in place
+    // through strides (0.4 % of the flops; fp32 MFMA, fc.hip).
+    {
+        const int H = p->h, W = p->w, K = p->c_in, M = p->c_out, Ho = 2 * H + 1, Wo = 2 * W + 1;
+        const int64_t HW = (int64_t)H * W, P = (int64_t)Ho * Wo;
+        const float* x = (const float*)p->x; const float* w = p->weight; float* y = (float*)p->y;
+        struct strip { int tap; int64_t b_off, b_sn; int cols; int64_t c_off, c_sn; int acc; };
+        const strip strips[7] = {
+            {0 * 3 + 2, W - 1, W, H, 2 * W, 2 * Wo, 0},                               // column, even rows 2Y   <- ky = 0 of row Y
+            {2 * 3 + 2, W - 1, W, H - 1, 2 * Wo + 2 * W, 2 * Wo, 1},                  //         even rows 2Y+2 <- ky = 2 of row Y (Y < H-1)
+            {1 * 3 + 2, W - 1, W, H, Wo + 2 * W, 2 * Wo, 0},                          //         odd rows 2Y+1  <- ky = 1
+            {2 * 3 + 0, (int64_t)(H - 1) * W, 1, W, (int64_t)2 * H * Wo, 2, 0},       // row, even columns 2X   <- kx = 0 of column X
+            {2 * 3 + 2, (int64_t)(H - 1) * W, 1, W - 1, (int64_t)2 * H * Wo + 2, 2, 1},   //   even columns 2X+2 <- kx = 2 of column X (X < W-1)
+            {2 * 3 + 1, (int64_t)(H - 1) * W, 1, W, (int64_t)2 * H * Wo + 1, 2, 0},   //      odd columns 2X+1  <- kx = 1
+            {2 * 3 + 2, HW - 1, 1, 1, P - 1, 1, 0},                                    // corner
+        };
+        for (const strip& s : strips) {
+            if (s.cols < 1) continue;
+            sgv_fc_params q{};
+            q.a = w + s.tap; q.a_stride_m = 9; q.a_stride_k = (int64_t)9 * M; q.a_stride_batch = 0;
+            q.b = x + s.b_off; q.b_stride_k = HW; q.b_stride_n = s.b_sn; q.b_stride_batch = (int64_t)K * HW;
+            q.c = y + s.c_off; q.c_stride_m = P; q.c_stride_n = s.c_sn; q.c_stride_batch = (int64_t)M * P;
+            q.m = M; q.n = s.cols; q.k = K; q.batch = p->n; q.accumulate = s.acc;
+            q.act = 1; q.alpha = 0.f; q.gain = 1.f; q.weight_gain = 1.f; q.bias_gain = 1.f;
+            rc = sgv_fc_launch(&q, stream, false);
+            if (rc != SGV_OK) return rc;
+        }
+    }
+    return SGV_OK;
 }

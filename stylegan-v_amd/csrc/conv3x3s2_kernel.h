@@ -38,6 +38,7 @@ struct s2_params {
     float* y;
     int n, k, m, h, w;     // h, w: the SMALL grid (strided: output; transposed: input)
     int tiles, grid;
+    int order;             // producer / consumer forms: 1 = a workgroup runs all m tiles of a spatial tile back to back
 };
 
 __device__ __forceinline__ tile_pos decode_tile_s2(const s2_params& p, int tile, int rows) {

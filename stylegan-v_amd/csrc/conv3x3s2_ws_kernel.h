@@ -1,0 +1,525 @@
+// Producer / consumer forms of the stride-2 members of the 3x3 family (conv3x3s2_kernel.h holds the one-role-per-wave forms and the
+// arithmetic: bf16 hi/lo split products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; same prepared weights).
+//
+//   conv3x3_s2_ws_kernel   y[n,m,Y,X] = sum_{k,ky,kx} wgt(m,k,ky,kx) * x[n,k,2Y+ky,2X+kx]        x: (2H+1)x(2W+1) -> y: HxW
+//
+// Reference: the `conv2d(stride=2)` behind the FIR of the down-sampling path (src/torch_utils/ops/conv2d_resample.py:113-126) and
+// the data gradient of the up-sampling path's `conv_transpose2d` (conv2d_gradfix.py:100-118).
+//
+// Why: in conv3x3_s2_kernel one workgroup (108 KiB LDS) owns a CU with ONE wave per SIMD that loads, splits, writes LDS and issues
+// the MFMAs in turn -- the matrix pipe idles 70 % of the time (profiles/r02_pmc_bench_step_MFMA_table.txt).  Same cure as
+// conv3x3_ws_kernel.h: 8 waves, roles split, LDS double-buffered, one barrier per 16-channel chunk.
+//
+//   waves 0-3 (consumers): wave = one output row x 32 px x 64 m (2 accumulator tiles); per tap 6 MFMAs against 6 operand reads that
+//                          were fetched one tap ahead;
+//   waves 4-6 (x producers): a stride-2 tile needs 4x the input of a stride-1 tile per MFMA, so the tile is 4 output rows: 16 channels x
+//                          9 rows x 65 columns.  Rows of the (2W+1)-wide tensor are only 4-byte aligned: unaligned `global_load_dwordx4`
+//                          (gfx950 runs with unaligned access mode on), items of 8 channels x 4 columns, de-interleaved into an even and an
+//                          odd column plane on their way into LDS so that tap kx reads plane kx & 1 at pixel + (kx >> 1);
+//   wave 7 (weight DMA):   36 KiB per chunk, global -> LDS.
+//
+// LDS: 2 x (x 37.1 KiB + weights 36 KiB) = 146.3 KiB, one workgroup per CU.
+#pragma once
+
+#include "conv3x3s2_kernel.h"
+#include "conv3x3_ws_kernel.h"
+
+namespace sgv_conv {
+
+constexpr int S2W_ROWS = 4;                              // output rows per tile
+constexpr int S2W_RIN = 2 * S2W_ROWS + 1;                // 9 input rows
+constexpr int S2W_PW = 33;                               // words per parity plane row (the even plane holds 33 columns)
+constexpr int S2W_XS_PLANE = S2W_RIN * 2 * S2W_PW;       // words per (hl, octet)
+constexpr int S2W_XS_WORDS = 4 * S2W_XS_PLANE;
+constexpr int S2W_IMAGE_WORDS = S2W_XS_WORDS + WS_WORDS;
+constexpr int S2W_LDS_BYTES = 2 * S2W_IMAGE_WORDS * 16;
+
+// ABL (tools/conv_s2_lab.hip only; results are wrong by construction): 1 x loads from 16-byte aligned addresses, 2 no weight DMA, 3 no x loads,
+// 4 no MFMAs, 5 no x split / LDS writes, 6 consumers only keep the barrier protocol (producer + DMA pipeline speed),
+// 7 producers and DMA only keep the barrier protocol (consumer speed).
+template <int TERMS, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void conv3x3_s2_ws_kernel(s2_params p) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int chunks = p.k / KC;
+    const int win = 2 * p.w + 1;
+    const size_t plane_in = (size_t)(2 * p.h + 1) * win, plane_out = (size_t)p.h * p.w;
+
+    // order 0: tile i of the launch goes to workgroup i % grid (the m tiles of one x tile run side by side on neighbouring CUs of an XCD);
+    // order 1: a workgroup takes a spatial tile and runs all its m tiles back to back (x re-read by the same CU: L2-resident by construction)
+    const int mts = p.m / TM;
+    const int first = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int units = p.order ? p.tiles / mts : p.tiles;
+    if (first >= units) return;
+    const int my_units = (units - first + p.grid - 1) / p.grid;
+    const int total = (p.order ? my_units * mts : my_units) * chunks;
+    auto tile_of = [&](int q) {
+        const int j = q / chunks;
+        return p.order ? (first + (j / mts) * p.grid) * mts + j % mts : first + j * p.grid;
+    };
+
+    if (wave == 7) {
+        // =========================================== weight DMA wave ===========================================
+        auto dma_w = [&](int q, u32x4* img) {
+            const tile_pos tp = decode_tile_s2(p, tile_of(q), S2W_ROWS);
+            const u32x4* wq = p.wprep + ((size_t)tp.mt * chunks + (q % chunks)) * WS_WORDS + lane;
+            u32x4* wl = img + S2W_XS_WORDS;
+#pragma unroll
+            for (int j = 0; j < 36; j++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wq + j * 64),
+                                                 (__attribute__((address_space(3))) void*)(wl + j * 64), 16, 0, 0);
+        };
+        dma_w(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // image 0 ready
+        for (int q = 0; q < total; q++) {
+            if (q + 1 < total && ABL != 2 && ABL != 7) dma_w(q + 1, lds + ((q + 1) & 1) * S2W_IMAGE_WORDS);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    if (wave >= 4) {
+        // =========================================== x waves (4, 5, 6) ===========================================
+        // 306 units per chunk: 288 items of 8 channels x 4 columns (9 rows x 16 groups x 2 octets: columns 0..63 of the tile) and 18 items for
+        // column 64 (taken as the last element of the group that ends there, so that nothing is read beyond the row).  Thread i of 192 takes
+        // units i and i + 192; every thread issues the same 16 loads per chunk (idle second units load a valid address and drop the result).
+        const int pt = t - 256;
+        constexpr int ITEMS = 32 * S2W_RIN;
+        const int u1 = pt + 192;
+        const int kind1 = u1 < ITEMS ? 0 : (u1 < ITEMS + 2 * S2W_RIN ? 1 : 2);
+        const int oct = pt & 1;
+        const int a_grp = (pt >> 1) & 15, a_row0 = pt >> 5, a_row1 = u1 >> 5;
+        const int h_row = (u1 - ITEMS) >> 1;
+        struct xset { f32x4 a[8]; f32x4 b[8]; };
+
+        auto load_x = [&](int q, xset& r) {
+            const tile_pos tp = decode_tile_s2(p, tile_of(q), S2W_ROWS);
+            const int c = q % chunks;
+            const float* xb_ = p.x + ((size_t)tp.n * p.k + c * KC + 8 * oct) * plane_in + (size_t)(2 * tp.y0) * win + 2 * tp.x0;
+            const float* q0 = xb_ + (size_t)a_row0 * win + 4 * a_grp;
+            const float* q1 = xb_ + (kind1 == 0 ? (size_t)a_row1 * win + 4 * a_grp : kind1 == 1 ? (size_t)h_row * win + 61 : 0);
+            if (ABL == 1) { q0 = (const float*)((uintptr_t)q0 & ~(uintptr_t)15); q1 = (const float*)((uintptr_t)q1 & ~(uintptr_t)15); }
+            const size_t cstep = ABL == 1 ? (plane_in & ~(size_t)3) : plane_in;
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * cstep) : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b[j]) : "v"(q1 + j * cstep) : "memory");
+        };
+        auto arrive = [&](xset& r, bool newer) {
+            if (newer) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; j++) { asm volatile("" : "+v"(r.a[j])); asm volatile("" : "+v"(r.b[j])); }
+        };
+        auto put = [&](u32x4* xs, int pos, const float* v) {
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            xs[pos] = hi;
+            if (TERMS > 1) xs[2 * S2W_XS_PLANE + pos] = lo;
+        };
+        // column 4 * grp + px of the tile -> plane (px & 1), word 2 * grp + (px >> 1)
+        auto put_item = [&](u32x4* xs, int row, int grp, const f32x4* src) {
+            const int base = (oct * S2W_RIN + row) * 2 * S2W_PW + 2 * grp;
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = src[j][px];
+                put(xs, base + (px & 1) * S2W_PW + (px >> 1), v);
+            }
+        };
+        auto store_x = [&](u32x4* xs, const xset& r) {
+            put_item(xs, a_row0, a_grp, r.a);
+            if (kind1 == 0) put_item(xs, a_row1, a_grp, r.b);
+            else if (kind1 == 1) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = r.b[j][3];
+                put(xs, (oct * S2W_RIN + h_row) * 2 * S2W_PW + 32, v);
+            }
+        };
+        auto step = [&](int q, xset& ld, xset& st) {
+            const bool more = q + 2 < total && ABL != 3 && ABL != 7;
+            if (more) load_x(q + 2, ld);
+            if (q + 1 < total) {
+                arrive(st, more);
+                if (ABL != 5 && ABL != 7) store_x(lds + ((q + 1) & 1) * S2W_IMAGE_WORDS, st);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+
+        xset s0, s1;
+        load_x(0, s0);
+        if (total > 1 && ABL != 3 && ABL != 7) load_x(1, s1);
+        arrive(s0, total > 1 && ABL != 3 && ABL != 7);
+        store_x(lds, s0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // image 0 ready
+        for (int q = 0; q < total; q += 2) {
+            step(q, s0, s1);
+            if (q + 1 < total) step(q + 1, s1, s0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // =========================================== consumers ===========================================
+    f32x16 acc[2];
+#pragma unroll
+    for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[hf][e] = 0.f;
+
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_barrier();   // image 0 ready
+    asm volatile("" ::: "memory");
+    for (int q = 0; q < total; q++) {
+        const u32x4* xs = lds + (q & 1) * S2W_IMAGE_WORDS;
+        const u32x4* ws = xs + S2W_XS_WORDS;
+        const int c = q % chunks;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int a_lane = (ln >> 5) * TM + (ln & 31);                                        // + ((hl * 9 + tap) * 2) * TM + hf * 32
+        const int b_lane = ((ln >> 5) * S2W_RIN + 2 * wave) * 2 * S2W_PW + (ln & 31);         // + (ky * 2 + (kx & 1)) * PW + (kx >> 1)
+
+        // operands are fetched TWO taps ahead (three register buffers): with one read behind each MFMA of a 6-MFMA tap, a distance of one tap
+        // would leave the last reads a single MFMA (32 cycles) to land
+        u32x4 a[3][2][2];    // [buffer][half][hl]
+        u32x4 b[3][2];       // [buffer][hl]
+        auto fetch = [&](int buf, int tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int pos = b_lane + (ky * 2 + (kx & 1)) * S2W_PW + (kx >> 1);
+            // in the order of first use: a_lo x b_hi, a_hi x b_lo, a_hi x b_hi
+            b[buf][0] = xs[pos];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++)
+                if (TERMS > 1) a[buf][hf][1] = ws[a_lane + ((1 * 9 + tap) * 2) * TM + hf * 32];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) a[buf][hf][0] = ws[a_lane + ((0 * 9 + tap) * 2) * TM + hf * 32];
+            if (TERMS > 1) b[buf][1] = xs[2 * S2W_XS_PLANE + pos];
+        };
+        constexpr int RD = TERMS > 1 ? 6 : 3;   // reads per tap
+        if (ABL != 6) {
+        fetch(0, 0);
+        fetch(1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int bb = tap % 3;
+            if (tap + 2 < 9) fetch((tap + 2) % 3, tap + 2);
+            if (TERMS > 1) {
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0)>(a[bb][hf][1], b[bb][0], acc[hf]);
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0)>(a[bb][hf][0], b[bb][1], acc[hf]);
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0)>(a[bb][hf][0], b[bb][0], acc[hf]);
+            constexpr int MF = TERMS > 1 ? 6 : 2;
+            const int reads = tap + 2 < 9 ? RD : 0;
+#pragma unroll
+            for (int i = 0; i < MF; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (TERMS == 1 && i == 0 && reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        }
+
+        if (c == chunks - 1) {
+            const tile_pos tp = decode_tile_s2(p, tile_of(q), S2W_ROWS);
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int g = le >> 5;
+            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane_out + (size_t)(tp.y0 + wave) * p.w + tp.x0 + (le & 31);
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+                    yb[(size_t)m * plane_out] = acc[hf][e];
+                    acc[hf][e] = 0.f;
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// conv3x3_s2_pairs_kernel: the same producer / consumer scheme with a tile of 8 output rows x 32 px x 128 output channels.
+//
+// Why a second form: the lab's ablations of the kernel above (profiles/r02_conv_s2_lab_ws_ablations.log) show consumers alone at
+// 0.51 ms, the producer + DMA pipeline alone at 0.82 ms and both together at 0.95 ms for the 128 -> 64 layer: per 16-channel chunk
+// a CU has to pull 37 KiB of x and 36 KiB of weights through its memory path for only 216 MFMAs (42 bytes per MFMA-pipe cycle;
+// the stride-1 kernel needs 10.7) and sustains about 20.  The tile has to give each byte more MFMAs, and LDS has to hold it twice:
+//   * 128 output channels and 8 output rows quadruple the MFMAs per (x, weight) byte pair;
+//   * a chunk is 8 input channels, and the MFMA's k = 16 is (two taps) x (8 channels): lanes 0-31 of the B operand read the pixel of
+//     tap 2j, lanes 32-63 the pixel of tap 2j+1 (same LDS word format, different address per lane half), the A operand holds the
+//     two taps' weights.  Nine taps = five pairs, the tenth tap has zero weights (10 % of the MFMAs are padding);
+//   * LDS image: x [hl][17 rows][2 column parities][33] x 16 B = 35.1 KiB + weights [hl][5 pairs][2][128 m] x 16 B = 40 KiB; two
+//     images = 150.1 KiB.  Per chunk 89 KiB of traffic (incl. the idle lanes' loads) for 480 MFMAs: 23 bytes per cycle at full rate.
+// A consumer wave owns 2 output rows x 128 m = 8 accumulator tiles; per pair 12 operand reads (8 A + 4 B) against 24 MFMAs, fetched one
+// pair ahead.
+constexpr int P2_TM = 128;
+constexpr int P2_KC = 8;
+constexpr int P2_ROWS = 8;
+constexpr int P2_RIN = 2 * P2_ROWS + 1;
+constexpr int P2_XS_PLANE = P2_RIN * 2 * S2W_PW;          // words per hl
+constexpr int P2_XS_WORDS = 2 * P2_XS_PLANE;
+constexpr int P2_WS_WORDS = 2 * 5 * 2 * P2_TM;            // [hl][pair][tap in pair][128 m]
+constexpr int P2_IMAGE_WORDS = P2_XS_WORDS + P2_WS_WORDS;
+constexpr int P2_LDS_BYTES = 2 * P2_IMAGE_WORDS * 16;
+
+// fp32 [M, K, 3, 3] -> bf16 hi/lo in [m tile of 128][chunk of 8 k][hl][pair][tap in pair][128 m][8 k]; tap 9 is zero.
+__global__ __launch_bounds__(256) void conv3x3_prep_weights_pairs(const float* w, u32x4* out, int m_total, int k_total, int terms) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    const int chunks = k_total / P2_KC;
+    const int total = (m_total / P2_TM) * chunks * 10 * P2_TM;
+    if (idx >= total) return;
+    int r = idx;
+    const int mi = r % P2_TM; r /= P2_TM;
+    const int tap = r % 10; r /= 10;
+    const int c = r % chunks;
+    const int mt = r / chunks;
+    const int m = mt * P2_TM + mi, k0 = c * P2_KC;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = tap < 9 ? w[((size_t)m * k_total + k0 + j) * 9 + tap] : 0.f;
+    u32x4 hi, lo;
+    split8(v, hi, lo);
+    const size_t base = ((size_t)mt * chunks + c) * P2_WS_WORDS;
+    out[base + (0 * 10 + tap) * P2_TM + mi] = hi;
+    if (terms > 1) out[base + (1 * 10 + tap) * P2_TM + mi] = lo;
+}
+
+__device__ __forceinline__ tile_pos decode_tile_p2(const s2_params& p, int tile) {
+    const int mts = p.m / P2_TM, segs = p.w / SEG, rbs = p.h / P2_ROWS;
+    tile_pos tp;
+    tp.mt = tile % mts;
+    int r = tile / mts;
+    tp.x0 = (r % segs) * SEG;
+    r /= segs;
+    tp.y0 = (r % rbs) * P2_ROWS;
+    tp.n = r / rbs;
+    return tp;
+}
+
+// ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
+template <int TERMS, int ABL = 0>
+__global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int chunks = p.k / P2_KC;
+    const int win = 2 * p.w + 1;
+    const size_t plane_in = (size_t)(2 * p.h + 1) * win, plane_out = (size_t)p.h * p.w;
+
+    const int first = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (first >= p.tiles) return;
+    const int my_tiles = (p.tiles - first + p.grid - 1) / p.grid;
+    const int total = my_tiles * chunks;
+    auto tile_of = [&](int q) { return first + (q / chunks) * p.grid; };
+
+    if (wave == 7) {
+        // =========================================== weight DMA wave ===========================================
+        auto dma_w = [&](int q, u32x4* img) {
+            const tile_pos tp = decode_tile_p2(p, tile_of(q));
+            const u32x4* wq = p.wprep + ((size_t)tp.mt * chunks + (q % chunks)) * P2_WS_WORDS + lane;
+            u32x4* wl = img + P2_XS_WORDS;
+#pragma unroll
+            for (int j = 0; j < P2_WS_WORDS / 64; j++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wq + j * 64),
+                                                 (__attribute__((address_space(3))) void*)(wl + j * 64), 16, 0, 0);
+        };
+        if (ABL != 7) dma_w(0, lds);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // image 0 ready
+        for (int q = 0; q < total; q++) {
+            if (q + 1 < total && ABL != 7) dma_w(q + 1, lds + ((q + 1) & 1) * P2_IMAGE_WORDS);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    if (wave >= 4) {
+        // =========================================== x waves (4, 5, 6) ===========================================
+        // 289 units per chunk: 272 items of 8 channels x 4 columns (17 rows x 16 groups) and 17 items for column 64 (the last element of the
+        // group that ends there).  Thread i of 192 takes units i and i + 192; every thread issues the same 16 loads per chunk.
+        const int pt = t - 256;
+        constexpr int ITEMS = 16 * P2_RIN;
+        const int u1 = pt + 192;
+        const int kind1 = u1 < ITEMS ? 0 : (u1 < ITEMS + P2_RIN ? 1 : 2);
+        const int a_grp = pt & 15, a_row0 = pt >> 4, a_row1 = u1 >> 4;
+        const int h_row = u1 - ITEMS;
+        struct xset { f32x4 a[8]; f32x4 b[8]; };
+
+        auto load_x = [&](int q, xset& r) {
+            const tile_pos tp = decode_tile_p2(p, tile_of(q));
+            const int c = q % chunks;
+            const float* xb_ = p.x + ((size_t)tp.n * p.k + c * P2_KC) * plane_in + (size_t)(2 * tp.y0) * win + 2 * tp.x0;
+            const float* q0 = xb_ + (size_t)a_row0 * win + 4 * a_grp;
+            const float* q1 = xb_ + (kind1 == 0 ? (size_t)a_row1 * win + 4 * a_grp : kind1 == 1 ? (size_t)h_row * win + 61 : 0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * plane_in) : "memory");
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b[j]) : "v"(q1 + j * plane_in) : "memory");
+        };
+        auto arrive = [&](xset& r, bool newer) {
+            if (newer) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; j++) { asm volatile("" : "+v"(r.a[j])); asm volatile("" : "+v"(r.b[j])); }
+        };
+        auto put = [&](u32x4* xs, int pos, const float* v) {
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            xs[pos] = hi;
+            if (TERMS > 1) xs[P2_XS_PLANE + pos] = lo;
+        };
+        auto put_item = [&](u32x4* xs, int row, int grp, const f32x4* src) {
+            const int base = row * 2 * S2W_PW + 2 * grp;
+#pragma unroll
+            for (int px = 0; px < 4; px++) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = src[j][px];
+                put(xs, base + (px & 1) * S2W_PW + (px >> 1), v);
+            }
+        };
+        auto store_x = [&](u32x4* xs, const xset& r) {
+            put_item(xs, a_row0, a_grp, r.a);
+            if (kind1 == 0) put_item(xs, a_row1, a_grp, r.b);
+            else if (kind1 == 1) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = r.b[j][3];
+                put(xs, h_row * 2 * S2W_PW + 32, v);
+            }
+        };
+        auto step = [&](int q, xset& ld, xset& st) {
+            const bool more = q + 2 < total && ABL != 7;
+            if (more) load_x(q + 2, ld);
+            if (q + 1 < total) {
+                arrive(st, more);
+                if (ABL != 7) store_x(lds + ((q + 1) & 1) * P2_IMAGE_WORDS, st);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+
+        xset s0, s1;
+        load_x(0, s0);
+        if (total > 1 && ABL != 7) load_x(1, s1);
+        arrive(s0, total > 1 && ABL != 7);
+        store_x(lds, s0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // image 0 ready
+        for (int q = 0; q < total; q += 2) {
+            step(q, s0, s1);
+            if (q + 1 < total) step(q + 1, s1, s0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // =========================================== consumers ===========================================
+    f32x16 acc[2][4];   // [row][m quarter]
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int mq = 0; mq < 4; mq++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[r][mq][e] = 0.f;
+
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_barrier();   // image 0 ready
+    asm volatile("" ::: "memory");
+    for (int q = 0; q < total; q++) {
+        const u32x4* xs = lds + (q & 1) * P2_IMAGE_WORDS;
+        const u32x4* ws = xs + P2_XS_WORDS;
+        const int c = q % chunks;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int g = ln >> 5;
+        const int a_lane = g * P2_TM + (ln & 31);                          // + ((hl * 5 + pair) * 2) * P2_TM + mq * 32
+        const int b_lane = (2 * wave) * 4 * S2W_PW + (ln & 31);            // + r * 4 * PW + tap offset of this lane half
+
+        if (ABL != 6) {
+        u32x4 a[2][4][2];    // [buffer][m quarter][hl]
+        u32x4 b[2][2][2];    // [buffer][row][hl]
+        auto tap_off = [](int tap) { const int ky = tap / 3, kx = tap % 3; return (ky * 2 + (kx & 1)) * S2W_PW + (kx >> 1); };
+        auto fetch = [&](int buf, int pair) {
+            const int o0 = tap_off(2 * pair), o1 = tap_off(pair == 4 ? 8 : 2 * pair + 1);   // the padding tap reads tap 8's pixels against zero weights
+            const int pos = b_lane + (g ? o1 : o0);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                b[buf][r][0] = xs[pos + r * 4 * S2W_PW];
+                if (TERMS > 1) b[buf][r][1] = xs[P2_XS_PLANE + pos + r * 4 * S2W_PW];
+            }
+#pragma unroll
+            for (int mq = 0; mq < 4; mq++) {
+                a[buf][mq][0] = ws[a_lane + ((0 * 5 + pair) * 2) * P2_TM + mq * 32];
+                if (TERMS > 1) a[buf][mq][1] = ws[a_lane + ((1 * 5 + pair) * 2) * P2_TM + mq * 32];
+            }
+        };
+        constexpr int RD = TERMS > 1 ? 12 : 6;
+        fetch(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, RD, 0);
+#pragma unroll
+        for (int pair = 0; pair < 5; pair++) {
+            const int bb = pair & 1;
+            if (pair + 1 < 5) fetch(bb ^ 1, pair + 1);
+            if (TERMS > 1) {
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0>(a[bb][mq][1], b[bb][r][0], acc[r][mq]);
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0>(a[bb][mq][0], b[bb][r][1], acc[r][mq]);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0>(a[bb][mq][0], b[bb][r][0], acc[r][mq]);
+            constexpr int MF = TERMS > 1 ? 24 : 8;
+            const int reads = pair + 1 < 5 ? RD : 0;
+#pragma unroll
+            for (int i = 0; i < MF; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        }
+
+        if (c == chunks - 1) {
+            const tile_pos tp = decode_tile_p2(p, tile_of(q));
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int ge = le >> 5;
+            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * P2_TM) * plane_out + (size_t)(tp.y0 + 2 * wave) * p.w + tp.x0 + (le & 31);
+#pragma unroll
+            for (int mq = 0; mq < 4; mq++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int m = mq * 32 + (e & 3) + 8 * (e >> 2) + 4 * ge;
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        yb[(size_t)m * plane_out + (size_t)r * p.w] = acc[r][mq][e];
+                        acc[r][mq][e] = 0.f;
+                    }
+                }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
+}  // namespace sgv_conv

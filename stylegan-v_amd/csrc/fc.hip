@@ -37,6 +37,8 @@ struct fc_params {
     float alpha, gain;                    // of that activation
     float wgain, bgain;                   // C = acc * wgain + bias * bgain
     int epilogue_act;                     // apply act/gain in the epilogue (forward form)
+    int64_t sab, sbb, scb;                // batch strides (blockIdx.z)
+    int accumulate;                       // C += ...
 };
 
 // AK / BK: operand is contiguous along k (row-major x, W in the forward form: each lane streams its own row with 16-B loads) or along the
@@ -54,9 +56,10 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int am = m0 + r, bn = n0 + r;
     const bool a_ok = am < p.m, b_ok = bn < p.n;
-    const float* ap = p.a + (size_t)(a_ok ? am : 0) * p.sam;
-    const float* arp = p.aref ? p.aref + (size_t)(a_ok ? am : 0) * p.sam : nullptr;
-    const float* bp = p.b + (size_t)(b_ok ? bn : 0) * p.sbn;
+    const size_t bz = blockIdx.z;
+    const float* ap = p.a + bz * p.sab + (size_t)(a_ok ? am : 0) * p.sam;
+    const float* arp = p.aref ? p.aref + bz * p.sab + (size_t)(a_ok ? am : 0) * p.sam : nullptr;
+    const float* bp = p.b + bz * p.sbb + (size_t)(b_ok ? bn : 0) * p.sbn;
     if (t < 32) rowstat[t] = 0.f;
 
     f32x16 acc0, acc1;
@@ -65,8 +68,8 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
     float a_sum = 0.f, a_sq = 0.f;
     // a step covers 8 consecutive k: lane (r, kk) holds k = k0 + 4 * kk + j for j = 0..3, MFMA j contracts the pair (k0 + j, k0 + 4 + j)
     const int steps = (p.k + 7) / 8;
-    const bool vec_a = AK && (p.k % 4 == 0) && ((((uintptr_t)p.a) | (uintptr_t)(p.sam * 4)) % 16 == 0) && (!p.aref || ((uintptr_t)p.aref % 16 == 0));
-    const bool vec_b = BK && (p.k % 4 == 0) && ((((uintptr_t)p.b) | (uintptr_t)(p.sbn * 4)) % 16 == 0);
+    const bool vec_a = AK && (p.k % 4 == 0) && ((((uintptr_t)p.a) | (uintptr_t)(p.sam * 4) | (uintptr_t)(p.sab * 4)) % 16 == 0) && (!p.aref || ((uintptr_t)p.aref % 16 == 0));
+    const bool vec_b = BK && (p.k % 4 == 0) && ((((uintptr_t)p.b) | (uintptr_t)(p.sbn * 4) | (uintptr_t)(p.sbb * 4)) % 16 == 0);
     for (int i = wave; i < steps; i += FC_WAVES) {
         const int k0 = 8 * i + 4 * kk;
         float av[4], bv[4], yv[4];
@@ -128,18 +131,18 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
         if (p.normalize) v *= 1.0f / sqrtf(rowstat[ml] / (float)p.k + 1e-8f);
         v = v * p.wgain + bias;
         if (p.epilogue_act) v = ((p.act == 3 && !(v > 0.f)) ? v * p.alpha : v) * p.gain;
-        if (m0 + ml < p.m && b_ok) p.c[(size_t)(m0 + ml) * p.scm + (size_t)bn * p.scn] = v;
+        if (m0 + ml < p.m && b_ok) {
+            float* cq = p.c + bz * p.scb + (size_t)(m0 + ml) * p.scm + (size_t)bn * p.scn;
+            *cq = p.accumulate ? *cq + v : v;
+        }
     }
 }
 
 }  // namespace sgv_fck
 
-extern "C" int sgv_fc(const sgv_fc_params* q, void* stream_) {
-    if (!q) return sgv_fail(SGV_ERR_INVALID_ARG, "fc: params is NULL");
-    if (!q->a || !q->b || !q->c) return sgv_fail(SGV_ERR_INVALID_ARG, "fc: NULL pointer");
-    if (q->m < 1 || q->n < 1 || q->k < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "fc: sizes must be positive");
-    if (q->act != 1 && q->act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "fc: act must be 1 (linear) or 3 (lrelu)");
-    if ((q->m + 31) / 32 > 65535) return sgv_fail(SGV_ERR_TOO_LARGE, "fc: too many rows");
+// shared with conv3x3.hip (the transposed convolution's last output row / column are six small batched products)
+int sgv_fc_launch(const sgv_fc_params* q, hipStream_t stream, bool account) {
+    const int batch = q->batch > 0 ? q->batch : 1;
     sgv_fck::fc_params p{};
     p.a = q->a; p.sam = q->a_stride_m; p.sak = q->a_stride_k; p.aref = q->a_ref;
     p.b = q->b; p.sbk = q->b_stride_k; p.sbn = q->b_stride_n;
@@ -148,13 +151,30 @@ extern "C" int sgv_fc(const sgv_fc_params* q, void* stream_) {
     p.m = q->m; p.n = q->n; p.k = q->k;
     p.normalize = q->normalize_a; p.act = q->act; p.alpha = q->alpha; p.gain = q->gain; p.wgain = q->weight_gain; p.bgain = q->bias_gain;
     p.epilogue_act = q->epilogue_act;
-    hipStream_t stream = (hipStream_t)stream_;
-    sgv_launch_scope scope(SGV_K_GEMM, stream, 4.0 * ((double)q->m * q->k + (double)q->n * q->k + (double)q->m * q->n), 2.0 * q->m * (double)q->n * q->k);
-    dim3 grid((unsigned)((q->n + 31) / 32), (unsigned)((q->m + 31) / 32)), block(sgv_fck::FC_WAVES * 64);
+    p.sab = q->a_stride_batch; p.sbb = q->b_stride_batch; p.scb = q->c_stride_batch; p.accumulate = q->accumulate;
+    dim3 grid((unsigned)((q->n + 31) / 32), (unsigned)((q->m + 31) / 32), (unsigned)batch), block(sgv_fck::FC_WAVES * 64);
     const bool ak = q->a_stride_k == 1, bk = q->b_stride_k == 1;
-    if (ak && bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 1>), grid, block, 0, stream, p);
-    else if (ak) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 0>), grid, block, 0, stream, p);
-    else if (bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 0>), grid, block, 0, stream, p);
+    auto go = [&] {
+        if (ak && bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 1>), grid, block, 0, stream, p);
+        else if (ak) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 0>), grid, block, 0, stream, p);
+        else if (bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 1>), grid, block, 0, stream, p);
+        else hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 0>), grid, block, 0, stream, p);
+    };
+    if (account) {
+        sgv_launch_scope scope(SGV_K_GEMM, stream, 4.0 * batch * ((double)q->m * q->k + (double)q->n * q->k + (double)q->m * q->n), 2.0 * batch * q->m * (double)q->n * q->k);
+        go();
+    } else {
+        go();
+    }
     return sgv_check_launch("fc_kernel");
+}
+
+extern "C" int sgv_fc(const sgv_fc_params* q, void* stream_) {
+    if (!q) return sgv_fail(SGV_ERR_INVALID_ARG, "fc: params is NULL");
+    if (!q->a || !q->b || !q->c) return sgv_fail(SGV_ERR_INVALID_ARG, "fc: NULL pointer");
+    if (q->m < 1 || q->n < 1 || q->k < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "fc: sizes must be positive");
+    if (q->act != 1 && q->act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "fc: act must be 1 (linear) or 3 (lrelu)");
+    if ((q->m + 31) / 32 > 65535 || q->batch > 65535 || q->batch < 0) return sgv_fail(SGV_ERR_TOO_LARGE, "fc: too many rows / batches");
+    if (q->batch > 1 && (q->a_rowsum || q->normalize_a)) return sgv_fail(SGV_ERR_UNSUPPORTED, "fc: row statistics are not batched");
+    return sgv_fc_launch(q, (hipStream_t)stream_, true);
 }

@@ -213,7 +213,8 @@ class FcParams(ctypes.Structure):
                 ('b', c_void_p), ('b_stride_k', c_int64), ('b_stride_n', c_int64),
                 ('c', c_void_p), ('c_stride_m', c_int64), ('c_stride_n', c_int64), ('bias', c_void_p), ('a_rowsum', c_void_p),
                 ('m', c_int32), ('n', c_int32), ('k', c_int32), ('normalize_a', c_int32), ('act', c_int32), ('alpha', c_float), ('gain', c_float),
-                ('weight_gain', c_float), ('bias_gain', c_float), ('epilogue_act', c_int32)]
+                ('weight_gain', c_float), ('bias_gain', c_float), ('epilogue_act', c_int32),
+                ('batch', c_int32), ('a_stride_batch', c_int64), ('b_stride_batch', c_int64), ('c_stride_batch', c_int64), ('accumulate', c_int32)]
 
 
 class ProfEntry(ctypes.Structure):

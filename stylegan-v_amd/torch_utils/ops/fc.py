@@ -43,7 +43,7 @@ def _launch(a, sam, sak, b, sbk, sbn, c, scm, scn, m, n, k, a_ref=None, bias=Non
     lib = custom_ops.get_native()
     p = custom_ops.FcParams(a.data_ptr(), sam, sak, a_ref.data_ptr() if a_ref is not None else None, b.data_ptr(), sbk, sbn, c.data_ptr(), scm, scn,
                             bias.data_ptr() if bias is not None else None, rowsum.data_ptr() if rowsum is not None else None, m, n, k, int(normalize), act,
-                            alpha, gain, wgain, bgain, int(epilogue_act))
+                            alpha, gain, wgain, bgain, int(epilogue_act), 1, 0, 0, 0, 0)
     with custom_ops.device_guard(c):
         custom_ops.check(lib.sgv_fc(p, custom_ops.raw_stream(c)), lib)
 

@@ -90,7 +90,7 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 12, 32, F32) == 0
     ws_strided = lib.sgv_conv3x3_s2_workspace_bytes(4, 64, 128, 16, 32, 0)
     ws_transposed = lib.sgv_conv3x3_s2_workspace_bytes(4, 64, 128, 16, 32, 2)
-    assert ws_strided == 64 * 128 * 9 * 4
+    assert ws_strided == 64 * 128 * 10 * 4   # ten taps: the tap-pair layout of the strided kernel pads the ninth pair
     assert ws_transposed == ws_strided + 4 * (4 * 64 * (16 + 32) + 2 * 64 * 3 * 128)   # + edge lines + edge weights
     # weight gradients: channels % 64
     assert lib.sgv_conv3x3_wrw_supported(96, 64, 64, 256, 256, F32) == 1

@@ -77,3 +77,23 @@ def test_mapping_network_is_two_launches_and_matches_the_composition():
     finally:
         fc.enabled = True
     assert ws.shape == (32, 14, 512) and _rel(ws, ref) < 1e-5
+
+
+def test_batched_strided_products_with_accumulate():
+    """The batch / accumulate fields of sgv_fc_params (used by the transposed convolution's edge strips): C[b] (+)= A · B[b] through arbitrary strides."""
+    g = torch.Generator().manual_seed(5)
+    batch, m, k, n = 5, 48, 72, 37
+    a = torch.randn(k, m, 3, generator=g).cuda()                    # A(m,k) = a[k][m][1]: stride 3 over m, 3m over k
+    b = torch.randn(batch, k, n, 2, generator=g).cuda()             # B(k,j) = b[bz][k][j][0]
+    c0 = torch.randn(batch, m, n, 2, generator=g).cuda()
+    ref = torch.einsum('km,bkj->bmj', a[:, :, 1].double(), b[..., 0].double())
+    for acc in (0, 1):
+        c = c0.clone()
+        lib = custom_ops.get_native()
+        p = custom_ops.FcParams(a.data_ptr() + 4, 3, 3 * m, None, b.data_ptr(), 2 * n, 2, c.data_ptr() + 4, 2 * n, 2, None, None, m, n, k, 0, 1, 0.0, 1.0, 1.0, 1.0, 0,
+                                batch, 0, k * n * 2, m * n * 2, acc)
+        with custom_ops.device_guard(c):
+            custom_ops.check(lib.sgv_fc(p, custom_ops.raw_stream(c)), lib)
+        want = ref + (c0[..., 1].double() if acc else 0)
+        assert _rel(c[..., 1], want) < 2e-6
+        assert torch.equal(c[..., 0], c0[..., 0])                   # the interleaved elements are not touched

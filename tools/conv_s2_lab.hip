@@ -5,6 +5,7 @@
 #include <math.h>
 #include <vector>
 #include "conv3x3s2_kernel.h"
+#include "conv3x3s2_ws_kernel.h"
 
 using namespace sgv_conv;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -37,6 +38,10 @@ __global__ void naive_t(const float* x, const float* w, double* y, int n, int k,
     y[idx] = s;
 }
 
+static int g_abl = 0;
+static int g_order = 0;
+static int g_ws = 0;   // 1: the producer / consumer forms (conv3x3s2_ws_kernel.h)
+
 template <int TERMS> static void launch(int kind, const float* x, const float* w, float* y, u32x4* wprep, int n, int k, int m, int h, int wd, int grid) {
     const int total = (m / TM) * (k / KC) * 9 * 2 * TM;
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3((total + 255) / 256), dim3(256), 0, 0, w, wprep, m, k, kind == 0 ? 0 : 2, TERMS);
@@ -50,7 +55,40 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
         CK(hipFuncSetAttribute((const void*)conv3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES));
         CK(hipFuncSetAttribute((const void*)convT3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES));
         CK(hipFuncSetAttribute((const void*)convT3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES));
+#define SGV_ATTR(A) CK(hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<1, A>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<3, A>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES));
+#define SGV_ATTR2(A) CK(hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, A>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3, A>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES));
+        SGV_ATTR2(0) SGV_ATTR2(6) SGV_ATTR2(7)
+        SGV_ATTR(0) SGV_ATTR(1) SGV_ATTR(2) SGV_ATTR(3) SGV_ATTR(4) SGV_ATTR(5) SGV_ATTR(6) SGV_ATTR(7)
         attr = true;
+    }
+    if (kind == 0 && g_ws == 2) {
+        const int words = (m / P2_TM) * (k / P2_KC) * 10 * P2_TM;
+        hipLaunchKernelGGL(conv3x3_prep_weights_pairs, dim3((words + 255) / 256), dim3(256), 0, 0, w, wprep, m, k, TERMS);
+        p.tiles = n * (h / P2_ROWS) * (wd / SEG) * (m / P2_TM);
+        p.grid = grid < p.tiles ? grid : p.tiles;
+        switch (g_abl) {
+            case 0: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 0>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p); break;
+            case 6: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 6>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p); break;
+            case 7: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 7>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p); break;
+        }
+        return;
+    }
+    if (kind == 0 && g_ws) {
+        p.tiles = n * (h / S2W_ROWS) * (wd / SEG) * (m / TM);
+        p.order = g_order;
+        const int units = g_order ? p.tiles / (m / TM) : p.tiles;
+        p.grid = grid < units ? grid : units;
+        switch (g_abl) {
+            case 0: hipLaunchKernelGGL((conv3x3_s2_ws_kernel<TERMS, 0>), dim3(p.grid), dim3(512), S2W_LDS_BYTES, 0, p); break;
+            case 1: hipLaunchKernelGGL((conv3x3_s2_ws_kernel<TERMS, 1>), dim3(p.grid), dim3(512), S2W_LDS_BYTES, 0, p); break;
+            case 2: hipLaunchKernelGGL((conv3x3_s2_ws_kernel<TERMS, 2>), dim3(p.grid), dim3(512), S2W_LDS_BYTES, 0, p); break;
+            case 3: hipLaunchKernelGGL((conv3x3_s2_ws_kernel<TERMS, 3>), dim3(p.grid), dim3(512), S2W_LDS_BYTES, 0, p); break;
+            case 4: hipLaunchKernelGGL((conv3x3_s2_ws_kernel<TERMS, 4>), dim3(p.grid), dim3(512), S2W_LDS_BYTES, 0, p); break;
+            case 5: hipLaunchKernelGGL((conv3x3_s2_ws_kernel<TERMS, 5>), dim3(p.grid), dim3(512), S2W_LDS_BYTES, 0, p); break;
+            case 6: hipLaunchKernelGGL((conv3x3_s2_ws_kernel<TERMS, 6>), dim3(p.grid), dim3(512), S2W_LDS_BYTES, 0, p); break;
+            case 7: hipLaunchKernelGGL((conv3x3_s2_ws_kernel<TERMS, 7>), dim3(p.grid), dim3(512), S2W_LDS_BYTES, 0, p); break;
+        }
+        return;
     }
     if (kind == 0) hipLaunchKernelGGL(conv3x3_s2_kernel<TERMS>, dim3(p.grid), dim3(256), S_LDS_BYTES, 0, p);
     else {
@@ -67,12 +105,19 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
 
 int main(int argc, char** argv) {
     const int reps = argc > 1 ? atoi(argv[1]) : 5;
+    g_ws = argc > 2 ? atoi(argv[2]) : 0;
+    g_abl = argc > 3 ? atoi(argv[3]) : 0;
+    const int only_kind = argc > 4 ? atoi(argv[4]) : -1;
+    g_order = argc > 5 ? atoi(argv[5]) : 0;
+    printf("order %d\n", g_order);
+    if (g_abl) printf("ABLATION %d: results are wrong by construction\n", g_abl);
+    printf("variant: %s\n", g_ws == 2 ? "producer / consumer, tap pairs, 8 rows x 128 m" : g_ws ? "producer / consumer (ws)" : "one role per wave");
     for (int kind = 0; kind < 2; kind++) {
         const int n = 2, k = 32, m = 128, h = 16, wd = 64;
         const int hb = 2 * h + 1, wb = 2 * wd + 1;
         const size_t nx = kind == 0 ? (size_t)n * k * hb * wb : (size_t)n * k * h * wd, ny = kind == 0 ? (size_t)n * m * h * wd : (size_t)n * m * hb * wb, nw = (size_t)m * k * 9;
         float *x, *w, *y; double* ref; u32x4* wprep;
-        CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&y, ny * 4)); CK(hipMalloc(&ref, ny * 8)); CK(hipMalloc(&wprep, nw * 4));
+        CK(hipMalloc(&x, nx * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&y, ny * 4)); CK(hipMalloc(&ref, ny * 8)); CK(hipMalloc(&wprep, nw * 4 / 9 * 10 + 1024));
         fill<<<(nx + 255) / 256, 256>>>(x, nx, 11u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 23u, 0.1f);
         if (kind == 0) naive_s<<<(ny + 255) / 256, 256>>>(x, w, ref, n, k, m, h, wd); else naive_t<<<(ny + 255) / 256, 256>>>(x, w, ref, n, k, m, h, wd);
         std::vector<double> r(ny); std::vector<float> gpu(ny);
@@ -95,10 +140,11 @@ int main(int argc, char** argv) {
         const int hb = 2 * s.r + 1;
         const size_t nbig = (size_t)s.n * s.cb * hb * hb, nsmall = (size_t)s.n * s.cs * s.r * s.r, nw = (size_t)s.cb * s.cs * 9;
         float *big, *small, *w; u32x4* wprep;
-        CK(hipMalloc(&big, nbig * 4)); CK(hipMalloc(&small, nsmall * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4));
+        CK(hipMalloc(&big, nbig * 4)); CK(hipMalloc(&small, nsmall * 4)); CK(hipMalloc(&w, nw * 4)); CK(hipMalloc(&wprep, nw * 4 / 9 * 10 + 1024));
         fill<<<(nbig + 255) / 256, 256>>>(big, nbig, 5u, 1.f); fill<<<(nsmall + 255) / 256, 256>>>(small, nsmall, 6u, 1.f); fill<<<(nw + 255) / 256, 256>>>(w, nw, 7u, 0.1f);
         const double flops = 2.0 * s.n * s.r * s.r * (double)s.cb * s.cs * 9;
         for (int kind = 0; kind < 2; kind++) for (int terms = 1; terms <= 3; terms += 2) {
+            if (only_kind >= 0 && kind != only_kind) continue;
             // D direction: strided big(cb) -> small(cs); its data gradient: transposed small(cs) -> big(cb)
             const float* x = kind == 0 ? big : small; float* y = kind == 0 ? small : big;
             const int k = kind == 0 ? s.cb : s.cs, m = kind == 0 ? s.cs : s.cb;
