@@ -125,6 +125,7 @@ def main():
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline leg; 0 disables it')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
     ap.add_argument('--ada-steps', type=int, default=8, help="steps of the aug=ada companion measurement (the reference's default augmentation, bgc pipeline); 0 disables it")
+    ap.add_argument('--bf16-steps', type=int, default=6, help='steps of the bf16-products companion measurement (fp32 tensors, one bf16 MFMA per product); 0 disables it')
     ap.add_argument('--strict-steps', type=int, default=8, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
     ap.add_argument('--aug', choices=['noaug', 'ada'], default='noaug', help="discriminator augmentation: the reference's default is ada (bgc pipeline, adaptive p)")
     ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs (single GPU; pays off at small per-GPU batches)')
@@ -247,6 +248,29 @@ def main():
         finally:
             conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms = default_terms
 
+    # bf16-products companion (BASELINE config 4 says "bf16 compute"): the same step, fp32 tensors and fp32 accumulation, but ONE bf16 MFMA per
+    # product in the 3x3 family (terms = 1: operands rounded to bf16, rel-L2 2e-3 per convolution) instead of the three of the split.
+    bf16c = None
+    if args.bf16_steps > 0 and lowp is None and default_terms == (3, 3):
+        conv2d_gradfix.native_conv_terms = conv2d_gradfix.native_wrw_terms = 1
+        try:
+            ts.batch_idx = 0
+            ts.step(); ts.step()
+            ts.batch_idx = 0
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.bf16_steps):
+                ts.step()
+            barrier()
+            t_s = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            if world > 1:
+                torch.distributed.all_reduce(t_s, op=torch.distributed.ReduceOp.MAX)
+            bf16c = dict(value=global_batch * args.frames * args.bf16_steps / float(t_s.item()), ms_per_step=1e3 * float(t_s.item()) / args.bf16_steps, steps=args.bf16_steps,
+                         what='same step, SGV_CONV_TERMS=1 SGV_WRW_TERMS=1: fp32 tensors, bf16-rounded operands (one MFMA per product), fp32 accumulate; '
+                              'outside the 1e-3 fp32 parity bar (2e-3 rel-L2 per 3x3 convolution), reported as the bf16-compute reading of BASELINE config 4')
+        finally:
+            conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms = default_terms
+
     # aug=ada companion: the reference's default discriminator augmentation (bgc pipeline: reflect-pad -> 2x up -> affine resample -> 2x down +
     # colour matrix on every D input, adaptive p) on the same models; same bracket, schedule restarted at iteration 0.
     ada = None
@@ -331,7 +355,7 @@ def main():
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
                                native_launches_per_step=launches / args.steps, hip_graphs=bool(ts.use_graphs)),
-                   value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada,
+                   value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c,
                    roofline=roofline, roofline_upfirdn2d=roofline_ufd, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -64,6 +64,8 @@ void init_once() {
     g_s2_ws = !(env && env[0] == '0');
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     g_attr_err = e;
@@ -229,8 +231,15 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
         else hipLaunchKernelGGL(conv3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(256), S_LDS_BYTES, stream, kp);
         return sgv_check_launch("conv3x3_s2_kernel");
     }
-    if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
-    else hipLaunchKernelGGL(convT3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
+    if (g_s2_ws) {
+        kp.tiles = p->n * (p->h / TW_ROWS) * (p->w / SEG) * (p->c_out / TM);
+        kp.grid = std::min(kp.tiles, g_cus);
+        if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_ws_kernel<1>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
+        else hipLaunchKernelGGL(convT3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
+    } else {
+        if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
+        else hipLaunchKernelGGL(convT3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
+    }
     rc = sgv_check_launch("convT3x3_s2_kernel");
     if (rc != SGV_OK) return rc;
     if (!g_edge_fc || p->n > 65535) {

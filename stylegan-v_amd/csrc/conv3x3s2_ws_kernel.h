@@ -522,4 +522,239 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// convT3x3_s2_ws_kernel: producer / consumer form of convT3x3_s2_kernel (conv3x3s2_kernel.h; same arithmetic, same prepared weights).
+//
+//   y[n,m,2Y+ky,2X+kx] += wgt(m,k,ky,kx) * x[n,k,Y,X]           x: HxW -> y: (2H+1)x(2W+1); the last row / column are left to the caller
+//
+// Reference: the `conv_transpose2d(stride=2)` in front of the FIR of the up-sampling path (conv2d_resample.py:128-137) and the data gradient of
+// the down-sampling path's strided convolution (conv2d_gradfix.py:100-118).
+//
+// Tile 4 input rows x 32 input px x 64 m; 7 waves:
+//   waves 0-3 (consumers): one input row each, the four output parity classes x 64 m = 8 accumulator tiles; per tap 6 MFMAs into the tap's
+//                          class, operands fetched two taps ahead (three register buffers);
+//   waves 4-5 (x producers): 90 units per chunk (80 items of 8 channels x 4 px + 10 left-halo pixels), one per thread, aligned 16-byte loads;
+//   wave 6 (weight DMA).
+// The x tile is small here (10 KiB), so LDS holds THREE images of 46.3 KiB: chunk q+2 is filled while chunk q is consumed, a fill has a whole
+// extra iteration to land (the DMA wave waits for the previous iteration's 36 pieces, not the ones just issued), and one barrier per chunk
+// still orders everything (image (q+2) % 3 was last read in iteration q-1).
+constexpr int TW_ROWS = 4;
+constexpr int TW_RIN = TW_ROWS + 1;                      // rows y0-1 .. y0+3
+constexpr int TW_PW = 33;                                // columns x0-1 .. x0+31
+constexpr int TW_XS_PLANE = TW_RIN * TW_PW;              // words per (hl, octet)
+constexpr int TW_XS_WORDS = 4 * TW_XS_PLANE;
+constexpr int TW_IMAGE_WORDS = TW_XS_WORDS + WS_WORDS;
+constexpr int TW_IMAGES = 3;
+constexpr int TW_LDS_BYTES = TW_IMAGES * TW_IMAGE_WORDS * 16;
+
+// ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
+template <int TERMS, int ABL = 0>
+__global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int chunks = p.k / KC;
+    const int wout = 2 * p.w + 1;
+    const size_t plane_in = (size_t)p.h * p.w, plane_out = (size_t)(2 * p.h + 1) * wout;
+
+    const int first = xcd_swizzle(blockIdx.x, gridDim.x);
+    if (first >= p.tiles) return;
+    const int my_tiles = (p.tiles - first + p.grid - 1) / p.grid;
+    const int total = my_tiles * chunks;
+    auto tile_of = [&](int q) { return first + (q / chunks) * p.grid; };
+    auto image = [&](int q) { return lds + (q % TW_IMAGES) * TW_IMAGE_WORDS; };
+
+    if (wave == 6) {
+        // =========================================== weight DMA wave ===========================================
+        auto dma_w = [&](int q) {
+            const tile_pos tp = decode_tile_s2(p, tile_of(q), TW_ROWS);
+            const u32x4* wq = p.wprep + ((size_t)tp.mt * chunks + (q % chunks)) * WS_WORDS + lane;
+            u32x4* wl = image(q) + TW_XS_WORDS;
+#pragma unroll
+            for (int j = 0; j < 36; j++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wq + j * 64),
+                                                 (__attribute__((address_space(3))) void*)(wl + j * 64), 16, 0, 0);
+        };
+        if (ABL != 7) { dma_w(0); if (total > 1) dma_w(1); }
+        if (total > 1 && ABL != 7) asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // image 0 ready
+        for (int q = 0; q < total; q++) {
+            const bool more = q + 2 < total && ABL != 7;
+            if (more) dma_w(q + 2);
+            // chunk q+1 (issued one iteration ago) must have landed before this barrier; the 36 pieces just issued may stay in flight
+            if (more) asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        return;
+    }
+    if (wave >= 4) {
+        // =========================================== x waves (4, 5) ===========================================
+        const int u = t - 256;                                   // 0..127; units 0..79 items (octet, row, quad), 80..89 halo (octet, row)
+        const int kind = u < 16 * TW_RIN ? 0 : (u < 18 * TW_RIN ? 1 : 2);
+        const int oct = u & 1;
+        const int a_quad = (u >> 1) & 7, a_row = kind == 0 ? u >> 4 : kind == 1 ? (u - 16 * TW_RIN) >> 1 : 0;
+        struct xset { f32x4 a[8]; bool ok; };
+
+        auto load_x = [&](int q, xset& r) {
+            const tile_pos tp = decode_tile_s2(p, tile_of(q), TW_ROWS);
+            const int c = q % chunks;
+            const float* xb_ = p.x + ((size_t)tp.n * p.k + c * KC + 8 * oct) * plane_in;
+            const int gy = tp.y0 - 1 + a_row;
+            const int gx = kind == 0 ? tp.x0 + 4 * a_quad : tp.x0 - 4;      // the halo pixel x0-1 is the last element of the group before the tile
+            r.ok = kind != 2 && gy >= 0 && gx >= 0;
+            const float* q0 = xb_ + (size_t)max(gy, 0) * p.w + max(gx, 0);
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * plane_in) : "memory");
+        };
+        auto arrive = [&](xset& r, bool newer) {
+            if (newer) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < 8; j++) asm volatile("" : "+v"(r.a[j]));
+        };
+        auto put = [&](u32x4* xs, int pos, float* v, bool ok) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) v[j] = ok ? v[j] : 0.f;
+            u32x4 hi, lo;
+            split8(v, hi, lo);
+            xs[pos] = hi;
+            if (TERMS > 1) xs[2 * TW_XS_PLANE + pos] = lo;
+        };
+        auto store_x = [&](u32x4* xs, const xset& r) {
+            if (kind == 0) {
+                const int base = (oct * TW_RIN + a_row) * TW_PW + 1 + 4 * a_quad;
+#pragma unroll
+                for (int px = 0; px < 4; px++) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) v[j] = r.a[j][px];
+                    put(xs, base + px, v, r.ok);
+                }
+            } else if (kind == 1) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) v[j] = r.a[j][3];
+                put(xs, (oct * TW_RIN + a_row) * TW_PW, v, r.ok);
+            }
+        };
+        // iteration q: start the loads of chunk q+3, write chunk q+2 (loaded an iteration ago) into image (q+2) % 3
+        auto step = [&](int q, xset& ld, xset& st) {
+            const bool more = q + 3 < total && ABL != 7;
+            if (more) load_x(q + 3, ld);
+            if (q + 2 < total) {
+                arrive(st, more);
+                if (ABL != 7) store_x(image(q + 2), st);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        };
+
+        xset s0, s1;
+        load_x(0, s0);
+        if (total > 1) load_x(1, s1);
+        arrive(s0, total > 1);
+        store_x(image(0), s0);
+        if (total > 2 && ABL != 7) load_x(2, s0);
+        if (total > 1) { arrive(s1, total > 2 && ABL != 7); store_x(image(1), s1); }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();   // images 0 and 1 ready
+        // chunk q+2 sits in s0 for even q, s1 for odd q
+        for (int q = 0; q < total; q += 2) {
+            step(q, s1, s0);
+            if (q + 1 < total) step(q + 1, s0, s1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+
+    // =========================================== consumers ===========================================
+    f32x16 acc[4][2];   // [class a*2+b][m half]
+#pragma unroll
+    for (int cl = 0; cl < 4; cl++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[cl][hf][e] = 0.f;
+
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_barrier();   // images 0 and 1 ready
+    asm volatile("" ::: "memory");
+    for (int q = 0; q < total; q++) {
+        const u32x4* xs = image(q);
+        const u32x4* ws = xs + TW_XS_WORDS;
+        const int c = q % chunks;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int a_lane = (ln >> 5) * TM + (ln & 31);
+        const int b_lane = ((ln >> 5) * TW_RIN + wave + 1) * TW_PW + (ln & 31) + 1;      // - dy * PW - dx
+
+        if (ABL != 6) {
+        u32x4 a[3][2][2];    // [buffer][half][hl]
+        u32x4 b[3][2];       // [buffer][hl]
+        auto fetch = [&](int buf, int tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int pos = b_lane - (ky == 2 ? TW_PW : 0) - (kx == 2 ? 1 : 0);   // tap 2 reaches back to the previous input row / column
+            b[buf][0] = xs[pos];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++)
+                if (TERMS > 1) a[buf][hf][1] = ws[a_lane + ((1 * 9 + tap) * 2) * TM + hf * 32];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) a[buf][hf][0] = ws[a_lane + ((0 * 9 + tap) * 2) * TM + hf * 32];
+            if (TERMS > 1) b[buf][1] = xs[2 * TW_XS_PLANE + pos];
+        };
+        constexpr int RD = TERMS > 1 ? 6 : 3;
+        fetch(0, 0);
+        fetch(1, 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int cl = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+            const int bb = tap % 3;
+            if (tap + 2 < 9) fetch((tap + 2) % 3, tap + 2);
+            if (TERMS > 1) {
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0>(a[bb][hf][1], b[bb][0], acc[cl][hf]);
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0>(a[bb][hf][0], b[bb][1], acc[cl][hf]);
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0>(a[bb][hf][0], b[bb][0], acc[cl][hf]);
+            constexpr int MF = TERMS > 1 ? 6 : 2;
+            const int reads = tap + 2 < 9 ? RD : 0;
+#pragma unroll
+            for (int i = 0; i < MF; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (TERMS == 1 && i == 0 && reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        }
+
+        if (c == chunks - 1) {
+            const tile_pos tp = decode_tile_s2(p, tile_of(q), TW_ROWS);
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int g = le >> 5;
+            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane_out + (size_t)(2 * (tp.y0 + wave)) * wout + 2 * (tp.x0 + (le & 31));
+#pragma unroll
+            for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
+                        float* qd = yb + (size_t)m * plane_out + (size_t)a2 * wout;
+                        qd[0] = acc[a2 * 2 + 0][hf][e];
+                        qd[1] = acc[a2 * 2 + 1][hf][e];
+                        acc[a2 * 2 + 0][hf][e] = 0.f;
+                        acc[a2 * 2 + 1][hf][e] = 0.f;
+                    }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
 }  // namespace sgv_conv

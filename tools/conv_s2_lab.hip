@@ -57,6 +57,8 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
         CK(hipFuncSetAttribute((const void*)convT3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES));
 #define SGV_ATTR(A) CK(hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<1, A>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<3, A>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES));
 #define SGV_ATTR2(A) CK(hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, A>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3, A>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES));
+#define SGV_ATTR3(A) CK(hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1, A>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<3, A>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
+        SGV_ATTR3(0) SGV_ATTR3(6) SGV_ATTR3(7)
         SGV_ATTR2(0) SGV_ATTR2(6) SGV_ATTR2(7)
         SGV_ATTR(0) SGV_ATTR(1) SGV_ATTR(2) SGV_ATTR(3) SGV_ATTR(4) SGV_ATTR(5) SGV_ATTR(6) SGV_ATTR(7)
         attr = true;
@@ -90,9 +92,18 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
         }
         return;
     }
+    if (kind == 1 && g_ws) {
+        p.tiles = n * (h / TW_ROWS) * (wd / SEG) * (m / TM);
+        p.grid = grid < p.tiles ? grid : p.tiles;
+        switch (g_abl) {
+            case 6: hipLaunchKernelGGL((convT3x3_s2_ws_kernel<TERMS, 6>), dim3(p.grid), dim3(448), TW_LDS_BYTES, 0, p); break;
+            case 7: hipLaunchKernelGGL((convT3x3_s2_ws_kernel<TERMS, 7>), dim3(p.grid), dim3(448), TW_LDS_BYTES, 0, p); break;
+            default: hipLaunchKernelGGL((convT3x3_s2_ws_kernel<TERMS, 0>), dim3(p.grid), dim3(448), TW_LDS_BYTES, 0, p); break;
+        }
+    }
     if (kind == 0) hipLaunchKernelGGL(conv3x3_s2_kernel<TERMS>, dim3(p.grid), dim3(256), S_LDS_BYTES, 0, p);
     else {
-        hipLaunchKernelGGL(convT3x3_s2_kernel<TERMS>, dim3(p.grid), dim3(512), T_LDS_BYTES, 0, p);
+        if (!g_ws) hipLaunchKernelGGL(convT3x3_s2_kernel<TERMS>, dim3(p.grid), dim3(512), T_LDS_BYTES, 0, p);
         static float* edge = nullptr; static size_t edge_cap = 0;
         const size_t need = convT3x3_s2_edge_floats(n, k, m, h, wd);
         if (need > edge_cap) { if (edge) CK(hipFree(edge)); CK(hipMalloc(&edge, need * 4)); edge_cap = need; }
