@@ -32,7 +32,7 @@ bool supported(int n, int k, int m, int h, int w, int dtype) {
 std::once_flag g_attr_once;
 int g_cus = 256;
 hipError_t g_attr_err = hipSuccess;
-bool g_edge_fc = true;  // SGV_CONVT_EDGE_FC=0: the gather + FMA edge kernels instead of the strided fc products
+bool g_edge_mfma = true;   // SGV_CONVT_EDGE_MFMA=0: the gather + FMA edge kernels instead of convT3x3_s2_edge_mfma
 bool g_s2_ws = true;    // SGV_S2_WS=0: the one-role-per-wave stride-2 kernels of conv3x3s2_kernel.h
 bool g_use_ws = true;   // SGV_CONV_WS=0: the 4-wave kernel of conv3x3_kernel.h instead of the producer / consumer form
 
@@ -69,8 +69,8 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     g_attr_err = e;
-    env = getenv("SGV_CONVT_EDGE_FC");
-    g_edge_fc = !(env && env[0] == '0');
+    env = getenv("SGV_CONVT_EDGE_MFMA");
+    g_edge_mfma = !(env && env[0] == '0');
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
@@ -242,7 +242,7 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
     }
     rc = sgv_check_launch("convT3x3_s2_kernel");
     if (rc != SGV_OK) return rc;
-    if (!g_edge_fc || p->n > 65535) {
+    if (!g_edge_mfma) {
         float* edge = (float*)((char*)p->workspace + (size_t)p->c_in * p->c_out * 9 * 4);
         const size_t edge_floats = convT3x3_s2_edge_floats(p->n, p->c_in, p->c_out, p->h, p->w);
         hipLaunchKernelGGL(convT3x3_s2_edge_gather, dim3((unsigned)((edge_floats + 255) / 256)), dim3(256), 0, stream, (const float*)p->x, p->weight, edge, p->n, p->c_in, p->c_out,
@@ -252,34 +252,8 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
                            p->c_in, p->c_out, p->h, p->w);
         return sgv_check_launch("convT3x3_s2_edge_kernel");
     }
-    // Last output column (ox = 2W: tap kx = 2 of input column W-1) and last output row (oy = 2H: tap ky = 2 of input row H-1):
-    // per sample, seven [c_out x c_in] x [c_in x line] products of one weight tap with one input line, read and written in place
-    // through strides (0.4 % of the flops; fp32 MFMA, fc.hip).
-    {
-        const int H = p->h, W = p->w, K = p->c_in, M = p->c_out, Ho = 2 * H + 1, Wo = 2 * W + 1;
-        const int64_t HW = (int64_t)H * W, P = (int64_t)Ho * Wo;
-        const float* x = (const float*)p->x; const float* w = p->weight; float* y = (float*)p->y;
-        struct strip { int tap; int64_t b_off, b_sn; int cols; int64_t c_off, c_sn; int acc; };
-        const strip strips[7] = {
-            {0 * 3 + 2, W - 1, W, H, 2 * W, 2 * Wo, 0},                               // column, even rows 2Y   <- ky = 0 of row Y
-            {2 * 3 + 2, W - 1, W, H - 1, 2 * Wo + 2 * W, 2 * Wo, 1},                  //         even rows 2Y+2 <- ky = 2 of row Y (Y < H-1)
-            {1 * 3 + 2, W - 1, W, H, Wo + 2 * W, 2 * Wo, 0},                          //         odd rows 2Y+1  <- ky = 1
-            {2 * 3 + 0, (int64_t)(H - 1) * W, 1, W, (int64_t)2 * H * Wo, 2, 0},       // row, even columns 2X   <- kx = 0 of column X
-            {2 * 3 + 2, (int64_t)(H - 1) * W, 1, W - 1, (int64_t)2 * H * Wo + 2, 2, 1},   //   even columns 2X+2 <- kx = 2 of column X (X < W-1)
-            {2 * 3 + 1, (int64_t)(H - 1) * W, 1, W, (int64_t)2 * H * Wo + 1, 2, 0},   //      odd columns 2X+1  <- kx = 1
-            {2 * 3 + 2, HW - 1, 1, 1, P - 1, 1, 0},                                    // corner
-        };
-        for (const strip& s : strips) {
-            if (s.cols < 1) continue;
-            sgv_fc_params q{};
-            q.a = w + s.tap; q.a_stride_m = 9; q.a_stride_k = (int64_t)9 * M; q.a_stride_batch = 0;
-            q.b = x + s.b_off; q.b_stride_k = HW; q.b_stride_n = s.b_sn; q.b_stride_batch = (int64_t)K * HW;
-            q.c = y + s.c_off; q.c_stride_m = P; q.c_stride_n = s.c_sn; q.c_stride_batch = (int64_t)M * P;
-            q.m = M; q.n = s.cols; q.k = K; q.batch = p->n; q.accumulate = s.acc;
-            q.act = 1; q.alpha = 0.f; q.gain = 1.f; q.weight_gain = 1.f; q.bias_gain = 1.f;
-            rc = sgv_fc_launch(&q, stream, false);
-            if (rc != SGV_OK) return rc;
-        }
-    }
-    return SGV_OK;
+    // last output row (oy = 2H) and column (ox = 2W): 0.4 % of the flops, one launch on the fp32 matrix pipe, x and w read in place
+    hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2), dim3(64), 0, stream, (const float*)p->x,
+                       p->weight, (float*)p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+    return sgv_check_launch("convT3x3_s2_edge_mfma");
 }

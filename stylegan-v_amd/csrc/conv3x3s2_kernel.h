@@ -431,4 +431,72 @@ __global__ __launch_bounds__(128) void convT3x3_s2_edge_kernel(const float* edge
     for (int j = 0; j < EDGE_MC; j++) yb[(size_t)j * hout * wout] = accv[j];
 }
 
+// convT3x3_s2_edge_mfma: both strips in one launch on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; plain fp32 products), reading x and w in place.
+// A wave owns 32 output channels x 32 source positions i of one (sample, strip) and keeps two accumulator tiles:
+//   even outputs  2i   = sum_k wt[0](m,k) * src(k,i) + wt[2](m,k) * src(k,i-1)
+//   odd outputs   2i+1 = sum_k wt[1](m,k) * src(k,i)
+// with (row strip, oy = 2H) src(k,i) = x[n,k,H-1,i], wt[t] = w[k][m][2][t] and (column strip, ox = 2W, without the corner) src(k,i) = x[n,k,i,W-1],
+// wt[t] = w[k][m][t][2].  MFMA operands are one float per lane: A lane (m = lane & 31, k = k0 + (lane >> 5)), B lane (i = lane & 31, same k).
+// grid = (ceil((max(H, W) + 1) / 32), n * (m / 32), 2 strips), 64 threads.
+typedef float f32x16e __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, const float* w, float* y, int n, int k, int m, int h, int wd) {
+    const int strip = blockIdx.z;
+    const int ls = strip == 0 ? wd : h;               // source line length
+    const int lo = strip == 0 ? 2 * wd + 1 : 2 * h;   // outputs of the strip
+    const int i0 = blockIdx.x * 32;
+    if (2 * i0 >= lo) return;
+    const int mts = m / 32;
+    const int nn = blockIdx.y / mts, m0 = (blockIdx.y % mts) * 32;
+    const int lane = threadIdx.x, l32 = lane & 31, g = lane >> 5;
+    const int i = i0 + l32;
+    const bool vb = i < ls, vm = i >= 1 && i - 1 < ls;
+    const size_t plane = (size_t)h * wd;
+    // src(k, i) = xs[k * plane + i * sstep]
+    const float* xs = x + (size_t)nn * k * plane + (strip == 0 ? (size_t)(h - 1) * wd : (size_t)(wd - 1));
+    const size_t sstep = strip == 0 ? 1 : wd;
+    const float* pb = xs + (size_t)(vb ? i : 0) * sstep + (size_t)g * plane;
+    const float* pm = xs + (size_t)(vm ? i - 1 : 0) * sstep + (size_t)g * plane;
+    // wt[t](m, k) = w[(k * M + m) * 9 + off_t]
+    const int o0 = strip == 0 ? 6 : 2, ostep = strip == 0 ? 1 : 3;
+    const float* pw = w + ((size_t)g * m + m0 + l32) * 9 + o0;
+    const size_t wk = (size_t)2 * m * 9, xk = 2 * plane;
+
+    f32x16e acc_e, acc_o;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { acc_e[e] = 0.f; acc_o[e] = 0.f; }
+    constexpr int U = 4;   // k pairs in flight
+    for (int k0 = 0; k0 < k; k0 += 2 * U) {
+        float a0[U], a1[U], a2[U], b[U], bm[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const bool ok = k0 + 2 * u < k;   // k is even; the tail of a k that is not a multiple of 8 is skipped
+            a0[u] = ok ? pw[u * wk] : 0.f;
+            a1[u] = ok ? pw[u * wk + ostep] : 0.f;
+            a2[u] = ok ? pw[u * wk + 2 * ostep] : 0.f;
+            b[u] = ok && vb ? pb[u * xk] : 0.f;
+            bm[u] = ok && vm ? pm[u * xk] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            acc_e = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b[u], acc_e, 0, 0, 0);
+            acc_o = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b[u], acc_o, 0, 0, 0);
+            acc_e = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[u], bm[u], acc_e, 0, 0, 0);
+        }
+        pw += U * wk; pb += U * xk; pm += U * xk;
+    }
+    const int hout = 2 * h + 1, wout = 2 * wd + 1;
+    const int pe = 2 * i, po = 2 * i + 1;
+    // element at position `pos` of the strip: row strip y[.., 2H, pos], column strip y[.., pos, 2W]
+    float* yb = y + ((size_t)nn * m + m0) * hout * wout + (strip == 0 ? (size_t)(hout - 1) * wout : (size_t)(wout - 1));
+    const size_t ystep = strip == 0 ? 1 : wout;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int mm = (e & 3) + 8 * (e >> 2) + 4 * g;
+        float* q = yb + (size_t)mm * hout * wout;
+        if (pe < lo) q[(size_t)pe * ystep] = acc_e[e];
+        if (po < lo) q[(size_t)po * ystep] = acc_o[e];
+    }
+}
+
 }  // namespace sgv_conv

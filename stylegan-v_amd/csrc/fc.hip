@@ -140,8 +140,7 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
 
 }  // namespace sgv_fck
 
-// shared with conv3x3.hip (the transposed convolution's last output row / column are six small batched products)
-int sgv_fc_launch(const sgv_fc_params* q, hipStream_t stream, bool account) {
+static int sgv_fc_launch(const sgv_fc_params* q, hipStream_t stream, bool account) {
     const int batch = q->batch > 0 ? q->batch : 1;
     sgv_fck::fc_params p{};
     p.a = q->a; p.sam = q->a_stride_m; p.sak = q->a_stride_k; p.aref = q->a_ref;

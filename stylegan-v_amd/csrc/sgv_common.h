@@ -78,6 +78,3 @@ static inline int sgv_check_launch(const char* what) {
     if (e != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "%s: %s", what, hipGetErrorString(e));
     return SGV_OK;
 }
-
-// csrc/fc.hip: the small-M dense kernel, also used by conv3x3.hip for the transposed convolution's edge strips (no argument checks)
-int sgv_fc_launch(const sgv_fc_params* q, hipStream_t stream, bool account);

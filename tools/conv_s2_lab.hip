@@ -104,10 +104,14 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
     if (kind == 0) hipLaunchKernelGGL(conv3x3_s2_kernel<TERMS>, dim3(p.grid), dim3(256), S_LDS_BYTES, 0, p);
     else {
         if (!g_ws) hipLaunchKernelGGL(convT3x3_s2_kernel<TERMS>, dim3(p.grid), dim3(512), T_LDS_BYTES, 0, p);
+        if (getenv("NO_EDGE")) return;
+        if (g_ws) {
+            hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3(((h > wd ? h : wd) + 1 + 31) / 32, n * (m / 32), 2), dim3(64), 0, 0, x, w, y, n, k, m, h, wd);
+            return;
+        }
         static float* edge = nullptr; static size_t edge_cap = 0;
         const size_t need = convT3x3_s2_edge_floats(n, k, m, h, wd);
         if (need > edge_cap) { if (edge) CK(hipFree(edge)); CK(hipMalloc(&edge, need * 4)); edge_cap = need; }
-        if (getenv("NO_EDGE")) return;
         hipLaunchKernelGGL(convT3x3_s2_edge_gather, dim3((need + 255) / 256), dim3(256), 0, 0, x, w, edge, n, k, m, h, wd);
         const int lmax = 2 * wd + 1 > 2 * h ? 2 * wd + 1 : 2 * h;
         hipLaunchKernelGGL(convT3x3_s2_edge_kernel, dim3((lmax + 127) / 128, n * (m / EDGE_MC), 2), dim3(128), 0, 0, edge, y, n, k, m, h, wd);
