@@ -192,6 +192,16 @@ def main():
     launches0 = custom_ops.launch_count()
     if args.graphs:
         args.no_prof = True   # a replayed graph launches nothing from the host: there are no per-launch events to record
+    if os.environ.get('SGV_TORCH_PROFILE'):
+        # developer aid: aten-level table of two steps with input shapes (who issues the element-wise kernels), to the given file
+        import torch.profiler as tprof
+        with tprof.profile(activities=[tprof.ProfilerActivity.CPU, tprof.ProfilerActivity.CUDA], record_shapes=True) as prof_t:
+            ts.step(); ts.step()
+            torch.cuda.synchronize()
+        if rank == 0:
+            with open(os.environ['SGV_TORCH_PROFILE'], 'w') as fh:
+                fh.write(prof_t.key_averages(group_by_input_shape=True).table(sort_by='cuda_time_total', row_limit=120, max_name_column_width=60, max_shapes_column_width=90))
+        ts.batch_idx = 0
     if not args.no_prof:
         custom_ops.prof_enable(1 << 17)
     barrier()

@@ -68,6 +68,8 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     g_attr_err = e;
     env = getenv("SGV_CONVT_EDGE_MFMA");
     g_edge_mfma = !(env && env[0] == '0');
@@ -176,7 +178,11 @@ extern "C" int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32
     return bytes;
 }
 
-extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream_) {
+namespace {
+
+bool pairs_shape(int c_out, int h) { return g_s2_ws && c_out % P2_TM == 0 && h % P2_ROWS == 0; }
+
+int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* ep, int dtype, void* stream_) {
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: params is NULL");
     if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: NULL pointer");
     if (!supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
@@ -190,7 +196,13 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
     hipStream_t stream = (hipStream_t)stream_;
 
-    const bool pairs = p->mode == 0 && g_s2_ws && p->c_out % P2_TM == 0 && p->h % P2_ROWS == 0;
+    const bool pairs = p->mode == 0 && pairs_shape(p->c_out, p->h);
+    if (ep) {
+        if (!pairs) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2_fused: needs the strided form (mode 0), c_out %% 128 == 0 and H %% 8 == 0 (and SGV_S2_WS != 0)");
+        if (ep->act != 1 && ep->act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: act must be 1 (linear) or 3 (lrelu)");
+        if (!(ep->gain > 0.f) || (ep->act == 3 && !(ep->alpha >= 0.f && ep->alpha <= 1.f))) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: needs gain > 0 and 0 <= alpha <= 1");
+        if (ep->bias && (((uintptr_t)ep->bias) & 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: bias must be 16-byte aligned");
+    }
     int rc;
     if (pairs) {
         const int words = (p->c_out / P2_TM) * (p->c_in / P2_KC) * 10 * P2_TM;
@@ -215,8 +227,15 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
     if (pairs) {
         kp.tiles = p->n * (p->h / P2_ROWS) * (p->w / SEG) * (p->c_out / P2_TM);
         kp.grid = std::min(kp.tiles, g_cus);
-        if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_pairs_kernel<1>, dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp);
-        else hipLaunchKernelGGL(conv3x3_s2_pairs_kernel<3>, dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp);
+        s2_epilogue ke{};
+        if (ep) { ke.bias = ep->bias; ke.residual = ep->residual; ke.act_out = ep->act_out; ke.act = ep->act; ke.alpha = ep->alpha; ke.gain = ep->gain; ke.clamp = ep->clamp; }
+        if (ep) {
+            if (p->terms == 1) hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<1, 0, 1>), dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
+            else hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<3, 0, 1>), dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
+        } else {
+            if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_pairs_kernel<1>, dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
+            else hipLaunchKernelGGL(conv3x3_s2_pairs_kernel<3>, dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
+        }
         return sgv_check_launch("conv3x3_s2_pairs_kernel");
     }
     if (p->mode == 0 && g_s2_ws) {
@@ -256,4 +275,18 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
     hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2), dim3(64), 0, stream, (const float*)p->x,
                        p->weight, (float*)p->y, p->n, p->c_in, p->c_out, p->h, p->w);
     return sgv_check_launch("convT3x3_s2_edge_mfma");
+}
+
+}  // namespace
+
+extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream_) { return conv3x3_s2_impl(p, nullptr, dtype, stream_); }
+
+extern "C" int sgv_conv3x3_s2_fused(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* e, int dtype, void* stream_) {
+    if (!e) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: epilogue is NULL");
+    return conv3x3_s2_impl(p, e, dtype, stream_);
+}
+
+extern "C" int sgv_conv3x3_s2_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {
+    std::call_once(g_attr_once, init_once);
+    return supported_s2(n, c_in, c_out, h, w, dtype) && pairs_shape(c_out, h) ? 1 : 0;
 }

@@ -309,9 +309,21 @@ __device__ __forceinline__ tile_pos decode_tile_p2(const s2_params& p, int tile)
     return tp;
 }
 
+// EPI = 1: the layer's tail on the accumulators before the store (layers.py Conv2dLayer.forward + the residual add of DiscriminatorBlock.forward,
+// networks.py:343-345):  a = clamp(lrelu_alpha(acc + bias[m]) * gain),  y = a + residual  -- evaluated as max(fma(acc, g, b*g), fma(acc, g*alpha,
+// b*g*alpha)) (valid for gain > 0, 0 <= alpha <= 1; alpha = 1 is the linear activation).  `act_out` (optional) receives a, which the backward
+// pass needs when a residual hides it.
+struct s2_epilogue {
+    const float* bias;       // [m] or NULL
+    const float* residual;   // [n, m, h, w] or NULL
+    float* act_out;          // [n, m, h, w] or NULL
+    int act;                 // 1 linear, 3 lrelu
+    float alpha, gain, clamp;   // clamp < 0: none
+};
+
 // ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
-template <int TERMS, int ABL = 0>
-__global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p) {
+template <int TERMS, int ABL = 0, int EPI = 0>
+__global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s2_epilogue ep) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -503,17 +515,33 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p) {
             int le = lane;
             asm volatile("" : "+v"(le));
             const int ge = le >> 5;
-            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * P2_TM) * plane_out + (size_t)(tp.y0 + 2 * wave) * p.w + tp.x0 + (le & 31);
+            const size_t off0 = ((size_t)tp.n * p.m + tp.mt * P2_TM) * plane_out + (size_t)(tp.y0 + 2 * wave) * p.w + tp.x0 + (le & 31);
+            float* yb = p.y + off0;
+            const float al = ep.act == 3 ? ep.alpha : 1.f;
+            const float g0 = ep.gain, g1 = ep.gain * al;
+            const float clamp_hi = ep.clamp >= 0.f ? ep.clamp : __builtin_inff();
 #pragma unroll
             for (int mq = 0; mq < 4; mq++)
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int m = mq * 32 + (e & 3) + 8 * (e >> 2) + 4 * ge;
+                for (int e4 = 0; e4 < 4; e4++) {
+                    const int m0 = mq * 32 + 8 * e4 + 4 * ge;
+                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                    if (EPI == 1 && ep.bias) bv = *(const f32x4*)(ep.bias + tp.mt * P2_TM + m0);
 #pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        yb[(size_t)m * plane_out + (size_t)r * p.w] = acc[r][mq][e];
-                        acc[r][mq][e] = 0.f;
-                    }
+                    for (int ei = 0; ei < 4; ei++)
+#pragma unroll
+                        for (int r = 0; r < 2; r++) {
+                            const size_t idx = (size_t)(m0 + ei) * plane_out + (size_t)r * p.w;
+                            float v = acc[r][mq][4 * e4 + ei];
+                            if (EPI == 1) {
+                                v = fmaxf(__builtin_fmaf(v, g0, bv[ei] * g0), __builtin_fmaf(v, g1, bv[ei] * g1));
+                                v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
+                                if (ep.act_out) ep.act_out[off0 + idx] = v;
+                                if (ep.residual) v += ep.residual[off0 + idx];
+                            }
+                            yb[idx] = v;
+                            acc[r][mq][4 * e4 + ei] = 0.f;
+                        }
                 }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

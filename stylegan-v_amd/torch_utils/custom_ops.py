@@ -191,6 +191,10 @@ class Conv3x3Epilogue(ctypes.Structure):
     _fields_ = [('x_scale', c_void_p), ('out_scale', c_void_p), ('bias', c_void_p), ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
 
 
+class Conv3x3S2Epilogue(ctypes.Structure):
+    _fields_ = [('bias', c_void_p), ('residual', c_void_p), ('act_out', c_void_p), ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
+
+
 class TimeEncodeParams(ctypes.Structure):
     _fields_ = [(name, c_void_p) for name in
                 ['periods', 'phases', 'al', 'ar', 'freqs', 'phase_scales', 't', 't_left', 't_right', 'alpha', 'out']] + \
@@ -240,6 +244,8 @@ ABI_SYMBOLS = {
     'sgv_conv3x3_s2': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
     'sgv_conv3x3_fused': (c_int, [ctypes.POINTER(Conv3x3Params), ctypes.POINTER(Conv3x3Epilogue), c_int, c_void_p]),
     'sgv_conv3x3_fused_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
+    'sgv_conv3x3_s2_fused': (c_int, [ctypes.POINTER(Conv3x3Params), ctypes.POINTER(Conv3x3S2Epilogue), c_int, c_void_p]),
+    'sgv_conv3x3_s2_fused_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_s2_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_s2_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'sgv_conv3x3_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),

@@ -55,6 +55,18 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     return op(x, w, stride=stride, padding=padding, groups=groups)
 
 
+def downsampling_filter_pass(x, f, down, padding=0, kernel_hw=(3, 3), flip_filter=False):
+    """The FIR pass that ``conv2d_resample`` puts in front of its strided convolution (`down > 1 and up == 1`, non-pointwise kernel): returns the
+    filtered tensor the stride-`down` convolution then reads, so that a caller can run a fused convolution tail on it (ops/fused_down_act.py)."""
+    fw, fh = _get_filter_size(f)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    px0 += (fw - down + 1) // 2
+    px1 += (fw - down) // 2
+    py0 += (fh - down + 1) // 2
+    py1 += (fh - down) // 2
+    return _ufd.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
+
+
 def upsampling_conv_parts(x, w, f, up, padding=0, groups=1, flip_weight=True):
     """First half of the `up > 1` branch of conv2d_resample: the stride-`up` transposed convolution, WITHOUT the FIR
     that follows it.  Returns (y, fir_padding): ``upfirdn2d(y, f, padding=fir_padding, gain=up**2)`` completes the op.

@@ -1,0 +1,132 @@
+"""Fused down-sampling 3x3 layer tail:  y = clamp(act(conv3x3_stride2(xb, W) + bias) * gain) (+ residual).
+
+``xb`` is the FIR-filtered (2H+1)x(2W+1) tensor that ``conv2d_resample`` hands to its strided convolution (conv2d_resample.py:113-126); the
+reference then runs ``bias_act`` as a separate pass (layers.py ``Conv2dLayer.forward``) and, in the residual discriminator block, adds the skip
+branch in a third one (``y.add_(x)``, networks.py:343-345).  As in ``fused_conv_act`` there is no reference op to mirror: the function is
+DEFINED as that composition (`strided_conv3x3_bias_act_composed`) and, where the kernel serves the shape, evaluated as
+
+  forward   ONE kernel (``sgv_conv3x3_s2_fused``, csrc/conv3x3s2_ws_kernel.h): bias / activation / gain / clamp and the residual add are applied to
+            the accumulators before the store; with a residual the activation output is stored too (the backward pass needs it).
+  backward  ``sgv_act_grad_scale`` (activation gradient from the saved activation output + the bias-gradient sums) -> transposed convolution
+            (data gradient) and stride-2 weight gradient on the hand-written kernels; the residual's gradient is dy itself.
+
+Second order: as ``fused_conv_act`` -- a backward that is itself recorded differentiates the composition; passes known to be differentiated twice run
+under ``fused_conv_act.composition_only()``.  Parity: tests/test_fused_conv_gpu.py against the oracle composition.
+"""
+
+import torch
+
+from .. import custom_ops
+from . import bias_act as _ba
+from . import conv2d_gradfix as _cg
+from . import fused_conv_act as _fca
+
+_S2 = (False, (2, 2), (0, 0), (0, 0), (1, 1), 1)     # cfg of the strided convolution
+_S2T = (True, (2, 2), (0, 0), (0, 0), (1, 1), 1)     # ... and of its data gradient
+
+
+def strided_conv3x3_bias_act_composed(xb, weight, bias=None, act='lrelu', alpha=None, gain=None, clamp=None, residual=None):
+    """The definition: strided convolution -> bias_act -> (+ residual), each differentiable to any order."""
+    y = _cg.conv2d(xb, weight.to(xb.dtype), stride=2)
+    y = _ba.bias_act(y, bias.to(y.dtype) if bias is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)
+    return residual.add_(y) if residual is not None else y       # the reference's in-place form (networks.py:345)
+
+
+def _launch(xb, weight, bias, residual, want_act, act_idx, alpha, gain, clamp):
+    lib = custom_ops.get_native()
+    n, ci, hb, wb = xb.shape
+    co = weight.shape[0]
+    hs, ws_ = (hb - 1) // 2, (wb - 1) // 2
+    y = torch.empty([n, co, hs, ws_], dtype=torch.float32, device=xb.device)
+    a = torch.empty_like(y) if want_act else None
+    wsb = int(lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, ws_, 0))
+    wsp = torch.empty([wsb], dtype=torch.uint8, device=xb.device)
+    p = custom_ops.Conv3x3Params(xb.data_ptr(), weight.data_ptr(), y.data_ptr(), wsp.data_ptr(), wsb, n, ci, co, hs, ws_, 0, _cg.native_conv_terms)
+    e = custom_ops.Conv3x3S2Epilogue(bias.data_ptr() if bias is not None else None, residual.data_ptr() if residual is not None else None,
+                                     a.data_ptr() if a is not None else None, act_idx, alpha, gain, clamp)
+    with custom_ops.device_guard(xb):
+        custom_ops.check(lib.sgv_conv3x3_s2_fused(p, e, 0, custom_ops.raw_stream(xb)), lib)
+    return y, a
+
+
+class _FusedDownFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xb, weight, bias, residual, cfg):
+        act, alpha, gain, clamp = cfg
+        b = bias.contiguous().float() if bias is not None else None
+        r = residual.contiguous() if residual is not None else None
+        need_graph = any(ctx.needs_input_grad[:3])
+        y, a = _launch(xb.contiguous(), weight.contiguous(), b, r, r is not None and need_graph, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
+        ctx.cfg = cfg
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        ctx.save_for_backward(xb, weight, bias, residual, a if a is not None else y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        act, alpha, gain, clamp = ctx.cfg
+        xb, weight, b, res, a = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # create_graph=True: differentiate the composition on the saved inputs (one extra forward, gradients of any order)
+            ins = [t for t, need in zip((xb, weight, b, res), ctx.needs_input_grad[:4]) if need and t is not None]
+            with torch.enable_grad():
+                y2 = strided_conv3x3_bias_act_composed(xb, weight, bias=b, act=act, alpha=alpha, gain=gain, clamp=(clamp if clamp >= 0 else None),
+                                                       residual=res.clone() if res is not None else None)
+                grads = iter(torch.autograd.grad(y2, ins, dy, create_graph=True, allow_unused=True))
+            return tuple(next(grads) if (need and t is not None) else None for t, need in zip((xb, weight, b, res), ctx.needs_input_grad[:4])) + (None,)
+        lib = custom_ops.get_native()
+        dy = dy.contiguous()
+        d_x = d_w = d_b = None
+        d_r = dy if (res is not None and ctx.needs_input_grad[3]) else None
+        if any(ctx.needs_input_grad[:3]):
+            n, co, h, w = a.shape
+            need_db = b is not None and ctx.needs_input_grad[2]
+            sums = torch.zeros([2, n * co], dtype=torch.float32, device=dy.device) if need_db else None
+            dz = torch.empty_like(a)
+            with custom_ops.device_guard(dy):
+                custom_ops.check(lib.sgv_act_grad_scale(dy.data_ptr(), a.data_ptr(), None, dz.data_ptr(), sums.data_ptr() if sums is not None else None, n * co, h * w,
+                                                        _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, custom_ops.raw_stream(dy)), lib)
+            if need_db:
+                d_b = sums[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
+            wc = weight.contiguous()
+            if ctx.needs_input_grad[0]:
+                d_x = _cg._native_conv(dz, wc, _S2T) if _cg._native_conv_ok(dz, wc, _S2T) else _cg._aten_conv(dz, wc, None, _S2T)
+            if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
+                if _cg._native_wrw_ok(dz, xb, _S2, tuple(weight.shape)):
+                    d_w = _cg._native_wrw(dz, xb, _S2, tuple(weight.shape))
+                else:
+                    _, d_w, _ = torch.ops.aten.convolution_backward(dz, xb, weight, None, (2, 2), (0, 0), (1, 1), False, (0, 0), 1, [False, True, False])
+        return d_x, d_w, d_b, d_r, None
+
+
+def _fusable(xb, weight, bias, residual, act, alpha, gain, clamp):
+    if act == 'linear' and clamp >= 0:   # same reference quirk as fused_conv_act: linear + clamp has an unmasked gradient
+        return False
+    if _fca.mode == 0 or _fca._composition_depth > 0 or _cg.native_conv_terms not in (1, 3) or not _cg.enabled or not _cg.native_conv_s2:
+        return False
+    if not (xb.is_cuda and xb.ndim == 4 and xb.dtype == torch.float32 and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    if act not in ('linear', 'lrelu') or not gain > 0 or (act == 'lrelu' and not 0 <= alpha <= 1):
+        return False
+    n, ci, hb, wb = xb.shape
+    co = weight.shape[0]
+    if weight.shape[1] != ci or hb % 2 == 0 or wb % 2 == 0 or hb < 3 or wb < 3:
+        return False
+    hs, ws_ = (hb - 1) // 2, (wb - 1) // 2
+    if bias is not None and tuple(bias.shape) != (co,):
+        return False
+    if residual is not None and (tuple(residual.shape) != (n, co, hs, ws_) or residual.dtype != torch.float32 or not residual.is_cuda):
+        return False
+    needs_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (xb, weight, bias, residual))
+    if needs_graph and _fca.mode < 2:
+        return False
+    return bool(custom_ops.get_native().sgv_conv3x3_s2_fused_supported(n, ci, co, hs, ws_, 0))
+
+
+def strided_conv3x3_bias_act(xb, weight, bias=None, act='lrelu', alpha=None, gain=None, clamp=None, residual=None):
+    """xb [N,I,2H+1,2W+1]; weight [O,I,3,3] (correlation, stride 2, no padding); bias [O] or None; residual [N,O,H,W] or None (consumed: the
+    composed form adds into it in place, as the reference does); act / alpha / gain / clamp as ``bias_act``."""
+    _, alpha_f, gain_f, clamp_f = _ba._resolve(act, alpha, gain, clamp)
+    if _fusable(xb, weight, bias, residual, act, alpha_f, gain_f, clamp_f):
+        return _FusedDownFn.apply(xb, weight, bias, residual, (act, alpha_f, gain_f, clamp_f))
+    return strided_conv3x3_bias_act_composed(xb, weight, bias=bias, act=act, alpha=alpha, gain=gain, clamp=clamp, residual=residual)

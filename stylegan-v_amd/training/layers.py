@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, fc, fused_conv_act, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_resample, fc, fused_conv_act, fused_down_act, upfirdn2d
 
 
 @misc.profiled_function
@@ -126,7 +126,9 @@ class Conv2dLayer(torch.nn.Module):
             else:
                 self.bias = None
 
-    def forward(self, x, gain=1):
+    def forward(self, x, gain=1, residual=None):
+        """``residual`` (optional, same shape as the result): added to the layer's output -- the `y.add_(x)` of the residual discriminator block
+        (networks.py:343-345) folded into the layer so that the down-sampling convolution can do it in its epilogue."""
         w = self.weight * (self.weight_gain * self.lr_multiplier)
         b = self.bias.to(x.dtype) * self.lr_multiplier if self.bias is not None else None
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
@@ -134,10 +136,18 @@ class Conv2dLayer(torch.nn.Module):
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu'):
             # stride-1 3x3 layer (DiscriminatorBlock conv0, epilogue conv): convolution + bias + activation as one kernel where served
             x = fused_conv_act.conv3x3_bias_act(x, w, bias=b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        elif self.up == 1 and self.down == 2 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
+                and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm:
+            # down-sampling 3x3 layer (DiscriminatorBlock conv1): FIR pass, then strided convolution + bias + activation (+ residual) as one kernel
+            xb = conv2d_resample.downsampling_filter_pass(x, self.resample_filter, down=self.down, padding=self.padding)
+            x = fused_down_act.strided_conv3x3_bias_act(xb, w, bias=b, act=self.activation, gain=self.act_gain * gain, clamp=clamp, residual=residual)
+            residual = None
         else:
             x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
                                                 padding=self.padding, flip_weight=(self.up == 1))
             x = bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+        if residual is not None:
+            x = residual.add_(x)
         if self.instance_norm:
             x = (x - x.mean(dim=(2, 3), keepdim=True)) / (x.std(dim=(2, 3), keepdim=True) + 1e-8)
         return x

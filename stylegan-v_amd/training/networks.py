@@ -341,8 +341,7 @@ class DiscriminatorBlock(torch.nn.Module):
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
             y = self.skip(x, gain=math.sqrt(0.5))
-            x = self.conv1(self.conv0(x), gain=math.sqrt(0.5))
-            x = y.add_(x)
+            x = self.conv1(self.conv0(x), gain=math.sqrt(0.5), residual=y)   # `x = y.add_(conv1(...))`, with the add inside the layer's last kernel
         else:
             x = self.conv1(self.conv0(x))
         assert x.dtype == dtype

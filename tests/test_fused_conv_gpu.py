@@ -115,3 +115,88 @@ def test_fused_layer_no_grad_pass_and_fallbacks():
     assert custom_ops.launch_count() - before == 2              # convolution, then bias_act as its own pass
     yt = fused_conv_act.conv3x3_bias_act(x, wt, act='tanh')
     assert yt.abs().max() <= 1
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Fused down-sampling layer tail (ops/fused_down_act.py -> sgv_conv3x3_s2_fused, csrc/conv3x3s2_ws_kernel.h) against the oracle's composition
+# `oracle.conv3x3(xb, w, stride=2) -> oracle.bias_act -> + residual`.
+
+@pytest.mark.parametrize('n,ci,co,hs,ws', [(2, 32, 128, 8, 32), (1, 64, 256, 16, 64), (3, 16, 128, 24, 32)])
+@pytest.mark.parametrize('act,clamp,with_res,with_bias', [('lrelu', None, True, True), ('lrelu', 0.7, True, True), ('lrelu', None, False, True),
+                                                          ('linear', None, True, False), ('lrelu', 0.9, False, False)])
+def test_fused_down_layer_forward_and_gradients_vs_oracle(n, ci, co, hs, ws, act, clamp, with_res, with_bias):
+    from stylegan_v_amd.torch_utils.ops import fused_down_act
+    g = torch.Generator().manual_seed(n * 11 + ci + co + hs)
+    xb = torch.randn([n, ci, 2 * hs + 1, 2 * ws + 1], generator=g)
+    wt = torch.randn([co, ci, 3, 3], generator=g) / (3 * ci ** 0.5)
+    b = torch.randn([co], generator=g) * 0.5 if with_bias else None
+    res = torch.randn([n, co, hs, ws], generator=g) if with_res else None
+    gain = 0.5 ** 0.5 * (2 ** 0.5 if act == 'lrelu' else 1.0)
+    dy = torch.randn([n, co, hs, ws], generator=g)
+    dev = lambda t: t.to(DEV).requires_grad_(True) if t is not None else None   # noqa: E731
+    xg, wg, bg, rg = dev(xb), dev(wt), dev(b), dev(res)
+    custom_ops.prof_enable(64)
+    y = fused_down_act.strided_conv3x3_bias_act(xg, wg, bias=bg, act=act, gain=gain, clamp=clamp, residual=rg.clone() if rg is not None else None)
+    custom_ops.prof_disable()
+    prof = custom_ops.prof_collect()
+    assert prof['conv3x3']['launches'] == 1 and prof.get('bias_act', {}).get('launches', 0) == 0, 'the forward pass must be ONE kernel'
+
+    y0 = torch.from_numpy(oracle.conv3x3(xb.double().numpy(), wt.double().numpy(), stride=2))
+    a_ref = oracle.bias_act(y0, b.double() if b is not None else None, act=act, gain=gain, clamp=clamp)
+    y_ref = a_ref + (res.double() if res is not None else 0.0)
+    scale = oracle.bias_act(y0, b.double() if b is not None else None, act=act, gain=gain).abs().max().item()
+    err = (y.detach().double().cpu() - y_ref).abs().max().item() / scale
+    assert err < 1e-5, f'forward: {err:.2e}'
+
+    ins = [t for t in (xg, wg, bg) if t is not None]
+    names = [k for k, t in zip('xwb', (xg, wg, bg)) if t is not None]
+    got = torch.autograd.grad(y, ins, dy.to(DEV))
+    # the activation derivative is selected by the sign / saturation of the kernel's own activation output (see _oracle_grads above)
+    # -- with a residual that is the kernel's act_out, which the same kernel without a residual returns as y (identical arithmetic)
+    with torch.no_grad():
+        a_gpu = fused_down_act.strided_conv3x3_bias_act(xg, wg, bias=bg, act=act, gain=gain, clamp=clamp).double().cpu()
+    dz = oracle.bias_act(dy.double(), b.double() if b is not None else None, act=act, gain=gain, clamp=clamp, grad=1, xref=y0, yref=a_gpu)
+    ref = dict(x=torch.from_numpy(oracle.conv3x3(dz.numpy(), wt.double().numpy(), stride=2, transposed=True)),
+               w=torch.from_numpy(oracle.conv3x3_weight_grad(dz.numpy(), xb.double().numpy(), stride=2)), b=dz.sum([0, 2, 3]))
+    for name, a in zip(names, got):
+        err = _rel(a, ref[name])
+        assert err < 3e-5, f'd{name}: {err:.2e}'
+    if rg is not None:   # the residual's gradient is dy itself
+        # (the residual handed to the op was a clone: differentiate through the clone)
+        r2 = dev(res)
+        y2 = fused_down_act.strided_conv3x3_bias_act(xg, wg, bias=bg, act=act, gain=gain, clamp=clamp, residual=r2 * 1.0)
+        (gr,) = torch.autograd.grad(y2, [r2], dy.to(DEV))
+        assert torch.equal(gr.cpu(), dy)
+
+
+def test_fused_down_layer_second_order_and_fallbacks():
+    from stylegan_v_amd.torch_utils.ops import fused_down_act
+    g = torch.Generator().manual_seed(9)
+    xb = torch.randn([2, 32, 17, 65], generator=g).to(DEV).requires_grad_(True)
+    wt = (torch.randn([128, 32, 3, 3], generator=g) / 17).to(DEV).requires_grad_(True)
+    b = (torch.randn([128], generator=g) * 0.1).to(DEV).requires_grad_(True)
+    res = torch.randn([2, 128, 8, 32], generator=g).to(DEV)
+
+    def r1(fn):
+        y = fn(xb, wt, bias=b, act='lrelu', residual=res.clone())
+        (gx,) = torch.autograd.grad(y.sum(), xb, create_graph=True)
+        return torch.autograd.grad(gx.square().sum(), [wt, b], allow_unused=True)
+    got = r1(fused_down_act.strided_conv3x3_bias_act)
+    with fused_conv_act.composition_only():
+        want = r1(fused_down_act.strided_conv3x3_bias_act)
+    for a, r in zip(got, want):
+        assert (a is None) == (r is None)
+        if a is not None:
+            assert _rel(a, r.double().cpu()) < 1e-4
+    # 64 output channels are not served by the tap-pair kernel: composition (strided convolution, bias_act, add as separate launches)
+    w64 = (torch.randn([64, 32, 3, 3], generator=g) / 17).to(DEV)
+    with torch.no_grad():
+        before = custom_ops.launch_count()
+        y = fused_down_act.strided_conv3x3_bias_act(xb, w64, act='lrelu')
+        assert custom_ops.launch_count() - before == 2
+        before = custom_ops.launch_count()
+        yf = fused_down_act.strided_conv3x3_bias_act(xb, wt, bias=b, act='lrelu', residual=res.clone())
+        assert custom_ops.launch_count() - before == 1
+        with fused_conv_act.composition_only():
+            yc = fused_down_act.strided_conv3x3_bias_act(xb, wt, bias=b, act='lrelu', residual=res.clone())
+    assert _rel(yf, yc.double().cpu()) < 1e-5 and y.shape == (2, 64, 8, 32)

@@ -69,9 +69,9 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
         p.tiles = n * (h / P2_ROWS) * (wd / SEG) * (m / P2_TM);
         p.grid = grid < p.tiles ? grid : p.tiles;
         switch (g_abl) {
-            case 0: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 0>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p); break;
-            case 6: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 6>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p); break;
-            case 7: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 7>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p); break;
+            case 0: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 0>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p, s2_epilogue{}); break;
+            case 6: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 6>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p, s2_epilogue{}); break;
+            case 7: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 7>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p, s2_epilogue{}); break;
         }
         return;
     }
