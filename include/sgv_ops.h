@@ -189,6 +189,10 @@ typedef struct sgv_pointwise_params {
 } sgv_pointwise_params;
 
 int sgv_pointwise_small(const sgv_pointwise_params* p, int dtype, void* stream);
+/* kind 1 (few -> many) with the layer tail applied before the store: y = clamp(act(y + bias[m]) * gain), the same operations in the same
+ * order as sgv_bias_act (bit-identical to the two-pass composition in fp32) -- the discriminator's fromRGB layer, layers.py Conv2dLayer.forward.
+ * bias [c_many] fp32 or NULL; act 1 linear / 3 lrelu; clamp < 0: none; fp32 tensors only. */
+int sgv_pointwise_act(const sgv_pointwise_params* p, const float* bias, int32_t act, float alpha, float gain, float clamp, int dtype, void* stream);
 int sgv_pointwise_outer(const void* a_few, const void* b_many, float* out, int32_t n, int32_t c_few, int32_t c_many, int32_t hw,
                         int dtype, void* stream);
 

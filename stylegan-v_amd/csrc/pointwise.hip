@@ -47,6 +47,10 @@ struct pw_params {
     int n, cm, cf, hw;       // hw is a multiple of 4 on this path
     int64_t w_stride_n;      // 0: weights shared by the batch
     int m_per_z;             // few2many: planes of the many side per blockIdx.z slice
+    // few2many epilogue (sgv_pointwise_act): y = clamp(act(y + bias[m]) * gain) in bias_act.hip's own operation order; act 0 = none
+    const float* bias;
+    int act;
+    float alpha, gain, clamp;
 };
 
 // MS == 1: grid = (ceil(hw/4/256), n), lane -> pixel quad, every lane walks all M planes.
@@ -106,7 +110,7 @@ __global__ __launch_bounds__(256) void pw_many2few_kernel(pw_params p) {
     for (int f = 0; f < F; f++) store4<T>(y + (size_t)f * p.hw, acc[f]);
 }
 
-template <typename T, int F>
+template <typename T, int F, int EPI = 0>
 __global__ __launch_bounds__(256) void pw_few2many_kernel(pw_params p) {
     const int n = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
@@ -126,6 +130,17 @@ __global__ __launch_bounds__(256) void pw_few2many_kernel(pw_params p) {
             const float wf = w[m * F + f];
 #pragma unroll
             for (int i = 0; i < 4; i++) o[i] = __builtin_fmaf(v[f][i], wf, o[i]);
+        }
+        if (EPI) {
+            const float bm = p.bias ? p.bias[m] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                float t = o[i] + bm;
+                if (p.act == 3) t = (t > 0.f) ? t : t * p.alpha;
+                t *= p.gain;
+                if (p.clamp >= 0.f) t = (t > -p.clamp & t < p.clamp) ? t : (t >= 0.f) ? p.clamp : -p.clamp;
+                o[i] = t;
+            }
         }
         store4<T>(y + (size_t)m * p.hw, o);
     }
@@ -224,6 +239,7 @@ int launch_pw(int kind, pw_params pp, hipStream_t stream) {
     if (pp.cf == F) {                                                                                               \
         if (kind == 0 && split) hipLaunchKernelGGL((pw_many2few_kernel<T, F, 4>), grid, dim3(256), 0, stream, pp);  \
         else if (kind == 0) hipLaunchKernelGGL((pw_many2few_kernel<T, F, 1>), grid, dim3(256), 0, stream, pp);      \
+        else if (pp.act) hipLaunchKernelGGL((pw_few2many_kernel<T, F, 1>), grid, dim3(256), 0, stream, pp);         \
         else hipLaunchKernelGGL((pw_few2many_kernel<T, F>), grid, dim3(256), 0, stream, pp);                        \
         return SGV_OK;                                                                                              \
     }
@@ -266,7 +282,7 @@ extern "C" int sgv_pointwise_small(const sgv_pointwise_params* p, int dtype, voi
     if (rc != SGV_OK) return rc;
     if (p->kind != 0 && p->kind != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise: kind must be 0 (many->few) or 1 (few->many)");
     hipStream_t stream = (hipStream_t)stream_;
-    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many};
+    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, nullptr, 0, 0.f, 1.f, -1.f};
     const double bytes = (double)(p->c_many + p->c_few) * p->n * p->hw * sgv_dtype_size(dtype);
     sgv_launch_scope scope(SGV_K_POINTWISE, stream, bytes, 2.0 * p->c_many * p->c_few * (double)p->n * p->hw);
     switch (dtype) {
@@ -274,6 +290,22 @@ extern "C" int sgv_pointwise_small(const sgv_pointwise_params* p, int dtype, voi
         case SGV_F16: rc = launch_pw<sgv_half_t>(p->kind, pp, stream); break;
         default: rc = launch_pw<sgv_bf16_t>(p->kind, pp, stream); break;
     }
+    if (rc != SGV_OK) return rc;
+    return sgv_check_launch("pointwise kernel");
+}
+
+extern "C" int sgv_pointwise_act(const sgv_pointwise_params* p, const float* bias, int32_t act, float alpha, float gain, float clamp, int dtype, void* stream_) {
+    if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_act: params is NULL");
+    int rc = check_common(p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, dtype, "pointwise_act");
+    if (rc != SGV_OK) return rc;
+    if (p->kind != 1) return sgv_fail(SGV_ERR_UNSUPPORTED, "pointwise_act: only the few -> many form (kind 1) has an epilogue");
+    if (dtype != SGV_F32) return sgv_fail(SGV_ERR_UNSUPPORTED, "pointwise_act: fp32 only (a 16-bit composition rounds between the two steps)");
+    if (act != 1 && act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_act: act must be 1 (linear) or 3 (lrelu)");
+    hipStream_t stream = (hipStream_t)stream_;
+    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, bias, act, alpha, gain, clamp};
+    const double bytes = (double)(p->c_many + p->c_few) * p->n * p->hw * 4.0;
+    sgv_launch_scope scope(SGV_K_POINTWISE, stream, bytes, 2.0 * p->c_many * p->c_few * (double)p->n * p->hw);
+    rc = launch_pw<float>(1, pp, stream);
     if (rc != SGV_OK) return rc;
     return sgv_check_launch("pointwise kernel");
 }

@@ -95,6 +95,65 @@ class _OuterFn(torch.autograd.Function):
         return da, db
 
 
+class _PointwiseActFn(torch.autograd.Function):
+    """y = bias_act(pointwise_conv(x, w), b) for the few -> many form as ONE kernel (sgv_pointwise_act; same operations in the same order as
+    the two-pass composition, so bit-identical in fp32).  The backward pass is assembled from the differentiable pieces the composition itself
+    uses (bias_act's gradient node, pointwise_conv, outer), so gradients of any order exist."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cfg):
+        from . import bias_act as _ba
+        act, alpha, gain, clamp = cfg
+        lib = custom_ops.get_native()
+        xc, wc = x.contiguous(), w.contiguous().float()
+        bc = b.contiguous().float() if b is not None else None
+        n, ci, h, wd = xc.shape
+        co = wc.shape[1]
+        y = torch.empty([n, co, h, wd], dtype=torch.float32, device=xc.device)
+        p = custom_ops.PointwiseParams(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), n, co, ci, h * wd, 0, 1)
+        with custom_ops.device_guard(xc):
+            custom_ops.check(lib.sgv_pointwise_act(p, bc.data_ptr() if bc is not None else None, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp,
+                                                   _DTYPE_CODES[xc.dtype], custom_ops.raw_stream(xc)), lib)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, w, b, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import bias_act as _ba
+        act, alpha, gain, clamp = ctx.cfg
+        x, w, b, y = ctx.saved_tensors
+        bcfg = (1, act, alpha, gain, clamp)
+        dy = dy.contiguous()
+        dz, db = dy, None
+        need_db = b is not None and ctx.needs_input_grad[2]
+        if act != 'linear' or gain != 1 or clamp >= 0:
+            if need_db and _ba._fused_db_ok(dy, tuple(b.shape), 1):
+                dz, db = _ba._BiasActGradDbFn.apply(dy, None, b, y, bcfg, b.shape[0], b.dtype)
+            else:
+                dz = _ba._BiasActGradFn.apply(dy, None, b, y, bcfg)
+        if need_db and db is None:
+            db = dz.sum([0, 2, 3]).to(b.dtype)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = pointwise_conv(dz, w.transpose(1, 2))
+        if ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled:
+            dw = outer(x, dz).transpose(1, 2).sum(0, keepdim=True).to(w.dtype)
+        return dx, dw, db, None
+
+
+def pointwise_conv_bias_act(x, w, b=None, act='linear', alpha=None, gain=None, clamp=None):
+    """bias_act(pointwise_conv(x, w), b, ...) -- fused into the convolution's store for the shared-weight few -> many fp32 case (the
+    discriminator's fromRGB: 3 -> C channels + bias + lrelu, layers.py Conv2dLayer.forward), the two-pass composition otherwise."""
+    from . import bias_act as _ba
+    co, ci = w.shape[1], w.shape[2]
+    if (act in ('linear', 'lrelu') and w.shape[0] == 1 and co > ci and x.dtype == torch.float32 and w.is_cuda and _native_ok(x, ci, co)
+            and (b is None or (b.is_cuda and tuple(b.shape) == (co,)))):
+        _, alpha_f, gain_f, clamp_f = _ba._resolve(act, alpha, gain, clamp)
+        return _PointwiseActFn.apply(x, w, b, (act, alpha_f, gain_f, clamp_f))
+    return _ba.bias_act(pointwise_conv(x, w), b.to(x.dtype) if b is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)
+
+
 def pointwise_conv(x, w):
     """x [N,Cin,H,W], w [N or 1, Cout, Cin] -> [N,Cout,H,W]; one of Cin / Cout must be <= 4 for the native path."""
     assert x.ndim == 4 and w.ndim == 3 and w.shape[2] == x.shape[1] and w.shape[0] in (1, x.shape[0])

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, fc, fused_conv_act, fused_down_act, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_resample, fc, fused_conv_act, fused_down_act, pointwise, upfirdn2d
 
 
 @misc.profiled_function
@@ -129,23 +129,34 @@ class Conv2dLayer(torch.nn.Module):
     def forward(self, x, gain=1, residual=None):
         """``residual`` (optional, same shape as the result): added to the layer's output -- the `y.add_(x)` of the residual discriminator block
         (networks.py:343-345) folded into the layer so that the down-sampling convolution can do it in its epilogue."""
-        w = self.weight * (self.weight_gain * self.lr_multiplier)
-        b = self.bias.to(x.dtype) * self.lr_multiplier if self.bias is not None else None
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
+        act_gain = self.act_gain * gain
+        fold = 1.0
+        if self.activation == 'linear' and clamp is None and act_gain != 1:
+            # (conv(x, w) + b) * g == conv(x, w * g) + b * g: the gain of a linear, un-clamped layer (the discriminator's skip branches, gain
+            # sqrt(0.5)) rides on the weights instead of costing a pass over the output and another over its gradient
+            fold, act_gain = act_gain, 1.0
+        w = self.weight * (self.weight_gain * self.lr_multiplier * fold)
+        b = self.bias.to(x.dtype) * (self.lr_multiplier * fold) if self.bias is not None else None
         if self.up == 1 and self.down == 1 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu'):
             # stride-1 3x3 layer (DiscriminatorBlock conv0, epilogue conv): convolution + bias + activation as one kernel where served
-            x = fused_conv_act.conv3x3_bias_act(x, w, bias=b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+            x = fused_conv_act.conv3x3_bias_act(x, w, bias=b, act=self.activation, gain=act_gain, clamp=clamp)
+        elif self.up == 1 and self.down == 1 and tuple(w.shape[2:]) == (1, 1) and w.shape[1] <= 4 and w.shape[0] > w.shape[1] and x.is_cuda \
+                and x.dtype == torch.float32 and x.is_contiguous() and pointwise.enabled:
+            # fromRGB: 1x1 convolution from <= 4 channels + bias + activation as one streaming kernel
+            x = pointwise.pointwise_conv_bias_act(x, w.reshape(1, w.shape[0], w.shape[1]), b, act=self.activation, gain=act_gain, clamp=clamp)
         elif self.up == 1 and self.down == 2 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm:
             # down-sampling 3x3 layer (DiscriminatorBlock conv1): FIR pass, then strided convolution + bias + activation (+ residual) as one kernel
             xb = conv2d_resample.downsampling_filter_pass(x, self.resample_filter, down=self.down, padding=self.padding)
-            x = fused_down_act.strided_conv3x3_bias_act(xb, w, bias=b, act=self.activation, gain=self.act_gain * gain, clamp=clamp, residual=residual)
+            x = fused_down_act.strided_conv3x3_bias_act(xb, w, bias=b, act=self.activation, gain=act_gain, clamp=clamp, residual=residual)
             residual = None
         else:
             x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
                                                 padding=self.padding, flip_weight=(self.up == 1))
-            x = bias_act.bias_act(x, b, act=self.activation, gain=self.act_gain * gain, clamp=clamp)
+            if b is not None or self.activation != 'linear' or act_gain != 1 or clamp is not None:   # (a no-op bias_act hands its input back as-is)
+                x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=clamp)
         if residual is not None:
             x = residual.add_(x)
         if self.instance_norm:

@@ -83,3 +83,37 @@ def test_conv2d_resample_uses_stream_kernel_for_fromrgb_shape():
     gxr, gwr = torch.autograd.grad(F.conv2d(xr, wr).square().sum(), [xr, wr])
     assert_close(gx, gxr, atol=1e-4, rtol=1e-4)
     assert_close(gw, gwr, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize('act,clamp,with_bias', [('lrelu', None, True), ('lrelu', 0.6, True), ('linear', None, True), ('lrelu', None, False)])
+def test_fused_fromrgb_tail_is_bit_identical_to_the_two_pass_composition(act, clamp, with_bias):
+    """sgv_pointwise_act = pointwise kernel + bias_act's own operations in its own order: one launch, bit-identical forward, the same first and
+    second order gradients as the composition (layers.py Conv2dLayer.forward of the discriminator's fromRGB)."""
+    from stylegan_v_amd.torch_utils import custom_ops
+    from stylegan_v_amd.torch_utils.ops import bias_act
+    torch.manual_seed(11)
+    n, ci, co, h, w = 3, 3, 64, 32, 32
+    mk = lambda *s: torch.randn(*s, device='cuda')   # noqa: E731
+    x, wt, b = mk(n, ci, h, w).requires_grad_(True), (mk(1, co, ci) / ci ** 0.5).requires_grad_(True), (mk(co) * 0.5).requires_grad_(True) if with_bias else None
+    gain = 2 ** 0.5 * 0.7
+
+    def composed(xx, ww, bb):
+        return bias_act.bias_act(pointwise.pointwise_conv(xx, ww), bb, act=act, gain=gain, clamp=clamp)
+
+    def fused(xx, ww, bb):
+        return pointwise.pointwise_conv_bias_act(xx, ww, bb, act=act, gain=gain, clamp=clamp)
+
+    with torch.no_grad():
+        before = custom_ops.launch_count()
+        yf = fused(x, wt, b)
+        assert custom_ops.launch_count() == before + 1
+        assert torch.equal(yf, composed(x, wt, b))
+
+    def r1(fn):
+        ins = [t for t in (x, wt, b) if t is not None]
+        y = fn(x, wt, b)
+        g = torch.autograd.grad((y * y.sin()).sum(), ins, create_graph=True)
+        gg = torch.autograd.grad(g[0].square().sum(), ins[1:], allow_unused=True)
+        return list(g) + [t for t in gg if t is not None]
+    for a, r in zip(r1(fused), r1(composed)):
+        assert_close(a, r, atol=1e-4, rtol=1e-4)
