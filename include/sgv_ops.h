@@ -272,15 +272,16 @@ int sgv_conv3x3_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t 
 int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);
 /* Strided 3x3 layer with its tail fused into the accumulator store (layers.py Conv2dLayer.forward after conv2d_resample's FIR; the residual
  * add of DiscriminatorBlock.forward, networks.py:343-345):
- *     a = clamp(act(conv3x3_s2(x, weight) + bias[m]) * gain),   y = a + residual
- * act 1 linear / 3 lrelu(alpha), gain > 0, 0 <= alpha <= 1, clamp < 0: none.  bias / residual / act_out may be NULL; act_out receives a (what
- * the activation gradient needs when a residual is added).  Shapes served: sgv_conv3x3_s2_fused_supported (mode 0, c_out % 128 == 0, H % 8 == 0). */
+ *     a = clamp(act(conv3x3_s2(x, weight) + bias[m]) * gain),   y = a   or, with accumulate != 0,   y += a
+ * act 1 linear / 3 lrelu(alpha), gain > 0, 0 <= alpha <= 1, clamp < 0: none.  `accumulate` is the reference's in-place `y.add_(x)`: p->y holds
+ * the skip branch's result on entry and each element receives one fp32 add.  bias / act_out may be NULL; act_out receives a (what the activation
+ * gradient needs once the sum hides it).  Shapes served: sgv_conv3x3_s2_fused_supported (mode 0, c_out % 128 == 0, H % 8 == 0). */
 typedef struct sgv_conv3x3_s2_epilogue {
     const float* bias;       /* [c_out], 16-byte aligned, or NULL */
-    const float* residual;   /* [n, c_out, h, w] or NULL */
     float* act_out;          /* [n, c_out, h, w] or NULL */
     int32_t act;
     float alpha, gain, clamp;
+    int32_t accumulate;
 } sgv_conv3x3_s2_epilogue;
 int sgv_conv3x3_s2_fused(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* e, int dtype, void* stream);
 int sgv_conv3x3_s2_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);

@@ -228,7 +228,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         kp.tiles = p->n * (p->h / P2_ROWS) * (p->w / SEG) * (p->c_out / P2_TM);
         kp.grid = std::min(kp.tiles, g_cus);
         s2_epilogue ke{};
-        if (ep) { ke.bias = ep->bias; ke.residual = ep->residual; ke.act_out = ep->act_out; ke.act = ep->act; ke.alpha = ep->alpha; ke.gain = ep->gain; ke.clamp = ep->clamp; }
+        if (ep) { ke.bias = ep->bias; ke.accumulate = ep->accumulate; ke.act_out = ep->act_out; ke.act = ep->act; ke.alpha = ep->alpha; ke.gain = ep->gain; ke.clamp = ep->clamp; }
         if (ep) {
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<1, 0, 1>), dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
             else hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<3, 0, 1>), dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);

@@ -310,15 +310,17 @@ __device__ __forceinline__ tile_pos decode_tile_p2(const s2_params& p, int tile)
 }
 
 // EPI = 1: the layer's tail on the accumulators before the store (layers.py Conv2dLayer.forward + the residual add of DiscriminatorBlock.forward,
-// networks.py:343-345):  a = clamp(lrelu_alpha(acc + bias[m]) * gain),  y = a + residual  -- evaluated as max(fma(acc, g, b*g), fma(acc, g*alpha,
-// b*g*alpha)) (valid for gain > 0, 0 <= alpha <= 1; alpha = 1 is the linear activation).  `act_out` (optional) receives a, which the backward
-// pass needs when a residual hides it.
+// networks.py:343-345):  a = clamp(lrelu_alpha(acc + bias[m]) * gain),  y = a  or, with `accumulate`, y += a  -- a evaluated as max(fma(acc, g, b*g),
+// fma(acc, g*alpha, b*g*alpha)) (valid for gain > 0, 0 <= alpha <= 1; alpha = 1 is the linear activation).  The residual add is the reference's own
+// in-place `y.add_(x)`: y holds the skip branch's result and every element receives exactly one no-return `global_atomic_add_f32` (fire and forget
+// like a store; a read-add-write in the epilogue measured 2.2x the kernel time because the MFMA waves sit on the load latency).  `act_out`
+// (optional) receives a, which the backward pass needs once the sum hides it.
 struct s2_epilogue {
     const float* bias;       // [m] or NULL
-    const float* residual;   // [n, m, h, w] or NULL
     float* act_out;          // [n, m, h, w] or NULL
     int act;                 // 1 linear, 3 lrelu
     float alpha, gain, clamp;   // clamp < 0: none
+    int accumulate;          // y += a instead of y = a
 };
 
 // ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
@@ -537,9 +539,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
                                 v = fmaxf(__builtin_fmaf(v, g0, bv[ei] * g0), __builtin_fmaf(v, g1, bv[ei] * g1));
                                 v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
                                 if (ep.act_out) ep.act_out[off0 + idx] = v;
-                                if (ep.residual) v += ep.residual[off0 + idx];
                             }
-                            yb[idx] = v;
+                            if (EPI == 1 && ep.accumulate) atomicAdd(yb + idx, v); else yb[idx] = v;
                             acc[r][mq][4 * e4 + ei] = 0.f;
                         }
                 }

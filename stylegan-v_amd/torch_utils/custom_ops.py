@@ -192,7 +192,7 @@ class Conv3x3Epilogue(ctypes.Structure):
 
 
 class Conv3x3S2Epilogue(ctypes.Structure):
-    _fields_ = [('bias', c_void_p), ('residual', c_void_p), ('act_out', c_void_p), ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
+    _fields_ = [('bias', c_void_p), ('act_out', c_void_p), ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float), ('accumulate', c_int32)]
 
 
 class TimeEncodeParams(ctypes.Structure):

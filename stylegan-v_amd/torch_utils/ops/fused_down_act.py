@@ -5,8 +5,9 @@ reference then runs ``bias_act`` as a separate pass (layers.py ``Conv2dLayer.for
 branch in a third one (``y.add_(x)``, networks.py:343-345).  As in ``fused_conv_act`` there is no reference op to mirror: the function is
 DEFINED as that composition (`strided_conv3x3_bias_act_composed`) and, where the kernel serves the shape, evaluated as
 
-  forward   ONE kernel (``sgv_conv3x3_s2_fused``, csrc/conv3x3s2_ws_kernel.h): bias / activation / gain / clamp and the residual add are applied to
-            the accumulators before the store; with a residual the activation output is stored too (the backward pass needs it).
+  forward   ONE kernel (``sgv_conv3x3_s2_fused``, csrc/conv3x3s2_ws_kernel.h): bias / activation / gain / clamp are applied to the accumulators
+            before the store; a residual is updated in place (one fp32 add per element, the reference's ``y.add_(x)``) and the activation output
+            is stored next to it (the backward pass needs it).
   backward  ``sgv_act_grad_scale`` (activation gradient from the saved activation output + the bias-gradient sums) -> transposed convolution
             (data gradient) and stride-2 weight gradient on the hand-written kernels; the residual's gradient is dy itself.
 
@@ -33,17 +34,18 @@ def strided_conv3x3_bias_act_composed(xb, weight, bias=None, act='lrelu', alpha=
 
 
 def _launch(xb, weight, bias, residual, want_act, act_idx, alpha, gain, clamp):
+    """`residual` (dense fp32, or None) is updated in place and returned: the reference's `y.add_(x)`."""
     lib = custom_ops.get_native()
     n, ci, hb, wb = xb.shape
     co = weight.shape[0]
     hs, ws_ = (hb - 1) // 2, (wb - 1) // 2
-    y = torch.empty([n, co, hs, ws_], dtype=torch.float32, device=xb.device)
+    y = residual if residual is not None else torch.empty([n, co, hs, ws_], dtype=torch.float32, device=xb.device)
     a = torch.empty_like(y) if want_act else None
     wsb = int(lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, ws_, 0))
     wsp = torch.empty([wsb], dtype=torch.uint8, device=xb.device)
     p = custom_ops.Conv3x3Params(xb.data_ptr(), weight.data_ptr(), y.data_ptr(), wsp.data_ptr(), wsb, n, ci, co, hs, ws_, 0, _cg.native_conv_terms)
-    e = custom_ops.Conv3x3S2Epilogue(bias.data_ptr() if bias is not None else None, residual.data_ptr() if residual is not None else None,
-                                     a.data_ptr() if a is not None else None, act_idx, alpha, gain, clamp)
+    e = custom_ops.Conv3x3S2Epilogue(bias.data_ptr() if bias is not None else None, a.data_ptr() if a is not None else None, act_idx, alpha, gain, clamp,
+                                     1 if residual is not None else 0)
     with custom_ops.device_guard(xb):
         custom_ops.check(lib.sgv_conv3x3_s2_fused(p, e, 0, custom_ops.raw_stream(xb)), lib)
     return y, a
@@ -54,30 +56,34 @@ class _FusedDownFn(torch.autograd.Function):
     def forward(ctx, xb, weight, bias, residual, cfg):
         act, alpha, gain, clamp = cfg
         b = bias.contiguous().float() if bias is not None else None
-        r = residual.contiguous() if residual is not None else None
         need_graph = any(ctx.needs_input_grad[:3])
-        y, a = _launch(xb.contiguous(), weight.contiguous(), b, r, r is not None and need_graph, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
+        y, a = _launch(xb.contiguous(), weight.contiguous(), b, residual, residual is not None and need_graph, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
+        if residual is not None:
+            ctx.mark_dirty(residual)
         ctx.cfg = cfg
+        ctx.has_res = residual is not None
         ctx.bias_dtype = bias.dtype if bias is not None else None
-        ctx.save_for_backward(xb, weight, bias, residual, a if a is not None else y)
+        # with a residual only the activation output is kept (the sum is not needed by any gradient)
+        ctx.save_for_backward(xb, weight, bias, a if residual is not None else y)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         act, alpha, gain, clamp = ctx.cfg
-        xb, weight, b, res, a = ctx.saved_tensors
+        xb, weight, b, a = ctx.saved_tensors
         if torch.is_grad_enabled():
-            # create_graph=True: differentiate the composition on the saved inputs (one extra forward, gradients of any order)
-            ins = [t for t, need in zip((xb, weight, b, res), ctx.needs_input_grad[:4]) if need and t is not None]
+            # create_graph=True: differentiate the composition on the saved inputs (one extra forward, gradients of any order); the residual enters
+            # the composition linearly, so its gradient is dy and a zero stand-in serves
+            ins = [t for t, need in zip((xb, weight, b), ctx.needs_input_grad[:3]) if need and t is not None]
             with torch.enable_grad():
-                y2 = strided_conv3x3_bias_act_composed(xb, weight, bias=b, act=act, alpha=alpha, gain=gain, clamp=(clamp if clamp >= 0 else None),
-                                                       residual=res.clone() if res is not None else None)
+                y2 = strided_conv3x3_bias_act_composed(xb, weight, bias=b, act=act, alpha=alpha, gain=gain, clamp=(clamp if clamp >= 0 else None))
                 grads = iter(torch.autograd.grad(y2, ins, dy, create_graph=True, allow_unused=True))
-            return tuple(next(grads) if (need and t is not None) else None for t, need in zip((xb, weight, b, res), ctx.needs_input_grad[:4])) + (None,)
+            out = tuple(next(grads) if (need and t is not None) else None for t, need in zip((xb, weight, b), ctx.needs_input_grad[:3]))
+            return out + (dy if (ctx.has_res and ctx.needs_input_grad[3]) else None, None)
         lib = custom_ops.get_native()
         dy = dy.contiguous()
         d_x = d_w = d_b = None
-        d_r = dy if (res is not None and ctx.needs_input_grad[3]) else None
+        d_r = dy if (ctx.has_res and ctx.needs_input_grad[3]) else None
         if any(ctx.needs_input_grad[:3]):
             n, co, h, w = a.shape
             need_db = b is not None and ctx.needs_input_grad[2]
@@ -115,7 +121,8 @@ def _fusable(xb, weight, bias, residual, act, alpha, gain, clamp):
     hs, ws_ = (hb - 1) // 2, (wb - 1) // 2
     if bias is not None and tuple(bias.shape) != (co,):
         return False
-    if residual is not None and (tuple(residual.shape) != (n, co, hs, ws_) or residual.dtype != torch.float32 or not residual.is_cuda):
+    if residual is not None and (tuple(residual.shape) != (n, co, hs, ws_) or residual.dtype != torch.float32 or not residual.is_cuda or not residual.is_contiguous()
+                                 or (residual.is_leaf and residual.requires_grad)):
         return False
     needs_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (xb, weight, bias, residual))
     if needs_graph and _fca.mode < 2:
