@@ -25,11 +25,13 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     if (!p->a || !p->b || !p->c) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: NULL pointer");
     if (p->m < 1 || p->n < 1 || p->k < 1 || p->batch < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: sizes must be positive");
     if (p->bias_mode < 0 || p->bias_mode > 2 || (p->bias_mode && !p->bias)) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: bad bias_mode");
-    if (p->batch > 65535) return sgv_fail(SGV_ERR_TOO_LARGE, "gemm: batch is too large");
+    const int ks = p->k_split > 1 ? p->k_split : 1;
+    if (ks > 1 && (p->k % ks != 0 || p->bias_mode != 0)) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: k_split must divide k and excludes a bias");
+    if ((int64_t)p->batch * ks > 65535) return sgv_fail(SGV_ERR_TOO_LARGE, "gemm: batch (x k_split) is too large");
     hipStream_t stream = (hipStream_t)stream_;
     gemm_params gp;
     gp.a = p->a; gp.b = p->b; gp.bias = p->bias; gp.c = p->c;
-    gp.m = p->m; gp.n = p->n; gp.k = p->k;
+    gp.m = p->m; gp.n = p->n; gp.k = p->k / ks; gp.ksplit = ks;
     gp.lda = p->lda; gp.ldb = p->ldb; gp.ldc = p->ldc;
     gp.trans_b = p->trans_b;
     gp.stride_a = p->stride_a; gp.stride_b = p->stride_b; gp.stride_c = p->stride_c;
@@ -40,14 +42,14 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     const double bytes = 4.0 * ((double)p->m * p->k * (p->stride_a ? p->batch : 1) + (double)p->n * p->k * (p->stride_b ? p->batch : 1) +
                                 (double)p->m * p->n * p->batch);
     sgv_launch_scope scope(SGV_K_GEMM, stream, bytes, flops);
-    dim3 grid((unsigned)(gp.tiles_m * gp.tiles_n), (unsigned)p->batch);
+    dim3 grid((unsigned)(gp.tiles_m * gp.tiles_n), (unsigned)(p->batch * ks));
     // Fast path (tools/gemm_lab.hip, profiles/r01_gemm_lab.log): whole tiles, 16-B aligned rows -> no bounds/alignment branches in
     // the K loop; 1x1 convolutions run bk16 + double-buffered LDS at 2 workgroups/CU, x @ w.T runs bk32.
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
-    const bool full16 = p->m % BM == 0 && p->n % BN == 0 && p->k % 16 == 0 && p->lda % 4 == 0 && p->ldb % 4 == 0 && p->stride_a % 4 == 0 &&
+    const bool full16 = p->m % BM == 0 && p->n % BN == 0 && gp.k % 16 == 0 && p->lda % 4 == 0 && p->ldb % 4 == 0 && p->stride_a % 4 == 0 &&
                         p->stride_b % 4 == 0 && al16(p->a) && al16(p->b);
     if (p->trans_b) {
-        if (full16 && p->k % 32 == 0) hipLaunchKernelGGL((gemm_f32_kernel<1, 32, 0, 1, 1>), grid, dim3(256), 0, stream, gp);
+        if (full16 && gp.k % 32 == 0) hipLaunchKernelGGL((gemm_f32_kernel<1, 32, 0, 1, 1>), grid, dim3(256), 0, stream, gp);
         else if (full16) hipLaunchKernelGGL((gemm_f32_kernel<1, 16, 1, 2, 1>), grid, dim3(256), 0, stream, gp);
         else hipLaunchKernelGGL((gemm_f32_kernel<1, 16, 0, 1, 0>), grid, dim3(256), 0, stream, gp);
     } else {

@@ -30,6 +30,7 @@ struct gemm_params {
     int64_t stride_a, stride_b, stride_c;
     int bias_mode;
     int tiles_m, tiles_n;
+    int ksplit;            // >= 1: slices of K per batch entry (k = slice length)
 };
 
 // [128 rows x BK] block of a row-major [rows, K] matrix (k contiguous): thread t -> row t/4 (+64 per pass), k-quad t%4 (+4 per k-pass).
@@ -113,10 +114,10 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
     const int tile = blockIdx.x;
     const int tm = tile % p.tiles_m;  // M fastest: consecutive workgroups share the B panel
     const int tn = tile / p.tiles_m;
-    const int batch = blockIdx.y;
-    const float* A = p.a + batch * p.stride_a;
-    const float* B = p.b + batch * p.stride_b;
-    float* C = p.c + batch * p.stride_c;
+    const int batch = (int)blockIdx.y / p.ksplit, slice = (int)blockIdx.y - batch * p.ksplit;   // p.k is the slice length
+    const float* A = p.a + batch * p.stride_a + (int64_t)slice * p.k;
+    const float* B = p.b + batch * p.stride_b + (TRANS_B ? (int64_t)slice * p.k : (int64_t)slice * p.k * p.ldb);
+    float* C = p.c + (int64_t)blockIdx.y * p.stride_c;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int lane = threadIdx.x & 63;

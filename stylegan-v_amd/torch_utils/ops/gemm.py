@@ -14,13 +14,13 @@ from .. import custom_ops
 enabled = True  # conv2d_resample routes whole-tile fp32 1x1 convolutions here
 
 
-def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0, sc=0, bias_mode=0):
+def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0, sc=0, bias_mode=0, k_split=1):
     lib = custom_ops.get_native()
     p = custom_ops.GemmParams()
     p.a, p.b, p.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
     p.m, p.n, p.k, p.lda, p.ldb, p.ldc = m, n, k, lda, ldb, ldc
-    p.trans_b, p.batch, p.stride_a, p.stride_b, p.stride_c, p.bias_mode = int(trans_b), batch, sa, sb, sc, bias_mode
+    p.trans_b, p.batch, p.stride_a, p.stride_b, p.stride_c, p.bias_mode, p.k_split = int(trans_b), batch, sa, sb, sc, bias_mode, k_split
     with torch.cuda.device_of(c):
         custom_ops.check(lib.sgv_gemm_f32(p, torch.cuda.current_stream(c.device).cuda_stream), lib)
     return c
@@ -119,8 +119,14 @@ class _Conv1x1WeightGradFn(torch.autograd.Function):
         dyc, xc = dy.contiguous(), x.contiguous()
         n, cout, h, wd = dyc.shape
         cin, hw = xc.shape[1], h * wd
-        per = torch.empty([n, cout, cin], dtype=torch.float32, device=x.device)
-        _launch(dyc, xc, None, per, cout, cin, hw, hw, hw, cin, True, batch=n, sa=cout * hw, sb=cin * hw, sc=cout * cin)
+        # few output tiles, long K: cut K so that the launch has >= ~512 workgroups (a [128 x 64] gradient over 96 samples is 96 workgroups
+        # of 16384 k-steps each otherwise: 1.5 ms where the operands stream in 0.3)
+        tiles = ((cout + 127) // 128) * ((cin + 127) // 128)
+        ks = 1
+        while n * tiles * ks < 512 and ks < 16 and hw % (ks * 2 * 32) == 0 and n * ks * 2 <= 65535:
+            ks *= 2
+        per = torch.empty([n * ks, cout, cin], dtype=torch.float32, device=x.device)
+        _launch(dyc, xc, None, per, cout, cin, hw, hw, hw, cin, True, batch=n, sa=cout * hw, sb=cin * hw, sc=cout * cin, k_split=ks)
         ctx.save_for_backward(dy, x)
         return per.sum(0)
 

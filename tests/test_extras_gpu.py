@@ -156,7 +156,7 @@ def test_conv2d_resample_routes_whole_tile_1x1_to_mfma_gemm_with_second_order_gr
         assert_close(a, r, atol=1e-4, rtol=1e-4, what='R1 d' + name)
 
 
-@pytest.mark.parametrize('n,cin,cout,h', [(3, 64, 128, 16), (2, 256, 512, 32), (2, 3, 64, 32), (1, 130, 70, 9), (2, 128, 256, 64), (2, 512, 512, 16), (2, 48, 128, 16)])
+@pytest.mark.parametrize('n,cin,cout,h', [(3, 64, 128, 16), (2, 256, 512, 32), (2, 3, 64, 32), (1, 130, 70, 9), (2, 128, 256, 64), (2, 512, 512, 16), (2, 48, 128, 16), (2, 64, 128, 128)])
 def test_gemm_conv1x1(n, cin, cout, h):
     g = torch.Generator().manual_seed(n + cin)
     x = torch.randn([n, cin, h, h], generator=g).to(DEV).requires_grad_(True)
