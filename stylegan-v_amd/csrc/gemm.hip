@@ -17,6 +17,7 @@
 
 #include "sgv_common.h"
 #include "gemm_kernel.h"
+#include <stdlib.h>
 
 using namespace sgv_gemm;
 
@@ -48,7 +49,13 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     auto al16 = [](const void* q) { return ((uintptr_t)q & 15) == 0; };
     const bool full16 = p->m % BM == 0 && p->n % BN == 0 && gp.k % 16 == 0 && p->lda % 4 == 0 && p->ldb % 4 == 0 && p->stride_a % 4 == 0 &&
                         p->stride_b % 4 == 0 && al16(p->a) && al16(p->b);
-    if (p->trans_b) {
+    static const bool allow_nk = !(getenv("SGV_GEMM_FULLNK") && getenv("SGV_GEMM_FULLNK")[0] == '0');
+    const bool full_nk = allow_nk && !full16 && p->n % BN == 0 && gp.k % 16 == 0 && p->lda % 4 == 0 && p->ldb % 4 == 0 && p->stride_a % 4 == 0 && p->stride_b % 4 == 0 &&
+                         al16(p->a) && al16(p->b);
+    if (full_nk) {   // whole tiles along n and k, any m
+        if (p->trans_b) hipLaunchKernelGGL((gemm_f32_kernel<1, 16, 1, 2, 2>), grid, dim3(256), 0, stream, gp);
+        else hipLaunchKernelGGL((gemm_f32_kernel<0, 16, 1, 2, 2>), grid, dim3(256), 0, stream, gp);
+    } else if (p->trans_b) {
         if (full16 && gp.k % 32 == 0) hipLaunchKernelGGL((gemm_f32_kernel<1, 32, 0, 1, 1>), grid, dim3(256), 0, stream, gp);
         else if (full16) hipLaunchKernelGGL((gemm_f32_kernel<1, 16, 1, 2, 1>), grid, dim3(256), 0, stream, gp);
         else hipLaunchKernelGGL((gemm_f32_kernel<1, 16, 0, 1, 0>), grid, dim3(256), 0, stream, gp);

@@ -43,7 +43,8 @@ __device__ __forceinline__ void load_rowmajor_k(const float* base, int64_t ld, i
     for (int kp = 0; kp < BK / 16; kp++)
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {
-            const int r = row0 + (t >> 2) + pass * 64;
+            int r = row0 + (t >> 2) + pass * 64;
+            if (FULL == 2) r = min(r, rows - 1);   // rows beyond the matrix repeat its last row; their products land in accumulator rows that are never stored
             const int kq = k0 + kp * 16 + (t & 3) * 4;
             const float* p = base + (int64_t)r * ld + kq;
             const bool row_ok = r < rows;
@@ -106,6 +107,7 @@ __device__ __forceinline__ void store_rowmajor_c(float (*lds)[LDT], const frag_k
 }
 
 // FULL = 1: the host guarantees m % 128 == n % 128 == k % BK == 0 and 16-B aligned rows -> no bounds or alignment branches.
+// FULL = 2: the same for n and k only; m is arbitrary (the 64-row products of the discriminator's first skip branch): A rows are clamped, C rows masked.
 template <int TRANS_B, int BK, int DBUF, int MINWG, int FULL>
 __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
     __shared__ __attribute__((aligned(16))) float As[DBUF + 1][BK][LDT];
@@ -136,9 +138,10 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
     frag_rk<BK> fa;
     frag_rk<BK> fb_t;
     frag_kc<BK> fb_n;
+    constexpr int FB = FULL ? 1 : 0;
     load_rowmajor_k<BK, FULL>(A, p.lda, m0, p.m, 0, p.k, fa);
-    if (TRANS_B) load_rowmajor_k<BK, FULL>(B, p.ldb, n0, p.n, 0, p.k, fb_t);
-    else load_rowmajor_c<BK, FULL>(B, p.ldb, n0, p.n, 0, p.k, fb_n);
+    if (TRANS_B) load_rowmajor_k<BK, FB>(B, p.ldb, n0, p.n, 0, p.k, fb_t);
+    else load_rowmajor_c<BK, FB>(B, p.ldb, n0, p.n, 0, p.k, fb_n);
 
     int cur = 0;
     for (int k0 = 0; k0 < p.k; k0 += BK) {
@@ -149,8 +152,8 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
         __syncthreads();
         if (k0 + BK < p.k) {  // prefetch the next tile into registers; lands during the MFMAs below
             load_rowmajor_k<BK, FULL>(A, p.lda, m0, p.m, k0 + BK, p.k, fa);
-            if (TRANS_B) load_rowmajor_k<BK, FULL>(B, p.ldb, n0, p.n, k0 + BK, p.k, fb_t);
-            else load_rowmajor_c<BK, FULL>(B, p.ldb, n0, p.n, k0 + BK, p.k, fb_n);
+            if (TRANS_B) load_rowmajor_k<BK, FB>(B, p.ldb, n0, p.n, k0 + BK, p.k, fb_t);
+            else load_rowmajor_c<BK, FB>(B, p.ldb, n0, p.n, k0 + BK, p.k, fb_n);
         }
         // Operands of step kk+2 are fetched from LDS while the four MFMAs of step kk run.
         float a0 = As[cur][lk][wm + lr], a1 = As[cur][lk][wm + 32 + lr];
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                if (!FULL && row >= p.m) continue;
+                if (FULL != 1 && row >= p.m) continue;
                 float v = acc[i][j][e] + bcol;
                 if (p.bias_mode == 2) v += p.bias[row];
                 C[(int64_t)row * p.ldc + col] = v;

@@ -125,6 +125,12 @@ class _Conv1x1WeightGradFn(torch.autograd.Function):
         ks = 1
         while n * tiles * ks < 512 and ks < 16 and hw % (ks * 2 * 32) == 0 and n * ks * 2 <= 65535:
             ks *= 2
+        if cin % 128 != 0 and cout % 128 == 0:
+            # the kernel's branch-free path wants whole 128-column tiles (rows are free): compute the transpose, rows = cin
+            per = torch.empty([n * ks, cin, cout], dtype=torch.float32, device=x.device)
+            _launch(xc, dyc, None, per, cin, cout, hw, hw, hw, cout, True, batch=n, sa=cin * hw, sb=cout * hw, sc=cout * cin, k_split=ks)
+            ctx.save_for_backward(dy, x)
+            return per.sum(0).t()
         per = torch.empty([n * ks, cout, cin], dtype=torch.float32, device=x.device)
         _launch(dyc, xc, None, per, cout, cin, hw, hw, hw, cin, True, batch=n, sa=cout * hw, sb=cin * hw, sc=cout * cin, k_split=ks)
         ctx.save_for_backward(dy, x)
