@@ -20,6 +20,10 @@
 
 #include "wrw_kernel.h"
 
+#ifndef SGV_WRW_RPM
+#define SGV_WRW_RPM 2
+#endif
+
 namespace sgv_wrw {
 
 // VIEWS = 3: the producers write three column-shifted copies of every x row (kx = 0, 1, 2) and the consumers issue aligned 16-B reads only;
@@ -31,7 +35,8 @@ constexpr int WS_DS = 2 * 3 * WS_DBUF;           // [hl][3 buffers][64][RS]
 constexpr int wrw_ws_lds_bytes(int views) { return (2 * 4 * views * WS_VIEW + WS_DS) * 2; }
 constexpr int WRW_WS_LDS_BYTES = wrw_ws_lds_bytes(3);
 
-template <int TERMS, int VIEWS = 1>
+// ABL (tools/wrw_lab.hip only; wrong results by construction): 6 consumers only keep the barrier protocol, 7 producers only keep it.
+template <int TERMS, int VIEWS = 1, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
     constexpr int WS_XSLOT = VIEWS * WS_VIEW;        // bf16 per (slot, hl)
     constexpr int WS_XS = 2 * 4 * WS_XSLOT;          // [hl][4 slots][views][64][RS]
@@ -70,6 +75,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         };
         // branch-free: out-of-image rows / columns load from a clamped address and are zeroed when they are written to LDS
         auto load_x = [&](int row, xrow& r) {
+            if (ABL == 7) return;
             r.ok = row >= 0 && row < p.h;
             r.okl = r.ok && x0 + lq - 1 >= 0;
             r.okr = r.ok && x0 + lq + 8 < p.w;
@@ -80,6 +86,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             asm volatile("global_load_dword %0, %1, off" : "=v"(r.r) : "v"(q + (r.okr ? 8 : 7)) : "memory");
         };
         auto load_dy = [&](int row, drow& r) {   // row is always inside the unit
+            if (ABL == 7) return;
             const float* q = dyb + (size_t)row * p.w;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a) : "v"(q) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b) : "v"(q + 4) : "memory");
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             lo = pack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
         };
         auto store_x = [&](int row, const xrow& r) {
+            if (ABL == 7) return;
             float v[10];
             v[0] = r.okl ? r.l : 0.f;
             v[9] = r.okr ? r.r : 0.f;
@@ -124,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             }
         };
         auto store_dy = [&](int buf, const drow& r) {
+            if (ABL == 7) return;
             float v[8];
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = r.a[k]; v[4 + k] = r.b[k]; }
@@ -249,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             // six sub-steps j = (c, ky): operands of sub-step j+1 are fetched before the nine MFMAs of sub-step j; the last one fetches the
             // first operands of row y+1 (dy row y+1 and x row y have been in LDS since before the previous barrier)
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
+            for (int j = 0; j < (ABL == 6 ? 0 : 6); j++) {
                 const int c = j / 3, ky = j % 3;
                 const int cur = j & 1, nxt = cur ^ 1;
                 int reads = RB;
@@ -278,10 +287,14 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
                 for (int kx = 0; kx < 3; kx++)
                     acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bh[kx]), acc[ky * 3 + kx], 0, 0, 0);
                 constexpr int MF = TERMS > 1 ? 9 : 3;
+                // RPM operand reads behind each of the first MFMAs: the earlier the last read issues, the more MFMAs cover its LDS latency
+                constexpr int RPM = TERMS > 1 ? SGV_WRW_RPM : 3;
 #pragma unroll
                 for (int i = 0; i < MF; i++) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+                    for (int r2 = 0; r2 < RPM; r2++)
+                        if (i * RPM + r2 < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

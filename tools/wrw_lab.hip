@@ -55,11 +55,15 @@ template <int TERMS> static void launch(const wrw_params& p) {
     hipLaunchKernelGGL(wrw3x3_kernel<TERMS>, grid, dim3(256), 0, 0, p);
 }
 
-template <int TERMS, int VIEWS> static void launch_ws(const wrw_params& p) {   // producer / consumer form (wrw_ws_kernel.h)
+template <int TERMS, int VIEWS, int ABL> static void launch_ws_abl(const wrw_params& p) {
     static bool attr = false;
-    if (!attr) { CK(hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<TERMS, VIEWS>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(VIEWS))); attr = true; }
+    if (!attr) { CK(hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<TERMS, VIEWS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(VIEWS))); attr = true; }
     dim3 grid((p.o / TO) * p.tiles_i, p.splits);
-    hipLaunchKernelGGL((wrw3x3_ws_kernel<TERMS, VIEWS>), grid, dim3(512), wrw_ws_lds_bytes(VIEWS), 0, p);
+    hipLaunchKernelGGL((wrw3x3_ws_kernel<TERMS, VIEWS, ABL>), grid, dim3(512), wrw_ws_lds_bytes(VIEWS), 0, p);
+}
+template <int TERMS, int VIEWS> static void launch_ws(const wrw_params& p) {   // producer / consumer form (wrw_ws_kernel.h); WRW_ABL = 6 / 7: ablations
+    static const int abl = getenv("WRW_ABL") ? atoi(getenv("WRW_ABL")) : 0;
+    if (abl == 6) launch_ws_abl<TERMS, VIEWS, 6>(p); else if (abl == 7) launch_ws_abl<TERMS, VIEWS, 7>(p); else launch_ws_abl<TERMS, VIEWS, 0>(p);
 }
 
 __global__ void naive_wrw_s2(const float* sm, const float* big, double* dw, int n, int cs, int cb, int h, int w) {
