@@ -271,9 +271,15 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
                            p->c_in, p->c_out, p->h, p->w);
         return sgv_check_launch("convT3x3_s2_edge_kernel");
     }
-    // last output row (oy = 2H) and column (ox = 2W): 0.4 % of the flops, one launch on the fp32 matrix pipe, x and w read in place
-    hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2), dim3(64), 0, stream, (const float*)p->x,
-                       p->weight, (float*)p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+    // last output row (oy = 2H) and column (ox = 2W): 0.4 % of the flops on the fp32 matrix pipe, after one pass that lays the six weight taps
+    // and the last input column out contiguously
+    {
+        float* edge = (float*)((char*)p->workspace + (size_t)p->c_in * p->c_out * 10 * 4);
+        const size_t prep = convT3x3_s2_edge_we_floats(p->c_in, p->c_out) + (size_t)p->n * p->c_in * p->h;
+        hipLaunchKernelGGL(convT3x3_s2_edge_prep, dim3((unsigned)((prep + 255) / 256)), dim3(256), 0, stream, (const float*)p->x, p->weight, edge, p->n, p->c_in, p->c_out, p->h, p->w);
+        hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2), dim3(64), 0, stream, (const float*)p->x,
+                           edge, (float*)p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+    }
     return sgv_check_launch("convT3x3_s2_edge_mfma");
 }
 

@@ -431,16 +431,36 @@ __global__ __launch_bounds__(128) void convT3x3_s2_edge_kernel(const float* edge
     for (int j = 0; j < EDGE_MC; j++) yb[(size_t)j * hout * wout] = accv[j];
 }
 
-// convT3x3_s2_edge_mfma: both strips in one launch on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; plain fp32 products), reading x and w in place.
+// convT3x3_s2_edge_prep + convT3x3_s2_edge_mfma: both strips in one launch on the fp32 matrix pipe (v_mfma_f32_32x32x2_f32; plain fp32 products).
 // A wave owns 32 output channels x 32 source positions i of one (sample, strip) and keeps two accumulator tiles:
 //   even outputs  2i   = sum_k wt[0](m,k) * src(k,i) + wt[2](m,k) * src(k,i-1)
 //   odd outputs   2i+1 = sum_k wt[1](m,k) * src(k,i)
 // with (row strip, oy = 2H) src(k,i) = x[n,k,H-1,i], wt[t] = w[k][m][2][t] and (column strip, ox = 2W, without the corner) src(k,i) = x[n,k,i,W-1],
 // wt[t] = w[k][m][t][2].  MFMA operands are one float per lane: A lane (m = lane & 31, k = k0 + (lane >> 5)), B lane (i = lane & 31, same k).
-// grid = (ceil((max(H, W) + 1) / 32), n * (m / 32), 2 strips), 64 threads.
+// Reading w (stride 9 floats over m) and the column x[:, :, :, W-1] (stride W) in place makes every load touch 10-32 cache lines and the kernel
+// address-unit bound (0.25 ms per layer); the prep kernel lays both out once:  edge = we[strip][tap][k][m] (2*3*K*M floats), col[n][k][H].
+__host__ __device__ inline size_t convT3x3_s2_edge_we_floats(int k, int m) { return (size_t)2 * 3 * k * m; }
+
+__global__ __launch_bounds__(256) void convT3x3_s2_edge_prep(const float* x, const float* w, float* edge, int n, int k, int m, int h, int wd) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n_w = convT3x3_s2_edge_we_floats(k, m), n_col = (size_t)n * k * h;
+    if (idx < n_w) {
+        size_t j = idx;
+        const int mm = j % m; j /= m;
+        const int kk = j % k; j /= k;
+        const int tap = j % 3; const int strip = j / 3;
+        edge[idx] = w[((size_t)kk * m + mm) * 9 + (strip == 0 ? 6 + tap : 3 * tap + 2)];
+    } else if (idx < n_w + n_col) {
+        const size_t j = idx - n_w;
+        const size_t c = j / h; const int i = j % h;
+        edge[idx] = x[(c * h + i) * wd + (wd - 1)];
+    }
+}
+
 typedef float f32x16e __attribute__((ext_vector_type(16)));
 
-__global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, const float* w, float* y, int n, int k, int m, int h, int wd) {
+// grid = (ceil((max(H, W) + 1) / 32), n * (m / 32), 2 strips), 64 threads.
+__global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, const float* edge, float* y, int n, int k, int m, int h, int wd) {
     const int strip = blockIdx.z;
     const int ls = strip == 0 ? wd : h;               // source line length
     const int lo = strip == 0 ? 2 * wd + 1 : 2 * h;   // outputs of the strip
@@ -452,30 +472,28 @@ __global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, cons
     const int i = i0 + l32;
     const bool vb = i < ls, vm = i >= 1 && i - 1 < ls;
     const size_t plane = (size_t)h * wd;
-    // src(k, i) = xs[k * plane + i * sstep]
-    const float* xs = x + (size_t)nn * k * plane + (strip == 0 ? (size_t)(h - 1) * wd : (size_t)(wd - 1));
-    const size_t sstep = strip == 0 ? 1 : wd;
-    const float* pb = xs + (size_t)(vb ? i : 0) * sstep + (size_t)g * plane;
-    const float* pm = xs + (size_t)(vm ? i - 1 : 0) * sstep + (size_t)g * plane;
-    // wt[t](m, k) = w[(k * M + m) * 9 + off_t]
-    const int o0 = strip == 0 ? 6 : 2, ostep = strip == 0 ? 1 : 3;
-    const float* pw = w + ((size_t)g * m + m0 + l32) * 9 + o0;
-    const size_t wk = (size_t)2 * m * 9, xk = 2 * plane;
+    // src(k, i) = xs[k * kstep + i]: the row strip reads x[n, k, H-1, :] in place, the column strip its gathered copy
+    const float* xs = strip == 0 ? x + (size_t)nn * k * plane + (size_t)(h - 1) * wd : edge + convT3x3_s2_edge_we_floats(k, m) + (size_t)nn * k * h;
+    const size_t kstep = strip == 0 ? plane : (size_t)h;
+    const float* pb = xs + (vb ? i : 0) + (size_t)g * kstep;
+    const float* pm = xs + (vm ? i - 1 : 0) + (size_t)g * kstep;
+    const size_t tk = (size_t)k * m;                  // floats per tap
+    const float* pw = edge + (size_t)strip * 3 * tk + (size_t)g * m + m0 + l32;
+    const size_t wk = (size_t)2 * m, xk = 2 * kstep;
 
     f32x16e acc_e, acc_o;
 #pragma unroll
     for (int e = 0; e < 16; e++) { acc_e[e] = 0.f; acc_o[e] = 0.f; }
-    constexpr int U = 4;   // k pairs in flight
+    constexpr int U = 4;   // k pairs in flight (k is a multiple of 16)
     for (int k0 = 0; k0 < k; k0 += 2 * U) {
         float a0[U], a1[U], a2[U], b[U], bm[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const bool ok = k0 + 2 * u < k;   // k is even; the tail of a k that is not a multiple of 8 is skipped
-            a0[u] = ok ? pw[u * wk] : 0.f;
-            a1[u] = ok ? pw[u * wk + ostep] : 0.f;
-            a2[u] = ok ? pw[u * wk + 2 * ostep] : 0.f;
-            b[u] = ok && vb ? pb[u * xk] : 0.f;
-            bm[u] = ok && vm ? pm[u * xk] : 0.f;
+            a0[u] = pw[u * wk];
+            a1[u] = pw[u * wk + tk];
+            a2[u] = pw[u * wk + 2 * tk];
+            b[u] = vb ? pb[u * xk] : 0.f;
+            bm[u] = vm ? pm[u * xk] : 0.f;
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {

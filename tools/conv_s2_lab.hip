@@ -106,7 +106,11 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
         if (!g_ws) hipLaunchKernelGGL(convT3x3_s2_kernel<TERMS>, dim3(p.grid), dim3(512), T_LDS_BYTES, 0, p);
         if (getenv("NO_EDGE")) return;
         if (g_ws) {
-            hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3(((h > wd ? h : wd) + 1 + 31) / 32, n * (m / 32), 2), dim3(64), 0, 0, x, w, y, n, k, m, h, wd);
+            static float* e2 = nullptr; static size_t e2_cap = 0;
+            const size_t prep = convT3x3_s2_edge_we_floats(k, m) + (size_t)n * k * h;
+            if (prep > e2_cap) { if (e2) CK(hipFree(e2)); CK(hipMalloc(&e2, prep * 4)); e2_cap = prep; }
+            hipLaunchKernelGGL(convT3x3_s2_edge_prep, dim3((prep + 255) / 256), dim3(256), 0, 0, x, w, e2, n, k, m, h, wd);
+            hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3(((h > wd ? h : wd) + 1 + 31) / 32, n * (m / 32), 2), dim3(64), 0, 0, x, e2, y, n, k, m, h, wd);
             return;
         }
         static float* edge = nullptr; static size_t edge_cap = 0;
