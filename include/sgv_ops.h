@@ -195,6 +195,15 @@ int sgv_pointwise_small(const sgv_pointwise_params* p, int dtype, void* stream);
 int sgv_pointwise_act(const sgv_pointwise_params* p, const float* bias, int32_t act, float alpha, float gain, float clamp, int dtype, void* stream);
 int sgv_pointwise_outer(const void* a_few, const void* b_many, float* out, int32_t n, int32_t c_few, int32_t c_many, int32_t hw,
                         int dtype, void* stream);
+/* The backward pass of sgv_pointwise_act without materialising the activation gradient dz = bias_act'(dy; y) (grad 1 from the saved output,
+ * linear / lrelu, gain, clamp mask):
+ *   sgv_pointwise_small_gradin : kind 0 with x = dy turned into dz on its way in            -> the input gradient  dx[n,f,p] = sum_m w[f,m] dz[n,m,p]
+ *   sgv_pointwise_outer_act    : out[n,f,m] += sum_p a[n,f,p] dz[n,m,p]; with ones_row the last of the c_few planes is the constant 1 (a holds
+ *                                c_few - 1 planes), so that row c_few - 1 of out is the bias gradient    -> weight and bias gradients in one pass
+ * fp32 tensors, 16-byte aligned. */
+int sgv_pointwise_small_gradin(const sgv_pointwise_params* p, const void* yref, int32_t act, float alpha, float gain, float clamp, int dtype, void* stream);
+int sgv_pointwise_outer_act(const void* a_few, const void* dy_many, const void* yref, float* out, int32_t n, int32_t c_few, int32_t c_many, int32_t hw,
+                            int32_t ones_row, int32_t act, float alpha, float gain, float clamp, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Weight gradient of a 3x3 / stride 1 / pad 1 convolution on dense NCHW tensors:

@@ -40,6 +40,14 @@ template <typename T> __device__ __forceinline__ void store4(T* p, const float* 
     *(px4<T>*)p = q;
 }
 
+// bias_act's first derivative for the two activations of this path, from the saved OUTPUT y (bias_act.cu:51-142 with yref): linear / lrelu slope
+// times gain, zero where the output sat on the clamp
+__device__ __forceinline__ float pw_act_grad(float dy, float y, int act, float alpha, float gain, float clamp) {
+    float dz = ((act == 3 && !(y > 0.f)) ? dy * alpha : dy) * gain;
+    if (clamp >= 0.f && !(y > -clamp & y < clamp)) dz = 0.f;
+    return dz;
+}
+
 struct pw_params {
     const void* x;
     const float* w;
@@ -51,6 +59,8 @@ struct pw_params {
     const float* bias;
     int act;
     float alpha, gain, clamp;
+    // many2few prologue (sgv_pointwise_small_gradin): x is a gradient dy and is turned into pw_act_grad(dy, yref) on its way in
+    const void* yref;
 };
 
 // MS == 1: grid = (ceil(hw/4/256), n), lane -> pixel quad, every lane walks all M planes.
@@ -77,6 +87,12 @@ __global__ __launch_bounds__(256) void pw_many2few_kernel(pw_params p) {
     for (int m = m0; m < m1; m++) {
         float v[4];
         load4<T>(x + (size_t)m * p.hw, v);
+        if (p.yref) {
+            float yv[4];
+            load4<T>((const T*)p.yref + (x - (const T*)p.x) + (size_t)m * p.hw, yv);
+#pragma unroll
+            for (int i = 0; i < 4; i++) v[i] = pw_act_grad(v[i], yv[i], p.act, p.alpha, p.gain, p.clamp);
+        }
 #pragma unroll
         for (int f = 0; f < F; f++) {
             const float wf = w[f * p.cm + m];
@@ -154,6 +170,12 @@ struct outer_params {
     int chunk;       // pixels per workgroup (multiple of 1024)
     int use_lds;     // reduce the 4 waves of a workgroup through LDS before the atomics
     int m_per_z;     // planes of the many side per blockIdx.z slice
+    // sgv_pointwise_outer_act: b is a gradient dy that becomes pw_act_grad(dy, yref); with ones_row the last few-side plane is the constant 1
+    // (not in memory: a has F - 1 planes), so that out[n, F-1, m] = sum_p dz = the bias gradient
+    const void* yref;
+    int act;
+    float alpha, gain, clamp;
+    int ones_row;
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -169,8 +191,9 @@ __global__ __launch_bounds__(256) void pw_outer_kernel(outer_params p) {
     const int p0 = blockIdx.x * p.chunk;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     extern __shared__ float red[];   // [4 waves][F][cm] partial sums when p.use_lds
-    const T* a = (const T*)p.a + (size_t)n * F * p.hw;
+    const T* a = (const T*)p.a + (size_t)n * (p.ones_row ? F - 1 : F) * p.hw;
     const T* b = (const T*)p.b + (size_t)n * p.cm * p.hw;
+    const T* yr = p.yref ? (const T*)p.yref + (size_t)n * p.cm * p.hw : nullptr;
     float av[F][PQ][4];
     int pix[PQ];
 #pragma unroll
@@ -178,7 +201,9 @@ __global__ __launch_bounds__(256) void pw_outer_kernel(outer_params p) {
         pix[k] = p0 + (k * 256 + threadIdx.x) * 4;
 #pragma unroll
         for (int f = 0; f < F; f++) {
-            if (pix[k] < p.hw && pix[k] < p0 + p.chunk) load4<T>(a + (size_t)f * p.hw + pix[k], av[f][k]);
+            const bool in = pix[k] < p.hw && pix[k] < p0 + p.chunk;
+            if (in && p.ones_row && f == F - 1) { av[f][k][0] = av[f][k][1] = av[f][k][2] = av[f][k][3] = 1.f; }
+            else if (in) load4<T>(a + (size_t)f * p.hw + pix[k], av[f][k]);
             else { av[f][k][0] = av[f][k][1] = av[f][k][2] = av[f][k][3] = 0.f; }
         }
     }
@@ -192,6 +217,12 @@ __global__ __launch_bounds__(256) void pw_outer_kernel(outer_params p) {
             if (pix[k] < p.hw && pix[k] < p0 + p.chunk) {
                 float bv[4];
                 load4<T>(b + (size_t)m * p.hw + pix[k], bv);
+                if (yr) {
+                    float yv[4];
+                    load4<T>(yr + (size_t)m * p.hw + pix[k], yv);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) bv[i] = pw_act_grad(bv[i], yv[i], p.act, p.alpha, p.gain, p.clamp);
+                }
 #pragma unroll
                 for (int f = 0; f < F; f++)
 #pragma unroll
@@ -282,7 +313,7 @@ extern "C" int sgv_pointwise_small(const sgv_pointwise_params* p, int dtype, voi
     if (rc != SGV_OK) return rc;
     if (p->kind != 0 && p->kind != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise: kind must be 0 (many->few) or 1 (few->many)");
     hipStream_t stream = (hipStream_t)stream_;
-    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, nullptr, 0, 0.f, 1.f, -1.f};
+    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, nullptr, 0, 0.f, 1.f, -1.f, nullptr};
     const double bytes = (double)(p->c_many + p->c_few) * p->n * p->hw * sgv_dtype_size(dtype);
     sgv_launch_scope scope(SGV_K_POINTWISE, stream, bytes, 2.0 * p->c_many * p->c_few * (double)p->n * p->hw);
     switch (dtype) {
@@ -302,7 +333,7 @@ extern "C" int sgv_pointwise_act(const sgv_pointwise_params* p, const float* bia
     if (dtype != SGV_F32) return sgv_fail(SGV_ERR_UNSUPPORTED, "pointwise_act: fp32 only (a 16-bit composition rounds between the two steps)");
     if (act != 1 && act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_act: act must be 1 (linear) or 3 (lrelu)");
     hipStream_t stream = (hipStream_t)stream_;
-    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, bias, act, alpha, gain, clamp};
+    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, bias, act, alpha, gain, clamp, nullptr};
     const double bytes = (double)(p->c_many + p->c_few) * p->n * p->hw * 4.0;
     sgv_launch_scope scope(SGV_K_POINTWISE, stream, bytes, 2.0 * p->c_many * p->c_few * (double)p->n * p->hw);
     rc = launch_pw<float>(1, pp, stream);
@@ -315,7 +346,7 @@ extern "C" int sgv_pointwise_outer(const void* a_few, const void* b_many, float*
     int rc = check_common(a_few, b_many, out, n, c_many, c_few, hw, dtype, "pointwise_outer");
     if (rc != SGV_OK) return rc;
     hipStream_t stream = (hipStream_t)stream_;
-    outer_params op{a_few, b_many, out, n, c_many, c_few, hw, 4096, 0, c_many};
+    outer_params op{a_few, b_many, out, n, c_many, c_few, hw, 4096, 0, c_many, nullptr, 0, 0.f, 1.f, -1.f, 0};
     const double bytes = (double)(c_many + c_few) * n * hw * sgv_dtype_size(dtype);
     sgv_launch_scope scope(SGV_K_POINTWISE, stream, bytes, 2.0 * c_many * c_few * (double)n * hw);
     switch (dtype) {
@@ -323,6 +354,38 @@ extern "C" int sgv_pointwise_outer(const void* a_few, const void* b_many, float*
         case SGV_F16: rc = launch_outer<sgv_half_t>(op, stream); break;
         default: rc = launch_outer<sgv_bf16_t>(op, stream); break;
     }
+    if (rc != SGV_OK) return rc;
+    return sgv_check_launch("pointwise_outer kernel");
+}
+
+extern "C" int sgv_pointwise_small_gradin(const sgv_pointwise_params* p, const void* yref, int32_t act, float alpha, float gain, float clamp, int dtype, void* stream_) {
+    if (!p || !yref) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_gradin: NULL pointer");
+    int rc = check_common(p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, dtype, "pointwise_gradin");
+    if (rc != SGV_OK) return rc;
+    if (p->kind != 0 || dtype != SGV_F32) return sgv_fail(SGV_ERR_UNSUPPORTED, "pointwise_gradin: the many -> few form (kind 0) on fp32 tensors only");
+    if (act != 1 && act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_gradin: act must be 1 (linear) or 3 (lrelu)");
+    if (((uintptr_t)yref) % 16 != 0) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_gradin: yref must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, nullptr, act, alpha, gain, clamp, yref};
+    sgv_launch_scope scope(SGV_K_POINTWISE, stream, (double)(2 * p->c_many + p->c_few) * p->n * p->hw * 4.0, 2.0 * p->c_many * p->c_few * (double)p->n * p->hw);
+    rc = launch_pw<float>(0, pp, stream);
+    if (rc != SGV_OK) return rc;
+    return sgv_check_launch("pointwise kernel");
+}
+
+extern "C" int sgv_pointwise_outer_act(const void* a_few, const void* dy_many, const void* yref, float* out, int32_t n, int32_t c_few, int32_t c_many, int32_t hw,
+                                       int32_t ones_row, int32_t act, float alpha, float gain, float clamp, int dtype, void* stream_) {
+    if (!yref) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_outer_act: NULL pointer");
+    int rc = check_common(a_few, dy_many, out, n, c_many, c_few, hw, dtype, "pointwise_outer_act");
+    if (rc != SGV_OK) return rc;
+    if (dtype != SGV_F32) return sgv_fail(SGV_ERR_UNSUPPORTED, "pointwise_outer_act: fp32 tensors only");
+    if (act != 1 && act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_outer_act: act must be 1 (linear) or 3 (lrelu)");
+    if (ones_row && c_few < 2) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_outer_act: ones_row needs c_few >= 2 (the constant plane is counted in c_few)");
+    if ((((uintptr_t)yref) | (uintptr_t)dy_many) % 16 != 0) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_outer_act: tensors must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    outer_params op{a_few, dy_many, out, n, c_many, c_few, hw, 4096, 0, c_many, yref, act, alpha, gain, clamp, ones_row ? 1 : 0};
+    sgv_launch_scope scope(SGV_K_POINTWISE, stream, (double)(2 * c_many + c_few) * n * hw * 4.0, 2.0 * c_many * c_few * (double)n * hw);
+    rc = launch_outer<float>(op, stream);
     if (rc != SGV_OK) return rc;
     return sgv_check_launch("pointwise_outer kernel");
 }

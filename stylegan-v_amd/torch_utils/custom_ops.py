@@ -240,6 +240,8 @@ ABI_SYMBOLS = {
     'sgv_scale_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'sgv_pointwise_small': (c_int, [ctypes.POINTER(PointwiseParams), c_int, c_void_p]),
     'sgv_pointwise_act': (c_int, [ctypes.POINTER(PointwiseParams), c_void_p, c_int32, c_float, c_float, c_float, c_int, c_void_p]),
+    'sgv_pointwise_small_gradin': (c_int, [ctypes.POINTER(PointwiseParams), c_void_p, c_int32, c_float, c_float, c_float, c_int, c_void_p]),
+    'sgv_pointwise_outer_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int, c_void_p]),
     'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_conv3x3': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
     'sgv_conv3x3_s2': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),

@@ -125,6 +125,34 @@ class _PointwiseActFn(torch.autograd.Function):
         x, w, b, y = ctx.saved_tensors
         bcfg = (1, act, alpha, gain, clamp)
         dy = dy.contiguous()
+        if not torch.is_grad_enabled() and dy.dtype == torch.float32 and x.shape[1] + 1 <= 4 and dy.data_ptr() % 16 == 0:
+            # first-order pass: the activation gradient dz is never written -- the weight + bias gradient kernel and the input gradient
+            # kernel evaluate it from (dy, y) on their way in
+            lib = custom_ops.get_native()
+            n, ci, h, wd = x.shape
+            co = w.shape[1]
+            aidx = _ba.activation_funcs[act].cuda_idx
+            dx = dw = db = None
+            need_dw = ctx.needs_input_grad[1] and not conv2d_gradfix.weight_gradients_disabled
+            need_db = b is not None and ctx.needs_input_grad[2]
+            with custom_ops.device_guard(dy):
+                stream = custom_ops.raw_stream(dy)
+                if need_dw or need_db:
+                    xc = x.contiguous()
+                    out = torch.zeros([n, ci + 1, co], dtype=torch.float32, device=dy.device)
+                    custom_ops.check(lib.sgv_pointwise_outer_act(xc.data_ptr(), dy.data_ptr(), y.data_ptr(), out.data_ptr(), n, ci + 1, co, h * wd, 1, aidx, alpha, gain,
+                                                                 clamp, _DTYPE_CODES[dy.dtype], stream), lib)
+                    tot = out.sum(0)                                  # [ci + 1, co]
+                    if need_dw:
+                        dw = tot[:ci].t().reshape(1, co, ci).to(w.dtype)
+                    if need_db:
+                        db = tot[ci].to(b.dtype)
+                if ctx.needs_input_grad[0]:
+                    wt = w.reshape(co, ci).t().contiguous().float()    # [ci, co]: dx[f] = sum_m w[m, f] dz[m]
+                    dx = torch.empty([n, ci, h, wd], dtype=torch.float32, device=dy.device)
+                    p = custom_ops.PointwiseParams(dy.data_ptr(), wt.data_ptr(), dx.data_ptr(), n, co, ci, h * wd, 0, 0)
+                    custom_ops.check(lib.sgv_pointwise_small_gradin(p, y.data_ptr(), aidx, alpha, gain, clamp, _DTYPE_CODES[dy.dtype], stream), lib)
+            return dx, dw, db, None
         dz, db = dy, None
         need_db = b is not None and ctx.needs_input_grad[2]
         if act != 'linear' or gain != 1 or clamp >= 0:

@@ -109,6 +109,18 @@ def test_fused_fromrgb_tail_is_bit_identical_to_the_two_pass_composition(act, cl
         assert custom_ops.launch_count() == before + 1
         assert torch.equal(yf, composed(x, wt, b))
 
+    # first-order pass (no graph of the gradient): weight + bias gradient and input gradient kernels evaluate the activation derivative from
+    # (dy, y) themselves -- two launches, no dz tensor
+    ins = [t for t in (x, wt, b) if t is not None]
+    dy = torch.randn(n, co, h, w, device='cuda')
+    yf = fused(x, wt, b)
+    before = custom_ops.launch_count()
+    got = torch.autograd.grad(yf, ins, dy)
+    assert custom_ops.launch_count() == before + 2
+    want = torch.autograd.grad(composed(x, wt, b), ins, dy)
+    for a, r, name in zip(got, want, 'xwb'):
+        assert_close(a, r, atol=2e-4 if name != 'x' else 1e-5, rtol=1e-5, what='first-order d' + name)
+
     def r1(fn):
         ins = [t for t in (x, wt, b) if t is not None]
         y = fn(x, wt, b)
