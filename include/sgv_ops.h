@@ -294,6 +294,8 @@ typedef struct sgv_conv3x3_s2_epilogue {
 } sgv_conv3x3_s2_epilogue;
 int sgv_conv3x3_s2_fused(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* e, int dtype, void* stream);
 int sgv_conv3x3_s2_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);
+/* as sgv_conv3x3_s2_supported, per mode: the transposed form (mode 2) also serves W = 16 / 8 with n % (32 / W) == 0, H % 4 == 0 */
+int sgv_conv3x3_s2_supported_mode(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode, int dtype);
 int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode);
 int sgv_conv3x3_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);
 int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out);

@@ -66,6 +66,10 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(2));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<3, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(2));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(4));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<3, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(4));
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
@@ -81,6 +85,12 @@ void init_once() {
 bool supported_s2(int n, int k, int m, int h, int w, int dtype) {   // h, w: the small (H x W) grid
     return dtype == SGV_F32 && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && w >= SEG && w % SEG == 0 && h >= S_ROWS && h % S_ROWS == 0 &&
            (int64_t)n * std::max(k, m) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
+}
+
+// W = 16 / 8: the producer / consumer kernels pack 2 / 4 samples into a 32-pixel tile row (transposed form so far)
+bool supported_s2_packed(int n, int k, int m, int h, int w, int mode, int dtype) {
+    if (!(dtype == SGV_F32 && mode == 2 && (w == 16 || w == 8))) return false;
+    return n >= 1 && n % (32 / w) == 0 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && h >= TW_ROWS && h % TW_ROWS == 0;
 }
 
 }  // namespace
@@ -185,7 +195,9 @@ bool pairs_shape(int c_out, int h) { return g_s2_ws && c_out % P2_TM == 0 && h %
 int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* ep, int dtype, void* stream_) {
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: params is NULL");
     if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: NULL pointer");
-    if (!supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
+    std::call_once(g_attr_once, init_once);
+    const bool packed = g_s2_ws && supported_s2_packed(p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
+    if (!packed && !supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, W %% 32 == 0, H %% 8 == 0 on the HxW grid (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_in, p->c_out, p->h, p->w, dtype);
     if (p->mode != 0 && p->mode != 2) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: mode must be 0 (strided convolution) or 2 (transposed convolution)");
@@ -250,7 +262,18 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         else hipLaunchKernelGGL(conv3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(256), S_LDS_BYTES, stream, kp);
         return sgv_check_launch("conv3x3_s2_kernel");
     }
-    if (g_s2_ws) {
+    if (packed) {
+        const int ss = 32 / p->w;
+        kp.tiles = (p->n / ss) * (p->h / TW_ROWS) * (p->c_out / TM);
+        kp.grid = std::min(kp.tiles, g_cus);
+        if (ss == 2) {
+            if (p->terms == 1) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<1, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
+            else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
+        } else {
+            if (p->terms == 1) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<1, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
+            else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
+        }
+    } else if (g_s2_ws) {
         kp.tiles = p->n * (p->h / TW_ROWS) * (p->w / SEG) * (p->c_out / TM);
         kp.grid = std::min(kp.tiles, g_cus);
         if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_ws_kernel<1>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
@@ -290,6 +313,11 @@ extern "C" int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stre
 extern "C" int sgv_conv3x3_s2_fused(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* e, int dtype, void* stream_) {
     if (!e) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: epilogue is NULL");
     return conv3x3_s2_impl(p, e, dtype, stream_);
+}
+
+extern "C" int sgv_conv3x3_s2_supported_mode(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode, int dtype) {
+    std::call_once(g_attr_once, init_once);
+    return supported_s2(n, c_in, c_out, h, w, dtype) || (g_s2_ws && supported_s2_packed(n, c_in, c_out, h, w, mode, dtype)) ? 1 : 0;
 }
 
 extern "C" int sgv_conv3x3_s2_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {

@@ -569,16 +569,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
 // still orders everything (image (q+2) % 3 was last read in iteration q-1).
 constexpr int TW_ROWS = 4;
 constexpr int TW_RIN = TW_ROWS + 1;                      // rows y0-1 .. y0+3
-constexpr int TW_PW = 33;                                // columns x0-1 .. x0+31
-constexpr int TW_XS_PLANE = TW_RIN * TW_PW;              // words per (hl, octet)
-constexpr int TW_XS_WORDS = 4 * TW_XS_PLANE;
-constexpr int TW_IMAGE_WORDS = TW_XS_WORDS + WS_WORDS;
+// S = samples per 32-pixel tile row: 1 (W % 32 == 0: a 32-px segment of one sample, columns x0-1 .. x0+31) or 2 / 4 (W = 16 / 8: whole rows of
+// S consecutive samples side by side, each with its own zero halo word -- the small-resolution layers that went to the vendor library before)
+constexpr int tw_pw(int s) { return 32 + s; }
+constexpr int tw_image_words(int s) { return 4 * TW_RIN * tw_pw(s) + WS_WORDS; }
 constexpr int TW_IMAGES = 3;
-constexpr int TW_LDS_BYTES = TW_IMAGES * TW_IMAGE_WORDS * 16;
+constexpr int tw_lds_bytes(int s) { return TW_IMAGES * tw_image_words(s) * 16; }
+constexpr int TW_LDS_BYTES = tw_lds_bytes(1);
+
+template <int S>
+__device__ __forceinline__ tile_pos decode_tile_tw(const s2_params& p, int tile) {   // tp.n = first sample of the tile
+    const int mts = p.m / TM, rbs = p.h / TW_ROWS;
+    tile_pos tp;
+    tp.mt = tile % mts;
+    int r = tile / mts;
+    if (S == 1) { const int segs = p.w / SEG; tp.x0 = (r % segs) * SEG; r /= segs; } else tp.x0 = 0;
+    tp.y0 = (r % rbs) * TW_ROWS;
+    tp.n = (r / rbs) * S;
+    return tp;
+}
 
 // ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
-template <int TERMS, int ABL = 0>
+template <int TERMS, int ABL = 0, int S = 1>
 __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
+    constexpr int TW_PW = tw_pw(S), TW_XS_PLANE = TW_RIN * TW_PW, TW_XS_WORDS = 4 * TW_XS_PLANE, TW_IMAGE_WORDS = tw_image_words(S);
+    constexpr int SW = 32 / S;   // pixels per sample in a tile row
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -596,7 +611,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
     if (wave == 6) {
         // =========================================== weight DMA wave ===========================================
         auto dma_w = [&](int q) {
-            const tile_pos tp = decode_tile_s2(p, tile_of(q), TW_ROWS);
+            const tile_pos tp = decode_tile_tw<S>(p, tile_of(q));
             const u32x4* wq = p.wprep + ((size_t)tp.mt * chunks + (q % chunks)) * WS_WORDS + lane;
             u32x4* wl = image(q) + TW_XS_WORDS;
 #pragma unroll
@@ -618,19 +633,22 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
     }
     if (wave >= 4) {
         // =========================================== x waves (4, 5) ===========================================
-        const int u = t - 256;                                   // 0..127; units 0..79 items (octet, row, quad), 80..89 halo (octet, row)
-        const int kind = u < 16 * TW_RIN ? 0 : (u < 18 * TW_RIN ? 1 : 2);
+        const int u = t - 256;                                   // 0..127; units 0..79 items (octet, row, quad), then 10 * S halo words (octet, row, sample)
+        const int kind = u < 16 * TW_RIN ? 0 : (u < (16 + 2 * S) * TW_RIN ? 1 : 2);
         const int oct = u & 1;
-        const int a_quad = (u >> 1) & 7, a_row = kind == 0 ? u >> 4 : kind == 1 ? (u - 16 * TW_RIN) >> 1 : 0;
+        const int hh = (u - 16 * TW_RIN) >> 1;
+        const int a_quad = (u >> 1) & 7, a_row = kind == 0 ? u >> 4 : kind == 1 ? hh % TW_RIN : 0;
+        const int a_s = kind == 0 ? a_quad / (SW / 4) : kind == 1 ? hh / TW_RIN : 0;     // sample inside the tile row
+        const int a_q = a_quad % (SW / 4);
         struct xset { f32x4 a[8]; bool ok; };
 
         auto load_x = [&](int q, xset& r) {
-            const tile_pos tp = decode_tile_s2(p, tile_of(q), TW_ROWS);
+            const tile_pos tp = decode_tile_tw<S>(p, tile_of(q));
             const int c = q % chunks;
-            const float* xb_ = p.x + ((size_t)tp.n * p.k + c * KC + 8 * oct) * plane_in;
+            const float* xb_ = p.x + ((size_t)(tp.n + a_s) * p.k + c * KC + 8 * oct) * plane_in;
             const int gy = tp.y0 - 1 + a_row;
-            const int gx = kind == 0 ? tp.x0 + 4 * a_quad : tp.x0 - 4;      // the halo pixel x0-1 is the last element of the group before the tile
-            r.ok = kind != 2 && gy >= 0 && gx >= 0;
+            const int gx = kind == 0 ? tp.x0 + 4 * a_q : tp.x0 - 4;         // the halo pixel x0-1 is the last element of the group before the tile
+            r.ok = kind != 2 && gy >= 0 && gx >= 0 && (S == 1 || kind == 0);   // packed samples: every halo word is image padding
             const float* q0 = xb_ + (size_t)max(gy, 0) * p.w + max(gx, 0);
 #pragma unroll
             for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * plane_in) : "memory");
@@ -651,7 +669,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
         };
         auto store_x = [&](u32x4* xs, const xset& r) {
             if (kind == 0) {
-                const int base = (oct * TW_RIN + a_row) * TW_PW + 1 + 4 * a_quad;
+                const int base = (oct * TW_RIN + a_row) * TW_PW + a_s * (SW + 1) + 1 + 4 * a_q;
 #pragma unroll
                 for (int px = 0; px < 4; px++) {
                     float v[8];
@@ -663,7 +681,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = r.a[j][3];
-                put(xs, (oct * TW_RIN + a_row) * TW_PW, v, r.ok);
+                put(xs, (oct * TW_RIN + a_row) * TW_PW + a_s * (SW + 1), v, r.ok);
             }
         };
         // iteration q: start the loads of chunk q+3, write chunk q+2 (loaded an iteration ago) into image (q+2) % 3
@@ -715,7 +733,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
         int ln = lane;
         asm volatile("" : "+v"(ln));
         const int a_lane = (ln >> 5) * TM + (ln & 31);
-        const int b_lane = ((ln >> 5) * TW_RIN + wave + 1) * TW_PW + (ln & 31) + 1;      // - dy * PW - dx
+        const int b_lane = ((ln >> 5) * TW_RIN + wave + 1) * TW_PW + ((ln & 31) / SW) * (SW + 1) + (ln & 31) % SW + 1;      // - dy * PW - dx
 
         if (ABL != 6) {
         u32x4 a[3][2][2];    // [buffer][half][hl]
@@ -761,11 +779,11 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
         }
 
         if (c == chunks - 1) {
-            const tile_pos tp = decode_tile_s2(p, tile_of(q), TW_ROWS);
+            const tile_pos tp = decode_tile_tw<S>(p, tile_of(q));
             int le = lane;
             asm volatile("" : "+v"(le));
             const int g = le >> 5;
-            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane_out + (size_t)(2 * (tp.y0 + wave)) * wout + 2 * (tp.x0 + (le & 31));
+            float* yb = p.y + ((size_t)(tp.n + (le & 31) / SW) * p.m + tp.mt * TM) * plane_out + (size_t)(2 * (tp.y0 + wave)) * wout + 2 * (tp.x0 + (le & 31) % SW);
 #pragma unroll
             for (int a2 = 0; a2 < 2; a2++)
 #pragma unroll

@@ -250,6 +250,7 @@ ABI_SYMBOLS = {
     'sgv_conv3x3_s2_fused': (c_int, [ctypes.POINTER(Conv3x3Params), ctypes.POINTER(Conv3x3S2Epilogue), c_int, c_void_p]),
     'sgv_conv3x3_s2_fused_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_s2_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
+    'sgv_conv3x3_s2_supported_mode': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_s2_workspace_bytes': (c_int64, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32]),
     'sgv_conv3x3_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_workspace_bytes': (c_int64, [c_int32, c_int32]),

@@ -143,9 +143,9 @@ def _native_conv_kind(x, w, cfg):
         return 's1' if lib.sgv_conv3x3_supported(n, ci, co, h, wd, 0) else None
     if stride == (2, 2) and padding == (0, 0) and native_conv_s2:
         if transposed:
-            return 's2' if lib.sgv_conv3x3_s2_supported(n, ci, co, h, wd, 0) else None
+            return 's2' if lib.sgv_conv3x3_s2_supported_mode(n, ci, co, h, wd, 2, 0) else None
         if h % 2 == 1 and wd % 2 == 1 and h >= 3 and wd >= 3:
-            return 's2' if lib.sgv_conv3x3_s2_supported(n, ci, co, (h - 1) // 2, (wd - 1) // 2, 0) else None
+            return 's2' if lib.sgv_conv3x3_s2_supported_mode(n, ci, co, (h - 1) // 2, (wd - 1) // 2, 0, 0) else None
     return None
 
 

@@ -117,6 +117,30 @@ def test_conv3x3_stride2_family_matches_fp64(n, cb, cs, h, w, transposed):
     assert torch.equal(conv2d_gradfix._native_conv(xi, wi, cfg).cpu().double(), ref_op(xi.double().cpu(), wi.double().cpu(), stride=2))
 
 
+@pytest.mark.parametrize('n,ci,co,h,w', [(4, 32, 64, 16, 16), (2, 64, 128, 8, 16), (4, 16, 64, 8, 8), (8, 48, 64, 4, 8), (6, 32, 64, 12, 16)])
+def test_transposed_stride2_on_small_images_packs_samples(n, ci, co, h, w):
+    """W = 16 / 8: the transposed kernel packs 2 / 4 samples into one 32-pixel tile row (each with its own zero halo); float64 reference,
+    exact on small integers, samples must not leak into each other (a non-zero sample next to a zero one)."""
+    g = torch.Generator().manual_seed(n + ci + co + h + w)
+    x = (torch.randn([n, ci, h, w], generator=g) + 0.3).to(DEV)
+    wt = (torch.randn([ci, co, 3, 3], generator=g) / (3 * ci ** 0.5)).to(DEV)
+    cfg = (True, (2, 2), (0, 0), (0, 0), (1, 1), 1)
+    assert conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2'
+    y = conv2d_gradfix._native_conv(x, wt, cfg)
+    ref = F.conv_transpose2d(x.double().cpu(), wt.double().cpu(), stride=2)
+    assert y.shape == ref.shape
+    l2, mx = _rel(y, ref)
+    assert l2 < 1e-5 and mx < 1e-5
+    xi = torch.randint(-3, 4, x.shape, generator=g).float()
+    xi[1::2] = 0                                                     # every second sample is zero: its output must be exactly zero
+    wi = torch.randint(-2, 3, wt.shape, generator=g).float()
+    yi = conv2d_gradfix._native_conv(xi.to(DEV), wi.to(DEV), cfg).cpu().double()
+    assert torch.equal(yi, F.conv_transpose2d(xi.double(), wi.double(), stride=2))
+    assert yi[1::2].abs().max() == 0
+    # odd batch for W = 16 (or a batch that is no multiple of 4 for W = 8) stays with the vendor library
+    assert conv2d_gradfix._native_conv_kind(x[:1], wt, cfg) is None
+
+
 def test_conv3x3_stride2_gradients_first_and_second_order():
     g = torch.Generator().manual_seed(4)
     x = torch.randn([2, 64, 17, 65], generator=g).to(DEV).requires_grad_(True)
