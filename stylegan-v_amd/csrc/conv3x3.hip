@@ -74,6 +74,9 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+#define SGV_P2_ATTR(T, E, SS) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<T, 0, E, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds_bytes(SS));
+    SGV_P2_ATTR(1, 0, 2) SGV_P2_ATTR(3, 0, 2) SGV_P2_ATTR(1, 1, 2) SGV_P2_ATTR(3, 1, 2) SGV_P2_ATTR(1, 0, 4) SGV_P2_ATTR(3, 0, 4) SGV_P2_ATTR(1, 1, 4) SGV_P2_ATTR(3, 1, 4)
+#undef SGV_P2_ATTR
     g_attr_err = e;
     env = getenv("SGV_CONVT_EDGE_MFMA");
     g_edge_mfma = !(env && env[0] == '0');
@@ -89,8 +92,9 @@ bool supported_s2(int n, int k, int m, int h, int w, int dtype) {   // h, w: the
 
 // W = 16 / 8: the producer / consumer kernels pack 2 / 4 samples into a 32-pixel tile row (transposed form so far)
 bool supported_s2_packed(int n, int k, int m, int h, int w, int mode, int dtype) {
-    if (!(dtype == SGV_F32 && mode == 2 && (w == 16 || w == 8))) return false;
-    return n >= 1 && n % (32 / w) == 0 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && h >= TW_ROWS && h % TW_ROWS == 0;
+    if (!(dtype == SGV_F32 && (w == 16 || w == 8) && n >= 1 && n % (32 / w) == 0 && k >= KC && k % KC == 0)) return false;
+    if (mode == 2) return m >= TM && m % TM == 0 && h >= TW_ROWS && h % TW_ROWS == 0;
+    return mode == 0 && m % P2_TM == 0 && h % P2_ROWS == 0;   // the strided form: the tap-pair kernel only
 }
 
 }  // namespace
@@ -208,7 +212,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
     hipStream_t stream = (hipStream_t)stream_;
 
-    const bool pairs = p->mode == 0 && pairs_shape(p->c_out, p->h);
+    const bool pairs = p->mode == 0 && pairs_shape(p->c_out, p->h) && (p->w >= SEG || packed);
     if (ep) {
         if (!pairs) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2_fused: needs the strided form (mode 0), c_out %% 128 == 0 and H %% 8 == 0 (and SGV_S2_WS != 0)");
         if (ep->act != 1 && ep->act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: act must be 1 (linear) or 3 (lrelu)");
@@ -237,17 +241,17 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     const double bytes = 4.0 * (p->mode == 0 ? big_px * p->c_in + small_px * p->c_out : small_px * p->c_in + big_px * p->c_out) + 4.0 * p->c_in * p->c_out * 9;
     sgv_launch_scope scope(SGV_K_CONV3X3, stream, bytes, 2.0 * small_px * p->c_in * (double)p->c_out * 9);
     if (pairs) {
-        kp.tiles = p->n * (p->h / P2_ROWS) * (p->w / SEG) * (p->c_out / P2_TM);
+        const int ss = p->w >= SEG ? 1 : 32 / p->w;
+        kp.tiles = ss == 1 ? p->n * (p->h / P2_ROWS) * (p->w / SEG) * (p->c_out / P2_TM) : (p->n / ss) * (p->h / P2_ROWS) * (p->c_out / P2_TM);
         kp.grid = std::min(kp.tiles, g_cus);
         s2_epilogue ke{};
         if (ep) { ke.bias = ep->bias; ke.accumulate = ep->accumulate; ke.act_out = ep->act_out; ke.act = ep->act; ke.alpha = ep->alpha; ke.gain = ep->gain; ke.clamp = ep->clamp; }
-        if (ep) {
-            if (p->terms == 1) hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<1, 0, 1>), dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
-            else hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<3, 0, 1>), dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
-        } else {
-            if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_pairs_kernel<1>, dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
-            else hipLaunchKernelGGL(conv3x3_s2_pairs_kernel<3>, dim3((unsigned)kp.grid), dim3(512), P2_LDS_BYTES, stream, kp, ke);
-        }
+#define SGV_P2_GO(T, E, SS) hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<T, 0, E, SS>), dim3((unsigned)kp.grid), dim3(512), p2_lds_bytes(SS), stream, kp, ke)
+#define SGV_P2_S(T, E) do { if (ss == 1) SGV_P2_GO(T, E, 1); else if (ss == 2) SGV_P2_GO(T, E, 2); else SGV_P2_GO(T, E, 4); } while (0)
+        if (ep) { if (p->terms == 1) SGV_P2_S(1, 1); else SGV_P2_S(3, 1); }
+        else { if (p->terms == 1) SGV_P2_S(1, 0); else SGV_P2_S(3, 0); }
+#undef SGV_P2_S
+#undef SGV_P2_GO
         return sgv_check_launch("conv3x3_s2_pairs_kernel");
     }
     if (p->mode == 0 && g_s2_ws) {
@@ -322,5 +326,5 @@ extern "C" int sgv_conv3x3_s2_supported_mode(int32_t n, int32_t c_in, int32_t c_
 
 extern "C" int sgv_conv3x3_s2_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {
     std::call_once(g_attr_once, init_once);
-    return supported_s2(n, c_in, c_out, h, w, dtype) && pairs_shape(c_out, h) ? 1 : 0;
+    return (supported_s2(n, c_in, c_out, h, w, dtype) || supported_s2_packed(n, c_in, c_out, h, w, 0, dtype)) && pairs_shape(c_out, h) ? 1 : 0;
 }

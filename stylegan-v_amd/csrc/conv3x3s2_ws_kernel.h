@@ -269,11 +269,13 @@ constexpr int P2_TM = 128;
 constexpr int P2_KC = 8;
 constexpr int P2_ROWS = 8;
 constexpr int P2_RIN = 2 * P2_ROWS + 1;
-constexpr int P2_XS_PLANE = P2_RIN * 2 * S2W_PW;          // words per hl
-constexpr int P2_XS_WORDS = 2 * P2_XS_PLANE;
 constexpr int P2_WS_WORDS = 2 * 5 * 2 * P2_TM;            // [hl][pair][tap in pair][128 m]
-constexpr int P2_IMAGE_WORDS = P2_XS_WORDS + P2_WS_WORDS;
-constexpr int P2_LDS_BYTES = 2 * P2_IMAGE_WORDS * 16;
+// S = samples per 32-pixel tile row: 1 (W % 32 == 0: a 32-px segment of one sample) or 2 / 4 (W = 16 / 8: whole rows of S consecutive samples side
+// by side).  A parity plane row holds S x (W + 1) = 32 + S words (sample s at s * (W + 1); the odd plane leaves one word per sample unused).
+constexpr int p2_pw(int s) { return 32 + s; }
+constexpr int p2_image_words(int s) { return 2 * P2_RIN * 2 * p2_pw(s) + P2_WS_WORDS; }
+constexpr int p2_lds_bytes(int s) { return 2 * p2_image_words(s) * 16; }
+constexpr int P2_LDS_BYTES = p2_lds_bytes(1);
 
 // fp32 [M, K, 3, 3] -> bf16 hi/lo in [m tile of 128][chunk of 8 k][hl][pair][tap in pair][128 m][8 k]; tap 9 is zero.
 __global__ __launch_bounds__(256) void conv3x3_prep_weights_pairs(const float* w, u32x4* out, int m_total, int k_total, int terms) {
@@ -297,15 +299,15 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights_pairs(const float* w
     if (terms > 1) out[base + (1 * 10 + tap) * P2_TM + mi] = lo;
 }
 
-__device__ __forceinline__ tile_pos decode_tile_p2(const s2_params& p, int tile) {
-    const int mts = p.m / P2_TM, segs = p.w / SEG, rbs = p.h / P2_ROWS;
+template <int S>
+__device__ __forceinline__ tile_pos decode_tile_p2(const s2_params& p, int tile) {   // tp.n = first sample of the tile
+    const int mts = p.m / P2_TM, rbs = p.h / P2_ROWS;
     tile_pos tp;
     tp.mt = tile % mts;
     int r = tile / mts;
-    tp.x0 = (r % segs) * SEG;
-    r /= segs;
+    if (S == 1) { const int segs = p.w / SEG; tp.x0 = (r % segs) * SEG; r /= segs; } else tp.x0 = 0;
     tp.y0 = (r % rbs) * P2_ROWS;
-    tp.n = r / rbs;
+    tp.n = (r / rbs) * S;
     return tp;
 }
 
@@ -324,8 +326,11 @@ struct s2_epilogue {
 };
 
 // ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
-template <int TERMS, int ABL = 0, int EPI = 0>
+template <int TERMS, int ABL = 0, int EPI = 0, int S = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s2_epilogue ep) {
+    constexpr int PW = p2_pw(S), P2_XS_PLANE = P2_RIN * 2 * PW, P2_XS_WORDS = 2 * P2_XS_PLANE, P2_IMAGE_WORDS = p2_image_words(S);
+    constexpr int SW = 32 / S;          // output pixels per sample in a tile row
+    constexpr int GPS = SW / 2;         // 4-column input groups per sample row (without the last, odd column)
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -342,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
     if (wave == 7) {
         // =========================================== weight DMA wave ===========================================
         auto dma_w = [&](int q, u32x4* img) {
-            const tile_pos tp = decode_tile_p2(p, tile_of(q));
+            const tile_pos tp = decode_tile_p2<S>(p, tile_of(q));
             const u32x4* wq = p.wprep + ((size_t)tp.mt * chunks + (q % chunks)) * P2_WS_WORDS + lane;
             u32x4* wl = img + P2_XS_WORDS;
 #pragma unroll
@@ -367,17 +372,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
         const int pt = t - 256;
         constexpr int ITEMS = 16 * P2_RIN;
         const int u1 = pt + 192;
-        const int kind1 = u1 < ITEMS ? 0 : (u1 < ITEMS + P2_RIN ? 1 : 2);
+        const int kind1 = u1 < ITEMS ? 0 : (u1 < ITEMS + S * P2_RIN ? 1 : 2);
         const int a_grp = pt & 15, a_row0 = pt >> 4, a_row1 = u1 >> 4;
-        const int h_row = u1 - ITEMS;
+        const int a_s = a_grp / GPS, a_g = a_grp % GPS;                      // sample inside the tile row, group inside the sample
+        const int h_row = (u1 - ITEMS) % P2_RIN, h_s = kind1 == 1 ? (u1 - ITEMS) / P2_RIN : 0;
+        const size_t sample = (size_t)p.k * plane_in;                         // elements between consecutive samples
         struct xset { f32x4 a[8]; f32x4 b[8]; };
 
         auto load_x = [&](int q, xset& r) {
-            const tile_pos tp = decode_tile_p2(p, tile_of(q));
+            const tile_pos tp = decode_tile_p2<S>(p, tile_of(q));
             const int c = q % chunks;
             const float* xb_ = p.x + ((size_t)tp.n * p.k + c * P2_KC) * plane_in + (size_t)(2 * tp.y0) * win + 2 * tp.x0;
-            const float* q0 = xb_ + (size_t)a_row0 * win + 4 * a_grp;
-            const float* q1 = xb_ + (kind1 == 0 ? (size_t)a_row1 * win + 4 * a_grp : kind1 == 1 ? (size_t)h_row * win + 61 : 0);
+            const float* q0 = xb_ + a_s * sample + (size_t)a_row0 * win + 4 * a_g;
+            const float* q1 = xb_ + (kind1 == 0 ? a_s * sample + (size_t)a_row1 * win + 4 * a_g : kind1 == 1 ? h_s * sample + (size_t)h_row * win + 2 * SW - 3 : 0);
 #pragma unroll
             for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * plane_in) : "memory");
 #pragma unroll
@@ -395,24 +402,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             xs[pos] = hi;
             if (TERMS > 1) xs[P2_XS_PLANE + pos] = lo;
         };
-        auto put_item = [&](u32x4* xs, int row, int grp, const f32x4* src) {
-            const int base = row * 2 * S2W_PW + 2 * grp;
+        auto put_item = [&](u32x4* xs, int row, int grp, const f32x4* src) {   // grp: group inside sample a_s
+            const int base = row * 2 * PW + a_s * (SW + 1) + 2 * grp;
 #pragma unroll
             for (int px = 0; px < 4; px++) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = src[j][px];
-                put(xs, base + (px & 1) * S2W_PW + (px >> 1), v);
+                put(xs, base + (px & 1) * PW + (px >> 1), v);
             }
         };
         auto store_x = [&](u32x4* xs, const xset& r) {
-            put_item(xs, a_row0, a_grp, r.a);
-            if (kind1 == 0) put_item(xs, a_row1, a_grp, r.b);
+            put_item(xs, a_row0, a_g, r.a);
+            if (kind1 == 0) put_item(xs, a_row1, a_g, r.b);
             else if (kind1 == 1) {
                 float v[8];
 #pragma unroll
                 for (int j = 0; j < 8; j++) v[j] = r.b[j][3];
-                put(xs, h_row * 2 * S2W_PW + 32, v);
+                put(xs, h_row * 2 * PW + h_s * (SW + 1) + SW, v);
             }
         };
         auto step = [&](int q, xset& ld, xset& st) {
@@ -461,19 +468,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
         asm volatile("" : "+v"(ln));
         const int g = ln >> 5;
         const int a_lane = g * P2_TM + (ln & 31);                          // + ((hl * 5 + pair) * 2) * P2_TM + mq * 32
-        const int b_lane = (2 * wave) * 4 * S2W_PW + (ln & 31);            // + r * 4 * PW + tap offset of this lane half
+        const int b_lane = (2 * wave) * 4 * PW + ((ln & 31) / SW) * (SW + 1) + (ln & 31) % SW;   // + r * 4 * PW + tap offset of this lane half
 
         if (ABL != 6) {
         u32x4 a[2][4][2];    // [buffer][m quarter][hl]
         u32x4 b[2][2][2];    // [buffer][row][hl]
-        auto tap_off = [](int tap) { const int ky = tap / 3, kx = tap % 3; return (ky * 2 + (kx & 1)) * S2W_PW + (kx >> 1); };
+        auto tap_off = [](int tap) { const int ky = tap / 3, kx = tap % 3; return (ky * 2 + (kx & 1)) * PW + (kx >> 1); };
         auto fetch = [&](int buf, int pair) {
             const int o0 = tap_off(2 * pair), o1 = tap_off(pair == 4 ? 8 : 2 * pair + 1);   // the padding tap reads tap 8's pixels against zero weights
             const int pos = b_lane + (g ? o1 : o0);
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                b[buf][r][0] = xs[pos + r * 4 * S2W_PW];
-                if (TERMS > 1) b[buf][r][1] = xs[P2_XS_PLANE + pos + r * 4 * S2W_PW];
+                b[buf][r][0] = xs[pos + r * 4 * PW];
+                if (TERMS > 1) b[buf][r][1] = xs[P2_XS_PLANE + pos + r * 4 * PW];
             }
 #pragma unroll
             for (int mq = 0; mq < 4; mq++) {
@@ -513,11 +520,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
         }
 
         if (c == chunks - 1) {
-            const tile_pos tp = decode_tile_p2(p, tile_of(q));
+            const tile_pos tp = decode_tile_p2<S>(p, tile_of(q));
             int le = lane;
             asm volatile("" : "+v"(le));
             const int ge = le >> 5;
-            const size_t off0 = ((size_t)tp.n * p.m + tp.mt * P2_TM) * plane_out + (size_t)(tp.y0 + 2 * wave) * p.w + tp.x0 + (le & 31);
+            const size_t off0 = ((size_t)(tp.n + (le & 31) / SW) * p.m + tp.mt * P2_TM) * plane_out + (size_t)(tp.y0 + 2 * wave) * p.w + tp.x0 + (le & 31) % SW;
             float* yb = p.y + off0;
             const float al = ep.act == 3 ? ep.alpha : 1.f;
             const float g0 = ep.gain, g1 = ep.gain * al;

@@ -141,6 +141,29 @@ def test_transposed_stride2_on_small_images_packs_samples(n, ci, co, h, w):
     assert conv2d_gradfix._native_conv_kind(x[:1], wt, cfg) is None
 
 
+@pytest.mark.parametrize('n,ci,co,h,w', [(4, 32, 128, 16, 16), (2, 64, 256, 8, 16), (4, 16, 128, 8, 8), (8, 48, 128, 16, 8)])
+def test_strided_stride2_on_small_images_packs_samples(n, ci, co, h, w):
+    """W = 16 / 8 outputs: the tap-pair kernel packs 2 / 4 samples into one 32-pixel tile row; float64 reference, exact on small integers, no
+    leakage between neighbouring samples."""
+    g = torch.Generator().manual_seed(n + ci + co + h + w)
+    x = (torch.randn([n, ci, 2 * h + 1, 2 * w + 1], generator=g) + 0.3).to(DEV)
+    wt = (torch.randn([co, ci, 3, 3], generator=g) / (3 * ci ** 0.5)).to(DEV)
+    cfg = (False, (2, 2), (0, 0), (0, 0), (1, 1), 1)
+    assert conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2'
+    y = conv2d_gradfix._native_conv(x, wt, cfg)
+    ref = F.conv2d(x.double().cpu(), wt.double().cpu(), stride=2)
+    assert y.shape == ref.shape
+    l2, mx = _rel(y, ref)
+    assert l2 < 1e-5 and mx < 1e-5
+    xi = torch.randint(-3, 4, x.shape, generator=g).float()
+    xi[1::2] = 0
+    wi = torch.randint(-2, 3, wt.shape, generator=g).float()
+    yi = conv2d_gradfix._native_conv(xi.to(DEV), wi.to(DEV), cfg).cpu().double()
+    assert torch.equal(yi, F.conv2d(xi.double(), wi.double(), stride=2))
+    assert yi[1::2].abs().max() == 0
+    assert conv2d_gradfix._native_conv_kind(x[:1], wt, cfg) is None
+
+
 def test_conv3x3_stride2_gradients_first_and_second_order():
     g = torch.Generator().manual_seed(4)
     x = torch.randn([2, 64, 17, 65], generator=g).to(DEV).requires_grad_(True)

@@ -121,7 +121,7 @@ def test_fused_layer_no_grad_pass_and_fallbacks():
 # Fused down-sampling layer tail (ops/fused_down_act.py -> sgv_conv3x3_s2_fused, csrc/conv3x3s2_ws_kernel.h) against the oracle's composition
 # `oracle.conv3x3(xb, w, stride=2) -> oracle.bias_act -> + residual`.
 
-@pytest.mark.parametrize('n,ci,co,hs,ws', [(2, 32, 128, 8, 32), (1, 64, 256, 16, 64), (3, 16, 128, 24, 32)])
+@pytest.mark.parametrize('n,ci,co,hs,ws', [(2, 32, 128, 8, 32), (1, 64, 256, 16, 64), (3, 16, 128, 24, 32), (4, 32, 128, 16, 16), (4, 16, 128, 8, 8)])
 @pytest.mark.parametrize('act,clamp,with_res,with_bias', [('lrelu', None, True, True), ('lrelu', 0.7, True, True), ('lrelu', None, False, True),
                                                           ('linear', None, True, False), ('lrelu', 0.9, False, False)])
 def test_fused_down_layer_forward_and_gradients_vs_oracle(n, ci, co, hs, ws, act, clamp, with_res, with_bias):
