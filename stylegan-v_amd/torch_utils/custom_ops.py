@@ -14,6 +14,7 @@ which shells out to nvcc through ``torch.utils.cpp_extension.load``.  Difference
   bias_act.py:49-50).
 """
 
+import contextlib
 import ctypes
 import hashlib
 import os
@@ -71,10 +72,24 @@ def _hipcc():
     return exe
 
 
+@contextlib.contextmanager
+def _build_file_lock():
+    """Cross-process guard of the in-tree build (one process per GPU: every rank would otherwise compile into the same csrc/_build/*.o
+    paths at once).  The role of the reference's FileBaton (src/torch_utils/custom_ops.py), done with flock on a lock file next to the .so."""
+    import fcntl
+    os.makedirs(os.path.join(CSRC_DIR, '_build'), exist_ok=True)
+    with open(os.path.join(CSRC_DIR, '_build', 'build.lock'), 'w') as fh:
+        fcntl.flock(fh, fcntl.LOCK_EX)
+        try:
+            yield
+        finally:
+            fcntl.flock(fh, fcntl.LOCK_UN)
+
+
 def build_native(force=False):
     """Compile every csrc/*.hip for gfx950 and link libsgv_hip.so in-tree.  Returns the .so path."""
-    with _lock:
-        if not force and is_built():
+    with _lock, _build_file_lock():
+        if not force and is_built():   # (another process may have built it while this one waited for the file lock)
             return LIB_PATH
         hipcc = _hipcc()
         hip, _ = _sources()

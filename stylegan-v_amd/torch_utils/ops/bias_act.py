@@ -117,6 +117,10 @@ def _native_call(x, b, xref, yref, dy, grad, dim, act_idx, alpha, gain, clamp, d
     y = torch.empty_like(x)
     if x.numel() == 0:
         return y
+    # The kernel moves 16-byte vectors: a dense view whose storage offset is not 16-byte aligned (x[1:] of an [N, 3] tensor is still
+    # "contiguous") is re-materialised here -- the reference op accepts such views, so this one does too.
+    realign = lambda t: t.clone(memory_format=torch.preserve_format) if (t is not None and t.data_ptr() % 16 != 0) else t   # noqa: E731
+    x, xref, yref, dy = realign(x), realign(xref), realign(yref), realign(dy)
     p = custom_ops.BiasActParams(x.data_ptr(), b.data_ptr() if b is not None else None, xref.data_ptr() if xref is not None else None,
                                  yref.data_ptr() if yref is not None else None, dy.data_ptr() if dy is not None else None, y.data_ptr(),
                                  grad, act_idx, alpha, gain, clamp, x.numel(), b.numel() if b is not None else 0,

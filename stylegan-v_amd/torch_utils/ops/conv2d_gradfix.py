@@ -16,7 +16,9 @@ the idea and uses backend-neutral ATen ops: every derivative of a convolution is
 forward / backward-data / backward-weight convolutions of the ORIGINAL geometry
 (``aten.convolution`` and ``aten.convolution_backward`` with an output mask), nested autograd Functions
 make any order available, and ``no_weight_gradients()`` really skips the weight-gradient convolution
-(used by the R1 / path-length passes, loss.py:111,162).  The convolutions themselves stay on MIOpen.
+(used by the R1 / path-length passes, loss.py:111,162).  Where the hand-written 3x3 family serves the shape (``_native_conv_kind`` /
+``_native_wrw_kind`` below: stride 1, stride 2 and transposed stride 2 on fp32 NCHW, csrc/conv3x3*.h, csrc/wrw*.h) each of those
+convolutions is one of its kernels -- forward, data gradient, weight gradient and every higher-order term; the vendor library keeps the rest.
 """
 
 import contextlib
@@ -158,6 +160,8 @@ def _native_conv(x, w, cfg):
     kind = _native_conv_kind(x, w, cfg)
     transposed = cfg[0]
     xc, wc = x.contiguous(), w.contiguous()
+    if xc.data_ptr() % 16 != 0:   # a dense view at a storage offset that is not 16-byte aligned: the kernels load 16-byte vectors
+        xc = xc.clone()
     n, ci, h, wd = xc.shape
     co = wc.shape[1] if transposed else wc.shape[0]
     if kind == 's1':

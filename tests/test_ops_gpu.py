@@ -329,3 +329,20 @@ def test_bias_act_errors():
         ba.bias_act(x, torch.zeros([4], device=DEV, dtype=torch.float64))
     with pytest.raises(KeyError):
         ba.bias_act(x, None, act='gelu')
+
+
+def test_bias_act_and_conv_accept_dense_views_at_unaligned_storage_offsets():
+    """x[1:] of an [N, 3] fp32 tensor is contiguous but starts 12 bytes into its storage: the reference op takes such views (bias_act.cpp:46-51
+    only asks for dense), so the 16-byte-vector kernels re-materialise them instead of raising."""
+    from stylegan_v_amd.torch_utils.ops import bias_act, conv2d_gradfix
+    base = torch.randn(5, 3, device='cuda')
+    x = base[1:]
+    assert x.is_contiguous() and x.data_ptr() % 16 != 0
+    b = torch.randn(3, device='cuda')
+    y = bias_act.bias_act(x, b, act='lrelu')
+    assert torch.allclose(y, bias_act.bias_act(x.clone(), b, act='lrelu'))
+    flat = torch.randn(1 + 2 * 64 * 16 * 32, device='cuda')
+    xc = flat[1:].view(2, 64, 16, 32)
+    assert xc.is_contiguous() and xc.data_ptr() % 16 != 0
+    w = torch.randn(64, 64, 3, 3, device='cuda') / 24
+    assert torch.allclose(conv2d_gradfix.conv2d(xc, w, padding=1), conv2d_gradfix.conv2d(xc.clone(), w, padding=1))
