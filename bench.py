@@ -72,7 +72,9 @@ def pmc_traffic(prefixes, dword_read_prefixes=()):
 
 
 def pmc_traffic_conv_family():
-    return pmc_traffic(('conv3x3_ws_kernel', 'conv3x3_kernel', 'conv3x3_small_kernel', 'convT3x3_s2_kernel', 'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
+    # every member reads with 16-byte loads now (the one-role-per-wave strided kernel, SGV_S2_WS=0, read dwords)
+    return pmc_traffic(('conv3x3_ws_kernel', 'conv3x3_kernel', 'conv3x3_small_kernel', 'convT3x3_s2_ws_kernel', 'convT3x3_s2_kernel', 'conv3x3_s2_pairs_kernel', 'conv3x3_s2_ws_kernel',
+                        'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
 
 
 def pmc_traffic_per_launch(prefix='upfirdn2d_lanes'):
@@ -335,7 +337,7 @@ def main():
                 terms = conv2d_gradfix.native_conv_terms if dom == 'conv3x3' else conv2d_gradfix.native_wrw_terms
                 achieved = e['flops'] / (e['ms'] * 1e-3) / 1e12
                 peak = MFMA_BF16_PEAK_TFLOPS / terms
-                roofline = dict(kernel={'conv3x3': 'conv3x3_kernel / conv3x3_s2_kernel / convT3x3_s2_kernel', 'conv_wrw': 'wrw3x3_kernel / wrw3x3_s2_kernel'}[dom], bound='mfma',
+                roofline = dict(kernel={'conv3x3': 'conv3x3_ws_kernel / conv3x3_s2_pairs_kernel / convT3x3_s2_ws_kernel (+ 16x16 / 8x8 and edge-strip members)', 'conv_wrw': 'wrw3x3_ws_kernel / wrw3x3_s2_kernel'}[dom], bound='mfma',
                                 achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=pmc_traffic_conv_family()[0] if dom == 'conv3x3' else pmc_traffic(('wrw3x3',))[0],
                                 traffic_source=(pmc_traffic_conv_family()[1] if dom == 'conv3x3' else pmc_traffic(('wrw3x3',))[1]) + ' (L2-miss bytes: Infinity-Cache hits included)',
                                 algorithmic_bytes_per_launch=e['bytes'] / e['launches'], launches=e['launches'],
