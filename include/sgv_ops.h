@@ -357,6 +357,8 @@ typedef struct sgv_gemm_params {
     int32_t bias_mode;                    /* 0 none, 1 bias[N] per column, 2 bias[M] per row */
     int32_t k_split;                      /* > 1: K is cut into k_split equal slices, slice s of batch entry b is written to c + (b * k_split + s) * stride_c
                                              (the caller sums them; no bias) -- long-K products with few output tiles, e.g. the 1x1 weight gradients */
+    const float* residual;                /* or NULL: C = A * op(B) (+ bias) + residual, residual laid out like C (ldc, stride_c) -- the sum of the
+                                             discriminator block's two branches (networks.py:343-345) formed in the skip convolution's store */
 } sgv_gemm_params;
 
 int sgv_gemm_f32(const sgv_gemm_params* p, void* stream);

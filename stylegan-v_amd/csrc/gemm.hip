@@ -27,7 +27,7 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     if (p->m < 1 || p->n < 1 || p->k < 1 || p->batch < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: sizes must be positive");
     if (p->bias_mode < 0 || p->bias_mode > 2 || (p->bias_mode && !p->bias)) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: bad bias_mode");
     const int ks = p->k_split > 1 ? p->k_split : 1;
-    if (ks > 1 && (p->k % ks != 0 || p->bias_mode != 0)) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: k_split must divide k and excludes a bias");
+    if (ks > 1 && (p->k % ks != 0 || p->bias_mode != 0 || p->residual)) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: k_split must divide k and excludes a bias / residual");
     if ((int64_t)p->batch * ks > 65535) return sgv_fail(SGV_ERR_TOO_LARGE, "gemm: batch (x k_split) is too large");
     hipStream_t stream = (hipStream_t)stream_;
     gemm_params gp;
@@ -37,6 +37,7 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     gp.trans_b = p->trans_b;
     gp.stride_a = p->stride_a; gp.stride_b = p->stride_b; gp.stride_c = p->stride_c;
     gp.bias_mode = p->bias_mode;
+    gp.residual = p->residual;
     gp.tiles_m = (p->m + BM - 1) / BM;
     gp.tiles_n = (p->n + BN - 1) / BN;
     const double flops = 2.0 * p->m * p->n * p->k * p->batch;

@@ -31,6 +31,7 @@ struct gemm_params {
     int bias_mode;
     int tiles_m, tiles_n;
     int ksplit;            // >= 1: slices of K per batch entry (k = slice length)
+    const float* residual; // added to the result before the store (same layout as c), or NULL
 };
 
 // [128 rows x BK] block of a row-major [rows, K] matrix (k contiguous): thread t -> row t/4 (+64 per pass), k-quad t%4 (+4 per k-pass).
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
     const float* A = p.a + batch * p.stride_a + (int64_t)slice * p.k;
     const float* B = p.b + batch * p.stride_b + (TRANS_B ? (int64_t)slice * p.k : (int64_t)slice * p.k * p.ldb);
     float* C = p.c + (int64_t)blockIdx.y * p.stride_c;
+    const float* RES = p.residual ? p.residual + (int64_t)blockIdx.y * p.stride_c : nullptr;
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int lane = threadIdx.x & 63;
@@ -190,6 +192,7 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
                 if (FULL != 1 && row >= p.m) continue;
                 float v = acc[i][j][e] + bcol;
                 if (p.bias_mode == 2) v += p.bias[row];
+                if (RES) v += RES[(int64_t)row * p.ldc + col];
                 C[(int64_t)row * p.ldc + col] = v;
             }
         }

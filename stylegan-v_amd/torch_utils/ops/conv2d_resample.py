@@ -55,6 +55,23 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     return op(x, w, stride=stride, padding=padding, groups=groups)
 
 
+def downsampling_conv1x1(x, w, f, down, padding=0, residual=None, flip_filter=False):
+    """``conv2d_resample`` for a 1x1 kernel with ``down > 1`` (FIR + decimate, then convolve on the small image: the skip branch of the
+    residual discriminator block) with the other branch's result added in the convolution's store where the MFMA GEMM serves the shape;
+    the fallback adds out of place (the residual is another layer's activation output, which its backward pass still needs)."""
+    out_ch, in_ch, kh, kw = _get_weight_shape(w)
+    assert kh == 1 and kw == 1 and down > 1
+    fw, fh = _get_filter_size(f)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    pads = [px0 + (fw - down + 1) // 2, px1 + (fw - down) // 2, py0 + (fh - down + 1) // 2, py1 + (fh - down) // 2]
+    x = _ufd.upfirdn2d(x=x, f=f, down=down, padding=pads, flip_filter=flip_filter)
+    if residual is not None and _gemm.enabled and w.dtype == torch.float32 and x.is_cuda and _gemm.is_full_tile_conv1x1(x, out_ch) \
+            and residual.dtype == torch.float32 and tuple(residual.shape) == (x.shape[0], out_ch, x.shape[2], x.shape[3]):
+        return _gemm.conv1x1(x, w, residual=residual)
+    y = _conv2d_wrapper(x=x, w=w)
+    return y + residual if residual is not None else y
+
+
 def downsampling_filter_pass(x, f, down, padding=0, kernel_hw=(3, 3), flip_filter=False):
     """The FIR pass that ``conv2d_resample`` puts in front of its strided convolution (`down > 1 and up == 1`, non-pointwise kernel): returns the
     filtered tensor the stride-`down` convolution then reads, so that a caller can run a fused convolution tail on it (ops/fused_down_act.py)."""

@@ -14,11 +14,12 @@ from .. import custom_ops
 enabled = True  # conv2d_resample routes whole-tile fp32 1x1 convolutions here
 
 
-def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0, sc=0, bias_mode=0, k_split=1):
+def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0, sc=0, bias_mode=0, k_split=1, residual=None):
     lib = custom_ops.get_native()
     p = custom_ops.GemmParams()
     p.a, p.b, p.c = a.data_ptr(), b.data_ptr(), c.data_ptr()
     p.bias = bias.data_ptr() if bias is not None else None
+    p.residual = residual.data_ptr() if residual is not None else None
     p.m, p.n, p.k, p.lda, p.ldb, p.ldc = m, n, k, lda, ldb, ldc
     p.trans_b, p.batch, p.stride_a, p.stride_b, p.stride_c, p.bias_mode, p.k_split = int(trans_b), batch, sa, sb, sc, bias_mode, k_split
     with torch.cuda.device_of(c):
@@ -82,8 +83,10 @@ def linear(x, w, b=None):
 
 
 class _Conv1x1Fn(torch.autograd.Function):
+    """y = conv1x1(x, w) (+ b) (+ residual): `residual` [N,Cout,H,W] is added in the kernel's store (the other branch of a residual block)."""
+
     @staticmethod
-    def forward(ctx, x, w, b):
+    def forward(ctx, x, w, b, residual):
         xc = x.contiguous()
         w2 = w.reshape(w.shape[0], -1).contiguous()
         n, cin, h, wd = xc.shape
@@ -91,7 +94,7 @@ class _Conv1x1Fn(torch.autograd.Function):
         hw = h * wd
         y = torch.empty([n, cout, h, wd], dtype=torch.float32, device=x.device)
         _launch(w2, xc, b.contiguous() if b is not None else None, y, cout, hw, cin, cin, hw, hw, False,
-                batch=n, sa=0, sb=cin * hw, sc=cout * hw, bias_mode=2 if b is not None else 0)
+                batch=n, sa=0, sb=cin * hw, sc=cout * hw, bias_mode=2 if b is not None else 0, residual=residual.contiguous() if residual is not None else None)
         ctx.save_for_backward(x, w)
         ctx.has_b = b is not None
         return y
@@ -107,7 +110,7 @@ class _Conv1x1Fn(torch.autograd.Function):
             dw = conv1x1_weight_grad(dy, x).reshape(w.shape)
         if ctx.has_b and ctx.needs_input_grad[2]:
             db = dy.sum([0, 2, 3])
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.needs_input_grad[3] else None)
 
 
 class _Conv1x1WeightGradFn(torch.autograd.Function):
@@ -161,8 +164,10 @@ def is_full_tile_conv1x1(x, cout):
             and x.shape[1] % 16 == 0)
 
 
-def conv1x1(x, w, b=None):
-    """1x1 convolution: x [N,Cin,H,W] contiguous, w [Cout,Cin,1,1] (or [Cout,Cin]) -> [N,Cout,H,W]."""
-    if _native_ok(x, w, b) and x.ndim == 4 and x.is_contiguous():
-        return _Conv1x1Fn.apply(x, w, b)
-    return torch.nn.functional.conv2d(x, w.reshape(w.shape[0], -1, 1, 1), b)
+def conv1x1(x, w, b=None, residual=None):
+    """1x1 convolution: x [N,Cin,H,W] contiguous, w [Cout,Cin,1,1] (or [Cout,Cin]) -> [N,Cout,H,W]; `residual` (same shape as the result,
+    fp32) is added to it -- inside the kernel on the native path."""
+    if _native_ok(x, w, b) and x.ndim == 4 and x.is_contiguous() and (residual is None or (residual.is_cuda and residual.dtype == torch.float32)):
+        return _Conv1x1Fn.apply(x, w, b, residual)
+    y = torch.nn.functional.conv2d(x, w.reshape(w.shape[0], -1, 1, 1), b)
+    return y + residual if residual is not None else y

@@ -146,6 +146,12 @@ class Conv2dLayer(torch.nn.Module):
                 and x.dtype == torch.float32 and x.is_contiguous() and pointwise.enabled:
             # fromRGB: 1x1 convolution from <= 4 channels + bias + activation as one streaming kernel
             x = pointwise.pointwise_conv_bias_act(x, w.reshape(1, w.shape[0], w.shape[1]), b, act=self.activation, gain=act_gain, clamp=clamp)
+        elif residual is not None and self.up == 1 and self.down > 1 and tuple(w.shape[2:]) == (1, 1) and b is None and self.activation == 'linear' \
+                and act_gain == 1 and clamp is None and x.is_cuda and x.dtype == torch.float32:
+            # skip branch of the residual block (gain already on the weights): FIR + decimate, then the 1x1 convolution whose store adds the
+            # other branch's result
+            x = conv2d_resample.downsampling_conv1x1(x, w, self.resample_filter, down=self.down, padding=self.padding, residual=residual)
+            residual = None
         elif self.up == 1 and self.down == 2 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm:
             # down-sampling 3x3 layer (DiscriminatorBlock conv1): FIR pass, then strided convolution + bias + activation (+ residual) as one kernel
@@ -158,7 +164,7 @@ class Conv2dLayer(torch.nn.Module):
             if b is not None or self.activation != 'linear' or act_gain != 1 or clamp is not None:   # (a no-op bias_act hands its input back as-is)
                 x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=clamp)
         if residual is not None:
-            x = residual.add_(x)
+            x = x + residual   # out of place: the residual may be an activation output that its own backward pass needs
         if self.instance_norm:
             x = (x - x.mean(dim=(2, 3), keepdim=True)) / (x.std(dim=(2, 3), keepdim=True) + 1e-8)
         return x

@@ -23,6 +23,7 @@ every convolution to cuDNN.
 """
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -34,6 +35,7 @@ from .motion import MotionMappingNetwork
 
 
 prefer_native_inference = True   # GPU eval-mode synthesis: scale-conv-scale through the native kernels instead of the grouped convolution
+residual_in_skip = os.environ.get('SGV_RES_IN_SKIP', '1') != '0'   # where the residual discriminator block forms its sum (see DiscriminatorBlock.forward)
 
 
 @misc.profiled_function
@@ -340,8 +342,14 @@ class DiscriminatorBlock(torch.nn.Module):
             x = x + y if x is not None else y
             img = upfirdn2d.downsample2d(img, self.resample_filter) if self.architecture == 'skip' else None
         if self.architecture == 'resnet':
-            y = self.skip(x, gain=math.sqrt(0.5))
-            x = self.conv1(self.conv0(x), gain=math.sqrt(0.5), residual=y)   # `x = y.add_(conv1(...))`, with the add inside the layer's last kernel
+            # `y = skip(x); x = conv1(conv0(x)); x = y.add_(x)` of the reference, evaluated in the other order so that the sum is formed in the
+            # store of the skip branch's 1x1 convolution (its GEMM has the spare load slots; the 3x3 kernel's MFMA waves do not)
+            if residual_in_skip:
+                y = self.conv1(self.conv0(x), gain=math.sqrt(0.5))
+                x = self.skip(x, gain=math.sqrt(0.5), residual=y)
+            else:   # the sum in the strided 3x3 kernel's store instead (one atomic add per element into the skip branch's result)
+                y = self.skip(x, gain=math.sqrt(0.5))
+                x = self.conv1(self.conv0(x), gain=math.sqrt(0.5), residual=y)
         else:
             x = self.conv1(self.conv0(x))
         assert x.dtype == dtype

@@ -415,3 +415,22 @@ def test_train_step_hipgraph_replay_matches_eager_schedule():
     assert moved > 10, 'the generator did not train under graph replay'
     for k in ('G/loss', 'D/loss'):
         assert torch.isfinite(ts.last_losses[k])
+
+
+def test_gemm_conv1x1_adds_a_residual_in_its_store():
+    """conv1x1(x, w, residual=r) == conv1x1(x, w) + r with one launch; d(residual) = dy (the discriminator block's `y.add_(x)`, networks.py:343-345)."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn([2, 64, 32, 32], generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn([128, 64, 1, 1], generator=g) / 8).to(DEV).requires_grad_(True)
+    r = torch.randn([2, 128, 32, 32], generator=g).to(DEV).requires_grad_(True)
+    before = custom_ops.launch_count()
+    y = gemm.conv1x1(x, w, residual=r)
+    assert custom_ops.launch_count() == before + 1
+    ref = torch.nn.functional.conv2d(x.double(), w.double()) + r.double()
+    assert_close(y, ref, atol=2e-5 * 8, rtol=2e-6, what='conv1x1 + residual')
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    gx, gw, gr = torch.autograd.grad(y, [x, w, r], dy)
+    rx, rw, rr = torch.autograd.grad(ref, [x, w, r], dy.double())
+    assert_close(gx, rx, atol=1e-3, rtol=1e-4, what='dx')
+    assert_close(gw, rw, atol=1e-3, rtol=1e-4, what='dw')
+    assert torch.equal(gr, dy)
