@@ -95,16 +95,20 @@ int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* stream);
  *           x = dy, yref = the forward output; additionally sum_g[n,c] += sum(g) and         upfirdn2d params describe the
  *           sum_gv[n,c] += sum(g * preactivation) over every plane, from which                transposed FIR, i.e. pad 2)
  *           dbias[c] = sum_n sum_g[n,c] and dscale[n,c] = (sum_gv - bias[c]*sum_g) / scale[n,c].
+ *   mode 3  dx = g(upfirdn2d(x)),  g(.) = . * act'(.) * gain masked by the clamp, evaluated at yref = the forward output of the
+ *           ACTIVATION that fed the (transposed) FIR -- yref has the shape of the result; sum_g[n,c] += sum(dx) (the bias gradient).
+ *           The backward pass of "bias_act, then the FIR in front of a strided convolution" (DiscriminatorBlock conv0 -> conv1,
+ *           networks.py:343-344 via conv2d_resample.py:113-126) in one pass instead of upfirdn2d + bias_act(grad 1).  scale / bias unused.
  * act: 1 linear or 3 lrelu (bias_act.py:23-33 indices).  scale / bias may be NULL (1 / 0).  Supported for the
- * lane-exchange kernel's FIR geometries only (mode 1: up=down=1, pad0 1; mode 2: up=down=1, pad0 2; 4x4 filter,
+ * lane-exchange kernel's FIR geometries only (modes 1, 3: up=down=1, pad0 1; mode 2: up=down=1, pad0 2; 4x4 filter,
  * dense NCHW); anything else returns SGV_ERR_UNSUPPORTED and the caller composes the three ops. */
 typedef struct sgv_fir_epilogue {
     int32_t mode;
     const float* scale; /* [n*c] fp32 or NULL */
     const float* bias;  /* [c] fp32 or NULL */
-    const void* yref;   /* mode 2: [n,c,in_h,in_w], dtype/layout of x */
-    float* sum_g;       /* mode 2: [n*c], zero-initialised by the caller, accumulated with atomics */
-    float* sum_gv;      /* mode 2: [n*c], likewise */
+    const void* yref;   /* mode 2: [n,c,in_h,in_w]; mode 3: [n,c,out_h,out_w]; dtype/layout of x */
+    float* sum_g;       /* modes 2, 3: [n*c], zero-initialised by the caller, accumulated with atomics */
+    float* sum_gv;      /* mode 2: [n*c], likewise (mode 3: may be NULL) */
     int32_t act;
     float alpha, gain, clamp; /* clamp < 0: none */
 } sgv_fir_epilogue;

@@ -369,11 +369,14 @@ template <typename T, int N> __device__ __forceinline__ void store_vec_plain(T* 
 // EPI = 1: fused forward epilogue   y = clamp(act(upfirdn2d(x) * scale[n,c] + bias[c]) * gain)  -- the FIR, the
 //          demodulation scaling and the bias/activation/clamp of a StyleGAN synthesis layer in ONE pass over the
 //          activation instead of three (networks.py:65-74,141-143 + conv2d_resample.py:138-139).
+// EPI = 3: fused backward epilogue  dx = d(bias_act)/dx at yref (OUTPUT-shaped) applied to upfirdn2d(x): the gradient of "activation, then FIR"
+//          (a discriminator conv0 whose output feeds the FIR of the down-sampling conv1) -- FIR-transposed pass and activation gradient in one;
+//          sum_g[n,c] += sum(dx).
 // EPI = 2: fused backward prologue  dx = upfirdn2d(g * scale),  g = d(bias_act)/dx at yref applied to the incoming
 //          gradient (bias_act.cu:60-61,133-142 grad=1 form), evaluated while the rows are loaded; the per-plane sums
 //          sum(g) and sum(g * preactivation) that give the bias and scale gradients are accumulated on the way.
 template <typename T, int UP, int DOWN, int PX0, int PY0, int XTRA, bool SEG, int WPB, int EPI>
-__global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI == 2 ? 6 : 8))) void upfirdn2d_lanes_kernel(lanes_params p) {
+__global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) void upfirdn2d_lanes_kernel(lanes_params p) {
     constexpr int FWP = 4, FHP = 4, DEPTH = (UP == 2 ? 2 : 1);  // row groups of loads in flight ahead of the math
     constexpr int TX = FWP / UP, TY = FHP / UP;
     constexpr int R0X = ((UP - 1 - PX0) % UP + UP) % UP, R0Y = ((UP - 1 - PY0) % UP + UP) % UP;
@@ -428,7 +431,8 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI == 2 ? 6 : 8))) voi
         if (plane_ok && p.ep_scale) ep_sc = p.ep_scale[plane];
         if (plane_ok && p.ep_bias) ep_bi = p.ep_bias[plane % p.chans];
     }
-    const T* yrefplane = (EPI == 2) ? (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w : nullptr;
+    const T* yrefplane = (EPI == 2) ? (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w
+                       : (EPI == 3) ? (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w : nullptr;
     float sum_g = 0.f, sum_gv = 0.f;
     const int own0 = cb * OWN;                               // first owned input column
     const bool own_full = plane_ok && own0 + OWN <= p.in_w;
@@ -630,6 +634,19 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI == 2 ? 6 : 8))) voi
                 const int ry = (R0Y + u * DOWN) / UP;
                 const int fy0 = UP - 1 - ((R0Y + u * DOWN) % UP);
                 float out[NOUT];
+                float yo[NOUT];
+                if constexpr (EPI == 3) {   // the forward output at this row's positions (same predicates as the stores below)
+#pragma unroll
+                    for (int v = 0; v < NOUT; v++) yo[v] = 0.f;
+                    const T* yr = yrefplane + (size_t)(oyd + u) * p.out_w + ox0;
+                    if (store_vec) row_loader<T, VEC>::run(yr, yo);
+                    else if (store_any) {
+#pragma unroll
+                        for (int v = 0; v < VEC; v++)
+                            if (ox0 + v < n_main) yo[v] = sgv_traits<T>::load(yr + v);
+                    }
+                    if constexpr (XTRA) { if (store_xtra) yo[VEC] = sgv_traits<T>::load(yr + VEC); }
+                }
 #pragma unroll
                 for (int v = 0; v < NOUT; v++) {
                     const int cx = (R0X + v * DOWN) / UP;
@@ -642,6 +659,12 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI == 2 ? 6 : 8))) voi
                             acc = __builtin_fmaf(win[ry + ky][cx + kx], ff[fy0 + ky * UP][fx0 + kx * UP], acc);
                     out[v] = acc * p.gain;
                     if constexpr (EPI == 1) out[v] = epi_fwd(out[v]);
+                    if constexpr (EPI == 3) {
+                        float pre;
+                        out[v] = epi_grad(out[v], yo[v], pre);
+                        const bool stored = v < VEC ? (store_vec || (store_any && ox0 + v < n_main)) : store_xtra;
+                        if (stored) sum_g += out[v];
+                    }
                 }
                 T* yrow = yplane + (size_t)(oyd + u) * p.out_w + ox0;
                 if (store_vec) {
@@ -658,7 +681,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI == 2 ? 6 : 8))) voi
             }
         }
     }
-    if constexpr (EPI == 2) {
+    if constexpr (EPI == 2 || EPI == 3) {
         // reduce over the lanes that share a plane (the whole wave, or one lane group with SEG), then one atomic per plane
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -666,7 +689,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI == 2 ? 6 : 8))) voi
         }
         if (sub == 0 && plane_ok) {
             atomicAdd(p.ep_sum_g + plane, sum_g);
-            atomicAdd(p.ep_sum_gv + plane, sum_gv);
+            if (p.ep_sum_gv) atomicAdd(p.ep_sum_gv + plane, sum_gv);
         }
     }
 }
@@ -684,6 +707,7 @@ lanes_fn pick_lanes_kernel(const sgv_upfirdn2d_params* p, int xtra, bool seg, in
                    : (xtra ? (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 1, false, LANES_WPB, E> : (lanes_fn)upfirdn2d_lanes_kernel<T, U, D, PX, PY, 0, false, LANES_WPB, E>);
     SGV_LANES_EPI(1, 1, 1, 1, 1)   // synthesis-layer epilogue: FIR (2r+1 -> 2r) * dcoefs + bias -> lrelu -> clamp
     SGV_LANES_EPI(1, 1, 2, 2, 2)   // its backward: lrelu'/clamp mask * dcoefs -> FIR (2r -> 2r+1), plane sums
+    SGV_LANES_EPI(1, 1, 1, 1, 3)   // backward of "activation, then the FIR in front of a strided convolution": FIR (2r+1 -> 2r), then lrelu'/clamp mask
 #undef SGV_LANES_EPI
     if (epi != 0) return nullptr;
 #define SGV_LANES(U, D, PX, PY)                                                                     \
@@ -940,17 +964,18 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
     int rc = validate(p, dtype);
     if (rc != SGV_OK) return rc;
     if (!e) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: epilogue is NULL");
-    if (e->mode != 1 && e->mode != 2) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode must be 1 (forward epilogue) or 2 (backward prologue)");
+    if (e->mode < 1 || e->mode > 3) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode must be 1 (forward epilogue), 2 (backward prologue) or 3 (backward epilogue)");
     if (e->act != 1 && e->act != 3) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: only linear (1) and lrelu (3) are fusable");
     if (e->act == 3 && e->alpha == 0.f) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: lrelu with alpha 0 is not invertible");
     if (e->mode == 2 && (!e->yref || !e->sum_g || !e->sum_gv)) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode 2 needs yref, sum_g and sum_gv");
+    if (e->mode == 3 && (!e->yref || !e->sum_g)) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode 3 needs yref and sum_g");
     hipStream_t stream = (hipStream_t)stream_;
     lanes_plan lplan;
     if (!plan_lanes(p, dtype, &lplan, e))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: geometry/layout not covered by the fused kernel (mode 1: up=down=1 pad 1, mode 2: up=down=1 pad 2, 4x4 filter, dense NCHW)");
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: geometry/layout not covered by the fused kernel (modes 1, 3: up=down=1 pad 1, mode 2: up=down=1 pad 2, 4x4 filter, dense NCHW)");
     const double es = (double)sgv_dtype_size(dtype);
     const double nin = (double)p->in_w * p->in_h * p->in_c * p->in_n, nout = (double)p->out_w * p->out_h * p->in_c * p->in_n;
-    const double bytes = (e->mode == 2 ? 2.0 * nin : nin) * es + nout * es;
+    const double bytes = (e->mode == 2 ? 2.0 * nin : nin) * es + (e->mode == 3 ? 2.0 * nout : nout) * es;
     sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
     hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
     return sgv_check_launch("upfirdn2d_lanes_kernel (fused)");

@@ -72,6 +72,13 @@ def downsampling_conv1x1(x, w, f, down, padding=0, residual=None, flip_filter=Fa
     return y + residual if residual is not None else y
 
 
+def downsampling_pads(f, down, padding=0):
+    """(px0, px1, py0, py1) of the FIR pass in front of a stride-`down` convolution (the arithmetic of ``conv2d_resample`` below)."""
+    fw, fh = _get_filter_size(f)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    return (px0 + (fw - down + 1) // 2, px1 + (fw - down) // 2, py0 + (fh - down + 1) // 2, py1 + (fh - down) // 2)
+
+
 def downsampling_filter_pass(x, f, down, padding=0, kernel_hw=(3, 3), flip_filter=False):
     """The FIR pass that ``conv2d_resample`` puts in front of its strided convolution (`down > 1 and up == 1`, non-pointwise kernel): returns the
     filtered tensor the stride-`down` convolution then reads, so that a caller can run a fused convolution tail on it (ops/fused_down_act.py)."""

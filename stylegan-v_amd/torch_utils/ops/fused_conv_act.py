@@ -169,3 +169,89 @@ def conv3x3_bias_act(x, weight, styles=None, dcoefs=None, bias=None, act='lrelu'
     if _fusable(x, weight, styles, dcoefs, bias, act, alpha_f, gain_f, clamp_f):
         return _FusedConvBiasActFn.apply(x, weight, styles, dcoefs, bias, (act, alpha_f, gain_f, clamp_f))
     return conv3x3_bias_act_composed(x, weight, styles=styles, dcoefs=dcoefs, bias=bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Stride-1 layer whose output goes straight into the FIR in front of a down-sampling convolution (DiscriminatorBlock: conv0 -> conv1,
+# networks.py:343-344; the FIR is conv2d_resample.py:113-126's).  Forward is the fused layer kernel followed by the FIR pass; what the pairing
+# buys is the backward pass: the FIR's gradient (another FIR) and the layer's activation gradient are ONE kernel (sgv_upfirdn2d_fused mode 3)
+# instead of upfirdn2d + sgv_act_grad_scale -- three tensor passes instead of five on the block's largest activations.
+
+def conv3x3_bias_act_then_fir_composed(x, weight, bias, f, pads, act='lrelu', alpha=None, gain=None, clamp=None):
+    from . import upfirdn2d as _ufd
+    y = conv3x3_bias_act_composed(x, weight, bias=bias, act=act, alpha=alpha, gain=gain, clamp=clamp)
+    return _ufd.upfirdn2d(y, f, padding=list(pads))
+
+
+class _FusedConvActFirFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, f, cfg):
+        from . import upfirdn2d as _ufd
+        act, alpha, gain, clamp, pads = cfg
+        b = bias.contiguous().float() if bias is not None else None
+        y0 = _launch_fused(x.contiguous(), weight.contiguous(), None, None, b, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
+        xb = _ufd.upfirdn2d(y0, f, padding=list(pads))
+        ctx.cfg = cfg
+        ctx.bias_dtype = bias.dtype if bias is not None else None
+        ctx.save_for_backward(x, weight, bias, f, y0)
+        return xb
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import fused_fir_act as _ffa
+        from . import upfirdn2d as _ufd
+        act, alpha, gain, clamp, pads = ctx.cfg
+        x, weight, b, f, y0 = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            ins = [t for t, need in zip((x, weight, b), ctx.needs_input_grad[:3]) if need and t is not None]
+            with torch.enable_grad():
+                y2 = conv3x3_bias_act_then_fir_composed(x, weight, b, f, pads, act=act, alpha=alpha, gain=gain, clamp=(clamp if clamp >= 0 else None))
+                grads = iter(torch.autograd.grad(y2, ins, g, create_graph=True, allow_unused=True))
+            return tuple(next(grads) if (need and t is not None) else None for t, need in zip((x, weight, b), ctx.needs_input_grad[:3])) + (None, None)
+        lib = custom_ops.get_native()
+        g = g.contiguous()
+        n, co, h, w = y0.shape
+        fh, fw = f.shape
+        # the gradient of upfirdn2d is upfirdn2d with the padding of upfirdn2d.py:251-261 and the filter flip inverted
+        bpads = (fw - pads[0] - 1, w - g.shape[3] + pads[0], fh - pads[2] - 1, h - g.shape[2] + pads[2])
+        dz = torch.empty_like(y0)
+        sums = torch.zeros([n * co], dtype=torch.float32, device=g.device)
+        e = custom_ops.FirEpilogue(3, None, None, y0.data_ptr(), sums.data_ptr(), None, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
+        with custom_ops.device_guard(g):
+            rc = lib.sgv_upfirdn2d_fused(_ffa._ufd_params(g, f, dz, bpads, True, 1.0), e, 0, custom_ops.raw_stream(g))
+        need_db = b is not None and ctx.needs_input_grad[2]
+        d_x = d_w = d_b = None
+        if rc == 0:
+            if need_db:
+                d_b = sums.reshape(n, co).sum(0).to(ctx.bias_dtype)
+        elif rc == -3:   # SGV_ERR_UNSUPPORTED (a geometry / width the lane-exchange kernel does not serve): the two passes
+            gy = _ufd.upfirdn2d(g, f, padding=list(bpads), flip_filter=True)
+            s2 = torch.zeros([2, n * co], dtype=torch.float32, device=g.device) if need_db else None
+            with custom_ops.device_guard(g):
+                custom_ops.check(lib.sgv_act_grad_scale(gy.data_ptr(), y0.data_ptr(), None, dz.data_ptr(), s2.data_ptr() if s2 is not None else None, n * co, h * w,
+                                                        _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, custom_ops.raw_stream(g)), lib)
+            if need_db:
+                d_b = s2[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
+        else:
+            custom_ops.check(rc, lib)
+        wc = weight.contiguous()
+        cfg1 = (False, (1, 1), (1, 1), (0, 0), (1, 1), 1)
+        if ctx.needs_input_grad[0]:
+            tcfg = (True, (1, 1), (1, 1), (0, 0), (1, 1), 1)
+            d_x = _cg._native_conv(dz, wc, tcfg) if _cg._native_conv_ok(dz, wc, tcfg) else _cg._aten_conv(dz, wc, None, tcfg)
+        if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
+            if _cg._native_wrw_ok(dz, x, cfg1, tuple(weight.shape)):
+                d_w = _cg._native_wrw(dz, x, cfg1, tuple(weight.shape))
+            else:
+                _, d_w, _ = torch.ops.aten.convolution_backward(dz, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
+        return d_x, d_w, d_b, None, None
+
+
+def conv3x3_bias_act_then_fir(x, weight, bias, f, pads, act='lrelu', alpha=None, gain=None, clamp=None):
+    """upfirdn2d(conv3x3_bias_act(x, weight, bias=bias, ...), f, padding=pads) for an un-modulated layer; pads = (px0, px1, py0, py1)."""
+    _, alpha_f, gain_f, clamp_f = _ba._resolve(act, alpha, gain, clamp)
+    pads = tuple(int(v) for v in pads)
+    if (_fusable(x, weight, None, None, bias, act, alpha_f, gain_f, clamp_f) and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4) and f.is_cuda
+            and f.dtype == torch.float32 and pads == (2, 2, 2, 2)):
+        return _FusedConvActFirFn.apply(x, weight, bias, f, (act, alpha_f, gain_f, clamp_f, pads))
+    return conv3x3_bias_act_then_fir_composed(x, weight, bias, f, pads, act=act, alpha=alpha, gain=gain, clamp=clamp)

@@ -126,9 +126,8 @@ class Conv2dLayer(torch.nn.Module):
             else:
                 self.bias = None
 
-    def forward(self, x, gain=1, residual=None):
-        """``residual`` (optional, same shape as the result): added to the layer's output -- the `y.add_(x)` of the residual discriminator block
-        (networks.py:343-345) folded into the layer so that the down-sampling convolution can do it in its epilogue."""
+    def _scaled_parameters(self, x, gain):
+        """(w, b, act_gain, clamp) of ``forward``: equalised-lr weight scale, and the gain of a linear un-clamped layer folded into the weights."""
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         act_gain = self.act_gain * gain
         fold = 1.0
@@ -138,6 +137,29 @@ class Conv2dLayer(torch.nn.Module):
             fold, act_gain = act_gain, 1.0
         w = self.weight * (self.weight_gain * self.lr_multiplier * fold)
         b = self.bias.to(x.dtype) * (self.lr_multiplier * fold) if self.bias is not None else None
+        return w, b, act_gain, clamp
+
+    def fusable_with_following_fir(self, x):
+        """A plain stride-1 3x3 layer on a GPU fp32 tensor: ``forward_then_fir`` may pair it with the FIR pass of the next (down-sampling) layer."""
+        return (self.up == 1 and self.down == 1 and self.padding == 1 and tuple(self.weight.shape[2:]) == (3, 3) and bool(fused_conv_act.mode) and x.is_cuda
+                and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm)
+
+    def accepts_prefiltered(self, x):
+        """A down-sampling 3x3 layer that ``forward(..., prefiltered=True)`` serves (x: the tensor the FIR pass will be applied to)."""
+        return (self.up == 1 and self.down == 2 and self.padding == 1 and tuple(self.weight.shape[2:]) == (3, 3) and bool(fused_conv_act.mode) and x.is_cuda
+                and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm)
+
+    def forward_then_fir(self, x, f, pads, gain=1):
+        """upfirdn2d(self(x, gain), f, padding=pads) -- this layer followed by the FIR pass in front of the next layer's strided convolution, as one
+        autograd node whose backward pass runs the FIR's gradient and this layer's activation gradient in one kernel."""
+        w, b, act_gain, clamp = self._scaled_parameters(x, gain)
+        return fused_conv_act.conv3x3_bias_act_then_fir(x, w, b, f, pads, act=self.activation, gain=act_gain, clamp=clamp)
+
+    def forward(self, x, gain=1, residual=None, prefiltered=False):
+        """``residual`` (optional, same shape as the result): added to the layer's output -- the `y.add_(x)` of the residual discriminator block
+        (networks.py:343-345) folded into the layer so that the down-sampling convolution can do it in its epilogue.
+        ``prefiltered``: x already went through this (down-sampling 3x3) layer's FIR pass (``forward_then_fir`` of the previous layer)."""
+        w, b, act_gain, clamp = self._scaled_parameters(x, gain)
         if self.up == 1 and self.down == 1 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu'):
             # stride-1 3x3 layer (DiscriminatorBlock conv0, epilogue conv): convolution + bias + activation as one kernel where served
@@ -155,10 +177,11 @@ class Conv2dLayer(torch.nn.Module):
         elif self.up == 1 and self.down == 2 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm:
             # down-sampling 3x3 layer (DiscriminatorBlock conv1): FIR pass, then strided convolution + bias + activation (+ residual) as one kernel
-            xb = conv2d_resample.downsampling_filter_pass(x, self.resample_filter, down=self.down, padding=self.padding)
+            xb = x if prefiltered else conv2d_resample.downsampling_filter_pass(x, self.resample_filter, down=self.down, padding=self.padding)
             x = fused_down_act.strided_conv3x3_bias_act(xb, w, bias=b, act=self.activation, gain=act_gain, clamp=clamp, residual=residual)
             residual = None
         else:
+            assert not prefiltered, 'prefiltered input is only understood by the fused down-sampling 3x3 path'
             x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
                                                 padding=self.padding, flip_weight=(self.up == 1))
             if b is not None or self.activation != 'linear' or act_gain != 1 or clamp is not None:   # (a no-op bias_act hands its input back as-is)

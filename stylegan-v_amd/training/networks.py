@@ -345,7 +345,13 @@ class DiscriminatorBlock(torch.nn.Module):
             # `y = skip(x); x = conv1(conv0(x)); x = y.add_(x)` of the reference, evaluated in the other order so that the sum is formed in the
             # store of the skip branch's 1x1 convolution (its GEMM has the spare load slots; the 3x3 kernel's MFMA waves do not)
             if residual_in_skip:
-                y = self.conv1(self.conv0(x), gain=math.sqrt(0.5))
+                if self.conv0.fusable_with_following_fir(x) and self.conv1.accepts_prefiltered(x):
+                    # conv0 and the FIR pass in front of conv1's strided convolution as one autograd node (one-kernel FIR + activation gradient)
+                    f1 = self.conv1.resample_filter
+                    xb = self.conv0.forward_then_fir(x, f1, conv2d_resample.downsampling_pads(f1, self.conv1.down, self.conv1.padding))
+                    y = self.conv1(xb, gain=math.sqrt(0.5), prefiltered=True)
+                else:
+                    y = self.conv1(self.conv0(x), gain=math.sqrt(0.5))
                 x = self.skip(x, gain=math.sqrt(0.5), residual=y)
             else:   # the sum in the strided 3x3 kernel's store instead (one atomic add per element into the skip branch's result)
                 y = self.skip(x, gain=math.sqrt(0.5))

@@ -200,3 +200,48 @@ def test_fused_down_layer_second_order_and_fallbacks():
         with fused_conv_act.composition_only():
             yc = fused_down_act.strided_conv3x3_bias_act(xb, wt, bias=b, act='lrelu', residual=res.clone())
     assert _rel(yf, yc.double().cpu()) < 1e-5 and y.shape == (2, 64, 8, 32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Stride-1 layer + the FIR in front of the next layer's strided convolution as one node (fused_conv_act.conv3x3_bias_act_then_fir): the backward
+# pass runs the FIR's gradient and the activation gradient in ONE kernel (sgv_upfirdn2d_fused mode 3).
+
+@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 160), (1, 32, 64, 32, 64), (3, 16, 128, 16, 32)])
+@pytest.mark.parametrize('act,clamp', [('lrelu', None), ('lrelu', 0.9), ('linear', None)])
+def test_layer_then_fir_matches_the_composition(n, ci, co, h, w, act, clamp):
+    from stylegan_v_amd.torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(n + ci + co + h + w)
+    x = torch.randn([n, ci, h, w], generator=g).to(DEV).requires_grad_(True)
+    wt = (torch.randn([co, ci, 3, 3], generator=g) / (3 * ci ** 0.5)).to(DEV).requires_grad_(True)
+    b = (torch.randn([co], generator=g) * 0.3).to(DEV).requires_grad_(True)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    pads = (2, 2, 2, 2)
+    gain = 2 ** 0.5 if act == 'lrelu' else 0.8
+    y = fused_conv_act.conv3x3_bias_act_then_fir(x, wt, b, f, pads, act=act, gain=gain, clamp=clamp)
+    with fused_conv_act.composition_only():
+        yc = fused_conv_act.conv3x3_bias_act_then_fir(x, wt, b, f, pads, act=act, gain=gain, clamp=clamp)
+    assert y.shape == (n, co, h + 1, w + 1) and _rel(y, yc.double().cpu()) < 1e-5
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    custom_ops.prof_enable(64)
+    got = torch.autograd.grad(y, [x, wt, b], dy)
+    custom_ops.prof_disable()
+    prof = custom_ops.prof_collect()
+    want = torch.autograd.grad(yc, [x, wt, b], dy)
+    for a, r, name in zip(got, want, 'xwb'):
+        # the activation mask comes from each side's own forward output: elements within rounding of the kink / clamp bound may differ
+        err = _rel(a, r.double().cpu())
+        assert err < 5e-4, f'd{name}: {err:.2e}'
+    if w + 1 >= 129 or True:
+        assert prof.get('modulate', {}).get('launches', 0) == 0, 'no separate activation-gradient pass'
+
+    def r1(fn):
+        yy = fn(x, wt, b, f, pads, act=act, gain=gain, clamp=clamp)
+        (gx,) = torch.autograd.grad(yy.sum(), x, create_graph=True)
+        return torch.autograd.grad(gx.square().sum(), [wt, b], allow_unused=True)
+    got2 = r1(fused_conv_act.conv3x3_bias_act_then_fir)
+    with fused_conv_act.composition_only():
+        want2 = r1(fused_conv_act.conv3x3_bias_act_then_fir)
+    for a, r in zip(got2, want2):
+        assert (a is None) == (r is None)
+        if a is not None:
+            assert _rel(a, r.double().cpu()) < 1e-4
