@@ -279,6 +279,8 @@ typedef struct sgv_conv3x3_epilogue {
     const float* bias;       /* [c_out]    or NULL */
     int32_t act;             /* 1 linear, 3 lrelu */
     float alpha, gain, clamp;
+    int32_t accumulate;      /* != 0: y += result (one fp32 add per element) -- e.g. a data gradient summed into the gradient that already
+                                arrived from the layer input's other consumer (act 1, gain 1, no bias / scales: the bare convolution) */
 } sgv_conv3x3_epilogue;
 int sgv_conv3x3_fused(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* e, int dtype, void* stream);
 int sgv_conv3x3_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype);

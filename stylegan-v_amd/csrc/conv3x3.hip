@@ -157,7 +157,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
         int pro = 0, epi = 0;
         if (ep) {
             wp.xscale = ep->x_scale; wp.oscale = ep->out_scale; wp.bias = ep->bias;
-            wp.act = ep->act; wp.alpha = ep->alpha; wp.gain = ep->gain; wp.clamp = ep->clamp;
+            wp.act = ep->act; wp.alpha = ep->alpha; wp.gain = ep->gain; wp.clamp = ep->clamp; wp.accumulate = ep->accumulate;
             pro = ep->x_scale ? 1 : 0;
             epi = 1;
         }

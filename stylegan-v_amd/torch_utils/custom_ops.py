@@ -203,7 +203,8 @@ class Conv3x3Params(ctypes.Structure):
 
 
 class Conv3x3Epilogue(ctypes.Structure):
-    _fields_ = [('x_scale', c_void_p), ('out_scale', c_void_p), ('bias', c_void_p), ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float)]
+    _fields_ = [('x_scale', c_void_p), ('out_scale', c_void_p), ('bias', c_void_p), ('act', c_int32), ('alpha', c_float), ('gain', c_float), ('clamp', c_float),
+                ('accumulate', c_int32)]
 
 
 class Conv3x3S2Epilogue(ctypes.Structure):

@@ -33,6 +33,7 @@ from . import modulation as _mod
 # 0: never fuse; 1: only passes that record no autograd graph (the generator pass of the D phase, inference); 2: training too
 mode = int(os.environ.get('SGV_FUSED_CONV', '2'))
 _composition_depth = 0
+accumulate_input_gradients = os.environ.get('SGV_ALIAS_ACC', '1') != '0'   # _FusedConvActFirFn: sum the layer input's two gradients in the data-gradient kernel's store
 
 
 @contextlib.contextmanager
@@ -56,16 +57,18 @@ def conv3x3_bias_act_composed(x, weight, styles=None, dcoefs=None, bias=None, ac
     return _ba.bias_act(y, bias.to(y.dtype) if bias is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 
-def _launch_fused(x, weight, styles, dcoefs, bias, act_idx, alpha, gain, clamp):
+def _launch_fused(x, weight, styles, dcoefs, bias, act_idx, alpha, gain, clamp, mode=0, accumulate_into=None):
+    """mode 0: forward (weight [O,I,3,3]); mode 1: data gradient of that layer (x is the output-side tensor, the result has I channels).
+    ``accumulate_into``: an existing fp32 tensor of the result's shape that receives  += result  instead of a fresh output."""
     lib = custom_ops.get_native()
     n, ci, h, w = x.shape
-    co = weight.shape[0]
-    y = torch.empty([n, co, h, w], dtype=torch.float32, device=x.device)
+    co = weight.shape[0] if mode == 0 else weight.shape[1]
+    y = accumulate_into if accumulate_into is not None else torch.empty([n, co, h, w], dtype=torch.float32, device=x.device)
     ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
     ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
-    p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, 0, _cg.native_conv_terms)
+    p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, mode, _cg.native_conv_terms)
     e = custom_ops.Conv3x3Epilogue(styles.data_ptr() if styles is not None else None, dcoefs.data_ptr() if dcoefs is not None else None,
-                                   bias.data_ptr() if bias is not None else None, act_idx, alpha, gain, clamp)
+                                   bias.data_ptr() if bias is not None else None, act_idx, alpha, gain, clamp, 1 if accumulate_into is not None else 0)
     with custom_ops.device_guard(x):
         custom_ops.check(lib.sgv_conv3x3_fused(p, e, 0, custom_ops.raw_stream(x)), lib)
     return y
@@ -191,13 +194,16 @@ class _FusedConvActFirFn(torch.autograd.Function):
         b = bias.contiguous().float() if bias is not None else None
         y0 = _launch_fused(x.contiguous(), weight.contiguous(), None, None, b, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
         xb = _ufd.upfirdn2d(y0, f, padding=list(pads))
+        ctx.set_materialize_grads(False)   # an unused output's gradient arrives as None, not as a tensor of zeros
         ctx.cfg = cfg
         ctx.bias_dtype = bias.dtype if bias is not None else None
         ctx.save_for_backward(x, weight, bias, f, y0)
-        return xb
+        # second output: x itself, for the layer input's OTHER consumer (the residual block's skip branch).  Its gradient then arrives here
+        # as g_alias and the data-gradient convolution adds into it in its store, instead of autograd adding two full tensors afterwards.
+        return xb, x.view_as(x)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_alias=None):
         from . import fused_fir_act as _ffa
         from . import upfirdn2d as _ufd
         act, alpha, gain, clamp, pads = ctx.cfg
@@ -207,7 +213,12 @@ class _FusedConvActFirFn(torch.autograd.Function):
             with torch.enable_grad():
                 y2 = conv3x3_bias_act_then_fir_composed(x, weight, b, f, pads, act=act, alpha=alpha, gain=gain, clamp=(clamp if clamp >= 0 else None))
                 grads = iter(torch.autograd.grad(y2, ins, g, create_graph=True, allow_unused=True))
-            return tuple(next(grads) if (need and t is not None) else None for t, need in zip((x, weight, b), ctx.needs_input_grad[:3])) + (None, None)
+            out = [next(grads) if (need and t is not None) else None for t, need in zip((x, weight, b), ctx.needs_input_grad[:3])]
+            if g_alias is not None and ctx.needs_input_grad[0]:
+                out[0] = g_alias if out[0] is None else out[0] + g_alias
+            return tuple(out) + (None, None)
+        if g is None:   # only the alias was used downstream
+            return (g_alias if ctx.needs_input_grad[0] else None), None, None, None, None
         lib = custom_ops.get_native()
         g = g.contiguous()
         n, co, h, w = y0.shape
@@ -238,7 +249,15 @@ class _FusedConvActFirFn(torch.autograd.Function):
         cfg1 = (False, (1, 1), (1, 1), (0, 0), (1, 1), 1)
         if ctx.needs_input_grad[0]:
             tcfg = (True, (1, 1), (1, 1), (0, 0), (1, 1), 1)
-            d_x = _cg._native_conv(dz, wc, tcfg) if _cg._native_conv_ok(dz, wc, tcfg) else _cg._aten_conv(dz, wc, None, tcfg)
+            ci = x.shape[1]
+            if (accumulate_input_gradients and g_alias is not None and g_alias.is_contiguous() and g_alias.dtype == torch.float32 and _cg.native_conv_terms in (1, 3)
+                    and lib.sgv_conv3x3_fused_supported(n, co, ci, h, w, 0)):
+                # the data gradient lands IN the gradient the skip branch produced (one fp32 add per element in the convolution's store)
+                d_x = _launch_fused(dz, wc, None, None, None, 1, 0.0, 1.0, -1.0, mode=1, accumulate_into=g_alias)
+            else:
+                d_x = _cg._native_conv(dz, wc, tcfg) if _cg._native_conv_ok(dz, wc, tcfg) else _cg._aten_conv(dz, wc, None, tcfg)
+                if g_alias is not None:
+                    d_x = d_x + g_alias
         if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
             if _cg._native_wrw_ok(dz, x, cfg1, tuple(weight.shape)):
                 d_w = _cg._native_wrw(dz, x, cfg1, tuple(weight.shape))
@@ -247,11 +266,15 @@ class _FusedConvActFirFn(torch.autograd.Function):
         return d_x, d_w, d_b, None, None
 
 
-def conv3x3_bias_act_then_fir(x, weight, bias, f, pads, act='lrelu', alpha=None, gain=None, clamp=None):
-    """upfirdn2d(conv3x3_bias_act(x, weight, bias=bias, ...), f, padding=pads) for an un-modulated layer; pads = (px0, px1, py0, py1)."""
+def conv3x3_bias_act_then_fir(x, weight, bias, f, pads, act='lrelu', alpha=None, gain=None, clamp=None, with_input_alias=False):
+    """upfirdn2d(conv3x3_bias_act(x, weight, bias=bias, ...), f, padding=pads) for an un-modulated layer; pads = (px0, px1, py0, py1).
+    ``with_input_alias``: also return x for its other consumer (a residual block's skip branch) -- through the fused node, so that the two
+    gradients of x meet inside the data-gradient convolution instead of in a separate addition."""
     _, alpha_f, gain_f, clamp_f = _ba._resolve(act, alpha, gain, clamp)
     pads = tuple(int(v) for v in pads)
     if (_fusable(x, weight, None, None, bias, act, alpha_f, gain_f, clamp_f) and f is not None and f.ndim == 2 and tuple(f.shape) == (4, 4) and f.is_cuda
             and f.dtype == torch.float32 and pads == (2, 2, 2, 2)):
-        return _FusedConvActFirFn.apply(x, weight, bias, f, (act, alpha_f, gain_f, clamp_f, pads))
-    return conv3x3_bias_act_then_fir_composed(x, weight, bias, f, pads, act=act, alpha=alpha, gain=gain, clamp=clamp)
+        xb, x_alias = _FusedConvActFirFn.apply(x, weight, bias, f, (act, alpha_f, gain_f, clamp_f, pads))
+        return (xb, x_alias) if with_input_alias else xb
+    xb = conv3x3_bias_act_then_fir_composed(x, weight, bias, f, pads, act=act, alpha=alpha, gain=gain, clamp=clamp)
+    return (xb, x) if with_input_alias else xb

@@ -149,11 +149,11 @@ class Conv2dLayer(torch.nn.Module):
         return (self.up == 1 and self.down == 2 and self.padding == 1 and tuple(self.weight.shape[2:]) == (3, 3) and bool(fused_conv_act.mode) and x.is_cuda
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm)
 
-    def forward_then_fir(self, x, f, pads, gain=1):
+    def forward_then_fir(self, x, f, pads, gain=1, with_input_alias=False):
         """upfirdn2d(self(x, gain), f, padding=pads) -- this layer followed by the FIR pass in front of the next layer's strided convolution, as one
         autograd node whose backward pass runs the FIR's gradient and this layer's activation gradient in one kernel."""
         w, b, act_gain, clamp = self._scaled_parameters(x, gain)
-        return fused_conv_act.conv3x3_bias_act_then_fir(x, w, b, f, pads, act=self.activation, gain=act_gain, clamp=clamp)
+        return fused_conv_act.conv3x3_bias_act_then_fir(x, w, b, f, pads, act=self.activation, gain=act_gain, clamp=clamp, with_input_alias=with_input_alias)
 
     def forward(self, x, gain=1, residual=None, prefiltered=False):
         """``residual`` (optional, same shape as the result): added to the layer's output -- the `y.add_(x)` of the residual discriminator block

@@ -348,7 +348,8 @@ class DiscriminatorBlock(torch.nn.Module):
                 if self.conv0.fusable_with_following_fir(x) and self.conv1.accepts_prefiltered(x):
                     # conv0 and the FIR pass in front of conv1's strided convolution as one autograd node (one-kernel FIR + activation gradient)
                     f1 = self.conv1.resample_filter
-                    xb = self.conv0.forward_then_fir(x, f1, conv2d_resample.downsampling_pads(f1, self.conv1.down, self.conv1.padding))
+                    # (x comes back as the node's second output for the skip branch: its gradient is then summed inside the data-gradient kernel)
+                    xb, x = self.conv0.forward_then_fir(x, f1, conv2d_resample.downsampling_pads(f1, self.conv1.down, self.conv1.padding), with_input_alias=True)
                     y = self.conv1(xb, gain=math.sqrt(0.5), prefiltered=True)
                 else:
                     y = self.conv1(self.conv0(x), gain=math.sqrt(0.5))

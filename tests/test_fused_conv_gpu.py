@@ -245,3 +245,32 @@ def test_layer_then_fir_matches_the_composition(n, ci, co, h, w, act, clamp):
         assert (a is None) == (r is None)
         if a is not None:
             assert _rel(a, r.double().cpu()) < 1e-4
+
+
+def test_layer_then_fir_sums_the_input_gradients_inside_the_data_gradient_kernel():
+    """with_input_alias: the layer input's other consumer reads the node's second output; its gradient is added to by the data-gradient
+    convolution's store (no separate full-tensor addition) and the total equals the composition's."""
+    from stylegan_v_amd.torch_utils.ops import upfirdn2d
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn([2, 64, 32, 64], generator=g).to(DEV).requires_grad_(True)
+    wt = (torch.randn([64, 64, 3, 3], generator=g) / 24).to(DEV).requires_grad_(True)
+    b = (torch.randn([64], generator=g) * 0.3).to(DEV).requires_grad_(True)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    dy = torch.randn([2, 64, 33, 65], generator=g).to(DEV)
+    dz = torch.randn([2, 64, 32, 64], generator=g).to(DEV)
+
+    def loss(alias):
+        xb, xa = fused_conv_act.conv3x3_bias_act_then_fir(x, wt, b, f, (2, 2, 2, 2), act='lrelu', with_input_alias=alias)
+        return (xb * dy).sum() + ((xa if alias else x) * 3.0 * dz).sum()
+    custom_ops.prof_enable(64)
+    got = torch.autograd.grad(loss(True), [x, wt, b])
+    custom_ops.prof_disable()
+    assert custom_ops.prof_collect()['conv3x3']['launches'] == 2          # forward and data gradient (the weight gradient is its own family)
+    with fused_conv_act.composition_only():
+        want = torch.autograd.grad(loss(False), [x, wt, b])
+    for a, r, name in zip(got, want, 'xwb'):
+        assert _rel(a, r.double().cpu()) < 5e-4, name
+    # only the alias used downstream: its gradient passes through untouched
+    xb, xa = fused_conv_act.conv3x3_bias_act_then_fir(x, wt, b, f, (2, 2, 2, 2), act='lrelu', with_input_alias=True)
+    (gx,) = torch.autograd.grad((xa * dz).sum(), [x])
+    assert torch.equal(gx, dz)
