@@ -260,8 +260,9 @@ def test_layer_then_fir_sums_the_input_gradients_inside_the_data_gradient_kernel
     dz = torch.randn([2, 64, 32, 64], generator=g).to(DEV)
 
     def loss(alias):
-        xb, xa = fused_conv_act.conv3x3_bias_act_then_fir(x, wt, b, f, (2, 2, 2, 2), act='lrelu', with_input_alias=alias)
-        return (xb * dy).sum() + ((xa if alias else x) * 3.0 * dz).sum()
+        out = fused_conv_act.conv3x3_bias_act_then_fir(x, wt, b, f, (2, 2, 2, 2), act='lrelu', with_input_alias=alias)
+        xb, xa = out if alias else (out, x)
+        return (xb * dy).sum() + (xa * 3.0 * dz).sum()
     custom_ops.prof_enable(64)
     got = torch.autograd.grad(loss(True), [x, wt, b])
     custom_ops.prof_disable()
