@@ -186,13 +186,21 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
             const int col = n0 + wn + j * 32 + lr;
             if (!FULL && col >= p.n) continue;
             const float bcol = (p.bias_mode == 1) ? p.bias[col] : 0.f;
+            // the residual's 16 values of this 32x32 tile are fetched as one batch before the stores (C and the residual never alias, but the
+            // compiler cannot know: interleaved, every load would wait behind the previous store)
+            float rv[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                rv[e] = (RES && (FULL == 1 || row < p.m)) ? RES[(int64_t)row * p.ldc + col] : 0.f;
+            }
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 if (FULL != 1 && row >= p.m) continue;
                 float v = acc[i][j][e] + bcol;
                 if (p.bias_mode == 2) v += p.bias[row];
-                if (RES) v += RES[(int64_t)row * p.ldc + col];
+                if (RES) v += rv[e];
                 C[(int64_t)row * p.ldc + col] = v;
             }
         }
