@@ -529,13 +529,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             const float al = ep.act == 3 ? ep.alpha : 1.f;
             const float g0 = ep.gain, g1 = ep.gain * al;
             const float clamp_hi = ep.clamp >= 0.f ? ep.clamp : __builtin_inff();
+            // all sixteen bias vectors of the tile first: on gfx9 loads and stores share vmcnt, so a load issued behind stores is not usable
+            // before those stores have drained
+            f32x4 bvs[4][4];
+#pragma unroll
+            for (int mq = 0; mq < 4; mq++)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; e4++) {
+                    bvs[mq][e4] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (EPI == 1 && ep.bias) bvs[mq][e4] = *(const f32x4*)(ep.bias + tp.mt * P2_TM + mq * 32 + 8 * e4 + 4 * ge);
+                }
 #pragma unroll
             for (int mq = 0; mq < 4; mq++)
 #pragma unroll
                 for (int e4 = 0; e4 < 4; e4++) {
                     const int m0 = mq * 32 + 8 * e4 + 4 * ge;
-                    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                    if (EPI == 1 && ep.bias) bv = *(const f32x4*)(ep.bias + tp.mt * P2_TM + m0);
+                    const f32x4 bv = bvs[mq][e4];
 #pragma unroll
                     for (int ei = 0; ei < 4; ei++)
 #pragma unroll
