@@ -159,7 +159,8 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
             wp.xscale = ep->x_scale; wp.oscale = ep->out_scale; wp.bias = ep->bias;
             wp.act = ep->act; wp.alpha = ep->alpha; wp.gain = ep->gain; wp.clamp = ep->clamp; wp.accumulate = ep->accumulate;
             pro = ep->x_scale ? 1 : 0;
-            epi = 1;
+            // a bare convolution (no scales, no bias, linear, gain 1, no clamp: the accumulate-into data gradient) keeps the plain store path
+            epi = (ep->out_scale || ep->bias || ep->act != 1 || ep->gain != 1.f || ep->clamp >= 0.f) ? 1 : 0;
         }
         hipLaunchKernelGGL(g_ws_kernels[p->terms == 3][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
         return sgv_check_launch("conv3x3_ws_kernel");

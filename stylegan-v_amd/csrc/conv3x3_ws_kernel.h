@@ -37,7 +37,7 @@ struct conv_ws_params {
     const float* bias;     // EPI >= 1: [m] or NULL
     int act;               // 1 linear, 3 lrelu  (bias_act.cu activation indices)
     float alpha, gain, clamp;   // clamp < 0: none
-    int accumulate;        // EPI >= 1: y += result (one no-return fp32 atomic per element) instead of y = result
+    int accumulate;        // y += result (one no-return fp32 atomic per element) instead of y = result
 };
 
 // PRO: 0 plain x, 1 x * xscale[n,k].
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                                 v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);   // one instruction; clamp_hi = +inf when there is no clamp
                             }
                             if (ABL == 4) asm volatile("" :: "v"(v));
-                            else if (EPI == 1 && pp.accumulate) atomicAdd(yb + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
+                            else if (pp.accumulate) atomicAdd(yb + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
                             else yb[(size_t)(m0 + ei) * plane + (size_t)r * p.w] = v;
                             acc[r][hf][4 * e4 + ei] = 0.f;
                         }
