@@ -245,15 +245,25 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(b.data(), y + na / 2, b.size() * 4, hipMemcpyDeviceToHost));
         double md = 0; for (size_t i = 0; i < a.size(); i++) md = fmax(md, fabs((double)a[i] - b[i]));
         const double flops = 2.0 * s.n * s.r * s.r * (double)s.c * s.c * 9;
-        float best[4] = {1e9f, 1e9f, 1e9f, 1e9f};
-        for (int round = 0; round < 3; round++) for (int v = 0; v < 4; v++) {
+        float best[7] = {1e9f, 1e9f, 1e9f, 1e9f, 1e9f, 1e9f, 1e9f};
+        static bool attr2 = false;
+        if (!attr2) {
+            CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+            CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+            CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 0, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+            attr2 = true;
+        }
+        for (int round = 0; round < 3; round++) for (int v = 0; v < 7; v++) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             CK(hipEventRecord(e0));
             for (int r = 0; r < reps; r++) {
                 if (v == 0) hipLaunchKernelGGL(conv3x3_kernel<3>, dim3(256), dim3(256), LDS_BYTES, 0, p0);
                 else if (v == 1) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
                 else if (v == 2) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 1, 1>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
-                else hipLaunchKernelGGL((conv3x3_ws_kernel<1, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+                else if (v == 3) hipLaunchKernelGGL((conv3x3_ws_kernel<1, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+                else if (v == 4) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 0, 1>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+                else if (v == 5) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 1, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
+                else hipLaunchKernelGGL((conv3x3_ws_kernel<3, 0, 1, 4>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
             }
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
@@ -261,6 +271,7 @@ int main(int argc, char** argv) {
         }
         printf("%-12s 4-wave %7.3f ms %6.1f TF | ws %7.3f ms %6.1f TF | ws+PRO+EPI %7.3f ms | ws terms=1 %7.3f ms %6.1f TF   (max |diff| ws vs 4-wave %.2e)\n", s.name,
                best[0], flops / best[0] / 1e9, best[1], flops / best[1] / 1e9, best[2], best[3], flops / best[3] / 1e9, md);
+        printf("%-12s    EPI only %7.3f ms | PRO only %7.3f ms | EPI without its stores %7.3f ms\n", s.name, best[4], best[5], best[6]);
         fflush(stdout);
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep)); CK(hipFree(xsc)); CK(hipFree(osc)); CK(hipFree(bias));
     }
