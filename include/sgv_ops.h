@@ -99,14 +99,17 @@ int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* stream);
  *           ACTIVATION that fed the (transposed) FIR -- yref has the shape of the result; sum_g[n,c] += sum(dx) (the bias gradient).
  *           The backward pass of "bias_act, then the FIR in front of a strided convolution" (DiscriminatorBlock conv0 -> conv1,
  *           networks.py:343-344 via conv2d_resample.py:113-126) in one pass instead of upfirdn2d + bias_act(grad 1).  scale / bias unused.
+ *   mode 4  y = upfirdn2d(x) + yref,  yref shaped like y: a gradient added to the one that already arrived from the same tensor's other
+ *           consumer (2x up-sampling geometry = the gradient of the 2x down-sampling FIR of the residual block's skip branch,
+ *           networks.py:343; the other summand is conv0's data gradient).  act / scale / bias / sums unused.
  * act: 1 linear or 3 lrelu (bias_act.py:23-33 indices).  scale / bias may be NULL (1 / 0).  Supported for the
- * lane-exchange kernel's FIR geometries only (modes 1, 3: up=down=1, pad0 1; mode 2: up=down=1, pad0 2; 4x4 filter,
+ * lane-exchange kernel's FIR geometries only (modes 1, 3: up=down=1, pad0 1; mode 2: up=down=1, pad0 2; mode 4: up=2, pad0 2; 4x4 filter,
  * dense NCHW); anything else returns SGV_ERR_UNSUPPORTED and the caller composes the three ops. */
 typedef struct sgv_fir_epilogue {
     int32_t mode;
     const float* scale; /* [n*c] fp32 or NULL */
     const float* bias;  /* [c] fp32 or NULL */
-    const void* yref;   /* mode 2: [n,c,in_h,in_w]; mode 3: [n,c,out_h,out_w]; dtype/layout of x */
+    const void* yref;   /* mode 2: [n,c,in_h,in_w]; modes 3, 4: [n,c,out_h,out_w]; dtype/layout of x */
     float* sum_g;       /* modes 2, 3: [n*c], zero-initialised by the caller, accumulated with atomics */
     float* sum_gv;      /* mode 2: [n*c], likewise (mode 3: may be NULL) */
     int32_t act;

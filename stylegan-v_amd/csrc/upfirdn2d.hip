@@ -372,6 +372,8 @@ template <typename T, int N> __device__ __forceinline__ void store_vec_plain(T* 
 // EPI = 3: fused backward epilogue  dx = d(bias_act)/dx at yref (OUTPUT-shaped) applied to upfirdn2d(x): the gradient of "activation, then FIR"
 //          (a discriminator conv0 whose output feeds the FIR of the down-sampling conv1) -- FIR-transposed pass and activation gradient in one;
 //          sum_g[n,c] += sum(dx).
+// EPI = 4: y = upfirdn2d(x) + yref (OUTPUT-shaped): a gradient summed into the one that already arrived from the tensor's other consumer
+//          (the residual discriminator block: the skip branch's FIR gradient + conv0's data gradient), in the store of the streaming pass.
 // EPI = 2: fused backward prologue  dx = upfirdn2d(g * scale),  g = d(bias_act)/dx at yref applied to the incoming
 //          gradient (bias_act.cu:60-61,133-142 grad=1 form), evaluated while the rows are loaded; the per-plane sums
 //          sum(g) and sum(g * preactivation) that give the bias and scale gradients are accumulated on the way.
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
         if (plane_ok && p.ep_bias) ep_bi = p.ep_bias[plane % p.chans];
     }
     const T* yrefplane = (EPI == 2) ? (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w
-                       : (EPI == 3) ? (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w : nullptr;
+                       : (EPI == 3 || EPI == 4) ? (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w : nullptr;
     float sum_g = 0.f, sum_gv = 0.f;
     const int own0 = cb * OWN;                               // first owned input column
     const bool own_full = plane_ok && own0 + OWN <= p.in_w;
@@ -635,7 +637,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
                 const int fy0 = UP - 1 - ((R0Y + u * DOWN) % UP);
                 float out[NOUT];
                 float yo[NOUT];
-                if constexpr (EPI == 3) {   // the forward output at this row's positions (same predicates as the stores below)
+                if constexpr (EPI == 3 || EPI == 4) {   // the forward output / the other summand at this row's positions (same predicates as the stores below)
 #pragma unroll
                     for (int v = 0; v < NOUT; v++) yo[v] = 0.f;
                     const T* yr = yrefplane + (size_t)(oyd + u) * p.out_w + ox0;
@@ -659,6 +661,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
                             acc = __builtin_fmaf(win[ry + ky][cx + kx], ff[fy0 + ky * UP][fx0 + kx * UP], acc);
                     out[v] = acc * p.gain;
                     if constexpr (EPI == 1) out[v] = epi_fwd(out[v]);
+                    if constexpr (EPI == 4) out[v] += yo[v];
                     if constexpr (EPI == 3) {
                         float pre;
                         out[v] = epi_grad(out[v], yo[v], pre);
@@ -708,6 +711,7 @@ lanes_fn pick_lanes_kernel(const sgv_upfirdn2d_params* p, int xtra, bool seg, in
     SGV_LANES_EPI(1, 1, 1, 1, 1)   // synthesis-layer epilogue: FIR (2r+1 -> 2r) * dcoefs + bias -> lrelu -> clamp
     SGV_LANES_EPI(1, 1, 2, 2, 2)   // its backward: lrelu'/clamp mask * dcoefs -> FIR (2r -> 2r+1), plane sums
     SGV_LANES_EPI(1, 1, 1, 1, 3)   // backward of "activation, then the FIR in front of a strided convolution": FIR (2r+1 -> 2r), then lrelu'/clamp mask
+    SGV_LANES_EPI(2, 1, 2, 2, 4)   // backward of the 2x down-sampling FIR (= 2x up-sampling) + the gradient from the input's other consumer
 #undef SGV_LANES_EPI
     if (epi != 0) return nullptr;
 #define SGV_LANES(U, D, PX, PY)                                                                     \
@@ -964,18 +968,19 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
     int rc = validate(p, dtype);
     if (rc != SGV_OK) return rc;
     if (!e) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: epilogue is NULL");
-    if (e->mode < 1 || e->mode > 3) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode must be 1 (forward epilogue), 2 (backward prologue) or 3 (backward epilogue)");
-    if (e->act != 1 && e->act != 3) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: only linear (1) and lrelu (3) are fusable");
-    if (e->act == 3 && e->alpha == 0.f) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: lrelu with alpha 0 is not invertible");
+    if (e->mode < 1 || e->mode > 4) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode must be 1 (forward epilogue), 2 (backward prologue), 3 (backward epilogue) or 4 (add)");
+    if (e->mode != 4 && e->act != 1 && e->act != 3) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: only linear (1) and lrelu (3) are fusable");
+    if (e->mode != 4 && e->act == 3 && e->alpha == 0.f) return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: lrelu with alpha 0 is not invertible");
+    if (e->mode == 4 && !e->yref) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode 4 needs yref (the other summand)");
     if (e->mode == 2 && (!e->yref || !e->sum_g || !e->sum_gv)) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode 2 needs yref, sum_g and sum_gv");
     if (e->mode == 3 && (!e->yref || !e->sum_g)) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode 3 needs yref and sum_g");
     hipStream_t stream = (hipStream_t)stream_;
     lanes_plan lplan;
     if (!plan_lanes(p, dtype, &lplan, e))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: geometry/layout not covered by the fused kernel (modes 1, 3: up=down=1 pad 1, mode 2: up=down=1 pad 2, 4x4 filter, dense NCHW)");
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: geometry/layout not covered by the fused kernel (modes 1, 3: up=down=1 pad 1, mode 2: up=down=1 pad 2, mode 4: up=2 pad 2, 4x4 filter, dense NCHW)");
     const double es = (double)sgv_dtype_size(dtype);
     const double nin = (double)p->in_w * p->in_h * p->in_c * p->in_n, nout = (double)p->out_w * p->out_h * p->in_c * p->in_n;
-    const double bytes = (e->mode == 2 ? 2.0 * nin : nin) * es + (e->mode == 3 ? 2.0 * nout : nout) * es;
+    const double bytes = (e->mode == 2 ? 2.0 * nin : nin) * es + (e->mode >= 3 ? 2.0 * nout : nout) * es;
     sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
     hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
     return sgv_check_launch("upfirdn2d_lanes_kernel (fused)");

@@ -55,7 +55,7 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     return op(x, w, stride=stride, padding=padding, groups=groups)
 
 
-def downsampling_conv1x1(x, w, f, down, padding=0, residual=None, flip_filter=False):
+def downsampling_conv1x1(x, w, f, down, padding=0, residual=None, flip_filter=False, prefiltered=False):
     """``conv2d_resample`` for a 1x1 kernel with ``down > 1`` (FIR + decimate, then convolve on the small image: the skip branch of the
     residual discriminator block) with the other branch's result added in the convolution's store where the MFMA GEMM serves the shape;
     the fallback adds out of place (the residual is another layer's activation output, which its backward pass still needs)."""
@@ -64,7 +64,8 @@ def downsampling_conv1x1(x, w, f, down, padding=0, residual=None, flip_filter=Fa
     fw, fh = _get_filter_size(f)
     px0, px1, py0, py1 = _parse_padding(padding)
     pads = [px0 + (fw - down + 1) // 2, px1 + (fw - down) // 2, py0 + (fh - down + 1) // 2, py1 + (fh - down) // 2]
-    x = _ufd.upfirdn2d(x=x, f=f, down=down, padding=pads, flip_filter=flip_filter)
+    if not prefiltered:   # (prefiltered: the caller already ran this FIR + decimate pass, e.g. fused_fir_act.fir_down_with_input_alias)
+        x = _ufd.upfirdn2d(x=x, f=f, down=down, padding=pads, flip_filter=flip_filter)
     if residual is not None and _gemm.enabled and w.dtype == torch.float32 and x.is_cuda and _gemm.is_full_tile_conv1x1(x, out_ch) \
             and residual.dtype == torch.float32 and tuple(residual.shape) == (x.shape[0], out_ch, x.shape[2], x.shape[3]):
         return _gemm.conv1x1(x, w, residual=residual)

@@ -30,10 +30,10 @@ def fir_bias_act_composed(x, f, scale=None, bias=None, padding=1, fir_gain=1, ac
     return _ba.bias_act(y, bias.to(y.dtype) if bias is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)
 
 
-def _ufd_params(x, f, y, pads, flip, gain):
+def _ufd_params(x, f, y, pads, flip, gain, up=1, down=1):
     n, c, h, w = x.shape
     xs, fs, ys = x.stride(), f.stride(), y.stride()
-    return custom_ops.Upfirdn2dParams(x.data_ptr(), f.data_ptr(), y.data_ptr(), 1, 1, 1, 1, pads[0], pads[1], pads[2], pads[3],
+    return custom_ops.Upfirdn2dParams(x.data_ptr(), f.data_ptr(), y.data_ptr(), up, up, down, down, pads[0], pads[1], pads[2], pads[3],
                                       int(bool(flip)), float(gain), w, h, c, n, xs[3], xs[2], xs[1], xs[0], f.shape[1], f.shape[0], fs[1], fs[0],
                                       y.shape[3], y.shape[2], ys[3], ys[2], ys[1], ys[0])
 
@@ -112,3 +112,56 @@ def fir_bias_act(x, f, scale=None, bias=None, padding=1, fir_gain=1, act='lrelu'
         return _FusedFirBiasActFn.apply(x, f, scale, bias, (pads, float(fir_gain), bool(flip_filter), act, alpha_f, gain_f, clamp_f))
     return fir_bias_act_composed(x, f, scale=scale, bias=bias, padding=padding, fir_gain=fir_gain, act=act, alpha=alpha, gain=gain, clamp=clamp,
                                  flip_filter=flip_filter)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# FIR + decimate of a tensor that has a second consumer (the residual discriminator block: the skip branch's `upfirdn2d(x, f, down=2)` next
+# to conv0(x), networks.py:343-344).  The node returns x itself as a second output for that other consumer; the other consumer's gradient
+# then arrives HERE and is added in the store of this node's own gradient pass (a 2x up-sampling FIR: one streaming kernel,
+# sgv_upfirdn2d_fused mode 4) instead of by a separate full-tensor addition.
+
+class _FirDownAliasFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f, cfg):
+        down, pads, flip = cfg
+        y = _ufd.upfirdn2d(x, f, down=down, padding=list(pads), flip_filter=flip)
+        ctx.set_materialize_grads(False)
+        ctx.cfg = cfg
+        ctx.in_shape = tuple(x.shape)
+        ctx.save_for_backward(f)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g_y, g_alias=None):
+        (f,) = ctx.saved_tensors
+        down, pads, flip = ctx.cfg
+        if g_y is None:
+            return g_alias, None, None
+        n, c, ih, iw = ctx.in_shape
+        oh, ow = g_y.shape[2], g_y.shape[3]
+        fh, fw = f.shape
+        # the gradient of upfirdn2d: up / down swapped, the padding of upfirdn2d.py:251-261, the filter flip inverted
+        bpads = (fw - pads[0] - 1, iw - ow * down + pads[0], fh - pads[2] - 1, ih - oh * down + pads[2])
+        fusable = (not torch.is_grad_enabled() and g_alias is not None and enabled and g_y.is_cuda and g_y.dtype == torch.float32 and g_alias.dtype == torch.float32
+                   and g_alias.is_contiguous() and tuple(g_alias.shape) == ctx.in_shape and tuple(f.shape) == (4, 4) and f.dtype == torch.float32)
+        if fusable:
+            lib = custom_ops.get_native()
+            g_y = g_y.contiguous()
+            gx = torch.empty(ctx.in_shape, dtype=torch.float32, device=g_y.device)
+            e = custom_ops.FirEpilogue(4, None, None, g_alias.data_ptr(), None, None, 1, 0.0, 1.0, -1.0)
+            with custom_ops.device_guard(g_y):
+                rc = lib.sgv_upfirdn2d_fused(_ufd_params(g_y, f, gx, bpads, not flip, 1.0, up=down, down=1), e, 0, custom_ops.raw_stream(g_y))
+            if rc == 0:
+                return gx, None, None
+            if rc != -3:   # anything but SGV_ERR_UNSUPPORTED (a geometry / width the lane-exchange kernel does not serve) is an error
+                custom_ops.check(rc, lib)
+        gx = _ufd.upfirdn2d(g_y, f, up=down, padding=list(bpads), flip_filter=not flip)
+        return (gx + g_alias if g_alias is not None else gx), None, None
+
+
+def fir_down_with_input_alias(x, f, down, pads, flip_filter=False):
+    """(upfirdn2d(x, f, down=down, padding=pads), x) -- hand the second result to x's other consumer (see _FirDownAliasFn)."""
+    pads = tuple(int(v) for v in pads)
+    if enabled and x.is_cuda and x.ndim == 4 and f is not None and f.ndim == 2 and f.is_cuda:
+        return _FirDownAliasFn.apply(x, f, (int(down), pads, bool(flip_filter)))
+    return _ufd.upfirdn2d(x, f, down=down, padding=list(pads), flip_filter=flip_filter), x

@@ -158,7 +158,8 @@ class Conv2dLayer(torch.nn.Module):
     def forward(self, x, gain=1, residual=None, prefiltered=False):
         """``residual`` (optional, same shape as the result): added to the layer's output -- the `y.add_(x)` of the residual discriminator block
         (networks.py:343-345) folded into the layer so that the down-sampling convolution can do it in its epilogue.
-        ``prefiltered``: x already went through this (down-sampling 3x3) layer's FIR pass (``forward_then_fir`` of the previous layer)."""
+        ``prefiltered``: x already went through this down-sampling layer's FIR pass (3x3: ``forward_then_fir`` of the previous layer; the 1x1 skip
+        branch with a residual: ``fused_fir_act.fir_down_with_input_alias``)."""
         w, b, act_gain, clamp = self._scaled_parameters(x, gain)
         if self.up == 1 and self.down == 1 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu'):
@@ -172,7 +173,7 @@ class Conv2dLayer(torch.nn.Module):
                 and act_gain == 1 and clamp is None and x.is_cuda and x.dtype == torch.float32:
             # skip branch of the residual block (gain already on the weights): FIR + decimate, then the 1x1 convolution whose store adds the
             # other branch's result
-            x = conv2d_resample.downsampling_conv1x1(x, w, self.resample_filter, down=self.down, padding=self.padding, residual=residual)
+            x = conv2d_resample.downsampling_conv1x1(x, w, self.resample_filter, down=self.down, padding=self.padding, residual=residual, prefiltered=prefiltered)
             residual = None
         elif self.up == 1 and self.down == 2 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
                 and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm:
@@ -181,7 +182,7 @@ class Conv2dLayer(torch.nn.Module):
             x = fused_down_act.strided_conv3x3_bias_act(xb, w, bias=b, act=self.activation, gain=act_gain, clamp=clamp, residual=residual)
             residual = None
         else:
-            assert not prefiltered, 'prefiltered input is only understood by the fused down-sampling 3x3 path'
+            assert not prefiltered, 'prefiltered input is only understood by the fused down-sampling paths'
             x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
                                                 padding=self.padding, flip_weight=(self.up == 1))
             if b is not None or self.activation != 'linear' or act_gain != 1 or clamp is not None:   # (a no-op bias_act hands its input back as-is)

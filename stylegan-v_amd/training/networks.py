@@ -35,6 +35,7 @@ from .motion import MotionMappingNetwork
 
 
 prefer_native_inference = True   # GPU eval-mode synthesis: scale-conv-scale through the native kernels instead of the grouped convolution
+alias_in_fir = os.environ.get('SGV_ALIAS_IN_FIR', '0') != '0'       # which of the block input's two consumers receives the other's gradient (see DiscriminatorBlock.forward)
 residual_in_skip = os.environ.get('SGV_RES_IN_SKIP', '1') != '0'   # where the residual discriminator block forms its sum (see DiscriminatorBlock.forward)
 
 
@@ -345,15 +346,26 @@ class DiscriminatorBlock(torch.nn.Module):
             # `y = skip(x); x = conv1(conv0(x)); x = y.add_(x)` of the reference, evaluated in the other order so that the sum is formed in the
             # store of the skip branch's 1x1 convolution (its GEMM has the spare load slots; the 3x3 kernel's MFMA waves do not)
             if residual_in_skip:
-                if self.conv0.fusable_with_following_fir(x) and self.conv1.accepts_prefiltered(x):
-                    # conv0 and the FIR pass in front of conv1's strided convolution as one autograd node (one-kernel FIR + activation gradient)
+                sk = self.skip
+                if (self.conv0.fusable_with_following_fir(x) and self.conv1.accepts_prefiltered(x) and tuple(sk.weight.shape[2:]) == (1, 1) and sk.down == 2
+                        and sk.up == 1 and sk.bias is None and sk.activation == 'linear' and sk.conv_clamp is None):
+                    # x has two consumers.  The skip branch's FIR + decimate node hands x on to conv0 as its second output, so conv0's data
+                    # gradient comes back to that node and is added in the store of its own gradient pass (a streaming 2x up-sampling FIR);
+                    # conv0 and the FIR pass in front of conv1's strided convolution are one node (one-kernel FIR + activation gradient).
                     f1 = self.conv1.resample_filter
-                    # (x comes back as the node's second output for the skip branch: its gradient is then summed inside the data-gradient kernel)
-                    xb, x = self.conv0.forward_then_fir(x, f1, conv2d_resample.downsampling_pads(f1, self.conv1.down, self.conv1.padding), with_input_alias=True)
-                    y = self.conv1(xb, gain=math.sqrt(0.5), prefiltered=True)
+                    pads1 = conv2d_resample.downsampling_pads(f1, self.conv1.down, self.conv1.padding)
+                    if alias_in_fir:
+                        xd, xc = fused_fir_act.fir_down_with_input_alias(x, sk.resample_filter, sk.down, conv2d_resample.downsampling_pads(sk.resample_filter, sk.down, sk.padding))
+                        xb = self.conv0.forward_then_fir(xc, f1, pads1)
+                        y = self.conv1(xb, gain=math.sqrt(0.5), prefiltered=True)
+                        x = sk(xd, gain=math.sqrt(0.5), residual=y, prefiltered=True)
+                    else:   # the other way round: conv0's node hands x to the skip branch and adds into its gradient with atomics in the data-gradient kernel
+                        xb, xs_ = self.conv0.forward_then_fir(x, f1, pads1, with_input_alias=True)
+                        y = self.conv1(xb, gain=math.sqrt(0.5), prefiltered=True)
+                        x = sk(xs_, gain=math.sqrt(0.5), residual=y)
                 else:
                     y = self.conv1(self.conv0(x), gain=math.sqrt(0.5))
-                x = self.skip(x, gain=math.sqrt(0.5), residual=y)
+                    x = sk(x, gain=math.sqrt(0.5), residual=y)
             else:   # the sum in the strided 3x3 kernel's store instead (one atomic add per element into the skip branch's result)
                 y = self.skip(x, gain=math.sqrt(0.5))
                 x = self.conv1(self.conv0(x), gain=math.sqrt(0.5), residual=y)

@@ -434,3 +434,36 @@ def test_gemm_conv1x1_adds_a_residual_in_its_store():
     assert_close(gx, rx, atol=1e-3, rtol=1e-4, what='dx')
     assert_close(gw, rw, atol=1e-3, rtol=1e-4, what='dw')
     assert torch.equal(gr, dy)
+
+
+@pytest.mark.parametrize('shape', [(2, 8, 64, 64), (3, 4, 256, 256), (2, 6, 32, 32), (1, 3, 16, 16)])
+def test_fir_down_with_input_alias_sums_the_gradients_in_its_own_pass(shape):
+    """fused_fir_act.fir_down_with_input_alias: the FIR + decimate node hands x to a second consumer; that consumer's gradient is added in the
+    store of the node's gradient pass (sgv_upfirdn2d_fused mode 4) -- same values as autograd's separate addition, first and second order."""
+    from stylegan_v_amd.torch_utils.ops import fused_fir_act, upfirdn2d
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(DEV).requires_grad_(True)
+    f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
+    gd = torch.randn([shape[0], shape[1], shape[2] // 2, shape[3] // 2], generator=g).to(DEV)
+    ga = torch.randn(shape, generator=g).to(DEV)
+
+    def loss(alias):
+        if alias:
+            xd, xa = fused_fir_act.fir_down_with_input_alias(x, f, 2, (1, 1, 1, 1))
+        else:
+            xd, xa = upfirdn2d.upfirdn2d(x, f, down=2, padding=1), x
+        return (xd * gd).sum() + (xa.square() * ga).sum()
+    xd, xa = fused_fir_act.fir_down_with_input_alias(x, f, 2, (1, 1, 1, 1))
+    assert torch.equal(xd, upfirdn2d.upfirdn2d(x, f, down=2, padding=1)) and torch.equal(xa, x)
+    before = custom_ops.launch_count()
+    (got,) = torch.autograd.grad(loss(True), [x])
+    n_alias = custom_ops.launch_count() - before
+    (want,) = torch.autograd.grad(loss(False), [x])
+    assert_close(got, want, atol=1e-5 * want.abs().max().item(), rtol=1e-5, what='dx')
+    assert n_alias == 2          # one FIR pass forward, one backward (with the addition inside)
+    # second order through the node
+    (g1,) = torch.autograd.grad(loss(True), [x], create_graph=True)
+    (g2,) = torch.autograd.grad(g1.square().sum(), [x])
+    (h1,) = torch.autograd.grad(loss(False), [x], create_graph=True)
+    (h2,) = torch.autograd.grad(h1.square().sum(), [x])
+    assert_close(g2, h2, atol=1e-4 * h2.abs().max().item(), rtol=1e-4, what='d2x')
