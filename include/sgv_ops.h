@@ -229,6 +229,9 @@ typedef struct sgv_conv_wrw_params {
 
 int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* stream);
 int sgv_conv3x3_wrw_supported(int32_t n, int32_t c_out, int32_t c_in, int32_t h, int32_t w, int dtype);
+/* the same with x[n,i,:,:] * x_scale[n,i] as the input operand (x_scale fp32 [n, c_in]): the weight gradient of a modulated layer
+ * (networks.py:66 `x * styles`) without materialising the scaled input again in the backward pass */
+int sgv_conv3x3_wrw_scaled(const sgv_conv_wrw_params* p, const float* x_scale, int dtype, void* stream);
 /* Stride-2 member (weight gradient of sgv_conv3x3_s2, either mode): dy = the SMALL tensor [n, c_out, h, w], x = the BIG one
  * [n, c_in, 2h+1, 2w+1];  dw[s,b,ky,kx] = sum_{n,Y,X} small[n,s,Y,X] * big[n,b,2Y+ky,2X+kx]  as [c_out, c_in, 3, 3]. */
 int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void* stream);

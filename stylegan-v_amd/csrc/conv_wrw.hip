@@ -35,7 +35,7 @@ extern "C" int sgv_conv3x3_wrw_supported(int32_t n, int32_t c_out, int32_t c_in,
     return supported(n, c_out, c_in, h, w, dtype) ? 1 : 0;
 }
 
-extern "C" int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* stream_) {
+static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, int dtype, void* stream_) {
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: params is NULL");
     if (!p->dy || !p->x || !p->dw) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: NULL pointer");
     if (!supported(p->n, p->c_out, p->c_in, p->h, p->w, dtype))
@@ -47,6 +47,7 @@ extern "C" int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* st
     wrw_params kp{};
     kp.dy = (const float*)p->dy; kp.x = (const float*)p->x; kp.dw = p->dw;
     kp.n = p->n; kp.o = p->c_out; kp.i = p->c_in; kp.h = p->h; kp.w = p->w;
+    kp.xscale = x_scale;
     kp.tiles_i = p->c_in / TI;
     const int tiles = (p->c_out / TO) * kp.tiles_i;
     // One workgroup per CU (profiles/r01_wrw_lab_v1.log: 256 persistent workgroups beat 512), spread over the output tiles.
@@ -80,9 +81,17 @@ extern "C" int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* st
         else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
         return sgv_check_launch("wrw3x3_ws_kernel");
     }
+    if (x_scale) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_scaled: the 4-wave kernel (SGV_WRW_WS=0) has no input scale");
     if (p->terms == 1) hipLaunchKernelGGL(wrw3x3_kernel<1>, grid, dim3(256), 0, stream, kp);
     else hipLaunchKernelGGL(wrw3x3_kernel<3>, grid, dim3(256), 0, stream, kp);
     return sgv_check_launch("wrw3x3_kernel");
+}
+
+extern "C" int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* stream_) { return conv3x3_wrw_impl(p, nullptr, dtype, stream_); }
+
+extern "C" int sgv_conv3x3_wrw_scaled(const sgv_conv_wrw_params* p, const float* x_scale, int dtype, void* stream_) {
+    if (!x_scale) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_scaled: x_scale is NULL");
+    return conv3x3_wrw_impl(p, x_scale, dtype, stream_);
 }
 
 extern "C" int sgv_conv3x3_wrw_s2_supported(int32_t n, int32_t c_small, int32_t c_big, int32_t h, int32_t w, int dtype) {

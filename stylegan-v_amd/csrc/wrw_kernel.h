@@ -52,6 +52,7 @@ struct wrw_params {
     int tiles_i;       // i / 64
     int splits;        // workgroups per output tile
     int units;         // n * (w / 32) * (h / rows)
+    const float* xscale;   // [n, i] or NULL: x[n,i,:,:] is multiplied by it on its way into LDS (the styles of a modulated layer, networks.py:66; producer / consumer kernel only)
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {

@@ -66,9 +66,11 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
 
         const float *xb = nullptr, *dyb = nullptr;
         int x0 = 0;
+        float xsc = 1.f;      // this thread's channel of p.xscale for the current unit's sample
         auto set_unit = [&](int u) {
             const int rb = u % rblocks, sg = (u / rblocks) % segs, n = u / (rblocks * segs);
             x0 = sg * SEG;
+            if (p.xscale) xsc = p.xscale[(size_t)n * p.i + i0 + lr];
             xb = p.x + ((size_t)n * p.i + i0 + lr) * plane + x0 + lq;
             dyb = p.dy + ((size_t)n * p.o + o0 + lr) * plane + x0 + lq;
             return rb * R;
@@ -101,10 +103,10 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         auto store_x = [&](int row, const xrow& r) {
             if (ABL == 7) return;
             float v[10];
-            v[0] = r.okl ? r.l : 0.f;
-            v[9] = r.okr ? r.r : 0.f;
+            v[0] = r.okl ? r.l * xsc : 0.f;
+            v[9] = r.okr ? r.r * xsc : 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { v[1 + k] = r.ok ? r.a[k] : 0.f; v[5 + k] = r.ok ? r.b[k] : 0.f; }
+            for (int k = 0; k < 4; k++) { v[1 + k] = r.ok ? r.a[k] * xsc : 0.f; v[5 + k] = r.ok ? r.b[k] * xsc : 0.f; }
             // even-start pairs (v1v2, v3v4, v5v6, v7v8) = view 1; odd-start pairs (v0v1, ..., v8v9): view 0 = first four, view 2 = last four
             unsigned eh[4], el[4], oh[5], ol[5];
 #pragma unroll

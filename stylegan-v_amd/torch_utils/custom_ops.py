@@ -272,6 +272,7 @@ ABI_SYMBOLS = {
     'sgv_conv3x3_workspace_bytes': (c_int64, [c_int32, c_int32]),
     'sgv_conv3x3_wrw': (c_int, [ctypes.POINTER(ConvWrwParams), c_int, c_void_p]),
     'sgv_conv3x3_wrw_s2': (c_int, [ctypes.POINTER(ConvWrwParams), c_int, c_void_p]),
+    'sgv_conv3x3_wrw_scaled': (c_int, [ctypes.POINTER(ConvWrwParams), c_void_p, c_int, c_void_p]),
     'sgv_conv3x3_wrw_s2_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_conv3x3_wrw_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_time_encode': (c_int, [ctypes.POINTER(TimeEncodeParams), c_void_p]),

@@ -210,10 +210,24 @@ def _native_wrw_ok(dy, x, cfg, w_shape):
     return _native_wrw_kind(dy, x, cfg, w_shape) is not None
 
 
-def _native_wrw(dy, x, cfg, w_shape):
+wrw_input_scale = os.environ.get('SGV_WRW_WS', '1') != '0' and os.environ.get('SGV_WRW_SCALE', '1') != '0'   # the stride-1 producer / consumer kernel can scale its input operand per (sample, channel)
+
+
+def _native_wrw(dy, x, cfg, w_shape, x_scale=None):
+    """``x_scale`` ([N, Cin] fp32; stride-1 forward layers only, see ``wrw_input_scale``): the gradient is taken with x * x_scale[:, :, None, None]."""
     lib = custom_ops.get_native()
     kind = _native_wrw_kind(dy, x, cfg, w_shape)
     dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    if kind == 's1' and x_scale is not None:
+        assert not cfg[0] and wrw_input_scale
+        dyc, xc, sc = dy.contiguous(), x.contiguous(), x_scale.contiguous()
+        n, ci, h, w = xc.shape
+        assert tuple(w_shape[:2]) == (dyc.shape[1], ci) and tuple(sc.shape) == (n, ci) and sc.dtype == torch.float32
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, native_wrw_terms)
+        with custom_ops.device_guard(xc):
+            custom_ops.check(lib.sgv_conv3x3_wrw_scaled(p, sc.data_ptr(), 0, custom_ops.raw_stream(xc)), lib)
+        return dw
+    assert x_scale is None
     if kind == 's1':
         dyc, xc = (x.contiguous(), dy.contiguous()) if cfg[0] else (dy.contiguous(), x.contiguous())   # weight is [dyc channels, xc channels, 3, 3]
         n, ci, h, w = xc.shape

@@ -133,11 +133,14 @@ class _FusedConvBiasActFn(torch.autograd.Function):
             else:
                 d_x = dxs
         if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
-            xs = _mod.scale_channels(x, s) if s is not None else x
-            if _cg._native_wrw_ok(dzd, xs, cfg, tuple(weight.shape)):
-                d_w = _cg._native_wrw(dzd, xs, cfg, tuple(weight.shape))
+            if s is not None and _cg.wrw_input_scale and _cg._native_wrw_kind(dzd, x, cfg, tuple(weight.shape)) == 's1':
+                d_w = _cg._native_wrw(dzd, x, cfg, tuple(weight.shape), x_scale=s)   # x * styles is formed on the operand's way into LDS
             else:
-                _, d_w, _ = torch.ops.aten.convolution_backward(dzd, xs, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
+                xs = _mod.scale_channels(x, s) if s is not None else x
+                if _cg._native_wrw_ok(dzd, xs, cfg, tuple(weight.shape)):
+                    d_w = _cg._native_wrw(dzd, xs, cfg, tuple(weight.shape))
+                else:
+                    _, d_w, _ = torch.ops.aten.convolution_backward(dzd, xs, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
         return d_x, d_w, d_s, d_d, d_b, None
 
 

@@ -124,3 +124,18 @@ def test_wrw_stride2_family(n, cs, cb, h, w, transposed):
     xi, dyi = (si, bi) if transposed else (bi, si)
     yi = F.conv_transpose2d(xi.double().cpu(), wz, stride=2) if transposed else F.conv2d(xi.double().cpu(), wz, stride=2)
     assert torch.equal(conv2d_gradfix._native_wrw(dyi, xi, cfg, (cs, cb, 3, 3)).cpu().double(), torch.autograd.grad(yi, wz, dyi.double().cpu())[0])
+
+
+def test_weight_gradient_with_input_scale_equals_scaling_first():
+    """sgv_conv3x3_wrw_scaled: x * x_scale[n, i] formed on the operand's way into LDS == scaling x first (the same fp32 products enter the split)."""
+    import torch
+    from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
+    g = torch.Generator().manual_seed(3)
+    n, co, ci, h, w = 3, 64, 128, 32, 64
+    dy = torch.randn([n, co, h, w], generator=g).cuda()
+    x = torch.randn([n, ci, h, w], generator=g).cuda()
+    s = (torch.randn([n, ci], generator=g) * 0.5 + 1).cuda()
+    cfg = (False, (1, 1), (1, 1), (0, 0), (1, 1), 1)
+    a = conv2d_gradfix._native_wrw(dy, x, cfg, (co, ci, 3, 3), x_scale=s)
+    b = conv2d_gradfix._native_wrw(dy, x * s[:, :, None, None], cfg, (co, ci, 3, 3))
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()     # atomics: the accumulation order over workgroups differs run to run
