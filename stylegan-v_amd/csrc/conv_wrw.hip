@@ -15,9 +15,12 @@ using namespace sgv_wrw;
 
 namespace {
 
+// images 16 / 8 pixels wide: 2 / 4 samples per 32-pixel row step (producer / consumer kernel, PACK form)
+bool packed_width(int h, int w) { return (w == 16 || w == 8) && h >= 1 && h <= 32; }
+
 bool supported(int n, int o, int i, int h, int w, int dtype) {
-    return dtype == SGV_F32 && n >= 1 && o >= TO && i >= TI && o % TO == 0 && i % TI == 0 && w >= SEG && w % SEG == 0 && h >= 1 &&
-           (h <= 32 || h % 32 == 0) && (int64_t)n * std::max(o, i) * h * w <= INT32_MAX;
+    return dtype == SGV_F32 && n >= 1 && o >= TO && i >= TI && o % TO == 0 && i % TI == 0 && h >= 1 &&
+           ((w >= SEG && w % SEG == 0 && (h <= 32 || h % 32 == 0)) || packed_width(h, w)) && (int64_t)n * std::max(o, i) * h * w <= INT32_MAX;
 }
 
 bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {
@@ -28,6 +31,10 @@ bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {
 std::once_flag g_once, g_ws_once;
 hipError_t g_attr_err = hipSuccess, g_ws_attr_err = hipSuccess;
 bool g_use_ws = true;   // SGV_WRW_WS=0: the 4-wave kernel of wrw_kernel.h instead of the producer / consumer form (wrw_ws_kernel.h)
+int scatter_flush() {   // SGV_WRW_FLUSH=scatter: the element-per-lane atomics instead of the LDS-staged contiguous ones (wrw_kernel.h flush_tile)
+    static const int v = [] { const char* e = getenv("SGV_WRW_FLUSH"); return (e && e[0] == 's') ? 1 : 0; }();
+    return v;
+}
 
 }  // namespace
 
@@ -39,7 +46,7 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: params is NULL");
     if (!p->dy || !p->x || !p->dw) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: NULL pointer");
     if (!supported(p->n, p->c_out, p->c_in, p->h, p->w, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw: needs fp32, channels %% 64 == 0, W %% 32 == 0, H <= 32 or H %% 32 == 0 (got n=%d o=%d i=%d h=%d w=%d dtype=%d)",
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw: needs fp32, channels %% 64 == 0, W %% 32 == 0 with H <= 32 or H %% 32 == 0, or W in {16, 8} with H <= 32 (got n=%d o=%d i=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_out, p->c_in, p->h, p->w, dtype);
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms must be 1 (bf16 products) or 3 (bf16x3 fp32 emulation)");
     if ((((uintptr_t)p->dy) | ((uintptr_t)p->x)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: dy and x must be 16-byte aligned");
@@ -48,19 +55,22 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
     kp.dy = (const float*)p->dy; kp.x = (const float*)p->x; kp.dw = p->dw;
     kp.n = p->n; kp.o = p->c_out; kp.i = p->c_in; kp.h = p->h; kp.w = p->w;
     kp.xscale = x_scale;
+    kp.scatter_flush = scatter_flush();
     kp.tiles_i = p->c_in / TI;
     const int tiles = (p->c_out / TO) * kp.tiles_i;
     // One workgroup per CU (profiles/r01_wrw_lab_v1.log: 256 persistent workgroups beat 512), spread over the output tiles.
     const int max_splits = std::max(1, 256 / std::max(1, std::min(tiles, 256)));
     // Rows per unit: every unit pays a two-barrier prologue with exposed load latency, so take the tallest row block that still spreads evenly
     // over the workgroups (whole column segments where the batch allows it).
+    const bool pack = p->w < SEG;
+    const int columns = pack ? (p->n + SEG / p->w - 1) / (SEG / p->w) : p->n * (p->w / SEG);   // 32-pixel column segments of the batch (packed: sample groups)
     kp.rows = std::min(p->h, 32);
     for (int rows : {p->h, 64}) {
         if (rows > p->h || p->h % rows) continue;
-        const int units = p->n * (p->w / SEG) * (p->h / rows), splits = std::min(units, max_splits);
+        const int units = columns * (p->h / rows), splits = std::min(units, max_splits);
         if (units % splits == 0 || units >= 8 * splits) { kp.rows = rows; break; }
     }
-    kp.units = p->n * (p->w / SEG) * (p->h / kp.rows);
+    kp.units = columns * (p->h / kp.rows);
     kp.splits = std::max(1, std::min(kp.units, max_splits));
     const size_t dw_bytes = (size_t)p->c_out * p->c_in * 9 * sizeof(float);
     hipError_t e = hipMemsetAsync(p->dw, 0, dw_bytes, stream);
@@ -71,11 +81,18 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
     std::call_once(g_ws_once, [] {
         hipError_t e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<3, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         g_ws_attr_err = e2;
         const char* env = getenv("SGV_WRW_WS");
         g_use_ws = !(env && env[0] == '0');
     });
     if (g_ws_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw: hipFuncSetAttribute failed: %s", hipGetErrorString(g_ws_attr_err));
+    if (pack) {   // the packed form exists in the producer / consumer kernel only
+        if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        return sgv_check_launch("wrw3x3_ws_kernel (packed)");
+    }
     if (g_use_ws) {
         if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
         else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
@@ -118,6 +135,7 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     kp.small = (const float*)p->dy; kp.big = (const float*)p->x; kp.dw = p->dw;
     kp.n = p->n; kp.cs = p->c_out; kp.cb = p->c_in; kp.h = p->h; kp.w = p->w;
     kp.rows = std::min(p->h, 32);
+    kp.scatter_flush = scatter_flush();
     kp.tiles_b = p->c_in / TI;
     kp.units = p->n * (p->w / SEG) * (p->h / kp.rows);
     const int tiles = (p->c_out / TO) * kp.tiles_b;

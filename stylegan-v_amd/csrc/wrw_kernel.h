@@ -53,11 +53,38 @@ struct wrw_params {
     int splits;        // workgroups per output tile
     int units;         // n * (w / 32) * (h / rows)
     const float* xscale;   // [n, i] or NULL: x[n,i,:,:] is multiplied by it on its way into LDS (the styles of a modulated layer, networks.py:66; producer / consumer kernel only)
+    int scatter_flush;     // 1: the element-per-lane flush (every lane of an atomic instruction in a different cache line) instead of flush_tile
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     f32x2 f = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
+}
+
+// End-of-kernel flush of one wave's nine 32 x 32 accumulators (row = first weight index, column = second) into dw[rows][ld][9] with atomics.
+// The MFMA layout puts the 64 lanes of an accumulator register into 64 different cache lines of dw (lane -> column: 36 B apart, lane half -> row);
+// 256 workgroups x 36,864 such atomics at the same moment cost 0.15-0.18 ms per launch (tools/wrw_lab.hip, WRW_ABL=8: 12 % of the kernel).  So the tile
+// goes through LDS, eight weight rows (8 x 32 columns x 9 taps = 2,304 consecutive-per-row floats) at a time, and every atomic instruction adds 64
+// CONSECUTIVE floats.  `stage` = 2,304 floats of LDS private to this wave: the only ordering needed is the wave's own (LDS operations of a wave are in order).
+constexpr int FLUSH_STAGE_FLOATS = 8 * 32 * 9;
+__device__ __forceinline__ void flush_tile(const f32x16 (&acc)[9], float* stage, float* dw, int ld, int row0, int col0) {
+    const int lane = threadIdx.x & 63, r32 = lane & 31, g = lane >> 5;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {     // C layout of the 32x32 MFMA: row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5): registers 4q .. 4q+3 hold rows 8q .. 8q+7
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the reads of the previous eight rows have their data
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) stage[(e + 4 * g) * 288 + r32 * 9 + k] = acc[k][4 * q + e];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 6
+        for (int t = 0; t < 36; t++) {
+            const int f = t * 64 + lane, r = f / 288, c = f - r * 288;
+            atomicAdd(dw + ((size_t)(row0 + 8 * q + r) * ld + col0) * 9 + c, stage[f]);
+        }
+    }
 }
 
 // 8 fp32 -> 8 bf16 hi (4 dwords) + 8 bf16 lo.
@@ -229,7 +256,9 @@ __global__ __launch_bounds__(256, 2) void wrw3x3_kernel(wrw_params p) {
         }
     }
 
-    // Flush.  C layout of the 32x32 MFMA: col (i) = lane & 31, row (o) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Flush (every wave is behind the loop's last barrier: the LDS tiles are free).
+    if (!p.scatter_flush) { flush_tile(acc, (float*)&xs[0][0][0] + (threadIdx.x >> 6) * FLUSH_STAGE_FLOATS, p.dw, p.i, o0 + wo, i0 + wi); return; }
+    // C layout of the 32x32 MFMA: col (i) = lane & 31, row (o) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 #pragma unroll
     for (int k = 0; k < 9; k++)
 #pragma unroll
@@ -262,6 +291,7 @@ struct wrw_s2_params {
     float* dw;            // [cs, cb, 3, 3]
     int n, cs, cb, h, w;
     int rows, tiles_b, splits, units;
+    int scatter_flush;    // as in wrw_params
 };
 
 template <int TERMS>
@@ -410,6 +440,7 @@ __global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
         }
     }
 
+    if (!p.scatter_flush) { flush_tile(acc, (float*)lds_s2 + (threadIdx.x >> 6) * FLUSH_STAGE_FLOATS, p.dw, p.cb, s0 + wo, b0 + wi); return; }
 #pragma unroll
     for (int k = 0; k < 9; k++)
 #pragma unroll

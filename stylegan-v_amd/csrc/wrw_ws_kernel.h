@@ -35,9 +35,14 @@ constexpr int WS_DS = 2 * 3 * WS_DBUF;           // [hl][3 buffers][64][RS]
 constexpr int wrw_ws_lds_bytes(int views) { return (2 * 4 * views * WS_VIEW + WS_DS) * 2; }
 constexpr int WRW_WS_LDS_BYTES = wrw_ws_lds_bytes(3);
 
-// ABL (tools/wrw_lab.hip only; wrong results by construction): 6 consumers only keep the barrier protocol, 7 producers only keep it.
-template <int TERMS, int VIEWS = 1, int ABL = 0>
+// ABL (tools/wrw_lab.hip only; wrong results by construction): 6 consumers only keep the barrier protocol, 7 producers only keep it, 8 no final flush.
+//
+// PACK: images 16 or 8 pixels wide (the < 32^2 layers): 2 or 4 samples sit side by side in the 32-pixel row step, a unit is (group of 32 / W
+// samples, row block).  The producers take every 8-pixel group from its own sample (left / right neighbours outside the sample's row are zero),
+// the consumers clear the one pixel that the kx = 0 / 2 shifts would otherwise pull across a sample boundary (VIEWS = 1 only).
+template <int TERMS, int VIEWS = 1, int ABL = 0, bool PACK = false>
 __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
+    static_assert(!PACK || VIEWS == 1, "packed samples: single-view form only");
     constexpr int WS_XSLOT = VIEWS * WS_VIEW;        // bf16 per (slot, hl)
     constexpr int WS_XS = 2 * 4 * WS_XSLOT;          // [hl][4 slots][views][64][RS]
     constexpr int XO = VIEWS == 1 ? XROW0 : 0;       // position of the segment's first pixel inside a row
@@ -53,7 +58,8 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
     const int vid = (nwg & 7) == 0 ? (lin & 7) * (nwg >> 3) + (lin >> 3) : lin;
     const int tile = vid % (int)gridDim.x, split = vid / (int)gridDim.x;
     const int o0 = (tile / p.tiles_i) * TO, i0 = (tile % p.tiles_i) * TI;
-    const int segs = p.w / SEG, rblocks = p.h / p.rows;
+    const int segs = PACK ? 1 : p.w / SEG, rblocks = p.h / p.rows;
+    const int spr = PACK ? SEG / p.w : 1;     // samples per row step
     const size_t plane = (size_t)p.h * p.w;
     const int R = p.rows;
 
@@ -67,20 +73,24 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         const float *xb = nullptr, *dyb = nullptr;
         int x0 = 0;
         float xsc = 1.f;      // this thread's channel of p.xscale for the current unit's sample
+        const int pxs = PACK ? (lq & (p.w - 1)) : lq;        // first pixel of the group inside its image row (minus x0)
+        bool smp_ok = true;                                   // PACK: this group's sample exists (the last group of a batch may be short)
         auto set_unit = [&](int u) {
-            const int rb = u % rblocks, sg = (u / rblocks) % segs, n = u / (rblocks * segs);
+            const int rb = u % rblocks, sg = (u / rblocks) % segs;
+            int n = u / (rblocks * segs);
             x0 = sg * SEG;
+            if (PACK) { n = n * spr + lq / p.w; smp_ok = n < p.n; n = min(n, p.n - 1); }
             if (p.xscale) xsc = p.xscale[(size_t)n * p.i + i0 + lr];
-            xb = p.x + ((size_t)n * p.i + i0 + lr) * plane + x0 + lq;
-            dyb = p.dy + ((size_t)n * p.o + o0 + lr) * plane + x0 + lq;
+            xb = p.x + ((size_t)n * p.i + i0 + lr) * plane + x0 + pxs;
+            dyb = p.dy + ((size_t)n * p.o + o0 + lr) * plane + x0 + pxs;
             return rb * R;
         };
         // branch-free: out-of-image rows / columns load from a clamped address and are zeroed when they are written to LDS
         auto load_x = [&](int row, xrow& r) {
             if (ABL == 7) return;
             r.ok = row >= 0 && row < p.h;
-            r.okl = r.ok && x0 + lq - 1 >= 0;
-            r.okr = r.ok && x0 + lq + 8 < p.w;
+            r.okl = r.ok && x0 + pxs - 1 >= 0;
+            r.okr = r.ok && x0 + pxs + 8 < p.w;
             const float* q = xb + (size_t)min(max(row, 0), p.h - 1) * p.w;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a) : "v"(q) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b) : "v"(q + 4) : "memory");
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             if (ABL == 7) return;
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { v[k] = r.a[k]; v[4 + k] = r.b[k]; }
+            for (int k = 0; k < 4; k++) { v[k] = (!PACK || smp_ok) ? r.a[k] : 0.f; v[4 + k] = (!PACK || smp_ok) ? r.b[k] : 0.f; }
             u32x4 hi, lo;
             split8(v, hi, lo);
             *(u32x4*)(ds + (size_t)buf * WS_DBUF + lr * RS + lq) = hi;
@@ -220,6 +230,15 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         const int a_lane = (wo + (ln & 31)) * RS + 8 * (ln >> 5);     // + 16 * c, bf16 units inside a dy buffer
         const int b_lane = (wi + (ln & 31)) * RS + 8 * (ln >> 5);     // + 16 * c, inside a view
 
+        unsigned keep_l[2] = {~0u, ~0u}, keep_r[2] = {~0u, ~0u};   // PACK: per k half c, lane group g = 2c + (lane >> 5) covers pixels 8g .. 8g + 7
+        if (PACK) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const int px = 8 * (2 * c + (ln >> 5));
+                keep_l[c] = (px & (p.w - 1)) == 0 ? 0u : ~0u;
+                keep_r[c] = ((px + 8) & (p.w - 1)) == 0 ? 0u : ~0u;
+            }
+        }
         u32x4 a[2][2];       // [buffer][hl]
         u32x4 b[2][2][3];    // [buffer][hl][kx]   (VIEWS = 1: [..][0] is unused, [1] the aligned word, [2].x / [2].y the dwords before / after it)
         auto fetch_a = [&](int buf, int dbuf, int c) {
@@ -241,9 +260,15 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             }
         };
         // operand of tap kx from what fetch_b left in the registers
-        auto view = [&](int buf, int hl, int kx) {
+        auto view = [&](int buf, int hl, int kx, int c) {
             if (VIEWS == 3 || kx == 1) return b[buf][hl][kx];
             const u32x4 d = b[buf][hl][1];
+            if (PACK) {   // pixel 8g - 1 / 8g + 8 of the neighbouring sample: not this sample's neighbour
+                if (kx == 0) return u32x4{__builtin_amdgcn_alignbyte(d[0], b[buf][hl][2][0] & keep_l[c], 2), __builtin_amdgcn_alignbyte(d[1], d[0], 2),
+                                          __builtin_amdgcn_alignbyte(d[2], d[1], 2), __builtin_amdgcn_alignbyte(d[3], d[2], 2)};
+                return u32x4{__builtin_amdgcn_alignbyte(d[1], d[0], 2), __builtin_amdgcn_alignbyte(d[2], d[1], 2), __builtin_amdgcn_alignbyte(d[3], d[2], 2),
+                             __builtin_amdgcn_alignbyte(b[buf][hl][2][1] & keep_r[c], d[3], 2)};
+            }
             const unsigned a01 = __builtin_amdgcn_alignbyte(d[1], d[0], 2), a12 = __builtin_amdgcn_alignbyte(d[2], d[1], 2), a23 = __builtin_amdgcn_alignbyte(d[3], d[2], 2);
             if (kx == 0) return u32x4{__builtin_amdgcn_alignbyte(d[0], b[buf][hl][2][0], 2), a01, a12, a23};
             return u32x4{a01, a12, a23, __builtin_amdgcn_alignbyte(b[buf][hl][2][1], d[3], 2)};
@@ -276,7 +301,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
                 const u32x4 a_hi = a[c][0], a_lo = a[c][1];   // the dy operand of k-half c lives in buffer c
                 u32x4 bh[3], bl[3];
 #pragma unroll
-                for (int kx = 0; kx < 3; kx++) { bh[kx] = view(cur, 0, kx); if (TERMS > 1) bl[kx] = view(cur, 1, kx); }
+                for (int kx = 0; kx < 3; kx++) { bh[kx] = view(cur, 0, kx, c); if (TERMS > 1) bl[kx] = view(cur, 1, kx, c); }
                 if (TERMS > 1) {
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
@@ -306,7 +331,9 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         db = (db + R) % 3;
     }
 
-    // Flush.  C layout of the 32x32 MFMA: col (i) = lane & 31, row (o) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+    // Flush (behind the last row's barrier nobody reads or writes the operand tiles any more).
+    if (ABL != 8 && !p.scatter_flush) { flush_tile(acc, (float*)lds_ws + wave * FLUSH_STAGE_FLOATS, p.dw, p.i, o0 + wo, i0 + wi); return; }
+    // C layout of the 32x32 MFMA: col (i) = lane & 31, row (o) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
     const int r32 = lane & 31, g = lane >> 5;
 #pragma unroll
     for (int k = 0; k < 9; k++)
@@ -314,7 +341,8 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         for (int e = 0; e < 16; e++) {
             const int o = o0 + wo + (e & 3) + 8 * (e >> 2) + 4 * g;
             const int i = i0 + wi + r32;
-            atomicAdd(p.dw + ((size_t)o * p.i + i) * 9 + k, acc[k][e]);
+            if (ABL == 8) { if (acc[k][e] == 12345.678f) atomicAdd(p.dw + ((size_t)o * p.i + i) * 9 + k, acc[k][e]); }   // ablation: (practically) no flush
+            else atomicAdd(p.dw + ((size_t)o * p.i + i) * 9 + k, acc[k][e]);
         }
 }
 

@@ -116,7 +116,7 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     q = custom_ops.ConvWrwParams()
     assert lib.sgv_conv3x3_wrw(q, F32, None) == -1
     q.dy = q.x = q.dw = addr
-    q.n, q.c_out, q.c_in, q.h, q.w, q.terms = 2, 64, 64, 32, 16, 3
+    q.n, q.c_out, q.c_in, q.h, q.w, q.terms = 2, 64, 64, 32, 24, 3
     assert lib.sgv_conv3x3_wrw(q, F32, None) == -3 and b'W % 32' in lib.sgv_last_error()
     assert lib.sgv_conv3x3_wrw_s2(q, F32, None) == -3
     r = custom_ops.PointwiseParams()

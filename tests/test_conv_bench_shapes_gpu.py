@@ -193,7 +193,7 @@ def _check_wrw(c_small, c_big, hs, stride, transposed, seed):
     print(f'[wrw {c_big}->{c_small} {hs} s{stride}{"T" if transposed else ""}] sampled block error {err:.2e}')
 
 
-@pytest.mark.parametrize('c,r', [(64, 256), (128, 128), (256, 64), (512, 32)])
+@pytest.mark.parametrize('c,r', [(64, 256), (128, 128), (256, 64), (512, 32), (512, 16), (512, 8)])
 def test_conv3x3_weight_gradient_at_benchmark_shapes(c, r):
     """Conv2dGradWeight of the stride-1 layers (conv2d_gradfix.py:140-170)."""
     _check_wrw(c, c, r, 1, False, seed=3 * c + r)

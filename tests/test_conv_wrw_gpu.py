@@ -34,7 +34,9 @@ def _rel(a, ref):
     return ((a - ref).norm() / ref.norm()).item(), ((a - ref).abs().max() / ref.abs().max()).item()
 
 
-@pytest.mark.parametrize('n,o,i,h,w', [(2, 64, 64, 32, 32), (1, 64, 128, 64, 64), (2, 128, 64, 64, 96), (3, 64, 64, 8, 32), (1, 192, 64, 96, 32), (2, 64, 64, 1, 32)])
+@pytest.mark.parametrize('n,o,i,h,w', [(2, 64, 64, 32, 32), (1, 64, 128, 64, 64), (2, 128, 64, 64, 96), (3, 64, 64, 8, 32), (1, 192, 64, 96, 32), (2, 64, 64, 1, 32),
+                                       # images 16 / 8 pixels wide: 2 / 4 samples share a 32-pixel row step (incl. batches that leave the last group short)
+                                       (4, 64, 64, 16, 16), (3, 128, 64, 16, 16), (1, 64, 64, 16, 16), (8, 64, 128, 8, 8), (5, 64, 64, 8, 8), (2, 64, 64, 4, 8), (7, 64, 64, 32, 16)])
 def test_wrw_bf16x3_matches_fp64_as_well_as_the_vendor_fp32_kernel(n, o, i, h, w):
     g = torch.Generator().manual_seed(n * 100 + o + i + h)
     dy = torch.randn([n, o, h, w], generator=g).to(DEV)
@@ -87,17 +89,19 @@ def test_conv2d_gradfix_uses_it_and_stays_twice_differentiable():
 
 def test_unsupported_shapes_fall_back_to_the_vendor_library():
     lib = custom_ops.get_native()
-    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 16, 16, 0) == 0    # W < 32
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 16, 16, 0) == 1    # 16 / 8 pixels wide: packed samples
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 4, 4, 0) == 0      # W < 8
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 24, 24, 0) == 0    # W not 8, 16 or a multiple of 32
     assert lib.sgv_conv3x3_wrw_supported(4, 64, 3, 32, 32, 0) == 0     # fromRGB-like channel counts
     assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 48, 32, 0) == 0    # H > 32 and not a multiple of 32
     assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 32, 32, 1) == 0    # fp16
-    x = torch.randn([2, 64, 16, 16], device=DEV, requires_grad=True)
+    x = torch.randn([2, 64, 4, 4], device=DEV, requires_grad=True)
     w = torch.randn([64, 64, 3, 3], device=DEV, requires_grad=True)
     custom_ops.prof_enable(64)
     torch.autograd.grad(conv2d_gradfix.conv2d(x, w, padding=1).sum(), [w])
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv_wrw']['launches'] == 0   # (the 16x16 forward itself runs on conv3x3_small_kernel)
-    p = custom_ops.ConvWrwParams(x.data_ptr(), x.data_ptr(), w.data_ptr(), 2, 64, 64, 16, 16, 3)
+    assert custom_ops.prof_collect()['conv_wrw']['launches'] == 0
+    p = custom_ops.ConvWrwParams(x.data_ptr(), x.data_ptr(), w.data_ptr(), 2, 64, 64, 4, 4, 3)
     assert lib.sgv_conv3x3_wrw(p, 0, None) == -3 and b'W % 32' in lib.sgv_last_error()
 
 
@@ -139,3 +143,10 @@ def test_weight_gradient_with_input_scale_equals_scaling_first():
     a = conv2d_gradfix._native_wrw(dy, x, cfg, (co, ci, 3, 3), x_scale=s)
     b = conv2d_gradfix._native_wrw(dy, x * s[:, :, None, None], cfg, (co, ci, 3, 3))
     assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()     # atomics: the accumulation order over workgroups differs run to run
+    # packed-sample form (16-pixel images): every 8-pixel group takes the scale of its own sample
+    n, h, w = 5, 16, 16
+    dy, x = torch.randn([n, co, h, w], generator=g).cuda(), torch.randn([n, ci, h, w], generator=g).cuda()
+    s = (torch.randn([n, ci], generator=g) * 0.5 + 1).cuda()
+    a = conv2d_gradfix._native_wrw(dy, x, cfg, (co, ci, 3, 3), x_scale=s)
+    b = conv2d_gradfix._native_wrw(dy, x * s[:, :, None, None], cfg, (co, ci, 3, 3))
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()

@@ -191,7 +191,7 @@ typedef float f4a __attribute__((ext_vector_type(4), aligned(16)));
 
 struct rawrow { float m[4]; float h; };
 
-template <int PF, int NT>
+template <int PF, int NT, int ABL = 0>
 __global__ __launch_bounds__(256) void k_cols4(P p, int colgroups, int strips) {
     const int lane = threadIdx.x & 63;
     const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -272,11 +272,13 @@ __global__ __launch_bounds__(256) void k_cols4(P p, int colgroups, int strips) {
             for (int r = 0; r < 3; r++)
 #pragma unroll
                 for (int i = 0; i < 7; i++) win[r][i] = win[r + 1][i];
-            expand(cur[k], win[3]);
+            if (ABL != 2) expand(cur[k], win[3]);
             float o[4];
 #pragma unroll
             for (int v = 0; v < 4; v++) {
                 float acc = 0.f;
+                if (ABL == 2) { o[v] = cur[k].m[v] + cur[k].h; continue; }                       // ablation: loads + stores only
+                if (ABL == 1) { o[v] = win[3][v] + win[3][v + 3] + win[0][v]; continue; }         // ablation: no FMAs (window and DPP kept)
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -339,7 +341,7 @@ int main(int argc, char** argv) {
         printf("%-34s avg %8.4f ms  min %8.4f ms   %7.1f GB/s (min %7.1f)  %5.1f%% of 8 TB/s\n", name, tot / reps, best, gb / (tot / reps) * 1e3, gb / best * 1e3, gb / (tot / reps) * 1e3 / 80.0);
     };
     bench("copy float4 (same bytes)", [&](const float* xi, float* yo) {
-        long n4 = (long)(ny / 4); hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const float4*)xi, (float4*)yo, n4); }, false);
+        long n4 = (long)((nx < ny ? nx : ny) / 4); hipLaunchKernelGGL(k_copy, dim3(2048), dim3(256), 0, 0, (const float4*)xi, (float4*)yo, n4); }, false);
     // the production library through its C ABI, same harness
     const char* so_path = getenv("SGV_LIB") ? getenv("SGV_LIB") : "stylegan-v_amd/csrc/libsgv_hip.so";
     void* so = dlopen(so_path, RTLD_NOW);
@@ -353,13 +355,16 @@ int main(int argc, char** argv) {
         bench("libsgv_hip sgv_upfirdn2d (C ABI)", [&](const float* xi, float* yo) { sgv_upfirdn2d_params r = q; r.x = xi; r.y = yo; if (sgv(&r, 0, nullptr)) printf("sgv error\n"); }, true);
     } else printf("libsgv_hip.so not found: %s\n", dlerror());
 #define RUNC(NTL, NTS, U) { std::string nm = std::string("copy2 ntl") + #NTL + " nts" + #NTS + " U" + #U; \
-      bench(nm.c_str(), [&](const float* xi, float* yo) { long n4 = (long)(ny / 4); hipLaunchKernelGGL((k_copy2<NTL, NTS, U>), dim3((unsigned)((n4 + 256 * U - 1) / (256 * U))), dim3(256), 0, 0, (const fv4*)xi, (fv4*)yo, n4); }, false); }
+      bench(nm.c_str(), [&](const float* xi, float* yo) { long n4 = (long)((nx < ny ? nx : ny) / 4); hipLaunchKernelGGL((k_copy2<NTL, NTS, U>), dim3((unsigned)((n4 + 256 * U - 1) / (256 * U))), dim3(256), 0, 0, (const fv4*)xi, (fv4*)yo, n4); }, false); }
     RUNC(0, 0, 1) RUNC(1, 1, 4)
     for (int sh : {8, 16}) {
         int strips4 = (OH + sh - 1) / sh; int cgs4 = (OW + 255) / 256; long waves4 = (long)planes * cgs4 * strips4; P q4 = p; q4.strip_h = sh;
 #define RUN4(PFV, NTV) { std::string nm = std::string("V3 cols dwordx4 PF") + #PFV + " NT" + #NTV + " strip " + std::to_string(sh); \
           bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q4; r.x = xi; r.y = yo; hipLaunchKernelGGL((k_cols4<PFV, NTV>), dim3((unsigned)((waves4 + 3) / 4)), dim3(256), 0, 0, r, cgs4, strips4); }, true); }
         RUN4(1, 1) RUN4(2, 1) RUN4(4, 1)
+#define RUN4A(PFV, NTV, AB) { std::string nm = std::string("V3 ablation ") + #AB + " PF" + #PFV + " NT" + #NTV + " strip " + std::to_string(sh); \
+          bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q4; r.x = xi; r.y = yo; hipLaunchKernelGGL((k_cols4<PFV, NTV, AB>), dim3((unsigned)((waves4 + 3) / 4)), dim3(256), 0, 0, r, cgs4, strips4); }, false); }
+        RUN4A(4, 1, 1) RUN4A(4, 1, 2) RUN4A(1, 1, 2) RUN4A(4, 2, 2)
     }
     for (int sh : std::vector<int>{}) {
         int strips = (OH + sh - 1) / sh;

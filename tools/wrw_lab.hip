@@ -47,6 +47,7 @@ static wrw_params make(const float* dy, const float* x, float* dw, int n, int o,
     const int tiles = (o / TO) * (i / TI);
     int splits = wgs / tiles; if (splits < 1) splits = 1; if (splits > p.units) splits = p.units;
     p.splits = splits;
+    p.scatter_flush = getenv("WRW_SCATTER") ? 1 : 0;   // the element-per-lane flush (A/B against flush_tile)
     return p;
 }
 
@@ -63,7 +64,7 @@ template <int TERMS, int VIEWS, int ABL> static void launch_ws_abl(const wrw_par
 }
 template <int TERMS, int VIEWS> static void launch_ws(const wrw_params& p) {   // producer / consumer form (wrw_ws_kernel.h); WRW_ABL = 6 / 7: ablations
     static const int abl = getenv("WRW_ABL") ? atoi(getenv("WRW_ABL")) : 0;
-    if (abl == 6) launch_ws_abl<TERMS, VIEWS, 6>(p); else if (abl == 7) launch_ws_abl<TERMS, VIEWS, 7>(p); else launch_ws_abl<TERMS, VIEWS, 0>(p);
+    if (abl == 6) launch_ws_abl<TERMS, VIEWS, 6>(p); else if (abl == 7) launch_ws_abl<TERMS, VIEWS, 7>(p); else if (abl == 8) launch_ws_abl<TERMS, VIEWS, 8>(p); else launch_ws_abl<TERMS, VIEWS, 0>(p);
 }
 
 __global__ void naive_wrw_s2(const float* sm, const float* big, double* dw, int n, int cs, int cb, int h, int w) {
@@ -88,6 +89,7 @@ template <int TERMS> static wrw_s2_params launch_s2(const float* sm, const float
     wrw_s2_params p{};
     p.small = sm; p.big = big; p.dw = dw; p.n = n; p.cs = cs; p.cb = cb; p.h = h; p.w = w;
     p.rows = h < 32 ? h : 32;
+    p.scatter_flush = getenv("WRW_SCATTER") ? 1 : 0;
     p.tiles_b = cb / TI;
     p.units = n * (w / SEG) * (h / p.rows);
     const int tiles = (cs / TO) * p.tiles_b;
