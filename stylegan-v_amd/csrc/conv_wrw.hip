@@ -24,8 +24,8 @@ bool supported(int n, int o, int i, int h, int w, int dtype) {
 }
 
 bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {
-    return dtype == SGV_F32 && n >= 1 && cs >= TO && cb >= TI && cs % TO == 0 && cb % TI == 0 && w >= SEG && w % SEG == 0 && h >= 1 && (h <= 32 || h % 32 == 0) &&
-           (int64_t)n * std::max(cs, cb) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
+    return dtype == SGV_F32 && n >= 1 && cs >= TO && cb >= TI && cs % TO == 0 && cb % TI == 0 && h >= 1 &&
+           ((w >= SEG && w % SEG == 0 && (h <= 32 || h % 32 == 0)) || packed_width(h, w)) && (int64_t)n * std::max(cs, cb) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
 }
 
 std::once_flag g_once, g_ws_once;
@@ -120,13 +120,15 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: params is NULL");
     if (!p->dy || !p->x || !p->dw) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: NULL pointer");
     if (!supported_s2(p->n, p->c_out, p->c_in, p->h, p->w, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_s2: needs fp32, channels %% 64 == 0, W %% 32 == 0, H <= 32 or H %% 32 == 0 on the HxW grid (got n=%d cs=%d cb=%d h=%d w=%d dtype=%d)",
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_s2: needs fp32, channels %% 64 == 0, and on the small HxW grid W %% 32 == 0 with H <= 32 or H %% 32 == 0, or W in {16, 8} with H <= 32 (got n=%d cs=%d cb=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_out, p->c_in, p->h, p->w, dtype);
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms must be 1 or 3");
     if (((uintptr_t)p->dy) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: the small tensor must be 16-byte aligned");
     std::call_once(g_once, [] {
         hipError_t e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
         g_attr_err = e;
     });
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
@@ -137,7 +139,8 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     kp.rows = std::min(p->h, 32);
     kp.scatter_flush = scatter_flush();
     kp.tiles_b = p->c_in / TI;
-    kp.units = p->n * (p->w / SEG) * (p->h / kp.rows);
+    const bool pack = p->w < SEG;
+    kp.units = (pack ? (p->n + SEG / p->w - 1) / (SEG / p->w) : p->n * (p->w / SEG)) * (p->h / kp.rows);
     const int tiles = (p->c_out / TO) * kp.tiles_b;
     kp.splits = std::max(1, std::min(kp.units, 256 / std::max(1, std::min(tiles, 256))));
     const size_t dw_bytes = (size_t)p->c_out * p->c_in * 9 * sizeof(float);
@@ -146,6 +149,11 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     const double small_px = (double)p->n * p->h * p->w, big_px = (double)p->n * (2 * p->h + 1) * (2 * p->w + 1);
     sgv_launch_scope scope(SGV_K_CONV_WRW, stream, 4.0 * (small_px * p->c_out + big_px * p->c_in) + dw_bytes, 2.0 * small_px * p->c_out * (double)p->c_in * 9);
     dim3 grid((unsigned)tiles, (unsigned)kp.splits);
+    if (pack) {
+        if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_kernel<1, true>), grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
+        else hipLaunchKernelGGL((wrw3x3_s2_kernel<3, true>), grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
+        return sgv_check_launch("wrw3x3_s2_kernel (packed)");
+    }
     if (p->terms == 1) hipLaunchKernelGGL(wrw3x3_s2_kernel<1>, grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
     else hipLaunchKernelGGL(wrw3x3_s2_kernel<3>, grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
     return sgv_check_launch("wrw3x3_s2_kernel");

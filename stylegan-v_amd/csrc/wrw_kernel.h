@@ -294,7 +294,11 @@ struct wrw_s2_params {
     int scatter_flush;    // as in wrw_params
 };
 
-template <int TERMS>
+//
+// PACK: small images 16 or 8 pixels wide (big: 33 / 17): 2 or 4 samples side by side in the 32-pixel row step, a unit is (group of 32 / W samples, row
+// block).  Every sample's last big column (2W, the kx = 2 neighbour of its last pixel) sits in the pad words of the channel row (position 80 + 2 * sample)
+// instead of behind the even plane, and the lane groups that end a sample take it from there.
+template <int TERMS, bool PACK = false>
 __global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_s2[];
     unsigned short* bs = lds_s2;                          // [hl][5 slots][64 cb][even RS | odd RS]
@@ -308,7 +312,18 @@ __global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
     const int vid = (nwg & 7) == 0 ? (lin & 7) * (nwg >> 3) + (lin >> 3) : lin;
     const int tile = vid % (int)gridDim.x, split = vid / (int)gridDim.x;
     const int s0 = (tile / p.tiles_b) * TO, b0 = (tile % p.tiles_b) * TI;
-    const int segs = p.w / SEG, rblocks = p.h / p.rows;
+    const int segs = PACK ? 1 : p.w / SEG, rblocks = p.h / p.rows;
+    const int wsh = PACK ? 31 - __builtin_clz(p.w) : 5;   // log2(W): W is 16 or 8 when PACK
+    const int spr = PACK ? SEG >> wsh : 1;     // samples per row step
+    // offset (inside a channel row of a ring slot) of the dword behind this lane's eight even columns, per k half c; PACK: where the group ends a
+    // sample, that sample's last big column (kept in the pad words)
+    int pe_off[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+        const int px = 16 * c + 8 * (lane >> 5);
+        pe_off[c] = px + 8;
+        if (PACK && ((px + 8) & (p.w - 1)) == 0) pe_off[c] = 2 * RS + 2 * (px >> wsh);
+    }
     const int hb = 2 * p.h + 1, wb = 2 * p.w + 1;
     const size_t plane_s = (size_t)p.h * p.w, plane_b = (size_t)hb * wb;
 
@@ -323,18 +338,24 @@ __global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
     struct big_regs { f32x4 v[4]; float edge; };
 
     for (int u = split; u < p.units; u += p.splits) {
-        const int rb = u % rblocks, sg = (u / rblocks) % segs, n = u / (rblocks * segs);
+        const int rb = u % rblocks, sg = (u / rblocks) % segs, n = (u / (rblocks * segs)) * spr;
         const int y0 = rb * p.rows, x0 = sg * SEG;
         const float* sb = p.small + ((size_t)n * p.cs + s0) * plane_s + x0;
         const float* bb = p.big + ((size_t)n * p.cb + b0) * plane_b + (size_t)(2 * y0) * wb + 2 * x0;
+        // PACK: sample `s` of the group (clamped to the batch; a sample past its end contributes zeros through the small operand)
+        auto sample_off = [&](int smp, size_t per_sample) { return (size_t)min(smp, p.n - 1 - n) * per_sample; };
 
         auto load_big = [&](int b, big_regs& r) {   // local big row b = 0 .. 2 * rows
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int it = t + 256 * j, quad = it & 15, ch = it >> 4;
-                r.v[j] = *(const f32x4_u*)(bb + (size_t)ch * plane_b + (size_t)b * wb + 4 * quad);
+                if (PACK) {   // quads per sample: W / 2
+                    const int smp = quad >> (wsh - 1), col = 4 * (quad & ((p.w >> 1) - 1));
+                    r.v[j] = *(const f32x4_u*)(bb + sample_off(smp, (size_t)p.cb * plane_b) + (size_t)ch * plane_b + (size_t)b * wb + col);
+                } else r.v[j] = *(const f32x4_u*)(bb + (size_t)ch * plane_b + (size_t)b * wb + 4 * quad);
             }
-            r.edge = t < TI ? bb[(size_t)t * plane_b + (size_t)b * wb + 64] : 0.f;
+            if (PACK) r.edge = t < TI * spr ? bb[sample_off(t >> 6, (size_t)p.cb * plane_b) + (size_t)(t & 63) * plane_b + (size_t)b * wb + 2 * p.w] : 0.f;
+            else r.edge = t < TI ? bb[(size_t)t * plane_b + (size_t)b * wb + 64] : 0.f;
         };
         auto store_big = [&](int b, const big_regs& r) {
             const int slot = b - 5 * ((b * 205) >> 10);   // b % 5
@@ -352,18 +373,21 @@ __global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
                     *(unsigned*)&bs[5 * BIG_SLOT + pos + RS] = lo;
                 }
             }
-            if (t < TI) {
+            if (t < TI * spr) {
                 const unsigned h = pack_bf16(r.edge, 0.f);
-                const int pos = slot * BIG_SLOT + t * BIG_CH + 32;
+                const int pos = slot * BIG_SLOT + (t & 63) * BIG_CH + (PACK ? 2 * RS + 2 * (t >> 6) : 32);
                 bs[pos] = (unsigned short)h;
                 if (TERMS > 1) bs[5 * BIG_SLOT + pos] = (unsigned short)pack_bf16(r.edge - __builtin_bit_cast(float, h << 16), 0.f);
             }
         };
         auto load_small = [&](int row, float* v) {
-            const float* q = sb + (size_t)lr * plane_s + (size_t)(y0 + row) * p.w + lq;
+            const int smp = PACK ? lq >> wsh : 0;
+            const float* q = sb + (size_t)lr * plane_s + (size_t)(y0 + row) * p.w + (PACK ? (lq & (p.w - 1)) : lq);
+            if (PACK) q += sample_off(smp, (size_t)p.cs * plane_s);
             const f32x4 a = *(const f32x4*)q, b = *(const f32x4*)(q + 4);
+            const bool live = !PACK || n + smp < p.n;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { v[k] = a[k]; v[4 + k] = b[k]; }
+            for (int k = 0; k < 4; k++) { v[k] = live ? a[k] : 0.f; v[4 + k] = live ? b[k] : 0.f; }
         };
         auto store_small = [&](int row, const float* v) {
             u32x4 hi, lo;
@@ -408,11 +432,12 @@ __global__ __launch_bounds__(256, 1) void wrw3x3_s2_kernel(wrw_s2_params p) {
                     const int b = 2 * i + ky;
                     const int slot = b - 5 * ((b * 205) >> 10);
                     const int pb = slot * BIG_SLOT + (wi + r32) * BIG_CH + 16 * c + 8 * g;
+                    const int pe = slot * BIG_SLOT + (wi + r32) * BIG_CH + pe_off[c];
                     u32x4 bv[2][3];
 #pragma unroll
                     for (int hl = 0; hl < (TERMS > 1 ? 2 : 1); hl++) {
                         const u32x4 e = *(const u32x4*)&bs[hl * 5 * BIG_SLOT + pb];
-                        const unsigned ea = *(const unsigned*)&bs[hl * 5 * BIG_SLOT + pb + 8];
+                        const unsigned ea = *(const unsigned*)&bs[hl * 5 * BIG_SLOT + pe];
                         bv[hl][0] = e;
                         bv[hl][1] = *(const u32x4*)&bs[hl * 5 * BIG_SLOT + pb + RS];
                         bv[hl][2] = u32x4{__builtin_amdgcn_alignbyte(e[1], e[0], 2), __builtin_amdgcn_alignbyte(e[2], e[1], 2), __builtin_amdgcn_alignbyte(e[3], e[2], 2),

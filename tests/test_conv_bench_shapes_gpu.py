@@ -199,7 +199,8 @@ def test_conv3x3_weight_gradient_at_benchmark_shapes(c, r):
     _check_wrw(c, c, r, 1, False, seed=3 * c + r)
 
 
-@pytest.mark.parametrize('cs,cb,hs,transposed', [(128, 64, 128, False), (512, 256, 32, False), (512, 256, 32, True), (128, 64, 128, True)])
+@pytest.mark.parametrize('cs,cb,hs,transposed', [(128, 64, 128, False), (512, 256, 32, False), (512, 256, 32, True), (128, 64, 128, True),
+                                                  (512, 512, 16, False), (512, 512, 16, True), (512, 512, 8, False), (512, 512, 8, True)])
 def test_conv3x3_stride2_weight_gradient_at_benchmark_shapes(cs, cb, hs, transposed):
     """... of the strided (D) and transposed (G) stride-2 layers; the weight is [c_small, c_big, 3, 3] in both."""
     _check_wrw(cs, cb, hs, 2, transposed, seed=5 * cs + hs + transposed)

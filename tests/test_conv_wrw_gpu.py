@@ -105,7 +105,9 @@ def test_unsupported_shapes_fall_back_to_the_vendor_library():
     assert lib.sgv_conv3x3_wrw(p, 0, None) == -3 and b'W % 32' in lib.sgv_last_error()
 
 
-@pytest.mark.parametrize('n,cs,cb,h,w', [(2, 64, 64, 8, 32), (1, 128, 64, 32, 64), (3, 64, 128, 64, 32), (2, 64, 64, 1, 96)])
+@pytest.mark.parametrize('n,cs,cb,h,w', [(2, 64, 64, 8, 32), (1, 128, 64, 32, 64), (3, 64, 128, 64, 32), (2, 64, 64, 1, 96),
+                                          # small grid 16 / 8 pixels wide (big 33 / 17): 2 / 4 samples per row step, incl. a short last group
+                                          (4, 64, 64, 16, 16), (3, 64, 128, 16, 16), (8, 128, 64, 8, 8), (5, 64, 64, 8, 8), (1, 64, 64, 4, 8)])
 @pytest.mark.parametrize('transposed', [False, True])
 def test_wrw_stride2_family(n, cs, cb, h, w, transposed):
     """Weight gradient of the strided (big -> small) and of the transposed (small -> big) 3x3 layer."""
