@@ -6,6 +6,7 @@
 #include "sgv_common.h"
 #include "wrw_kernel.h"
 #include "wrw_ws_kernel.h"
+#include "wrw_s2_ws_kernel.h"
 
 #include <algorithm>
 #include <mutex>
@@ -30,6 +31,7 @@ bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {
 
 std::once_flag g_once, g_ws_once;
 hipError_t g_attr_err = hipSuccess, g_ws_attr_err = hipSuccess;
+bool g_use_s2_ws = true;   // SGV_WRW_S2_WS=0: the 4-wave stride-2 kernel of wrw_kernel.h instead of the producer / consumer form (wrw_s2_ws_kernel.h)
 bool g_use_ws = true;   // SGV_WRW_WS=0: the 4-wave kernel of wrw_kernel.h instead of the producer / consumer form (wrw_ws_kernel.h)
 int scatter_flush() {   // SGV_WRW_FLUSH=scatter: the element-per-lane atomics instead of the LDS-staged contiguous ones (wrw_kernel.h flush_tile)
     static const int v = [] { const char* e = getenv("SGV_WRW_FLUSH"); return (e && e[0] == 's') ? 1 : 0; }();
@@ -129,6 +131,12 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        const char* env = getenv("SGV_WRW_S2_WS");
+        g_use_s2_ws = !(env && env[0] == '0');
         g_attr_err = e;
     });
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
@@ -149,6 +157,16 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     const double small_px = (double)p->n * p->h * p->w, big_px = (double)p->n * (2 * p->h + 1) * (2 * p->w + 1);
     sgv_launch_scope scope(SGV_K_CONV_WRW, stream, 4.0 * (small_px * p->c_out + big_px * p->c_in) + dw_bytes, 2.0 * small_px * p->c_out * (double)p->c_in * 9);
     dim3 grid((unsigned)tiles, (unsigned)kp.splits);
+    if (g_use_s2_ws) {
+        if (pack) {
+            if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, true>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+            else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<3, true>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+        } else {
+            if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, false>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+            else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<3, false>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+        }
+        return sgv_check_launch("wrw3x3_s2_ws_kernel");
+    }
     if (pack) {
         if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_kernel<1, true>), grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL((wrw3x3_s2_kernel<3, true>), grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);

@@ -8,6 +8,7 @@
 #include <vector>
 #include "wrw_kernel.h"
 #include "wrw_ws_kernel.h"
+#include "wrw_s2_ws_kernel.h"
 
 using namespace sgv_wrw;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -98,6 +99,19 @@ template <int TERMS> static wrw_s2_params launch_s2(const float* sm, const float
     static bool attr = false;
     if (!attr) { CK(hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES));
                  CK(hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES)); attr = true; }
+    static const int ws = getenv("WRW_S2_WS") ? atoi(getenv("WRW_S2_WS")) : 1;     // 0: 4-wave kernel; 1: producer / consumer; 6 / 7: its ablations
+    if (ws) {
+        static bool attr2 = false;
+        if (!attr2) { CK(hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<TERMS, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES));
+                      CK(hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<TERMS, false, 6>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES));
+                      CK(hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<TERMS, false, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES));
+                      CK(hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<TERMS, false, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES)); attr2 = true; }
+        if (ws == 9) { hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<TERMS, false, 9>), dim3(tiles, p.splits), dim3(512), WRW_S2_WS_LDS_BYTES, 0, p); return p; }
+        if (ws == 6) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<TERMS, false, 6>), dim3(tiles, p.splits), dim3(512), WRW_S2_WS_LDS_BYTES, 0, p);
+        else if (ws == 7) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<TERMS, false, 7>), dim3(tiles, p.splits), dim3(512), WRW_S2_WS_LDS_BYTES, 0, p);
+        else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<TERMS, false, 0>), dim3(tiles, p.splits), dim3(512), WRW_S2_WS_LDS_BYTES, 0, p);
+        return p;
+    }
     hipLaunchKernelGGL(wrw3x3_s2_kernel<TERMS>, dim3(tiles, p.splits), dim3(256), WRW_S2_LDS_BYTES, 0, p);
     return p;
 }
