@@ -13,12 +13,16 @@
 //            data grad dx = (dz @ W) * wg                                      A = dz, B = W       (mapping input), operand A can be
 //            weight gr dW = (dz^T @ x) * wg,  db = bg * sum_m dz               A = dz^T, B = x     "dy with the activation gradient
 //                                                                                                   applied from the saved output"
-// Tiling: a workgroup owns a 32 x 32 output tile (grid = N/32 x M/32: 16..256 workgroups for the layers above); its sixteen waves split
-// K sixteen ways, each accumulates whole 32x32 MFMA tiles (two independent accumulators), partial tiles are added through LDS, then the
-// epilogue.
+// Tiling: a workgroup owns a 32 x 32 output tile (grid = N/32 x M/32: 16..256 workgroups for the layers above); its waves -- one per 8-deep
+// k step, at most sixteen -- split K, each accumulates whole 32x32 MFMA tiles (two independent accumulators), partial tiles are added through
+// LDS, then the epilogue.  (The wave count follows K: the weight gradient of the 8192 -> 512 epilogue layer is 4,096 tiles of K = 32; with
+// sixteen waves each of them spent its time adding twelve empty partial tiles: 86 -> 19 us.)
 // Algorithmic bytes: 4 * (M*K + N*K + M*N); flops 2*M*N*K.
 
 #include "sgv_common.h"
+
+#include <algorithm>
+#include <stdlib.h>
 
 namespace sgv_fck {
 
@@ -45,12 +49,14 @@ struct fc_params {
 // tile's row / column index (consecutive lanes read consecutive floats: scalar loads, one 128-B line per half wave).
 // WAVES split K; every wave keeps two accumulators so that consecutive MFMAs are independent (a v_mfma_f32_32x32x2_f32 takes 64 cycles
 // and a dependent one cannot start earlier): the serial chain of the K = 8192 epilogue layer is 128 MFMAs instead of 1024.
-constexpr int FC_WAVES = 16;
+constexpr int FC_WAVES = 16;     // at most
 
-template <int AK, int BK>
+// FC_UNROLL = k steps whose loads are issued together
+template <int AK, int BK, int FC_UNROLL>
 __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
-    __shared__ float red[FC_WAVES - 1][32 * 32];
+    extern __shared__ float red[];          // [waves - 1][32 * 32]
     __shared__ float rowstat[32];
+    const int waves = blockDim.x >> 6;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int r = lane & 31, kk = lane >> 5;
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
@@ -70,39 +76,47 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
     const int steps = (p.k + 7) / 8;
     const bool vec_a = AK && (p.k % 4 == 0) && ((((uintptr_t)p.a) | (uintptr_t)(p.sam * 4) | (uintptr_t)(p.sab * 4)) % 16 == 0) && (!p.aref || ((uintptr_t)p.aref % 16 == 0));
     const bool vec_b = BK && (p.k % 4 == 0) && ((((uintptr_t)p.b) | (uintptr_t)(p.sbn * 4) | (uintptr_t)(p.sbb * 4)) % 16 == 0);
-    for (int i = wave; i < steps; i += FC_WAVES) {
-        const int k0 = 8 * i + 4 * kk;
-        float av[4], bv[4], yv[4];
-        if (vec_a) {
-            const bool ok = a_ok && k0 < p.k;
-            const float4 q = ok ? *(const float4*)(ap + k0) : float4{0.f, 0.f, 0.f, 0.f};
-            av[0] = q.x; av[1] = q.y; av[2] = q.z; av[3] = q.w;
-            if (arp) { const float4 w = ok ? *(const float4*)(arp + k0) : float4{0.f, 0.f, 0.f, 0.f}; yv[0] = w.x; yv[1] = w.y; yv[2] = w.z; yv[3] = w.w; }
-        } else {
+    for (int i0 = wave; i0 < steps; i0 += waves * FC_UNROLL) {
+        float av[FC_UNROLL][4], bv[FC_UNROLL][4], yv[FC_UNROLL][4];
+        // all loads of FC_UNROLL steps first (a step past the end loads nothing and contributes zeros) ...
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bool ok = a_ok && k0 + j < p.k;
-                av[j] = ok ? ap[(size_t)(k0 + j) * p.sak] : 0.f;
-                if (arp) yv[j] = ok ? arp[(size_t)(k0 + j) * p.sak] : 0.f;
+        for (int u = 0; u < FC_UNROLL; u++) {
+            const int k0 = 8 * (i0 + u * waves) + 4 * kk;
+            if (vec_a) {
+                const bool ok = a_ok && k0 < p.k;
+                const float4 q = ok ? *(const float4*)(ap + k0) : float4{0.f, 0.f, 0.f, 0.f};
+                av[u][0] = q.x; av[u][1] = q.y; av[u][2] = q.z; av[u][3] = q.w;
+                if (arp) { const float4 w = ok ? *(const float4*)(arp + k0) : float4{0.f, 0.f, 0.f, 0.f}; yv[u][0] = w.x; yv[u][1] = w.y; yv[u][2] = w.z; yv[u][3] = w.w; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool ok = a_ok && k0 + j < p.k;
+                    av[u][j] = ok ? ap[(size_t)(k0 + j) * p.sak] : 0.f;
+                    if (arp) yv[u][j] = ok ? arp[(size_t)(k0 + j) * p.sak] : 0.f;
+                }
+            }
+            if (vec_b) {
+                const float4 q = (b_ok && k0 < p.k) ? *(const float4*)(bp + k0) : float4{0.f, 0.f, 0.f, 0.f};
+                bv[u][0] = q.x; bv[u][1] = q.y; bv[u][2] = q.z; bv[u][3] = q.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) bv[u][j] = (b_ok && k0 + j < p.k) ? bp[(size_t)(k0 + j) * p.sbk] : 0.f;
             }
         }
-        if (vec_b) {
-            const float4 q = (b_ok && k0 < p.k) ? *(const float4*)(bp + k0) : float4{0.f, 0.f, 0.f, 0.f};
-            bv[0] = q.x; bv[1] = q.y; bv[2] = q.z; bv[3] = q.w;
-        } else {
+        // ... then the arithmetic
 #pragma unroll
-            for (int j = 0; j < 4; j++) bv[j] = (b_ok && k0 + j < p.k) ? bp[(size_t)(k0 + j) * p.sbk] : 0.f;
-        }
+        for (int u = 0; u < FC_UNROLL; u++) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if (arp) av[j] = ((p.act == 3 && !(yv[j] > 0.f)) ? av[j] * p.alpha : av[j]) * p.gain;
-            a_sum += av[j];
-            a_sq = __builtin_fmaf(av[j], av[j], a_sq);
+            for (int j = 0; j < 4; j++) {
+                if (arp) av[u][j] = ((p.act == 3 && !(yv[u][j] > 0.f)) ? av[u][j] * p.alpha : av[u][j]) * p.gain;
+                a_sum += av[u][j];
+                a_sq = __builtin_fmaf(av[u][j], av[u][j], a_sq);
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][0], bv[u][0], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][1], bv[u][1], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][2], bv[u][2], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][3], bv[u][3], acc1, 0, 0, 0);
         }
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc1, 0, 0, 0);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2], bv[2], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[3], bv[3], acc1, 0, 0, 0);
     }
 #pragma unroll
     for (int e = 0; e < 16; e++) acc0[e] += acc1[e];
@@ -116,7 +130,7 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
     // C layout of the 32x32 MFMA: col (n) = lane & 31, row (m) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     if (wave > 0) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) red[wave - 1][((e & 3) + 8 * (e >> 2) + 4 * kk) * 32 + r] = acc0[e];
+        for (int e = 0; e < 16; e++) red[(wave - 1) * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kk) * 32 + r] = acc0[e];
     }
     __syncthreads();
     if (wave != 0) return;
@@ -126,8 +140,7 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
     for (int e = 0; e < 16; e++) {
         const int ml = (e & 3) + 8 * (e >> 2) + 4 * kk;
         float v = acc0[e];
-#pragma unroll
-        for (int w = 0; w < FC_WAVES - 1; w++) v += red[w][ml * 32 + r];
+        for (int w = 0; w < waves - 1; w++) v += red[w * 1024 + ml * 32 + r];
         if (p.normalize) v *= 1.0f / sqrtf(rowstat[ml] / (float)p.k + 1e-8f);
         v = v * p.wgain + bias;
         if (p.epilogue_act) v = ((p.act == 3 && !(v > 0.f)) ? v * p.alpha : v) * p.gain;
@@ -151,13 +164,28 @@ static int sgv_fc_launch(const sgv_fc_params* q, hipStream_t stream, bool accoun
     p.normalize = q->normalize_a; p.act = q->act; p.alpha = q->alpha; p.gain = q->gain; p.wgain = q->weight_gain; p.bgain = q->bias_gain;
     p.epilogue_act = q->epilogue_act;
     p.sab = q->a_stride_batch; p.sbb = q->b_stride_batch; p.scb = q->c_stride_batch; p.accumulate = q->accumulate;
-    dim3 grid((unsigned)((q->n + 31) / 32), (unsigned)((q->m + 31) / 32), (unsigned)batch), block(sgv_fck::FC_WAVES * 64);
+    // SGV_FC_UNROLL=4: four k steps' loads in flight per wave -- measured slower (tools/fc_bench.py: the [2048, 5632] x [5632, 512] products of the
+    // motion network's conv1d layers 359 -> 631 us in the data-gradient form), kept for the lab only
+    static const int unroll_env = [] { const char* e = getenv("SGV_FC_UNROLL"); return e ? atoi(e) : 1; }();
+    static const int waves_env = [] { const char* e = getenv("SGV_FC_WAVES"); return e ? atoi(e) : 0; }();     // 0: follow K
+    const int unroll = unroll_env == 1 ? 1 : 4;
+    const int steps = (q->k + 7) / 8;
+    const int waves = waves_env > 0 ? std::min(waves_env, sgv_fck::FC_WAVES) : std::max(1, std::min(sgv_fck::FC_WAVES, (steps + unroll - 1) / unroll));
+    const size_t lds = (size_t)(waves - 1) * 1024 * sizeof(float);
+    dim3 grid((unsigned)((q->n + 31) / 32), (unsigned)((q->m + 31) / 32), (unsigned)batch), block(waves * 64);
     const bool ak = q->a_stride_k == 1, bk = q->b_stride_k == 1;
     auto go = [&] {
-        if (ak && bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 1>), grid, block, 0, stream, p);
-        else if (ak) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 0>), grid, block, 0, stream, p);
-        else if (bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 1>), grid, block, 0, stream, p);
-        else hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 0>), grid, block, 0, stream, p);
+        if (unroll == 1) {
+            if (ak && bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 1, 1>), grid, block, lds, stream, p);
+            else if (ak) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 0, 1>), grid, block, lds, stream, p);
+            else if (bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 1, 1>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 0, 1>), grid, block, lds, stream, p);
+        } else {
+            if (ak && bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 1, 4>), grid, block, lds, stream, p);
+            else if (ak) hipLaunchKernelGGL((sgv_fck::fc_kernel<1, 0, 4>), grid, block, lds, stream, p);
+            else if (bk) hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 1, 4>), grid, block, lds, stream, p);
+            else hipLaunchKernelGGL((sgv_fck::fc_kernel<0, 0, 4>), grid, block, lds, stream, p);
+        }
     };
     if (account) {
         sgv_launch_scope scope(SGV_K_GEMM, stream, 4.0 * batch * ((double)q->m * q->k + (double)q->n * q->k + (double)q->m * q->n), 2.0 * batch * q->m * (double)q->n * q->k);
