@@ -20,6 +20,7 @@ from .. import custom_ops
 from . import bias_act as _ba
 
 enabled = True
+large_m = 1024   # rows from which the tiled GEMM serves a dense layer (the 32 x 32-tile kernel of csrc/fc.hip is built for M = a few dozen)
 
 
 def dense_ref(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear', normalize=False, act_gain=None):
@@ -100,5 +101,11 @@ def dense(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear', no
     if enabled and x.is_cuda and x.ndim == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32 and act in ('linear', 'lrelu') \
             and (bias is None or bias.dtype == torch.float32) and x.shape[0] <= 65535 * 32:
         again = float(_ba.activation_funcs[act].def_gain if act_gain is None else act_gain)
+        if x.shape[0] >= large_m and not normalize and weight.shape[1] >= 256 and weight.shape[0] >= 128:
+            # thousands of rows (the unfolded trajectories of the motion network, layers.py `EqLRConv1d.forward_nlc`: [32 * 76, 11 * 512] x [5632, 512]):
+            # the 128 x 128-tile GEMM (csrc/gemm_kernel.h) + the fused bias / activation pass; both differentiable (twice)
+            from . import gemm as _gemm
+            b = bias * bias_gain if (bias is not None and bias_gain != 1) else bias
+            return _ba.bias_act(_gemm.linear(x, weight * weight_gain), b, act=act, gain=again)
         return _DenseFn.apply(x, weight, bias, (float(weight_gain), float(bias_gain), act, bool(normalize), again))
     return dense_ref(x, weight, bias, weight_gain, bias_gain, act, normalize, act_gain)

@@ -37,10 +37,20 @@ def _native_ok(*tensors):
 
 
 def matmul_nt(a, b, bias=None):
-    """a [M,K] @ b[N,K]^T (+ bias[N]) -> [M,N], no autograd."""
+    """a [M,K] @ b[N,K]^T (+ bias[N]) -> [M,N], no autograd.  Few output tiles and a long K (the [2112, 5632] x [5632, 512] products of the motion
+    network's trajectory convolutions: 68 tiles on 256 CUs): K is cut into slices that run as separate workgroups and are summed afterwards."""
     a, b = a.contiguous(), b.contiguous()
     m, k = a.shape
     n = b.shape[0]
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    ks = 1
+    while tiles * ks < 192 and ks < 8 and k % (ks * 2 * 32) == 0 and k // (ks * 2) >= 256:
+        ks *= 2
+    if ks > 1:
+        per = torch.empty([ks, m, n], dtype=torch.float32, device=a.device)
+        _launch(a, b, None, per, m, n, k, k, k, n, True, batch=1, sc=m * n, k_split=ks)
+        c = per.sum(0)
+        return c + bias.unsqueeze(0) if bias is not None else c
     c = torch.empty([m, n], dtype=torch.float32, device=a.device)
     return _launch(a, b, bias, c, m, n, k, k, k, n, True, bias_mode=1 if bias is not None else 0)
 

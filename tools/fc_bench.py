@@ -27,3 +27,17 @@ for name, m, k, n in [('epilogue 8192->512 x32', 32, 8192, 512), ('affine 512->5
     out.append(f'{name:30s} fwd {f:7.1f}  dx {g:7.1f}  dw {h:7.1f} us')
 print(f"UNROLL={os.environ.get('SGV_FC_UNROLL', '4')} WAVES={os.environ.get('SGV_FC_WAVES', '0')}")
 print('\n'.join(out))
+
+# the trajectory convolutions as dense layers: 32 x 32-tile kernel vs tiled GEMM route (fc.large_m)
+for m in (2432, 2112):
+    k, n = 5632, 512
+    x = torch.randn([m, k], device='cuda', requires_grad=True); w = torch.randn([n, k], device='cuda', requires_grad=True); b = torch.randn([n], device='cuda', requires_grad=True)
+    dy = torch.randn([m, n], device='cuda')
+    for lm in (1 << 30, 1024):
+        fc.large_m = lm
+        def run():
+            y = fc.dense(x, w, b, weight_gain=0.01, bias_gain=0.01, act='lrelu', act_gain=1)
+            torch.autograd.grad(y, [x, w, b], dy)
+        def fwd():
+            with torch.no_grad(): fc.dense(x, w, b, weight_gain=0.01, bias_gain=0.01, act='lrelu', act_gain=1)
+        print(f'conv1d as dense, M = {m}: route {"fc kernel " if lm > 4096 else "tiled GEMM"}  fwd {t(fwd):7.1f} us   fwd + bwd {t(run):7.1f} us')
