@@ -105,7 +105,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         const int oct = pt & 1;                                                   // same for both units (192 and ITEMS are even)
         const int a_quad = (pt >> 1) & 7, a_row0 = pt >> 4, a_row1 = u1 >> 4;     // u1 >> 4 = a_row0 + 12
         const int hh = u1 - ITEMS, h_side = (hh >> 1) & 1, h_row = hh >> 2;
-        struct xset { f32x4 a[8]; f32x4 b[8]; f32x4 sc[2]; bool ok0, ok1; };
+        struct xset { f32x4 a[8]; f32x4 b[8]; f32x4 sc[2]; float ep0, ep1; bool ok0, ok1; };
 
         // Branch-free: every thread issues the same 16 (+2) loads per chunk -- out-of-image positions load from a clamped address and are zeroed
         // when they are written to LDS -- so that the compiler can count them (`s_waitcnt vmcnt(16)` before the previous set is consumed)
@@ -134,15 +134,29 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.sc[0]) : "v"(sp) : "memory");
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.sc[1]) : "v"(sp + 4) : "memory");
             }
+            if (EPI >= 1) {
+                // the tile's output scale and bias (consumed by put_ep with the tile's LAST chunk) travel with every chunk's set as two more counted
+                // loads: as plain C++ loads inside put_ep the compiler put `s_waitcnt vmcnt(0)` in front of their use, which drained the chunk
+                // prefetch queue once per tile (64-channel layers: 4 chunks per tile)
+                const int m = tp.mt * TM + (pt & (TM - 1));
+                const float* po = pp.oscale ? pp.oscale + (size_t)tp.n * p.m + m : p.x;
+                const float* pb = pp.bias ? pp.bias + m : p.x;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(r.ep0) : "v"(po) : "memory");
+                asm volatile("global_load_dword %0, %1, off" : "=v"(r.ep1) : "v"(pb) : "memory");
+            }
         };
         // everything issued before the `newer` most recent loads has landed; re-define the set's registers after the wait so that no use can be
         // scheduled above it
         auto arrive = [&](xset& r, bool newer) {
-            if (newer) { if (PRO == 1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (newer) {   // loads per set: 16 + 2 (PRO) + 2 (EPI)
+                if (PRO == 1 && EPI >= 1) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+                else if (PRO == 1 || EPI >= 1) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 8; j++) { asm volatile("" : "+v"(r.a[j])); asm volatile("" : "+v"(r.b[j])); }
             if (PRO == 1) { asm volatile("" : "+v"(r.sc[0])); asm volatile("" : "+v"(r.sc[1])); }
+            if (EPI >= 1) { asm volatile("" : "+v"(r.ep0)); asm volatile("" : "+v"(r.ep1)); }
         };
         auto put = [&](u32x4* xs, int pos, float* v, const xset& r, bool ok) {
 #pragma unroll
@@ -179,13 +193,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 put(xs, (oct * RIN + h_row) * PIN + (h_side ? SEG + 1 : 0), v, r, r.ok1);
             }
         };
-        auto put_ep = [&](int q, u32x4* img) {   // the tile's epilogue vectors ride with its LAST chunk
+        auto put_ep = [&](int q, u32x4* img, const xset& r) {   // the tile's epilogue vectors ride with its LAST chunk (r: that chunk's set)
             if (EPI == 0 || (q % chunks) != chunks - 1 || pt >= TM) return;
-            const tile_pos tp = decode_tile(p, first + (q / chunks) * p.grid, TROWS);
             float* ep = (float*)(img + XS_WORDS + WS_WORDS);
-            const int m = tp.mt * TM + pt;
-            const float c0 = (pp.oscale ? pp.oscale[(size_t)tp.n * p.m + m] : 1.f) * pp.gain;
-            const float c1 = (pp.bias ? pp.bias[m] : 0.f) * pp.gain;
+            const float c0 = (pp.oscale ? r.ep0 : 1.f) * pp.gain;
+            const float c1 = (pp.bias ? r.ep1 : 0.f) * pp.gain;
             const float al = pp.act == 3 ? pp.alpha : 1.f;
             ep[pt] = c0;
             ep[TM + pt] = c1;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 u32x4* img = lds + ((q + 1) & 1) * WS_IMAGE_WORDS;    // last read by the consumers in iteration q-1, i.e. before the previous barrier
                 arrive(st, more);
                 store_x(img, st);
-                put_ep(q + 1, img);
+                put_ep(q + 1, img, st);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the LDS writes; the loads just issued stay in flight across the barrier
             __builtin_amdgcn_s_barrier();
@@ -211,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         if (total > 1) load_x(1, s1);
         arrive(s0, total > 1);
         store_x(lds, s0);
-        put_ep(0, lds);
+        put_ep(0, lds, s0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // image 0 ready
         for (int q = 0; q < total; q += 2) {

@@ -35,7 +35,8 @@ constexpr int WS_DS = 2 * 3 * WS_DBUF;           // [hl][3 buffers][64][RS]
 constexpr int wrw_ws_lds_bytes(int views) { return (2 * 4 * views * WS_VIEW + WS_DS) * 2; }
 constexpr int WRW_WS_LDS_BYTES = wrw_ws_lds_bytes(3);
 
-// ABL (tools/wrw_lab.hip only; wrong results by construction): 6 consumers only keep the barrier protocol, 7 producers only keep it, 8 no final flush.
+// ABL (tools/wrw_lab.hip only; wrong results by construction): 6 consumers only keep the barrier protocol, 7 producers only keep it, 8 no final flush,
+// 10 producers without the split arithmetic, 11 producers without global loads; 12 = 6 + 10; 13 = 6 with opaque register values instead of loads.
 //
 // PACK: images 16 or 8 pixels wide (the < 32^2 layers): 2 or 4 samples sit side by side in the 32-pixel row step, a unit is (group of 32 / W
 // samples, row block).  The producers take every 8-pixel group from its own sample (left / right neighbours outside the sample's row are zero),
@@ -80,14 +81,17 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             int n = u / (rblocks * segs);
             x0 = sg * SEG;
             if (PACK) { n = n * spr + lq / p.w; smp_ok = n < p.n; n = min(n, p.n - 1); }
-            if (p.xscale) xsc = p.xscale[(size_t)n * p.i + i0 + lr];
+            // inline asm like the row loads: a load the COMPILER tracks makes it put `s_waitcnt vmcnt(0)` in front of the first use of xsc in every
+            // step, which drains the whole prefetch queue (measured: producers alone 1.0 ms with it, see the lab log); waited for with the prologue rows
+            if (p.xscale) asm volatile("global_load_dword %0, %1, off" : "=v"(xsc) : "v"(p.xscale + (size_t)n * p.i + i0 + lr) : "memory");
             xb = p.x + ((size_t)n * p.i + i0 + lr) * plane + x0 + pxs;
             dyb = p.dy + ((size_t)n * p.o + o0 + lr) * plane + x0 + pxs;
             return rb * R;
         };
         // branch-free: out-of-image rows / columns load from a clamped address and are zeroed when they are written to LDS
         auto load_x = [&](int row, xrow& r) {
-            if (ABL == 7) return;
+            if (ABL == 7 || ABL == 11) return;
+            if (ABL == 13) { r.ok = true; r.okl = r.okr = true; asm volatile("" : "=v"(r.a), "=v"(r.b), "=v"(r.l), "=v"(r.r)); return; }   // opaque values instead of loads
             r.ok = row >= 0 && row < p.h;
             r.okl = r.ok && x0 + pxs - 1 >= 0;
             r.okr = r.ok && x0 + pxs + 8 < p.w;
@@ -98,7 +102,8 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             asm volatile("global_load_dword %0, %1, off" : "=v"(r.r) : "v"(q + (r.okr ? 8 : 7)) : "memory");
         };
         auto load_dy = [&](int row, drow& r) {   // row is always inside the unit
-            if (ABL == 7) return;
+            if (ABL == 7 || ABL == 11) return;
+            if (ABL == 13) { asm volatile("" : "=v"(r.a), "=v"(r.b)); return; }
             const float* q = dyb + (size_t)row * p.w;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a) : "v"(q) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b) : "v"(q + 4) : "memory");
@@ -112,6 +117,13 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         };
         auto store_x = [&](int row, const xrow& r) {
             if (ABL == 7) return;
+            if (ABL == 10 || ABL == 12) {   // no split arithmetic: raw register bits go to LDS
+                const int slot = (row + 1) & 3;
+                unsigned short* dst = xs + (size_t)slot * WS_XSLOT + lr * RS + XO + lq;
+                *(u32x4*)dst = __builtin_bit_cast(u32x4, r.a);
+                if (TERMS > 1) *(u32x4*)(dst + 4 * WS_XSLOT) = __builtin_bit_cast(u32x4, r.b);
+                return;
+            }
             float v[10];
             v[0] = r.okl ? r.l * xsc : 0.f;
             v[9] = r.okr ? r.r * xsc : 0.f;
@@ -145,6 +157,11 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         };
         auto store_dy = [&](int buf, const drow& r) {
             if (ABL == 7) return;
+            if (ABL == 10 || ABL == 12) {
+                *(u32x4*)(ds + (size_t)buf * WS_DBUF + lr * RS + lq) = __builtin_bit_cast(u32x4, r.a);
+                if (TERMS > 1) *(u32x4*)(ds + (size_t)(3 + buf) * WS_DBUF + lr * RS + lq) = __builtin_bit_cast(u32x4, r.b);
+                return;
+            }
             float v[8];
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = (!PACK || smp_ok) ? r.a[k] : 0.f; v[4 + k] = (!PACK || smp_ok) ? r.b[k] : 0.f; }
@@ -154,8 +171,17 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             if (TERMS > 1) *(u32x4*)(ds + (size_t)(3 + buf) * WS_DBUF + lr * RS + lq) = lo;
         };
 
-        xrow px0, px1, px2, sx0, sx1;     // prologue rows y0-1, y0, y0+1; step sets
-        drow pd0, pd1, sd0, sd1;          // prologue dy rows y0, y0+1; step sets
+        // Item j of a unit = {x row y0+j+2, dy row y0+j+2}: what step j writes to LDS (x for step j+1's ky = 2, dy for step j+2: dy runs two rows
+        // ahead).  Its loads are issued DEPTH steps earlier and land in one of DEPTH + 1 register sets: with one step of lookahead the producers
+        // alone needed 1.03-1.24 ms per layer for data the consumers use up in 0.69-0.76 ms (tools/wrw_lab.hip WRW_ABL=6 / 7; without the global
+        // loads the whole kernel runs in 0.77 ms): 17 KB in flight per CU against 2-3 us of loaded-memory latency.  Every item issues the same six
+        // loads (the dy row of the last item repeats the unit's last row) so that the wait counts are constants.
+        constexpr int DEPTH = 3;
+        struct iset { xrow x; drow d; };
+        iset s0, s1, s2, s3;
+        // prologue rows (x y0-1, y0, y0+1; dy y0, y0+1) of the NEXT unit are loaded during a unit's last step, when every set is idle
+        xrow &px0 = s0.x, &px1 = s1.x, &px2 = s2.x;
+        drow &pd0 = s0.d, &pd1 = s1.d;
         int db = 0;                        // dy buffer of the unit's first row (advances by one per row, mod 3)
         auto issue_prologue = [&](int u) {
             const int y0 = set_unit(u);
@@ -164,19 +190,19 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             if (R > 1) load_dy(y0 + 1, pd1);
             return y0;
         };
-        // step k of a unit (row y = y0 + k): start the loads of x row y+3 / dy row y+3 into `ld`, then write x row y+2 / dy row y+2 from `st`
-        auto step = [&](int y0, int k, xrow& ldx, drow& ldd, xrow& stx, drow& std_, int next_u) {
-            const int y = y0 + k;
-            // during step k: x row y+2 (step k+1's ky = 2) and dy row y+2 (step k+2's: dy runs two rows ahead) go to LDS; their loads were
-            // issued during step k-1.  First start the loads of step k+1's writes.
-            const bool issue = k + 2 < R;
-            if (issue) { load_x(y + 3, ldx); if (k + 3 < R) load_dy(y + 3, ldd); }
+        auto load_item = [&](int y0, int j, iset& s) { load_x(y0 + j + 2, s.x); load_dy(y0 + min(j + 2, R - 1), s.d); };
+        // step k of a unit (row y = y0 + k): start the loads of item k + DEPTH into `ld`, then write item k from `st`
+        auto step = [&](int y0, int k, iset& ld, iset& st, int next_u) {
+            if (k + DEPTH <= R - 2) load_item(y0, k + DEPTH, ld);
             if (k + 1 < R) {
-                if (issue) { if (k + 3 < R) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
+                const int after = min(DEPTH, R - 2 - k);     // items issued after item k
+                if (after >= 3) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+                else if (after == 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+                else if (after == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                touch_x(stx);
-                store_x(y + 2, stx);
-                if (k + 2 < R) { touch_d(std_); store_dy((db + k + 2) % 3, std_); }
+                touch_x(st.x); touch_d(st.d);
+                store_x(y0 + k + 2, st.x);
+                if (k + 2 < R) store_dy((db + k + 2) % 3, st.d);
             }
             if (k == R - 1 && next_u < p.units) issue_prologue(next_u);   // lands during the consumers' last row of this unit
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -189,18 +215,23 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             const int y0 = set_unit(u);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prologue rows (issued during the previous unit's last step)
             touch_x(px0); touch_x(px1); touch_x(px2); touch_d(pd0); touch_d(pd1);
+            asm volatile("" : "+v"(xsc));
             __builtin_amdgcn_s_barrier();                              // A: the consumers are done with the previous unit
             store_x(y0 - 1, px0); store_x(y0, px1); store_x(y0 + 1, px2);
             store_dy(db % 3, pd0);
             if (R > 1) store_dy((db + 1) % 3, pd1);
-            // the sets of step 0: x row y0+2, dy row y0+2
-            if (R > 1) { load_x(y0 + 2, sx0); if (R > 2) load_dy(y0 + 2, sd0); }
+            // items 0 .. DEPTH-1
+            if (0 <= R - 2) load_item(y0, 0, s0);
+            if (1 <= R - 2) load_item(y0, 1, s1);
+            if (2 <= R - 2) load_item(y0, 2, s2);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                              // B: rows y0-1 .. y0+1 and dy y0, y0+1 are in LDS
             const int next_u = u + p.splits;
-            for (int k = 0; k < R; k += 2) {
-                step(y0, k, sx1, sd1, sx0, sd0, next_u);
-                if (k + 1 < R) step(y0, k + 1, sx0, sd0, sx1, sd1, next_u);
+            for (int k = 0; k < R; k += 4) {
+                step(y0, k, s3, s0, next_u);
+                if (k + 1 < R) step(y0, k + 1, s0, s1, next_u);
+                if (k + 2 < R) step(y0, k + 2, s1, s2, next_u);
+                if (k + 3 < R) step(y0, k + 3, s2, s3, next_u);
             }
             db = (db + R) % 3;
         }
@@ -285,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             // six sub-steps j = (c, ky): operands of sub-step j+1 are fetched before the nine MFMAs of sub-step j; the last one fetches the
             // first operands of row y+1 (dy row y+1 and x row y have been in LDS since before the previous barrier)
 #pragma unroll
-            for (int j = 0; j < (ABL == 6 ? 0 : 6); j++) {
+            for (int j = 0; j < ((ABL == 6 || ABL == 12 || ABL == 13) ? 0 : 6); j++) {
                 const int c = j / 3, ky = j % 3;
                 const int cur = j & 1, nxt = cur ^ 1;
                 int reads = RB;
