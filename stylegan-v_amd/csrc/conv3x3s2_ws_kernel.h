@@ -273,7 +273,8 @@ constexpr int P2_WS_WORDS = 2 * 5 * 2 * P2_TM;            // [hl][pair][tap in p
 // S = samples per 32-pixel tile row: 1 (W % 32 == 0: a 32-px segment of one sample) or 2 / 4 (W = 16 / 8: whole rows of S consecutive samples side
 // by side).  A parity plane row holds S x (W + 1) = 32 + S words (sample s at s * (W + 1); the odd plane leaves one word per sample unused).
 constexpr int p2_pw(int s) { return 32 + s; }
-constexpr int p2_image_words(int s) { return 2 * P2_RIN * 2 * p2_pw(s) + P2_WS_WORDS; }
+constexpr int P2_EP_WORDS = P2_TM / 4;                      // the tile's 128 bias values (EPI = 1), behind the weights of the tile's last chunk
+constexpr int p2_image_words(int s) { return 2 * P2_RIN * 2 * p2_pw(s) + P2_WS_WORDS + P2_EP_WORDS; }
 constexpr int p2_lds_bytes(int s) { return 2 * p2_image_words(s) * 16; }
 constexpr int P2_LDS_BYTES = p2_lds_bytes(1);
 
@@ -354,6 +355,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             for (int j = 0; j < P2_WS_WORDS / 64; j++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wq + j * 64),
                                                  (__attribute__((address_space(3))) void*)(wl + j * 64), 16, 0, 0);
+            // EPI = 1: the tile's bias vector rides with its last chunk (read from LDS by the consumers' epilogue: as global loads there they cost the
+            // consumer wave a full memory latency per tile -- and, loads and stores sharing vmcnt on gfx9, the drain of the previous tile's stores)
+            if (EPI == 1 && ep.bias && (q % chunks) == chunks - 1 && lane < P2_EP_WORDS)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const u32x4*)(ep.bias + tp.mt * P2_TM) + lane),
+                                                 (__attribute__((address_space(3))) void*)(wl + P2_WS_WORDS), 16, 0, 0);
         };
         if (ABL != 7) dma_w(0, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -529,15 +535,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             const float al = ep.act == 3 ? ep.alpha : 1.f;
             const float g0 = ep.gain, g1 = ep.gain * al;
             const float clamp_hi = ep.clamp >= 0.f ? ep.clamp : __builtin_inff();
-            // all sixteen bias vectors of the tile first: on gfx9 loads and stores share vmcnt, so a load issued behind stores is not usable
-            // before those stores have drained
+            // all sixteen bias vectors of the tile first (from the LDS copy the DMA wave made with this chunk's weights)
+            const float* bias_lds = (const float*)(ws + P2_WS_WORDS);
             f32x4 bvs[4][4];
 #pragma unroll
             for (int mq = 0; mq < 4; mq++)
 #pragma unroll
                 for (int e4 = 0; e4 < 4; e4++) {
                     bvs[mq][e4] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (EPI == 1 && ep.bias) bvs[mq][e4] = *(const f32x4*)(ep.bias + tp.mt * P2_TM + mq * 32 + 8 * e4 + 4 * ge);
+                    if (EPI == 1 && ep.bias) bvs[mq][e4] = *(const f32x4*)(bias_lds + mq * 32 + 8 * e4 + 4 * ge);
                 }
 #pragma unroll
             for (int mq = 0; mq < 4; mq++)

@@ -36,7 +36,7 @@ constexpr int wrw_ws_lds_bytes(int views) { return (2 * 4 * views * WS_VIEW + WS
 constexpr int WRW_WS_LDS_BYTES = wrw_ws_lds_bytes(3);
 
 // ABL (tools/wrw_lab.hip only; wrong results by construction): 6 consumers only keep the barrier protocol, 7 producers only keep it, 8 no final flush,
-// 10 producers without the split arithmetic, 11 producers without global loads; 12 = 6 + 10; 13 = 6 with opaque register values instead of loads.
+// 10 producers without the split arithmetic, 11 producers without global loads; 12 = 6 + 10; 13 = 6 with opaque register values instead of loads, 14 = the full kernel with them.
 //
 // PACK: images 16 or 8 pixels wide (the < 32^2 layers): 2 or 4 samples sit side by side in the 32-pixel row step, a unit is (group of 32 / W
 // samples, row block).  The producers take every 8-pixel group from its own sample (left / right neighbours outside the sample's row are zero),
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         // branch-free: out-of-image rows / columns load from a clamped address and are zeroed when they are written to LDS
         auto load_x = [&](int row, xrow& r) {
             if (ABL == 7 || ABL == 11) return;
-            if (ABL == 13) { r.ok = true; r.okl = r.okr = true; asm volatile("" : "=v"(r.a), "=v"(r.b), "=v"(r.l), "=v"(r.r)); return; }   // opaque values instead of loads
+            if (ABL == 13 || ABL == 14) { r.ok = true; r.okl = r.okr = true; asm volatile("" : "=v"(r.a), "=v"(r.b), "=v"(r.l), "=v"(r.r)); return; }   // opaque values instead of loads
             r.ok = row >= 0 && row < p.h;
             r.okl = r.ok && x0 + pxs - 1 >= 0;
             r.okr = r.ok && x0 + pxs + 8 < p.w;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         };
         auto load_dy = [&](int row, drow& r) {   // row is always inside the unit
             if (ABL == 7 || ABL == 11) return;
-            if (ABL == 13) { asm volatile("" : "=v"(r.a), "=v"(r.b)); return; }
+            if (ABL == 13 || ABL == 14) { asm volatile("" : "=v"(r.a), "=v"(r.b)); return; }
             const float* q = dyb + (size_t)row * p.w;
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a) : "v"(q) : "memory");
             asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b) : "v"(q + 4) : "memory");

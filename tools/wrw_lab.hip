@@ -65,7 +65,7 @@ template <int TERMS, int VIEWS, int ABL> static void launch_ws_abl(const wrw_par
 }
 template <int TERMS, int VIEWS> static void launch_ws(const wrw_params& p) {   // producer / consumer form (wrw_ws_kernel.h); WRW_ABL = 6 / 7: ablations
     static const int abl = getenv("WRW_ABL") ? atoi(getenv("WRW_ABL")) : 0;
-    if (abl == 6) launch_ws_abl<TERMS, VIEWS, 6>(p); else if (abl == 7) launch_ws_abl<TERMS, VIEWS, 7>(p); else if (abl == 8) launch_ws_abl<TERMS, VIEWS, 8>(p); else if (abl == 10) launch_ws_abl<TERMS, VIEWS, 10>(p); else if (abl == 11) launch_ws_abl<TERMS, VIEWS, 11>(p); else if (abl == 12) launch_ws_abl<TERMS, VIEWS, 12>(p); else if (abl == 13) launch_ws_abl<TERMS, VIEWS, 13>(p); else launch_ws_abl<TERMS, VIEWS, 0>(p);
+    if (abl == 6) launch_ws_abl<TERMS, VIEWS, 6>(p); else if (abl == 7) launch_ws_abl<TERMS, VIEWS, 7>(p); else if (abl == 8) launch_ws_abl<TERMS, VIEWS, 8>(p); else if (abl == 10) launch_ws_abl<TERMS, VIEWS, 10>(p); else if (abl == 11) launch_ws_abl<TERMS, VIEWS, 11>(p); else if (abl == 12) launch_ws_abl<TERMS, VIEWS, 12>(p); else if (abl == 13) launch_ws_abl<TERMS, VIEWS, 13>(p); else if (abl == 14) launch_ws_abl<TERMS, VIEWS, 14>(p); else launch_ws_abl<TERMS, VIEWS, 0>(p);
 }
 
 __global__ void naive_wrw_s2(const float* sm, const float* big, double* dw, int n, int cs, int cb, int h, int w) {
