@@ -299,6 +299,122 @@ __global__ __launch_bounds__(256) void k_cols4(P p, int colgroups, int strips) {
     }
 }
 
+// ---------------- V4: V3 with the row loads as inline asm and counted waits ----------------
+// hipcc puts `s_waitcnt vmcnt(0)` directly behind the row load of V3 / of the product kernel (the loaded value is merged with the zero row through a
+// select inside the same conditional block), so no load is in flight while the previous rows are filtered: only occupancy hides the memory
+// latency.  Here every row issues exactly two loads (main 16 B + halo dword; out-of-range rows load a clamped row and are zeroed on use) and
+// the wait in front of a row group's use counts the VMEM instructions issued behind its loads (the next group's loads are issued BEFORE the wait:
+// two groups in flight).  Requires whole-vector stores in every lane (out_w % 4 == 0) and in_w >= 4.
+template <int PF>
+__global__ __launch_bounds__(256) void k_cols4_asm(P p, int colgroups, int strips, int getenv_drain) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = wave % strips;
+    const int cg = (wave / strips) % colgroups;
+    const int pl = wave / (strips * colgroups);
+    if (pl >= p.planes) return;
+    float ff[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) ff[a][b] = p.f[(3 - a) * 4 + (3 - b)];
+    const float* xp = p.x + (size_t)pl * p.in_h * p.in_w;
+    float* yp = p.y + (size_t)pl * p.out_h * p.out_w;
+    const int ox = cg * 256 + lane * 4;
+    const int ix0 = ox - p.pad;
+    const int base = min(max(ix0, 0), p.in_w - 4);
+    const int sh = base - ix0;
+    const bool lane_dead = (ix0 >= p.in_w) || (ix0 + 3 < 0);
+    const int ixh = cg * 256 + 256 - p.pad + lane;
+    const bool halo_ok = lane < 3 && ixh >= 0 && ixh < p.in_w;
+    const int ixh_c = min(max(ixh, 0), p.in_w - 1);
+    const int oy_a = strip * p.strip_h, oy_b = min(oy_a + p.strip_h, p.out_h);
+    const int iy0 = oy_a - p.pad;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    struct raw { f4v m; float h; };
+    auto issue = [&](int iy, raw& r) {   // always two loads
+        const float* row = xp + (size_t)min(max(iy, 0), p.in_h - 1) * p.in_w;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.m) : "v"(row + base) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.h) : "v"(row + ixh_c) : "memory");
+    };
+    auto expand = [&](int iy, raw& r, float* dst) {
+        asm volatile("" : "+v"(r.m)); asm volatile("" : "+v"(r.h));
+        const bool row_ok = iy >= 0 && iy < p.in_h;
+        float m[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float v = r.m[i];
+#pragma unroll
+            for (int d = 1; d <= 3; d++) {
+                if (i - d >= 0) v = (sh == d) ? r.m[i - d] : v; else v = (sh == d) ? 0.f : v;
+                if (i + d < 4) v = (sh == -d) ? r.m[i + d] : v; else v = (sh == -d) ? 0.f : v;
+            }
+            m[i] = (row_ok && !lane_dead) ? v : 0.f;
+        }
+        const float hv = (row_ok && halo_ok) ? r.h : 0.f;
+        float h0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), 0));
+        float h1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), 1));
+        float h2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, hv), 2));
+        dst[0] = m[0]; dst[1] = m[1]; dst[2] = m[2]; dst[3] = m[3];
+        dst[4] = wave_shl1(m[0], h0);
+        dst[5] = wave_shl1(m[1], h1);
+        dst[6] = wave_shl1(m[2], h2);
+    };
+    float win[4][7];
+    // Two register sets used alternately and never copied: the compiler believes an asm load's result is there at once, so nothing may read, move
+    // or re-allocate these registers between the load and the `touch` behind the counted wait (expand() starts with it).
+    raw pr[3], sa[PF], sb[PF];
+#pragma unroll
+    for (int r = 0; r < 3; r++) issue(iy0 + r, pr[r]);
+    int iy = iy0 + 3;
+#pragma unroll
+    for (int k = 0; k < PF; k++) issue(iy + k, sa[k]);
+    if (PF == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else if (PF == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if (PF == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 3; r++) expand(iy0 + r, pr[r], win[1 + r]);
+    auto group = [&](int oy, raw* cur, raw* nxt) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) issue(iy + PF + k, nxt[k]);   // the group after this one
+        // Newer than this group's loads: the previous group's PF stores and the 2 PF loads just issued.  Loads complete in order among themselves, but
+        // a store can be acknowledged before an older load has returned (waiting for <= 3 PF outstanding gave wrong results: 2-8 M mismatches), so
+        // the only safe count is the number of newer LOADS -- which also makes the wave wait for the previous group's stores.
+        if (getenv_drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (PF == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else if (PF == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (PF == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int i = 0; i < 7; i++) win[r][i] = win[r + 1][i];
+            expand(iy + k, cur[k], win[3]);
+            float o[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[j][v + i], ff[j][i], acc);
+                o[v] = acc * p.gain;
+            }
+            float* yr = yp + (size_t)(oy + k) * p.out_w + ox;
+            f4v sv; sv[0] = o[0]; sv[1] = o[1]; sv[2] = o[2]; sv[3] = o[3];
+            // s_nop: a store of more than 64 bits reads its data registers a few cycles AFTER issue; the compiler's hazard recogniser inserts the wait
+            // states for its own stores but cannot see into inline asm (without it the next address computation landed in the data registers:
+            // 15 wrong outputs per row group)
+            asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 2" :: "v"(yr), "v"(sv) : "memory");
+        }
+        iy += PF;
+    };
+    for (int oy = oy_a; oy < oy_b; oy += 2 * PF) {     // strip heights are multiples of 2 PF
+        group(oy, sa, sb);
+        group(oy + PF, sb, sa);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 int main(int argc, char** argv) {
     int N = argc > 1 ? atoi(argv[1]) : 32;
     int C = 64, IH = argc > 2 ? atoi(argv[2]) : 257, IW = IH, pad = argc > 3 ? atoi(argv[3]) : 1;
@@ -330,7 +446,11 @@ int main(int argc, char** argv) {
         if (check) {
             CK(hipMemcpy(hy.data(), y, ny * 4, hipMemcpyDeviceToHost));
             size_t bad = 0; for (size_t i = 0; i < ny; i++) if (!(hy[i] == href[i])) bad++;
-            if (bad) printf("  !! %s: %zu mismatches\n", name, bad);
+            if (bad) {
+                printf("  !! %s: %zu mismatches\n", name, bad);
+                int shown = 0;
+                for (size_t i = 0; i < ny && shown < 24; i++) if (!(hy[i] == href[i])) { printf("     plane %zu row %zu col %zu: got %g want %g\n", i / ((size_t)OH * OW), (i / OW) % OH, i % OW, hy[i], href[i]); shown++; }
+            }
         }
         float best = 1e9, tot = 0; int reps = 12;
         for (int r = 0; r < reps; r++) {
@@ -362,6 +482,11 @@ int main(int argc, char** argv) {
 #define RUN4(PFV, NTV) { std::string nm = std::string("V3 cols dwordx4 PF") + #PFV + " NT" + #NTV + " strip " + std::to_string(sh); \
           bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q4; r.x = xi; r.y = yo; hipLaunchKernelGGL((k_cols4<PFV, NTV>), dim3((unsigned)((waves4 + 3) / 4)), dim3(256), 0, 0, r, cgs4, strips4); }, true); }
         RUN4(1, 1) RUN4(2, 1) RUN4(4, 1)
+        if (OW % 4 == 0 && OH % sh == 0) {   // (and sh % 8 == 0)
+#define RUN5(PFV) { std::string nm = std::string("V4 asm loads, counted waits PF") + #PFV + " strip " + std::to_string(sh); \
+          bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q4; r.x = xi; r.y = yo; hipLaunchKernelGGL((k_cols4_asm<PFV>), dim3((unsigned)((waves4 + 3) / 4)), dim3(256), 0, 0, r, cgs4, strips4, getenv("UFD_DRAIN") ? 1 : 0); }, true); }
+        RUN5(1) RUN5(2) RUN5(4) if (sh % 16 == 0) RUN5(8)
+        }
 #define RUN4A(PFV, NTV, AB) { std::string nm = std::string("V3 ablation ") + #AB + " PF" + #PFV + " NT" + #NTV + " strip " + std::to_string(sh); \
           bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q4; r.x = xi; r.y = yo; hipLaunchKernelGGL((k_cols4<PFV, NTV, AB>), dim3((unsigned)((waves4 + 3) / 4)), dim3(256), 0, 0, r, cgs4, strips4); }, false); }
         RUN4A(4, 1, 1) RUN4A(4, 1, 2) RUN4A(1, 1, 2) RUN4A(4, 2, 2)
