@@ -15,8 +15,10 @@ every 16th, each followed by nan_to_num + Adam, then the G_ema update.  Per-GPU 
 (weak scaling): `--batch-gpu` videos x 3 frames per rank; DDP all-reduces G/D gradients over RCCL.
 
 The single JSON line carries, besides the contract fields:
-  roofline      the dominant hand-written kernel family of the step (largest summed time; the 3x3 convolution kernels): algorithmic flops (or bytes) /
-                HIP-event time summed over every launch inside the timed steps (events recorded by the C ABI on the launch stream)
+  roofline      the step's dominant hand-written kernel (largest summed time: conv3x3_ws_kernel, the stride-1 3x3 convolution): algorithmic flops /
+                HIP-event time summed over its launches inside the second half of the timed steps (events recorded by the C ABI on the launch stream;
+                on every step they cost 2.5-4 % of the step, profiles/r02_bench_prof_overhead.log)
+  roofline_conv_family  the same over the whole 3x3 convolution family (what earlier rounds' lines reported under `roofline`)
   roofline_upfirdn2d  the same for the upfirdn2d lane-exchange kernel against the HBM roofline (second half of BASELINE.json's metric)
   kernels       the same accounting for every native kernel family
   cpu_baseline  the same training step on the host CPU through the plain-PyTorch op path (a restatement
@@ -204,12 +206,17 @@ def main():
             with open(os.environ['SGV_TORCH_PROFILE'], 'w') as fh:
                 fh.write(prof_t.key_averages(group_by_input_shape=True).table(sort_by='cuda_time_total', row_limit=120, max_name_column_width=60, max_shapes_column_width=90))
         ts.batch_idx = 0
-    if not args.no_prof:
-        custom_ops.prof_enable(1 << 17)
+    # Per-launch HIP events (two event packets around every native launch, ~2,500 launches per step) cost 2.5-4 % of the step when they are
+    # recorded on every step (same box: 549-559 img/s with, 572-574 without; profiles/r02_bench_prof_overhead.log).  They are therefore recorded on
+    # the SECOND HALF of the timed steps only: with the default 20 steps that is steps 10-19, which hold one R1 iteration in ten like the whole
+    # window (steps 0 and 16), so the kernel mix of the sample is the mix of the window.  `value` is still the wall time of all K steps.
+    prof_from = args.steps // 2
     barrier()
     t0 = time.perf_counter()
     phases_run = {}
-    for _ in range(args.steps):
+    for i_step in range(args.steps):
+        if not args.no_prof and i_step == prof_from:
+            custom_ops.prof_enable(1 << 17)
         for name in ts.step():
             phases_run[name] = phases_run.get(name, 0) + 1
     barrier()
@@ -311,6 +318,7 @@ def main():
         kernels = {}
         roofline = None
         roofline_ufd = None
+        roofline_family = None
         if prof is not None:
             for name, e in prof.items():
                 if e['launches'] == 0:
@@ -329,22 +337,31 @@ def main():
                                     frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch()[0], launches=r['launches'],
                                     traffic_source=pmc_traffic_per_launch()[1] + ' (reads x2, gfx950 correction)',
                                     avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
-                                    note='all launches inside the timed steps (every layer size, fwd+bwd+double-bwd), size-weighted')
-            # The contract's `roofline` is the dominant hand-written kernel family of the step (largest summed HIP-event time).
-            dom = max((n for n in prof if prof[n]['launches']), key=lambda n: prof[n]['ms'], default=None)
-            if dom in ('conv3x3', 'conv_wrw'):
-                e = prof[dom]
-                terms = conv2d_gradfix.native_conv_terms if dom == 'conv3x3' else conv2d_gradfix.native_wrw_terms
+                                    note=f'all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1}; every layer size, fwd+bwd+double-bwd), size-weighted')
+            # The contract's `roofline` is the step's dominant hand-written kernel (largest summed HIP-event time): the stride-1 producer / consumer
+            # 3x3 kernel, accounted on its own (SGV_K_CONV3X3_S1); `roofline_conv_family` keeps the figure of the whole 3x3 family that earlier rounds'
+            # lines reported under `roofline` (stride 1 + stride 2 + transposed + 16^2 / 8^2 + edge-strip members, flop-weighted).
+            def mfma_roofline(e, terms, kernel, traffic):
                 achieved = e['flops'] / (e['ms'] * 1e-3) / 1e12
                 peak = MFMA_BF16_PEAK_TFLOPS / terms
-                roofline = dict(kernel={'conv3x3': 'conv3x3_ws_kernel / conv3x3_s2_pairs_kernel / convT3x3_s2_ws_kernel (+ 16x16 / 8x8 and edge-strip members)', 'conv_wrw': 'wrw3x3_ws_kernel / wrw3x3_s2_kernel'}[dom], bound='mfma',
-                                achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=pmc_traffic_conv_family()[0] if dom == 'conv3x3' else pmc_traffic(('wrw3x3',))[0],
-                                traffic_source=(pmc_traffic_conv_family()[1] if dom == 'conv3x3' else pmc_traffic(('wrw3x3',))[1]) + ' (L2-miss bytes: Infinity-Cache hits included)',
-                                algorithmic_bytes_per_launch=e['bytes'] / e['launches'], launches=e['launches'],
-                                avg_launch_us=1e3 * e['ms'] / e['launches'], algorithmic_flops_per_launch=e['flops'] / e['launches'],
-                                executed_bf16_TFLOPs=achieved * terms, bf16_dense_peak_TFLOPs=MFMA_BF16_PEAK_TFLOPS, fp32_mfma_peak_TFLOPs=157.3,
-                                note=f'algorithmic flops = 2*N*H*W*Cin*Cout*9 (fp32-equivalent); the kernel issues {terms} bf16 MFMAs per product (hi/lo split, fp32 accumulate), '
-                                     f'so its ceiling is the bf16 dense peak / {terms}; all launches of the family inside the timed steps, flop-weighted')
+                return dict(kernel=kernel, bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=traffic[0],
+                            traffic_source=traffic[1] + ' (L2-miss bytes: Infinity-Cache hits included)',
+                            algorithmic_bytes_per_launch=e['bytes'] / e['launches'], launches=e['launches'],
+                            avg_launch_us=1e3 * e['ms'] / e['launches'], algorithmic_flops_per_launch=e['flops'] / e['launches'],
+                            executed_bf16_TFLOPs=achieved * terms, bf16_dense_peak_TFLOPs=MFMA_BF16_PEAK_TFLOPS, fp32_mfma_peak_TFLOPs=157.3,
+                            note=f'algorithmic flops = 2*N*H*W*Cin*Cout*9 (fp32-equivalent); the kernel issues {terms} bf16 MFMAs per product (hi/lo split, fp32 accumulate), '
+                                 f'so its ceiling is the bf16 dense peak / {terms}; all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1}), flop-weighted')
+            roofline_family = None
+            if prof['conv3x3']['launches']:
+                roofline_family = mfma_roofline(prof['conv3x3'], conv2d_gradfix.native_conv_terms,
+                                                'conv3x3_ws_kernel / conv3x3_s2_pairs_kernel / convT3x3_s2_ws_kernel (+ 16x16 / 8x8 and edge-strip members)', pmc_traffic_conv_family())
+            singles = {n: e for n, e in prof.items() if e['launches'] and n != 'conv3x3'}     # 'conv3x3' is a sum that contains 'conv3x3_s1'
+            dom = max(singles, key=lambda n: singles[n]['ms'], default=None)
+            if dom == 'conv3x3_s1':
+                roofline = mfma_roofline(prof[dom], conv2d_gradfix.native_conv_terms, 'conv3x3_ws_kernel (stride 1, forward and data gradient, incl. the variants with the layer tail in the store)',
+                                         pmc_traffic(('conv3x3_ws_kernel',)))
+            elif dom == 'conv_wrw':
+                roofline = mfma_roofline(prof[dom], conv2d_gradfix.native_wrw_terms, 'wrw3x3_ws_kernel / wrw3x3_s2_ws_kernel', pmc_traffic(('wrw3x3',)))
             elif dom == 'gemm':
                 e = prof[dom]
                 achieved = e['flops'] / (e['ms'] * 1e-3) / 1e12
@@ -368,7 +385,7 @@ def main():
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
                                native_launches_per_step=launches / args.steps, hip_graphs=bool(ts.use_graphs)),
                    value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c,
-                   roofline=roofline, roofline_upfirdn2d=roofline_ufd, kernels=kernels, cpu_baseline=cpu)
+                   roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -424,8 +424,9 @@ enum sgv_kernel_family {
     SGV_K_UPFIRDN2D_LANES = 6,
     SGV_K_POINTWISE = 7,
     SGV_K_CONV_WRW = 8,
-    SGV_K_CONV3X3 = 9,
-    SGV_K_COUNT = 10
+    SGV_K_CONV3X3 = 9,          /* every 3x3 convolution launch except the >= 32 pixel stride-1 kernel */
+    SGV_K_CONV3X3_S1 = 10,      /* conv3x3_ws_kernel (stride 1, forward and data gradient, images >= 32 pixels): the step's dominant kernel */
+    SGV_K_COUNT = 11
 };
 typedef struct sgv_prof_entry {
     int64_t launches;

@@ -140,7 +140,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * (p->c_out / TM);
     kp.grid = std::min(kp.tiles, g_cus);
     const double elems = (double)p->n * p->h * p->w;
-    sgv_launch_scope scope(SGV_K_CONV3X3, stream, 4.0 * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9);
+    sgv_launch_scope scope(small ? SGV_K_CONV3X3 : SGV_K_CONV3X3_S1, stream, 4.0 * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9);
     if (small) {
         if (p->w == 16) {
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);

@@ -157,7 +157,7 @@ def native_loaded():
 c_void_p, c_int, c_int32, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 SGV_F32, SGV_F16, SGV_BF16, SGV_F64 = 0, 1, 2, 3
-SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw', 'conv3x3']
+SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw', 'conv3x3', 'conv3x3_s1']
 
 
 class Upfirdn2dParams(ctypes.Structure):
@@ -349,5 +349,10 @@ def prof_disable():
 def prof_collect():
     entries = (ProfEntry * len(SGV_K_NAMES))()
     check(get_native().sgv_prof_collect(entries))
-    return {name: dict(launches=int(e.launches), ms=float(e.ms), bytes=float(e.bytes), flops=float(e.flops))
-            for name, e in zip(SGV_K_NAMES, entries)}
+    out = {name: dict(launches=int(e.launches), ms=float(e.ms), bytes=float(e.bytes), flops=float(e.flops))
+           for name, e in zip(SGV_K_NAMES, entries)}
+    # 'conv3x3' stays the whole 3x3 convolution family (forward / data gradient of every stride and size); 'conv3x3_s1' is its largest member
+    # on its own (conv3x3_ws_kernel, the stride-1 producer / consumer kernel on images >= 32 pixels)
+    for key in ('launches', 'ms', 'bytes', 'flops'):
+        out['conv3x3'][key] += out['conv3x3_s1'][key]
+    return out
