@@ -217,7 +217,9 @@ int sgv_pointwise_outer_act(const void* a_few, const void* dy_many, const void* 
  *   dw[o,i,ky,kx] = sum_{n,y,x} dy[n,o,y,x] * x[n,i,y+ky-1,x+kx-1]          dw: [c_out, c_in, 3, 3] fp32 (overwritten)
  * terms = 3: fp32 emulated on the bf16 matrix pipe with hi/lo splitting (bf16x3, ~2^-17 relative per product, fp32
  * accumulation); terms = 1: plain bf16 products.  sgv_conv3x3_wrw_supported() tells whether a shape/dtype is served
- * (fp32, channels % 64 == 0, w % 32 == 0, h <= 32 or h % 32 == 0); everything else stays with the vendor library.
+ * (fp32, channels % 64 == 0, and either w % 32 == 0 with h <= 32 or h % 32 == 0, or w in {16, 8} with h <= 32: 2 / 4 samples then share a
+ * 32-pixel row step, any n); everything else stays with the vendor library.  dw is accumulated with atomics (summation order, and with it the
+ * last bit, varies from run to run).
  */
 typedef struct sgv_conv_wrw_params {
     const void* dy; /* [n, c_out, h, w] */
@@ -233,7 +235,8 @@ int sgv_conv3x3_wrw_supported(int32_t n, int32_t c_out, int32_t c_in, int32_t h,
  * (networks.py:66 `x * styles`) without materialising the scaled input again in the backward pass */
 int sgv_conv3x3_wrw_scaled(const sgv_conv_wrw_params* p, const float* x_scale, int dtype, void* stream);
 /* Stride-2 member (weight gradient of sgv_conv3x3_s2, either mode): dy = the SMALL tensor [n, c_out, h, w], x = the BIG one
- * [n, c_in, 2h+1, 2w+1];  dw[s,b,ky,kx] = sum_{n,Y,X} small[n,s,Y,X] * big[n,b,2Y+ky,2X+kx]  as [c_out, c_in, 3, 3]. */
+ * [n, c_in, 2h+1, 2w+1];  dw[s,b,ky,kx] = sum_{n,Y,X} small[n,s,Y,X] * big[n,b,2Y+ky,2X+kx]  as [c_out, c_in, 3, 3].  Same shape rule as
+ * the stride-1 member, on the small grid (w % 32 == 0, or w in {16, 8} with packed samples). */
 int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void* stream);
 int sgv_conv3x3_wrw_s2_supported(int32_t n, int32_t c_small, int32_t c_big, int32_t h, int32_t w, int dtype);
 
