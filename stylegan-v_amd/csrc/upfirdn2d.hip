@@ -336,6 +336,7 @@ struct lanes_params {
     int plane_groups;  // SEG: groups of planes sharing a wave; otherwise == planes
     int nt_store;      // stream the output past the caches (tensors larger than the Infinity Cache)
     int lds_share;     // hand the vertical halo rows from wave to wave through LDS
+    int pad;           // upfirdn2d_fir_asm_kernel only: pad_x0 == pad_y0
     // fused epilogue / prologue (EPI != 0), see sgv_fir_epilogue in include/sgv_ops.h
     const float* ep_scale;  // [planes] or NULL
     const float* ep_bias;   // [chans] or NULL
@@ -697,6 +698,134 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Dedicated instantiation of the hot FIR geometry -- fp32, up = down = 1, 4x4 filter, pad_x0 = pad_y0 = P (1 or 2), out = in + 2P - 3 on both
+// axes, out_w % 4 in {0, 1}, plain upfirdn2d (no fused epilogue): the pass after an up-sampling convolution (2r+1 -> 2r) and the pass in front
+// of a strided one (r -> r+1) -- with the row loads as inline asm and counted waits.
+//
+// Same walk as the lanes kernel (a wave owns a strip of rows of one plane, a lane 4 (+1) output columns, neighbours' columns by DPP, the wave's
+// right halo by one masked dword load + v_readlane, 4-row window in registers, taps in SGPRs, non-temporal stores).  The difference is WHEN the
+// loads are waited for: hipcc puts `s_waitcnt vmcnt(0)` directly behind a row load written in C++ (the value is merged with the zero row inside the
+// same conditional block), so in the lanes kernel nothing is in flight while the previous rows are filtered and only occupancy hides the memory
+// latency.  Here every row issues exactly two loads (16 B main + halo dword; out-of-range rows load a clamped row and are zeroed on use, edge
+// lanes load a window clamped into the row and shift it back with selects) into one of two register sets that are never copied, and the wait in
+// front of a set's use allows the 2 PF loads issued since into the other set to stay outstanding (loads return in order; the stores and anything
+// else issued in between only make the wait stricter): two row groups in flight across the arithmetic and the stores.  tools/ufd_lab.hip V4:
+// 5.6 TB/s = 70 % of 8 TB/s on [32,64,257,257] -> 256^2 where the lanes kernel reaches 5.0-5.3 (profiles/r02_ufd_lab_v4_asm_loads.log).
+// No LDS hand-off between strips (the three halo rows come from L2).  Tap order per output: ascending row, then ascending column, one fmaf chain
+// -- the reference loop's order, bit-identical to the oracle like every other path.
+template <int XTRA, int PF>
+__global__ __launch_bounds__(256) void upfirdn2d_fir_asm_kernel(lanes_params p) {
+    constexpr int NEED = 7 + XTRA, NH = 3 + XTRA, NOUT = 4 + XTRA;
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int strip = wave % p.strips;
+    const int cg = (wave / p.strips) % p.col_groups;
+    const int pl = wave / (p.strips * p.col_groups);
+    if (pl >= p.planes) return;
+    float ff[4][4];
+    {   // lane t < 16 fetches tap (t/4, t%4); v_readlane broadcasts the 16 values into SGPRs (same indexing as the lanes kernel)
+        const int ta = (lane >> 2) & 3, tb = lane & 3;
+        float t = 0.f;
+        if (lane < 16) {
+            const int fa = p.flip ? ta : 3 - ta, fb = p.flip ? tb : 3 - tb;
+            t = p.f[fa * p.f_sh + fb * p.f_sw];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) ff[a][b] = lane_bcast(t, a * 4 + b);
+    }
+    const float* xp = (const float*)p.x + (size_t)pl * p.in_h * p.in_w;
+    float* yp = (float*)p.y + (size_t)pl * p.out_h * p.out_w;
+    const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of 4
+    const int ox = cg * 256 + lane * 4;
+    const int ix0 = ox - p.pad;
+    const int base = min(max(ix0, 0), p.in_w - 4);              // the 4-column load window, clamped into the row
+    const int sh = base - ix0;                                  // how far it moved (|sh| <= 3 for lanes that own live columns)
+    const bool cols_dead = ix0 >= p.in_w || ix0 + 3 < 0;
+    const int ixh = cg * 256 + 256 - p.pad + lane;              // lanes 0 .. NH-1: the columns right of lane 63's block
+    const bool halo_ok = lane < NH && ixh >= 0 && ixh < p.in_w;
+    const int ixh_c = min(max(ixh, 0), p.in_w - 1);
+    const bool st_vec = ox < n_main;                            // whole vectors only (n_main % 4 == 0)
+    const bool st_xtra = XTRA && ox + 4 == p.out_w - 1;
+    const int oy_a = strip * p.strip_h, oy_b = min(oy_a + p.strip_h, p.out_h);
+    const int iy0 = oy_a - p.pad;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    struct raw { f4v m; float h; };
+    auto issue = [&](int iy, raw& r) {   // always two loads
+        const float* row = xp + (size_t)min(max(iy, 0), p.in_h - 1) * p.in_w;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.m) : "v"(row + base) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(r.h) : "v"(row + ixh_c) : "memory");
+    };
+    auto expand = [&](int iy, raw& r, float* dst) {   // first use of the set behind the counted wait: pin its registers there
+        asm volatile("" : "+v"(r.m));
+        asm volatile("" : "+v"(r.h));
+        const bool row_ok = iy >= 0 && iy < p.in_h;
+        float m[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {   // undo the clamp: m[i] = column ix0 + i = loaded[i - sh] where that exists, else 0 (padding)
+            float v = r.m[i];
+#pragma unroll
+            for (int d = 1; d <= 3; d++) {
+                if (i - d >= 0) v = (sh == d) ? r.m[i - d] : v; else v = (sh == d) ? 0.f : v;
+                if (i + d < 4) v = (sh == -d) ? r.m[i + d] : v; else v = (sh == -d) ? 0.f : v;
+            }
+            m[i] = (row_ok && !cols_dead) ? v : 0.f;
+        }
+        const float hv = (row_ok && halo_ok) ? r.h : 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) dst[i] = m[i];
+#pragma unroll
+        for (int i = 0; i < NH; i++) dst[4 + i] = dpp_wave_shl1(m[i], lane_bcast(hv, i));
+    };
+    float win[4][NEED];
+    // Two register sets used alternately and never copied: the compiler believes an asm load's result is there at once, so nothing may read, move
+    // or re-allocate these registers between the load and the pin in expand().
+    raw pr[3], sa[PF], sb[PF];
+#pragma unroll
+    for (int r = 0; r < 3; r++) issue(iy0 + r, pr[r]);
+    int iy = iy0 + 3;
+#pragma unroll
+    for (int k = 0; k < PF; k++) issue(iy + k, sa[k]);
+    if (PF == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < 3; r++) expand(iy0 + r, pr[r], win[1 + r]);
+    auto group = [&](int oy, raw* cur, raw* nxt) {
+#pragma unroll
+        for (int k = 0; k < PF; k++) issue(iy + PF + k, nxt[k]);   // the group after this one (rows past the strip load clamped rows nobody uses)
+        if (PF == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < PF; k++) {
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int i = 0; i < NEED; i++) win[r][i] = win[r + 1][i];
+            expand(iy + k, cur[k], win[3]);
+            if (oy + k >= oy_b) continue;   // wave-uniform
+            float o[NOUT];
+#pragma unroll
+            for (int v = 0; v < NOUT; v++) {
+                float acc = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[j][v + i], ff[j][i], acc);
+                o[v] = acc * p.gain;
+            }
+            float* yr = yp + (size_t)(oy + k) * p.out_w + ox;
+            if (st_vec) { if (p.nt_store) store_vec_nt<float, 4>(yr, o); else store_vec_plain<float, 4>(yr, o); }
+            if constexpr (XTRA) { if (st_xtra) yr[4] = o[4]; }
+        }
+        iy += PF;
+    };
+    for (int oy = oy_a; oy < oy_b; oy += 2 * PF) {
+        group(oy, sa, sb);
+        group(oy + PF, sb, sa);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the loads of the rows past the strip
+}
+
 typedef void (*lanes_fn)(lanes_params);
 constexpr int LANES_WPB = 4;  // waves per workgroup (8 measured equal: the halo hand-off already covers 3 of 4 strip seams)
 
@@ -932,6 +1061,24 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
     lanes_plan lplan;
     if (plan_lanes(p, dtype, &lplan)) {
         sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
+        static const int fir_asm = []() { const char* e = getenv("SGV_FIR_ASM"); return e ? atoi(e) : 1; }();
+        const int n_main = p->out_w % 4 == 1 ? p->out_w - 1 : p->out_w;
+        if (fir_asm && dtype == SGV_F32 && p->up_x == 1 && p->up_y == 1 && p->down_x == 1 && p->down_y == 1 && p->f_w == 4 && p->f_h == 4 &&
+            p->pad_x0 == p->pad_y0 && (p->pad_x0 == 1 || p->pad_x0 == 2) && p->out_w == p->in_w + 2 * p->pad_x0 - 3 && p->out_h == p->in_h + 2 * p->pad_y0 - 3 &&
+            n_main % 4 == 0 && n_main > 128 && p->in_w >= 4 && (((uintptr_t)p->y) & 3) == 0) {
+            // the hot FIR geometry at >= 129 output columns: its own kernel (asm row loads, counted waits)
+            lanes_params lp = lplan.lp;
+            lp.pad = p->pad_x0;
+            lp.col_groups = (n_main + 255) / 256;
+            lp.strip_h = 16;
+            lp.strips = (p->out_h + 15) / 16;
+            const int64_t waves = (int64_t)lp.planes * lp.col_groups * lp.strips;
+            if ((waves + 3) / 4 <= 0x7fffffff) {
+                if (p->out_w % 4 == 1) hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<1, 4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, lp);
+                else hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<0, 4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, lp);
+                return sgv_check_launch("upfirdn2d_fir_asm_kernel");
+            }
+        }
         hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
         return sgv_check_launch("upfirdn2d_lanes_kernel");
     }
