@@ -79,8 +79,8 @@ def pmc_traffic_conv_family():
                         'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
 
 
-def pmc_traffic_per_launch(prefix='upfirdn2d_lanes'):
-    return pmc_traffic((prefix,))
+def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_fir_asm')):
+    return pmc_traffic(tuple(prefixes))
 
 
 def cpu_baseline(res, frames, seconds_cap):
@@ -333,7 +333,7 @@ def main():
             r = prof['upfirdn2d_lanes']
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-                roofline_ufd = dict(kernel='upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
+                roofline_ufd = dict(kernel='upfirdn2d_lanes_kernel / upfirdn2d_fir_asm_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
                                     frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch()[0], launches=r['launches'],
                                     traffic_source=pmc_traffic_per_launch()[1] + ' (reads x2, gfx950 correction)',
                                     avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
