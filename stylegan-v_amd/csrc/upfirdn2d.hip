@@ -1074,8 +1074,15 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
             lp.strips = (p->out_h + 15) / 16;
             const int64_t waves = (int64_t)lp.planes * lp.col_groups * lp.strips;
             if ((waves + 3) / 4 <= 0x7fffffff) {
-                if (p->out_w % 4 == 1) hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<1, 4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, lp);
-                else hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<0, 4>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, stream, lp);
+                static const int pf_env = []() { const char* e = getenv("SGV_FIR_PF"); return e ? atoi(e) : 4; }();   // rows per group: 4 (default) or 2
+                const dim3 grid((unsigned)((waves + 3) / 4));
+                if (pf_env == 2) {
+                    if (p->out_w % 4 == 1) hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<1, 2>), grid, dim3(256), 0, stream, lp);
+                    else hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<0, 2>), grid, dim3(256), 0, stream, lp);
+                } else {
+                    if (p->out_w % 4 == 1) hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<1, 4>), grid, dim3(256), 0, stream, lp);
+                    else hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<0, 4>), grid, dim3(256), 0, stream, lp);
+                }
                 return sgv_check_launch("upfirdn2d_fir_asm_kernel");
             }
         }
