@@ -122,3 +122,16 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     r = custom_ops.PointwiseParams()
     assert lib.sgv_pointwise_small(r, F32, None) == -1
     assert lib.sgv_bias_act_db(custom_ops.BiasActParams(), None, 1, F32, None) == -1 and b'db is NULL' in lib.sgv_last_error()
+
+
+def test_profiling_families_match_the_header_enum():
+    """sgv_prof_collect() writes SGV_K_COUNT entries into the array the Python side sizes from SGV_K_NAMES: the two lists must agree, name by name."""
+    import os
+    import re
+    header = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include', 'sgv_ops.h')).read()
+    enum = re.findall(r'SGV_K_([A-Z0-9_]+)\s*=\s*(\d+)', header)
+    count = [int(v) for k, v in enum if k == 'COUNT'][0]
+    names = {int(v): k.lower() for k, v in enum if k != 'COUNT'}
+    assert count == len(custom_ops.SGV_K_NAMES) == len(names)
+    for idx, name in enumerate(custom_ops.SGV_K_NAMES):
+        assert names[idx] == name, (idx, names[idx], name)
