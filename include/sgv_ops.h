@@ -11,32 +11,53 @@
  * Nothing throws across the ABI.
  *
  * Each entry point names the reference interface it replaces (paths relative to the
- * universome/stylegan-v checkout):
+ * universome/stylegan-v checkout); the comment in front of each declaration below is the authority,
+ * this map is the index:
  *
- *   sgv_upfirdn2d      <- `_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1,
- *                          pady0, pady1, flip, gain)`  src/torch_utils/ops/upfirdn2d.cpp:16,98-101
- *                          (kernel parameter block: src/torch_utils/ops/upfirdn2d.h:14-40)
- *   sgv_upfirdn2d_fused <- no single reference op: upfirdn2d + x*dcoefs + bias_act of a synthesis layer
- *                          src/training/networks.py:65-74,141-143 in one kernel (forward and backward forms)
- *   sgv_bias_act       <- `_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain,
- *                          clamp)`  src/torch_utils/ops/bias_act.cpp:32,94-97
- *                          (kernel parameter block: src/torch_utils/ops/bias_act.h:12-31)
- *   sgv_weight_sqsum / sgv_demod_coefs / sgv_scale_channels
- *                      <- the weight (de)modulation arithmetic of `modulated_conv2d`
- *                          src/training/networks.py:57-74 (no native counterpart in the
- *                          reference: it materialises w[N,O,I,kh,kw] in PyTorch)
- *   sgv_pointwise_small / sgv_pointwise_outer
- *                      <- the 1x1 `conv2d` of ToRGBLayer (networks.py:148-163, C_out = 3) and of the discriminator's
- *                          `fromrgb` layer (networks.py:447, C_in = 3) and their gradients, conv2d_resample.py:40-54
- *   sgv_conv3x3        <- `conv2d` / `conv_transpose2d` of conv2d_gradfix.py:35-43,100-118 for 3x3 stride-1 layers (forward + data gradient)
- *   sgv_conv3x3_wrw    <- `Conv2dGradWeight` of conv2d_gradfix.py:140-170 (cudnn_convolution_backward_weight) for 3x3 stride-1 layers
- *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail
- *                          src/training/motion.py:201-212
- *   sgv_gemm_f32       <- `torch.addmm` / `matmul` of FullyConnectedLayer and the dense 1x1
- *                          convolutions  src/training/layers.py:133-137,
- *                          src/torch_utils/ops/conv2d_resample.py:40-54
- *   sgv_prof_*         <- no reference counterpart: per-launch HIP-event timing used by
- *                          bench.py to report roofline numbers.
+ *   sgv_upfirdn2d, sgv_upfirdn2d_kernel_kind
+ *                      <- `_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip, gain)`
+ *                          src/torch_utils/ops/upfirdn2d.cpp:16,98-101 (parameter block upfirdn2d.h:14-40, kernels upfirdn2d.cu:29-200)
+ *   sgv_upfirdn2d_fused <- no single reference op: upfirdn2d -> x*dcoefs -> bias_act of an up-sampling SynthesisLayer
+ *                          (src/training/networks.py:65-74,141-143; modes 1, 2), the gradient of "bias_act, then the FIR in front of a
+ *                          strided convolution" (DiscriminatorBlock conv0 -> conv1, networks.py:343-344; mode 3), FIR gradient + add (mode 4)
+ *   sgv_bias_act, sgv_bias_act_db
+ *                      <- `_plugin.bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)` src/torch_utils/ops/bias_act.cpp:32,94-97
+ *                          (parameter block bias_act.h:12-31, kernel bias_act.cu:23-147); `_db`: with `dx.sum(...)` of bias_act.py:185
+ *   sgv_weight_sqsum, sgv_demod_coefs, sgv_scale_channels, sgv_plane_dot
+ *                      <- the weight (de)modulation arithmetic of `modulated_conv2d` networks.py:57-74 and its styles gradient
+ *                          (no native counterpart in the reference: it materialises w[N,O,I,kh,kw] in PyTorch)
+ *   sgv_act_grad_scale, sgv_scale_dot
+ *                      <- the element-wise backward of a fused stride-1 layer: bias_act grad-1 (bias_act.cu:60-61,133-142) x dcoefs with the
+ *                          bias / dcoefs plane sums; `dxs * styles` with the styles gradient (networks.py:66)
+ *   sgv_pointwise_small, sgv_pointwise_outer, sgv_pointwise_act, sgv_pointwise_small_gradin, sgv_pointwise_outer_act
+ *                      <- the 1x1 `conv2d` of ToRGBLayer (networks.py:148-163, C_out = 3) and of the discriminator's `fromrgb`
+ *                          layer (networks.py:447, C_in = 3), their gradients (conv2d_resample.py:40-54), and fromRGB with its
+ *                          `bias_act` (layers.py Conv2dLayer.forward) as one pass in each direction
+ *   sgv_conv3x3, sgv_conv3x3_supported, sgv_conv3x3_workspace_bytes
+ *                      <- `conv2d` / `conv_transpose2d` of conv2d_gradfix.py:35-43,100-118 for 3x3 stride-1 layers (forward + data gradient)
+ *   sgv_conv3x3_fused, sgv_conv3x3_fused_supported
+ *                      <- a whole stride-1 layer: x*styles -> conv -> *dcoefs -> bias_act (networks.py:65-74,141-143; Conv2dLayer.forward)
+ *   sgv_conv3x3_s2, sgv_conv3x3_s2_supported, sgv_conv3x3_s2_supported_mode, sgv_conv3x3_s2_workspace_bytes
+ *                      <- the stride-2 `conv2d` / `conv_transpose2d` either side of the FIR, conv2d_resample.py:113-137
+ *   sgv_conv3x3_s2_fused, sgv_conv3x3_s2_fused_supported
+ *                      <- a down-sampling layer's tail: strided conv -> bias_act -> `y.add_(x)` of DiscriminatorBlock.forward networks.py:343-345
+ *   sgv_conv3x3_wrw, sgv_conv3x3_wrw_scaled, sgv_conv3x3_wrw_s2 (+ _supported)
+ *                      <- `Conv2dGradWeight` of conv2d_gradfix.py:140-170 (cudnn_convolution_backward_weight) for all of the above
+ *   sgv_gemm_f32       <- the dense 1x1 skip `conv2d` of DiscriminatorBlock (networks.py:452 via conv2d_resample.py:40-54), its data and
+ *                          weight gradients; the unfolded trajectory convolutions of motion.py:18-156 at thousands of rows
+ *   sgv_fc             <- `FullyConnectedLayer.forward` src/training/layers.py:108-138 (weight gain, bias gain, addmm / matmul, bias_act),
+ *                          `normalize_2nd_moment` layers.py:16-18, and through unfolded rows `EqLRConv1d` of motion.py
+ *   sgv_multi_nan_to_num_f32
+ *                      <- the `misc.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad)` loop of
+ *                          src/training/training_loop.py:384-386 as one launch over the whole gradient list
+ *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail src/training/motion.py:201-212
+ *   sgv_affine_resample <- `affine_grid` + `grid_sample` of the ADA geometric execution src/training/augment.py:297-300 and its backward
+ *                          src/torch_utils/ops/grid_sample_gradfix.py:45-83
+ *   sgv_prof_*, sgv_launch_count, sgv_variant_count, sgv_variant_name
+ *                      <- no reference counterpart: per-launch HIP-event timing and launch / kernel-variant counters used by
+ *                          bench.py (roofline numbers) and by the tests (proof of which kernel served a shape)
+ *   sgv_version, sgv_last_error
+ *                      <- the TORCH_CHECK messages of upfirdn2d.cpp:19-36 / bias_act.cpp:35-81 as a thread-local string
  */
 #ifndef SGV_OPS_H
 #define SGV_OPS_H
@@ -412,6 +433,12 @@ typedef struct sgv_fc_params {
 int sgv_fc(const sgv_fc_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * In-place torch.nan_to_num(x, nan, posinf, neginf) over a LIST of fp32 tensors in one launch per 96 tensors: the per-parameter gradient
+ * sanitising loop of src/training/training_loop.py:384-386.  `tensors` / `numels` are HOST arrays of `count` device pointers / element
+ * counts; the table is passed in the kernel arguments, nothing is copied or allocated. */
+int sgv_multi_nan_to_num_f32(float* const* tensors, const int64_t* numels, int32_t count, float nan, float posinf, float neginf, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Per-launch timing (bench.py roofline leg).  When enabled, every sgv_* launch is bracketed by
  * two HIP events on its own stream; sgv_prof_collect synchronises those events and reports, per
  * kernel family, launch count, summed milliseconds and summed algorithmic bytes
@@ -429,7 +456,8 @@ enum sgv_kernel_family {
     SGV_K_CONV_WRW = 8,
     SGV_K_CONV3X3 = 9,          /* every 3x3 convolution launch except the >= 32 pixel stride-1 kernel */
     SGV_K_CONV3X3_S1 = 10,      /* conv3x3_ws_kernel (stride 1, forward and data gradient, images >= 32 pixels): the step's dominant kernel */
-    SGV_K_COUNT = 11
+    SGV_K_FC = 11,              /* sgv_fc (dense layers; the tiled GEMM keeps SGV_K_GEMM) */
+    SGV_K_COUNT = 12
 };
 typedef struct sgv_prof_entry {
     int64_t launches;
@@ -444,6 +472,11 @@ int sgv_prof_collect(sgv_prof_entry* out /* [SGV_K_COUNT] */); /* syncs events, 
 
 /* Total number of kernel launches issued through this library since load (all threads). */
 int64_t sgv_launch_count(void);
+
+/* Which kernel served a call: one counter per kernel variant (the members of a family that a shape / switch selects between), bumped
+ * at launch time.  sgv_variant_name(i) is NULL for i outside [0, number of variants); sgv_variant_count(i) is -1 there. */
+int64_t sgv_variant_count(int32_t variant);
+const char* sgv_variant_name(int32_t variant);
 
 int sgv_version(void);
 const char* sgv_last_error(void);

@@ -271,6 +271,7 @@ static int bias_act_launch(const sgv_bias_act_params* p, float* db, int db_slots
     const double bytes = (double)p->size_x * es * streams + (p->b ? (double)p->size_b * es : 0.0);
     sgv_launch_scope scope(SGV_K_BIAS_ACT, stream, bytes);
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), 0, stream, kp, bmode, nt_store);
+    sgv_note_variant(SGV_V_bias_act);
     return sgv_check_launch("bias_act_kernel");
 }
 

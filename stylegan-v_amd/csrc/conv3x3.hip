@@ -149,6 +149,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
             else hipLaunchKernelGGL((conv3x3_small_kernel<3, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
         }
+        sgv_note_variant(SGV_V_conv_small);
         return sgv_check_launch("conv3x3_small_kernel");
     }
     if (ep || g_use_ws) {
@@ -163,10 +164,12 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
             epi = (ep->out_scale || ep->bias || ep->act != 1 || ep->gain != 1.f || ep->clamp >= 0.f) ? 1 : 0;
         }
         hipLaunchKernelGGL(g_ws_kernels[p->terms == 3][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
+        sgv_note_variant((pro || epi) ? SGV_V_conv_s1_ws_fused : (ep && ep->accumulate) ? SGV_V_conv_s1_ws_accumulate : SGV_V_conv_s1_ws);
         return sgv_check_launch("conv3x3_ws_kernel");
     }
     if (p->terms == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     else hipLaunchKernelGGL(conv3x3_kernel<3>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
+    sgv_note_variant(SGV_V_conv_s1_4wave);
     return sgv_check_launch("conv3x3_kernel");
 }
 
@@ -253,6 +256,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         else { if (p->terms == 1) SGV_P2_S(1, 0); else SGV_P2_S(3, 0); }
 #undef SGV_P2_S
 #undef SGV_P2_GO
+        sgv_note_variant(ss == 1 ? (ep ? SGV_V_conv_s2_pairs_fused : SGV_V_conv_s2_pairs) : (ep ? SGV_V_conv_s2_pairs_packed_fused : SGV_V_conv_s2_pairs_packed));
         return sgv_check_launch("conv3x3_s2_pairs_kernel");
     }
     if (p->mode == 0 && g_s2_ws) {
@@ -260,11 +264,13 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         kp.grid = std::min(kp.tiles, g_cus);
         if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_ws_kernel<1>, dim3((unsigned)kp.grid), dim3(512), S2W_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL(conv3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(512), S2W_LDS_BYTES, stream, kp);
+        sgv_note_variant(SGV_V_conv_s2_ws);
         return sgv_check_launch("conv3x3_s2_ws_kernel");
     }
     if (p->mode == 0) {
         if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(256), S_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL(conv3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(256), S_LDS_BYTES, stream, kp);
+        sgv_note_variant(SGV_V_conv_s2_1role);
         return sgv_check_launch("conv3x3_s2_kernel");
     }
     if (packed) {
@@ -287,6 +293,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL(convT3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
     }
+    sgv_note_variant(packed ? SGV_V_convT_ws_packed : g_s2_ws ? SGV_V_convT_ws : SGV_V_convT_1role);
     rc = sgv_check_launch("convT3x3_s2_kernel");
     if (rc != SGV_OK) return rc;
     if (!g_edge_mfma) {
@@ -297,6 +304,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         const int lmax = std::max(2 * p->w + 1, 2 * p->h);
         hipLaunchKernelGGL(convT3x3_s2_edge_kernel, dim3((unsigned)((lmax + 127) / 128), (unsigned)(p->n * (p->c_out / EDGE_MC)), 2), dim3(128), 0, stream, edge, (float*)p->y, p->n,
                            p->c_in, p->c_out, p->h, p->w);
+        sgv_note_variant(SGV_V_convT_edge_gather);
         return sgv_check_launch("convT3x3_s2_edge_kernel");
     }
     // last output row (oy = 2H) and column (ox = 2W): 0.4 % of the flops on the fp32 matrix pipe, after one pass that lays the six weight taps
@@ -308,6 +316,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2), dim3(64), 0, stream, (const float*)p->x,
                            edge, (float*)p->y, p->n, p->c_in, p->c_out, p->h, p->w);
     }
+    sgv_note_variant(SGV_V_convT_edge_mfma);
     return sgv_check_launch("convT3x3_s2_edge_mfma");
 }
 

@@ -21,6 +21,7 @@
 // One barrier per chunk.  The producers' VALU / LDS-write / VMEM instructions issue in the gaps between the consumer's MFMAs of the
 // same SIMD (separate pipes).  LDS: 2 x (x tile 38.3 KiB + weights 36 KiB + 512 B epilogue vectors) = 149.5 KiB, one workgroup per CU.
 #pragma once
+#include <type_traits>
 
 #include "conv3x3_kernel.h"
 
@@ -325,29 +326,36 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
             const int g = le >> 5;
             float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane + (size_t)(tp.y0 + 4 * wave) * p.w + tp.x0 + (le & 31);
             const float* ep = (const float*)(ws + WS_WORDS);
-            const float clamp_hi = pp.clamp >= 0.f ? pp.clamp : __builtin_inff();
+            // The clamp is one v_med3_f32 -- which returns min3 when an operand is NaN, so a NaN accumulator would be stored as -clamp.  With a
+            // clamp that IS bias_act's result (bias_act.cu:142: every comparison with NaN fails -> -clamp); without one the reference propagates the
+            // NaN, so the un-clamped store path has no med3 at all: two instantiations of the store loop behind one wave-uniform branch per tile.
+            auto store_tile = [&](auto clamped) {
+                constexpr bool CLAMP = decltype(clamped)::value;
+                const float clamp_hi = pp.clamp;
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++)
+                for (int hf = 0; hf < 2; hf++)
 #pragma unroll
-                for (int e4 = 0; e4 < 4; e4++) {
-                    const int m0 = hf * 32 + 8 * e4 + 4 * g;
-                    f32x4 c0, c1, c2, c3;
-                    if (EPI == 1) { c0 = *(const f32x4*)(ep + m0); c1 = *(const f32x4*)(ep + TM + m0); c2 = *(const f32x4*)(ep + 2 * TM + m0); c3 = *(const f32x4*)(ep + 3 * TM + m0); }
+                    for (int e4 = 0; e4 < 4; e4++) {
+                        const int m0 = hf * 32 + 8 * e4 + 4 * g;
+                        f32x4 c0, c1, c2, c3;
+                        if (EPI == 1) { c0 = *(const f32x4*)(ep + m0); c1 = *(const f32x4*)(ep + TM + m0); c2 = *(const f32x4*)(ep + 2 * TM + m0); c3 = *(const f32x4*)(ep + 3 * TM + m0); }
 #pragma unroll
-                    for (int r = 0; r < 4; r++)
+                        for (int r = 0; r < 4; r++)
 #pragma unroll
-                        for (int ei = 0; ei < 4; ei++) {
-                            float v = acc[r][hf][4 * e4 + ei];
-                            if (EPI == 1) {
-                                v = fmaxf(__builtin_fmaf(v, c0[ei], c1[ei]), __builtin_fmaf(v, c2[ei], c3[ei]));
-                                v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);   // one instruction; clamp_hi = +inf when there is no clamp
+                            for (int ei = 0; ei < 4; ei++) {
+                                float v = acc[r][hf][4 * e4 + ei];
+                                if (EPI == 1) {
+                                    v = fmaxf(__builtin_fmaf(v, c0[ei], c1[ei]), __builtin_fmaf(v, c2[ei], c3[ei]));
+                                    if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
+                                }
+                                if (ABL == 4) asm volatile("" :: "v"(v));
+                                else if (pp.accumulate) atomicAdd(yb + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
+                                else yb[(size_t)(m0 + ei) * plane + (size_t)r * p.w] = v;
+                                acc[r][hf][4 * e4 + ei] = 0.f;
                             }
-                            if (ABL == 4) asm volatile("" :: "v"(v));
-                            else if (pp.accumulate) atomicAdd(yb + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
-                            else yb[(size_t)(m0 + ei) * plane + (size_t)r * p.w] = v;
-                            acc[r][hf][4 * e4 + ei] = 0.f;
-                        }
-                }
+                    }
+            };
+            if (EPI == 1 && pp.clamp >= 0.f) store_tile(std::true_type{}); else store_tile(std::false_type{});
         }
         // every LDS read of this image has been consumed by an MFMA above; the asm statements keep the compiler from moving LDS
         // accesses across the barrier (a plain s_barrier is not a memory fence, and __syncthreads() would also drain the stores)

@@ -20,6 +20,7 @@
 //
 // LDS: 2 x (x 37.1 KiB + weights 36 KiB) = 146.3 KiB, one workgroup per CU.
 #pragma once
+#include <type_traits>
 
 #include "conv3x3s2_kernel.h"
 #include "conv3x3_ws_kernel.h"
@@ -534,7 +535,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             float* yb = p.y + off0;
             const float al = ep.act == 3 ? ep.alpha : 1.f;
             const float g0 = ep.gain, g1 = ep.gain * al;
-            const float clamp_hi = ep.clamp >= 0.f ? ep.clamp : __builtin_inff();
             // all sixteen bias vectors of the tile first (from the LDS copy the DMA wave made with this chunk's weights)
             const float* bias_lds = (const float*)(ws + P2_WS_WORDS);
             f32x4 bvs[4][4];
@@ -545,27 +545,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
                     bvs[mq][e4] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (EPI == 1 && ep.bias) bvs[mq][e4] = *(const f32x4*)(bias_lds + mq * 32 + 8 * e4 + 4 * ge);
                 }
+            // v_med3_f32 turns a NaN into -clamp: bias_act's own result when there IS a clamp (bias_act.cu:142), wrong without one (the reference
+            // propagates the NaN) -- so the un-clamped store loop is its own instantiation behind one wave-uniform branch per tile
+            auto store_tile = [&](auto clamped) {
+                constexpr bool CLAMP = decltype(clamped)::value;
+                const float clamp_hi = ep.clamp;
 #pragma unroll
-            for (int mq = 0; mq < 4; mq++)
+                for (int mq = 0; mq < 4; mq++)
 #pragma unroll
-                for (int e4 = 0; e4 < 4; e4++) {
-                    const int m0 = mq * 32 + 8 * e4 + 4 * ge;
-                    const f32x4 bv = bvs[mq][e4];
+                    for (int e4 = 0; e4 < 4; e4++) {
+                        const int m0 = mq * 32 + 8 * e4 + 4 * ge;
+                        const f32x4 bv = bvs[mq][e4];
 #pragma unroll
-                    for (int ei = 0; ei < 4; ei++)
+                        for (int ei = 0; ei < 4; ei++)
 #pragma unroll
-                        for (int r = 0; r < 2; r++) {
-                            const size_t idx = (size_t)(m0 + ei) * plane_out + (size_t)r * p.w;
-                            float v = acc[r][mq][4 * e4 + ei];
-                            if (EPI == 1) {
-                                v = fmaxf(__builtin_fmaf(v, g0, bv[ei] * g0), __builtin_fmaf(v, g1, bv[ei] * g1));
-                                v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
-                                if (ep.act_out) ep.act_out[off0 + idx] = v;
+                            for (int r = 0; r < 2; r++) {
+                                const size_t idx = (size_t)(m0 + ei) * plane_out + (size_t)r * p.w;
+                                float v = acc[r][mq][4 * e4 + ei];
+                                if (EPI == 1) {
+                                    v = fmaxf(__builtin_fmaf(v, g0, bv[ei] * g0), __builtin_fmaf(v, g1, bv[ei] * g1));
+                                    if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
+                                    if (ep.act_out) ep.act_out[off0 + idx] = v;
+                                }
+                                if (EPI == 1 && ep.accumulate) atomicAdd(yb + idx, v); else yb[idx] = v;
+                                acc[r][mq][4 * e4 + ei] = 0.f;
                             }
-                            if (EPI == 1 && ep.accumulate) atomicAdd(yb + idx, v); else yb[idx] = v;
-                            acc[r][mq][4 * e4 + ei] = 0.f;
-                        }
-                }
+                    }
+            };
+            if (EPI == 1 && ep.clamp >= 0.f) store_tile(std::true_type{}); else store_tile(std::false_type{});
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();

@@ -93,16 +93,19 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
     if (pack) {   // the packed form exists in the producer / consumer kernel only
         if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
         else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        sgv_note_variant(SGV_V_wrw_s1_ws_packed);
         return sgv_check_launch("wrw3x3_ws_kernel (packed)");
     }
     if (g_use_ws) {
         if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
         else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        sgv_note_variant(x_scale ? SGV_V_wrw_s1_ws_scaled : SGV_V_wrw_s1_ws);
         return sgv_check_launch("wrw3x3_ws_kernel");
     }
     if (x_scale) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_scaled: the 4-wave kernel (SGV_WRW_WS=0) has no input scale");
     if (p->terms == 1) hipLaunchKernelGGL(wrw3x3_kernel<1>, grid, dim3(256), 0, stream, kp);
     else hipLaunchKernelGGL(wrw3x3_kernel<3>, grid, dim3(256), 0, stream, kp);
+    sgv_note_variant(SGV_V_wrw_s1_4wave);
     return sgv_check_launch("wrw3x3_kernel");
 }
 
@@ -165,14 +168,17 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
             if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, false>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
             else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<3, false>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
         }
+        sgv_note_variant(pack ? SGV_V_wrw_s2_ws_packed : SGV_V_wrw_s2_ws);
         return sgv_check_launch("wrw3x3_s2_ws_kernel");
     }
     if (pack) {
         if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_kernel<1, true>), grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL((wrw3x3_s2_kernel<3, true>), grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
+        sgv_note_variant(SGV_V_wrw_s2_4wave_packed);
         return sgv_check_launch("wrw3x3_s2_kernel (packed)");
     }
     if (p->terms == 1) hipLaunchKernelGGL(wrw3x3_s2_kernel<1>, grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
     else hipLaunchKernelGGL(wrw3x3_s2_kernel<3>, grid, dim3(256), WRW_S2_LDS_BYTES, stream, kp);
+    sgv_note_variant(SGV_V_wrw_s2_4wave);
     return sgv_check_launch("wrw3x3_s2_kernel");
 }

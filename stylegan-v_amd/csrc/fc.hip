@@ -188,11 +188,12 @@ static int sgv_fc_launch(const sgv_fc_params* q, hipStream_t stream, bool accoun
         }
     };
     if (account) {
-        sgv_launch_scope scope(SGV_K_GEMM, stream, 4.0 * batch * ((double)q->m * q->k + (double)q->n * q->k + (double)q->m * q->n), 2.0 * batch * q->m * (double)q->n * q->k);
+        sgv_launch_scope scope(SGV_K_FC, stream, 4.0 * batch * ((double)q->m * q->k + (double)q->n * q->k + (double)q->m * q->n), 2.0 * batch * q->m * (double)q->n * q->k);
         go();
     } else {
         go();
     }
+    sgv_note_variant(SGV_V_fc);
     return sgv_check_launch("fc_kernel");
 }
 

@@ -64,5 +64,6 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
         if (full16) hipLaunchKernelGGL((gemm_f32_kernel<0, 16, 1, 2, 1>), grid, dim3(256), 0, stream, gp);
         else hipLaunchKernelGGL((gemm_f32_kernel<0, 16, 0, 1, 0>), grid, dim3(256), 0, stream, gp);
     }
+    sgv_note_variant(SGV_V_gemm_f32);
     return sgv_check_launch("gemm_f32_kernel");
 }

@@ -272,6 +272,7 @@ int launch_pw(int kind, pw_params pp, hipStream_t stream) {
         else if (kind == 0) hipLaunchKernelGGL((pw_many2few_kernel<T, F, 1>), grid, dim3(256), 0, stream, pp);      \
         else if (pp.act) hipLaunchKernelGGL((pw_few2many_kernel<T, F, 1>), grid, dim3(256), 0, stream, pp);         \
         else hipLaunchKernelGGL((pw_few2many_kernel<T, F>), grid, dim3(256), 0, stream, pp);                        \
+        sgv_note_variant(kind == 0 ? SGV_V_pw_many2few : pp.act ? SGV_V_pw_few2many_act : SGV_V_pw_few2many);            \
         return SGV_OK;                                                                                              \
     }
     SGV_PW(1) SGV_PW(2) SGV_PW(3) SGV_PW(4)
@@ -287,7 +288,7 @@ int launch_outer(outer_params op, hipStream_t stream) {
     grid.z = (unsigned)((op.cm + op.m_per_z - 1) / op.m_per_z);
     op.use_lds = 16 * op.cf * op.m_per_z <= 32768 ? 1 : 0;
 #define SGV_OUT(F)                                                                                                  \
-    if (op.cf == F) { hipLaunchKernelGGL((pw_outer_kernel<T, F, 4>), grid, dim3(256), op.use_lds ? 16u * F * op.m_per_z : 0u, stream, op); return SGV_OK; }
+    if (op.cf == F) { hipLaunchKernelGGL((pw_outer_kernel<T, F, 4>), grid, dim3(256), op.use_lds ? 16u * F * op.m_per_z : 0u, stream, op); sgv_note_variant(SGV_V_pw_outer); return SGV_OK; }
     SGV_OUT(1) SGV_OUT(2) SGV_OUT(3) SGV_OUT(4)
 #undef SGV_OUT
     return sgv_fail(SGV_ERR_UNSUPPORTED, "pointwise: the small channel count must be 1..4");

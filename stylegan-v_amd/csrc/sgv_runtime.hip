@@ -20,6 +20,16 @@ extern "C" const char* sgv_last_error(void) { return g_err; }
 extern "C" int sgv_version(void) { return SGV_VERSION; }
 extern "C" int64_t sgv_launch_count(void) { return g_launches.load(); }
 
+static std::atomic<int64_t> g_variants[SGV_V_COUNT];
+static const char* const g_variant_names[SGV_V_COUNT] = {
+#define SGV_V_NAME(name) #name,
+    SGV_VARIANTS(SGV_V_NAME)
+#undef SGV_V_NAME
+};
+void sgv_note_variant(int v) { if (v >= 0 && v < SGV_V_COUNT) g_variants[v].fetch_add(1, std::memory_order_relaxed); }
+extern "C" int64_t sgv_variant_count(int32_t v) { return (v >= 0 && v < SGV_V_COUNT) ? g_variants[v].load() : -1; }
+extern "C" const char* sgv_variant_name(int32_t v) { return (v >= 0 && v < SGV_V_COUNT) ? g_variant_names[v] : nullptr; }
+
 // ---------------------------------------------------------------------------------------------
 // Profiler: a fixed pool of event pairs; one record per launch while enabled.
 

@@ -157,7 +157,7 @@ def native_loaded():
 c_void_p, c_int, c_int32, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 SGV_F32, SGV_F16, SGV_BF16, SGV_F64 = 0, 1, 2, 3
-SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw', 'conv3x3', 'conv3x3_s1']
+SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw', 'conv3x3', 'conv3x3_s1', 'fc']
 
 
 class Upfirdn2dParams(ctypes.Structure):
@@ -279,10 +279,13 @@ ABI_SYMBOLS = {
     'sgv_affine_resample': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_gemm_f32': (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
     'sgv_fc': (c_int, [ctypes.POINTER(FcParams), c_void_p]),
+    'sgv_multi_nan_to_num_f32': (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int32, c_float, c_float, c_float, c_void_p]),
     'sgv_prof_enable': (c_int, [c_int32]),
     'sgv_prof_disable': (c_int, []),
     'sgv_prof_collect': (c_int, [ctypes.POINTER(ProfEntry)]),
     'sgv_launch_count': (c_int64, []),
+    'sgv_variant_count': (c_int64, [c_int32]),
+    'sgv_variant_name': (ctypes.c_char_p, [c_int32]),
     'sgv_version': (c_int, []),
     'sgv_last_error': (ctypes.c_char_p, []),
 }
@@ -333,6 +336,17 @@ class device_guard:
 
 def launch_count():
     return int(get_native().sgv_launch_count()) if native_loaded() else 0
+
+
+def kernel_variant_counts():
+    """{variant name: launches since load}: which member of each kernel family served the calls (sgv_variant_count of the C ABI)."""
+    lib, out, i = get_native(), {}, 0
+    while True:
+        name = lib.sgv_variant_name(i)
+        if name is None:
+            return out
+        out[name.decode()] = int(lib.sgv_variant_count(i))
+        i += 1
 
 
 # ----------------------------------------------------------------------------------------------

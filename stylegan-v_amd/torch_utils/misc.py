@@ -16,6 +16,27 @@ import torch
 nan_to_num = torch.nan_to_num
 
 
+def nan_to_num_list_(tensors, nan=0.0, posinf=None, neginf=None):
+    """In-place ``nan_to_num`` over a list of tensors: the per-parameter gradient loop of training_loop.py:384-386.  Dense fp32 GPU tensors
+    go through ONE native launch per 96 tensors (csrc/multi_tensor.hip); anything else takes torch's op, tensor by tensor."""
+    native, rest = [], []
+    for t in tensors:
+        (native if (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) else rest).append(t)
+    for t in rest:
+        torch.nan_to_num(t, nan=nan, posinf=posinf, neginf=neginf, out=t)
+    if native:
+        import ctypes
+        from . import custom_ops
+        lib = custom_ops.get_native()
+        fin = torch.finfo(torch.float32)
+        ptrs = (ctypes.c_void_p * len(native))(*[t.data_ptr() for t in native])
+        sizes = (ctypes.c_int64 * len(native))(*[t.numel() for t in native])
+        with custom_ops.device_guard(native[0]):
+            custom_ops.check(lib.sgv_multi_nan_to_num_f32(ptrs, sizes, len(native), float(nan), float(fin.max if posinf is None else posinf),
+                                                          float(fin.min if neginf is None else neginf), custom_ops.raw_stream(native[0])), lib)
+    return tensors
+
+
 class suppress_tracer_warnings(warnings.catch_warnings):
     """``with`` block that silences torch.jit tracer warnings (shape values used as constants)."""
 

@@ -64,6 +64,18 @@ class AugmentPipe(torch.nn.Module):
         self.xint_max, self.scale_std, self.rotate_max, self.aniso_std, self.xfrac_std = xint_max, scale_std, rotate_max, aniso_std, xfrac_std
         self.brightness_std, self.contrast_std, self.hue_max, self.saturation_std = brightness_std, contrast_std, hue_max, saturation_std
         self.register_buffer('Hz_geom', upfirdn2d.setup_filter(SYM6))
+        # True: reflect-pad by the worst-case margin (w - 1, h - 1: what the margin below is clamped to anyway) instead of reading the batch's
+        # margin back from the device.  Same result (extra padding is never sampled), no device -> host sync, static shapes: what hipGraph
+        # capture needs.  The price is a padded image of (3w - 2) x (3h - 2) instead of typically (w + 12) x (h + 12).
+        self.static_margin = False
+        self._const = {}
+
+    def _c(self, key, device, make):
+        """Small constant tensors, created once per device (not inside every forward: a host -> device copy is illegal under stream capture)."""
+        k = (key, str(device))
+        if k not in self._const:
+            self._const[k] = make().to(device)
+        return self._const[k]
 
     # -- parameter draws ------------------------------------------------------------------------------------------------------
     def _draw(self, name, shape, kind, neutral, device, pct, prob=None):
@@ -126,10 +138,9 @@ class AugmentPipe(torch.nn.Module):
             images = self._resample(images, g_inv)
 
         # ---- colour transform C (augment.py:306-368) ----
-        c_mat, coloured = torch.eye(4, device=dev).unsqueeze(0), False
-        luma = torch.tensor([1, 1, 1, 0], device=dev, dtype=torch.float32) / math.sqrt(3)
-        vv = luma.outer(luma)
-        eye4 = torch.eye(4, device=dev)
+        eye4 = self._c('eye4', dev, lambda: torch.eye(4))
+        c_mat, coloured = eye4.unsqueeze(0), False
+        vv = self._c('vv', dev, lambda: (torch.tensor([1., 1., 1., 0.]) / math.sqrt(3)).outer(torch.tensor([1., 1., 1., 0.]) / math.sqrt(3)))
         if on['brightness'] > 0:
             b = self._draw('brightness', [n], 'normal', 0, dev, pct) * self.brightness_std
             c_mat, coloured = _mat([[1, 0, 0, b], [0, 1, 0, b], [0, 0, 1, b], [0, 0, 0, 1]], like) @ c_mat, True
@@ -141,10 +152,10 @@ class AugmentPipe(torch.nn.Module):
             c_mat, coloured = (eye4 - 2 * vv * i) @ c_mat, True          # Householder reflection about the luma axis
         if on['hue'] > 0 and ch > 1:
             th = self._draw('hue', [n], 'uniform', 0, dev, pct) * math.pi * self.hue_max
-            k = torch.tensor([[0, -1, 1, 0], [1, 0, -1, 0], [-1, 1, 0, 0], [0, 0, 0, 0]], device=dev, dtype=torch.float32) / math.sqrt(3)   # cross-product matrix of the luma axis
+            k = self._c('cross', dev, lambda: torch.tensor([[0., -1, 1, 0], [1, 0, -1, 0], [-1, 1, 0, 0], [0, 0, 0, 0]]) / math.sqrt(3))   # cross-product matrix of the luma axis
             cth, sth = torch.cos(th).reshape(n, 1, 1), torch.sin(th).reshape(n, 1, 1)
-            rot = vv * (1 - cth) + torch.diag(torch.tensor([1., 1., 1., 0.], device=dev)) * cth + k * sth     # Rodrigues about v
-            rot = rot + torch.diag(torch.tensor([0., 0., 0., 1.], device=dev))
+            rot = vv * (1 - cth) + self._c('d1110', dev, lambda: torch.diag(torch.tensor([1., 1., 1., 0.]))) * cth + k * sth     # Rodrigues about v
+            rot = rot + self._c('d0001', dev, lambda: torch.diag(torch.tensor([0., 0., 0., 1.])))
             c_mat, coloured = rot @ c_mat, True
         if on['saturation'] > 0 and ch > 1:
             s = torch.exp2(self._draw('saturation', [n, 1, 1], 'normal', 0, dev, pct) * self.saturation_std)
@@ -169,14 +180,17 @@ class AugmentPipe(torch.nn.Module):
         n, ch, h, w = images.shape
         dev = images.device
         cx, cy = (w - 1) / 2, (h - 1) / 2
-        corners = torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], device=dev, dtype=torch.float32)
-        cp = g_inv @ corners.t()                                          # [n, 3, 4]: where the output corners come from
         pad = self.Hz_geom.shape[0] // 4
-        ext = cp[:, :2, :].permute(1, 0, 2).flatten(1)                    # [2, n * 4]
-        margin = torch.cat([-ext, ext]).max(dim=1).values                 # [x0, y0, x1, y1]
-        margin = margin + torch.tensor([pad * 2 - cx, pad * 2 - cy] * 2, device=dev)
-        margin = margin.clamp(min=0).minimum(torch.tensor([w - 1, h - 1] * 2, device=dev, dtype=torch.float32))
-        mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().tolist())     # one device -> host read per call, as in the reference (:283)
+        if self.static_margin:
+            mx0, my0, mx1, my1 = w - 1, h - 1, w - 1, h - 1                   # the clamp bound of the reference's margin (:281-282)
+        else:
+            corners = self._c(('corners', w, h), dev, lambda: torch.tensor([[-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1]], dtype=torch.float32))
+            cp = g_inv @ corners.t()                                          # [n, 3, 4]: where the output corners come from
+            ext = cp[:, :2, :].permute(1, 0, 2).flatten(1)                    # [2, n * 4]
+            margin = torch.cat([-ext, ext]).max(dim=1).values                 # [x0, y0, x1, y1]
+            margin = margin + self._c(('moff', w, h, pad), dev, lambda: torch.tensor([pad * 2 - cx, pad * 2 - cy] * 2, dtype=torch.float32))
+            margin = margin.clamp(min=0).minimum(self._c(('mmax', w, h), dev, lambda: torch.tensor([w - 1, h - 1] * 2, dtype=torch.float32)))
+            mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().tolist())     # one device -> host read per call, as in the reference (:283)
         images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
         g_inv = _translate((mx0 - mx1) / 2, (my0 - my1) / 2, images) @ g_inv
         images = upfirdn2d.upsample2d(images, self.Hz_geom, up=2)

@@ -10,6 +10,7 @@ MFMA, weight / bias gains, bias and leaky relu in the epilogue) -- no vendor con
 built: ``gen_strategy='conv'`` and ``fourier=True`` (configs/model/stylegan-v.yaml:19-27).
 """
 
+import contextlib
 import math
 
 import numpy as np
@@ -67,6 +68,21 @@ class AlignedTimeEncoder(torch.nn.Module):
                                interp_weights.reshape(-1).float())
 
 
+_t_bound = []   # innermost `frame_times_bounded_by` bound; a module-level stack, NOT module state: it neither survives pickling nor reaches G_ema
+
+
+@contextlib.contextmanager
+def frame_times_bounded_by(bound):
+    """Promise that every frame time `t` handed to a MotionMappingNetwork inside the block is <= `bound` (a training loop that draws
+    t < max_num_frames by construction).  `get_max_traj_len` then skips the reference's `t.max().item()` device->host read
+    (src/training/motion.py:97-100); the trajectory gather clamps its index so that a broken promise cannot read out of bounds."""
+    _t_bound.append(float(bound))
+    try:
+        yield
+    finally:
+        _t_bound.pop()
+
+
 class MotionMappingNetwork(torch.nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -81,12 +97,9 @@ class MotionMappingNetwork(torch.nn.Module):
         )
         self.num_additional_codes = (k - 1) * 2  # the two valid convolutions eat (k-1) codes each
 
-    t_bound = None   # if set (training loops that draw t < max_num_frames by construction): skips the device->host read of t.max() below,
-                     # a pipeline stall per generator pass and illegal under hipGraph capture
-
     def get_max_traj_len(self, t):
-        if self.t_bound is not None:
-            max_t = max(self.cfg.sampling.max_num_frames - 1, float(self.t_bound))
+        if _t_bound:     # inside `frame_times_bounded_by`: no device->host read of t.max() (a pipeline stall per pass, illegal under hipGraph capture)
+            max_t = max(self.cfg.sampling.max_num_frames - 1, _t_bound[-1])
         else:
             max_t = max(self.cfg.sampling.max_num_frames - 1, float(t.max().item()))
         return int(math.ceil(max_t / self.cfg.motion.motion_z_distance)) + 2
@@ -115,6 +128,8 @@ class MotionMappingNetwork(torch.nn.Module):
             trajs = self.conv(x.permute(0, 2, 1)).permute(0, 2, 1)  # [B, L - 2(k-1), v_dim]
 
         left_idx = (t / dist).floor().long()
+        if _t_bound:   # nothing compared t with the promised bound on the host: keep both gathers inside the trajectory whatever t holds
+            left_idx = left_idx.clamp(0, trajs.shape[1] - 2)
         rows = torch.arange(b, device=c.device).unsqueeze(1).expand(-1, f)
         u_left = trajs[rows, left_idx]
         u_right = trajs[rows, left_idx + 1]

@@ -20,6 +20,7 @@ import torch
 
 from ..torch_utils import misc
 from . import config as cfgs
+from . import motion
 from .loss import StyleGAN2Loss
 from .networks import Discriminator, Generator
 
@@ -88,29 +89,36 @@ class TrainStep:
         # Phase list with lazy regularisation (training_loop.py:238-252): reg every `interval` iterations with
         # lr and betas rescaled by c = interval / (interval + 1).
         self.phases = []
+        # torch's fused multi-tensor Adam on the GPU (same update rule as the reference's torch.optim.Adam, training_loop.py:245-251; one launch per
+        # parameter group instead of ~12 multi-tensor passes)
+        adam_kw = dict(fused=True) if self.device.type == 'cuda' else {}
         for name, module, interval in (('G', self.G, train_cfg.G_reg_interval), ('D', self.D, train_cfg.D_reg_interval)):
             if interval is None:
-                opt = torch.optim.Adam(module.parameters(), lr=train_cfg.lr, betas=tuple(train_cfg.betas), eps=1e-8)
+                opt = torch.optim.Adam(module.parameters(), lr=train_cfg.lr, betas=tuple(train_cfg.betas), eps=1e-8, **adam_kw)
                 self.phases.append(dict(name=name + 'both', module=module, opt=opt, interval=1))
             else:
                 ratio = interval / (interval + 1)
-                opt = torch.optim.Adam(module.parameters(), lr=train_cfg.lr * ratio, betas=tuple(b ** ratio for b in train_cfg.betas), eps=1e-8)
+                opt = torch.optim.Adam(module.parameters(), lr=train_cfg.lr * ratio, betas=tuple(b ** ratio for b in train_cfg.betas), eps=1e-8, **adam_kw)
                 self.phases.append(dict(name=name + 'main', module=module, opt=opt, interval=1))
                 self.phases.append(dict(name=name + 'reg', module=module, opt=opt, interval=interval))
         self.cur_nimg = 0
         self.batch_idx = 0
         self.last_losses = {}
-        # frame times are drawn inside [0, max_num_frames - 1) here (sample_frame_times): no need to read t.max() back from the device
-        for mod in (self.G, self.G_ema):
-            if getattr(mod.synthesis, 'motion_encoder', None) is not None:
-                mod.synthesis.motion_encoder.t_bound = self.sampling.max_num_frames - 1
-        # hipGraph replay of the two every-iteration phases (small per-GPU batches are launch-bound: ~1600 launches per iteration)
-        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda' and not self.ddp and self.augment_pipe is None
+        # Frame times are drawn inside [0, max_num_frames - 1) here (sample_frame_times), so the training passes promise that bound to the
+        # motion encoder (motion.frame_times_bounded_by) instead of reading t.max() back from the device.  The promise is scoped to
+        # `_run_phase`: G / G_ema used outside of it (evaluation, long-video generation) keep the reference's t.max() behaviour.
+        self._t_bound = float(self.sampling.max_num_frames - 1)
+        # hipGraph replay of the two every-iteration phases (small per-GPU batches are launch-bound).  Works with DDP (the RCCL all-reduce
+        # is captured with the phase; 11 eager DDP iterations precede the capture, torch's DDP-under-graphs recipe) and with ADA (the pipe
+        # pads by its static worst-case margin while graphs are on, so that nothing is read back to the host).
+        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
         self._graphs = {}
         if self.use_graphs:
             for phase in self.phases:
                 for group in phase['opt'].param_groups:
                     group['capturable'] = True
+            if self.augment_pipe is not None:
+                self.augment_pipe.static_margin = True
 
     def set_augment(self, augment):
         """'noaug' or 'ada' (see __init__); can be switched on an existing instance (bench.py times both on the same models)."""
@@ -120,8 +128,11 @@ class TrainStep:
             self.augment_pipe = AugmentPipe(**BGC).train().requires_grad_(False).to(self.device)
             self.augment_pipe.p.copy_(torch.zeros([]))
             self.ada = dict(self._ada_cfg, acc=torch.zeros([2], device=self.device))
-            self.use_graphs = False   # the ADA pipe reads its padding back to the host
+            self.augment_pipe.static_margin = bool(getattr(self, 'use_graphs', False))   # no device -> host read of the padding under capture
+            self._graphs = {}         # phases captured without the pipe are stale
         else:
+            if getattr(self, 'augment_pipe', None) is not None:
+                self._graphs = {}
             self.augment_pipe, self.ada = None, None
         self.loss.augment_pipe = self.augment_pipe
         self.loss.video_consistent_aug = augment == 'ada'
@@ -142,36 +153,56 @@ class TrainStep:
     def _run_phase(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
         phase['opt'].zero_grad(set_to_none=True)
         phase['module'].requires_grad_(True)
-        losses = self.loss.accumulate_gradients(phase=phase['name'], real_img=real_img, real_c=real_c, real_t=real_t, gen_z=gen_z,
-                                                gen_c=gen_c, gen_t=gen_t, sync=True, gain=phase['interval'])
+        with motion.frame_times_bounded_by(self._t_bound):
+            losses = self.loss.accumulate_gradients(phase=phase['name'], real_img=real_img, real_c=real_c, real_t=real_t, gen_z=gen_z,
+                                                    gen_c=gen_c, gen_t=gen_t, sync=True, gain=phase['interval'])
         phase['module'].requires_grad_(False)
-        for p in phase['module'].parameters():
-            if p.grad is not None:
-                misc.nan_to_num(p.grad, nan=0, posinf=1e5, neginf=-1e5, out=p.grad)
+        grads = [p.grad for p in phase['module'].parameters() if p.grad is not None]
+        if grads:
+            sanitize_gradients_(grads)
         phase['opt'].step()
         return losses
 
+    # -- the same phase as ONE hipGraph launch ------------------------------------------------------------------------------------
+    def _training_state(self, phase):
+        """Every tensor a run of `phase` may write: parameters and buffers of G and D (the generator's w_avg moves in every G pass) and the
+        phase's optimiser state."""
+        tensors = [t.detach() for mod in (self.G, self.D) for t in misc.params_and_buffers(mod)]
+        opt_state = [(p, k, v) for p, st in phase['opt'].state.items() for k, v in st.items() if isinstance(v, torch.Tensor)]
+        return tensors, opt_state
+
     def _run_phase_graph(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
-        """The same phase as ONE hipGraph launch: first call = two eager warm-up runs on a side stream (library initialisation, allocator
-        warm-up, Adam state) and the capture; later calls copy the inputs into the captured buffers and replay.  Every kernel of the
-        native library launches on torch's current stream without allocating or synchronising, so it is capture-safe as is."""
+        """First call of a phase: eager warm-up runs on a side stream (library initialisation, allocator warm-up, Adam state allocation,
+        DDP bucket rebuild) -- on the LIVE models, so parameters, buffers and optimiser state are put back afterwards: the warm-up must not
+        count as training -- then the capture (which executes nothing) and ONE replay, which is this iteration's update.  Later calls copy the
+        inputs into the captured buffers and replay.  Every kernel of the native library launches on torch's current stream without
+        allocating or synchronising, so it is capture-safe as is."""
         name = phase['name']
         entry = self._graphs.get(name)
         if entry is None:
             static = dict(real_img=real_img.clone(), real_c=real_c.clone(), real_t=real_t.clone(), gen_z=gen_z.clone(), gen_c=gen_c.clone(), gen_t=gen_t.clone())
+            tensors, opt_before = self._training_state(phase)
+            saved = [t.clone() for t in tensors]
+            saved_opt = {(id(p), k): v.clone() for p, k, v in opt_before}
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
-                for _ in range(2):
+                for _ in range(11 if self.ddp else 2):
                     self._run_phase(phase, **static)
+                with torch.no_grad():
+                    for t, s0 in zip(tensors, saved):
+                        t.copy_(s0)
+                    for p, k, v in self._training_state(phase)[1]:      # in place: the capture below records these tensors' addresses
+                        s0 = saved_opt.get((id(p), k))
+                        v.copy_(s0) if s0 is not None else v.zero_()
             torch.cuda.current_stream(self.device).wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 out = self._run_phase(phase, **static)
             entry = self._graphs[name] = dict(graph=graph, static=static, out=out)
-            return {k: v.clone() for k, v in out.items()}
-        for key, val in (('real_img', real_img), ('real_c', real_c), ('real_t', real_t), ('gen_z', gen_z), ('gen_c', gen_c), ('gen_t', gen_t)):
-            entry['static'][key].copy_(val)
+        else:
+            for key, val in (('real_img', real_img), ('real_c', real_c), ('real_t', real_t), ('gen_z', gen_z), ('gen_c', gen_c), ('gen_t', gen_t)):
+                entry['static'][key].copy_(val)
         entry['graph'].replay()
         return {k: v.clone() for k, v in entry['out'].items()}
 
@@ -212,11 +243,17 @@ class TrainStep:
         with torch.no_grad():
             ema_params = list(self.G_ema.parameters())
             torch._foreach_lerp_(ema_params, [p.detach() for p in self.G.parameters()], 1 - beta)  # p_ema.lerp(p, 1-beta) == p.lerp(p_ema, beta)
-            for b_ema, b in zip(self.G_ema.buffers(), self.G.buffers()):
-                b_ema.copy_(b)
+            torch._foreach_copy_(list(self.G_ema.buffers()), list(self.G.buffers()))
         self.cur_nimg += self.batch_size * self.frames
         self.batch_idx += 1
         return ran
+
+
+def sanitize_gradients_(grads):
+    """`misc.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad)` for every gradient of the phase
+    (training_loop.py:384-386) -- one multi-tensor launch per 96 gradients instead of one launch per parameter."""
+    with torch.no_grad():
+        misc.nan_to_num_list_(grads, nan=0.0, posinf=1e5, neginf=-1e5)
 
 
 def smoke_step(device):

@@ -325,6 +325,70 @@ def gen_networks_mid():
     save('networks_mid', arrays, meta)
 
 
+def gen_networks_full():
+    """Third module golden: the benchmark's own models -- FFS 256^2, cfg=auto (fmaps 0.5: channels 512,512,512,512,256,128,64; mapping depth 2;
+    src/train.py:138-200, configs/model/stylegan-v.yaml), 2 videos x 3 frames.  Parameters are drawn on both sides with
+    tests/util.py:seeded_parameters_; outputs are stored whole (images as float16-exact values are NOT assumed: float32), gradients as strided samples."""
+    from omegaconf import OmegaConf
+    from training.networks import Generator, Discriminator
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import seeded_parameters_, sample_flat
+    RES = 256
+    sampling = dict(type='random', num_frames_per_video=3, max_num_frames=1024, total_dists=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048], max_dist=32)
+    gcfg = OmegaConf.create(dict(sampling=sampling, use_noise=False, input=dict(type='temporal'), w_dim=512, z_dim=512, c_dim=0,
+                                 motion=dict(z_dim=512, v_dim=512, motion_z_distance=16, gen_strategy='conv', kernel_size=11, use_fractional_t=True, fourier=True),
+                                 time_enc=dict(cond_type='concat_const', dim=256, min_period_len=16, max_period_len=1024, phase_dropout_std=1.0)))
+    dcfg = OmegaConf.create(dict(sampling=sampling, concat_res=16, num_frames_div_factor=2, dummy_c=False))
+    torch.manual_seed(4049)
+    G = Generator(c_dim=0, w_dim=512, img_resolution=RES, img_channels=3, mapping_kwargs=dict(num_layers=2, cfg=gcfg),
+                  synthesis_kwargs=dict(channel_base=16384, channel_max=512, num_fp16_res=0, conv_clamp=None), cfg=gcfg)
+    D = Discriminator(c_dim=0, img_resolution=RES, img_channels=3, channel_base=16384, channel_max=512, num_fp16_res=0, conv_clamp=None,
+                      mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2), cfg=dcfg)
+    assert sum(p.numel() for p in G.parameters()) == 32105941 and sum(p.numel() for p in D.parameters()) == 25333568
+    seeded_parameters_(G, 303)
+    seeded_parameters_(D, 404)
+    g = torch.Generator().manual_seed(79)
+    B, F = 2, 3
+    z = torch.randn([B, 512], generator=g)
+    c = torch.zeros([B, 0])
+    t = torch.sort(torch.rand([B, F], generator=g) * 40, dim=1).values
+    traj_len = G.synthesis.motion_encoder.get_max_traj_len(t) + G.synthesis.motion_encoder.num_additional_codes
+    motion_z = torch.randn([B, traj_len, 512], generator=g)
+    arrays = {'z': z, 't': t, 'motion_z': motion_z}
+    G.train(); D.train()
+    ws = G.mapping(z, c, skip_w_avg_update=True)
+    arrays['ws'] = sample_flat(ws)
+    img_train = G.synthesis(ws, t=t, c=c, motion_z=motion_z)
+    arrays['img_train'] = img_train.half()       # D's input below is this rounded image on both sides (0.6 MB instead of 4.7)
+    img_in = img_train.detach().half().float()
+    arrays['img_train_sample'] = sample_flat(img_train, limit=65536)
+    arrays['logits_fake'] = D(img_in, c, t)['image_logits']
+    G.zero_grad(); D.zero_grad()
+    img = G.synthesis(G.mapping(z, c, skip_w_avg_update=True), t=t, c=c, motion_z=motion_z)
+    loss_g = torch.nn.functional.softplus(-D(img, c, t)['image_logits']).mean()
+    loss_g.backward()
+    arrays['loss_Gmain'] = loss_g
+    for name, p in G.named_parameters():
+        arrays['gradG.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p), limit=1024)
+    G.zero_grad(); D.zero_grad()
+    real = (torch.rand([B * F, 3, RES, RES], generator=torch.Generator().manual_seed(1079)) * 2 - 1).half()   # the test re-draws it (seed in meta) instead of reading 2.4 MB
+    real = real.float()
+    real_tmp = real.clone().requires_grad_(True)
+    logits_real = D(real_tmp, c, t)['image_logits']
+    (r1_grads,) = torch.autograd.grad(logits_real.sum(), real_tmp, create_graph=True)
+    r1 = r1_grads.square().sum([1, 2, 3])
+    loss_d = (torch.nn.functional.softplus(-logits_real) + (r1 * 0.5).view(-1, F).mean(dim=1)).mean()
+    loss_d.backward()
+    arrays['logits_real'] = logits_real
+    arrays['r1_penalty'] = r1
+    arrays['loss_Dreal_r1'] = loss_d
+    for name, p in D.named_parameters():
+        arrays['gradD.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p), limit=1024)
+    meta = dict(B=B, F=F, res=RES, w_dim=512, z_dim=512, seed_G=303, seed_D=404, real_seed=1079,
+                G_params=sum(p.numel() for p in G.parameters()), D_params=sum(p.numel() for p in D.parameters()))
+    save('networks_full', arrays, meta)
+
+
 def gen_augment():
     """ADA `bgc` pipeline (src/training/augment.py) at fixed percentiles of every augmentation parameter (the reference's own
     `debug_percentile` hook makes the transform deterministic), on 3-frame clips folded into 9 channels (loss.py:58-66)."""
@@ -374,5 +438,6 @@ if __name__ == '__main__':
     gen_conv_ops()
     gen_networks()
     gen_networks_mid()
+    gen_networks_full()
     gen_augment()
     gen_time_encoder()

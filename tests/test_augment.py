@@ -39,6 +39,20 @@ def test_augment_pipe_identity_at_p0_and_ada_update():
         AugmentPipe(noise=1)
 
 
+def test_static_worst_case_margin_reproduces_the_measured_margin_path():
+    """`static_margin` (what hipGraph capture needs: no device -> host read of the padding) pads by the bound the reference clamps its margin
+    to; the extra padding is never sampled, so outputs and gradients match the reference goldens like the default path does."""
+    pipe = AugmentPipe(**BGC)
+    pipe.static_margin = True
+    x0 = AUG.t('x')
+    for i, pct in enumerate(AUG.meta['percentiles']):
+        x = x0.clone().requires_grad_(True)
+        y = pipe(x, debug_percentile=pct)
+        assert_close(y, AUG.t(f'y{i}'), atol=3e-5, rtol=3e-5, what=f'static margin, percentile {pct}')
+        (dx,) = torch.autograd.grad((y * AUG.t(f'v{i}')).sum(), x)
+        assert_close(dx, AUG.t(f'dx{i}'), atol=3e-4, rtol=3e-4, what=f'static margin, input gradient at percentile {pct}')
+
+
 @pytest.mark.gpu
 def test_augment_pipe_matches_reference_gpu():
     before = custom_ops.launch_count()

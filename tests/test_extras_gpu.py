@@ -282,7 +282,7 @@ def test_reference_time_encoder_golden_on_gpu():
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
     # two trajectory convolutions + (periods | phases | left aligners) + right aligners on the dense-layer kernel, then the fused sin/cos/lerp tail
-    assert prof['gemm']['launches'] == 4 and prof['time_encode']['launches'] == 1 and prof['bias_act']['launches'] == 0, prof
+    assert prof['fc']['launches'] == 4 and prof['gemm']['launches'] == 0 and prof['time_encode']['launches'] == 1 and prof['bias_act']['launches'] == 0, prof
     assert_close(out['motion_v'], G.t('motion_v'), atol=1e-3, rtol=1e-3, what='motion_v')
     # gradients of every encoder parameter through the kernels' backward forms vs the float64 CPU evaluation of the same module
     enc64 = MotionMappingNetwork(gcfg).double()
@@ -415,6 +415,124 @@ def test_train_step_hipgraph_replay_matches_eager_schedule():
     assert moved > 10, 'the generator did not train under graph replay'
     for k in ('G/loss', 'D/loss'):
         assert torch.isfinite(ts.last_losses[k])
+
+
+def _small_train_step(**kw):
+    from stylegan_v_amd.training import config as cfgs
+    from stylegan_v_amd.training.train_step import TrainStep
+    g_kwargs, d_kwargs = cfgs.small_test_model_kwargs(res=32)
+    train_cfg = cfgs.Config(r1_gamma=1.0, lr=0.0025, betas=(0.0, 0.99), ema_kimg=1.0, ema_rampup=0.05, G_reg_interval=4, D_reg_interval=16, pl_weight=0.0)
+    return TrainStep(g_kwargs, d_kwargs, train_cfg, device='cuda', batch_gpu=4, world_size=1, **kw)
+
+
+def test_hipgraph_capture_iteration_applies_exactly_one_update():
+    """the warm-up runs before the capture must not train.  After the first (capturing) iteration the Adam step counters read 1
+    and the parameters equal an eager run's parameters after ONE update from the same state; the returned losses come from a replay."""
+    eager, graphed = _small_train_step(use_graphs=False), _small_train_step(use_graphs=True)
+    graphed.G.load_state_dict(eager.G.state_dict()); graphed.D.load_state_dict(eager.D.state_dict()); graphed.G_ema.load_state_dict(eager.G_ema.state_dict())
+    real = eager.synthetic_real_batch()
+    from stylegan_v_amd.training.train_step import sample_frame_times
+    real_t = sample_frame_times(eager.sampling, eager.batch_gpu, device='cuda')
+    for ts in (eager, graphed):
+        ts.gen = torch.Generator().manual_seed(1234)      # the same latents on both sides
+        ts.batch_idx = 1                                  # an iteration without the regularisation phases: Gmain, Dmain only
+        torch.manual_seed(7)                              # the device generator draws the motion noise / phase dropout
+        assert ts.step(real_img=real, real_t=real_t) == ['Gmain', 'Dmain']
+    torch.cuda.synchronize()
+    for phase in graphed.phases:
+        for st in phase['opt'].state.values():
+            assert float(st['step']) == 1.0, 'the capture iteration must count as ONE optimiser step'
+    # the device RNG streams of the two runs differ (graph capture registers its own philox offsets), so the comparison is on the update's
+    # size, not its bits: lr 0.0025 with Adam's first step moves every touched weight by ~lr; two extra warm-up steps would triple that
+    for (name, pe), (_, pg) in zip(eager.G.named_parameters(), graphed.G.named_parameters()):
+        if pe.numel() > 1:
+            assert (pg - pe).abs().max().item() <= 2.2 * 0.0025 * max(1.0, float(getattr(pe, 'lr_mul', 1.0))) * 100, name
+    for k in ('G/loss', 'D/loss'):
+        assert torch.isfinite(graphed.last_losses[k])
+        assert abs(float(graphed.last_losses[k]) - float(eager.last_losses[k])) < 0.5, 'losses of the capture iteration are replayed values, not pool garbage'
+
+
+def test_train_step_scopes_the_frame_time_bound_to_its_own_passes():
+    """no permanent t_bound on G / G_ema -- outside TrainStep's passes the motion encoder sizes its trajectory from t.max() again."""
+    ts = _small_train_step()
+    ts.step()
+    enc = ts.G_ema.synthesis.motion_encoder
+    assert not hasattr(enc, 't_bound') or enc.t_bound is None
+    far = torch.tensor([[0.0, 500.0, 900.0]], device='cuda')
+    assert enc.get_max_traj_len(far) == int(-(-900.0 // enc.cfg.motion.motion_z_distance)) + 2
+    with torch.no_grad():
+        img = ts.G_ema(torch.randn([1, ts.z_dim], device='cuda'), torch.zeros([1, 0], device='cuda'), far)     # long-video generation works
+    assert torch.isfinite(img).all()
+
+
+def test_train_step_graphs_with_ddp_and_ada_on_an_nccl_group_of_one():
+    """Config 4's regime: DDP (RCCL all-reduce captured with the phase), hipGraph replay and aug=ada together."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    os.environ.setdefault('MASTER_PORT', '29533')
+    os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+    try:
+        ts = _small_train_step(ddp=True, use_graphs=True, augment='ada')
+        assert ts.ddp and ts.use_graphs and ts.augment_pipe is not None and ts.augment_pipe.static_margin
+        assert ts.step() == ['Gmain', 'Greg', 'Dmain', 'Dreg']
+        torch.cuda.synchronize()
+        launches = custom_ops.launch_count()
+        ts.augment_pipe.p.fill_(0.3)        # augmentations really drawn inside the replayed graphs
+        before = {k: v.detach().clone() for k, v in ts.D.named_parameters()}
+        for _ in range(3):
+            assert ts.step() == ['Gmain', 'Dmain']
+        torch.cuda.synchronize()
+        assert set(ts._graphs) == {'Gmain', 'Dmain'}
+        assert custom_ops.launch_count() == launches, 'replayed phases must not launch from the host'
+        assert sum(int(not torch.equal(v, before[k])) for k, v in ts.D.named_parameters()) > 10
+        for name, p in list(ts.G.named_parameters()) + list(ts.D.named_parameters()):
+            assert torch.isfinite(p).all(), name
+        assert torch.isfinite(ts.last_losses['D/loss']) and 'signs_real' in ts.last_losses
+        # and the eager schedule on the same kind of instance reaches the same loss range (same models, same data distribution)
+        te = _small_train_step(ddp=True, use_graphs=False, augment='ada')
+        te.step(); te.step()
+        assert abs(float(te.last_losses['D/loss']) - float(ts.last_losses['D/loss'])) < 1.0
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_multi_tensor_nan_to_num_matches_torch_per_tensor():
+    """sgv_multi_nan_to_num_f32 (training_loop.py:384-386 as one launch): 200 tensors of ragged sizes incl. empty, unaligned views and tails."""
+    from stylegan_v_amd.torch_utils import misc
+    g = torch.Generator().manual_seed(3)
+    sizes = [0, 1, 3, 4095, 4096, 4097, 70000] + [int(v) for v in torch.randint(1, 30000, [193], generator=g)]
+    base = [torch.randn([n + 1], generator=g).to(DEV) for n in sizes]
+    tensors = [b[1:] if i % 5 == 0 else b[:-1] for i, b in enumerate(base)]      # every fifth one is a 4-byte-offset (unaligned) view
+    for i, t in enumerate(tensors):
+        if t.numel():
+            idx = torch.randint(0, t.numel(), [min(t.numel(), 7)], generator=g).to(DEV)
+            t[idx] = torch.tensor([float('nan'), float('inf'), -float('inf'), 3e38, -3e38, 0.0, 1.0])[:idx.numel()].to(DEV)
+    want = [torch.nan_to_num(t, nan=0.0, posinf=1e5, neginf=-1e5) for t in tensors]
+    before = custom_ops.launch_count()
+    misc.nan_to_num_list_(tensors, nan=0.0, posinf=1e5, neginf=-1e5)
+    assert custom_ops.launch_count() - before == 3          # 199 non-empty tensors, 96 per launch
+    for t, w in zip(tensors, want):
+        assert torch.equal(t, w)
+
+
+def test_fma_reference_golden_on_gpu():
+    """a9: `fma(a, b, c)` and its broadcast-aware gradients (src/torch_utils/ops/fma.py:15-58) against the reference golden, on the device."""
+    from stylegan_v_amd.torch_utils.ops import fma
+    G = Golden('conv_ops')       # float64 fixture: run in float64 and in float32 on the device
+    for dt, tol in ((torch.float64, 1e-12), (torch.float32, 2e-5)):
+        a, b, c = (G.t('fma_' + n, dtype=dt, device=DEV).requires_grad_(True) for n in 'abc')
+        y = fma.fma(a, b, c)
+        assert y.is_cuda and y.dtype == dt
+        assert_close(y, G.t('fma_y'), atol=tol, rtol=tol, what='fma y')
+        grads = torch.autograd.grad(y, [a, b, c], G.t('fma_dy', dtype=dt, device=DEV))
+        for gname, gt, ref in zip(('da', 'db', 'dc'), grads, (a, b, c)):
+            assert gt.shape == ref.shape
+            assert_close(gt, G.t('fma_' + gname), atol=tol * 10, rtol=tol * 10, what='fma ' + gname)
 
 
 def test_gemm_conv1x1_adds_a_residual_in_its_store():
