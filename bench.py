@@ -128,9 +128,11 @@ def main():
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline leg; 0 disables it')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
+    ap.add_argument('--clean-steps', type=int, default=-1, help='steps of the un-instrumented repeat of the timed window (value_no_prof); -1 = --steps, 0 disables it')
     ap.add_argument('--ada-steps', type=int, default=8, help="steps of the aug=ada companion measurement (the reference's default augmentation, bgc pipeline); 0 disables it")
     ap.add_argument('--bf16-steps', type=int, default=6, help='steps of the bf16-products companion measurement (fp32 tensors, one bf16 MFMA per product); 0 disables it')
     ap.add_argument('--strict-steps', type=int, default=8, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
+    ap.add_argument('--pl-steps', type=int, default=8, help='steps of the path-length-regularisation companion (F=1, pl_weight=2); 0 disables it')
     ap.add_argument('--aug', choices=['noaug', 'ada'], default='noaug', help="discriminator augmentation: the reference's default is ada (bgc pipeline, adaptive p)")
     ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs (single GPU; pays off at small per-GPU batches)')
     ap.add_argument('--lowp', choices=['none', 'fp16', 'bf16'], default='none',
@@ -205,6 +207,11 @@ def main():
         if rank == 0:
             with open(os.environ['SGV_TORCH_PROFILE'], 'w') as fh:
                 fh.write(prof_t.key_averages(group_by_input_shape=True).table(sort_by='cuda_time_total', row_limit=120, max_name_column_width=60, max_shapes_column_width=90))
+                # every op / kernel by call count (two steps): who issues the small launches
+                avgs = sorted(prof_t.key_averages(), key=lambda e: -e.count)
+                fh.write('\n\n%-90s %8s %12s %12s\n' % ('name (all ops and kernels of 2 steps, by call count)', 'calls', 'cpu ms', 'device ms'))
+                for e in avgs[:300]:
+                    fh.write('%-90s %8d %12.3f %12.3f\n' % (e.key[:90], e.count, e.cpu_time_total / 1e3, getattr(e, 'device_time_total', getattr(e, 'cuda_time_total', 0.0)) / 1e3))
         ts.batch_idx = 0
     # Per-launch HIP events (two event packets around every native launch, ~2,500 launches per step) cost 2.5-4 % of the step when they are
     # recorded on every step (same box: 549-559 img/s with, 572-574 without; profiles/r02_bench_prof_overhead.log).  They are therefore recorded on
@@ -223,9 +230,23 @@ def main():
     elapsed = time.perf_counter() - t0
     launches = custom_ops.launch_count() - launches0
     prof = None
+    ufd_by_size = None
     if not args.no_prof:
         custom_ops.prof_disable()
-        prof = custom_ops.prof_collect()
+        records = custom_ops.prof_collect_records(1 << 17)
+        prof = {name: dict(launches=0, ms=0.0, bytes=0.0, flops=0.0) for name in custom_ops.SGV_K_NAMES}
+        sizes = {}
+        for fam, ms, nbytes, nflops in records:
+            e = prof[fam]
+            e['launches'] += 1; e['ms'] += ms; e['bytes'] += nbytes; e['flops'] += nflops
+            if fam == 'upfirdn2d_lanes':
+                g = sizes.setdefault(int(nbytes), [0, 0.0])
+                g[0] += 1; g[1] += ms
+        for key in ('launches', 'ms', 'bytes', 'flops'):      # 'conv3x3' is the whole family incl. its largest member 'conv3x3_s1' (as custom_ops.prof_collect)
+            prof['conv3x3'][key] += prof['conv3x3_s1'][key]
+        # the upfirdn2d launches of the sample grouped by their algorithmic byte count (= by layer size and fused mode): where the size-weighted mean comes from
+        ufd_by_size = [dict(algorithmic_MB=b / 1e6, launches=n, avg_us=1e3 * ms / n, GBps=b * n / (ms * 1e-3) / 1e9, share_of_family_time=ms / max(prof['upfirdn2d_lanes']['ms'], 1e-9))
+                       for b, (n, ms) in sorted(sizes.items(), reverse=True)]
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -233,6 +254,24 @@ def main():
     elapsed = float(t_max.item())
     frames_total = global_batch * args.frames * args.steps
     value = frames_total / elapsed
+
+    # The same K steps once more WITHOUT the per-launch event recording (`value` carries the recorder's own cost on half of its steps, 1.5-2 %):
+    # same schedule start, same bracket, MAX over ranks -> `value_no_prof`.
+    value_no_prof = None
+    if not args.no_prof and args.clean_steps != 0:
+        k_clean = args.steps if args.clean_steps < 0 else args.clean_steps
+        ts.batch_idx = 0
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(k_clean):
+            ts.step()
+        barrier()
+        t_c = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(t_c, op=torch.distributed.ReduceOp.MAX)
+        value_no_prof = dict(value=global_batch * args.frames * k_clean / float(t_c.item()), ms_per_step=1e3 * float(t_c.item()) / k_clean, steps=k_clean)
+    elif args.no_prof:
+        value_no_prof = dict(value=value, ms_per_step=1e3 * elapsed / args.steps, steps=args.steps)
 
     # Strict-fp32 companion (the reference's fp32 mode is allow_tf32=False, training_loop.py:129,141-142): the same step with every
     # 3x3 convolution on the vendor library's fp32 kernels instead of the split-bf16 matrix-pipe kernels.  Same schedule start
@@ -312,6 +351,39 @@ def main():
         finally:
             ts.set_augment('noaug')
 
+    # Path-length companion ("time PL in a separate F=1 run"): the reference's PL term only runs with one frame per video
+    # (loss.py:117), so this is config 3 with num_frames_per_video = 1 and pl_weight = 2 (the StyleGAN2 default, train.py:189): Gmain, Greg (PL:
+    # second order through G) every 4th, Dmain, Dreg every 16th; its own models (the frame count changes D's input layer), same bracket.
+    plc = None
+    if args.pl_steps > 0 and lowp is None and not args.graphs:
+        g_kw1, d_kw1, train_cfg1 = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=True, num_frames_per_video=1)
+        train_cfg1.pl_weight = 2.0
+        ts1 = TrainStep(g_kw1, d_kw1, train_cfg1, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, augment='noaug')
+        try:
+            tw = time.perf_counter()
+            ts1.step(); ts1.step()
+            torch.cuda.synchronize()
+            if rank == 0:
+                log(f'[bench] PL / F=1 companion: warm-up {time.perf_counter() - tw:.1f} s')
+            ts1.batch_idx = 0
+            barrier()
+            t1 = time.perf_counter()
+            pl_phases = {}
+            for _ in range(args.pl_steps):
+                for name in ts1.step():
+                    pl_phases[name] = pl_phases.get(name, 0) + 1
+            barrier()
+            t_p = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            if world > 1:
+                torch.distributed.all_reduce(t_p, op=torch.distributed.ReduceOp.MAX)
+            plc = dict(value=global_batch * 1 * args.pl_steps / float(t_p.item()), ms_per_step=1e3 * float(t_p.item()) / args.pl_steps, steps=args.pl_steps, phases_run=pl_phases,
+                       pl_penalty=float(ts1.last_losses.get('G/reg', float('nan'))),
+                       what='config 3 with num_frames_per_video=1 and pl_weight=2: Gmain + Greg (path-length regularisation, double backward through G, batch shrink 2) '
+                            'every 4th + Dmain + Dreg (R1) every 16th; frames/s = videos/s here')
+        finally:
+            del ts1
+            torch.cuda.empty_cache()
+
     F32_LABEL = 'f32' if conv2d_gradfix.native_conv_terms == 0 and conv2d_gradfix.native_wrw_terms == 0 else \
         'fp32 I/O + fp32 accumulate everywhere; 3x3 convolution products are 2-way-bf16-split (hi/lo, 3 MFMAs per product: 16-bit mantissa operands, 4e-6 rel. error vs fp64; NOT strict fp32 -- see value_strict_fp32)'
     if rank == 0:
@@ -384,8 +456,9 @@ def main():
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
                                native_launches_per_step=launches / args.steps, hip_graphs=bool(ts.use_graphs)),
-                   value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c,
-                   roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, kernels=kernels, cpu_baseline=cpu)
+                   value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof,
+                   value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
+                   roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, upfirdn2d_by_size=ufd_by_size, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -469,6 +469,14 @@ typedef struct sgv_prof_entry {
 int sgv_prof_enable(int32_t max_records); /* allocates the event pool (host side only) */
 int sgv_prof_disable(void);
 int sgv_prof_collect(sgv_prof_entry* out /* [SGV_K_COUNT] */); /* syncs events, resets pool */
+/* The same, launch by launch (in launch order) instead of summed per family: fills at most `max_records` entries, returns the number of recorded
+ * launches (which may exceed max_records), or a negative SGV_ERR_* code.  Resets the pool like sgv_prof_collect. */
+typedef struct sgv_prof_record {
+    int32_t family; /* enum sgv_kernel_family */
+    float ms;
+    double bytes, flops;
+} sgv_prof_record;
+int sgv_prof_collect_records(sgv_prof_record* out, int32_t max_records);
 
 /* Total number of kernel launches issued through this library since load (all threads). */
 int64_t sgv_launch_count(void);

@@ -84,6 +84,22 @@ extern "C" int sgv_prof_collect(sgv_prof_entry* out) {
     return SGV_OK;
 }
 
+extern "C" int sgv_prof_collect_records(sgv_prof_record* out, int32_t max_records) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!out || max_records < 0) return sgv_fail(SGV_ERR_INVALID_ARG, "sgv_prof_collect_records: bad output array");
+    int n = g_prof_next.load();
+    if (n > (int)g_prof_pool.size()) n = (int)g_prof_pool.size();
+    for (int i = 0; i < n; i++) {
+        prof_record& r = g_prof_pool[i];
+        if (hipEventSynchronize(r.stop) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_collect_records: event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) ms = 0.f;
+        if (i < max_records) out[i] = sgv_prof_record{r.family, ms, r.bytes, r.flops};
+    }
+    g_prof_next = 0;
+    return n;
+}
+
 sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops) : slot(-1), stream(s) {
     g_launches.fetch_add(1, std::memory_order_relaxed);
     if (!g_prof_on.load(std::memory_order_relaxed)) return;

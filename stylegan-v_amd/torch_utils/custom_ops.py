@@ -237,6 +237,10 @@ class FcParams(ctypes.Structure):
                 ('batch', c_int32), ('a_stride_batch', c_int64), ('b_stride_batch', c_int64), ('c_stride_batch', c_int64), ('accumulate', c_int32)]
 
 
+class ProfRecord(ctypes.Structure):
+    _fields_ = [('family', c_int32), ('ms', c_float), ('bytes', c_double), ('flops', c_double)]
+
+
 class ProfEntry(ctypes.Structure):
     _fields_ = [('launches', c_int64), ('ms', c_double), ('bytes', c_double), ('flops', c_double)]
 
@@ -283,6 +287,7 @@ ABI_SYMBOLS = {
     'sgv_prof_enable': (c_int, [c_int32]),
     'sgv_prof_disable': (c_int, []),
     'sgv_prof_collect': (c_int, [ctypes.POINTER(ProfEntry)]),
+    'sgv_prof_collect_records': (c_int, [ctypes.POINTER(ProfRecord), c_int32]),
     'sgv_launch_count': (c_int64, []),
     'sgv_variant_count': (c_int64, [c_int32]),
     'sgv_variant_name': (ctypes.c_char_p, [c_int32]),
@@ -358,6 +363,15 @@ def prof_enable(max_records=1 << 16):
 
 def prof_disable():
     check(get_native().sgv_prof_disable())
+
+
+def prof_collect_records(max_records=1 << 16):
+    """[(family name, ms, algorithmic bytes, algorithmic flops)] per recorded launch, in launch order (resets the pool)."""
+    recs = (ProfRecord * max_records)()
+    n = get_native().sgv_prof_collect_records(recs, max_records)
+    if n < 0:
+        check(n)
+    return [(SGV_K_NAMES[r.family], float(r.ms), float(r.bytes), float(r.flops)) for r in recs[:min(n, max_records)]]
 
 
 def prof_collect():

@@ -15,11 +15,14 @@ import torch
 
 from .. import custom_ops
 from . import bias_act as _ba
+from . import fused_conv_act as _fca
 from . import modulation as _mod
 from . import upfirdn2d as _ufd
 from .upfirdn2d import _DTYPE_CODES
 
-enabled = True  # module switch (training with path-length regularisation needs double backward -> composition)
+enabled = True  # module switch.  Second order: passes known to be differentiated twice (path-length regularisation, R1; training/loss.py) run under
+                # ``fused_conv_act.composition_only()`` and take the composition; a fused node whose gradient is differentiated anyway
+                # (``create_graph=True``) switches its backward to the composition on the saved inputs -- gradients of any order exist.
 
 
 def fir_bias_act_composed(x, f, scale=None, bias=None, padding=1, fir_gain=1, act='lrelu', alpha=None, gain=None, clamp=None, flip_filter=False):
@@ -43,6 +46,7 @@ class _FusedFirBiasActFn(torch.autograd.Function):
     def forward(ctx, x, f, scale, bias, cfg):
         pads, fir_gain, flip, act, alpha, gain, clamp = cfg
         lib = custom_ops.get_native()
+        x_in = x
         x = x.contiguous()
         n, c, h, w = x.shape
         fh, fw = f.shape
@@ -59,14 +63,26 @@ class _FusedFirBiasActFn(torch.autograd.Function):
         ctx.x_shape = x.shape
         ctx.has_scale, ctx.has_bias = scale is not None, bias is not None
         ctx.scale_shape = scale.shape if scale is not None else None
-        ctx.save_for_backward(y, f, sc, bi)
+        # x, scale and bias themselves (with their history) serve the create_graph path of backward; holding x alive costs memory, not bandwidth
+        ctx.save_for_backward(y, f, sc, bi, x_in, scale, bias)
         return y
 
     @staticmethod
-    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         pads, fir_gain, flip, act, alpha, gain, clamp = ctx.cfg
-        y, f, sc, bi = ctx.saved_tensors
+        y, f, sc, bi, x_in, scale, bias = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # create_graph=True (this gradient is differentiated again, e.g. a path-length or R1 pass that did not announce itself through
+            # `composition_only()`): differentiate the composition on the saved inputs instead -- one extra forward, gradients of any order.
+            ins = [t for t, need in zip((x_in, scale, bias), (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])) if need and t is not None]
+            with torch.enable_grad():
+                y2 = fir_bias_act_composed(x_in, f, scale=scale, bias=bias, padding=list(pads), fir_gain=fir_gain, act=act, alpha=alpha, gain=gain,
+                                           clamp=(clamp if clamp >= 0 else None), flip_filter=flip)
+                grads = iter(torch.autograd.grad(y2, ins, dy, create_graph=True, allow_unused=True))
+            g_x = next(grads) if (ctx.needs_input_grad[0]) else None
+            g_s = next(grads) if (ctx.needs_input_grad[2] and scale is not None) else None
+            g_b = next(grads) if (ctx.needs_input_grad[3] and bias is not None) else None
+            return g_x, None, g_s, g_b, None
         lib = custom_ops.get_native()
         dy = dy.contiguous()
         n, c, ih, iw = ctx.x_shape
@@ -91,6 +107,8 @@ class _FusedFirBiasActFn(torch.autograd.Function):
 
 
 def _fusable(x, f, scale, bias, pads, act, alpha):
+    if _fca._composition_depth > 0:     # a pass that is differentiated twice: evaluate the definition
+        return False
     if not (enabled and x.is_cuda and x.ndim == 4 and x.dtype in (torch.float32, torch.float16, torch.bfloat16)):
         return False
     if f is None or f.ndim != 2 or f.shape[0] > 4 or f.shape[1] > 4 or not f.is_cuda:
@@ -99,7 +117,7 @@ def _fusable(x, f, scale, bias, pads, act, alpha):
         return False
     if scale is not None and (scale.dtype != torch.float32 or scale.numel() != x.shape[0] * x.shape[1]):
         return False
-    return True  # the fused node is first-order only: differentiating it twice raises (once_differentiable); see `enabled`
+    return True
 
 
 def fir_bias_act(x, f, scale=None, bias=None, padding=1, fir_gain=1, act='lrelu', alpha=None, gain=None, clamp=None, flip_filter=False):

@@ -76,9 +76,6 @@ class TrainStep:
                 mod.requires_grad_(False)
             for p in misc.params_and_buffers(self.G_ema):  # G_ema: sync initial values only
                 torch.distributed.broadcast(p, src=0)
-        if train_cfg.pl_weight != 0:  # path-length regularisation differentiates G twice: the fused epilogue node is first-order only
-            from ..torch_utils.ops import fused_fir_act
-            fused_fir_act.enabled = False
         # Discriminator augmentation (train.py:238-277, training_loop.py:197-205): 'ada' = the bgc pipeline with p starting at 0 and adapted
         # every `ada_interval` iterations from the sign of D's outputs on real clips; one transform per video (configs/model/stylegan-v.yaml:58).
         self.augment_pipe, self.ada = None, None
@@ -108,9 +105,9 @@ class TrainStep:
         # motion encoder (motion.frame_times_bounded_by) instead of reading t.max() back from the device.  The promise is scoped to
         # `_run_phase`: G / G_ema used outside of it (evaluation, long-video generation) keep the reference's t.max() behaviour.
         self._t_bound = float(self.sampling.max_num_frames - 1)
-        # hipGraph replay of the two every-iteration phases (small per-GPU batches are launch-bound).  Works with DDP (the RCCL all-reduce
-        # is captured with the phase; 11 eager DDP iterations precede the capture, torch's DDP-under-graphs recipe) and with ADA (the pipe
-        # pads by its static worst-case margin while graphs are on, so that nothing is read back to the host).
+        # hipGraph replay of the two every-iteration phases (small per-GPU batches are launch-bound).  Works with DDP (the graph's backward
+        # runs un-synchronised, one flat RCCL all-reduce of the gradients follows the replay) and with ADA (the pipe pads by its static
+        # worst-case margin while graphs are on, so that nothing is read back to the host).
         self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
         self._graphs = {}
         if self.use_graphs:
@@ -150,20 +147,38 @@ class TrainStep:
         return z, c, t
 
     # -- one phase: zero_grad -> accumulate_gradients -> nan_to_num -> Adam (training_loop.py:351-389) -----------------
-    def _run_phase(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
+    def _phase_gradients(self, phase, sync, real_img, real_c, real_t, gen_z, gen_c, gen_t):
         phase['opt'].zero_grad(set_to_none=True)
         phase['module'].requires_grad_(True)
         with motion.frame_times_bounded_by(self._t_bound):
             losses = self.loss.accumulate_gradients(phase=phase['name'], real_img=real_img, real_c=real_c, real_t=real_t, gen_z=gen_z,
-                                                    gen_c=gen_c, gen_t=gen_t, sync=True, gain=phase['interval'])
+                                                    gen_c=gen_c, gen_t=gen_t, sync=sync, gain=phase['interval'])
         phase['module'].requires_grad_(False)
+        return losses
+
+    def _phase_update(self, phase):
         grads = [p.grad for p in phase['module'].parameters() if p.grad is not None]
         if grads:
             sanitize_gradients_(grads)
         phase['opt'].step()
+
+    def _run_phase(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
+        losses = self._phase_gradients(phase, True, real_img, real_c, real_t, gen_z, gen_c, gen_t)
+        self._phase_update(phase)
         return losses
 
-    # -- the same phase as ONE hipGraph launch ------------------------------------------------------------------------------------
+    def _allreduce_gradients(self, phase):
+        """Average the phase module's gradients over the ranks as ONE flat all-reduce (what DDP's buckets do during backward in the eager path).
+        Used behind a replayed hipGraph, whose backward pass ran with DDP's own synchronisation off."""
+        grads = [p.grad for p in phase['module'].parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        torch.distributed.all_reduce(flat)
+        flat.mul_(1.0 / self.world_size)
+        torch._foreach_copy_(grads, [v.view_as(g) for v, g in zip(flat.split([g.numel() for g in grads]), grads)])
+
+    # -- the same phase as hipGraph launches --------------------------------------------------------------------------------------
     def _training_state(self, phase):
         """Every tensor a run of `phase` may write: parameters and buffers of G and D (the generator's w_avg moves in every G pass) and the
         phase's optimiser state."""
@@ -172,11 +187,14 @@ class TrainStep:
         return tensors, opt_state
 
     def _run_phase_graph(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
-        """First call of a phase: eager warm-up runs on a side stream (library initialisation, allocator warm-up, Adam state allocation,
-        DDP bucket rebuild) -- on the LIVE models, so parameters, buffers and optimiser state are put back afterwards: the warm-up must not
-        count as training -- then the capture (which executes nothing) and ONE replay, which is this iteration's update.  Later calls copy the
-        inputs into the captured buffers and replay.  Every kernel of the native library launches on torch's current stream without
-        allocating or synchronising, so it is capture-safe as is."""
+        """A phase as two hipGraphs: (A) zero_grad + forward + backward, (B) gradient sanitising + Adam; under DDP the gradient all-reduce runs
+        eagerly between them (the graph's backward pass has DDP's own synchronisation switched off, so no collective is captured -- capturing
+        RCCL inside DDP's reducer crashed `capture_end` on ROCm 7.2 / torch 2.10).
+        First call of a phase: eager warm-up runs on a side stream (library initialisation, allocator warm-up, Adam state allocation) -- on
+        the LIVE models, so parameters, buffers and optimiser state are put back afterwards: the warm-up must not count as training -- then the
+        two captures (which execute nothing) and one replay of each, which is this iteration's update.  Later calls copy the inputs into the
+        captured buffers and replay.  Every kernel of the native library launches on torch's current stream without allocating or
+        synchronising, so it is capture-safe as is."""
         name = phase['name']
         entry = self._graphs.get(name)
         if entry is None:
@@ -187,8 +205,9 @@ class TrainStep:
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
-                for _ in range(11 if self.ddp else 2):
-                    self._run_phase(phase, **static)
+                for _ in range(2):
+                    self._phase_gradients(phase, False, **static)
+                    self._phase_update(phase)
                 with torch.no_grad():
                     for t, s0 in zip(tensors, saved):
                         t.copy_(s0)
@@ -196,14 +215,19 @@ class TrainStep:
                         s0 = saved_opt.get((id(p), k))
                         v.copy_(s0) if s0 is not None else v.zero_()
             torch.cuda.current_stream(self.device).wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                out = self._run_phase(phase, **static)
-            entry = self._graphs[name] = dict(graph=graph, static=static, out=out)
+            g_grad, g_upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_grad):
+                out = self._phase_gradients(phase, False, **static)
+            with torch.cuda.graph(g_upd, pool=g_grad.pool()):
+                self._phase_update(phase)
+            entry = self._graphs[name] = dict(grad=g_grad, update=g_upd, static=static, out=out)
         else:
             for key, val in (('real_img', real_img), ('real_c', real_c), ('real_t', real_t), ('gen_z', gen_z), ('gen_c', gen_c), ('gen_t', gen_t)):
                 entry['static'][key].copy_(val)
-        entry['graph'].replay()
+        entry['grad'].replay()
+        if self.ddp:
+            self._allreduce_gradients(phase)
+        entry['update'].replay()
         return {k: v.clone() for k, v in entry['out'].items()}
 
     # -- one iteration ----------------------------------------------------------------------------

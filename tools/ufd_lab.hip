@@ -415,6 +415,99 @@ __global__ __launch_bounds__(256) void k_cols4_asm(P p, int colgroups, int strip
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// ---------------- V6: tile through LDS, every load of the workgroup issued up front (copy-like request pattern) ----------------
+// A workgroup of NW waves owns TR = 4 NW output rows x 256 output columns of one plane.  Load phase: the TR + 3 input rows are dealt round-robin
+// to the waves; a wave issues ALL its row loads (16 B per lane + the 3-column right halo by lanes 0..2) back to back, undoes the edge clamp,
+// and parks the rows -- zero padding included -- in LDS.  One barrier.  Compute phase: wave w produces output rows 4w .. 4w+3 from LDS rows
+// 4w .. 4w+6 (two aligned ds_read_b128 per lane and row: own four columns + the next four), same fmaf order as every other variant.
+// Short-lived workgroups whose requests all leave at t = 0, like the float4 copy that reaches 6.2 TB/s; over-fetch (TR + 3) / TR.
+template <int NW, int NT>
+__global__ __launch_bounds__(64 * NW) void k_tile(P p, int colgroups, int tiles_y) {
+    constexpr int TR = 4 * NW, ROWS = TR + 3, PITCH = 264;     // floats per LDS row (256 + 4 halo + 4 pad; 16-byte aligned rows)
+    __shared__ float lds[ROWS * PITCH];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ty = blockIdx.x % tiles_y;
+    const int cg = (blockIdx.x / tiles_y) % colgroups;
+    const int pl = blockIdx.x / (tiles_y * colgroups);
+    float ff[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) ff[a][b] = p.f[(3 - a) * 4 + (3 - b)];
+    const float* xp = p.x + (size_t)pl * p.in_h * p.in_w;
+    float* yp = p.y + (size_t)pl * p.out_h * p.out_w;
+    const int ox = cg * 256 + lane * 4;
+    const int ix0 = ox - p.pad;
+    const int base = min(max(ix0, 0), p.in_w - 4);
+    const int sh = base - ix0;
+    const bool lane_dead = (ix0 >= p.in_w) || (ix0 + 3 < 0);
+    const int ixh = cg * 256 + 256 - p.pad + lane;
+    const bool halo_ok = lane < 3 && ixh >= 0 && ixh < p.in_w;
+    const int ixh_c = min(max(ixh, 0), p.in_w - 1);
+    const int oy0 = ty * TR;
+    const int iy0 = oy0 - p.pad;
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    constexpr int RPW = (ROWS + NW - 1) / NW;        // rows per wave in the load phase
+    f4v m[RPW]; float h[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = wave + k * NW;                  // tile row
+        const int iy = min(max(iy0 + r, 0), p.in_h - 1);
+        const float* row = xp + (size_t)iy * p.in_w;
+        if (r < ROWS) {
+            m[k] = NT ? __builtin_nontemporal_load((const f4v*)(row + base)) : *(const f4v*)(row + base);
+            h[k] = lane < 3 ? row[ixh_c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = wave + k * NW;
+        if (r >= ROWS) continue;
+        const int iy = iy0 + r;
+        const bool row_ok = iy >= 0 && iy < p.in_h;
+        f4v o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float v = m[k][i];
+#pragma unroll
+            for (int d = 1; d <= 3; d++) {
+                if (i - d >= 0) v = (sh == d) ? m[k][i - d] : v; else v = (sh == d) ? 0.f : v;
+                if (i + d < 4) v = (sh == -d) ? m[k][i + d] : v; else v = (sh == -d) ? 0.f : v;
+            }
+            o[i] = (row_ok && !lane_dead) ? v : 0.f;
+        }
+        *(f4v*)(lds + r * PITCH + lane * 4) = o;
+        if (lane < 4) lds[r * PITCH + 256 + lane] = (row_ok && halo_ok) ? h[k] : 0.f;    // lane 3 writes the pad word (zero)
+    }
+    __syncthreads();
+    float win[7][8];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const f4v a = *(const f4v*)(lds + (4 * wave + r) * PITCH + lane * 4);
+        const f4v b = *(const f4v*)(lds + (4 * wave + r) * PITCH + lane * 4 + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { win[r][i] = a[i]; win[r][4 + i] = b[i]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int oy = oy0 + 4 * wave + k;
+        if (oy >= p.out_h) break;
+        f4v sv;
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[k + j][v + i], ff[j][i], acc);
+            sv[v] = acc * p.gain;
+        }
+        if (ox < p.out_w) __builtin_nontemporal_store(sv, (f4v*)(yp + (size_t)oy * p.out_w + ox));
+    }
+}
+
 int main(int argc, char** argv) {
     int N = argc > 1 ? atoi(argv[1]) : 32;
     int C = 64, IH = argc > 2 ? atoi(argv[2]) : 257, IW = IH, pad = argc > 3 ? atoi(argv[3]) : 1;
@@ -454,8 +547,9 @@ int main(int argc, char** argv) {
         }
         float best = 1e9, tot = 0; int reps = 12;
         for (int r = 0; r < reps; r++) {
-            CK(hipEventRecord(e0)); launch(x[r % NBUF], y); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); best = ms < best ? ms : best; tot += ms;
+            // four back-to-back launches per bracket: the host-side cost of a launch (the C ABI plans inside its call) hides behind the previous kernel
+            CK(hipEventRecord(e0)); for (int q = 0; q < 4; q++) launch(x[(r + q) % NBUF], y); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms *= 0.25f; best = ms < best ? ms : best; tot += ms;
         }
         double gb = (nx + ny) * 4 / 1e9;
         printf("%-34s avg %8.4f ms  min %8.4f ms   %7.1f GB/s (min %7.1f)  %5.1f%% of 8 TB/s\n", name, tot / reps, best, gb / (tot / reps) * 1e3, gb / best * 1e3, gb / (tot / reps) * 1e3 / 80.0);
@@ -490,6 +584,13 @@ int main(int argc, char** argv) {
 #define RUN4A(PFV, NTV, AB) { std::string nm = std::string("V3 ablation ") + #AB + " PF" + #PFV + " NT" + #NTV + " strip " + std::to_string(sh); \
           bench(nm.c_str(), [&](const float* xi, float* yo) { P r = q4; r.x = xi; r.y = yo; hipLaunchKernelGGL((k_cols4<PFV, NTV, AB>), dim3((unsigned)((waves4 + 3) / 4)), dim3(256), 0, 0, r, cgs4, strips4); }, false); }
         RUN4A(4, 1, 1) RUN4A(4, 1, 2) RUN4A(1, 1, 2) RUN4A(4, 2, 2)
+    }
+
+    if (OW % 4 == 0) {
+#define RUN6(NWV, NTV) { const int TRv = 4 * NWV; int tiles_y = (OH + TRv - 1) / TRv; int cgs6 = (OW + 255) / 256; long blocks = (long)planes * cgs6 * tiles_y; \
+          std::string nm = std::string("V6 LDS tile, loads up front, ") + std::to_string(TRv) + " rows NT" + #NTV; \
+          bench(nm.c_str(), [&](const float* xi, float* yo) { P r = p; r.x = xi; r.y = yo; hipLaunchKernelGGL((k_tile<NWV, NTV>), dim3((unsigned)blocks), dim3(64 * NWV), 0, 0, r, cgs6, tiles_y); }, true); }
+        RUN6(4, 0) RUN6(4, 1) RUN6(8, 0) RUN6(8, 1) RUN6(16, 0)
     }
     for (int sh : std::vector<int>{}) {
         int strips = (OH + sh - 1) / sh;
