@@ -896,6 +896,204 @@ __global__ __launch_bounds__(256) void upfirdn2d_fir_asm_kernel(lanes_params p) 
     rows(oy_a + 3 * PF, sb);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Tile kernel: the FIR passes (up = down = 1, filter <= 4x4, pad 0..3) of any width -- the pass after an up-sampling convolution (2r+1 -> 2r),
+// the pass in front of a strided one (r -> r+1) and their gradients; plain (EPI = 0), with the synthesis layer's forward epilogue (EPI = 1,
+// sgv_upfirdn2d_fused mode 1) or with the backward epilogue of "activation, then FIR" (EPI = 3, mode 3).
+//
+// Round 3 (tools/ufd_lab.hip V6, profiles/r03_ufd_lab_tile.log): a workgroup of 4 waves owns 16 output rows x 64 lanes x 4 (+1) output columns.
+// LOAD phase: the 19 input rows of the tile are dealt round-robin to the waves and EVERY load of the workgroup leaves at t = 0 -- per row one
+// 16-byte load per lane (the window clamped into the row, shifted back with selects) plus the 3 (+1) right-halo columns by the first lanes of a
+// row -- exactly the request pattern of the float4 copy that reaches 6.2-6.4 TB/s on this part, instead of a strip walk that interleaves
+// loads, arithmetic and stores for the lifetime of a wave (lanes kernel 5.0-5.3, asm-load strip kernel 5.4-5.6 on the headline call; this
+// kernel 5.8-6.0).  The rows are parked, zero padding included, in LDS; one barrier.  COMPUTE phase: wave w produces output rows 4w .. 4w+3
+// from LDS rows 4w .. 4w+6 (two aligned ds_read_b128 per lane and row: its own four columns and the next four), one fmaf chain per output in the
+// reference's tap order (rows, then columns) -- bit-identical to the oracle like every other path -- and streams the rows out.  No inline
+// asm, no counted waits: nothing here depends on what the compiler does with registers an asm load has not yet written.
+// Narrow planes (<= 128 columns): 64 >> lpr_log2 planes sit side by side in the 64 lanes, each with its own halo words in the LDS row.
+struct tile_params {
+    const void* x;
+    const float* f;
+    void* y;
+    int flip;
+    float gain;
+    int in_w, in_h, out_w, out_h;
+    int planes;
+    int f_w, f_h;
+    int64_t f_sw, f_sh;
+    int pad_x, pad_y;
+    int lpr_log2;      // lanes per plane row = 1 << lpr_log2 (64: one plane per wave row, col_groups column groups of 256 outputs)
+    int col_groups;
+    int row_tiles;     // ceil(out_h / 16)
+    int nt_store;
+    const float* ep_scale;  // EPI 1: [planes] or NULL
+    const float* ep_bias;   // EPI 1: [chans] or NULL
+    const void* ep_yref;    // EPI 3: the forward output, OUTPUT-shaped
+    float* ep_sum_g;        // EPI 3: [planes], += sum of the result over the plane
+    int ep_act;
+    float ep_alpha, ep_gain, ep_clamp;
+    int chans;
+};
+
+constexpr int TILE_ROWS = 16, TILE_IN_ROWS = TILE_ROWS + 3;
+inline int tile_lds_floats(int lpr_log2) { return TILE_IN_ROWS * (64 >> lpr_log2) * ((4 << lpr_log2) + 8); }
+
+template <typename T, int XTRA, int EPI>
+__global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
+    constexpr int NH = 3 + XTRA, NOUT = 4 + XTRA;
+    extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rt = blockIdx.x % p.row_tiles;
+    const int cg = (blockIdx.x / p.row_tiles) % p.col_groups;
+    const int pg = blockIdx.x / (p.row_tiles * p.col_groups);
+    const int lpr = 1 << p.lpr_log2;
+    const int sub = lane & (lpr - 1), slot = lane >> p.lpr_log2;
+    const int plane = pg * (64 >> p.lpr_log2) + slot;
+    const bool plane_ok = plane < p.planes;
+    const int seg_pitch = 4 * lpr + 8;                        // floats of one plane's row in LDS: 4 per lane + the halo words (16-byte aligned)
+    const int row_pitch = (64 >> p.lpr_log2) * seg_pitch;
+    float ff[4][4];
+    {   // lane t < 16 fetches tap (t/4, t%4); v_readlane broadcasts the 16 values into SGPRs (same indexing as the lanes kernel)
+        const int ta = (lane >> 2) & 3, tb = lane & 3;
+        float t = 0.f;
+        if (lane < 16 && ta < p.f_h && tb < p.f_w) {
+            const int fa = p.flip ? ta : p.f_h - 1 - ta, fb = p.flip ? tb : p.f_w - 1 - tb;
+            t = p.f[fa * p.f_sh + fb * p.f_sw];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) ff[a][b] = lane_bcast(t, a * 4 + b);
+    }
+    const T* xp = (const T*)p.x + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w;
+    T* yp = (T*)p.y + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
+    const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of 4
+    const int ox = (cg * 64 + sub) * 4;
+    const int ix0 = ox - p.pad_x;
+    const int base = min(max(ix0, 0), p.in_w - 4);              // the 4-column load window, clamped into the row
+    const int sh = base - ix0;                                  // how far it moved (|sh| <= 3 for lanes that own live columns)
+    const bool cols_dead = !plane_ok || ix0 >= p.in_w || ix0 + 3 < 0;
+    const int ixh = (cg * 64 + lpr) * 4 - p.pad_x + sub;        // lanes sub < NH of a plane row: the columns right of its last lane's block
+    const bool halo_ok = plane_ok && sub < NH && ixh >= 0 && ixh < p.in_w;
+    const int ixh_c = min(max(ixh, 0), p.in_w - 1);
+    const int oy0 = rt * TILE_ROWS;
+    const int iy0 = oy0 - p.pad_y;
+    const bool st_vec = plane_ok && ox < n_main;
+    const bool st_xtra = XTRA && plane_ok && ox + 4 == p.out_w - 1;
+
+    // ---- load phase: rows wave, wave + 4, ... of the 19; everything is issued before anything is used ----
+    constexpr int RPW = (TILE_IN_ROWS + 3) / 4;
+    float m[RPW][4], h[RPW];
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = wave + 4 * k;
+        const T* row = xp + (size_t)min(max(iy0 + r, 0), p.in_h - 1) * p.in_w;
+#pragma unroll
+        for (int i = 0; i < 4; i++) m[k][i] = 0.f;
+        h[k] = 0.f;
+        if (r < TILE_IN_ROWS) {
+            row_loader<T, 4>::run(row + base, m[k]);
+            if (sub < NH) h[k] = sgv_traits<T>::load(row + ixh_c);
+        }
+    }
+    float yo[4][NOUT];
+    if constexpr (EPI == 3) {   // the forward output at this wave's four output rows (same predicates as the stores)
+        const T* yrp = (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+#pragma unroll
+            for (int v = 0; v < NOUT; v++) yo[k][v] = 0.f;
+            const int oy = min(oy0 + 4 * wave + k, p.out_h - 1);
+            const T* yr = yrp + (size_t)oy * p.out_w + ox;
+            if (st_vec) row_loader<T, 4>::run(yr, yo[k]);
+            if constexpr (XTRA) { if (st_xtra) yo[k][4] = sgv_traits<T>::load(yr + 4); }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < RPW; k++) {
+        const int r = wave + 4 * k;
+        if (r >= TILE_IN_ROWS) continue;
+        const int iy = iy0 + r;
+        const bool row_ok = iy >= 0 && iy < p.in_h;
+        f4v o;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {   // undo the clamp: column ix0 + i = loaded[i - sh] where that exists, else 0 (padding)
+            float v = m[k][i];
+#pragma unroll
+            for (int d = 1; d <= 3; d++) {
+                if (i - d >= 0) v = (sh == d) ? m[k][i - d] : v; else v = (sh == d) ? 0.f : v;
+                if (i + d < 4) v = (sh == -d) ? m[k][i + d] : v; else v = (sh == -d) ? 0.f : v;
+            }
+            o[i] = (row_ok && !cols_dead) ? v : 0.f;
+        }
+        float* lrow = tile_lds + r * row_pitch + slot * seg_pitch;
+        *(f4v*)(lrow + 4 * sub) = o;
+        if (sub < 8) lrow[4 * lpr + sub] = (row_ok && halo_ok) ? h[k] : 0.f;     // halo words; the rest of the 8 are zero
+    }
+    __syncthreads();
+
+    // ---- compute phase: output rows 4 wave .. 4 wave + 3 from LDS rows 4 wave .. 4 wave + 6 ----
+    float win[7][8];
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const float* lrow = tile_lds + (4 * wave + r) * row_pitch + slot * seg_pitch + 4 * sub;
+        const f4v a = *(const f4v*)lrow;
+        const f4v b = *(const f4v*)(lrow + 4);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { win[r][i] = a[i]; win[r][4 + i] = b[i]; }
+    }
+    float ep_sc = 1.f, ep_bi = 0.f;
+    if constexpr (EPI == 1) {
+        if (plane_ok && p.ep_scale) ep_sc = p.ep_scale[plane];
+        if (plane_ok && p.ep_bias) ep_bi = p.ep_bias[plane % p.chans];
+    }
+    float sum_g = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int oy = oy0 + 4 * wave + k;
+        if (oy >= p.out_h) break;   // wave-uniform
+        float o[NOUT];
+#pragma unroll
+        for (int v = 0; v < NOUT; v++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[k + j][v + i], ff[j][i], acc);
+            float t = acc * p.gain;
+            if constexpr (EPI == 1) {   // bias -> activation -> gain -> clamp, the operation order of bias_act.cu:51-142 (grad 0); identical to the lanes kernel's
+                t = t * ep_sc;
+                t = t + ep_bi;
+                if (p.ep_act == 3) t = (t > 0.f) ? t : t * p.ep_alpha;
+                t *= p.ep_gain;
+                if (p.ep_clamp >= 0.f) t = (t > -p.ep_clamp & t < p.ep_clamp) ? t : (t >= 0.f) ? p.ep_clamp : -p.ep_clamp;
+            }
+            if constexpr (EPI == 3) {   // grad-1 form (bias_act.cu:60-61,133-142): dy * act'(pre) * gain, zero where the forward output was clamped
+                const float yref = yo[k][v];
+                const float yy = (p.ep_gain != 0.f) ? yref / p.ep_gain : 0.f;
+                float g = t;
+                if (p.ep_act == 3) g = (yy > 0.f) ? t : t * p.ep_alpha;
+                g *= p.ep_gain;
+                if (p.ep_clamp >= 0.f) g = (yref > -p.ep_clamp & yref < p.ep_clamp) ? g : 0.f;
+                t = g;
+                if (v < 4 ? st_vec : st_xtra) sum_g += t;
+            }
+            o[v] = t;
+        }
+        T* yr = yp + (size_t)oy * p.out_w + ox;
+        if (st_vec) { if (p.nt_store) store_vec_nt<T, 4>(yr, o); else store_vec_plain<T, 4>(yr, o); }
+        if constexpr (XTRA) { if (st_xtra) sgv_traits<T>::store(yr + 4, o[4]); }
+    }
+    if constexpr (EPI == 3) {   // reduce over the lanes of a plane row, then one atomic per plane and wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+            if (off < lpr) sum_g += __shfl_xor(sum_g, off, 64);
+        if (sub == 0 && plane_ok && oy0 + 4 * wave < p.out_h) atomicAdd(p.ep_sum_g + plane, sum_g);
+    }
+}
+
 typedef void (*lanes_fn)(lanes_params);
 constexpr int LANES_WPB = 4;  // waves per workgroup (8 measured equal: the halo hand-off already covers 3 of 4 strip seams)
 
@@ -1086,6 +1284,66 @@ bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan, cons
     return true;
 }
 
+// ---- upfirdn2d_tile_kernel: planning and launch ----
+bool tile_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2, int* col_groups, int* xtra) {
+    static const int tile_on = []() { const char* e = getenv("SGV_UFD_TILE"); return e ? atoi(e) : 1; }();   // SGV_UFD_TILE=0: the strip-walking kernels of rounds 1-2
+    if (!tile_on || dtype == SGV_F64) return false;
+    if (p->up_x != 1 || p->up_y != 1 || p->down_x != 1 || p->down_y != 1 || p->f_w > 4 || p->f_h > 4) return false;
+    if (p->pad_x0 < 0 || p->pad_x0 > 3 || p->pad_y0 < 0 || p->pad_y0 > 3 || p->in_w < 4) return false;
+    if (!dense_nchw(p->in_w, p->in_h, p->in_c, p->in_sw, p->in_sh, p->in_sc, p->in_sn)) return false;
+    if (!dense_nchw(p->out_w, p->out_h, p->in_c, p->out_sw, p->out_sh, p->out_sc, p->out_sn)) return false;
+    const int xt = (p->out_w > 4 && p->out_w % 4 == 1) ? 1 : 0;
+    const int n_main = xt ? p->out_w - 1 : p->out_w;
+    if (n_main % 4 != 0) return false;
+    const int cbs = n_main / 4;
+    if (cbs <= 32) {
+        int l = 2;
+        while ((1 << l) < cbs) l++;
+        *lpr_log2 = l; *col_groups = 1;
+    } else {
+        *lpr_log2 = 6; *col_groups = (cbs + 63) / 64;
+    }
+    *xtra = xt;
+    return true;
+}
+
+template <typename T>
+void launch_tile_t(const tile_params& tp, int xtra, int epi, dim3 grid, size_t lds, hipStream_t stream) {
+#define SGV_TILE_GO(X, E) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E>), grid, dim3(256), lds, stream, tp)
+    if (epi == 0) { if (xtra) SGV_TILE_GO(1, 0); else SGV_TILE_GO(0, 0); }
+    else if (epi == 1) { if (xtra) SGV_TILE_GO(1, 1); else SGV_TILE_GO(0, 1); }
+    else { if (xtra) SGV_TILE_GO(1, 3); else SGV_TILE_GO(0, 3); }
+#undef SGV_TILE_GO
+}
+
+int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dtype, int lpr_log2, int col_groups, int xtra, hipStream_t stream) {
+    tile_params tp{};
+    tp.x = p->x; tp.f = p->f; tp.y = p->y; tp.flip = p->flip; tp.gain = p->gain;
+    tp.in_w = p->in_w; tp.in_h = p->in_h; tp.out_w = p->out_w; tp.out_h = p->out_h; tp.planes = p->in_c * p->in_n;
+    tp.f_w = p->f_w; tp.f_h = p->f_h; tp.f_sw = p->f_sw; tp.f_sh = p->f_sh;
+    tp.pad_x = p->pad_x0; tp.pad_y = p->pad_y0;
+    tp.lpr_log2 = lpr_log2; tp.col_groups = col_groups;
+    tp.row_tiles = (p->out_h + TILE_ROWS - 1) / TILE_ROWS;
+    const double out_bytes = (double)p->out_w * p->out_h * tp.planes * sgv_dtype_size(dtype);
+    tp.nt_store = out_bytes > 300e6 ? 1 : 0;
+    tp.ep_act = 1; tp.ep_alpha = 0.f; tp.ep_gain = 1.f; tp.ep_clamp = -1.f; tp.chans = p->in_c;
+    const int epi = e ? e->mode : 0;
+    if (e) {
+        tp.ep_scale = e->scale; tp.ep_bias = e->bias; tp.ep_yref = e->yref; tp.ep_sum_g = e->sum_g;
+        tp.ep_act = e->act; tp.ep_alpha = e->alpha; tp.ep_gain = e->gain; tp.ep_clamp = e->clamp;
+    }
+    const int ppw = 64 >> lpr_log2;
+    const int64_t blocks = (int64_t)((tp.planes + ppw - 1) / ppw) * col_groups * tp.row_tiles;
+    if (blocks > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: too many workgroups");
+    const size_t lds = (size_t)tile_lds_floats(lpr_log2) * sizeof(float);
+    const dim3 grid((unsigned)blocks);
+    if (dtype == SGV_F32) launch_tile_t<float>(tp, xtra, epi, grid, lds, stream);
+    else if (dtype == SGV_F16) launch_tile_t<sgv_half_t>(tp, xtra, epi, grid, lds, stream);
+    else launch_tile_t<sgv_bf16_t>(tp, xtra, epi, grid, lds, stream);
+    sgv_note_variant(epi == 0 ? SGV_V_ufd_tile : epi == 1 ? SGV_V_ufd_tile_fused1 : SGV_V_ufd_tile_fused3);
+    return sgv_check_launch("upfirdn2d_tile_kernel");
+}
+
 // upfirdn2d_fir_asm_kernel serves: fp32, up = down = 1, 4x4 filter, pad 1 or 2 on both axes with the matching output size, >= 129 output columns
 bool fir_asm_geometry(const sgv_upfirdn2d_params* p, int dtype) {
     static const int fir_asm = []() { const char* e = getenv("SGV_FIR_ASM"); return e ? atoi(e) : 1; }();
@@ -1147,6 +1405,8 @@ void launch_generic(const generic_params& gp, hipStream_t stream) {
 extern "C" int sgv_upfirdn2d_kernel_kind(const sgv_upfirdn2d_params* p, int dtype) {
     int rc = validate(p, dtype);
     if (rc != SGV_OK) return rc;
+    int lpr_log2, col_groups, xtra;
+    if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra)) return 3;
     lanes_plan lplan;
     if (plan_lanes(p, dtype, &lplan)) return 2;
     rows_plan plan;
@@ -1159,6 +1419,13 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
     hipStream_t stream = (hipStream_t)stream_;
     const double bytes = ((double)p->in_w * p->in_h + (double)p->out_w * p->out_h) * p->in_c * p->in_n * sgv_dtype_size(dtype);
 
+    {
+        int lpr_log2, col_groups, xtra;
+        if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra)) {   // every up = down = 1 FIR pass: the LDS-tile kernel
+            sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
+            return launch_tile(p, nullptr, dtype, lpr_log2, col_groups, xtra, stream);
+        }
+    }
     lanes_plan lplan;
     if (plan_lanes(p, dtype, &lplan)) {
         sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
@@ -1209,6 +1476,15 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
     if (e->mode == 2 && (!e->yref || !e->sum_g || !e->sum_gv)) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode 2 needs yref, sum_g and sum_gv");
     if (e->mode == 3 && (!e->yref || !e->sum_g)) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d_fused: mode 3 needs yref and sum_g");
     hipStream_t stream = (hipStream_t)stream_;
+    const double es0 = (double)sgv_dtype_size(dtype);
+    const double nin0 = (double)p->in_w * p->in_h * p->in_c * p->in_n, nout0 = (double)p->out_w * p->out_h * p->in_c * p->in_n;
+    if (e->mode == 1 || e->mode == 3) {
+        int lpr_log2, col_groups, xtra;
+        if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra)) {
+            sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, nin0 * es0 + (e->mode == 3 ? 2.0 * nout0 : nout0) * es0);
+            return launch_tile(p, e, dtype, lpr_log2, col_groups, xtra, stream);
+        }
+    }
     lanes_plan lplan;
     if (!plan_lanes(p, dtype, &lplan, e))
         return sgv_fail(SGV_ERR_UNSUPPORTED, "upfirdn2d_fused: geometry/layout not covered by the fused kernel (modes 1, 3: up=down=1 pad 1, mode 2: up=down=1 pad 2, mode 4: up=2 pad 2, 4x4 filter, dense NCHW)");

@@ -216,9 +216,11 @@ class TrainStep:
                         v.copy_(s0) if s0 is not None else v.zero_()
             torch.cuda.current_stream(self.device).wait_stream(side)
             g_grad, g_upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g_grad):
+            # thread_local: the RCCL watchdog thread of an initialised process group queries events while this thread captures, which the
+            # default (global) capture mode treats as an error in the OTHER thread (observed: segmentation fault in capture_end)
+            with torch.cuda.graph(g_grad, capture_error_mode='thread_local'):
                 out = self._phase_gradients(phase, False, **static)
-            with torch.cuda.graph(g_upd, pool=g_grad.pool()):
+            with torch.cuda.graph(g_upd, pool=g_grad.pool(), capture_error_mode='thread_local'):
                 self._phase_update(phase)
             entry = self._graphs[name] = dict(grad=g_grad, update=g_upd, static=static, out=out)
         else:

@@ -277,7 +277,8 @@ def test_fused_fir_bias_act_is_twice_differentiable(shape):
     before = custom_ops.kernel_variant_counts()
     got = second_order(fused_fir_act.fir_bias_act)
     after = custom_ops.kernel_variant_counts()
-    assert (after['ufd_lanes_fused1'] + after['ufd_fir_asm_fused1']) - (before['ufd_lanes_fused1'] + before['ufd_fir_asm_fused1']) == 1, 'the forward pass ran the fused kernel'
+    fused1 = ('ufd_lanes_fused1', 'ufd_fir_asm_fused1', 'ufd_tile_fused1')
+    assert sum(after[k] - before[k] for k in fused1) == 1, 'the forward pass ran the fused kernel'
     want = second_order(fused_fir_act.fir_bias_act_composed)
     with fused_conv_act.composition_only():
         inside = second_order(fused_fir_act.fir_bias_act)
@@ -487,39 +488,14 @@ def test_train_step_scopes_the_frame_time_bound_to_its_own_passes():
 
 
 def test_train_step_graphs_with_ddp_and_ada_on_an_nccl_group_of_one():
-    """Config 4's regime: DDP (RCCL all-reduce captured with the phase), hipGraph replay and aug=ada together."""
+    """Config 4's regime: DDP over an RCCL group, hipGraph replay and aug=ada together (tests/ddp_graph_worker.py, in a child process: a crash
+    inside graph capture must not take the test session down)."""
     import os
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    os.environ.setdefault('MASTER_PORT', '29533')
-    os.environ.setdefault('TORCH_NCCL_ASYNC_ERROR_HANDLING', '0')
-    created = not dist.is_initialized()
-    if created:
-        dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
-    try:
-        ts = _small_train_step(ddp=True, use_graphs=True, augment='ada')
-        assert ts.ddp and ts.use_graphs and ts.augment_pipe is not None and ts.augment_pipe.static_margin
-        assert ts.step() == ['Gmain', 'Greg', 'Dmain', 'Dreg']
-        torch.cuda.synchronize()
-        launches = custom_ops.launch_count()
-        ts.augment_pipe.p.fill_(0.3)        # augmentations really drawn inside the replayed graphs
-        before = {k: v.detach().clone() for k, v in ts.D.named_parameters()}
-        for _ in range(3):
-            assert ts.step() == ['Gmain', 'Dmain']
-        torch.cuda.synchronize()
-        assert set(ts._graphs) == {'Gmain', 'Dmain'}
-        assert custom_ops.launch_count() == launches, 'replayed phases must not launch from the host'
-        assert sum(int(not torch.equal(v, before[k])) for k, v in ts.D.named_parameters()) > 10
-        for name, p in list(ts.G.named_parameters()) + list(ts.D.named_parameters()):
-            assert torch.isfinite(p).all(), name
-        assert torch.isfinite(ts.last_losses['D/loss']) and 'signs_real' in ts.last_losses
-        # and the eager schedule on the same kind of instance reaches the same loss range (same models, same data distribution)
-        te = _small_train_step(ddp=True, use_graphs=False, augment='ada')
-        te.step(); te.step()
-        assert abs(float(te.last_losses['D/loss']) - float(ts.last_losses['D/loss'])) < 1.0
-    finally:
-        if created:
-            dist.destroy_process_group()
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ddp_graph_worker.py')
+    res = subprocess.run([sys.executable, worker, '29541'], capture_output=True, text=True, timeout=420)
+    assert res.returncode == 0 and res.stdout.strip().endswith('OK'), f'rc={res.returncode}\n{res.stdout[-2000:]}\n{res.stderr[-4000:]}'
 
 
 def test_multi_tensor_nan_to_num_matches_torch_per_tensor():
@@ -585,7 +561,7 @@ def test_path_length_regularisation_step_runs_with_the_fused_epilogues_on():
             fused_fir_act.enabled = True
         outs.append({k: float(v) for k, v in ts.last_losses.items()})
     after = custom_ops.kernel_variant_counts()
-    assert after['ufd_lanes_fused1'] - before['ufd_lanes_fused1'] > 0 and fused_fir_act.enabled, 'Gmain of the PL run must keep the fused epilogue'
+    assert sum(after[k] - before[k] for k in ('ufd_lanes_fused1', 'ufd_fir_asm_fused1', 'ufd_tile_fused1')) > 0 and fused_fir_act.enabled, 'Gmain of the PL run must keep the fused epilogue'
     for k in ('G/loss', 'G/reg', 'D/loss', 'D/reg'):
         assert abs(outs[0][k] - outs[1][k]) <= 2e-3 * max(1.0, abs(outs[1][k])), (k, outs)
     for (name, pa), (_, pb) in zip(a.G.named_parameters(), b.G.named_parameters()):
