@@ -396,6 +396,9 @@ typedef struct sgv_gemm_params {
                                              (the caller sums them; no bias) -- long-K products with few output tiles, e.g. the 1x1 weight gradients */
     const float* residual;                /* or NULL: C = A * op(B) (+ bias) + residual, residual laid out like C (ldc, stride_c) -- the sum of the
                                              discriminator block's two branches (networks.py:343-345) formed in the skip convolution's store */
+    int32_t exact_fp32;                   /* 0: products as 2-way bf16 splits on the bf16 matrix pipe (3 MFMAs per product, fp32 accumulate, 4.4e-6 relative error:
+                                             the arithmetic of the 3x3 family) where the shape allows (n % 128 == 0, k % 32 == 0, 16-byte aligned rows);
+                                             1: always v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain over k).  SGV_GEMM_TERMS=0 forces 1 for the process */
 } sgv_gemm_params;
 
 int sgv_gemm_f32(const sgv_gemm_params* p, void* stream);

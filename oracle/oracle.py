@@ -118,7 +118,7 @@ _ACT_DEFAULTS = {'linear': (0, 1), 'relu': (0, np.sqrt(2)), 'lrelu': (0.2, np.sq
 def bias_act(x, b=None, dim=1, act='linear', alpha=None, gain=None, clamp=None, grad=0, xref=None, yref=None, dy=None):
     """Oracle bias_act kernel call (any grad order) on dense CPU tensors sharing x's layout."""
     lib = _get()
-    assert x.device.type == 'cpu'
+    assert x.device.type == 'cpu' and x.is_contiguous(), 'oracle.bias_act walks dense memory: pass a contiguous tensor'
     da, dg = _ACT_DEFAULTS[act]
     alpha = float(da if alpha is None else alpha)
     gain = float(dg if gain is None else gain)

@@ -21,6 +21,8 @@
 
 using namespace sgv_gemm;
 
+static inline int slice_ok(const sgv_gemm_params*, int) { return 1; }   // k % 32 == 0 keeps every K slice 16-byte aligned
+
 extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: params is NULL");
     if (!p->a || !p->b || !p->c) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: NULL pointer");
@@ -53,6 +55,23 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     static const bool allow_nk = !(getenv("SGV_GEMM_FULLNK") && getenv("SGV_GEMM_FULLNK")[0] == '0');
     const bool full_nk = allow_nk && !full16 && p->n % BN == 0 && gp.k % 16 == 0 && p->lda % 4 == 0 && p->ldb % 4 == 0 && p->stride_a % 4 == 0 && p->stride_b % 4 == 0 &&
                          al16(p->a) && al16(p->b);
+    // bf16x3 member (gemm_kernel.h): whole tiles along n, k % 32 == 0, 16-byte aligned k-contiguous rows; any m.  SGV_GEMM_TERMS=0 keeps every
+    // product on the exact-fp32 matrix pipe.
+    static const bool allow_x3 = !(getenv("SGV_GEMM_TERMS") && getenv("SGV_GEMM_TERMS")[0] == '0');
+    const bool x3 = allow_x3 && !p->exact_fp32 && p->n % BN == 0 && gp.k % X3_BK == 0 && p->lda % 4 == 0 && p->stride_a % 4 == 0 && al16(p->a) && (int64_t)slice_ok(p, ks) &&
+                    (!p->trans_b || (p->ldb % 4 == 0 && p->stride_b % 4 == 0 && al16(p->b)));
+    if (x3) {
+        static const hipError_t attr_err = [] {
+            hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+            return e;
+        }();
+        if (attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+        if (p->trans_b) hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, grid, dim3(256), X3_LDS_BYTES, stream, gp);
+        else hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, dim3(256), X3_LDS_BYTES, stream, gp);
+        sgv_note_variant(SGV_V_gemm_bf16x3);
+        return sgv_check_launch("gemm_bf16x3_kernel");
+    }
     if (full_nk) {   // whole tiles along n and k, any m
         if (p->trans_b) hipLaunchKernelGGL((gemm_f32_kernel<1, 16, 1, 2, 2>), grid, dim3(256), 0, stream, gp);
         else hipLaunchKernelGGL((gemm_f32_kernel<0, 16, 1, 2, 2>), grid, dim3(256), 0, stream, gp);

@@ -206,4 +206,179 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
         }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+// gemm_bf16x3_kernel: the same contraction on the bf16 matrix pipe with fp32 emulation -- every fp32 operand is split v = hi + lo
+// (hi = bf16_rne(v), lo = bf16_rne(v - hi)) on its way into LDS and a product is a_lo*b_hi + a_hi*b_lo + a_hi*b_hi: three
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate), the arithmetic of the 3x3 convolution family (conv3x3_kernel.h; 4.4e-6 relative error, exact on
+// small integers).  Ceiling 2500 / 3 = 833 TFLOP/s fp32-equivalent against 157 of the fp32-input MFMA above: the dense 1x1 / skip GEMMs of the
+// discriminator (networks.py:452) stop being bound by the fp32 matrix pipe and become streams of their operands.
+//
+// Same 128 x 128 tile, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles; K in chunks of 32 (two k = 16 MFMA steps), two LDS stages, one
+// barrier per chunk, the global loads of chunk q + 1 in flight during the MFMAs of chunk q.  LDS layout [hi|lo][k octet][row] of 16-byte words
+// (8 bf16 along k): the operand fetch of an MFMA -- lanes 0-31 consecutive rows of octet 2s, lanes 32-63 of octet 2s + 1 -- is a conflict-free
+// ds_read_b128.  Fill: A ([M, K], k contiguous) and B of TRANS_B = 1 ([N, K]): a thread loads 16 consecutive k of one row (4 x 16 B) and writes two
+// octets; B of TRANS_B = 0 ([K, N], n contiguous -- the NCHW activation of a 1x1 convolution): a thread gathers the 8 k of two octets for ONE
+// column with dword loads that are coalesced across the wave (64 consecutive n), so that the transposition costs no LDS bank conflict.
+// Requirements (host-checked): n % 128 == 0, k % 32 == 0, 16-byte aligned rows of the k-contiguous operands; any m (rows clamped, stores masked).
+typedef __bf16 gbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gbf16x2 __attribute__((ext_vector_type(2)));
+typedef float gf32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int X3_BK = 32;                          // k per chunk
+constexpr int X3_PITCH = BM + 2;                   // 16-byte words per (hi/lo, octet) plane: 128 rows + 2 (plane offsets of 8 banks: conflict-free fills)
+constexpr int X3_PLANES = 2 * (X3_BK / 8);         // hi/lo x 4 octets
+constexpr int X3_STAGE_WORDS = 2 * X3_PLANES * X3_PITCH;   // A and B
+constexpr int X3_LDS_BYTES = 2 * X3_STAGE_WORDS * 16;      // two stages: 66,560 bytes
+
+__device__ __forceinline__ unsigned x3_pack(float a, float b) {
+    gf32x2 f = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, gbf16x2));
+}
+__device__ __forceinline__ void x3_split8(const float* v, gu32x4& hi, gu32x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const unsigned h = x3_pack(v[2 * j], v[2 * j + 1]);
+        const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+        hi[j] = h;
+        lo[j] = x3_pack(v[2 * j] - h0, v[2 * j + 1] - h1);
+    }
+}
+
+template <int TRANS_B>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
+    extern __shared__ __attribute__((aligned(16))) gu32x4 x3_lds[];
+    const int tile = blockIdx.x;
+    const int tm = tile % p.tiles_m;  // M fastest: consecutive workgroups share the B panel
+    const int tn = tile / p.tiles_m;
+    const int batch = (int)blockIdx.y / p.ksplit, slice = (int)blockIdx.y - batch * p.ksplit;   // p.k is the slice length
+    const float* A = p.a + batch * p.stride_a + (int64_t)slice * p.k;
+    const float* B = p.b + batch * p.stride_b + (TRANS_B ? (int64_t)slice * p.k : (int64_t)slice * p.k * p.ldb);
+    float* C = p.c + (int64_t)blockIdx.y * p.stride_c;
+    const float* RES = p.residual ? p.residual + (int64_t)blockIdx.y * p.stride_c : nullptr;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // fill roles: k-contiguous operands -- thread -> (row t / 2, k half t % 2: octets 2h, 2h + 1)
+    const int f_row = t >> 1, f_half = t & 1;
+    const float* a_src = A + (int64_t)min(m0 + f_row, p.m - 1) * p.lda + f_half * 16;   // rows beyond the matrix repeat its last row; their products are never stored
+    const float* bt_src = TRANS_B ? B + (int64_t)(n0 + f_row) * p.ldb + f_half * 16 : nullptr;
+    // n-contiguous B -- thread -> (column t % 128, octet pair t / 128)
+    const int g_col = t & 127, g_pair = t >> 7;
+    const float* bn_src = TRANS_B ? nullptr : B + (int64_t)(g_pair * 16) * p.ldb + n0 + g_col;
+
+    float ra[16], rb[16];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *(const float4*)(a_src + k0 + 4 * q);
+            ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
+        }
+        if (TRANS_B) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v = *(const float4*)(bt_src + k0 + 4 * q);
+                rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) rb[e] = bn_src[(int64_t)(k0 + e) * p.ldb];
+        }
+    };
+    auto store_chunk = [&](int stage) {
+        gu32x4* as = x3_lds + stage * X3_STAGE_WORDS;
+        gu32x4* bs = as + X3_PLANES * X3_PITCH;
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            gu32x4 hi, lo;
+            x3_split8(ra + 8 * o, hi, lo);
+            as[(0 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = hi;
+            as[(1 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = lo;
+            x3_split8(rb + 8 * o, hi, lo);
+            if (TRANS_B) {
+                bs[(0 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = hi;
+                bs[(1 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = lo;
+            } else {
+                bs[(0 * 4 + 2 * g_pair + o) * X3_PITCH + g_col] = hi;
+                bs[(1 * 4 + 2 * g_pair + o) * X3_PITCH + g_col] = lo;
+            }
+        }
+    };
+
+    load_chunk(0);
+    int cur = 0;
+    for (int k0 = 0; k0 < p.k; k0 += X3_BK) {
+        store_chunk(cur);
+        __syncthreads();     // stage `cur` is complete; the other stage's readers finished before their own barrier of the previous chunk
+        if (k0 + X3_BK < p.k) load_chunk(k0 + X3_BK);
+        const gu32x4* as = x3_lds + cur * X3_STAGE_WORDS;
+        const gu32x4* bs = as + X3_PLANES * X3_PITCH;
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            gu32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) {
+                ah[i] = as[(0 * 4 + 2 * s + lk) * X3_PITCH + wm + 32 * i + lr];
+                al[i] = as[(1 * 4 + 2 * s + lk) * X3_PITCH + wm + 32 * i + lr];
+                bh[i] = bs[(0 * 4 + 2 * s + lk) * X3_PITCH + wn + 32 * i + lr];
+                bl[i] = bs[(1 * 4 + 2 * s + lk) * X3_PITCH + wn + 32 * i + lr];
+            }
+            // small terms first; three passes over the four accumulators: an MFMA never waits for the one just before it
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, al[i]), __builtin_bit_cast(gbf16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, ah[i]), __builtin_bit_cast(gbf16x8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, ah[i]), __builtin_bit_cast(gbf16x8, bh[j]), acc[i][j], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+
+    // Epilogue (as gemm_f32_kernel).  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+    const bool full_m = m0 + BM <= p.m;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int col = n0 + wn + j * 32 + lr;
+            const float bcol = (p.bias_mode == 1) ? p.bias[col] : 0.f;
+            float rv[16];
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                rv[e] = (RES && (full_m || row < p.m)) ? RES[(int64_t)row * p.ldc + col] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                if (!full_m && row >= p.m) continue;
+                float v = acc[i][j][e] + bcol;
+                if (p.bias_mode == 2) v += p.bias[row];
+                if (RES) v += rv[e];
+                C[(int64_t)row * p.ldc + col] = v;
+            }
+        }
+}
+
 }  // namespace sgv_gemm

@@ -954,19 +954,17 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     const bool plane_ok = plane < p.planes;
     const int seg_pitch = 4 * lpr + 8;                        // floats of one plane's row in LDS: 4 per lane + the halo words (16-byte aligned)
     const int row_pitch = (64 >> p.lpr_log2) * seg_pitch;
+    // The taps through the scalar cache (every index is wave-uniform): the lanes kernel's "16 lanes load, v_readlane broadcasts" makes hipcc wait
+    // for that vector load (vmcnt(0)) BEFORE the row loads below are issued -- a whole memory latency in front of every workgroup's requests
+    // (ISA of the first version of this kernel; the lab kernel, which read the taps with s_load, was 6 % faster for that reason alone).
     float ff[4][4];
-    {   // lane t < 16 fetches tap (t/4, t%4); v_readlane broadcasts the 16 values into SGPRs (same indexing as the lanes kernel)
-        const int ta = (lane >> 2) & 3, tb = lane & 3;
-        float t = 0.f;
-        if (lane < 16 && ta < p.f_h && tb < p.f_w) {
-            const int fa = p.flip ? ta : p.f_h - 1 - ta, fb = p.flip ? tb : p.f_w - 1 - tb;
-            t = p.f[fa * p.f_sh + fb * p.f_sw];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            ff[a][b] = 0.f;
+            if (a < p.f_h && b < p.f_w) ff[a][b] = p.f[(p.flip ? a : p.f_h - 1 - a) * p.f_sh + (p.flip ? b : p.f_w - 1 - b) * p.f_sw];
         }
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) ff[a][b] = lane_bcast(t, a * 4 + b);
-    }
     const T* xp = (const T*)p.x + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w;
     T* yp = (T*)p.y + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
     const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of 4

@@ -224,7 +224,7 @@ class GemmParams(ctypes.Structure):
         ('lda', c_int64), ('ldb', c_int64), ('ldc', c_int64),
         ('trans_b', c_int32), ('batch', c_int32),
         ('stride_a', c_int64), ('stride_b', c_int64), ('stride_c', c_int64),
-        ('bias_mode', c_int32), ('k_split', c_int32), ('residual', c_void_p),
+        ('bias_mode', c_int32), ('k_split', c_int32), ('residual', c_void_p), ('exact_fp32', c_int32),
     ]
 
 

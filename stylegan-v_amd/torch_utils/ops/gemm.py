@@ -12,6 +12,7 @@ import torch
 from .. import custom_ops
 
 enabled = True  # conv2d_resample routes whole-tile fp32 1x1 convolutions here
+exact_fp32 = False  # True: every product on the exact-fp32 matrix pipe (default: split-bf16 products where the shape allows, as the 3x3 family)
 
 
 def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0, sc=0, bias_mode=0, k_split=1, residual=None):
@@ -22,6 +23,7 @@ def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0,
     p.residual = residual.data_ptr() if residual is not None else None
     p.m, p.n, p.k, p.lda, p.ldb, p.ldc = m, n, k, lda, ldb, ldc
     p.trans_b, p.batch, p.stride_a, p.stride_b, p.stride_c, p.bias_mode, p.k_split = int(trans_b), batch, sa, sb, sc, bias_mode, k_split
+    p.exact_fp32 = 1 if (exact_fp32 or _gradfix().native_conv_terms == 0) else 0   # the strict-fp32 switch of the 3x3 family covers the dense products too
     with torch.cuda.device_of(c):
         custom_ops.check(lib.sgv_gemm_f32(p, torch.cuda.current_stream(c.device).cuda_stream), lib)
     return c

@@ -54,7 +54,7 @@ class TrainStep:
     """Holds G, D, G_ema, optimisers and the loss; ``step()`` runs one iteration of the phase schedule."""
 
     def __init__(self, g_kwargs, d_kwargs, train_cfg, device, batch_gpu, world_size=1, rank=0, seed=0, ddp=None, bucket_cap_mb=25, use_graphs=False, augment='noaug',
-                 ada_target=0.6, ada_interval=4, ada_kimg=500):
+                 ada_target=0.6, ada_interval=4, ada_kimg=500, ddp_manual=None):
         self.device, self.batch_gpu, self.world_size, self.rank = torch.device(device), batch_gpu, world_size, rank
         self.train_cfg = train_cfg
         self.G, self.D, self.G_ema = build_models(g_kwargs, d_kwargs, device, seed=seed)
@@ -65,17 +65,25 @@ class TrainStep:
         self.gen = torch.Generator().manual_seed(seed * world_size + rank)  # rank-specific latents (training_loop.py:137-139)
         self.batch_size = batch_gpu * world_size
 
-        # DDP wrappers only add the gradient all-reduce; parameters stay shared with the raw modules.
+        # Multi-GPU: DDP wrappers only add the gradient all-reduce; parameters stay shared with the raw modules.  With hipGraph replay the
+        # wrappers are left out and the gradients of the phase's module are averaged by ONE flat all-reduce behind its backward pass
+        # (`_allreduce_gradients`; same mean as DDP's buckets, not overlapped with the backward -- ~1.5 ms against a 58 ms step): torch's DDP
+        # reducer under stream capture crashed `capture_end` on ROCm 7.2 / torch 2.10 even with its synchronisation switched off.
         self.ddp = (world_size > 1) if ddp is None else ddp
+        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
+        self.ddp_manual = self.ddp and (self.use_graphs if ddp_manual is None else bool(ddp_manual))
         modules = dict(G_mapping=self.G.mapping, G_synthesis=self.G.synthesis, D=self.D)
-        if self.ddp:
+        if self.ddp and not self.ddp_manual:
             ids = [self.device.index] if self.device.type == 'cuda' else None
             for name, mod in list(modules.items()):
                 mod.requires_grad_(True)
                 modules[name] = torch.nn.parallel.DistributedDataParallel(mod, device_ids=ids, broadcast_buffers=False, bucket_cap_mb=bucket_cap_mb)
                 mod.requires_grad_(False)
-            for p in misc.params_and_buffers(self.G_ema):  # G_ema: sync initial values only
-                torch.distributed.broadcast(p, src=0)
+        if self.ddp:
+            with torch.no_grad():
+                for mod in ((self.G, self.D, self.G_ema) if self.ddp_manual else (self.G_ema,)):   # DDP's constructor broadcasts G / D itself
+                    for p in misc.params_and_buffers(mod):
+                        torch.distributed.broadcast(p, src=0)
         # Discriminator augmentation (train.py:238-277, training_loop.py:197-205): 'ada' = the bgc pipeline with p starting at 0 and adapted
         # every `ada_interval` iterations from the sign of D's outputs on real clips; one transform per video (configs/model/stylegan-v.yaml:58).
         self.augment_pipe, self.ada = None, None
@@ -108,7 +116,6 @@ class TrainStep:
         # hipGraph replay of the two every-iteration phases (small per-GPU batches are launch-bound).  Works with DDP (the graph's backward
         # runs un-synchronised, one flat RCCL all-reduce of the gradients follows the replay) and with ADA (the pipe pads by its static
         # worst-case margin while graphs are on, so that nothing is read back to the host).
-        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
         self._graphs = {}
         if self.use_graphs:
             for phase in self.phases:
@@ -164,6 +171,8 @@ class TrainStep:
 
     def _run_phase(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
         losses = self._phase_gradients(phase, True, real_img, real_c, real_t, gen_z, gen_c, gen_t)
+        if self.ddp_manual:
+            self._allreduce_gradients(phase)
         self._phase_update(phase)
         return losses
 
@@ -187,9 +196,8 @@ class TrainStep:
         return tensors, opt_state
 
     def _run_phase_graph(self, phase, real_img, real_c, real_t, gen_z, gen_c, gen_t):
-        """A phase as two hipGraphs: (A) zero_grad + forward + backward, (B) gradient sanitising + Adam; under DDP the gradient all-reduce runs
-        eagerly between them (the graph's backward pass has DDP's own synchronisation switched off, so no collective is captured -- capturing
-        RCCL inside DDP's reducer crashed `capture_end` on ROCm 7.2 / torch 2.10).
+        """A phase as two hipGraphs: (A) zero_grad + forward + backward, (B) gradient sanitising + Adam; with several ranks the flat gradient
+        all-reduce runs eagerly between them (no collective is captured).
         First call of a phase: eager warm-up runs on a side stream (library initialisation, allocator warm-up, Adam state allocation) -- on
         the LIVE models, so parameters, buffers and optimiser state are put back afterwards: the warm-up must not count as training -- then the
         two captures (which execute nothing) and one replay of each, which is this iteration's update.  Later calls copy the inputs into the
@@ -227,7 +235,7 @@ class TrainStep:
             for key, val in (('real_img', real_img), ('real_c', real_c), ('real_t', real_t), ('gen_z', gen_z), ('gen_c', gen_c), ('gen_t', gen_t)):
                 entry['static'][key].copy_(val)
         entry['grad'].replay()
-        if self.ddp:
+        if self.ddp_manual:
             self._allreduce_gradients(phase)
         entry['update'].replay()
         return {k: v.clone() for k, v in entry['out'].items()}

@@ -29,7 +29,7 @@ def main():
     stylegan_v_amd.configure_miopen()
     dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
     ts = make(ddp=True, use_graphs=True, augment='ada')
-    assert ts.ddp and ts.use_graphs and ts.augment_pipe is not None and ts.augment_pipe.static_margin
+    assert ts.ddp and ts.ddp_manual and ts.use_graphs and ts.augment_pipe is not None and ts.augment_pipe.static_margin
     assert ts.step() == ['Gmain', 'Greg', 'Dmain', 'Dreg']
     torch.cuda.synchronize()
     for phase in ts.phases:

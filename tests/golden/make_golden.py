@@ -328,7 +328,10 @@ def gen_networks_mid():
 def gen_networks_full():
     """Third module golden: the benchmark's own models -- FFS 256^2, cfg=auto (fmaps 0.5: channels 512,512,512,512,256,128,64; mapping depth 2;
     src/train.py:138-200, configs/model/stylegan-v.yaml), 2 videos x 3 frames.  Parameters are drawn on both sides with
-    tests/util.py:seeded_parameters_; outputs are stored whole (images as float16-exact values are NOT assumed: float32), gradients as strided samples."""
+    tests/util.py:seeded_parameters_.  The reference modules are evaluated TWICE, in float64 and in float32: the float64 run is the golden
+    (outputs whole or strided samples, gradients as strided samples), the float32 run gives every tensor's `noise` = max |f32 - f64| / max |f64| --
+    what the reference's own fp32 evaluation loses on that tensor (gradients of the earliest layers pass through ~30 convolutions with heavy
+    cancellation; a fixed 1e-3 would demand more than fp32 arithmetic delivers there)."""
     from omegaconf import OmegaConf
     from training.networks import Generator, Discriminator
     sys.path.insert(0, os.path.dirname(HERE))
@@ -350,42 +353,80 @@ def gen_networks_full():
     g = torch.Generator().manual_seed(79)
     B, F = 2, 3
     z = torch.randn([B, 512], generator=g)
-    c = torch.zeros([B, 0])
     t = torch.sort(torch.rand([B, F], generator=g) * 40, dim=1).values
     traj_len = G.synthesis.motion_encoder.get_max_traj_len(t) + G.synthesis.motion_encoder.num_additional_codes
     motion_z = torch.randn([B, traj_len, 512], generator=g)
-    arrays = {'z': z, 't': t, 'motion_z': motion_z}
+    real = (torch.rand([B * F, 3, RES, RES], generator=torch.Generator().manual_seed(1079)) * 2 - 1).half().float()   # the test re-draws it (seed in meta) instead of reading 2.4 MB
     G.train(); D.train()
-    ws = G.mapping(z, c, skip_w_avg_update=True)
-    arrays['ws'] = sample_flat(ws)
-    img_train = G.synthesis(ws, t=t, c=c, motion_z=motion_z)
-    arrays['img_train'] = img_train.half()       # D's input below is this rounded image on both sides (0.6 MB instead of 4.7)
-    img_in = img_train.detach().half().float()
-    arrays['img_train_sample'] = sample_flat(img_train, limit=65536)
-    arrays['logits_fake'] = D(img_in, c, t)['image_logits']
-    G.zero_grad(); D.zero_grad()
-    img = G.synthesis(G.mapping(z, c, skip_w_avg_update=True), t=t, c=c, motion_z=motion_z)
-    loss_g = torch.nn.functional.softplus(-D(img, c, t)['image_logits']).mean()
-    loss_g.backward()
-    arrays['loss_Gmain'] = loss_g
-    for name, p in G.named_parameters():
-        arrays['gradG.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p), limit=1024)
-    G.zero_grad(); D.zero_grad()
-    real = (torch.rand([B * F, 3, RES, RES], generator=torch.Generator().manual_seed(1079)) * 2 - 1).half()   # the test re-draws it (seed in meta) instead of reading 2.4 MB
-    real = real.float()
-    real_tmp = real.clone().requires_grad_(True)
-    logits_real = D(real_tmp, c, t)['image_logits']
-    (r1_grads,) = torch.autograd.grad(logits_real.sum(), real_tmp, create_graph=True)
-    r1 = r1_grads.square().sum([1, 2, 3])
-    loss_d = (torch.nn.functional.softplus(-logits_real) + (r1 * 0.5).view(-1, F).mean(dim=1)).mean()
-    loss_d.backward()
-    arrays['logits_real'] = logits_real
-    arrays['r1_penalty'] = r1
-    arrays['loss_Dreal_r1'] = loss_d
-    for name, p in D.named_parameters():
-        arrays['gradD.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p), limit=1024)
-    meta = dict(B=B, F=F, res=RES, w_dim=512, z_dim=512, seed_G=303, seed_D=404, real_seed=1079,
+
+    import training.networks as ref_networks, training.layers as ref_layers, training.motion as ref_motion
+
+    class _Torch64:
+        """Stand-in for the `torch` global of the reference's model files during the float64 run: their hard-wired `torch.float32` casts
+        (networks.py:227,261,351,461,552; layers.py:74; motion.py:114-116) become float64, everything else is torch."""
+        float32 = torch.float64
+
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+    def evaluate(dt):
+        """Everything the test compares, with modules and inputs in dtype `dt`."""
+        Gd, Dd = G.to(dt), D.to(dt)
+        for mod in (Gd, Dd):        # conv2d_resample.py:86 / upfirdn2d.py:177 want the FIR taps in float32 (exactly representable: k / 64)
+            for name, buf in mod.named_buffers():
+                if name.endswith('resample_filter'):
+                    buf.data = buf.data.float()
+        for m in (ref_networks, ref_layers, ref_motion):
+            m.torch = _Torch64() if dt == torch.float64 else torch
+        try:
+            return _evaluate(Gd, Dd, dt)
+        finally:
+            for m in (ref_networks, ref_layers, ref_motion):
+                m.torch = torch
+
+    def _evaluate(Gd, Dd, dt):
+        zz, tt, mz, c = z.to(dt), t.to(dt), motion_z.to(dt), torch.zeros([B, 0], dtype=dt)
+        out = {}
+        ws = Gd.mapping(zz, c, skip_w_avg_update=True)
+        out['ws'] = sample_flat(ws)
+        img_train = Gd.synthesis(ws, t=tt, c=c, motion_z=mz)
+        out['img_train'] = img_train.detach()
+        out['img_train_sample'] = sample_flat(img_train, limit=65536)
+        out['logits_fake'] = Dd(img_train.detach().float().half().to(dt), c, tt)['image_logits']   # D's input: the image rounded to fp16 on every side
+        Gd.zero_grad(); Dd.zero_grad()
+        img = Gd.synthesis(Gd.mapping(zz, c, skip_w_avg_update=True), t=tt, c=c, motion_z=mz)
+        loss_g = torch.nn.functional.softplus(-Dd(img, c, tt)['image_logits']).mean()
+        loss_g.backward()
+        out['loss_Gmain'] = loss_g
+        for name, p in Gd.named_parameters():
+            out['gradG.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p), limit=1024)
+        Gd.zero_grad(); Dd.zero_grad()
+        real_tmp = real.to(dt).requires_grad_(True)
+        logits_real = Dd(real_tmp, c, tt)['image_logits']
+        (r1_grads,) = torch.autograd.grad(logits_real.sum(), real_tmp, create_graph=True)
+        r1 = r1_grads.square().sum([1, 2, 3])
+        loss_d = (torch.nn.functional.softplus(-logits_real) + (r1 * 0.5).view(-1, F).mean(dim=1)).mean()
+        loss_d.backward()
+        out['logits_real'], out['r1_penalty'], out['loss_Dreal_r1'] = logits_real, r1, loss_d
+        for name, p in Dd.named_parameters():
+            out['gradD.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p), limit=1024)
+        return {k: v.detach().clone() for k, v in out.items()}
+
+    r32 = evaluate(torch.float32)
+    r64 = evaluate(torch.float64)
+    arrays = {'z': z, 't': t, 'motion_z': motion_z}
+    noise = {}
+    for key, v64 in r64.items():
+        scale = max(v64.abs().max().item(), 1e-300)
+        noise[key] = float((r32[key].double() - v64).abs().max().item() / scale)
+        if key == 'img_train':
+            arrays[key] = v64.float().half()       # whole image at fp16 resolution (0.6 MB instead of 4.7); `img_train_sample` carries fp32 samples
+        else:
+            arrays[key] = v64 if key.startswith('grad') else v64.float()
+    meta = dict(B=B, F=F, res=RES, w_dim=512, z_dim=512, seed_G=303, seed_D=404, real_seed=1079, noise=noise,
                 G_params=sum(p.numel() for p in G.parameters()), D_params=sum(p.numel() for p in D.parameters()))
+    worst = sorted(noise.items(), key=lambda kv: -kv[1])[:8]
+    print('largest fp32-vs-fp64 noise of the reference itself:', ', '.join('%s %.1e' % kv for kv in worst))
     save('networks_full', arrays, meta)
 
 

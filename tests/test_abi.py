@@ -61,7 +61,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(custom_ops.Upfirdn2dParams) == 176
     assert ctypes.sizeof(custom_ops.BiasActParams) == 80
     assert ctypes.sizeof(custom_ops.TimeEncodeParams) == 96
-    assert ctypes.sizeof(custom_ops.GemmParams) == 120
+    assert ctypes.sizeof(custom_ops.GemmParams) == 128
     assert ctypes.sizeof(custom_ops.ProfEntry) == 32
     assert ctypes.sizeof(custom_ops.PointwiseParams) == 56
     assert ctypes.sizeof(custom_ops.ConvWrwParams) == 48

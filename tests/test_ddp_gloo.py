@@ -19,14 +19,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make(world, rank, batch_gpu, ddp):
+def _make(world, rank, batch_gpu, ddp, ddp_manual=None):
     from stylegan_v_amd.training import config as cfgs
     from stylegan_v_amd.training.train_step import TrainStep
     g_kwargs, d_kwargs = cfgs.small_test_model_kwargs(res=32)
     # D's minibatch-std groups must not straddle ranks for the equivalence: group size 2 with 2 videos per rank
     train_cfg = cfgs.Config(r1_gamma=1.0, lr=0.0025, betas=(0.0, 0.99), ema_kimg=1.0, ema_rampup=0.05, G_reg_interval=4, D_reg_interval=16,
                             pl_weight=0.0)
-    return TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=batch_gpu, world_size=world, rank=rank, seed=0, ddp=ddp)
+    return TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=batch_gpu, world_size=world, rank=rank, seed=0, ddp=ddp, ddp_manual=ddp_manual)
 
 
 def _phase_grads(ts, phase, real_img, real_t, z, t):
@@ -65,6 +65,20 @@ def _worker(rank, world, port, out_dir):
         for phase in ('Gmain', 'Dmain', 'Dreg'):
             torch.manual_seed(77 + rank)  # rank-local RNG stream for the in-forward randn
             res[phase] = _phase_grads(ts, phase, real[sl], real_t[sl], z[sl], t[sl])
+        # the wrapper-free form used under hipGraph replay (one flat all-reduce behind the backward pass) gives the same averaged gradients
+        tm = _make(world, rank, batch_gpu=2, ddp=True, ddp_manual=True)
+        assert tm.ddp_manual and not isinstance(tm.loss.D, torch.nn.parallel.DistributedDataParallel)
+        tm.G.load_state_dict(ts.G.state_dict()); tm.D.load_state_dict(ts.D.state_dict())
+        for phase in ('Gmain', 'Dmain', 'Dreg'):
+            torch.manual_seed(77 + rank)
+            _phase_grads(tm, phase, real[sl], real_t[sl], z[sl], t[sl])
+            tm._allreduce_gradients(next(ph for ph in tm.phases if ph['name'] == phase))
+            mod = tm.G if phase.startswith('G') else tm.D
+            for name, p in mod.named_parameters():
+                if p.grad is not None:
+                    want = res[phase][name]
+                    assert (p.grad - want).abs().max().item() <= 1e-6 * (want.abs().max().item() + 1e-6), f'manual all-reduce differs from DDP: {phase} {name}'
+        assert tm.step() == ['Gmain', 'Greg', 'Dmain', 'Dreg']
         # gating: a D-only phase must leave G's DDP wrappers un-synchronised and vice versa (no hang == correct gating)
         ran = ts.step()
         assert ran == ['Gmain', 'Greg', 'Dmain', 'Dreg']

@@ -64,7 +64,7 @@ def _s1_slab_oracle(x, w, s, d, b, n, r0, r1, alpha, gain, transposed=False):
     xs = x[n:n + 1, :, lo:hi].double().cpu()
     if s is not None:
         xs = xs * s[n:n + 1].double().cpu()[:, :, None, None]
-    acc = torch.from_numpy(oracle.conv3x3(xs.numpy(), w.double().cpu().numpy(), stride=1, transposed=transposed))[:, :, r0 - lo:r0 - lo + (r1 - r0)]
+    acc = torch.from_numpy(oracle.conv3x3(xs.numpy(), w.double().cpu().numpy(), stride=1, transposed=transposed))[:, :, r0 - lo:r0 - lo + (r1 - r0)].contiguous()   # oracle.bias_act reads dense memory
     if d is not None:
         acc = acc * d[n:n + 1].double().cpu()[:, :, None, None]
     return acc, oracle.bias_act(acc, b.double().cpu() if b is not None else None, act='lrelu', alpha=alpha, gain=gain)
@@ -210,7 +210,7 @@ def test_fused_fir_epilogue_modes_1_and_2_at_benchmark_shape():
     yc = fused_fir_act.fir_bias_act_composed(x, f, scale=sc, bias=b, padding=1, fir_gain=4, act='lrelu')
     assert torch.equal(y, yc), 'mode 1 differs from the three-pass composition of this library (fp32: same operations, same order)'
     for n, ch in _planes():
-        u = oracle.upfirdn2d(x[n:n + 1, ch:ch + 1].detach().cpu(), f.cpu(), padding=1, gain=4)
+        u = oracle.upfirdn2d(x[n:n + 1, ch:ch + 1].detach().cpu().contiguous(), f.cpu(), padding=1, gain=4)
         ref = oracle.bias_act(u * sc[n, ch].detach().cpu(), b[ch:ch + 1].detach().cpu(), act='lrelu')
         assert torch.equal(y[n:n + 1, ch:ch + 1].detach().cpu(), ref), f'plane ({n}, {ch}): mode 1 is not bit-exact vs oracle.upfirdn2d -> * scale -> oracle.bias_act'
 
@@ -226,8 +226,8 @@ def test_fused_fir_epilogue_modes_1_and_2_at_benchmark_shape():
         err = (got - want).abs().max().item() / want.abs().max().item()
         assert err < 2e-5, f'mode 2 {name} gradient (in-kernel plane sums): {err:.2e}'
     for n, ch in _planes():
-        yp = y[n:n + 1, ch:ch + 1].detach().cpu()
-        gz = oracle.bias_act(dy[n:n + 1, ch:ch + 1].cpu(), None, act='lrelu', grad=1, xref=yp, yref=yp)     # lrelu: the sign of y selects the branch
+        yp = y[n:n + 1, ch:ch + 1].detach().cpu().contiguous()
+        gz = oracle.bias_act(dy[n:n + 1, ch:ch + 1].cpu().contiguous(), None, act='lrelu', grad=1, xref=yp, yref=yp)     # lrelu: the sign of y selects the branch
         ref = oracle.upfirdn2d(gz * sc[n, ch].detach().cpu(), f.cpu(), padding=2, flip_filter=True, gain=4)
         assert torch.equal(gx[n:n + 1, ch:ch + 1].cpu(), ref), f'plane ({n}, {ch}): mode 2 is not bit-exact vs the oracle composition'
 
@@ -254,7 +254,7 @@ def test_fused_fir_backward_epilogue_mode_3_at_benchmark_shape():
     ps = want.sum(dim=(2, 3), dtype=torch.float64).reshape(-1)
     assert (sums.double() - ps).abs().max().item() / ps.abs().max().item() < 2e-5, 'in-kernel plane sums'
     for n, ch in _planes():
-        u = oracle.upfirdn2d(gin[n:n + 1, ch:ch + 1].cpu(), f.cpu(), padding=list(bpads), flip_filter=True)
-        yp = y0[n:n + 1, ch:ch + 1].cpu()
+        u = oracle.upfirdn2d(gin[n:n + 1, ch:ch + 1].cpu().contiguous(), f.cpu(), padding=list(bpads), flip_filter=True).contiguous()
+        yp = y0[n:n + 1, ch:ch + 1].cpu().contiguous()
         ref = oracle.bias_act(u, None, act='lrelu', alpha=alpha, gain=gain, grad=1, xref=yp, yref=yp)
         assert torch.equal(dz[n:n + 1, ch:ch + 1].cpu(), ref), f'plane ({n}, {ch}): mode 3 is not bit-exact vs oracle.upfirdn2d -> oracle.bias_act(grad=1)'
