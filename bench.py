@@ -118,6 +118,109 @@ def cpu_baseline(res, frames, seconds_cap):
                 sample=f'{done} training iteration(s) at batch 1 video x {frames} frames, {res}x{res}, fp32 (iteration 0 includes Greg+Dreg), {spent:.1f} s')
 
 
+def synthesis_workload(args, world, rank, device):
+    """BASELINE configs[4] (`g1024`: SkyTimelapse 1024x1024 synthesis, 16-frame clips, min_period_len 256, 8 clips over 8 GPUs = one clip per
+    GPU and step) / configs[1] (`g256`: FFS 256x256 generator forward, 32 videos x 3 frames): the reference's generation loop
+    (src/scripts/generate.py:43-145 -> Generator.forward in eval mode, networks.py:370-401) on synthetic latents, replicas only (no collective).
+    A step = one batch of clips through G; value = frames/s over all ranks.  `roofline` = the upfirdn2d chain (HBM-bound; 16 calls per forward
+    at 1024^2), with a per-size table; per-family accounting as in the training workload."""
+    from stylegan_v_amd.torch_utils import custom_ops
+    from stylegan_v_amd.training import config as cfgs
+    from stylegan_v_amd.training.networks import Generator
+    res, frames = (1024, 16) if args.workload == 'g1024' else (256, 3)
+    clips = args.clips_gpu if args.workload == 'g1024' else args.batch_gpu
+    g_kwargs, _, _ = cfgs.model_kwargs(resolution=res, batch_size=clips * world, num_gpus=world, min_period_len=256 if res == 1024 else 16, num_frames_per_video=frames)
+    torch.manual_seed(rank)
+    G = Generator(**g_kwargs).to(device).eval().requires_grad_(False)
+    z, c = torch.randn([clips, 512], device=device), torch.zeros([clips, 0], device=device)
+    t = torch.arange(frames, device=device, dtype=torch.float32).unsqueeze(0).repeat(clips, 1) if res == 1024 else \
+        torch.sort(torch.rand([clips, frames], device=device) * 100, dim=1).values
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            G(z, c, t)
+        launches0 = custom_ops.launch_count()
+        if not args.no_prof:
+            custom_ops.prof_enable(1 << 16)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            img = G(z, c, t)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        records = []
+        if not args.no_prof:
+            custom_ops.prof_disable()
+            records = custom_ops.prof_collect_records(1 << 16)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                G(z, c, t)
+            barrier()
+            clean = time.perf_counter() - t1
+        else:
+            clean = elapsed
+    assert img.shape == (clips * frames, 3, res, res) and bool(torch.isfinite(img).all())
+    t_max = torch.tensor([elapsed, clean], dtype=torch.float64, device=device)
+    if world > 1:
+        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
+    elapsed, clean = float(t_max[0]), float(t_max[1])
+    if rank == 0:
+        fam, sizes = {}, {}
+        for name, ms, nbytes, nflops in records:
+            e = fam.setdefault(name, dict(launches=0, ms=0.0, bytes=0.0, flops=0.0))
+            e['launches'] += 1; e['ms'] += ms; e['bytes'] += nbytes; e['flops'] += nflops
+            if name == 'upfirdn2d_lanes':
+                g = sizes.setdefault(int(nbytes), [0, 0.0])
+                g[0] += 1; g[1] += ms
+        kernels = {n: dict(launches=e['launches'], ms_total=e['ms'], avg_us=1e3 * e['ms'] / e['launches'],
+                           **({'GBps': e['bytes'] / (e['ms'] * 1e-3) / 1e9} if e['bytes'] > 0 else {}), **({'TFLOPs': e['flops'] / (e['ms'] * 1e-3) / 1e12} if e['flops'] > 0 else {}))
+                   for n, e in fam.items() if e['launches']}
+        roofline, by_size = None, None
+        if 'upfirdn2d_lanes' in fam:
+            r = fam['upfirdn2d_lanes']
+            achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
+            roofline = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel (the FIR / 2x up-sampling chain of the synthesis network)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS,
+                            unit='GB/s', frac=achieved / HBM_PEAK_GBPS, frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=None, launches=r['launches'],
+                            launches_per_forward=r['launches'] / args.steps, algorithmic_bytes_per_forward=r['bytes'] / args.steps, avg_launch_us=1e3 * r['ms'] / r['launches'],
+                            share_of_forward_time=r['ms'] / (1e3 * elapsed),
+                            note='size-weighted over every upfirdn2d launch of the timed forwards (HIP events recorded by the C ABI on the launch stream); no PMC pass for this workload')
+            by_size = [dict(algorithmic_MB=b / 1e6, launches=n, avg_us=1e3 * ms / n, GBps=b * n / (ms * 1e-3) / 1e9, share_of_family_time=ms / r['ms']) for b, (n, ms) in sorted(sizes.items(), reverse=True)]
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            # CPU leg: the same generator on the host cores through the plain-PyTorch op path, ONE frame (the clip is 16 of them)
+            log('[bench] timing the CPU baseline leg ...')
+            threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1), 64))
+            torch.set_num_threads(threads)
+            Gc = Generator(**g_kwargs).eval().requires_grad_(False)
+            zc, cc, tc = torch.randn([1, 512]), torch.zeros([1, 0]), torch.zeros([1, 1])
+            with torch.no_grad():
+                tcpu = time.perf_counter()
+                Gc(zc, cc, tc)
+                first = time.perf_counter() - tcpu
+                done, spent = 1, first
+                while spent + first < args.cpu_seconds and done < 8:
+                    tcpu = time.perf_counter(); Gc(zc, cc, tc); spent += time.perf_counter() - tcpu; done += 1
+            cpu = dict(value=done / spent, unit='img/s', cores=threads, kind='port', sample=f'{done} single-frame forward(s) of the same generator at {res}x{res} on the host, fp32, {spent:.1f} s')
+        workload = (f'SkyTimelapse-config generator synthesis {res}x{res} (fmaps 1, min_period_len 256), {clips} clip(s) x {frames} frames per GPU and step, eval mode, fp32'
+                    if res == 1024 else f'FFS-config generator forward {res}x{res}, {clips} videos x {frames} frames per GPU and step, eval mode, fp32')
+        out = dict(metric=f'G synthesis images/sec at {res}^2 ({frames}-frame clips)', value=clips * frames * world * args.steps / elapsed, unit='img/s', n_gpus=world, steps=args.steps,
+                   warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
+                   dtype='fp32 I/O + fp32 accumulate; 3x3 convolution products are 2-way-bf16-split where the hand-written kernels serve the channel counts (>= 64 output channels), vendor fp32 below',
+                   data='synthetic',
+                   config=dict(workload=workload, clips_per_gpu=clips, frames_per_clip=frames, parallelism=f'replicas x{world} (no collective)',
+                               native_launches_per_forward=(custom_ops.launch_count() - launches0) / (2 * args.steps if not args.no_prof else args.steps)),
+                   value_no_prof=clips * frames * world * args.steps / clean, roofline=roofline, upfirdn2d_by_size=by_size, kernels=kernels, cpu_baseline=cpu)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -127,6 +230,10 @@ def main():
     ap.add_argument('--res', type=int, default=256)
     ap.add_argument('--frames', type=int, default=3)
     ap.add_argument('--cpu-seconds', type=float, default=25.0, help='budget of the CPU baseline leg; 0 disables it')
+    ap.add_argument('--workload', choices=['train256', 'g1024', 'g256'], default='train256',
+                    help="train256: the G+D training step (BASELINE configs[2], the default); g1024 / g256: generator synthesis of 16-frame clips at "
+                         "1024^2 (BASELINE configs[4], SkyTimelapse config: fmaps 1, min_period_len 256) / 3-frame clips at 256^2 (configs[1])")
+    ap.add_argument('--clips-gpu', type=int, default=1, help='g1024 / g256: clips per GPU and step (configs[4]: 8 clips over 8 GPUs)')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
     ap.add_argument('--clean-steps', type=int, default=-1, help='steps of the un-instrumented repeat of the timed window (value_no_prof); -1 = --steps, 0 disables it')
     ap.add_argument('--ada-steps', type=int, default=8, help="steps of the aug=ada companion measurement (the reference's default augmentation, bgc pipeline); 0 disables it")
@@ -176,6 +283,8 @@ def main():
     # "find" would time every solver (incl. the naive one) on full-size tensors for many minutes: use immediate mode.
     import stylegan_v_amd
     stylegan_v_amd.configure_miopen(immediate=os.environ.get('SGV_MIOPEN_FIND', '0') != '1')
+    if args.workload != 'train256':
+        return synthesis_workload(args, world, rank, device)
     global_batch = args.batch_gpu * world
     lowp = {'none': None, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.lowp]
     g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=(lowp is None),

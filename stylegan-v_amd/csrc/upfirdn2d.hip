@@ -938,7 +938,9 @@ struct tile_params {
 constexpr int TILE_ROWS = 16, TILE_IN_ROWS = TILE_ROWS + 3;
 inline int tile_lds_floats(int lpr_log2) { return TILE_IN_ROWS * (64 >> lpr_log2) * ((4 << lpr_log2) + 8); }
 
-template <typename T, int XTRA, int EPI>
+// WIDE: one plane per wave row (lpr_log2 == 6): the LDS pitches are compile-time constants (the instantiation of the >= 129-column calls, which
+// carry most of the bytes; the run-time-pitch form spent ~30 % more instructions on addresses and measured 6-8 % below tools/ufd_lab.hip V6).
+template <typename T, int XTRA, int EPI, bool WIDE>
 __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     constexpr int NH = 3 + XTRA, NOUT = 4 + XTRA;
     extern __shared__ __attribute__((aligned(16))) float tile_lds[];
@@ -948,23 +950,29 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     const int rt = blockIdx.x % p.row_tiles;
     const int cg = (blockIdx.x / p.row_tiles) % p.col_groups;
     const int pg = blockIdx.x / (p.row_tiles * p.col_groups);
-    const int lpr = 1 << p.lpr_log2;
-    const int sub = lane & (lpr - 1), slot = lane >> p.lpr_log2;
-    const int plane = pg * (64 >> p.lpr_log2) + slot;
+    const int lpr = WIDE ? 64 : 1 << p.lpr_log2;
+    const int sub = WIDE ? lane : lane & (lpr - 1), slot = WIDE ? 0 : lane >> p.lpr_log2;
+    const int plane = WIDE ? pg : pg * (64 >> p.lpr_log2) + slot;
     const bool plane_ok = plane < p.planes;
     const int seg_pitch = 4 * lpr + 8;                        // floats of one plane's row in LDS: 4 per lane + the halo words (16-byte aligned)
-    const int row_pitch = (64 >> p.lpr_log2) * seg_pitch;
+    const int row_pitch = WIDE ? 264 : (64 >> p.lpr_log2) * seg_pitch;
     // The taps through the scalar cache (every index is wave-uniform): the lanes kernel's "16 lanes load, v_readlane broadcasts" makes hipcc wait
     // for that vector load (vmcnt(0)) BEFORE the row loads below are issued -- a whole memory latency in front of every workgroup's requests
     // (ISA of the first version of this kernel; the lab kernel, which read the taps with s_load, was 6 % faster for that reason alone).
     float ff[4][4];
+    {
+        const int fsh = (int)p.f_sh, fsw = (int)p.f_sw;          // a filter is at most 4 x 4: 32-bit index arithmetic on the scalar unit
+        const int a0 = p.flip ? 0 : (p.f_h - 1) * fsh, da = p.flip ? fsh : -fsh;
+        const int b0 = p.flip ? 0 : (p.f_w - 1) * fsw, db = p.flip ? fsw : -fsw;
 #pragma unroll
-    for (int a = 0; a < 4; a++)
+        for (int a = 0; a < 4; a++)
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
-            ff[a][b] = 0.f;
-            if (a < p.f_h && b < p.f_w) ff[a][b] = p.f[(p.flip ? a : p.f_h - 1 - a) * p.f_sh + (p.flip ? b : p.f_w - 1 - b) * p.f_sw];
-        }
+            for (int b = 0; b < 4; b++) {
+                const bool live = a < p.f_h && b < p.f_w;
+                const float v = p.f[live ? a0 + a * da + b0 + b * db : 0];
+                ff[a][b] = live ? v : 0.f;
+            }
+    }
     const T* xp = (const T*)p.x + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w;
     T* yp = (T*)p.y + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
     const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of 4
@@ -1307,7 +1315,8 @@ bool tile_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2, int*
 
 template <typename T>
 void launch_tile_t(const tile_params& tp, int xtra, int epi, dim3 grid, size_t lds, hipStream_t stream) {
-#define SGV_TILE_GO(X, E) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E>), grid, dim3(256), lds, stream, tp)
+#define SGV_TILE_GO(X, E) do { if (tp.lpr_log2 == 6) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, true>), grid, dim3(256), lds, stream, tp); \
+                               else hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false>), grid, dim3(256), lds, stream, tp); } while (0)
     if (epi == 0) { if (xtra) SGV_TILE_GO(1, 0); else SGV_TILE_GO(0, 0); }
     else if (epi == 1) { if (xtra) SGV_TILE_GO(1, 1); else SGV_TILE_GO(0, 1); }
     else { if (xtra) SGV_TILE_GO(1, 3); else SGV_TILE_GO(0, 3); }

@@ -118,7 +118,7 @@ def test_dense_with_thousands_of_rows_runs_on_the_tiled_gemm(m, k, n, act):
     x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
     yr = fc.dense_ref(x64, w64, b64, wg, bg, act, False, 1)
     want = torch.autograd.grad(yr, [x64, w64, b64], dy.double(), create_graph=True)
-    assert _rel(y.detach(), yr.detach()) < 5e-6
+    assert _rel(y.detach(), yr.detach()) < 1e-5      # split-bf16 products (tiled GEMM): 4.4e-6 of the result's scale
     for a, r, name in zip(got, want, ['dx', 'dw', 'db']):
         assert _rel(a.detach(), r.detach()) < 2e-5, f'{name}: {_rel(a.detach(), r.detach()):.2e}'
     if m <= 1500:   # second order (not met in training for these layers: kept correct all the same)
