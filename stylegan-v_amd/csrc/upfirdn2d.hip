@@ -956,23 +956,6 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     const bool plane_ok = plane < p.planes;
     const int seg_pitch = 4 * lpr + 8;                        // floats of one plane's row in LDS: 4 per lane + the halo words (16-byte aligned)
     const int row_pitch = WIDE ? 264 : (64 >> p.lpr_log2) * seg_pitch;
-    // The taps through the scalar cache (every index is wave-uniform): the lanes kernel's "16 lanes load, v_readlane broadcasts" makes hipcc wait
-    // for that vector load (vmcnt(0)) BEFORE the row loads below are issued -- a whole memory latency in front of every workgroup's requests
-    // (ISA of the first version of this kernel; the lab kernel, which read the taps with s_load, was 6 % faster for that reason alone).
-    float ff[4][4];
-    {
-        const int fsh = (int)p.f_sh, fsw = (int)p.f_sw;          // a filter is at most 4 x 4: 32-bit index arithmetic on the scalar unit
-        const int a0 = p.flip ? 0 : (p.f_h - 1) * fsh, da = p.flip ? fsh : -fsh;
-        const int b0 = p.flip ? 0 : (p.f_w - 1) * fsw, db = p.flip ? fsw : -fsw;
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                const bool live = a < p.f_h && b < p.f_w;
-                const float v = p.f[live ? a0 + a * da + b0 + b * db : 0];
-                ff[a][b] = live ? v : 0.f;
-            }
-    }
     const T* xp = (const T*)p.x + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w;
     T* yp = (T*)p.y + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
     const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of 4
@@ -1016,6 +999,24 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
             if (st_vec) row_loader<T, 4>::run(yr, yo[k]);
             if constexpr (XTRA) { if (st_xtra) yo[k][4] = sgv_traits<T>::load(yr + 4); }
         }
+    }
+    // The taps, AFTER the row loads have been issued and through the scalar cache (every index is wave-uniform).  Two things the first versions of this
+    // kernel got wrong, each worth ~5 % against tools/ufd_lab.hip V6: the lanes kernel's "16 lanes load, v_readlane broadcasts" makes hipcc wait for that
+    // vector load (vmcnt(0)) BEFORE the row loads are issued, and scalar tap loads placed in front of the row loads put two dependent scalar-memory
+    // round trips (kernel arguments, then the taps) in front of every workgroup's requests.
+    float ff[4][4];
+    {
+        const int fsh = (int)p.f_sh, fsw = (int)p.f_sw;          // a filter is at most 4 x 4: 32-bit index arithmetic on the scalar unit
+        const int a0 = p.flip ? 0 : (p.f_h - 1) * fsh, da = p.flip ? fsh : -fsh;
+        const int b0 = p.flip ? 0 : (p.f_w - 1) * fsw, db = p.flip ? fsw : -fsw;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const bool live = a < p.f_h && b < p.f_w;
+                const float v = p.f[live ? a0 + a * da + b0 + b * db : 0];
+                ff[a][b] = live ? v : 0.f;
+            }
     }
 #pragma unroll
     for (int k = 0; k < RPW; k++) {

@@ -169,7 +169,7 @@ def test_gemm_conv1x1(n, cin, cout, h):
     got = torch.autograd.grad(y, [x, w, b], dy)
     want = torch.autograd.grad(ref, [x, w, b], dy.double())
     for a, r, name in zip(got, want, 'xwb'):
-        assert_close(a, r, atol=1e-3, rtol=1e-4, what='d' + name)
+        assert_close(a, r, atol=1e-3 + 1e-5 * r.abs().max().item(), rtol=1e-4, what='d' + name)
 
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])

@@ -192,6 +192,12 @@ def _planes():
     return [(0, 0), (N // 2 + 1, 31), (N - 1, 63)]
 
 
+def _dense(t):
+    """CPU copy with canonical strides (oracle.bias_act compares strides; a [1, 1, H, W] slice of a batch keeps the batch's strides in its size-1 dims)."""
+    t = t.detach().cpu()
+    return t.reshape(-1).clone().reshape(t.shape)
+
+
 def test_fused_fir_epilogue_modes_1_and_2_at_benchmark_shape():
     """The up-sampling SynthesisLayer's tail (upfirdn2d -> * dcoefs -> bias_act, conv2d_resample.py:138-139 + networks.py:70-74,141-143) as one
     kernel (mode 1) and its backward as one kernel (mode 2), b256.conv0: [96, 64, 257, 257] -> [96, 64, 256, 256]."""
@@ -210,8 +216,8 @@ def test_fused_fir_epilogue_modes_1_and_2_at_benchmark_shape():
     yc = fused_fir_act.fir_bias_act_composed(x, f, scale=sc, bias=b, padding=1, fir_gain=4, act='lrelu')
     assert torch.equal(y, yc), 'mode 1 differs from the three-pass composition of this library (fp32: same operations, same order)'
     for n, ch in _planes():
-        u = oracle.upfirdn2d(x[n:n + 1, ch:ch + 1].detach().cpu().contiguous(), f.cpu(), padding=1, gain=4)
-        ref = oracle.bias_act(u * sc[n, ch].detach().cpu(), b[ch:ch + 1].detach().cpu(), act='lrelu')
+        u = oracle.upfirdn2d(_dense(x[n:n + 1, ch:ch + 1]), f.cpu(), padding=1, gain=4)
+        ref = oracle.bias_act(_dense(u * sc[n, ch].detach().cpu()), b[ch:ch + 1].detach().cpu(), act='lrelu')
         assert torch.equal(y[n:n + 1, ch:ch + 1].detach().cpu(), ref), f'plane ({n}, {ch}): mode 1 is not bit-exact vs oracle.upfirdn2d -> * scale -> oracle.bias_act'
 
     dy = torch.randn(y.shape, generator=g, device=DEV)
@@ -226,9 +232,9 @@ def test_fused_fir_epilogue_modes_1_and_2_at_benchmark_shape():
         err = (got - want).abs().max().item() / want.abs().max().item()
         assert err < 2e-5, f'mode 2 {name} gradient (in-kernel plane sums): {err:.2e}'
     for n, ch in _planes():
-        yp = y[n:n + 1, ch:ch + 1].detach().cpu().contiguous()
-        gz = oracle.bias_act(dy[n:n + 1, ch:ch + 1].cpu().contiguous(), None, act='lrelu', grad=1, xref=yp, yref=yp)     # lrelu: the sign of y selects the branch
-        ref = oracle.upfirdn2d(gz * sc[n, ch].detach().cpu(), f.cpu(), padding=2, flip_filter=True, gain=4)
+        yp = _dense(y[n:n + 1, ch:ch + 1])
+        gz = oracle.bias_act(_dense(dy[n:n + 1, ch:ch + 1]), None, act='lrelu', grad=1, xref=yp, yref=yp)     # lrelu: the sign of y selects the branch
+        ref = oracle.upfirdn2d(_dense(gz * sc[n, ch].detach().cpu()), f.cpu(), padding=2, flip_filter=True, gain=4)
         assert torch.equal(gx[n:n + 1, ch:ch + 1].cpu(), ref), f'plane ({n}, {ch}): mode 2 is not bit-exact vs the oracle composition'
 
 
@@ -254,7 +260,7 @@ def test_fused_fir_backward_epilogue_mode_3_at_benchmark_shape():
     ps = want.sum(dim=(2, 3), dtype=torch.float64).reshape(-1)
     assert (sums.double() - ps).abs().max().item() / ps.abs().max().item() < 2e-5, 'in-kernel plane sums'
     for n, ch in _planes():
-        u = oracle.upfirdn2d(gin[n:n + 1, ch:ch + 1].cpu().contiguous(), f.cpu(), padding=list(bpads), flip_filter=True).contiguous()
-        yp = y0[n:n + 1, ch:ch + 1].cpu().contiguous()
+        u = _dense(oracle.upfirdn2d(_dense(gin[n:n + 1, ch:ch + 1]), f.cpu(), padding=list(bpads), flip_filter=True))
+        yp = _dense(y0[n:n + 1, ch:ch + 1])
         ref = oracle.bias_act(u, None, act='lrelu', alpha=alpha, gain=gain, grad=1, xref=yp, yref=yp)
         assert torch.equal(dz[n:n + 1, ch:ch + 1].cpu(), ref), f'plane ({n}, {ch}): mode 3 is not bit-exact vs oracle.upfirdn2d -> oracle.bias_act(grad=1)'
