@@ -28,6 +28,7 @@
 //    (numel(x) + numel(y)) * sizeof(T)   [+ 4*fw*fh, negligible]       
 
 #include "sgv_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 #pragma clang fp contract(off)
@@ -940,7 +941,12 @@ inline int tile_lds_floats(int lpr_log2) { return TILE_IN_ROWS * (64 >> lpr_log2
 
 // WIDE: one plane per wave row (lpr_log2 == 6): the LDS pitches are compile-time constants (the instantiation of the >= 129-column calls, which
 // carry most of the bytes; the run-time-pitch form spent ~30 % more instructions on addresses and measured 6-8 % below tools/ufd_lab.hip V6).
-template <typename T, int XTRA, int EPI, bool WIDE>
+// NT: stream the output past the caches (tensors larger than the Infinity Cache).  A template parameter, not a branch: with both store forms in the
+//     kernel -- even as two copies of the row loop behind one wave-uniform branch -- the headline call ran 5 % slower (tools/ufd_lab.hip
+//     SGV_TILE_EXP=8, profiles/r03_ufd_tile_bisect.log).
+// F44: the filter is a dense 4 x 4 fp32 array (what setup_filter produces): its 16 taps are ONE s_load_dwordx16 issued with the kernel arguments;
+//     sixteen separately addressed scalar loads (any size <= 4 x 4, any strides: F44 = false) cost 3-4 % on the same call.
+template <typename T, int XTRA, int EPI, bool WIDE, bool NT, bool F44>
 __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     constexpr int NH = 3 + XTRA, NOUT = 4 + XTRA;
     extern __shared__ __attribute__((aligned(16))) float tile_lds[];
@@ -956,6 +962,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     const bool plane_ok = plane < p.planes;
     const int seg_pitch = 4 * lpr + 8;                        // floats of one plane's row in LDS: 4 per lane + the halo words (16-byte aligned)
     const int row_pitch = WIDE ? 264 : (64 >> p.lpr_log2) * seg_pitch;
+    float ff[4][4];
+    if constexpr (F44) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) ff[a][b] = p.flip ? p.f[a * 4 + b] : p.f[(3 - a) * 4 + (3 - b)];
+    }
     const T* xp = (const T*)p.x + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w;
     T* yp = (T*)p.y + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
     const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of 4
@@ -1000,12 +1013,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
             if constexpr (XTRA) { if (st_xtra) yo[k][4] = sgv_traits<T>::load(yr + 4); }
         }
     }
-    // The taps, AFTER the row loads have been issued and through the scalar cache (every index is wave-uniform).  Two things the first versions of this
-    // kernel got wrong, each worth ~5 % against tools/ufd_lab.hip V6: the lanes kernel's "16 lanes load, v_readlane broadcasts" makes hipcc wait for that
-    // vector load (vmcnt(0)) BEFORE the row loads are issued, and scalar tap loads placed in front of the row loads put two dependent scalar-memory
-    // round trips (kernel arguments, then the taps) in front of every workgroup's requests.
-    float ff[4][4];
-    {
+    // Any other filter: the taps AFTER the row loads have been issued, through the scalar cache (every index is wave-uniform).  (The lanes kernel's
+    // "16 lanes load, v_readlane broadcasts" makes hipcc wait for that vector load -- vmcnt(0) -- BEFORE the row loads are issued.)
+    if constexpr (!F44) {
         const int fsh = (int)p.f_sh, fsw = (int)p.f_sw;          // a filter is at most 4 x 4: 32-bit index arithmetic on the scalar unit
         const int a0 = p.flip ? 0 : (p.f_h - 1) * fsh, da = p.flip ? fsh : -fsh;
         const int b0 = p.flip ? 0 : (p.f_w - 1) * fsw, db = p.flip ? fsw : -fsw;
@@ -1090,7 +1100,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
             o[v] = t;
         }
         T* yr = yp + (size_t)oy * p.out_w + ox;
-        if (st_vec) { if (p.nt_store) store_vec_nt<T, 4>(yr, o); else store_vec_plain<T, 4>(yr, o); }
+        if (st_vec) { if (NT) store_vec_nt<T, 4>(yr, o); else store_vec_plain<T, 4>(yr, o); }
         if constexpr (XTRA) { if (st_xtra) sgv_traits<T>::store(yr + 4, o[4]); }
     }
     if constexpr (EPI == 3) {   // reduce over the lanes of a plane row, then one atomic per plane and wave
@@ -1314,14 +1324,24 @@ bool tile_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2, int*
     return true;
 }
 
+template <typename T, int X, int E>
+void launch_tile_xe(const tile_params& tp, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
+    // dense 4 x 4 filters get the specialised forms (WIDE x NT); any other filter the general one
+    if (!f44) { hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, false, false>), grid, dim3(256), lds, stream, tp); return; }
+    if (tp.lpr_log2 == 6) {
+        if (tp.nt_store) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, true, true, true>), grid, dim3(256), lds, stream, tp);
+        else hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, true, false, true>), grid, dim3(256), lds, stream, tp);
+    } else {
+        if (tp.nt_store) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, true, true>), grid, dim3(256), lds, stream, tp);
+        else hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, false, true>), grid, dim3(256), lds, stream, tp);
+    }
+}
+
 template <typename T>
-void launch_tile_t(const tile_params& tp, int xtra, int epi, dim3 grid, size_t lds, hipStream_t stream) {
-#define SGV_TILE_GO(X, E) do { if (tp.lpr_log2 == 6) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, true>), grid, dim3(256), lds, stream, tp); \
-                               else hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false>), grid, dim3(256), lds, stream, tp); } while (0)
-    if (epi == 0) { if (xtra) SGV_TILE_GO(1, 0); else SGV_TILE_GO(0, 0); }
-    else if (epi == 1) { if (xtra) SGV_TILE_GO(1, 1); else SGV_TILE_GO(0, 1); }
-    else { if (xtra) SGV_TILE_GO(1, 3); else SGV_TILE_GO(0, 3); }
-#undef SGV_TILE_GO
+void launch_tile_t(const tile_params& tp, int xtra, int epi, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
+    if (epi == 0) { if (xtra) launch_tile_xe<T, 1, 0>(tp, f44, grid, lds, stream); else launch_tile_xe<T, 0, 0>(tp, f44, grid, lds, stream); }
+    else if (epi == 1) { if (xtra) launch_tile_xe<T, 1, 1>(tp, f44, grid, lds, stream); else launch_tile_xe<T, 0, 1>(tp, f44, grid, lds, stream); }
+    else { if (xtra) launch_tile_xe<T, 1, 3>(tp, f44, grid, lds, stream); else launch_tile_xe<T, 0, 3>(tp, f44, grid, lds, stream); }
 }
 
 int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dtype, int lpr_log2, int col_groups, int xtra, hipStream_t stream) {
@@ -1345,9 +1365,11 @@ int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dt
     if (blocks > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: too many workgroups");
     const size_t lds = (size_t)tile_lds_floats(lpr_log2) * sizeof(float);
     const dim3 grid((unsigned)blocks);
-    if (dtype == SGV_F32) launch_tile_t<float>(tp, xtra, epi, grid, lds, stream);
-    else if (dtype == SGV_F16) launch_tile_t<sgv_half_t>(tp, xtra, epi, grid, lds, stream);
-    else launch_tile_t<sgv_bf16_t>(tp, xtra, epi, grid, lds, stream);
+    const bool f44 = p->f_w == 4 && p->f_h == 4 && p->f_sw == 1 && p->f_sh == 4;
+    if (!f44) tp.nt_store = 0;      // the general-filter form has one (plain-store) instantiation
+    if (dtype == SGV_F32) launch_tile_t<float>(tp, xtra, epi, f44, grid, lds, stream);
+    else if (dtype == SGV_F16) launch_tile_t<sgv_half_t>(tp, xtra, epi, f44, grid, lds, stream);
+    else launch_tile_t<sgv_bf16_t>(tp, xtra, epi, f44, grid, lds, stream);
     sgv_note_variant(epi == 0 ? SGV_V_ufd_tile : epi == 1 ? SGV_V_ufd_tile_fused1 : SGV_V_ufd_tile_fused3);
     return sgv_check_launch("upfirdn2d_tile_kernel");
 }

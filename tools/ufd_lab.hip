@@ -8,6 +8,9 @@
 #include <string>
 #include <dlfcn.h>
 #include "../include/sgv_ops.h"
+// the product's own translation units: its kernels can then be launched directly, without the C ABI in between (V7 below)
+#include "../stylegan-v_amd/csrc/sgv_runtime.hip"
+#include "../stylegan-v_amd/csrc/upfirdn2d.hip"
 #pragma clang fp contract(off)
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
@@ -586,6 +589,23 @@ int main(int argc, char** argv) {
         RUN4A(4, 1, 1) RUN4A(4, 1, 2) RUN4A(1, 1, 2) RUN4A(4, 2, 2)
     }
 
+    {   // V7: the PRODUCT's upfirdn2d_tile_kernel launched directly from this harness (same parameters as the C ABI builds)
+        tile_params tp{};
+        tp.f = f; tp.flip = 0; tp.gain = 4.0f; tp.in_w = IW; tp.in_h = IH; tp.out_w = OW; tp.out_h = OH; tp.planes = planes; tp.f_w = tp.f_h = 4; tp.f_sw = 1; tp.f_sh = 4;
+        tp.pad_x = tp.pad_y = pad; tp.lpr_log2 = 6; tp.col_groups = (OW / 4 + 63) / 64; tp.row_tiles = (OH + 15) / 16; tp.nt_store = 1;
+        tp.ep_act = 1; tp.ep_gain = 1.f; tp.ep_clamp = -1.f; tp.chans = C;
+        const long blocks7 = (long)planes * tp.col_groups * tp.row_tiles;
+        const size_t lds7 = (size_t)tile_lds_floats(6) * 4;
+        if (OW % 4 == 0) {
+            bench("V7 product tile kernel, direct launch", [&](const float* xi, float* yo) { tile_params r = tp; r.x = xi; r.y = yo;
+                hipLaunchKernelGGL((upfirdn2d_tile_kernel<float, 0, 0, true, true, true>), dim3((unsigned)blocks7), dim3(256), lds7, 0, r); }, true);
+            bench("V7b product tile kernel (run-time pitches), direct", [&](const float* xi, float* yo) { tile_params r = tp; r.x = xi; r.y = yo;
+                hipLaunchKernelGGL((upfirdn2d_tile_kernel<float, 0, 0, false, true, true>), dim3((unsigned)blocks7), dim3(256), lds7, 0, r); }, true);
+        } else if (OW % 4 == 1) {
+            bench("V7 product tile kernel XTRA, direct launch", [&](const float* xi, float* yo) { tile_params r = tp; r.x = xi; r.y = yo;
+                hipLaunchKernelGGL((upfirdn2d_tile_kernel<float, 1, 0, true, true, true>), dim3((unsigned)blocks7), dim3(256), lds7, 0, r); }, true);
+        }
+    }
     if (OW % 4 == 0) {
 #define RUN6(NWV, NTV) { const int TRv = 4 * NWV; int tiles_y = (OH + TRv - 1) / TRv; int cgs6 = (OW + 255) / 256; long blocks = (long)planes * cgs6 * tiles_y; \
           std::string nm = std::string("V6 LDS tile, loads up front, ") + std::to_string(TRv) + " rows NT" + #NTV; \
