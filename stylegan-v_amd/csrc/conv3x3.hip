@@ -24,9 +24,13 @@ int small_samples(int n, int h, int w) {
     return 0;
 }
 
+bool io16(int dtype) { return dtype == SGV_BF16 || dtype == SGV_F16; }
+
+// 16-bit tensors (bf16 / fp16 activations, fp32 weights): the producer / consumer kernels only (images >= 32 pixels), single bf16 operands (terms = 1)
 bool supported(int n, int k, int m, int h, int w, int dtype) {
-    if (!(dtype == SGV_F32 && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && (int64_t)n * std::max(k, m) * h * w <= INT32_MAX)) return false;
-    return (w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0) || small_samples(n, h, w) > 0;
+    if (!((dtype == SGV_F32 || io16(dtype)) && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && (int64_t)n * std::max(k, m) * h * w <= INT32_MAX)) return false;
+    if (w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0) return true;
+    return dtype == SGV_F32 && small_samples(n, h, w) > 0;
 }
 
 std::once_flag g_attr_once;
@@ -43,6 +47,10 @@ typedef void (*ws_kernel_t)(conv_ws_params);
 const ws_kernel_t g_ws_kernels[2][2][2] = {
     {{conv3x3_ws_kernel<1, 0, 0>, conv3x3_ws_kernel<1, 0, 1>}, {conv3x3_ws_kernel<1, 1, 0>, conv3x3_ws_kernel<1, 1, 1>}},
     {{conv3x3_ws_kernel<3, 0, 0>, conv3x3_ws_kernel<3, 0, 1>}, {conv3x3_ws_kernel<3, 1, 0>, conv3x3_ws_kernel<3, 1, 1>}}};
+// 16-bit tensors: [bf16 | fp16][PRO][EPI]
+const ws_kernel_t g_ws_kernels_io[2][2][2] = {
+    {{conv3x3_ws_kernel<1, 0, 0, 0, 1, 1>, conv3x3_ws_kernel<1, 0, 1, 0, 1, 1>}, {conv3x3_ws_kernel<1, 1, 0, 0, 1, 1>, conv3x3_ws_kernel<1, 1, 1, 0, 1, 1>}},
+    {{conv3x3_ws_kernel<1, 0, 0, 0, 1, 2>, conv3x3_ws_kernel<1, 0, 1, 0, 1, 2>}, {conv3x3_ws_kernel<1, 1, 0, 0, 1, 2>, conv3x3_ws_kernel<1, 1, 1, 0, 1, 2>}}};
 
 void init_once() {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -55,8 +63,10 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-    for (int t = 0; t < 2; t++) for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++)
+    for (int t = 0; t < 2; t++) for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)g_ws_kernels[t][a][b], hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)g_ws_kernels_io[t][a][b], hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+    }
     g_attr_err = e;
     const char* env = getenv("SGV_CONV_WS");
     g_use_ws = !(env && env[0] == '0');
@@ -113,8 +123,10 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: params is NULL", who);
     if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: NULL pointer", who);
     if (!supported(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, and W %% 32 == 0, H %% 16 == 0 or 16x16 / 8x8 images (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32 / bf16 / fp16 tensors, c_in %% 16 == 0, c_out %% 64 == 0, and W %% 32 == 0, H %% 16 == 0 (fp32 also: 16x16 / 8x8 images) (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
                         who, p->n, p->c_in, p->c_out, p->h, p->w, dtype);
+    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: 16-bit tensors need terms = 1 (one bf16 operand per value)", who);
+    if (io16(dtype) && ep && ep->accumulate) return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: accumulate needs fp32 tensors", who);
     if (ep && !big_image(p->h, p->w)) return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: the fused form needs W %% 32 == 0 and H %% 16 == 0 (got h=%d w=%d)", who, p->h, p->w);
     if (ep && (ep->act != 1 && ep->act != 3)) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: act must be 1 (linear) or 3 (lrelu)", who);
     if (ep && (!(ep->gain > 0.f) || (ep->act == 3 && !(ep->alpha >= 0.f && ep->alpha <= 1.f)))) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: needs gain > 0 and 0 <= alpha <= 1", who);
@@ -140,7 +152,8 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * (p->c_out / TM);
     kp.grid = std::min(kp.tiles, g_cus);
     const double elems = (double)p->n * p->h * p->w;
-    sgv_launch_scope scope(small ? SGV_K_CONV3X3 : SGV_K_CONV3X3_S1, stream, 4.0 * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9);
+    const double es = io16(dtype) ? 2.0 : 4.0;
+    sgv_launch_scope scope(small ? SGV_K_CONV3X3 : SGV_K_CONV3X3_S1, stream, es * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9);
     if (small) {
         if (p->w == 16) {
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
@@ -152,7 +165,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
         sgv_note_variant(SGV_V_conv_small);
         return sgv_check_launch("conv3x3_small_kernel");
     }
-    if (ep || g_use_ws) {
+    if (ep || g_use_ws || io16(dtype)) {
         conv_ws_params wp{};
         wp.c = kp;
         int pro = 0, epi = 0;
@@ -162,6 +175,11 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
             pro = ep->x_scale ? 1 : 0;
             // a bare convolution (no scales, no bias, linear, gain 1, no clamp: the accumulate-into data gradient) keeps the plain store path
             epi = (ep->out_scale || ep->bias || ep->act != 1 || ep->gain != 1.f || ep->clamp >= 0.f) ? 1 : 0;
+        }
+        if (io16(dtype)) {
+            hipLaunchKernelGGL(g_ws_kernels_io[dtype == SGV_F16][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
+            sgv_note_variant(SGV_V_conv_lowp);
+            return sgv_check_launch("conv3x3_ws_kernel (16-bit tensors)");
         }
         hipLaunchKernelGGL(g_ws_kernels[p->terms == 3][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
         sgv_note_variant((pro || epi) ? SGV_V_conv_s1_ws_fused : (ep && ep->accumulate) ? SGV_V_conv_s1_ws_accumulate : SGV_V_conv_s1_ws);

@@ -45,7 +45,7 @@ constexpr int LDS_BYTES = (XS_WORDS + WS_WORDS) * 16;
 constexpr int lds_bytes_rw(int rw) { return (4 * (4 * rw + 2) * PIN + WS_WORDS) * 16; }
 
 struct conv_params {
-    const float* x;        // [n, k, h, w]
+    const float* x;        // [n, k, h, w]   (conv3x3_ws_kernel with IO != 0: 16-bit elements behind the same pointers)
     const u32x4* wprep;    // [m tiles][k chunks][hl][tap][octet][64][8 bf16]
     float* y;              // [n, m, h, w]
     int n, k, m, h, w;

@@ -24,6 +24,7 @@
 #include <type_traits>
 
 #include "conv3x3_kernel.h"
+#include "sgv_io16.h"
 
 namespace sgv_conv {
 
@@ -55,8 +56,12 @@ __device__ __forceinline__ f32x16 ws_mma(u32x4 a, u32x4 b, f32x16 c) {
 // ABL (tools/conv_lab.hip only; results are wrong by construction): 1 producers only keep the barrier protocol (consumer-only speed), 2 no MFMAs
 // (operand reads + barriers), 3 no operand reads (MFMA issue + barriers), 4 no epilogue stores, 5 producers without global loads / DMA.
 // PRIO: s_setprio level of the consumer waves (the producers' VALU-heavy split competes for the SIMD's issue slots).
-template <int TERMS, int PRO, int EPI, int ABL = 0, int PRIO = 1>
+// IO: element format of x and y (sgv_io16.h): 0 fp32; 1 bf16 / 2 fp16 tensors (TERMS = 1: one bf16 operand per value, fp32 accumulate, 16-bit stores;
+//     weights, scales and the bias stay fp32) -- the mixed-precision blocks of the reference (networks.py:227,461), same loads count, same waits.
+template <int TERMS, int PRO, int EPI, int ABL = 0, int PRIO = 1, int IO = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
+    static_assert(IO == 0 || TERMS == 1, "16-bit tensors are multiplied as single bf16 operands");
+    using namespace sgv_io;
     const conv_params& p = pp.c;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     const int t = threadIdx.x, lane = t & 63;
@@ -106,7 +111,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         const int oct = pt & 1;                                                   // same for both units (192 and ITEMS are even)
         const int a_quad = (pt >> 1) & 7, a_row0 = pt >> 4, a_row1 = u1 >> 4;     // u1 >> 4 = a_row0 + 12
         const int hh = u1 - ITEMS, h_side = (hh >> 1) & 1, h_row = hh >> 2;
-        struct xset { f32x4 a[8]; f32x4 b[8]; f32x4 sc[2]; float ep0, ep1; bool ok0, ok1; };
+        struct xset { px4<IO> a[8]; px4<IO> b[8]; f32x4 sc[2]; float ep0, ep1; bool ok0, ok1; };
 
         // Branch-free: every thread issues the same 16 (+2) loads per chunk -- out-of-image positions load from a clamped address and are zeroed
         // when they are written to LDS -- so that the compiler can count them (`s_waitcnt vmcnt(16)` before the previous set is consumed)
@@ -114,22 +119,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         auto load_x = [&](int q, xset& r) {
             const tile_pos tp = decode_tile(p, first + (q / chunks) * p.grid, TROWS);
             const int c = q % chunks;
-            const float* xb_ = p.x + ((size_t)tp.n * p.k + c * KC + 8 * oct) * plane;
+            const size_t xb_ = ((size_t)tp.n * p.k + c * KC + 8 * oct) * plane;      // element offsets into p.x
             const int gy0 = tp.y0 - 1 + a_row0;
             const int gy1 = tp.y0 - 1 + (kind1 == 0 ? a_row1 : h_row);
             const int gx0 = tp.x0 + 4 * a_quad;
             const int gx1 = kind1 == 0 ? gx0 : (h_side ? tp.x0 + SEG : tp.x0 - 4);
             r.ok0 = gy0 >= 0 && gy0 < p.h;
             r.ok1 = kind1 != 2 && gy1 >= 0 && gy1 < p.h && gx1 >= 0 && gx1 < p.w;
-            const float* q0 = xb_ + (size_t)min(max(gy0, 0), p.h - 1) * p.w + gx0;
-            const float* q1 = xb_ + (size_t)min(max(gy1, 0), p.h - 1) * p.w + min(max(gx1, 0), p.w - 4);
+            const size_t q0 = xb_ + (size_t)min(max(gy0, 0), p.h - 1) * p.w + gx0;
+            const size_t q1 = xb_ + (size_t)min(max(gy1, 0), p.h - 1) * p.w + min(max(gx1, 0), p.w - 4);
             // The loads are inline asm on purpose: hipcc's own wait insertion cannot keep a load in flight across the loop back edge (it
             // emitted vmcnt(15) where 31 was needed, i.e. waited for one of the loads just issued), which puts the HBM latency back on
             // the producers' path.  Their destinations are unprotected until the counted s_waitcnt in `arrive` (cdna_hip_programming.md 5.7).
 #pragma unroll
-            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * plane) : "memory");
+            for (int j = 0; j < 8; j++) px4_load<IO>(r.a[j], at<IO>(p.x, q0 + j * plane));
 #pragma unroll
-            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b[j]) : "v"(q1 + j * plane) : "memory");
+            for (int j = 0; j < 8; j++) px4_load<IO>(r.b[j], at<IO>(p.x, q1 + j * plane));
             if (PRO == 1) {
                 const float* sp = pp.xscale + (size_t)tp.n * p.k + c * KC + 8 * oct;
                 asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.sc[0]) : "v"(sp) : "memory");
@@ -140,8 +145,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 // loads: as plain C++ loads inside put_ep the compiler put `s_waitcnt vmcnt(0)` in front of their use, which drained the chunk
                 // prefetch queue once per tile (64-channel layers: 4 chunks per tile)
                 const int m = tp.mt * TM + (pt & (TM - 1));
-                const float* po = pp.oscale ? pp.oscale + (size_t)tp.n * p.m + m : p.x;
-                const float* pb = pp.bias ? pp.bias + m : p.x;
+                const float* po = pp.oscale ? pp.oscale + (size_t)tp.n * p.m + m : (const float*)p.x;
+                const float* pb = pp.bias ? pp.bias + m : (const float*)p.x;
                 asm volatile("global_load_dword %0, %1, off" : "=v"(r.ep0) : "v"(po) : "memory");
                 asm volatile("global_load_dword %0, %1, off" : "=v"(r.ep1) : "v"(pb) : "memory");
             }
@@ -155,7 +160,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < 8; j++) { asm volatile("" : "+v"(r.a[j])); asm volatile("" : "+v"(r.b[j])); }
+            for (int j = 0; j < 8; j++) { px4_pin<IO>(r.a[j]); px4_pin<IO>(r.b[j]); }
             if (PRO == 1) { asm volatile("" : "+v"(r.sc[0])); asm volatile("" : "+v"(r.sc[1])); }
             if (EPI >= 1) { asm volatile("" : "+v"(r.ep0)); asm volatile("" : "+v"(r.ep1)); }
         };
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 for (int px = 0; px < 4; px++) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = r.a[j][px];
+                    for (int j = 0; j < 8; j++) v[j] = px4_get<IO>(r.a[j], px);
                     put(xs, base + px, v, r, r.ok0);
                 }
             }
@@ -184,13 +189,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 for (int px = 0; px < 4; px++) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = r.b[j][px];
+                    for (int j = 0; j < 8; j++) v[j] = px4_get<IO>(r.b[j], px);
                     put(xs, base + px, v, r, r.ok1);
                 }
             } else if (kind1 == 1) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = h_side ? r.b[j][0] : r.b[j][3];   // right halo: first pixel of the next group; left halo: last of the previous
+                for (int j = 0; j < 8; j++) v[j] = h_side ? px4_get<IO>(r.b[j], 0) : px4_get<IO>(r.b[j], 3);   // right halo: first pixel of the next group; left halo: last of the previous
                 put(xs, (oct * RIN + h_row) * PIN + (h_side ? SEG + 1 : 0), v, r, r.ok1);
             }
         };
@@ -324,7 +329,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
             int le = lane;                      // opaque copy: everything lane-dependent below is recomputed per tile instead of being
             asm volatile("" : "+v"(le));        // hoisted out of the chunk loop and spilled (nine scratch reloads, each behind a vmcnt(0))
             const int g = le >> 5;
-            float* yb = p.y + ((size_t)tp.n * p.m + tp.mt * TM) * plane + (size_t)(tp.y0 + 4 * wave) * p.w + tp.x0 + (le & 31);
+            const size_t yoff = ((size_t)tp.n * p.m + tp.mt * TM) * plane + (size_t)(tp.y0 + 4 * wave) * p.w + tp.x0 + (le & 31);
+            float* yb = (float*)p.y + yoff;      // (fp32 tensors; 16-bit ones are stored through out_store)
             const float* ep = (const float*)(ws + WS_WORDS);
             // The clamp is one v_med3_f32 -- which returns min3 when an operand is NaN, so a NaN accumulator would be stored as -clamp.  With a
             // clamp that IS bias_act's result (bias_act.cu:142: every comparison with NaN fails -> -clamp); without one the reference propagates the
@@ -349,6 +355,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                                     if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
                                 }
                                 if (ABL == 4) asm volatile("" :: "v"(v));
+                                else if (IO != 0) out_store<IO>(p.y, yoff + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
                                 else if (pp.accumulate) atomicAdd(yb + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
                                 else yb[(size_t)(m0 + ei) * plane + (size_t)r * p.w] = v;
                                 acc[r][hf][4 * e4 + ei] = 0.f;

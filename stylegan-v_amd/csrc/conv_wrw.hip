@@ -19,9 +19,13 @@ namespace {
 // images 16 / 8 pixels wide: 2 / 4 samples per 32-pixel row step (producer / consumer kernel, PACK form)
 bool packed_width(int h, int w) { return (w == 16 || w == 8) && h >= 1 && h <= 32; }
 
+bool io16(int dtype) { return dtype == SGV_BF16 || dtype == SGV_F16; }
+
+// 16-bit tensors (bf16 / fp16 dy and x, fp32 dw): the producer / consumer kernel on images >= 32 pixels wide, single bf16 operands (terms = 1)
 bool supported(int n, int o, int i, int h, int w, int dtype) {
-    return dtype == SGV_F32 && n >= 1 && o >= TO && i >= TI && o % TO == 0 && i % TI == 0 && h >= 1 &&
-           ((w >= SEG && w % SEG == 0 && (h <= 32 || h % 32 == 0)) || packed_width(h, w)) && (int64_t)n * std::max(o, i) * h * w <= INT32_MAX;
+    if (!((dtype == SGV_F32 || io16(dtype)) && n >= 1 && o >= TO && i >= TI && o % TO == 0 && i % TI == 0 && h >= 1 && (int64_t)n * std::max(o, i) * h * w <= INT32_MAX)) return false;
+    if (w >= SEG && w % SEG == 0 && (h <= 32 || h % 32 == 0)) return true;
+    return dtype == SGV_F32 && packed_width(h, w);
 }
 
 bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {
@@ -51,6 +55,7 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw: needs fp32, channels %% 64 == 0, W %% 32 == 0 with H <= 32 or H %% 32 == 0, or W in {16, 8} with H <= 32 (got n=%d o=%d i=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_out, p->c_in, p->h, p->w, dtype);
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms must be 1 (bf16 products) or 3 (bf16x3 fp32 emulation)");
+    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: 16-bit tensors need terms = 1 (one bf16 operand per value)");
     if ((((uintptr_t)p->dy) | ((uintptr_t)p->x)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: dy and x must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     wrw_params kp{};
@@ -78,18 +83,26 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
     hipError_t e = hipMemsetAsync(p->dw, 0, dw_bytes, stream);
     if (e != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw: hipMemsetAsync failed: %s", hipGetErrorString(e));
     const double elems = (double)p->n * p->h * p->w;
-    sgv_launch_scope scope(SGV_K_CONV_WRW, stream, 4.0 * elems * (p->c_out + p->c_in) + dw_bytes, 2.0 * elems * p->c_out * (double)p->c_in * 9);
+    sgv_launch_scope scope(SGV_K_CONV_WRW, stream, (io16(dtype) ? 2.0 : 4.0) * elems * (p->c_out + p->c_in) + dw_bytes, 2.0 * elems * p->c_out * (double)p->c_in * 9);
     dim3 grid((unsigned)tiles, (unsigned)kp.splits);
     std::call_once(g_ws_once, [] {
         hipError_t e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<3, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1, 0, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         g_ws_attr_err = e2;
         const char* env = getenv("SGV_WRW_WS");
         g_use_ws = !(env && env[0] == '0');
     });
     if (g_ws_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw: hipFuncSetAttribute failed: %s", hipGetErrorString(g_ws_attr_err));
+    if (io16(dtype)) {
+        if (dtype == SGV_BF16) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1, 0, false, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        else hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1, 0, false, 2>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        sgv_note_variant(SGV_V_wrw_lowp);
+        return sgv_check_launch("wrw3x3_ws_kernel (16-bit tensors)");
+    }
     if (pack) {   // the packed form exists in the producer / consumer kernel only
         if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
         else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);

@@ -19,6 +19,7 @@
 #pragma once
 
 #include "wrw_kernel.h"
+#include "sgv_io16.h"
 
 #ifndef SGV_WRW_RPM
 #define SGV_WRW_RPM 2
@@ -41,9 +42,13 @@ constexpr int WRW_WS_LDS_BYTES = wrw_ws_lds_bytes(3);
 // PACK: images 16 or 8 pixels wide (the < 32^2 layers): 2 or 4 samples sit side by side in the 32-pixel row step, a unit is (group of 32 / W
 // samples, row block).  The producers take every 8-pixel group from its own sample (left / right neighbours outside the sample's row are zero),
 // the consumers clear the one pixel that the kx = 0 / 2 shifts would otherwise pull across a sample boundary (VIEWS = 1 only).
-template <int TERMS, int VIEWS = 1, int ABL = 0, bool PACK = false>
+// IO: element format of dy and x (sgv_io16.h): 0 fp32; 1 bf16 / 2 fp16 (TERMS = 1: single bf16 operands; dw and the input scale stay fp32).  Same six
+//     loads per item -- dwordx4 -> dwordx2, halo dword -> ushort -- so every counted wait below holds for all formats.
+template <int TERMS, int VIEWS = 1, int ABL = 0, bool PACK = false, int IO = 0>
 __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
     static_assert(!PACK || VIEWS == 1, "packed samples: single-view form only");
+    static_assert(IO == 0 || TERMS == 1, "16-bit tensors are multiplied as single bf16 operands");
+    using namespace sgv_io;
     constexpr int WS_XSLOT = VIEWS * WS_VIEW;        // bf16 per (slot, hl)
     constexpr int WS_XS = 2 * 4 * WS_XSLOT;          // [hl][4 slots][views][64][RS]
     constexpr int XO = VIEWS == 1 ? XROW0 : 0;       // position of the segment's first pixel inside a row
@@ -68,10 +73,10 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         // =========================================== producers ===========================================
         const int pt = t - 256;
         const int lr = pt >> 2, lq = (pt & 3) * 8;           // channel row and first pixel of this thread's 8-pixel group
-        struct xrow { f32x4 a, b; float l, r; bool ok, okl, okr; };      // x[row][x0 + lq - 1 .. x0 + lq + 8]
-        struct drow { f32x4 a, b; };
+        struct xrow { px4<IO> a, b; px1<IO> l, r; bool ok, okl, okr; };      // x[row][x0 + lq - 1 .. x0 + lq + 8]
+        struct drow { px4<IO> a, b; };
 
-        const float *xb = nullptr, *dyb = nullptr;
+        size_t xb = 0, dyb = 0;      // element offsets into p.x / p.dy
         int x0 = 0;
         float xsc = 1.f;      // this thread's channel of p.xscale for the current unit's sample
         const int pxs = PACK ? (lq & (p.w - 1)) : lq;        // first pixel of the group inside its image row (minus x0)
@@ -84,32 +89,32 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             // inline asm like the row loads: a load the COMPILER tracks makes it put `s_waitcnt vmcnt(0)` in front of the first use of xsc in every
             // step, which drains the whole prefetch queue (measured: producers alone 1.0 ms with it, see the lab log); waited for with the prologue rows
             if (p.xscale) asm volatile("global_load_dword %0, %1, off" : "=v"(xsc) : "v"(p.xscale + (size_t)n * p.i + i0 + lr) : "memory");
-            xb = p.x + ((size_t)n * p.i + i0 + lr) * plane + x0 + pxs;
-            dyb = p.dy + ((size_t)n * p.o + o0 + lr) * plane + x0 + pxs;
+            xb = ((size_t)n * p.i + i0 + lr) * plane + x0 + pxs;
+            dyb = ((size_t)n * p.o + o0 + lr) * plane + x0 + pxs;
             return rb * R;
         };
         // branch-free: out-of-image rows / columns load from a clamped address and are zeroed when they are written to LDS
         auto load_x = [&](int row, xrow& r) {
             if (ABL == 7 || ABL == 11) return;
-            if (ABL == 13 || ABL == 14) { r.ok = true; r.okl = r.okr = true; asm volatile("" : "=v"(r.a), "=v"(r.b), "=v"(r.l), "=v"(r.r)); return; }   // opaque values instead of loads
+            if (ABL == 13 || ABL == 14) { r.ok = true; r.okl = r.okr = true; px4_opaque<IO>(r.a); px4_opaque<IO>(r.b); px1_opaque<IO>(r.l); px1_opaque<IO>(r.r); return; }   // opaque values instead of loads
             r.ok = row >= 0 && row < p.h;
             r.okl = r.ok && x0 + pxs - 1 >= 0;
             r.okr = r.ok && x0 + pxs + 8 < p.w;
-            const float* q = xb + (size_t)min(max(row, 0), p.h - 1) * p.w;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a) : "v"(q) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b) : "v"(q + 4) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(r.l) : "v"(q + (r.okl ? -1 : 0)) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(r.r) : "v"(q + (r.okr ? 8 : 7)) : "memory");
+            const size_t q = xb + (size_t)min(max(row, 0), p.h - 1) * p.w;
+            px4_load<IO>(r.a, at<IO>(p.x, q));
+            px4_load<IO>(r.b, at<IO>(p.x, q + 4));
+            px1_load<IO>(r.l, at<IO>(p.x, q - (r.okl ? 1 : 0)));
+            px1_load<IO>(r.r, at<IO>(p.x, q + (r.okr ? 8 : 7)));
         };
         auto load_dy = [&](int row, drow& r) {   // row is always inside the unit
             if (ABL == 7 || ABL == 11) return;
-            if (ABL == 13 || ABL == 14) { asm volatile("" : "=v"(r.a), "=v"(r.b)); return; }
-            const float* q = dyb + (size_t)row * p.w;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a) : "v"(q) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b) : "v"(q + 4) : "memory");
+            if (ABL == 13 || ABL == 14) { px4_opaque<IO>(r.a); px4_opaque<IO>(r.b); return; }
+            const size_t q = dyb + (size_t)row * p.w;
+            px4_load<IO>(r.a, at<IO>(p.dy, q));
+            px4_load<IO>(r.b, at<IO>(p.dy, q + 4));
         };
-        auto touch_x = [&](xrow& r) { asm volatile("" : "+v"(r.a)); asm volatile("" : "+v"(r.b)); asm volatile("" : "+v"(r.l)); asm volatile("" : "+v"(r.r)); };
-        auto touch_d = [&](drow& r) { asm volatile("" : "+v"(r.a)); asm volatile("" : "+v"(r.b)); };
+        auto touch_x = [&](xrow& r) { px4_pin<IO>(r.a); px4_pin<IO>(r.b); px1_pin<IO>(r.l); px1_pin<IO>(r.r); };
+        auto touch_d = [&](drow& r) { px4_pin<IO>(r.a); px4_pin<IO>(r.b); };
         // one pair of neighbouring pixels -> packed bf16 hi and lo
         auto pair = [&](float a, float b, unsigned& hi, unsigned& lo) {
             hi = pack_bf16(a, b);
@@ -120,15 +125,17 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             if (ABL == 10 || ABL == 12) {   // no split arithmetic: raw register bits go to LDS
                 const int slot = (row + 1) & 3;
                 unsigned short* dst = xs + (size_t)slot * WS_XSLOT + lr * RS + XO + lq;
-                *(u32x4*)dst = __builtin_bit_cast(u32x4, r.a);
-                if (TERMS > 1) *(u32x4*)(dst + 4 * WS_XSLOT) = __builtin_bit_cast(u32x4, r.b);
+                if constexpr (IO == 0) {
+                    *(u32x4*)dst = __builtin_bit_cast(u32x4, r.a.v);
+                    if (TERMS > 1) *(u32x4*)(dst + 4 * WS_XSLOT) = __builtin_bit_cast(u32x4, r.b.v);
+                }
                 return;
             }
             float v[10];
-            v[0] = r.okl ? r.l * xsc : 0.f;
-            v[9] = r.okr ? r.r * xsc : 0.f;
+            v[0] = r.okl ? px1_get<IO>(r.l) * xsc : 0.f;
+            v[9] = r.okr ? px1_get<IO>(r.r) * xsc : 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { v[1 + k] = r.ok ? r.a[k] * xsc : 0.f; v[5 + k] = r.ok ? r.b[k] * xsc : 0.f; }
+            for (int k = 0; k < 4; k++) { v[1 + k] = r.ok ? px4_get<IO>(r.a, k) * xsc : 0.f; v[5 + k] = r.ok ? px4_get<IO>(r.b, k) * xsc : 0.f; }
             // even-start pairs (v1v2, v3v4, v5v6, v7v8) = view 1; odd-start pairs (v0v1, ..., v8v9): view 0 = first four, view 2 = last four
             unsigned eh[4], el[4], oh[5], ol[5];
 #pragma unroll
@@ -158,13 +165,15 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         auto store_dy = [&](int buf, const drow& r) {
             if (ABL == 7) return;
             if (ABL == 10 || ABL == 12) {
-                *(u32x4*)(ds + (size_t)buf * WS_DBUF + lr * RS + lq) = __builtin_bit_cast(u32x4, r.a);
-                if (TERMS > 1) *(u32x4*)(ds + (size_t)(3 + buf) * WS_DBUF + lr * RS + lq) = __builtin_bit_cast(u32x4, r.b);
+                if constexpr (IO == 0) {
+                    *(u32x4*)(ds + (size_t)buf * WS_DBUF + lr * RS + lq) = __builtin_bit_cast(u32x4, r.a.v);
+                    if (TERMS > 1) *(u32x4*)(ds + (size_t)(3 + buf) * WS_DBUF + lr * RS + lq) = __builtin_bit_cast(u32x4, r.b.v);
+                }
                 return;
             }
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { v[k] = (!PACK || smp_ok) ? r.a[k] : 0.f; v[4 + k] = (!PACK || smp_ok) ? r.b[k] : 0.f; }
+            for (int k = 0; k < 4; k++) { v[k] = (!PACK || smp_ok) ? px4_get<IO>(r.a, k) : 0.f; v[4 + k] = (!PACK || smp_ok) ? px4_get<IO>(r.b, k) : 0.f; }
             u32x4 hi, lo;
             split8(v, hi, lo);
             *(u32x4*)(ds + (size_t)buf * WS_DBUF + lr * RS + lq) = hi;
