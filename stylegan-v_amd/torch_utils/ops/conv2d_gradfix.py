@@ -43,6 +43,21 @@ def no_weight_gradients():
         weight_gradients_disabled = previous
 
 
+# Mixed precision (the reference's `num_fp16_res` blocks, networks.py:227,461; bf16 is this build's extension): activations in fp16 / bf16, fp32
+# master weights.  The hand-written kernels take the 16-bit tensors together with the fp32 weight (every value becomes one bf16 operand, fp32
+# accumulate) and return weight gradients in fp32 -- `cast_weight` therefore leaves the weight alone where they serve the call; the vendor
+# fallback below receives `w.to(x.dtype)` like the reference's `weight.to(x.dtype)` (networks.py:67).
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+native_lowp = os.environ.get('SGV_CONV_LOWP', '1') != '0'
+
+
+def cast_weight(w, x):
+    """The weight as conv2d / conv_transpose2d want it for input x: fp32 master weights stay fp32 next to 16-bit GPU activations (native mixed path)."""
+    if native_lowp and enabled and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and w.dtype == torch.float32 and native_conv_terms in (1, 3):
+        return w
+    return w.to(x.dtype)
+
+
 def _pair(v):
     return (int(v), int(v)) if isinstance(v, int) else tuple(int(i) for i in v)
 
@@ -55,7 +70,7 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
         cfg = (False, _pair(stride), _pair(padding), (0, 0), _pair(dilation), int(groups))
         if _native_conv_ok(input, weight, cfg):
             return _native_conv(input, weight, cfg)
-    return torch.nn.functional.conv2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
+    return torch.nn.functional.conv2d(input=input, weight=weight.to(input.dtype), bias=bias, stride=stride, padding=padding, dilation=dilation, groups=groups)
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
@@ -66,7 +81,7 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
         cfg = (True, _pair(stride), _pair(padding), _pair(output_padding), _pair(dilation), int(groups))
         if _native_conv_ok(input, weight, cfg):
             return _native_conv(input, weight, cfg)
-    return torch.nn.functional.conv_transpose2d(input=input, weight=weight, bias=bias, stride=stride, padding=padding,
+    return torch.nn.functional.conv_transpose2d(input=input, weight=weight.to(input.dtype), bias=bias, stride=stride, padding=padding,
                                                 output_padding=output_padding, groups=groups, dilation=dilation)
 
 
@@ -102,7 +117,7 @@ class _Conv(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         if b is None and _native_conv_ok(x, w, cfg):
             return _native_conv(x, w, cfg)
-        return _aten_conv(x, w, b, cfg)
+        return _aten_conv(x, w.to(x.dtype), b, cfg)
 
     @staticmethod
     def backward(ctx, dy):
@@ -113,7 +128,7 @@ class _Conv(torch.autograd.Function):
             dx = _Conv.apply(dy, w, None, bcfg)
             assert dx.shape == x.shape
         if ctx.needs_input_grad[1] and not weight_gradients_disabled:
-            dw = _ConvGradWeight.apply(dy, x, ctx.cfg, tuple(w.shape))
+            dw = _ConvGradWeight.apply(dy, x, ctx.cfg, tuple(w.shape), w.dtype)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = dy.sum([0, 2, 3])
         return dx, dw, db, None
@@ -134,7 +149,10 @@ def _native_conv_kind(x, w, cfg):
     transposed, stride, padding, output_padding, dilation, groups = cfg
     if native_conv_terms not in (1, 3) or groups != 1 or dilation != (1, 1) or output_padding != (0, 0):
         return None
-    if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3) or not (x.is_cuda and w.is_cuda) or x.dtype != torch.float32 or w.dtype != torch.float32:
+    if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3) or not (x.is_cuda and w.is_cuda) or x.dtype not in _DT or w.dtype not in (torch.float32, x.dtype):
+        return None
+    dt = _DT[x.dtype]
+    if dt != 0 and not native_lowp:
         return None
     n, ci, h, wd = x.shape
     co = w.shape[1] if transposed else w.shape[0]
@@ -142,12 +160,12 @@ def _native_conv_kind(x, w, cfg):
         return None
     lib = custom_ops.get_native()
     if stride == (1, 1) and padding == (1, 1):
-        return 's1' if lib.sgv_conv3x3_supported(n, ci, co, h, wd, 0) else None
+        return 's1' if lib.sgv_conv3x3_supported(n, ci, co, h, wd, dt) else None
     if stride == (2, 2) and padding == (0, 0) and native_conv_s2:
         if transposed:
-            return 's2' if lib.sgv_conv3x3_s2_supported_mode(n, ci, co, h, wd, 2, 0) else None
+            return 's2' if lib.sgv_conv3x3_s2_supported_mode(n, ci, co, h, wd, 2, dt) else None
         if h % 2 == 1 and wd % 2 == 1 and h >= 3 and wd >= 3:
-            return 's2' if lib.sgv_conv3x3_s2_supported_mode(n, ci, co, (h - 1) // 2, (wd - 1) // 2, 0, 0) else None
+            return 's2' if lib.sgv_conv3x3_s2_supported_mode(n, ci, co, (h - 1) // 2, (wd - 1) // 2, 0, dt) else None
     return None
 
 
@@ -159,27 +177,29 @@ def _native_conv(x, w, cfg):
     lib = custom_ops.get_native()
     kind = _native_conv_kind(x, w, cfg)
     transposed = cfg[0]
-    xc, wc = x.contiguous(), w.contiguous()
+    dt = _DT[x.dtype]
+    terms = native_conv_terms if dt == 0 else 1      # 16-bit tensors: every value is one bf16 operand
+    xc, wc = x.contiguous(), w.float().contiguous()  # the kernels read fp32 weights (a 16-bit copy handed in by a caller is widened again: same bf16 operands)
     if xc.data_ptr() % 16 != 0:   # a dense view at a storage offset that is not 16-byte aligned: the kernels load 16-byte vectors
         xc = xc.clone()
     n, ci, h, wd = xc.shape
     co = wc.shape[1] if transposed else wc.shape[0]
     if kind == 's1':
-        y = torch.empty([n, co, h, wd], dtype=torch.float32, device=x.device)
+        y = torch.empty([n, co, h, wd], dtype=x.dtype, device=x.device)
         ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
         ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
-        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, wd, 1 if transposed else 0, native_conv_terms)
+        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, wd, 1 if transposed else 0, terms)
         fn = lib.sgv_conv3x3
     else:
         hs, wsm = (h, wd) if transposed else ((h - 1) // 2, (wd - 1) // 2)   # the small grid
-        y = torch.empty([n, co, 2 * hs + 1, 2 * wsm + 1] if transposed else [n, co, hs, wsm], dtype=torch.float32, device=x.device)
+        y = torch.empty([n, co, 2 * hs + 1, 2 * wsm + 1] if transposed else [n, co, hs, wsm], dtype=x.dtype, device=x.device)
         mode = 2 if transposed else 0
         ws_bytes = int(lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, wsm, mode))
         ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
-        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, hs, wsm, mode, native_conv_terms)
+        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, hs, wsm, mode, terms)
         fn = lib.sgv_conv3x3_s2
     with custom_ops.device_guard(xc):
-        custom_ops.check(fn(p, 0, custom_ops.raw_stream(xc)), lib)
+        custom_ops.check(fn(p, dt, custom_ops.raw_stream(xc)), lib)
     return y
 
 
@@ -188,7 +208,10 @@ def _native_wrw_kind(dy, x, cfg, w_shape):
     transposed, stride, padding, output_padding, dilation, groups = cfg
     if native_wrw_terms not in (1, 3) or groups != 1 or dilation != (1, 1) or output_padding != (0, 0):
         return None
-    if tuple(w_shape[2:]) != (3, 3) or not (dy.is_cuda and x.is_cuda) or dy.dtype != torch.float32 or x.dtype != torch.float32:
+    if tuple(w_shape[2:]) != (3, 3) or not (dy.is_cuda and x.is_cuda) or x.dtype not in _DT or dy.dtype != x.dtype:
+        return None
+    dt = _DT[x.dtype]
+    if dt != 0 and not native_lowp:
         return None
     lib = custom_ops.get_native()
     n, ci, h, w = x.shape
@@ -196,13 +219,13 @@ def _native_wrw_kind(dy, x, cfg, w_shape):
         if dy.shape[2:] != x.shape[2:]:
             return None
         # a transposed stride-1 layer (only met as a derivative of a convolution) has the same formula with x and dy swapped
-        return 's1' if lib.sgv_conv3x3_wrw_supported(n, dy.shape[1] if not transposed else ci, ci if not transposed else dy.shape[1], h, w, 0) else None
+        return 's1' if lib.sgv_conv3x3_wrw_supported(n, dy.shape[1] if not transposed else ci, ci if not transposed else dy.shape[1], h, w, dt) else None
     if stride == (2, 2) and padding == (0, 0) and native_conv_s2:
         small, big = (x, dy) if transposed else (dy, x)
         hs, ws = small.shape[2:]
         if tuple(big.shape[2:]) != (2 * hs + 1, 2 * ws + 1):
             return None
-        return 's2' if lib.sgv_conv3x3_wrw_s2_supported(n, small.shape[1], big.shape[1], hs, ws, 0) else None
+        return 's2' if lib.sgv_conv3x3_wrw_s2_supported(n, small.shape[1], big.shape[1], hs, ws, dt) else None
     return None
 
 
@@ -217,32 +240,34 @@ def _native_wrw(dy, x, cfg, w_shape, x_scale=None):
     """``x_scale`` ([N, Cin] fp32; stride-1 forward layers only, see ``wrw_input_scale``): the gradient is taken with x * x_scale[:, :, None, None]."""
     lib = custom_ops.get_native()
     kind = _native_wrw_kind(dy, x, cfg, w_shape)
-    dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)
+    dt = _DT[x.dtype]
+    terms = native_wrw_terms if dt == 0 else 1
+    dw = torch.empty(w_shape, dtype=torch.float32, device=x.device)    # fp32 whatever the tensors' format
     if kind == 's1' and x_scale is not None:
         assert not cfg[0] and wrw_input_scale
         dyc, xc, sc = dy.contiguous(), x.contiguous(), x_scale.contiguous()
         n, ci, h, w = xc.shape
         assert tuple(w_shape[:2]) == (dyc.shape[1], ci) and tuple(sc.shape) == (n, ci) and sc.dtype == torch.float32
-        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, native_wrw_terms)
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, terms)
         with custom_ops.device_guard(xc):
-            custom_ops.check(lib.sgv_conv3x3_wrw_scaled(p, sc.data_ptr(), 0, custom_ops.raw_stream(xc)), lib)
+            custom_ops.check(lib.sgv_conv3x3_wrw_scaled(p, sc.data_ptr(), dt, custom_ops.raw_stream(xc)), lib)
         return dw
     assert x_scale is None
     if kind == 's1':
         dyc, xc = (x.contiguous(), dy.contiguous()) if cfg[0] else (dy.contiguous(), x.contiguous())   # weight is [dyc channels, xc channels, 3, 3]
         n, ci, h, w = xc.shape
         assert tuple(w_shape[:2]) == (dyc.shape[1], ci)
-        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, native_wrw_terms)
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, terms)
         fn = lib.sgv_conv3x3_wrw
     else:   # the weight is [c_small, c_big, 3, 3] for both the strided ([c_out, c_in]) and the transposed ([c_in, c_out]) layer
         small, big = ((x, dy) if cfg[0] else (dy, x))
         dyc, xc = small.contiguous(), big.contiguous()
         n, cs, hs, ws = dyc.shape
         assert tuple(w_shape[:2]) == (cs, xc.shape[1])
-        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, cs, xc.shape[1], hs, ws, native_wrw_terms)
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, cs, xc.shape[1], hs, ws, terms)
         fn = lib.sgv_conv3x3_wrw_s2
     with custom_ops.device_guard(xc):
-        custom_ops.check(fn(p, 0, custom_ops.raw_stream(xc)), lib)
+        custom_ops.check(fn(p, dt, custom_ops.raw_stream(xc)), lib)
     return dw
 
 
@@ -251,16 +276,17 @@ class _ConvGradWeight(torch.autograd.Function):
     derivatives are again plain convolutions."""
 
     @staticmethod
-    def forward(ctx, dy, x, cfg, w_shape):
+    def forward(ctx, dy, x, cfg, w_shape, w_dtype=None):
         transposed, stride, padding, output_padding, dilation, groups = cfg
         ctx.cfg = cfg
         ctx.save_for_backward(dy, x)
+        w_dtype = x.dtype if w_dtype is None else w_dtype
         if _native_wrw_ok(dy, x, cfg, w_shape):
-            return _native_wrw(dy, x, cfg, w_shape)
+            return _native_wrw(dy, x, cfg, w_shape).to(w_dtype)
         w_like = x.new_empty(w_shape)  # only its shape/dtype are read when output_mask selects the weight gradient
         _, dw, _ = torch.ops.aten.convolution_backward(dy, x, w_like, None, stride, padding, dilation, transposed, output_padding, groups,
                                                        [False, True, False])
-        return dw
+        return dw.to(w_dtype)
 
     @staticmethod
     def backward(ctx, d_dw):
@@ -273,4 +299,4 @@ class _ConvGradWeight(torch.autograd.Function):
             bcfg = _data_grad_cfg(ctx.cfg, x.shape[2:], dy.shape[2:], d_dw.shape[2:])
             g_x = _Conv.apply(dy, d_dw, None, bcfg)
             assert g_x.shape == x.shape
-        return g_dy, g_x, None, None
+        return (g_dy, g_x) + (None,) * (len(ctx.needs_input_grad) - 2)

@@ -46,7 +46,7 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
         if x.stride(1) == 1 and min(out_ch, in_ch_per_group) < 64:
             if out_ch <= 4 and groups == 1:
                 n, _, h, wd = x.shape
-                y = w.reshape(out_ch, in_ch_per_group) @ x.reshape(n, in_ch_per_group, -1)
+                y = w.reshape(out_ch, in_ch_per_group).to(x.dtype) @ x.reshape(n, in_ch_per_group, -1)
                 y = y.reshape(n, out_ch, h, wd)
             else:
                 y = conv2d_gradfix.conv2d(x.contiguous(), w.contiguous(), groups=groups)
@@ -125,7 +125,7 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     ``padding`` is relative to the upsampled image and applied once, up front.
     ``flip_weight=True`` = correlation, ``flip_filter=False`` = convolution (conv2d_resample.py:59-83)."""
     assert isinstance(x, torch.Tensor) and x.ndim == 4
-    assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype == x.dtype
+    assert isinstance(w, torch.Tensor) and w.ndim == 4 and w.dtype in (x.dtype, torch.float32)   # fp32 master weights next to 16-bit activations: conv2d_gradfix.cast_weight
     assert f is None or (isinstance(f, torch.Tensor) and f.ndim in (1, 2) and f.dtype == torch.float32)
     assert isinstance(up, int) and up >= 1
     assert isinstance(down, int) and down >= 1

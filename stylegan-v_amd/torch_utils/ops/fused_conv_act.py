@@ -51,7 +51,7 @@ def conv3x3_bias_act_composed(x, weight, styles=None, dcoefs=None, bias=None, ac
     """The definition: scale -> conv -> scale -> bias_act, each differentiable to any order."""
     if styles is not None:
         x = _mod.scale_channels(x, styles)
-    y = _cg.conv2d(x, weight.to(x.dtype), padding=1)
+    y = _cg.conv2d(x, _cg.cast_weight(weight, x), padding=1)
     if dcoefs is not None:
         y = _mod.scale_channels(y, dcoefs)
     return _ba.bias_act(y, bias.to(y.dtype) if bias is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)

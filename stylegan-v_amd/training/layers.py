@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, fc, fused_conv_act, fused_down_act, pointwise, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, fc, fused_conv_act, fused_down_act, pointwise, upfirdn2d
 
 
 @misc.profiled_function
@@ -183,7 +183,7 @@ class Conv2dLayer(torch.nn.Module):
             residual = None
         else:
             assert not prefiltered, 'prefiltered input is only understood by the fused down-sampling paths'
-            x = conv2d_resample.conv2d_resample(x=x, w=w.to(x.dtype), f=self.resample_filter, up=self.up, down=self.down,
+            x = conv2d_resample.conv2d_resample(x=x, w=conv2d_gradfix.cast_weight(w, x), f=self.resample_filter, up=self.up, down=self.down,
                                                 padding=self.padding, flip_weight=(self.up == 1))
             if b is not None or self.activation != 'linear' or act_gain != 1 or clamp is not None:   # (a no-op bias_act hands its input back as-is)
                 x = bias_act.bias_act(x, b, act=self.activation, gain=act_gain, clamp=clamp)

@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_resample, fma, fused_conv_act, fused_fir_act, modulation, pointwise, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, fma, fused_conv_act, fused_fir_act, modulation, pointwise, upfirdn2d
 from .layers import Conv2dLayer, FullyConnectedLayer, GenInput, MappingNetwork, TemporalDifferenceEncoder
 from .motion import MotionMappingNetwork
 
@@ -63,7 +63,7 @@ def modulated_conv2d(x, weight, styles, noise=None, up=1, down=1, padding=0, res
 
     if not fused_modconv:
         x = modulation.scale_channels(x, styles)
-        x = conv2d_resample.conv2d_resample(x=x, w=weight.to(x.dtype), f=resample_filter, up=up, down=down, padding=padding,
+        x = conv2d_resample.conv2d_resample(x=x, w=conv2d_gradfix.cast_weight(weight, x), f=resample_filter, up=up, down=down, padding=padding,
                                             flip_weight=flip_weight)
         if demodulate and noise is not None:
             return fma.fma(x, dcoefs.to(x.dtype).reshape(n, -1, 1, 1), noise.to(x.dtype))
@@ -122,7 +122,7 @@ class SynthesisLayer(torch.nn.Module):
                 s = s / s.norm(float('inf'), dim=1, keepdim=True)
             dcoefs = modulation.demod_coefs(weight, s)
             x = modulation.scale_channels(x, s)
-            x, fir_pad = conv2d_resample.upsampling_conv_parts(x, weight.to(x.dtype), self.resample_filter, up=self.up, padding=self.padding,
+            x, fir_pad = conv2d_resample.upsampling_conv_parts(x, conv2d_gradfix.cast_weight(weight, x), self.resample_filter, up=self.up, padding=self.padding,
                                                                flip_weight=False)
             return fused_fir_act.fir_bias_act(x, self.resample_filter, scale=dcoefs, bias=self.bias, padding=fir_pad, fir_gain=self.up ** 2,
                                               act=self.activation, gain=self.act_gain * gain, clamp=clamp)

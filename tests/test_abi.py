@@ -81,7 +81,11 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     assert lib.sgv_conv3x3_supported(96, 512, 512, 4, 4, F32) == 0
     assert lib.sgv_conv3x3_supported(96, 3, 64, 256, 256, F32) == 0
     assert lib.sgv_conv3x3_supported(96, 64, 32, 256, 256, F32) == 0
-    assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, F16) == 0
+    # 16-bit tensors (fp32 weights and accumulate): the producer / consumer kernel of the big images only
+    assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, F16) == 1
+    assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, custom_ops.SGV_BF16) == 1
+    assert lib.sgv_conv3x3_supported(96, 512, 512, 16, 16, F16) == 0
+    assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, custom_ops.SGV_F64) == 0
     assert lib.sgv_conv3x3_workspace_bytes(64, 128) == 64 * 128 * 9 * 4
     # stride 2 (h, w = the small grid): W % 32, H % 8
     assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 128, 128, F32) == 1
