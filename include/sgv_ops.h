@@ -26,7 +26,7 @@
  *   sgv_weight_sqsum, sgv_demod_coefs, sgv_scale_channels, sgv_plane_dot
  *                      <- the weight (de)modulation arithmetic of `modulated_conv2d` networks.py:57-74 and its styles gradient
  *                          (no native counterpart in the reference: it materialises w[N,O,I,kh,kw] in PyTorch)
- *   sgv_act_grad_scale, sgv_scale_dot
+ *   sgv_act_grad_scale[_t], sgv_scale_dot[_t]
  *                      <- the element-wise backward of a fused stride-1 layer: bias_act grad-1 (bias_act.cu:60-61,133-142) x dcoefs with the
  *                          bias / dcoefs plane sums; `dxs * styles` with the styles gradient (networks.py:66)
  *   sgv_pointwise_small, sgv_pointwise_outer, sgv_pointwise_act, sgv_pointwise_small_gradin, sgv_pointwise_outer_act
@@ -199,6 +199,11 @@ int sgv_scale_channels(const void* x, const float* s, void* y, int32_t n, int32_
 int sgv_act_grad_scale(const float* dy, const float* y, const float* d, float* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
                        float gain, float clamp, void* stream);
 int sgv_scale_dot(const float* a, const float* b, const float* s, float* out, float* dot, int32_t planes, int32_t hw, void* stream);
+/* The same two passes on fp32 / fp16 / bf16 tensors (dy, y, out resp. a, b, out in `dtype`; d, s, the sums and the dot products fp32; arithmetic in fp32,
+ * one rounding on the store): the backward of the fused layer inside the mixed-precision blocks (networks.py:227,461 `num_fp16_res`). */
+int sgv_act_grad_scale_t(const void* dy, const void* y, const float* d, void* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
+                         float gain, float clamp, int dtype, void* stream);
+int sgv_scale_dot_t(const void* a, const void* b, const float* s, void* out, float* dot, int32_t planes, int32_t hw, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * 1x1 convolutions with <= 4 channels on one side, as HBM streams (ToRGB Cin->3, fromRGB 3->C; NCHW, fp32 accumulate):

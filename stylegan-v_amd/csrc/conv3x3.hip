@@ -87,6 +87,14 @@ void init_once() {
 #define SGV_P2_ATTR(T, E, SS) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<T, 0, E, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds_bytes(SS));
     SGV_P2_ATTR(1, 0, 2) SGV_P2_ATTR(3, 0, 2) SGV_P2_ATTR(1, 1, 2) SGV_P2_ATTR(3, 1, 2) SGV_P2_ATTR(1, 0, 4) SGV_P2_ATTR(3, 0, 4) SGV_P2_ATTR(1, 1, 4) SGV_P2_ATTR(3, 1, 4)
 #undef SGV_P2_ATTR
+#define SGV_P2_ATTR_IO(E, SS) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, 0, E, SS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds_bytes(SS)); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, 0, E, SS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds_bytes(SS));
+    SGV_P2_ATTR_IO(0, 1) SGV_P2_ATTR_IO(1, 1) SGV_P2_ATTR_IO(0, 2) SGV_P2_ATTR_IO(1, 2) SGV_P2_ATTR_IO(0, 4) SGV_P2_ATTR_IO(1, 4)
+#undef SGV_P2_ATTR_IO
+#define SGV_TW_ATTR_IO(SS) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1, 0, SS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(SS)); \
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1, 0, SS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(SS));
+    SGV_TW_ATTR_IO(1) SGV_TW_ATTR_IO(2) SGV_TW_ATTR_IO(4)
+#undef SGV_TW_ATTR_IO
     g_attr_err = e;
     env = getenv("SGV_CONVT_EDGE_MFMA");
     g_edge_mfma = !(env && env[0] == '0');
@@ -96,16 +104,22 @@ void init_once() {
 }
 
 bool supported_s2(int n, int k, int m, int h, int w, int dtype) {   // h, w: the small (H x W) grid
-    return dtype == SGV_F32 && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && w >= SEG && w % SEG == 0 && h >= S_ROWS && h % S_ROWS == 0 &&
+    return (dtype == SGV_F32 || io16(dtype)) && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && w >= SEG && w % SEG == 0 && h >= S_ROWS && h % S_ROWS == 0 &&
            (int64_t)n * std::max(k, m) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
 }
 
 // W = 16 / 8: the producer / consumer kernels pack 2 / 4 samples into a 32-pixel tile row (transposed form so far)
 bool supported_s2_packed(int n, int k, int m, int h, int w, int mode, int dtype) {
-    if (!(dtype == SGV_F32 && (w == 16 || w == 8) && n >= 1 && n % (32 / w) == 0 && k >= KC && k % KC == 0)) return false;
+    if (!((dtype == SGV_F32 || io16(dtype)) && (w == 16 || w == 8) && n >= 1 && n % (32 / w) == 0 && k >= KC && k % KC == 0)) return false;
     if (mode == 2) return m >= TM && m % TM == 0 && h >= TW_ROWS && h % TW_ROWS == 0;
     return mode == 0 && m % P2_TM == 0 && h % P2_ROWS == 0;   // the strided form: the tap-pair kernel only
 }
+
+bool pairs_shape(int c_out, int h) { return g_s2_ws && c_out % P2_TM == 0 && h % P2_ROWS == 0; }
+
+// 16-bit tensors: the producer / consumer kernels only -- the tap-pair kernel for the strided form (c_out % 128, H % 8), convT3x3_s2_ws_kernel + the MFMA
+// edge strips for the transposed one
+bool s2_mode_ok(int c_out, int h, int mode, int dtype) { return !io16(dtype) || (g_s2_ws && (mode == 2 ? g_edge_mfma : pairs_shape(c_out, h))); }
 
 }  // namespace
 
@@ -204,8 +218,9 @@ extern "C" int sgv_conv3x3_fused_supported(int32_t n, int32_t c_in, int32_t c_ou
     return supported(n, c_in, c_out, h, w, dtype) && big_image(h, w) ? 1 : 0;
 }
 
-extern "C" int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {
-    return supported_s2(n, c_in, c_out, h, w, dtype) ? 1 : 0;
+extern "C" int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {   // both forms
+    std::call_once(g_attr_once, init_once);
+    return supported_s2(n, c_in, c_out, h, w, dtype) && s2_mode_ok(c_out, h, 0, dtype) && s2_mode_ok(c_out, h, 2, dtype) ? 1 : 0;
 }
 
 extern "C" int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode) {
@@ -216,20 +231,22 @@ extern "C" int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32
 
 namespace {
 
-bool pairs_shape(int c_out, int h) { return g_s2_ws && c_out % P2_TM == 0 && h % P2_ROWS == 0; }
 
 int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* ep, int dtype, void* stream_) {
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: params is NULL");
     if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: NULL pointer");
     std::call_once(g_attr_once, init_once);
-    const bool packed = g_s2_ws && supported_s2_packed(p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
-    if (!packed && !supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs fp32, c_in %% 16 == 0, c_out %% 64 == 0, W %% 32 == 0, H %% 8 == 0 on the HxW grid (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
-                        p->n, p->c_in, p->c_out, p->h, p->w, dtype);
     if (p->mode != 0 && p->mode != 2) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: mode must be 0 (strided convolution) or 2 (transposed convolution)");
+    const bool packed = g_s2_ws && supported_s2_packed(p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
+    if ((!packed && !supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype)) || !s2_mode_ok(p->c_out, p->h, p->mode, dtype))
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs c_in %% 16 == 0, c_out %% 64 == 0, W %% 32 == 0, H %% 8 == 0 on the HxW grid; 16-bit tensors: the strided form with c_out %% 128 == 0, the transposed form with the MFMA edge strips (got n=%d c_in=%d c_out=%d h=%d w=%d mode=%d dtype=%d)",
+                        p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms must be 1 or 3");
+    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: 16-bit tensors need terms = 1 (one bf16 operand per value)");
+    if (io16(dtype) && ep && ep->accumulate) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2_fused: accumulate needs fp32 tensors");
+    const int io = dtype == SGV_BF16 ? 1 : dtype == SGV_F16 ? 2 : 0;
     if (p->workspace_bytes < sgv_conv3x3_s2_workspace_bytes(p->n, p->c_in, p->c_out, p->h, p->w, p->mode)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: workspace is too small");
-    if ((((uintptr_t)p->workspace) & 15) || (p->mode == 2 && (((uintptr_t)p->x) & 15))) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: workspace (and x of the transposed form) must be 16-byte aligned");
+    if ((((uintptr_t)p->workspace) & 15) || (p->mode == 2 && (((uintptr_t)p->x) & (io ? 7 : 15)))) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: workspace (and x of the transposed form: four elements) must be 16-byte aligned");
     std::call_once(g_attr_once, init_once);
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
     hipStream_t stream = (hipStream_t)stream_;
@@ -260,7 +277,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     kp.tiles = p->n * (p->h / S_ROWS) * (p->w / SEG) * (p->c_out / TM);
     kp.grid = std::min(kp.tiles, g_cus);
     const double small_px = (double)p->n * p->h * p->w, big_px = (double)p->n * (2 * p->h + 1) * (2 * p->w + 1);
-    const double bytes = 4.0 * (p->mode == 0 ? big_px * p->c_in + small_px * p->c_out : small_px * p->c_in + big_px * p->c_out) + 4.0 * p->c_in * p->c_out * 9;
+    const double bytes = (io ? 2.0 : 4.0) * (p->mode == 0 ? big_px * p->c_in + small_px * p->c_out : small_px * p->c_in + big_px * p->c_out) + 4.0 * p->c_in * p->c_out * 9;
     sgv_launch_scope scope(SGV_K_CONV3X3, stream, bytes, 2.0 * small_px * p->c_in * (double)p->c_out * 9);
     if (pairs) {
         const int ss = p->w >= SEG ? 1 : 32 / p->w;
@@ -268,12 +285,15 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         kp.grid = std::min(kp.tiles, g_cus);
         s2_epilogue ke{};
         if (ep) { ke.bias = ep->bias; ke.accumulate = ep->accumulate; ke.act_out = ep->act_out; ke.act = ep->act; ke.alpha = ep->alpha; ke.gain = ep->gain; ke.clamp = ep->clamp; }
-#define SGV_P2_GO(T, E, SS) hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<T, 0, E, SS>), dim3((unsigned)kp.grid), dim3(512), p2_lds_bytes(SS), stream, kp, ke)
-#define SGV_P2_S(T, E) do { if (ss == 1) SGV_P2_GO(T, E, 1); else if (ss == 2) SGV_P2_GO(T, E, 2); else SGV_P2_GO(T, E, 4); } while (0)
-        if (ep) { if (p->terms == 1) SGV_P2_S(1, 1); else SGV_P2_S(3, 1); }
-        else { if (p->terms == 1) SGV_P2_S(1, 0); else SGV_P2_S(3, 0); }
+#define SGV_P2_GO(T, E, SS, IO) hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<T, 0, E, SS, IO>), dim3((unsigned)kp.grid), dim3(512), p2_lds_bytes(SS), stream, kp, ke)
+#define SGV_P2_S(T, E, IO) do { if (ss == 1) SGV_P2_GO(T, E, 1, IO); else if (ss == 2) SGV_P2_GO(T, E, 2, IO); else SGV_P2_GO(T, E, 4, IO); } while (0)
+        if (io == 1) { if (ep) SGV_P2_S(1, 1, 1); else SGV_P2_S(1, 0, 1); }
+        else if (io == 2) { if (ep) SGV_P2_S(1, 1, 2); else SGV_P2_S(1, 0, 2); }
+        else if (ep) { if (p->terms == 1) SGV_P2_S(1, 1, 0); else SGV_P2_S(3, 1, 0); }
+        else { if (p->terms == 1) SGV_P2_S(1, 0, 0); else SGV_P2_S(3, 0, 0); }
 #undef SGV_P2_S
 #undef SGV_P2_GO
+        if (io) sgv_note_variant(SGV_V_conv_s2_lowp);
         sgv_note_variant(ss == 1 ? (ep ? SGV_V_conv_s2_pairs_fused : SGV_V_conv_s2_pairs) : (ep ? SGV_V_conv_s2_pairs_packed_fused : SGV_V_conv_s2_pairs_packed));
         return sgv_check_launch("conv3x3_s2_pairs_kernel");
     }
@@ -291,7 +311,17 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         sgv_note_variant(SGV_V_conv_s2_1role);
         return sgv_check_launch("conv3x3_s2_kernel");
     }
-    if (packed) {
+    if (io) {
+        const int ss = packed ? 32 / p->w : 1;
+        kp.tiles = ss == 1 ? p->n * (p->h / TW_ROWS) * (p->w / SEG) * (p->c_out / TM) : (p->n / ss) * (p->h / TW_ROWS) * (p->c_out / TM);
+        kp.grid = std::min(kp.tiles, g_cus);
+#define SGV_TW_GO(SS, IO) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<1, 0, SS, IO>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(SS), stream, kp)
+#define SGV_TW_S(IO) do { if (ss == 1) SGV_TW_GO(1, IO); else if (ss == 2) SGV_TW_GO(2, IO); else SGV_TW_GO(4, IO); } while (0)
+        if (io == 1) SGV_TW_S(1); else SGV_TW_S(2);
+#undef SGV_TW_S
+#undef SGV_TW_GO
+        sgv_note_variant(SGV_V_convT_lowp);
+    } else if (packed) {
         const int ss = 32 / p->w;
         kp.tiles = (p->n / ss) * (p->h / TW_ROWS) * (p->c_out / TM);
         kp.grid = std::min(kp.tiles, g_cus);
@@ -330,9 +360,18 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     {
         float* edge = (float*)((char*)p->workspace + (size_t)p->c_in * p->c_out * 10 * 4);
         const size_t prep = convT3x3_s2_edge_we_floats(p->c_in, p->c_out) + (size_t)p->n * p->c_in * p->h;
-        hipLaunchKernelGGL(convT3x3_s2_edge_prep, dim3((unsigned)((prep + 255) / 256)), dim3(256), 0, stream, (const float*)p->x, p->weight, edge, p->n, p->c_in, p->c_out, p->h, p->w);
-        hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2), dim3(64), 0, stream, (const float*)p->x,
-                           edge, (float*)p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+        const size_t prep_io = prep + (size_t)p->n * p->c_in * p->w;   // 16-bit tensors: the last input row is gathered as fp32 as well
+        const dim3 eg((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2);
+        if (io == 0) {
+            hipLaunchKernelGGL(convT3x3_s2_edge_prep<0>, dim3((unsigned)((prep + 255) / 256)), dim3(256), 0, stream, p->x, p->weight, edge, p->n, p->c_in, p->c_out, p->h, p->w);
+            hipLaunchKernelGGL(convT3x3_s2_edge_mfma<0>, eg, dim3(64), 0, stream, (const float*)p->x, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+        } else if (io == 1) {
+            hipLaunchKernelGGL(convT3x3_s2_edge_prep<1>, dim3((unsigned)((prep_io + 255) / 256)), dim3(256), 0, stream, p->x, p->weight, edge, p->n, p->c_in, p->c_out, p->h, p->w);
+            hipLaunchKernelGGL(convT3x3_s2_edge_mfma<1>, eg, dim3(64), 0, stream, (const float*)nullptr, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+        } else {
+            hipLaunchKernelGGL(convT3x3_s2_edge_prep<2>, dim3((unsigned)((prep_io + 255) / 256)), dim3(256), 0, stream, p->x, p->weight, edge, p->n, p->c_in, p->c_out, p->h, p->w);
+            hipLaunchKernelGGL(convT3x3_s2_edge_mfma<2>, eg, dim3(64), 0, stream, (const float*)nullptr, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+        }
     }
     sgv_note_variant(SGV_V_convT_edge_mfma);
     return sgv_check_launch("convT3x3_s2_edge_mfma");
@@ -349,10 +388,10 @@ extern "C" int sgv_conv3x3_s2_fused(const sgv_conv3x3_params* p, const sgv_conv3
 
 extern "C" int sgv_conv3x3_s2_supported_mode(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode, int dtype) {
     std::call_once(g_attr_once, init_once);
-    return supported_s2(n, c_in, c_out, h, w, dtype) || (g_s2_ws && supported_s2_packed(n, c_in, c_out, h, w, mode, dtype)) ? 1 : 0;
+    return (supported_s2(n, c_in, c_out, h, w, dtype) || (g_s2_ws && supported_s2_packed(n, c_in, c_out, h, w, mode, dtype))) && s2_mode_ok(c_out, h, mode, dtype) ? 1 : 0;
 }
 
 extern "C" int sgv_conv3x3_s2_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {
     std::call_once(g_attr_once, init_once);
-    return (supported_s2(n, c_in, c_out, h, w, dtype) || supported_s2_packed(n, c_in, c_out, h, w, 0, dtype)) && pairs_shape(c_out, h) ? 1 : 0;
+    return (supported_s2(n, c_in, c_out, h, w, dtype) || supported_s2_packed(n, c_in, c_out, h, w, 0, dtype)) && pairs_shape(c_out, h) && s2_mode_ok(c_out, h, 0, dtype) ? 1 : 0;
 }

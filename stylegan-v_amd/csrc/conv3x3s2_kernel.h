@@ -19,6 +19,7 @@
 #pragma once
 
 #include "conv3x3_kernel.h"
+#include "sgv_io16.h"
 
 namespace sgv_conv {
 
@@ -441,26 +442,41 @@ __global__ __launch_bounds__(128) void convT3x3_s2_edge_kernel(const float* edge
 // address-unit bound (0.25 ms per layer); the prep kernel lays both out once:  edge = we[strip][tap][k][m] (2*3*K*M floats), col[n][k][H].
 __host__ __device__ inline size_t convT3x3_s2_edge_we_floats(int k, int m) { return (size_t)2 * 3 * k * m; }
 
-__global__ __launch_bounds__(256) void convT3x3_s2_edge_prep(const float* x, const float* w, float* edge, int n, int k, int m, int h, int wd) {
+// IO != 0 (16-bit x, sgv_io16.h): the weights are rounded to bf16 like the main kernel's operands, and the last input ROW is gathered as fp32 too
+// (row[n][k][W] behind col[n][k][H]) so that the strip kernel reads fp32 lines for both strips.
+template <int IO>
+__global__ __launch_bounds__(256) void convT3x3_s2_edge_prep(const void* x, const float* w, float* edge, int n, int k, int m, int h, int wd) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t n_w = convT3x3_s2_edge_we_floats(k, m), n_col = (size_t)n * k * h;
+    const size_t n_w = convT3x3_s2_edge_we_floats(k, m), n_col = (size_t)n * k * h, n_row = IO ? (size_t)n * k * wd : 0;
+    auto ld = [&](size_t e) -> float {
+        if constexpr (IO == 0) return ((const float*)x)[e];
+        else if constexpr (IO == 1) return __builtin_bit_cast(float, (unsigned)((const uint16_t*)x)[e] << 16);
+        else return __builtin_bit_cast(float, pack_bf16((float)((const _Float16*)x)[e], 0.f) << 16);   // the operand the main kernel multiplies
+    };
     if (idx < n_w) {
         size_t j = idx;
         const int mm = j % m; j /= m;
         const int kk = j % k; j /= k;
         const int tap = j % 3; const int strip = j / 3;
-        edge[idx] = w[((size_t)kk * m + mm) * 9 + (strip == 0 ? 6 + tap : 3 * tap + 2)];
+        float v = w[((size_t)kk * m + mm) * 9 + (strip == 0 ? 6 + tap : 3 * tap + 2)];
+        if (IO) v = __builtin_bit_cast(float, pack_bf16(v, 0.f) << 16);
+        edge[idx] = v;
     } else if (idx < n_w + n_col) {
         const size_t j = idx - n_w;
         const size_t c = j / h; const int i = j % h;
-        edge[idx] = x[(c * h + i) * wd + (wd - 1)];
+        edge[idx] = ld((c * h + i) * wd + (wd - 1));
+    } else if (idx < n_w + n_col + n_row) {
+        const size_t j = idx - n_w - n_col;
+        const size_t c = j / wd; const int i = j % wd;
+        edge[idx] = ld((c * h + (h - 1)) * wd + i);
     }
 }
 
 typedef float f32x16e __attribute__((ext_vector_type(16)));
 
 // grid = (ceil((max(H, W) + 1) / 32), n * (m / 32), 2 strips), 64 threads.
-__global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, const float* edge, float* y, int n, int k, int m, int h, int wd) {
+template <int IO>
+__global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, const float* edge, void* y, int n, int k, int m, int h, int wd) {
     const int strip = blockIdx.z;
     const int ls = strip == 0 ? wd : h;               // source line length
     const int lo = strip == 0 ? 2 * wd + 1 : 2 * h;   // outputs of the strip
@@ -473,8 +489,10 @@ __global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, cons
     const bool vb = i < ls, vm = i >= 1 && i - 1 < ls;
     const size_t plane = (size_t)h * wd;
     // src(k, i) = xs[k * kstep + i]: the row strip reads x[n, k, H-1, :] in place, the column strip its gathered copy
-    const float* xs = strip == 0 ? x + (size_t)nn * k * plane + (size_t)(h - 1) * wd : edge + convT3x3_s2_edge_we_floats(k, m) + (size_t)nn * k * h;
-    const size_t kstep = strip == 0 ? plane : (size_t)h;
+    // (16-bit tensors: the row strip reads its gathered fp32 copy as well, x is not touched)
+    const float* xs = strip == 0 ? (IO ? edge + convT3x3_s2_edge_we_floats(k, m) + (size_t)n * k * h + (size_t)nn * k * wd : x + (size_t)nn * k * plane + (size_t)(h - 1) * wd)
+                                 : edge + convT3x3_s2_edge_we_floats(k, m) + (size_t)nn * k * h;
+    const size_t kstep = strip == 0 ? (IO ? (size_t)wd : plane) : (size_t)h;
     const float* pb = xs + (vb ? i : 0) + (size_t)g * kstep;
     const float* pm = xs + (vm ? i - 1 : 0) + (size_t)g * kstep;
     const size_t tk = (size_t)k * m;                  // floats per tap
@@ -506,14 +524,14 @@ __global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, cons
     const int hout = 2 * h + 1, wout = 2 * wd + 1;
     const int pe = 2 * i, po = 2 * i + 1;
     // element at position `pos` of the strip: row strip y[.., 2H, pos], column strip y[.., pos, 2W]
-    float* yb = y + ((size_t)nn * m + m0) * hout * wout + (strip == 0 ? (size_t)(hout - 1) * wout : (size_t)(wout - 1));
+    const size_t yb = ((size_t)nn * m + m0) * hout * wout + (strip == 0 ? (size_t)(hout - 1) * wout : (size_t)(wout - 1));
     const size_t ystep = strip == 0 ? 1 : wout;
 #pragma unroll
     for (int e = 0; e < 16; e++) {
         const int mm = (e & 3) + 8 * (e >> 2) + 4 * g;
-        float* q = yb + (size_t)mm * hout * wout;
-        if (pe < lo) q[(size_t)pe * ystep] = acc_e[e];
-        if (po < lo) q[(size_t)po * ystep] = acc_o[e];
+        const size_t q = yb + (size_t)mm * hout * wout;
+        if (pe < lo) sgv_io::out_store<IO>(y, q + (size_t)pe * ystep, acc_e[e]);
+        if (po < lo) sgv_io::out_store<IO>(y, q + (size_t)po * ystep, acc_o[e]);
     }
 }
 

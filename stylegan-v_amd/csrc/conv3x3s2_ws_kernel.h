@@ -24,6 +24,7 @@
 
 #include "conv3x3s2_kernel.h"
 #include "conv3x3_ws_kernel.h"
+#include "sgv_io16.h"
 
 namespace sgv_conv {
 
@@ -328,8 +329,12 @@ struct s2_epilogue {
 };
 
 // ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
-template <int TERMS, int ABL = 0, int EPI = 0, int S = 1>
+// IO: element format of x / y / act_out (sgv_io16.h: 0 fp32, 1 bf16, 2 fp16; 16-bit tensors with TERMS = 1 and without `accumulate`) -- same number of
+// load instructions (dwordx2 at 2-byte aligned addresses instead of dwordx4 at 4-byte aligned ones), so the counted waits are those of the fp32 form.
+template <int TERMS, int ABL = 0, int EPI = 0, int S = 1, int IO = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s2_epilogue ep) {
+    using namespace sgv_io;
+    static_assert(IO == 0 || TERMS == 1, "16-bit tensors are single bf16 operands");
     constexpr int PW = p2_pw(S), P2_XS_PLANE = P2_RIN * 2 * PW, P2_XS_WORDS = 2 * P2_XS_PLANE, P2_IMAGE_WORDS = p2_image_words(S);
     constexpr int SW = 32 / S;          // output pixels per sample in a tile row
     constexpr int GPS = SW / 2;         // 4-column input groups per sample row (without the last, odd column)
@@ -384,24 +389,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
         const int a_s = a_grp / GPS, a_g = a_grp % GPS;                      // sample inside the tile row, group inside the sample
         const int h_row = (u1 - ITEMS) % P2_RIN, h_s = kind1 == 1 ? (u1 - ITEMS) / P2_RIN : 0;
         const size_t sample = (size_t)p.k * plane_in;                         // elements between consecutive samples
-        struct xset { f32x4 a[8]; f32x4 b[8]; };
+        struct xset { px4<IO> a[8]; px4<IO> b[8]; };
 
         auto load_x = [&](int q, xset& r) {
             const tile_pos tp = decode_tile_p2<S>(p, tile_of(q));
             const int c = q % chunks;
-            const float* xb_ = p.x + ((size_t)tp.n * p.k + c * P2_KC) * plane_in + (size_t)(2 * tp.y0) * win + 2 * tp.x0;
-            const float* q0 = xb_ + a_s * sample + (size_t)a_row0 * win + 4 * a_g;
-            const float* q1 = xb_ + (kind1 == 0 ? a_s * sample + (size_t)a_row1 * win + 4 * a_g : kind1 == 1 ? h_s * sample + (size_t)h_row * win + 2 * SW - 3 : 0);
+            const char* xb_ = at<IO>(p.x, ((size_t)tp.n * p.k + c * P2_KC) * plane_in + (size_t)(2 * tp.y0) * win + 2 * tp.x0);
+            const char* q0 = xb_ + (a_s * sample + (size_t)a_row0 * win + 4 * a_g) * fmt<IO>::ES;
+            const char* q1 = xb_ + (kind1 == 0 ? a_s * sample + (size_t)a_row1 * win + 4 * a_g : kind1 == 1 ? h_s * sample + (size_t)h_row * win + 2 * SW - 3 : 0) * fmt<IO>::ES;
+            const size_t cstep = plane_in * fmt<IO>::ES;
 #pragma unroll
-            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * plane_in) : "memory");
+            for (int j = 0; j < 8; j++) px4_load<IO>(r.a[j], q0 + j * cstep);
 #pragma unroll
-            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b[j]) : "v"(q1 + j * plane_in) : "memory");
+            for (int j = 0; j < 8; j++) px4_load<IO>(r.b[j], q1 + j * cstep);
         };
         auto arrive = [&](xset& r, bool newer) {
             if (newer) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < 8; j++) { asm volatile("" : "+v"(r.a[j])); asm volatile("" : "+v"(r.b[j])); }
+            for (int j = 0; j < 8; j++) { px4_pin<IO>(r.a[j]); px4_pin<IO>(r.b[j]); }
         };
         auto put = [&](u32x4* xs, int pos, const float* v) {
             u32x4 hi, lo;
@@ -409,13 +415,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             xs[pos] = hi;
             if (TERMS > 1) xs[P2_XS_PLANE + pos] = lo;
         };
-        auto put_item = [&](u32x4* xs, int row, int grp, const f32x4* src) {   // grp: group inside sample a_s
+        auto put_item = [&](u32x4* xs, int row, int grp, const px4<IO>* src) {   // grp: group inside sample a_s
             const int base = row * 2 * PW + a_s * (SW + 1) + 2 * grp;
 #pragma unroll
             for (int px = 0; px < 4; px++) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = src[j][px];
+                for (int j = 0; j < 8; j++) v[j] = px4_get<IO>(src[j], px);
                 put(xs, base + (px & 1) * PW + (px >> 1), v);
             }
         };
@@ -425,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             else if (kind1 == 1) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = r.b[j][3];
+                for (int j = 0; j < 8; j++) v[j] = px4_get<IO>(r.b[j], 3);
                 put(xs, h_row * 2 * PW + h_s * (SW + 1) + SW, v);
             }
         };
@@ -532,7 +538,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             asm volatile("" : "+v"(le));
             const int ge = le >> 5;
             const size_t off0 = ((size_t)(tp.n + (le & 31) / SW) * p.m + tp.mt * P2_TM) * plane_out + (size_t)(tp.y0 + 2 * wave) * p.w + tp.x0 + (le & 31) % SW;
-            float* yb = p.y + off0;
             const float al = ep.act == 3 ? ep.alpha : 1.f;
             const float g0 = ep.gain, g1 = ep.gain * al;
             // all sixteen bias vectors of the tile first (from the LDS copy the DMA wave made with this chunk's weights)
@@ -565,9 +570,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
                                 if (EPI == 1) {
                                     v = fmaxf(__builtin_fmaf(v, g0, bv[ei] * g0), __builtin_fmaf(v, g1, bv[ei] * g1));
                                     if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
-                                    if (ep.act_out) ep.act_out[off0 + idx] = v;
+                                    if (ep.act_out) out_store<IO>(ep.act_out, off0 + idx, v);
                                 }
-                                if (EPI == 1 && ep.accumulate) atomicAdd(yb + idx, v); else yb[idx] = v;
+                                if (IO == 0 && EPI == 1 && ep.accumulate) atomicAdd(p.y + off0 + idx, v); else out_store<IO>(p.y, off0 + idx, v);
                                 acc[r][mq][4 * e4 + ei] = 0.f;
                             }
                     }
@@ -619,8 +624,11 @@ __device__ __forceinline__ tile_pos decode_tile_tw(const s2_params& p, int tile)
 }
 
 // ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
-template <int TERMS, int ABL = 0, int S = 1>
+// IO: element format of x / y (sgv_io16.h; 16-bit tensors with TERMS = 1): 8-byte aligned dwordx2 loads, two 2-byte stores per accumulator pair.
+template <int TERMS, int ABL = 0, int S = 1, int IO = 0>
 __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
+    using namespace sgv_io;
+    static_assert(IO == 0 || TERMS == 1, "16-bit tensors are single bf16 operands");
     constexpr int TW_PW = tw_pw(S), TW_XS_PLANE = TW_RIN * TW_PW, TW_XS_WORDS = 4 * TW_XS_PLANE, TW_IMAGE_WORDS = tw_image_words(S);
     constexpr int SW = 32 / S;   // pixels per sample in a tile row
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
@@ -669,24 +677,24 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
         const int a_quad = (u >> 1) & 7, a_row = kind == 0 ? u >> 4 : kind == 1 ? hh % TW_RIN : 0;
         const int a_s = kind == 0 ? a_quad / (SW / 4) : kind == 1 ? hh / TW_RIN : 0;     // sample inside the tile row
         const int a_q = a_quad % (SW / 4);
-        struct xset { f32x4 a[8]; bool ok; };
+        struct xset { px4<IO> a[8]; bool ok; };
 
         auto load_x = [&](int q, xset& r) {
             const tile_pos tp = decode_tile_tw<S>(p, tile_of(q));
             const int c = q % chunks;
-            const float* xb_ = p.x + ((size_t)(tp.n + a_s) * p.k + c * KC + 8 * oct) * plane_in;
             const int gy = tp.y0 - 1 + a_row;
             const int gx = kind == 0 ? tp.x0 + 4 * a_q : tp.x0 - 4;         // the halo pixel x0-1 is the last element of the group before the tile
             r.ok = kind != 2 && gy >= 0 && gx >= 0 && (S == 1 || kind == 0);   // packed samples: every halo word is image padding
-            const float* q0 = xb_ + (size_t)max(gy, 0) * p.w + max(gx, 0);
+            const char* q0 = at<IO>(p.x, ((size_t)(tp.n + a_s) * p.k + c * KC + 8 * oct) * plane_in + (size_t)max(gy, 0) * p.w + max(gx, 0));
+            const size_t cstep = plane_in * fmt<IO>::ES;
 #pragma unroll
-            for (int j = 0; j < 8; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a[j]) : "v"(q0 + j * plane_in) : "memory");
+            for (int j = 0; j < 8; j++) px4_load<IO>(r.a[j], q0 + j * cstep);
         };
         auto arrive = [&](xset& r, bool newer) {
             if (newer) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-            for (int j = 0; j < 8; j++) asm volatile("" : "+v"(r.a[j]));
+            for (int j = 0; j < 8; j++) px4_pin<IO>(r.a[j]);
         };
         auto put = [&](u32x4* xs, int pos, float* v, bool ok) {
 #pragma unroll
@@ -703,13 +711,13 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
                 for (int px = 0; px < 4; px++) {
                     float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; j++) v[j] = r.a[j][px];
+                    for (int j = 0; j < 8; j++) v[j] = px4_get<IO>(r.a[j], px);
                     put(xs, base + px, v, r.ok);
                 }
             } else if (kind == 1) {
                 float v[8];
 #pragma unroll
-                for (int j = 0; j < 8; j++) v[j] = r.a[j][3];
+                for (int j = 0; j < 8; j++) v[j] = px4_get<IO>(r.a[j], 3);
                 put(xs, (oct * TW_RIN + a_row) * TW_PW + a_s * (SW + 1), v, r.ok);
             }
         };
@@ -812,7 +820,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
             int le = lane;
             asm volatile("" : "+v"(le));
             const int g = le >> 5;
-            float* yb = p.y + ((size_t)(tp.n + (le & 31) / SW) * p.m + tp.mt * TM) * plane_out + (size_t)(2 * (tp.y0 + wave)) * wout + 2 * (tp.x0 + (le & 31) % SW);
+            const size_t yb = ((size_t)(tp.n + (le & 31) / SW) * p.m + tp.mt * TM) * plane_out + (size_t)(2 * (tp.y0 + wave)) * wout + 2 * (tp.x0 + (le & 31) % SW);
 #pragma unroll
             for (int a2 = 0; a2 < 2; a2++)
 #pragma unroll
@@ -820,9 +828,9 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-                        float* qd = yb + (size_t)m * plane_out + (size_t)a2 * wout;
-                        qd[0] = acc[a2 * 2 + 0][hf][e];
-                        qd[1] = acc[a2 * 2 + 1][hf][e];
+                        const size_t qd = yb + (size_t)m * plane_out + (size_t)a2 * wout;
+                        out_store<IO>(p.y, qd, acc[a2 * 2 + 0][hf][e]);
+                        out_store<IO>(p.y, qd + 1, acc[a2 * 2 + 1][hf][e]);
                         acc[a2 * 2 + 0][hf][e] = 0.f;
                         acc[a2 * 2 + 1][hf][e] = 0.f;
                     }

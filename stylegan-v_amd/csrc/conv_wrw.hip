@@ -28,8 +28,8 @@ bool supported(int n, int o, int i, int h, int w, int dtype) {
     return dtype == SGV_F32 && packed_width(h, w);
 }
 
-bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {
-    return dtype == SGV_F32 && n >= 1 && cs >= TO && cb >= TI && cs % TO == 0 && cb % TI == 0 && h >= 1 &&
+bool supported_s2(int n, int cs, int cb, int h, int w, int dtype) {   // 16-bit tensors: the producer / consumer kernel (checked at launch: SGV_WRW_S2_WS)
+    return (dtype == SGV_F32 || io16(dtype)) && n >= 1 && cs >= TO && cb >= TI && cs % TO == 0 && cb % TI == 0 && h >= 1 &&
            ((w >= SEG && w % SEG == 0 && (h <= 32 || h % 32 == 0)) || packed_width(h, w)) && (int64_t)n * std::max(cs, cb) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
 }
 
@@ -141,7 +141,8 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_s2: needs fp32, channels %% 64 == 0, and on the small HxW grid W %% 32 == 0 with H <= 32 or H %% 32 == 0, or W in {16, 8} with H <= 32 (got n=%d cs=%d cb=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_out, p->c_in, p->h, p->w, dtype);
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms must be 1 or 3");
-    if (((uintptr_t)p->dy) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: the small tensor must be 16-byte aligned");
+    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: 16-bit tensors need terms = 1 (one bf16 operand per value)");
+    if (((uintptr_t)p->dy) & (io16(dtype) ? 7 : 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: the small tensor must be aligned to four elements");
     std::call_once(g_once, [] {
         hipError_t e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
@@ -151,11 +152,16 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
         const char* env = getenv("SGV_WRW_S2_WS");
         g_use_s2_ws = !(env && env[0] == '0');
         g_attr_err = e;
     });
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
+    if (io16(dtype) && !g_use_s2_ws) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_s2: 16-bit tensors need the producer / consumer kernel (SGV_WRW_S2_WS != 0)");
     hipStream_t stream = (hipStream_t)stream_;
     wrw_s2_params kp{};
     kp.small = (const float*)p->dy; kp.big = (const float*)p->x; kp.dw = p->dw;
@@ -171,8 +177,19 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     hipError_t e = hipMemsetAsync(p->dw, 0, dw_bytes, stream);
     if (e != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw_s2: hipMemsetAsync failed: %s", hipGetErrorString(e));
     const double small_px = (double)p->n * p->h * p->w, big_px = (double)p->n * (2 * p->h + 1) * (2 * p->w + 1);
-    sgv_launch_scope scope(SGV_K_CONV_WRW, stream, 4.0 * (small_px * p->c_out + big_px * p->c_in) + dw_bytes, 2.0 * small_px * p->c_out * (double)p->c_in * 9);
+    sgv_launch_scope scope(SGV_K_CONV_WRW, stream, (io16(dtype) ? 2.0 : 4.0) * (small_px * p->c_out + big_px * p->c_in) + dw_bytes, 2.0 * small_px * p->c_out * (double)p->c_in * 9);
     dim3 grid((unsigned)tiles, (unsigned)kp.splits);
+    if (io16(dtype)) {
+        if (pack) {
+            if (dtype == SGV_BF16) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, true, 0, 1>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+            else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, true, 0, 2>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+        } else {
+            if (dtype == SGV_BF16) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, false, 0, 1>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+            else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, false, 0, 2>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+        }
+        sgv_note_variant(SGV_V_wrw_s2_lowp);
+        return sgv_check_launch("wrw3x3_s2_ws_kernel (16-bit tensors)");
+    }
     if (g_use_s2_ws) {
         if (pack) {
             if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, true>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);

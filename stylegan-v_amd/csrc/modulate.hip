@@ -137,14 +137,17 @@ void launch_plane_dot(const void* a, const void* b, float* out, int planes, int 
 //   sums[0][plane] += sum dz                            -> bias gradient (summed over samples by the caller)
 //   sums[1][plane] += sum dz * v,  v = pre-activation   -> demodulation-coefficient gradient: (sums[1] - bias * sums[0]) / d
 // dz * v needs no inverse activation: dz = dy * gain * slope and v = y / (gain * slope), so dz * v = dy * y wherever dz != 0.
-__global__ __launch_bounds__(256) void act_grad_scale_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ d,
-                                                             float* __restrict__ out, float* __restrict__ sums, int planes, int hw, int act, float alpha, float gain,
+// T: element type of dy / y / out (d and the sums are fp32); 16-bit tensors: arithmetic in fp32, one rounding on the store.
+template <typename T>
+__global__ __launch_bounds__(256) void act_grad_scale_kernel(const T* __restrict__ dy, const T* __restrict__ y, const float* __restrict__ d,
+                                                             T* __restrict__ out, float* __restrict__ sums, int planes, int hw, int act, float alpha, float gain,
                                                              float clamp, int vec_ok) {
+    constexpr int N = vec16<T>::N;
     const int plane = blockIdx.y;
     const int p0 = blockIdx.x * PD_CHUNK, p1 = min(hw, p0 + PD_CHUNK);
-    const float* gp = dy + (size_t)plane * hw;
-    const float* yp = y + (size_t)plane * hw;
-    float* op = out + (size_t)plane * hw;
+    const T* gp = dy + (size_t)plane * hw;
+    const T* yp = y + (size_t)plane * hw;
+    T* op = out + (size_t)plane * hw;
     const float dsc = d ? d[plane] : 1.f;
     float sg = 0.f, sgv = 0.f;
     auto one = [&](float g, float yy) {
@@ -156,14 +159,15 @@ __global__ __launch_bounds__(256) void act_grad_scale_kernel(const float* __rest
         return dz * dsc;
     };
     if (vec_ok) {
-        for (int i = p0 + threadIdx.x * 4; i < p1; i += 256 * 4) {
-            const float4 g = *(const float4*)(gp + i), yy = *(const float4*)(yp + i);
-            float4 o;
-            o.x = one(g.x, yy.x); o.y = one(g.y, yy.y); o.z = one(g.z, yy.z); o.w = one(g.w, yy.w);
-            *(float4*)(op + i) = o;
+        for (int i = p0 + threadIdx.x * N; i < p1; i += 256 * N) {
+            const vec16<T> g = *(const vec16<T>*)(gp + i), yy = *(const vec16<T>*)(yp + i);
+            vec16<T> o;
+#pragma unroll
+            for (int k = 0; k < N; k++) sgv_traits<T>::store(&o.e[k], one(sgv_traits<T>::load(&g.e[k]), sgv_traits<T>::load(&yy.e[k])));
+            *(vec16<T>*)(op + i) = o;
         }
     } else {
-        for (int i = p0 + threadIdx.x; i < p1; i += 256) op[i] = one(gp[i], yp[i]);
+        for (int i = p0 + threadIdx.x; i < p1; i += 256) sgv_traits<T>::store(op + i, one(sgv_traits<T>::load(gp + i), sgv_traits<T>::load(yp + i)));
     }
     if (!sums) return;
 #pragma unroll
@@ -177,23 +181,31 @@ __global__ __launch_bounds__(256) void act_grad_scale_kernel(const float* __rest
 
 // out = a * s[plane] and dot[plane] += sum a * b in one pass: the input gradient dx = dxs * styles of a modulated layer together with the
 // styles gradient sum_px dxs * x (networks.py:66), instead of plane_dot + scale_channels (5 tensor passes -> 3).
-__global__ __launch_bounds__(256) void scale_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ s, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(256) void scale_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ s, T* __restrict__ out,
                                                         float* __restrict__ dot, int hw, int vec_ok) {
+    constexpr int N = vec16<T>::N;
     const int plane = blockIdx.y;
     const int p0 = blockIdx.x * PD_CHUNK, p1 = min(hw, p0 + PD_CHUNK);
-    const float* ap = a + (size_t)plane * hw;
-    const float* bp = b + (size_t)plane * hw;
-    float* op = out + (size_t)plane * hw;
+    const T* ap = a + (size_t)plane * hw;
+    const T* bp = b + (size_t)plane * hw;
+    T* op = out + (size_t)plane * hw;
     const float sc = s[plane];
     float acc = 0.f;
     if (vec_ok) {
-        for (int i = p0 + threadIdx.x * 4; i < p1; i += 256 * 4) {
-            const float4 va = *(const float4*)(ap + i), vb = *(const float4*)(bp + i);
-            acc = __builtin_fmaf(va.x, vb.x, acc); acc = __builtin_fmaf(va.y, vb.y, acc); acc = __builtin_fmaf(va.z, vb.z, acc); acc = __builtin_fmaf(va.w, vb.w, acc);
-            *(float4*)(op + i) = float4{va.x * sc, va.y * sc, va.z * sc, va.w * sc};
+        for (int i = p0 + threadIdx.x * N; i < p1; i += 256 * N) {
+            const vec16<T> va = *(const vec16<T>*)(ap + i), vb = *(const vec16<T>*)(bp + i);
+            vec16<T> o;
+#pragma unroll
+            for (int k = 0; k < N; k++) {
+                const float av = sgv_traits<T>::load(&va.e[k]);
+                acc = __builtin_fmaf(av, sgv_traits<T>::load(&vb.e[k]), acc);
+                sgv_traits<T>::store(&o.e[k], av * sc);
+            }
+            *(vec16<T>*)(op + i) = o;
         }
     } else {
-        for (int i = p0 + threadIdx.x; i < p1; i += 256) { const float va = ap[i]; acc = __builtin_fmaf(va, bp[i], acc); op[i] = va * sc; }
+        for (int i = p0 + threadIdx.x; i < p1; i += 256) { const float va = sgv_traits<T>::load(ap + i); acc = __builtin_fmaf(va, sgv_traits<T>::load(bp + i), acc); sgv_traits<T>::store(op + i, va * sc); }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
@@ -205,30 +217,47 @@ __global__ __launch_bounds__(256) void scale_dot_kernel(const float* __restrict_
 
 }  // namespace
 
-extern "C" int sgv_act_grad_scale(const float* dy, const float* y, const float* d, float* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
-                                  float gain, float clamp, void* stream_) {
+extern "C" int sgv_act_grad_scale_t(const void* dy, const void* y, const float* d, void* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
+                                    float gain, float clamp, int dtype, void* stream_) {
     if (!dy || !y || !out) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: NULL pointer");
     if (planes < 1 || hw < 1 || planes > 65535) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: needs 1 <= planes <= 65535, hw >= 1");
     if ((int64_t)planes * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "act_grad_scale: tensors are too large");
     if (act != 1 && act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: act must be 1 (linear) or 3 (lrelu)");
+    const size_t es = sgv_dtype_size(dtype);
+    if (es == 0 || dtype == SGV_F64) return sgv_fail(SGV_ERR_UNSUPPORTED, "act_grad_scale: unsupported dtype %d", dtype);
     hipStream_t stream = (hipStream_t)stream_;
-    sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * 4.0);
-    const int vec_ok = (hw % 4 == 0) && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * (double)es);
+    const int vec_ok = (hw % (16 / (int)es) == 0) && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
     dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)planes);
-    hipLaunchKernelGGL(act_grad_scale_kernel, grid, dim3(256), 0, stream, dy, y, d, out, sums, planes, hw, act, alpha, gain, clamp, vec_ok);
+    if (dtype == SGV_F32) hipLaunchKernelGGL(act_grad_scale_kernel<float>, grid, dim3(256), 0, stream, (const float*)dy, (const float*)y, d, (float*)out, sums, planes, hw, act, alpha, gain, clamp, vec_ok);
+    else if (dtype == SGV_F16) hipLaunchKernelGGL(act_grad_scale_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)dy, (const sgv_half_t*)y, d, (sgv_half_t*)out, sums, planes, hw, act, alpha, gain, clamp, vec_ok);
+    else hipLaunchKernelGGL(act_grad_scale_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)dy, (const sgv_bf16_t*)y, d, (sgv_bf16_t*)out, sums, planes, hw, act, alpha, gain, clamp, vec_ok);
     return sgv_check_launch("act_grad_scale_kernel");
 }
 
-extern "C" int sgv_scale_dot(const float* a, const float* b, const float* s, float* out, float* dot, int32_t planes, int32_t hw, void* stream_) {
+extern "C" int sgv_act_grad_scale(const float* dy, const float* y, const float* d, float* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
+                                  float gain, float clamp, void* stream_) {
+    return sgv_act_grad_scale_t(dy, y, d, out, sums, planes, hw, act, alpha, gain, clamp, SGV_F32, stream_);
+}
+
+extern "C" int sgv_scale_dot_t(const void* a, const void* b, const float* s, void* out, float* dot, int32_t planes, int32_t hw, int dtype, void* stream_) {
     if (!a || !b || !s || !out || !dot) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: NULL pointer");
     if (planes < 1 || hw < 1 || planes > 65535) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: needs 1 <= planes <= 65535, hw >= 1");
     if ((int64_t)planes * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "scale_dot: tensors are too large");
+    const size_t es = sgv_dtype_size(dtype);
+    if (es == 0 || dtype == SGV_F64) return sgv_fail(SGV_ERR_UNSUPPORTED, "scale_dot: unsupported dtype %d", dtype);
     hipStream_t stream = (hipStream_t)stream_;
-    sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * 4.0);
-    const int vec_ok = (hw % 4 == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0);
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * (double)es);
+    const int vec_ok = (hw % (16 / (int)es) == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0);
     dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)planes);
-    hipLaunchKernelGGL(scale_dot_kernel, grid, dim3(256), 0, stream, a, b, s, out, dot, hw, vec_ok);
+    if (dtype == SGV_F32) hipLaunchKernelGGL(scale_dot_kernel<float>, grid, dim3(256), 0, stream, (const float*)a, (const float*)b, s, (float*)out, dot, hw, vec_ok);
+    else if (dtype == SGV_F16) hipLaunchKernelGGL(scale_dot_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)a, (const sgv_half_t*)b, s, (sgv_half_t*)out, dot, hw, vec_ok);
+    else hipLaunchKernelGGL(scale_dot_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)a, (const sgv_bf16_t*)b, s, (sgv_bf16_t*)out, dot, hw, vec_ok);
     return sgv_check_launch("scale_dot_kernel");
+}
+
+extern "C" int sgv_scale_dot(const float* a, const float* b, const float* s, float* out, float* dot, int32_t planes, int32_t hw, void* stream_) {
+    return sgv_scale_dot_t(a, b, s, out, dot, planes, hw, SGV_F32, stream_);
 }
 
 extern "C" int sgv_plane_dot(const void* a, const void* b, float* out, int32_t planes, int32_t hw, int dtype, void* stream_) {

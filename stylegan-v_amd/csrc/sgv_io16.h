@@ -63,11 +63,11 @@ template <int IO> __device__ __forceinline__ float px1_get(const px1<IO>& r) {
 }
 
 // ---- stores ------------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint16_t f32_to_bf16_rne(float v) {
-    uint32_t u = __builtin_bit_cast(uint32_t, v);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
+__device__ __forceinline__ uint16_t f32_to_bf16_rne(float v) {   // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+    typedef float io_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 io_bf16x2 __attribute__((ext_vector_type(2)));
+    const io_f32x2 f = {v, 0.f};
+    return (uint16_t)__builtin_bit_cast(unsigned, __builtin_convertvector(f, io_bf16x2));
 }
 template <int IO> __device__ __forceinline__ void out_store(void* base, size_t index, float v) {
     if constexpr (IO == 0) ((float*)base)[index] = v;

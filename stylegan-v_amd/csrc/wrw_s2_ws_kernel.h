@@ -21,6 +21,7 @@
 #pragma once
 
 #include "wrw_kernel.h"
+#include "sgv_io16.h"
 
 namespace sgv_wrw {
 
@@ -30,8 +31,12 @@ constexpr int WRW_S2_WS_LDS_BYTES = (2 * 5 * BIG_SLOT + 2 * 3 * S2W_SMALL) * 2;
 // PACK: as in wrw3x3_s2_kernel (small grid 16 / 8 pixels wide, 2 / 4 samples per row step, per-sample last big column in the row's pad words).
 // ABL (tools/wrw_lab.hip only; wrong results by construction): 6 consumers only keep the barrier protocol, 7 producers only keep it, 9 full kernel with the
 // big-row loads forced onto 16-byte boundaries (for odd b the rows then start 12 bytes early: still 4-byte granular, see the lab log).
-template <int TERMS, bool PACK = false, int ABL = 0>
+// IO: element format of the two activation tensors (sgv_io16.h; 16-bit tensors with TERMS = 1; dw stays fp32): the same load instructions at half the width.
+template <int TERMS, bool PACK = false, int ABL = 0, int IO = 0>
 __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
+    using namespace sgv_io;
+    static_assert(IO == 0 || TERMS == 1, "16-bit tensors are single bf16 operands");
+    constexpr int ES = fmt<IO>::ES;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds_s2w[];
     unsigned short* bs = lds_s2w;                          // ((hl * 5 + slot) * 64 + cb) * BIG_CH + {px: even plane | RS + px: odd plane | 2 RS ..: pad}
     unsigned short* as = lds_s2w + 2 * 5 * BIG_SLOT;       // ((hl * 3 + buf) * 64 + cs) * RS + px
@@ -53,87 +58,89 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
         // =========================================== producers ===========================================
         const int pt = t - 256;
         const int lr = pt >> 2, lq = (pt & 3) * 8;     // small row: channel, first pixel of this thread's 8-pixel group
-        struct bset { f32x4 v[4]; float e; };         // one big row: four 4-column quads (quad (pt + 256 j) & 15 of channel (pt + 256 j) >> 4) + this thread's edge column
-        struct sset { f32x4 a, b; };                  // one small row: 8 pixels
+        struct bset { px4<IO> v[4]; px1<IO> e; };         // one big row: four 4-column quads (quad (pt + 256 j) & 15 of channel (pt + 256 j) >> 4) + this thread's edge column
+        struct sset { px4<IO> a, b; };                // one small row: 8 pixels
         struct rset { bset b0, b1; sset s; };
 
-        const float* bq[4] = {nullptr, nullptr, nullptr, nullptr};   // first element of this thread's four quads in local big row 0
-        const float* be = nullptr;                                     // ... of its edge column (channel pt & 63; PACK: of sample pt >> 6)
-        const float* sq = nullptr;                                     // ... of its 8 small pixels in local small row 0
+        const char* bq[4] = {nullptr, nullptr, nullptr, nullptr};    // first element of this thread's four quads in local big row 0
+        const char* be = nullptr;                                      // ... of its edge column (channel pt & 63; PACK: of sample pt >> 6)
+        const char* sq = nullptr;                                      // ... of its 8 small pixels in local small row 0
         bool live = true;                                              // PACK: this thread's small sample exists (the last group of a batch may be short)
         auto set_unit = [&](int u) {
             const int rb = u % rblocks, sg = (u / rblocks) % segs, n = (u / (rblocks * segs)) * spr;
             const int y0 = rb * R, x0 = sg * SEG;
-            const float* bb = p.big + ((size_t)n * p.cb + b0) * plane_b + (size_t)(2 * y0) * wb + 2 * x0;
-            const float* sb = p.small + ((size_t)n * p.cs + s0) * plane_s + (size_t)y0 * p.w + x0;
+            const char* bb = at<IO>(p.big, ((size_t)n * p.cb + b0) * plane_b + (size_t)(2 * y0) * wb + 2 * x0);
+            const char* sb = at<IO>(p.small, ((size_t)n * p.cs + s0) * plane_s + (size_t)y0 * p.w + x0);
             const int last = p.n - 1 - n;     // samples of the group beyond the batch are clamped to its last one (their small operand is zeroed)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int it = pt + 256 * j, quad = it & 15, ch = it >> 4;
-                if (PACK) bq[j] = bb + ((size_t)min(quad >> (wsh - 1), last) * p.cb + ch) * plane_b + 4 * (quad & ((p.w >> 1) - 1));
-                else bq[j] = bb + (size_t)ch * plane_b + 4 * quad;
+                if (PACK) bq[j] = bb + (((size_t)min(quad >> (wsh - 1), last) * p.cb + ch) * plane_b + 4 * (quad & ((p.w >> 1) - 1))) * ES;
+                else bq[j] = bb + ((size_t)ch * plane_b + 4 * quad) * ES;
             }
             if (ABL == 9) {   // lab: what would 16-byte aligned big rows buy (wrong data)
 #pragma unroll
-                for (int j = 0; j < 4; j++) bq[j] = (const float*)((uintptr_t)bq[j] & ~(uintptr_t)15);
+                for (int j = 0; j < 4; j++) bq[j] = (const char*)((uintptr_t)bq[j] & ~(uintptr_t)15);
             }
-            if (PACK) be = bb + ((size_t)min(min(pt >> 6, spr - 1), last) * p.cb + (pt & 63)) * plane_b + 2 * p.w;
-            else be = bb + (size_t)(pt & 63) * plane_b + 64;
+            if (PACK) be = bb + (((size_t)min(min(pt >> 6, spr - 1), last) * p.cb + (pt & 63)) * plane_b + 2 * p.w) * ES;
+            else be = bb + ((size_t)(pt & 63) * plane_b + 64) * ES;
             if (PACK) {
                 const int smp = lq >> wsh;
                 live = smp <= last;
-                sq = sb + ((size_t)min(smp, last) * p.cs + lr) * plane_s + (lq & (p.w - 1));
-            } else sq = sb + (size_t)lr * plane_s + lq;
+                sq = sb + (((size_t)min(smp, last) * p.cs + lr) * plane_s + (lq & (p.w - 1))) * ES;
+            } else sq = sb + ((size_t)lr * plane_s + lq) * ES;
         };
         // The loads are inline asm (counted s_waitcnt below; see conv3x3_ws_kernel.h): their destinations are unprotected until `touch`.
         auto load_big = [&](int b, bset& r) {   // local big row b = 0 .. 2 R
             if (ABL == 6) return;
-            const size_t o = (size_t)b * wb;
+            const size_t o = (size_t)b * wb * ES;
 #pragma unroll
-            for (int j = 0; j < 4; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.v[j]) : "v"(bq[j] + o) : "memory");
-            asm volatile("global_load_dword %0, %1, off" : "=v"(r.e) : "v"(be + o) : "memory");
+            for (int j = 0; j < 4; j++) px4_load<IO>(r.v[j], bq[j] + o);
+            px1_load<IO>(r.e, be + o);
         };
         auto load_small = [&](int row, sset& r) {
             if (ABL == 6) return;
-            const float* q = sq + (size_t)row * p.w;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.a) : "v"(q) : "memory");
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.b) : "v"(q + 4) : "memory");
+            const char* q = sq + (size_t)row * p.w * ES;
+            px4_load<IO>(r.a, q);
+            px4_load<IO>(r.b, q + 4 * ES);
         };
         auto touch_b = [&](bset& r) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) asm volatile("" : "+v"(r.v[j]));
-            asm volatile("" : "+v"(r.e));
+            for (int j = 0; j < 4; j++) px4_pin<IO>(r.v[j]);
+            px1_pin<IO>(r.e);
         };
-        auto touch_s = [&](sset& r) { asm volatile("" : "+v"(r.a)); asm volatile("" : "+v"(r.b)); };
+        auto touch_s = [&](sset& r) { px4_pin<IO>(r.a); px4_pin<IO>(r.b); };
         auto store_big = [&](int b, const bset& r) {
             if (ABL == 6) return;
             const int slot = b - 5 * ((b * 205) >> 10);   // b % 5
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int it = pt + 256 * j, quad = it & 15, ch = it >> 4;
-                const unsigned he = pack_bf16(r.v[j][0], r.v[j][2]), ho = pack_bf16(r.v[j][1], r.v[j][3]);
+                const float v0 = px4_get<IO>(r.v[j], 0), v1 = px4_get<IO>(r.v[j], 1), v2 = px4_get<IO>(r.v[j], 2), v3 = px4_get<IO>(r.v[j], 3);
+                const unsigned he = pack_bf16(v0, v2), ho = pack_bf16(v1, v3);
                 const int pos = slot * BIG_SLOT + ch * BIG_CH + 2 * quad;
                 *(unsigned*)&bs[pos] = he;
                 *(unsigned*)&bs[pos + RS] = ho;
                 if (TERMS > 1) {
-                    const unsigned le = pack_bf16(r.v[j][0] - __builtin_bit_cast(float, he << 16), r.v[j][2] - __builtin_bit_cast(float, he & 0xffff0000u));
-                    const unsigned lo = pack_bf16(r.v[j][1] - __builtin_bit_cast(float, ho << 16), r.v[j][3] - __builtin_bit_cast(float, ho & 0xffff0000u));
+                    const unsigned le = pack_bf16(v0 - __builtin_bit_cast(float, he << 16), v2 - __builtin_bit_cast(float, he & 0xffff0000u));
+                    const unsigned lo = pack_bf16(v1 - __builtin_bit_cast(float, ho << 16), v3 - __builtin_bit_cast(float, ho & 0xffff0000u));
                     *(unsigned*)&bs[5 * BIG_SLOT + pos] = le;
                     *(unsigned*)&bs[5 * BIG_SLOT + pos + RS] = lo;
                 }
             }
             if (pt < TI * spr) {
-                const unsigned h = pack_bf16(r.e, 0.f);
+                const float ev = px1_get<IO>(r.e);
+                const unsigned h = pack_bf16(ev, 0.f);
                 const int pos = slot * BIG_SLOT + (pt & 63) * BIG_CH + (PACK ? 2 * RS + 2 * (pt >> 6) : 32);
                 bs[pos] = (unsigned short)h;
-                if (TERMS > 1) bs[5 * BIG_SLOT + pos] = (unsigned short)pack_bf16(r.e - __builtin_bit_cast(float, h << 16), 0.f);
+                if (TERMS > 1) bs[5 * BIG_SLOT + pos] = (unsigned short)pack_bf16(ev - __builtin_bit_cast(float, h << 16), 0.f);
             }
         };
         auto store_small = [&](int buf, const sset& r) {
             if (ABL == 6) return;
             float v[8];
 #pragma unroll
-            for (int k = 0; k < 4; k++) { v[k] = (!PACK || live) ? r.a[k] : 0.f; v[4 + k] = (!PACK || live) ? r.b[k] : 0.f; }
+            for (int k = 0; k < 4; k++) { v[k] = (!PACK || live) ? px4_get<IO>(r.a, k) : 0.f; v[4 + k] = (!PACK || live) ? px4_get<IO>(r.b, k) : 0.f; }
             u32x4 hi, lo;
             split8(v, hi, lo);
             *(u32x4*)&as[buf * S2W_SMALL + lr * RS + lq] = hi;

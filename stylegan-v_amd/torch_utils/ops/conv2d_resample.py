@@ -69,7 +69,7 @@ def downsampling_conv1x1(x, w, f, down, padding=0, residual=None, flip_filter=Fa
     if residual is not None and _gemm.enabled and w.dtype == torch.float32 and x.is_cuda and _gemm.is_full_tile_conv1x1(x, out_ch) \
             and residual.dtype == torch.float32 and tuple(residual.shape) == (x.shape[0], out_ch, x.shape[2], x.shape[3]):
         return _gemm.conv1x1(x, w, residual=residual)
-    y = _conv2d_wrapper(x=x, w=w)
+    y = _conv2d_wrapper(x=x, w=conv2d_gradfix.cast_weight(w, x))
     return y + residual if residual is not None else y
 
 

@@ -16,7 +16,8 @@ reference op to mirror, so -- like ``fused_fir_act`` -- this is 
 Second order: when the node's gradient is itself differentiated (``create_graph=True``) its backward switches to differentiating
 the composition on the saved inputs (one extra forward), so gradients of any order exist.  Passes that are known to be
 differentiated twice (R1, path-length regularisation; training/loss.py) run under ``composition_only()`` and skip the fused
-forward altogether; so do CPU tensors, 16-bit tensors and shapes the kernel does not serve.  Parity: forward within fused-multiply-add rounding of the composition (1e-6),
+forward altogether; so do CPU tensors and shapes the kernel does not serve.  fp16 / bf16 activations (the mixed-precision blocks) take the same kernels with
+16-bit tensor I/O: fp32 weight, scales, bias and accumulators.  Parity: forward within fused-multiply-add rounding of the composition (1e-6),
 tests/test_fused_conv_gpu.py against the oracle composition.
 """
 
@@ -59,18 +60,22 @@ def conv3x3_bias_act_composed(x, weight, styles=None, dcoefs=None, bias=None, ac
 
 def _launch_fused(x, weight, styles, dcoefs, bias, act_idx, alpha, gain, clamp, mode=0, accumulate_into=None):
     """mode 0: forward (weight [O,I,3,3]); mode 1: data gradient of that layer (x is the output-side tensor, the result has I channels).
-    ``accumulate_into``: an existing fp32 tensor of the result's shape that receives  += result  instead of a fresh output."""
+    ``accumulate_into``: an existing fp32 tensor of the result's shape that receives  += result  instead of a fresh output.
+    x may be fp16 / bf16 (the mixed-precision blocks): the result has x's format, the weight / scales / bias stay fp32 (single bf16 operands, fp32 accumulate)."""
     lib = custom_ops.get_native()
     n, ci, h, w = x.shape
     co = weight.shape[0] if mode == 0 else weight.shape[1]
-    y = accumulate_into if accumulate_into is not None else torch.empty([n, co, h, w], dtype=torch.float32, device=x.device)
+    dt = _cg._DT[x.dtype]
+    assert accumulate_into is None or dt == 0
+    y = accumulate_into if accumulate_into is not None else torch.empty([n, co, h, w], dtype=x.dtype, device=x.device)
     ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
     ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
-    p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, mode, _cg.native_conv_terms)
+    weight = weight.float()
+    p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, mode, _cg.native_conv_terms if dt == 0 else 1)
     e = custom_ops.Conv3x3Epilogue(styles.data_ptr() if styles is not None else None, dcoefs.data_ptr() if dcoefs is not None else None,
                                    bias.data_ptr() if bias is not None else None, act_idx, alpha, gain, clamp, 1 if accumulate_into is not None else 0)
     with custom_ops.device_guard(x):
-        custom_ops.check(lib.sgv_conv3x3_fused(p, e, 0, custom_ops.raw_stream(x)), lib)
+        custom_ops.check(lib.sgv_conv3x3_fused(p, e, dt, custom_ops.raw_stream(x)), lib)
     return y
 
 
@@ -110,10 +115,12 @@ class _FusedConvBiasActFn(torch.autograd.Function):
         need_sums = (b is not None and ctx.needs_input_grad[4]) or (d is not None and ctx.needs_input_grad[3])
         sums = torch.zeros([2, n * co], dtype=torch.float32, device=dy.device) if need_sums else None
         dzd = torch.empty_like(y)     # gradient w.r.t. the convolution result: bias_act gradient times dcoefs
+        dt = _cg._DT[y.dtype]
+        dy = dy.to(y.dtype)
         with custom_ops.device_guard(dy):
-            custom_ops.check(lib.sgv_act_grad_scale(dy.data_ptr(), y.data_ptr(), d.data_ptr() if d is not None else None, dzd.data_ptr(),
-                                                    sums.data_ptr() if sums is not None else None, n * co, h * w,
-                                                    _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, stream), lib)
+            custom_ops.check(lib.sgv_act_grad_scale_t(dy.data_ptr(), y.data_ptr(), d.data_ptr() if d is not None else None, dzd.data_ptr(),
+                                                      sums.data_ptr() if sums is not None else None, n * co, h * w,
+                                                      _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, dt, stream), lib)
         d_x = d_w = d_s = d_d = d_b = None
         if b is not None and ctx.needs_input_grad[4]:
             d_b = sums[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
@@ -123,12 +130,12 @@ class _FusedConvBiasActFn(torch.autograd.Function):
         cfg = (False, (1, 1), (1, 1), (0, 0), (1, 1), 1)
         if ctx.needs_input_grad[0] or (s is not None and ctx.needs_input_grad[2]):
             tcfg = (True, (1, 1), (1, 1), (0, 0), (1, 1), 1)                                    # data gradient: the transposed form, same kernel family
-            dxs = _cg._native_conv(dzd, weight, tcfg) if _cg._native_conv_ok(dzd, weight, tcfg) else _cg._aten_conv(dzd, weight, None, tcfg)
+            dxs = _cg._native_conv(dzd, weight, tcfg) if _cg._native_conv_ok(dzd, weight, tcfg) else _cg._aten_conv(dzd, weight.to(dzd.dtype), None, tcfg)
             if s is not None:
                 d_x = torch.empty_like(dxs)
                 dot = torch.zeros([n * ci], dtype=torch.float32, device=dy.device)
                 with custom_ops.device_guard(dy):
-                    custom_ops.check(lib.sgv_scale_dot(dxs.data_ptr(), x.data_ptr(), s.data_ptr(), d_x.data_ptr(), dot.data_ptr(), n * ci, h * w, stream), lib)
+                    custom_ops.check(lib.sgv_scale_dot_t(dxs.data_ptr(), x.data_ptr(), s.data_ptr(), d_x.data_ptr(), dot.data_ptr(), n * ci, h * w, dt, stream), lib)
                 d_s = dot.reshape(n, ci)
             else:
                 d_x = dxs
@@ -140,7 +147,8 @@ class _FusedConvBiasActFn(torch.autograd.Function):
                 if _cg._native_wrw_ok(dzd, xs, cfg, tuple(weight.shape)):
                     d_w = _cg._native_wrw(dzd, xs, cfg, tuple(weight.shape))
                 else:
-                    _, d_w, _ = torch.ops.aten.convolution_backward(dzd, xs, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
+                    _, d_w, _ = torch.ops.aten.convolution_backward(dzd, xs, weight.to(xs.dtype), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
+            d_w = d_w.to(weight.dtype)
         return d_x, d_w, d_s, d_d, d_b, None
 
 
@@ -149,7 +157,9 @@ def _fusable(x, weight, styles, dcoefs, bias, act, alpha, gain, clamp):
         return False
     if mode == 0 or _composition_depth > 0 or _cg.native_conv_terms not in (1, 3) or not _cg.enabled:
         return False
-    if not (x.is_cuda and x.ndim == 4 and x.dtype == torch.float32 and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)):
+    if not (x.is_cuda and x.ndim == 4 and x.dtype in _cg._DT and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    if x.dtype != torch.float32 and not _cg.native_lowp:
         return False
     if act not in ('linear', 'lrelu') or not gain > 0 or (act == 'lrelu' and not 0 <= alpha <= 1):
         return False
@@ -165,7 +175,7 @@ def _fusable(x, weight, styles, dcoefs, bias, act, alpha, gain, clamp):
     needs_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (x, weight, styles, dcoefs, bias))
     if needs_graph and mode < 2:
         return False
-    return bool(custom_ops.get_native().sgv_conv3x3_fused_supported(n, ci, co, h, w, 0))
+    return bool(custom_ops.get_native().sgv_conv3x3_fused_supported(n, ci, co, h, w, _cg._DT[x.dtype]))
 
 
 def conv3x3_bias_act(x, weight, styles=None, dcoefs=None, bias=None, act='lrelu', alpha=None, gain=None, clamp=None):
@@ -229,10 +239,12 @@ class _FusedConvActFirFn(torch.autograd.Function):
         # the gradient of upfirdn2d is upfirdn2d with the padding of upfirdn2d.py:251-261 and the filter flip inverted
         bpads = (fw - pads[0] - 1, w - g.shape[3] + pads[0], fh - pads[2] - 1, h - g.shape[2] + pads[2])
         dz = torch.empty_like(y0)
+        dt = _cg._DT[y0.dtype]
+        g = g.to(y0.dtype)
         sums = torch.zeros([n * co], dtype=torch.float32, device=g.device)
         e = custom_ops.FirEpilogue(3, None, None, y0.data_ptr(), sums.data_ptr(), None, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
         with custom_ops.device_guard(g):
-            rc = lib.sgv_upfirdn2d_fused(_ffa._ufd_params(g, f, dz, bpads, True, 1.0), e, 0, custom_ops.raw_stream(g))
+            rc = lib.sgv_upfirdn2d_fused(_ffa._ufd_params(g, f, dz, bpads, True, 1.0), e, dt, custom_ops.raw_stream(g))
         need_db = b is not None and ctx.needs_input_grad[2]
         d_x = d_w = d_b = None
         if rc == 0:
@@ -242,8 +254,8 @@ class _FusedConvActFirFn(torch.autograd.Function):
             gy = _ufd.upfirdn2d(g, f, padding=list(bpads), flip_filter=True)
             s2 = torch.zeros([2, n * co], dtype=torch.float32, device=g.device) if need_db else None
             with custom_ops.device_guard(g):
-                custom_ops.check(lib.sgv_act_grad_scale(gy.data_ptr(), y0.data_ptr(), None, dz.data_ptr(), s2.data_ptr() if s2 is not None else None, n * co, h * w,
-                                                        _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, custom_ops.raw_stream(g)), lib)
+                custom_ops.check(lib.sgv_act_grad_scale_t(gy.data_ptr(), y0.data_ptr(), None, dz.data_ptr(), s2.data_ptr() if s2 is not None else None, n * co, h * w,
+                                                          _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, dt, custom_ops.raw_stream(g)), lib)
             if need_db:
                 d_b = s2[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
         else:
@@ -253,19 +265,20 @@ class _FusedConvActFirFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             tcfg = (True, (1, 1), (1, 1), (0, 0), (1, 1), 1)
             ci = x.shape[1]
-            if (accumulate_input_gradients and g_alias is not None and g_alias.is_contiguous() and g_alias.dtype == torch.float32 and _cg.native_conv_terms in (1, 3)
+            if (accumulate_input_gradients and g_alias is not None and g_alias.is_contiguous() and g_alias.dtype == torch.float32 and dt == 0 and _cg.native_conv_terms in (1, 3)
                     and lib.sgv_conv3x3_fused_supported(n, co, ci, h, w, 0)):
                 # the data gradient lands IN the gradient the skip branch produced (one fp32 add per element in the convolution's store)
                 d_x = _launch_fused(dz, wc, None, None, None, 1, 0.0, 1.0, -1.0, mode=1, accumulate_into=g_alias)
             else:
-                d_x = _cg._native_conv(dz, wc, tcfg) if _cg._native_conv_ok(dz, wc, tcfg) else _cg._aten_conv(dz, wc, None, tcfg)
+                d_x = _cg._native_conv(dz, wc, tcfg) if _cg._native_conv_ok(dz, wc, tcfg) else _cg._aten_conv(dz, wc.to(dz.dtype), None, tcfg)
                 if g_alias is not None:
                     d_x = d_x + g_alias
         if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
             if _cg._native_wrw_ok(dz, x, cfg1, tuple(weight.shape)):
                 d_w = _cg._native_wrw(dz, x, cfg1, tuple(weight.shape))
             else:
-                _, d_w, _ = torch.ops.aten.convolution_backward(dz, x, weight, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
+                _, d_w, _ = torch.ops.aten.convolution_backward(dz, x, weight.to(x.dtype), None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
+            d_w = d_w.to(weight.dtype)
         return d_x, d_w, d_b, None, None
 
 

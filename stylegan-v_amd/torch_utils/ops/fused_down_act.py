@@ -28,26 +28,30 @@ _S2T = (True, (2, 2), (0, 0), (0, 0), (1, 1), 1)     # ... and of its data gradi
 
 def strided_conv3x3_bias_act_composed(xb, weight, bias=None, act='lrelu', alpha=None, gain=None, clamp=None, residual=None):
     """The definition: strided convolution -> bias_act -> (+ residual), each differentiable to any order."""
-    y = _cg.conv2d(xb, weight.to(xb.dtype), stride=2)
+    y = _cg.conv2d(xb, _cg.cast_weight(weight, xb), stride=2)
     y = _ba.bias_act(y, bias.to(y.dtype) if bias is not None else None, act=act, alpha=alpha, gain=gain, clamp=clamp)
     return residual.add_(y) if residual is not None else y       # the reference's in-place form (networks.py:345)
 
 
 def _launch(xb, weight, bias, residual, want_act, act_idx, alpha, gain, clamp):
-    """`residual` (dense fp32, or None) is updated in place and returned: the reference's `y.add_(x)`."""
+    """`residual` (dense fp32, or None) is updated in place and returned: the reference's `y.add_(x)`.  xb may be fp16 / bf16 (no residual then):
+    the result has its format; weight and bias stay fp32."""
     lib = custom_ops.get_native()
     n, ci, hb, wb = xb.shape
     co = weight.shape[0]
     hs, ws_ = (hb - 1) // 2, (wb - 1) // 2
-    y = residual if residual is not None else torch.empty([n, co, hs, ws_], dtype=torch.float32, device=xb.device)
+    dt = _cg._DT[xb.dtype]
+    assert residual is None or dt == 0
+    weight = weight.float()
+    y = residual if residual is not None else torch.empty([n, co, hs, ws_], dtype=xb.dtype, device=xb.device)
     a = torch.empty_like(y) if want_act else None
     wsb = int(lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, ws_, 0))
     wsp = torch.empty([wsb], dtype=torch.uint8, device=xb.device)
-    p = custom_ops.Conv3x3Params(xb.data_ptr(), weight.data_ptr(), y.data_ptr(), wsp.data_ptr(), wsb, n, ci, co, hs, ws_, 0, _cg.native_conv_terms)
+    p = custom_ops.Conv3x3Params(xb.data_ptr(), weight.data_ptr(), y.data_ptr(), wsp.data_ptr(), wsb, n, ci, co, hs, ws_, 0, _cg.native_conv_terms if dt == 0 else 1)
     e = custom_ops.Conv3x3S2Epilogue(bias.data_ptr() if bias is not None else None, a.data_ptr() if a is not None else None, act_idx, alpha, gain, clamp,
                                      1 if residual is not None else 0)
     with custom_ops.device_guard(xb):
-        custom_ops.check(lib.sgv_conv3x3_s2_fused(p, e, 0, custom_ops.raw_stream(xb)), lib)
+        custom_ops.check(lib.sgv_conv3x3_s2_fused(p, e, dt, custom_ops.raw_stream(xb)), lib)
     return y, a
 
 
@@ -89,19 +93,21 @@ class _FusedDownFn(torch.autograd.Function):
             need_db = b is not None and ctx.needs_input_grad[2]
             sums = torch.zeros([2, n * co], dtype=torch.float32, device=dy.device) if need_db else None
             dz = torch.empty_like(a)
+            dy = dy.to(a.dtype)
             with custom_ops.device_guard(dy):
-                custom_ops.check(lib.sgv_act_grad_scale(dy.data_ptr(), a.data_ptr(), None, dz.data_ptr(), sums.data_ptr() if sums is not None else None, n * co, h * w,
-                                                        _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, custom_ops.raw_stream(dy)), lib)
+                custom_ops.check(lib.sgv_act_grad_scale_t(dy.data_ptr(), a.data_ptr(), None, dz.data_ptr(), sums.data_ptr() if sums is not None else None, n * co, h * w,
+                                                          _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, _cg._DT[a.dtype], custom_ops.raw_stream(dy)), lib)
             if need_db:
                 d_b = sums[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
             wc = weight.contiguous()
             if ctx.needs_input_grad[0]:
-                d_x = _cg._native_conv(dz, wc, _S2T) if _cg._native_conv_ok(dz, wc, _S2T) else _cg._aten_conv(dz, wc, None, _S2T)
+                d_x = _cg._native_conv(dz, wc, _S2T) if _cg._native_conv_ok(dz, wc, _S2T) else _cg._aten_conv(dz, wc.to(dz.dtype), None, _S2T)
             if ctx.needs_input_grad[1] and not _cg.weight_gradients_disabled:
                 if _cg._native_wrw_ok(dz, xb, _S2, tuple(weight.shape)):
                     d_w = _cg._native_wrw(dz, xb, _S2, tuple(weight.shape))
                 else:
-                    _, d_w, _ = torch.ops.aten.convolution_backward(dz, xb, weight, None, (2, 2), (0, 0), (1, 1), False, (0, 0), 1, [False, True, False])
+                    _, d_w, _ = torch.ops.aten.convolution_backward(dz, xb, weight.to(xb.dtype), None, (2, 2), (0, 0), (1, 1), False, (0, 0), 1, [False, True, False])
+                d_w = d_w.to(weight.dtype)
         return d_x, d_w, d_b, d_r, None
 
 
@@ -110,7 +116,9 @@ def _fusable(xb, weight, bias, residual, act, alpha, gain, clamp):
         return False
     if _fca.mode == 0 or _fca._composition_depth > 0 or _cg.native_conv_terms not in (1, 3) or not _cg.enabled or not _cg.native_conv_s2:
         return False
-    if not (xb.is_cuda and xb.ndim == 4 and xb.dtype == torch.float32 and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)):
+    if not (xb.is_cuda and xb.ndim == 4 and xb.dtype in _cg._DT and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    if xb.dtype != torch.float32 and (not _cg.native_lowp or residual is not None):   # the in-place residual add is an fp32 atomic
         return False
     if act not in ('linear', 'lrelu') or not gain > 0 or (act == 'lrelu' and not 0 <= alpha <= 1):
         return False
@@ -127,7 +135,7 @@ def _fusable(xb, weight, bias, residual, act, alpha, gain, clamp):
     needs_graph = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (xb, weight, bias, residual))
     if needs_graph and _fca.mode < 2:
         return False
-    return bool(custom_ops.get_native().sgv_conv3x3_s2_fused_supported(n, ci, co, hs, ws_, 0))
+    return bool(custom_ops.get_native().sgv_conv3x3_s2_fused_supported(n, ci, co, hs, ws_, _cg._DT[xb.dtype]))
 
 
 def strided_conv3x3_bias_act(xb, weight, bias=None, act='lrelu', alpha=None, gain=None, clamp=None, residual=None):

@@ -139,15 +139,20 @@ class Conv2dLayer(torch.nn.Module):
         b = self.bias.to(x.dtype) * (self.lr_multiplier * fold) if self.bias is not None else None
         return w, b, act_gain, clamp
 
+    @staticmethod
+    def _fused_dtype(x):
+        """Tensor formats the fused layer kernels take: fp32, and fp16 / bf16 (mixed-precision blocks) unless SGV_CONV_LOWP=0."""
+        return x.dtype == torch.float32 or (x.dtype in (torch.float16, torch.bfloat16) and conv2d_gradfix.native_lowp)
+
     def fusable_with_following_fir(self, x):
-        """A plain stride-1 3x3 layer on a GPU fp32 tensor: ``forward_then_fir`` may pair it with the FIR pass of the next (down-sampling) layer."""
+        """A plain stride-1 3x3 layer on a GPU tensor: ``forward_then_fir`` may pair it with the FIR pass of the next (down-sampling) layer."""
         return (self.up == 1 and self.down == 1 and self.padding == 1 and tuple(self.weight.shape[2:]) == (3, 3) and bool(fused_conv_act.mode) and x.is_cuda
-                and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm)
+                and self._fused_dtype(x) and self.activation in ('linear', 'lrelu') and not self.instance_norm)
 
     def accepts_prefiltered(self, x):
         """A down-sampling 3x3 layer that ``forward(..., prefiltered=True)`` serves (x: the tensor the FIR pass will be applied to)."""
         return (self.up == 1 and self.down == 2 and self.padding == 1 and tuple(self.weight.shape[2:]) == (3, 3) and bool(fused_conv_act.mode) and x.is_cuda
-                and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm)
+                and self._fused_dtype(x) and self.activation in ('linear', 'lrelu') and not self.instance_norm)
 
     def forward_then_fir(self, x, f, pads, gain=1, with_input_alias=False):
         """upfirdn2d(self(x, gain), f, padding=pads) -- this layer followed by the FIR pass in front of the next layer's strided convolution, as one
@@ -162,7 +167,7 @@ class Conv2dLayer(torch.nn.Module):
         branch with a residual: ``fused_fir_act.fir_down_with_input_alias``)."""
         w, b, act_gain, clamp = self._scaled_parameters(x, gain)
         if self.up == 1 and self.down == 1 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
-                and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu'):
+                and self._fused_dtype(x) and self.activation in ('linear', 'lrelu'):
             # stride-1 3x3 layer (DiscriminatorBlock conv0, epilogue conv): convolution + bias + activation as one kernel where served
             x = fused_conv_act.conv3x3_bias_act(x, w, bias=b, act=self.activation, gain=act_gain, clamp=clamp)
         elif self.up == 1 and self.down == 1 and tuple(w.shape[2:]) == (1, 1) and w.shape[1] <= 4 and w.shape[0] > w.shape[1] and x.is_cuda \
@@ -170,13 +175,13 @@ class Conv2dLayer(torch.nn.Module):
             # fromRGB: 1x1 convolution from <= 4 channels + bias + activation as one streaming kernel
             x = pointwise.pointwise_conv_bias_act(x, w.reshape(1, w.shape[0], w.shape[1]), b, act=self.activation, gain=act_gain, clamp=clamp)
         elif residual is not None and self.up == 1 and self.down > 1 and tuple(w.shape[2:]) == (1, 1) and b is None and self.activation == 'linear' \
-                and act_gain == 1 and clamp is None and x.is_cuda and x.dtype == torch.float32:
+                and act_gain == 1 and clamp is None and x.is_cuda and self._fused_dtype(x):
             # skip branch of the residual block (gain already on the weights): FIR + decimate, then the 1x1 convolution whose store adds the
             # other branch's result
             x = conv2d_resample.downsampling_conv1x1(x, w, self.resample_filter, down=self.down, padding=self.padding, residual=residual, prefiltered=prefiltered)
             residual = None
         elif self.up == 1 and self.down == 2 and self.padding == 1 and tuple(w.shape[2:]) == (3, 3) and fused_conv_act.mode and x.is_cuda \
-                and x.dtype == torch.float32 and self.activation in ('linear', 'lrelu') and not self.instance_norm:
+                and self._fused_dtype(x) and self.activation in ('linear', 'lrelu') and not self.instance_norm:
             # down-sampling 3x3 layer (DiscriminatorBlock conv1): FIR pass, then strided convolution + bias + activation (+ residual) as one kernel
             xb = x if prefiltered else conv2d_resample.downsampling_filter_pass(x, self.resample_filter, down=self.down, padding=self.padding)
             x = fused_down_act.strided_conv3x3_bias_act(xb, w, bias=b, act=self.activation, gain=act_gain, clamp=clamp, residual=residual)

@@ -126,12 +126,17 @@ class SynthesisLayer(torch.nn.Module):
                                                                flip_weight=False)
             return fused_fir_act.fir_bias_act(x, self.resample_filter, scale=dcoefs, bias=self.bias, padding=fir_pad, fir_gain=self.up ** 2,
                                               act=self.activation, gain=self.act_gain * gain, clamp=clamp)
-        if self.up == 1 and not fused_modconv and noise is None and fused_conv_act.mode and x.is_cuda and x.dtype == torch.float32 \
+        if self.up == 1 and not fused_modconv and noise is None and fused_conv_act.mode and x.is_cuda \
+                and (x.dtype == torch.float32 or (x.dtype in (torch.float16, torch.bfloat16) and conv2d_gradfix.native_lowp)) \
                 and self.activation in ('linear', 'lrelu') and tuple(self.weight.shape[2:]) == (3, 3) and self.padding == 1:
             # Stride-1 layer, training formulation: [x*s -> conv3x3 -> *dcoefs + bias -> act -> clamp] as one kernel where the shape is
             # served (ops/fused_conv_act.py), as the four-op composition otherwise.
-            dcoefs = modulation.demod_coefs(self.weight, styles)
-            return fused_conv_act.conv3x3_bias_act(x, self.weight, styles=styles, dcoefs=dcoefs, bias=self.bias, act=self.activation,
+            weight, s = self.weight, styles
+            if x.dtype == torch.float16:  # same fp16 range guard as modulated_conv2d (the data gradient is stored before it meets the styles)
+                weight = weight * (1 / math.sqrt(weight[0].numel()) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
+                s = s / s.norm(float('inf'), dim=1, keepdim=True)
+            dcoefs = modulation.demod_coefs(weight, s)
+            return fused_conv_act.conv3x3_bias_act(x, weight, styles=s, dcoefs=dcoefs, bias=self.bias, act=self.activation,
                                                    gain=self.act_gain * gain, clamp=clamp)
         x = modulated_conv2d(x=x, weight=self.weight, styles=styles, noise=noise, up=self.up, padding=self.padding,
                              resample_filter=self.resample_filter, flip_weight=(self.up == 1), fused_modconv=fused_modconv)

@@ -1,4 +1,5 @@
-"""16-bit (bf16 / fp16) tensor I/O of the stride-1 3x3 convolution and weight-gradient kernels (csrc/sgv_io16.h) through the C ABI.
+"""16-bit (bf16 / fp16) tensor I/O of the 3x3 convolution and weight-gradient kernels -- stride 1, stride 2, transposed stride 2, and the forms that
+pack 2 / 4 narrow samples into a tile row (csrc/sgv_io16.h) -- through the C ABI.
 
 The mixed-precision blocks of the reference (`num_fp16_res`, src/training/networks.py:227,461) hand fp16 activations and `weight.to(x.dtype)`
 to cuDNN.  Here the kernels read the 16-bit activations and the fp32 master weight, turn every value into ONE bf16 operand of the matrix
@@ -157,3 +158,180 @@ def test_autograd_with_fp32_master_weight(dtype):
     (gx2r,) = torch.autograd.grad((dxr ** 2).sum() + (dwr ** 2).sum(), [xr])
     assert gx2.dtype == dtype
     assert ((gx2.double() - gx2r).abs().max() / gx2r.abs().max()).item() < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# stride 2: the strided form (x (2H+1)x(2W+1) -> y HxW, the tap-pair kernel), the transposed form (x HxW -> y (2H+1)x(2W+1), producer / consumer kernel
+# + the MFMA edge strips) and their weight gradient; W = 16 / 8 on the small grid: 2 / 4 samples per tile row
+S2 = (False, (2, 2), (0, 0), (0, 0), (1, 1), 1)
+S2T = (True, (2, 2), (0, 0), (0, 0), (1, 1), 1)
+
+
+def _conv_s2(x, w, transposed):
+    cfg = S2T if transposed else S2
+    assert conv2d_gradfix._native_conv_kind(x, w, cfg) == 's2', 'this 16-bit stride-2 shape is not served by the hand-written kernel'
+    name = 'convT_lowp' if transposed else 'conv_s2_lowp'
+    before = custom_ops.kernel_variant_counts().get(name, 0)
+    y = conv2d_gradfix._native_conv(x, w, cfg)
+    assert custom_ops.kernel_variant_counts().get(name, 0) == before + 1
+    assert y.dtype == x.dtype
+    return y
+
+
+def _ref_s2(x, w, transposed):
+    return oracle.conv3x3(x.double().cpu().numpy(), w.double().cpu().numpy(), stride=2, transposed=transposed)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('transposed', [False, True])
+@pytest.mark.parametrize('n,ci,co,hs,ws', [(2, 64, 128, 8, 32), (1, 128, 128, 16, 64), (3, 16, 128, 8, 32), (4, 64, 128, 16, 16), (8, 32, 128, 8, 8), (2, 64, 256, 24, 32)])
+def test_conv3x3_s2_16bit_tensors(dtype, transposed, n, ci, co, hs, ws):
+    """hs x ws: the small grid.  Strided: x [n, ci, 2hs+1, 2ws+1] -> y [n, co, hs, ws]; transposed: x [n, ci, hs, ws] -> y [n, co, 2hs+1, 2ws+1]."""
+    g = torch.Generator().manual_seed(n + ci + co + hs + ws + (7 if transposed else 0))
+    xshape = [n, ci, hs, ws] if transposed else [n, ci, 2 * hs + 1, 2 * ws + 1]
+    wshape = [ci, co, 3, 3] if transposed else [co, ci, 3, 3]
+    xi = torch.randint(-3, 4, xshape, generator=g).to(DEV).to(dtype)
+    wi = torch.randint(-2, 3, wshape, generator=g).float().to(DEV)
+    yi = _conv_s2(xi, wi, transposed)
+    want = torch.from_numpy(_ref_s2(xi, wi, transposed)).to(dtype)
+    assert yi.shape == want.shape
+    bad = yi.cpu() != want
+    assert not bad.any(), f'{int(bad.sum())} of {want.numel()} elements differ from the once-rounded exact result (last row {int(bad[:, :, -1].sum())}, last column {int(bad[:, :, :, -1].sum())})'
+    x = (torch.randn(xshape, generator=g) + 0.25).to(DEV).to(dtype)
+    w = (torch.randn(wshape, generator=g) / (3 * ci ** 0.5)).to(DEV)
+    y = _conv_s2(x, w, transposed).double().cpu().numpy()
+    same_operands = _ref_s2(_bf16(x.float()), _bf16(w), transposed)
+    scale = np.abs(same_operands).max()
+    err = np.abs(y - same_operands)
+    assert (err <= ULP[dtype] * np.abs(same_operands) + 1e-5 * scale).all(), f'worst {err.max() / scale:.2e} of scale beyond summation order + one output rounding'
+    full = _ref_s2(x, w, transposed)
+    tol = np.abs(y - full).max() / np.abs(full).max()
+    print(f'[{dtype} s2 {ci}->{co} small grid {hs}x{ws}{" T" if transposed else ""}] error vs float64 on the fp32 weight: {tol:.2e} of scale')
+    assert tol < 1e-2
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('transposed', [False, True])
+@pytest.mark.parametrize('n,cs,cb,hs,ws', [(2, 64, 64, 8, 32), (1, 128, 64, 32, 64), (4, 64, 128, 16, 16), (5, 64, 64, 8, 8), (2, 64, 64, 64, 32)])
+def test_conv3x3_s2_weight_gradient_16bit_tensors(dtype, transposed, n, cs, cb, hs, ws):
+    """cs / cb: channels of the small (hs x ws) / big ((2hs+1) x (2ws+1)) tensor; the weight is [cs, cb, 3, 3] for the strided layer (dy small, x big) and
+    for the transposed one (x small, dy big)."""
+    g = torch.Generator().manual_seed(n * 10 + cs + cb + hs + ws)
+    cfg = S2T if transposed else S2
+    shape = (cs, cb, 3, 3)
+
+    def run(small, big):
+        dy, x = (big, small) if transposed else (small, big)
+        assert conv2d_gradfix._native_wrw_kind(dy, x, cfg, shape) == 's2', 'this 16-bit stride-2 shape is not served by the hand-written kernel'
+        before = custom_ops.kernel_variant_counts().get('wrw_s2_lowp', 0)
+        dw = conv2d_gradfix._native_wrw(dy, x, cfg, shape)
+        assert custom_ops.kernel_variant_counts().get('wrw_s2_lowp', 0) == before + 1
+        assert dw.dtype == torch.float32
+        return dw.double().cpu().numpy()
+
+    def ref(small, big):   # the strided layer's formula; the transposed layer has the same one with the roles of x and dy swapped
+        return oracle.conv3x3_weight_grad(small.double().cpu().numpy(), big.double().cpu().numpy(), stride=2)
+
+    si = torch.randint(-3, 4, [n, cs, hs, ws], generator=g).to(DEV).to(dtype)
+    bi = torch.randint(-3, 4, [n, cb, 2 * hs + 1, 2 * ws + 1], generator=g).to(DEV).to(dtype)
+    assert np.array_equal(run(si, bi), ref(si, bi))
+    sm = torch.randn([n, cs, hs, ws], generator=g).to(DEV).to(dtype)
+    bg = (torch.randn([n, cb, 2 * hs + 1, 2 * ws + 1], generator=g) * 1.5 + 0.25).to(DEV).to(dtype)
+    got = run(sm, bg)
+    same = ref(_bf16(sm.float()), _bf16(bg.float()))
+    assert np.abs(got - same).max() / np.abs(same).max() < 1e-5
+    full = ref(sm, bg)
+    tol = np.abs(got - full).max() / np.abs(full).max()
+    print(f'[{dtype} dw s2 {cs}x{cb} small grid {hs}x{ws}] error vs float64 on the unrounded tensors: {tol:.2e} of scale')
+    assert tol < (1e-5 if dtype == torch.bfloat16 else 1e-2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_conv3x3_s2_16bit_at_the_benchmark_shape(dtype):
+    """96 frames, 64 <-> 128 channels between 257x257 and 128x128: the 16-bit kernels reproduce their fp32 twins (exact on integer data, pinned to the
+    oracle in test_conv_bench_shapes_gpu.py) after the one output rounding, in both directions, and the weight gradient exactly."""
+    g = torch.Generator(device=DEV).manual_seed(12)
+    n = 96
+    big = torch.randint(-3, 4, [n, 64, 257, 257], generator=g, device=DEV).to(dtype)
+    small = torch.randint(-3, 4, [n, 128, 128, 128], generator=g, device=DEV).to(dtype)
+    w = torch.randint(-2, 3, [128, 64, 3, 3], generator=g, device=DEV).float()
+    y = _conv_s2(big, w, False)
+    assert torch.equal(y, conv2d_gradfix._native_conv(big.float(), w, S2).to(dtype))
+    yt = _conv_s2(small, w, True)
+    assert torch.equal(yt, conv2d_gradfix._native_conv(small.float(), w, S2T).to(dtype))
+    dw = conv2d_gradfix._native_wrw(small, big, S2, (128, 64, 3, 3))
+    assert torch.equal(dw, conv2d_gradfix._native_wrw(small.float(), big.float(), S2, (128, 64, 3, 3)))
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------------
+# whole layers on 16-bit activations (ops/fused_conv_act.py, ops/fused_down_act.py): the fused kernels against the float64 composition
+def _rel_l2(got, ref):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    return ((got - ref).norm() / ref.norm()).item()
+
+
+def _lrelu_layer_f64(x, w, s, d, b, stride):
+    x = x * s[:, :, None, None] if s is not None else x
+    y = torch.nn.functional.conv2d(x, w, padding=1 if stride == 1 else 0, stride=stride)
+    y = y * d[:, :, None, None] if d is not None else y
+    return torch.nn.functional.leaky_relu(y + b[None, :, None, None], 0.2) * np.sqrt(2)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('modulated', [False, True])
+def test_fused_stride1_layer_on_16bit_activations(dtype, modulated):
+    from stylegan_v_amd.torch_utils.ops import fused_conv_act
+    g = torch.Generator().manual_seed(21)
+    n, ci, co, r = 4, 64, 128, 64
+    x = torch.randn([n, ci, r, r], generator=g).to(DEV).to(dtype).requires_grad_(True)
+    w = (torch.randn([co, ci, 3, 3], generator=g) / 24).to(DEV).requires_grad_(True)
+    b = (torch.randn([co], generator=g) * 0.1).to(DEV).requires_grad_(True)
+    s = (torch.rand([n, ci], generator=g) + 0.5).to(DEV).requires_grad_(True) if modulated else None
+    d = (torch.rand([n, co], generator=g) + 0.5).to(DEV).requires_grad_(True) if modulated else None
+    ins = [t for t in (x, w, b, s, d) if t is not None]
+    before = custom_ops.kernel_variant_counts()
+    y = fused_conv_act.conv3x3_bias_act(x, w, styles=s, dcoefs=d, bias=b, act='lrelu')
+    after = custom_ops.kernel_variant_counts()
+    assert after.get('conv_s1_ws_fused', 0) == before.get('conv_s1_ws_fused', 0) + 1 and after.get('conv_lowp', 0) == before.get('conv_lowp', 0) + 1
+    assert y.dtype == dtype
+    dy = torch.randn(y.shape, generator=g).to(DEV).to(dtype)
+    grads = torch.autograd.grad(y, ins, dy)
+    assert grads[0].dtype == dtype and all(t.dtype == torch.float32 for t in grads[1:])
+    ins64 = [t.detach().double().requires_grad_(True) for t in ins]
+    x6, w6, b6 = ins64[:3]
+    s6, d6 = (ins64[3], ins64[4]) if modulated else (None, None)
+    y6 = _lrelu_layer_f64(x6, w6, s6, d6, b6, 1)
+    grads6 = torch.autograd.grad(y6, ins64, dy.double())
+    errs = [_rel_l2(y, y6)] + [_rel_l2(a, r_) for a, r_ in zip(grads, grads6)]
+    print(f'[{dtype} fused s1 layer, modulated={modulated}] rel-L2 of y, dx, dw, db{", ds, dd" if modulated else ""}:', ' '.join(f'{e:.1e}' for e in errs))
+    assert max(errs) < 1e-2    # stated 16-bit tolerance (2^-9 per operand / stored intermediate, a handful of lrelu sign flips at the kink)
+    # and no further from float64 than the same layer evaluated op by op in the tensor format
+    with fused_conv_act.composition_only():
+        yc = fused_conv_act.conv3x3_bias_act(x, w, styles=s, dcoefs=d, bias=b, act='lrelu')
+    assert _rel_l2(y, y6) <= 1.5 * _rel_l2(yc, y6) + 1e-4
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_fused_downsampling_layer_on_16bit_activations(dtype):
+    from stylegan_v_amd.torch_utils.ops import fused_down_act
+    g = torch.Generator().manual_seed(22)
+    n, ci, co, hs = 4, 64, 128, 32
+    xb = torch.randn([n, ci, 2 * hs + 1, 2 * hs + 1], generator=g).to(DEV).to(dtype).requires_grad_(True)
+    w = (torch.randn([co, ci, 3, 3], generator=g) / 24).to(DEV).requires_grad_(True)
+    b = (torch.randn([co], generator=g) * 0.1).to(DEV).requires_grad_(True)
+    before = custom_ops.kernel_variant_counts()
+    y = fused_down_act.strided_conv3x3_bias_act(xb, w, bias=b, act='lrelu')
+    after = custom_ops.kernel_variant_counts()
+    assert after.get('conv_s2_pairs_fused', 0) == before.get('conv_s2_pairs_fused', 0) + 1 and after.get('conv_s2_lowp', 0) == before.get('conv_s2_lowp', 0) + 1
+    assert y.dtype == dtype
+    dy = torch.randn(y.shape, generator=g).to(DEV).to(dtype)
+    grads = torch.autograd.grad(y, [xb, w, b], dy)
+    assert grads[0].dtype == dtype and grads[1].dtype == torch.float32
+    ins64 = [t.detach().double().requires_grad_(True) for t in (xb, w, b)]
+    y6 = _lrelu_layer_f64(ins64[0], ins64[1], None, None, ins64[2], 2)
+    grads6 = torch.autograd.grad(y6, ins64, dy.double())
+    errs = [_rel_l2(y, y6)] + [_rel_l2(a, r_) for a, r_ in zip(grads, grads6)]
+    print(f'[{dtype} fused down layer] rel-L2 of y, dx, dw, db:', ' '.join(f'{e:.1e}' for e in errs))
+    assert max(errs) < 1e-2
+    after2 = custom_ops.kernel_variant_counts()
+    assert after2.get('convT_lowp', 0) == after.get('convT_lowp', 0) + 1 and after2.get('wrw_s2_lowp', 0) == after.get('wrw_s2_lowp', 0) + 1
