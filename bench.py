@@ -239,6 +239,7 @@ def main():
     ap.add_argument('--ada-steps', type=int, default=8, help="steps of the aug=ada companion measurement (the reference's default augmentation, bgc pipeline); 0 disables it")
     ap.add_argument('--bf16-steps', type=int, default=6, help='steps of the bf16-products companion measurement (fp32 tensors, one bf16 MFMA per product); 0 disables it')
     ap.add_argument('--strict-steps', type=int, default=8, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
+    ap.add_argument('--lowp-steps', type=int, default=8, help="steps of the mixed-precision companion (bf16 tensors in the blocks >= 32^2: the reference's num_fp16_res=4 with bf16, BASELINE config 4); 0 disables it")
     ap.add_argument('--pl-steps', type=int, default=8, help='steps of the path-length-regularisation companion (F=1, pl_weight=2); 0 disables it')
     ap.add_argument('--aug', choices=['noaug', 'ada'], default='noaug', help="discriminator augmentation: the reference's default is ada (bgc pipeline, adaptive p)")
     ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs (single GPU; pays off at small per-GPU batches)')
@@ -493,6 +494,39 @@ def main():
             del ts1
             torch.cuda.empty_cache()
 
+    # Mixed-precision companion (BASELINE config 4, "bf16 compute"): config 3 with the reference's own mixed-precision switch (train.py:173-174:
+    # num_fp16_res = 4, conv_clamp = 256 -> the blocks at 32^2 .. 256^2 hold 16-bit activations) and bf16 as the 16-bit format: 16-bit tensor I/O on
+    # the hand-written kernels, fp32 master weights, fp32 accumulate, fp32 weight gradients.  Its own models; same bracket and schedule.
+    lowpc = None
+    if args.lowp_steps > 0 and lowp is None and not args.graphs and args.workload == 'train256':
+        g_kw2, d_kw2, train_cfg2 = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=False, num_frames_per_video=args.frames,
+                                                     lowp_dtype=torch.bfloat16)
+        ts2 = TrainStep(g_kw2, d_kw2, train_cfg2, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, augment=args.aug)
+        try:
+            tw = time.perf_counter()
+            ts2.step(); ts2.batch_idx = 0; ts2.step()
+            torch.cuda.synchronize()
+            if rank == 0:
+                log(f'[bench] mixed-precision (bf16) companion: warm-up {time.perf_counter() - tw:.1f} s')
+            ts2.batch_idx = 0
+            barrier()
+            t1 = time.perf_counter()
+            lp_phases = {}
+            for _ in range(args.lowp_steps):
+                for name in ts2.step():
+                    lp_phases[name] = lp_phases.get(name, 0) + 1
+            barrier()
+            t_l = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+            if world > 1:
+                torch.distributed.all_reduce(t_l, op=torch.distributed.ReduceOp.MAX)
+            lowpc = dict(value=global_batch * args.frames * args.lowp_steps / float(t_l.item()), ms_per_step=1e3 * float(t_l.item()) / args.lowp_steps, steps=args.lowp_steps,
+                         dtype='bf16 (blocks >= 32^2; f32 accumulate, f32 master weights, f32 weight gradients)', phases_run=lp_phases,
+                         what='config 3 with num_fp16_res=4, conv_clamp=256 (train.py:173-174) and bf16 as the 16-bit format: 16-bit tensor I/O on the hand-written '
+                              'convolution / FIR / bias_act kernels; parity at the stated 16-bit tolerance 1e-2 (tests/test_conv_lowp_gpu.py)')
+        finally:
+            del ts2
+            torch.cuda.empty_cache()
+
     F32_LABEL = 'f32' if conv2d_gradfix.native_conv_terms == 0 and conv2d_gradfix.native_wrw_terms == 0 else \
         'fp32 I/O + fp32 accumulate everywhere; 3x3 convolution products are 2-way-bf16-split (hi/lo, 3 MFMAs per product: 16-bit mantissa operands, 4e-6 rel. error vs fp64; NOT strict fp32 -- see value_strict_fp32)'
     if rank == 0:
@@ -567,6 +601,7 @@ def main():
                                native_launches_per_step=launches / args.steps, hip_graphs=bool(ts.use_graphs)),
                    value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof,
                    value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
+                   value_lowp_bf16=lowpc['value'] if lowpc else None, lowp_bf16=lowpc,
                    roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, upfirdn2d_by_size=ufd_by_size, kernels=kernels, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -193,6 +193,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
         if (io16(dtype)) {
             hipLaunchKernelGGL(g_ws_kernels_io[dtype == SGV_F16][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
             sgv_note_variant(SGV_V_conv_lowp);
+            if (pro || epi) sgv_note_variant(SGV_V_conv_s1_ws_fused);
             return sgv_check_launch("conv3x3_ws_kernel (16-bit tensors)");
         }
         hipLaunchKernelGGL(g_ws_kernels[p->terms == 3][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);

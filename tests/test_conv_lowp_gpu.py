@@ -270,11 +270,32 @@ def _rel_l2(got, ref):
     return ((got - ref).norm() / ref.norm()).item()
 
 
-def _lrelu_layer_f64(x, w, s, d, b, stride):
+def _lrelu_layer_f64(x, w, s, d, b, stride, positive=None):
+    """float64 layer.  `positive` (bool, the output's shape): use THIS sign pattern for the leaky relu instead of the pre-activation's own -- the gradient
+    reference: a 16-bit evaluation flips the sign of the few pre-activations that lie within its rounding error of zero, and the backward pass of any
+    implementation (the reference's fp16 one included: bias_act.py:185 masks with the stored output) then follows its own forward pattern."""
     x = x * s[:, :, None, None] if s is not None else x
     y = torch.nn.functional.conv2d(x, w, padding=1 if stride == 1 else 0, stride=stride)
     y = y * d[:, :, None, None] if d is not None else y
-    return torch.nn.functional.leaky_relu(y + b[None, :, None, None], 0.2) * np.sqrt(2)
+    y = y + b[None, :, None, None]
+    positive = y > 0 if positive is None else positive
+    return torch.where(positive, y, 0.2 * y) * np.sqrt(2)
+
+
+def _check_layer(name, y, grads, ins, dy, s6d6, stride):
+    """Forward against the float64 layer; gradients against the float64 layer differentiated on the kernel's own sign pattern; the patterns themselves
+    differ in < 0.5 % of the elements.  Stated 16-bit tolerance: 1e-2 (rel-L2)."""
+    ins64 = [t.detach().double().requires_grad_(True) for t in ins]
+    x6, w6, b6 = ins64[:3]
+    s6, d6 = (ins64[3], ins64[4]) if s6d6 else (None, None)
+    y6 = _lrelu_layer_f64(x6, w6, s6, d6, b6, stride)
+    flips = ((y > 0) != (y6 > 0)).float().mean().item()
+    ym = _lrelu_layer_f64(x6, w6, s6, d6, b6, stride, positive=(y > 0))
+    grads6 = torch.autograd.grad(ym, ins64, dy.double())
+    errs = [_rel_l2(y, y6)] + [_rel_l2(a, r_) for a, r_ in zip(grads, grads6)]
+    print(f'[{name}] rel-L2 of y and of the gradients (x, w, b, ...):', ' '.join(f'{e:.1e}' for e in errs), f'| sign flips {flips:.1e}')
+    assert max(errs) < 1e-2 and flips < 5e-3
+    return y6
 
 
 @pytest.mark.parametrize('dtype', DTYPES)
@@ -297,14 +318,7 @@ def test_fused_stride1_layer_on_16bit_activations(dtype, modulated):
     dy = torch.randn(y.shape, generator=g).to(DEV).to(dtype)
     grads = torch.autograd.grad(y, ins, dy)
     assert grads[0].dtype == dtype and all(t.dtype == torch.float32 for t in grads[1:])
-    ins64 = [t.detach().double().requires_grad_(True) for t in ins]
-    x6, w6, b6 = ins64[:3]
-    s6, d6 = (ins64[3], ins64[4]) if modulated else (None, None)
-    y6 = _lrelu_layer_f64(x6, w6, s6, d6, b6, 1)
-    grads6 = torch.autograd.grad(y6, ins64, dy.double())
-    errs = [_rel_l2(y, y6)] + [_rel_l2(a, r_) for a, r_ in zip(grads, grads6)]
-    print(f'[{dtype} fused s1 layer, modulated={modulated}] rel-L2 of y, dx, dw, db{", ds, dd" if modulated else ""}:', ' '.join(f'{e:.1e}' for e in errs))
-    assert max(errs) < 1e-2    # stated 16-bit tolerance (2^-9 per operand / stored intermediate, a handful of lrelu sign flips at the kink)
+    y6 = _check_layer(f'{dtype} fused s1 layer, modulated={modulated}', y, grads, ins, dy, modulated, 1)
     # and no further from float64 than the same layer evaluated op by op in the tensor format
     with fused_conv_act.composition_only():
         yc = fused_conv_act.conv3x3_bias_act(x, w, styles=s, dcoefs=d, bias=b, act='lrelu')
@@ -327,11 +341,6 @@ def test_fused_downsampling_layer_on_16bit_activations(dtype):
     dy = torch.randn(y.shape, generator=g).to(DEV).to(dtype)
     grads = torch.autograd.grad(y, [xb, w, b], dy)
     assert grads[0].dtype == dtype and grads[1].dtype == torch.float32
-    ins64 = [t.detach().double().requires_grad_(True) for t in (xb, w, b)]
-    y6 = _lrelu_layer_f64(ins64[0], ins64[1], None, None, ins64[2], 2)
-    grads6 = torch.autograd.grad(y6, ins64, dy.double())
-    errs = [_rel_l2(y, y6)] + [_rel_l2(a, r_) for a, r_ in zip(grads, grads6)]
-    print(f'[{dtype} fused down layer] rel-L2 of y, dx, dw, db:', ' '.join(f'{e:.1e}' for e in errs))
-    assert max(errs) < 1e-2
+    _check_layer(f'{dtype} fused down layer', y, grads, [xb, w, b], dy, False, 2)
     after2 = custom_ops.kernel_variant_counts()
     assert after2.get('convT_lowp', 0) == after.get('convT_lowp', 0) + 1 and after2.get('wrw_s2_lowp', 0) == after.get('wrw_s2_lowp', 0) + 1
