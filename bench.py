@@ -341,14 +341,18 @@ def main():
     launches = custom_ops.launch_count() - launches0
     prof = None
     ufd_by_size = None
+    by_variant = None
     if not args.no_prof:
         custom_ops.prof_disable()
-        records = custom_ops.prof_collect_records(1 << 17)
+        records = custom_ops.prof_collect_records(1 << 17, with_variant=True)
         prof = {name: dict(launches=0, ms=0.0, bytes=0.0, flops=0.0) for name in custom_ops.SGV_K_NAMES}
         sizes = {}
-        for fam, ms, nbytes, nflops in records:
+        by_variant = {}
+        for fam, ms, nbytes, nflops, variant in records:
             e = prof[fam]
             e['launches'] += 1; e['ms'] += ms; e['bytes'] += nbytes; e['flops'] += nflops
+            v = by_variant.setdefault(variant or fam, dict(launches=0, ms=0.0, bytes=0.0, flops=0.0))
+            v['launches'] += 1; v['ms'] += ms; v['bytes'] += nbytes; v['flops'] += nflops
             if fam == 'upfirdn2d_lanes':
                 g = sizes.setdefault(int(nbytes), [0, 0.0])
                 g[0] += 1; g[1] += ms
@@ -587,6 +591,22 @@ def main():
                 roofline = dict(kernel=dom, bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS, traffic=None, launches=e['launches'])
             else:
                 roofline = roofline_ufd
+        # the same sample by kernel variant (which member of a family a call took; a call = the kernel + its auxiliary launches): TFLOP/s against the
+        # split-bf16 ceiling for the matrix-pipe members, GB/s against HBM for the streams
+        variants = None
+        if by_variant:
+            total_ms = sum(v['ms'] for v in by_variant.values())
+            variants = {}
+            for name, v in sorted(by_variant.items(), key=lambda kv: -kv[1]['ms']):
+                row = dict(launches=v['launches'], ms_per_step=v['ms'] / max(args.steps - prof_from, 1), avg_us=1e3 * v['ms'] / v['launches'], share_of_native_time=v['ms'] / total_ms)
+                if v['flops'] > 0:
+                    row['TFLOPs'] = v['flops'] / (v['ms'] * 1e-3) / 1e12
+                    if name.startswith(('conv_', 'convT_', 'wrw_')):
+                        one_term = name.endswith('_lowp') or conv2d_gradfix.native_conv_terms == 1
+                        row['frac_of_ceiling'] = row['TFLOPs'] / (MFMA_BF16_PEAK_TFLOPS if one_term else MFMA_BF16_PEAK_TFLOPS / 3)
+                if v['bytes'] > 0:
+                    row['GBps'] = v['bytes'] / (v['ms'] * 1e-3) / 1e9
+                variants[name] = row
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
             log('[bench] timing the CPU baseline leg ...')
@@ -602,7 +622,7 @@ def main():
                    value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof,
                    value_strict_fp32=strict['value'] if strict else (value if default_terms == (0, 0) and lowp is None else None), strict_fp32=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
                    value_lowp_bf16=lowpc['value'] if lowpc else None, lowp_bf16=lowpc,
-                   roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, upfirdn2d_by_size=ufd_by_size, kernels=kernels, cpu_baseline=cpu)
+                   roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, upfirdn2d_by_size=ufd_by_size, kernels=kernels, kernels_by_variant=variants, cpu_baseline=cpu)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

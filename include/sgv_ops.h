@@ -481,8 +481,10 @@ int sgv_prof_collect(sgv_prof_entry* out /* [SGV_K_COUNT] */); /* syncs events, 
 /* The same, launch by launch (in launch order) instead of summed per family: fills at most `max_records` entries, returns the number of recorded
  * launches (which may exceed max_records), or a negative SGV_ERR_* code.  Resets the pool like sgv_prof_collect. */
 typedef struct sgv_prof_record {
-    int32_t family; /* enum sgv_kernel_family */
-    float ms;
+    int32_t family;  /* enum sgv_kernel_family */
+    int32_t variant; /* index into sgv_variant_name(): the kernel variant the call took (the first one it noted), or -1 */
+    float ms;        /* the whole call: auxiliary launches (weight preparation, edge strips, memset) included */
+    float reserved;
     double bytes, flops;
 } sgv_prof_record;
 int sgv_prof_collect_records(sgv_prof_record* out, int32_t max_records);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_ws_kernel(s2_params p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // image 0 ready
         for (int q = 0; q < total; q++) {
-            if (q + 1 < total && ABL != 2 && ABL != 7) dma_w(q + 1, lds + ((q + 1) & 1) * S2W_IMAGE_WORDS);
+            if (q + 1 < total && ABL != 2 && (ABL != 7 && ABL != 10)) dma_w(q + 1, lds + ((q + 1) & 1) * S2W_IMAGE_WORDS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -143,11 +143,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_ws_kernel(s2_params p) {
             }
         };
         auto step = [&](int q, xset& ld, xset& st) {
-            const bool more = q + 2 < total && ABL != 3 && ABL != 7;
+            const bool more = q + 2 < total && ABL != 3 && (ABL != 7 && ABL != 10);
             if (more) load_x(q + 2, ld);
             if (q + 1 < total) {
                 arrive(st, more);
-                if (ABL != 5 && ABL != 7) store_x(lds + ((q + 1) & 1) * S2W_IMAGE_WORDS, st);
+                if (ABL != 5 && (ABL != 7 && ABL != 10)) store_x(lds + ((q + 1) & 1) * S2W_IMAGE_WORDS, st);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_ws_kernel(s2_params p) {
 
         xset s0, s1;
         load_x(0, s0);
-        if (total > 1 && ABL != 3 && ABL != 7) load_x(1, s1);
-        arrive(s0, total > 1 && ABL != 3 && ABL != 7);
+        if (total > 1 && ABL != 3 && (ABL != 7 && ABL != 10)) load_x(1, s1);
+        arrive(s0, total > 1 && ABL != 3 && (ABL != 7 && ABL != 10));
         store_x(lds, s0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // image 0 ready
@@ -328,7 +328,7 @@ struct s2_epilogue {
     int accumulate;          // y += a instead of y = a
 };
 
-// ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
+// ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it, 8 the full kernel without its stores, 10 = 7 + 8.
 // IO: element format of x / y / act_out (sgv_io16.h: 0 fp32, 1 bf16, 2 fp16; 16-bit tensors with TERMS = 1 and without `accumulate`) -- same number of
 // load instructions (dwordx2 at 2-byte aligned addresses instead of dwordx4 at 4-byte aligned ones), so the counted waits are those of the fp32 form.
 template <int TERMS, int ABL = 0, int EPI = 0, int S = 1, int IO = 0>
@@ -367,11 +367,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const u32x4*)(ep.bias + tp.mt * P2_TM) + lane),
                                                  (__attribute__((address_space(3))) void*)(wl + P2_WS_WORDS), 16, 0, 0);
         };
-        if (ABL != 7) dma_w(0, lds);
+        if ((ABL != 7 && ABL != 10)) dma_w(0, lds);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // image 0 ready
         for (int q = 0; q < total; q++) {
-            if (q + 1 < total && ABL != 7) dma_w(q + 1, lds + ((q + 1) & 1) * P2_IMAGE_WORDS);
+            if (q + 1 < total && (ABL != 7 && ABL != 10)) dma_w(q + 1, lds + ((q + 1) & 1) * P2_IMAGE_WORDS);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -436,11 +436,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             }
         };
         auto step = [&](int q, xset& ld, xset& st) {
-            const bool more = q + 2 < total && ABL != 7;
+            const bool more = q + 2 < total && (ABL != 7 && ABL != 10);
             if (more) load_x(q + 2, ld);
             if (q + 1 < total) {
                 arrive(st, more);
-                if (ABL != 7) store_x(lds + ((q + 1) & 1) * P2_IMAGE_WORDS, st);
+                if ((ABL != 7 && ABL != 10)) store_x(lds + ((q + 1) & 1) * P2_IMAGE_WORDS, st);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -448,8 +448,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
 
         xset s0, s1;
         load_x(0, s0);
-        if (total > 1 && ABL != 7) load_x(1, s1);
-        arrive(s0, total > 1 && ABL != 7);
+        if (total > 1 && (ABL != 7 && ABL != 10)) load_x(1, s1);
+        arrive(s0, total > 1 && (ABL != 7 && ABL != 10));
         store_x(lds, s0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // image 0 ready
@@ -572,7 +572,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
                                     if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
                                     if (ep.act_out) out_store<IO>(ep.act_out, off0 + idx, v);
                                 }
-                                if (IO == 0 && EPI == 1 && ep.accumulate) atomicAdd(p.y + off0 + idx, v); else out_store<IO>(p.y, off0 + idx, v);
+                                if (ABL == 8 || ABL == 10) asm volatile("" :: "v"(v));   // lab: no stores
+                                else if (IO == 0 && EPI == 1 && ep.accumulate) atomicAdd(p.y + off0 + idx, v); else out_store<IO>(p.y, off0 + idx, v);
                                 acc[r][mq][4 * e4 + ei] = 0.f;
                             }
                     }
@@ -623,7 +624,9 @@ __device__ __forceinline__ tile_pos decode_tile_tw(const s2_params& p, int tile)
     return tp;
 }
 
-// ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it.
+// ABL (lab only): 6 consumers only keep the barrier protocol, 7 producers and DMA only keep it, 8 the full kernel without its stores, 10 = 7 + 8
+// (profiles/r03_s2_lab_store_burst.log: the tile-end stores cost the 64 <- 128 channel layer 21 %, and pairing the even / odd columns into one 8-byte store
+// or starting the workgroups staggered changes nothing -- the burst is HBM-write bound, 128 KiB per CU and tile at ~11 B/clk/CU).
 // IO: element format of x / y (sgv_io16.h; 16-bit tensors with TERMS = 1): 8-byte aligned dwordx2 loads, two 2-byte stores per accumulator pair.
 template <int TERMS, int ABL = 0, int S = 1, int IO = 0>
 __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
@@ -656,11 +659,11 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wq + j * 64),
                                                  (__attribute__((address_space(3))) void*)(wl + j * 64), 16, 0, 0);
         };
-        if (ABL != 7) { dma_w(0); if (total > 1) dma_w(1); }
-        if (total > 1 && ABL != 7) asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((ABL != 7 && ABL != 10)) { dma_w(0); if (total > 1) dma_w(1); }
+        if (total > 1 && (ABL != 7 && ABL != 10)) asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // image 0 ready
         for (int q = 0; q < total; q++) {
-            const bool more = q + 2 < total && ABL != 7;
+            const bool more = q + 2 < total && (ABL != 7 && ABL != 10);
             if (more) dma_w(q + 2);
             // chunk q+1 (issued one iteration ago) must have landed before this barrier; the 36 pieces just issued may stay in flight
             if (more) asm volatile("s_waitcnt vmcnt(36)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -723,11 +726,11 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
         };
         // iteration q: start the loads of chunk q+3, write chunk q+2 (loaded an iteration ago) into image (q+2) % 3
         auto step = [&](int q, xset& ld, xset& st) {
-            const bool more = q + 3 < total && ABL != 7;
+            const bool more = q + 3 < total && (ABL != 7 && ABL != 10);
             if (more) load_x(q + 3, ld);
             if (q + 2 < total) {
                 arrive(st, more);
-                if (ABL != 7) store_x(image(q + 2), st);
+                if ((ABL != 7 && ABL != 10)) store_x(image(q + 2), st);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -738,8 +741,8 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
         if (total > 1) load_x(1, s1);
         arrive(s0, total > 1);
         store_x(image(0), s0);
-        if (total > 2 && ABL != 7) load_x(2, s0);
-        if (total > 1) { arrive(s1, total > 2 && ABL != 7); store_x(image(1), s1); }
+        if (total > 2 && (ABL != 7 && ABL != 10)) load_x(2, s0);
+        if (total > 1) { arrive(s1, total > 2 && (ABL != 7 && ABL != 10)); store_x(image(1), s1); }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // images 0 and 1 ready
         // chunk q+2 sits in s0 for even q, s1 for odd q
@@ -829,8 +832,11 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
                     for (int e = 0; e < 16; e++) {
                         const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
                         const size_t qd = yb + (size_t)m * plane_out + (size_t)a2 * wout;
-                        out_store<IO>(p.y, qd, acc[a2 * 2 + 0][hf][e]);
-                        out_store<IO>(p.y, qd + 1, acc[a2 * 2 + 1][hf][e]);
+                        if (ABL == 8 || ABL == 10) { asm volatile("" :: "v"(acc[a2 * 2 + 0][hf][e])); asm volatile("" :: "v"(acc[a2 * 2 + 1][hf][e])); }   // lab: no stores
+                        else {
+                            out_store<IO>(p.y, qd, acc[a2 * 2 + 0][hf][e]);
+                            out_store<IO>(p.y, qd + 1, acc[a2 * 2 + 1][hf][e]);
+                        }
                         acc[a2 * 2 + 0][hf][e] = 0.f;
                         acc[a2 * 2 + 1][hf][e] = 0.f;
                     }

@@ -26,7 +26,13 @@ static const char* const g_variant_names[SGV_V_COUNT] = {
     SGV_VARIANTS(SGV_V_NAME)
 #undef SGV_V_NAME
 };
-void sgv_note_variant(int v) { if (v >= 0 && v < SGV_V_COUNT) g_variants[v].fetch_add(1, std::memory_order_relaxed); }
+static thread_local int g_scope_slot = -1;   // profiler record of the sgv_launch_scope that is open on this thread, if any
+static void prof_note_variant(int v);
+void sgv_note_variant(int v) {
+    if (v < 0 || v >= SGV_V_COUNT) return;
+    g_variants[v].fetch_add(1, std::memory_order_relaxed);
+    prof_note_variant(v);
+}
 extern "C" int64_t sgv_variant_count(int32_t v) { return (v >= 0 && v < SGV_V_COUNT) ? g_variants[v].load() : -1; }
 extern "C" const char* sgv_variant_name(int32_t v) { return (v >= 0 && v < SGV_V_COUNT) ? g_variant_names[v] : nullptr; }
 
@@ -35,7 +41,7 @@ extern "C" const char* sgv_variant_name(int32_t v) { return (v >= 0 && v < SGV_V
 
 struct prof_record {
     hipEvent_t start, stop;
-    int family;
+    int family, variant;
     double bytes, flops;
 };
 
@@ -43,6 +49,10 @@ static std::mutex g_prof_mu;
 static std::vector<prof_record> g_prof_pool;
 static std::atomic<int> g_prof_next{0};
 static std::atomic<bool> g_prof_on{false};
+static void prof_note_variant(int v) {
+    const int i = g_scope_slot;
+    if (i >= 0 && i < (int)g_prof_pool.size() && g_prof_pool[i].variant < 0) g_prof_pool[i].variant = v;   // the first note of a call names it
+}
 
 extern "C" int sgv_prof_enable(int32_t max_records) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -94,7 +104,7 @@ extern "C" int sgv_prof_collect_records(sgv_prof_record* out, int32_t max_record
         if (hipEventSynchronize(r.stop) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_collect_records: event sync failed");
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) ms = 0.f;
-        if (i < max_records) out[i] = sgv_prof_record{r.family, ms, r.bytes, r.flops};
+        if (i < max_records) out[i] = sgv_prof_record{r.family, r.variant, ms, 0.f, r.bytes, r.flops};
     }
     g_prof_next = 0;
     return n;
@@ -107,12 +117,14 @@ sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, doub
     if (i >= (int)g_prof_pool.size()) return;  // pool exhausted: launch is simply not recorded
     prof_record& r = g_prof_pool[i];
     r.family = family;
+    r.variant = -1;
     r.bytes = bytes;
     r.flops = flops;
     slot = i;
+    g_scope_slot = i;
     (void)hipEventRecord(r.start, stream);
 }
 
 sgv_launch_scope::~sgv_launch_scope() {
-    if (slot >= 0) (void)hipEventRecord(g_prof_pool[slot].stop, stream);
+    if (slot >= 0) { (void)hipEventRecord(g_prof_pool[slot].stop, stream); g_scope_slot = -1; }
 }

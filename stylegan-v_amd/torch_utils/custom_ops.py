@@ -238,7 +238,7 @@ class FcParams(ctypes.Structure):
 
 
 class ProfRecord(ctypes.Structure):
-    _fields_ = [('family', c_int32), ('ms', c_float), ('bytes', c_double), ('flops', c_double)]
+    _fields_ = [('family', c_int32), ('variant', c_int32), ('ms', c_float), ('reserved', c_float), ('bytes', c_double), ('flops', c_double)]
 
 
 class ProfEntry(ctypes.Structure):
@@ -367,13 +367,23 @@ def prof_disable():
     check(get_native().sgv_prof_disable())
 
 
-def prof_collect_records(max_records=1 << 16):
-    """[(family name, ms, algorithmic bytes, algorithmic flops)] per recorded launch, in launch order (resets the pool)."""
+def prof_collect_records(max_records=1 << 16, with_variant=False):
+    """[(family name, ms, algorithmic bytes, algorithmic flops)] per recorded call, in launch order (resets the pool); ``with_variant``: a fifth
+    element, the name of the kernel variant the call took (None where the family has no variants)."""
     recs = (ProfRecord * max_records)()
-    n = get_native().sgv_prof_collect_records(recs, max_records)
+    lib = get_native()
+    n = lib.sgv_prof_collect_records(recs, max_records)
     if n < 0:
         check(n)
-    return [(SGV_K_NAMES[r.family], float(r.ms), float(r.bytes), float(r.flops)) for r in recs[:min(n, max_records)]]
+    if not with_variant:
+        return [(SGV_K_NAMES[r.family], float(r.ms), float(r.bytes), float(r.flops)) for r in recs[:min(n, max_records)]]
+    names = {}
+    def vname(v):
+        if v not in names:
+            p = lib.sgv_variant_name(v) if v >= 0 else None
+            names[v] = p.decode() if p else None
+        return names[v]
+    return [(SGV_K_NAMES[r.family], float(r.ms), float(r.bytes), float(r.flops), vname(int(r.variant))) for r in recs[:min(n, max_records)]]
 
 
 def prof_collect():

@@ -58,8 +58,8 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
 #define SGV_ATTR(A) CK(hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<1, A>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<3, A>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES));
 #define SGV_ATTR2(A) CK(hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, A>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3, A>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES));
 #define SGV_ATTR3(A) CK(hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1, A>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES)); CK(hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<3, A>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES));
-        SGV_ATTR3(0) SGV_ATTR3(6) SGV_ATTR3(7)
-        SGV_ATTR2(0) SGV_ATTR2(6) SGV_ATTR2(7)
+        SGV_ATTR3(0) SGV_ATTR3(6) SGV_ATTR3(7) SGV_ATTR3(8) SGV_ATTR3(10)
+        SGV_ATTR2(0) SGV_ATTR2(6) SGV_ATTR2(7) SGV_ATTR2(8) SGV_ATTR2(10)
         SGV_ATTR(0) SGV_ATTR(1) SGV_ATTR(2) SGV_ATTR(3) SGV_ATTR(4) SGV_ATTR(5) SGV_ATTR(6) SGV_ATTR(7)
         attr = true;
     }
@@ -72,6 +72,8 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
             case 0: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 0>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p, s2_epilogue{}); break;
             case 6: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 6>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p, s2_epilogue{}); break;
             case 7: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 7>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p, s2_epilogue{}); break;
+            case 8: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 8>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p, s2_epilogue{}); break;
+            case 10: hipLaunchKernelGGL((conv3x3_s2_pairs_kernel<TERMS, 10>), dim3(p.grid), dim3(512), P2_LDS_BYTES, 0, p, s2_epilogue{}); break;
         }
         return;
     }
@@ -98,6 +100,8 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
         switch (g_abl) {
             case 6: hipLaunchKernelGGL((convT3x3_s2_ws_kernel<TERMS, 6>), dim3(p.grid), dim3(448), TW_LDS_BYTES, 0, p); break;
             case 7: hipLaunchKernelGGL((convT3x3_s2_ws_kernel<TERMS, 7>), dim3(p.grid), dim3(448), TW_LDS_BYTES, 0, p); break;
+            case 8: hipLaunchKernelGGL((convT3x3_s2_ws_kernel<TERMS, 8>), dim3(p.grid), dim3(448), TW_LDS_BYTES, 0, p); break;
+            case 10: hipLaunchKernelGGL((convT3x3_s2_ws_kernel<TERMS, 10>), dim3(p.grid), dim3(448), TW_LDS_BYTES, 0, p); break;
             default: hipLaunchKernelGGL((convT3x3_s2_ws_kernel<TERMS, 0>), dim3(p.grid), dim3(448), TW_LDS_BYTES, 0, p); break;
         }
     }
@@ -109,8 +113,8 @@ template <int TERMS> static void launch(int kind, const float* x, const float* w
             static float* e2 = nullptr; static size_t e2_cap = 0;
             const size_t prep = convT3x3_s2_edge_we_floats(k, m) + (size_t)n * k * h;
             if (prep > e2_cap) { if (e2) CK(hipFree(e2)); CK(hipMalloc(&e2, prep * 4)); e2_cap = prep; }
-            hipLaunchKernelGGL(convT3x3_s2_edge_prep, dim3((prep + 255) / 256), dim3(256), 0, 0, x, w, e2, n, k, m, h, wd);
-            hipLaunchKernelGGL(convT3x3_s2_edge_mfma, dim3(((h > wd ? h : wd) + 1 + 31) / 32, n * (m / 32), 2), dim3(64), 0, 0, x, e2, y, n, k, m, h, wd);
+            hipLaunchKernelGGL(convT3x3_s2_edge_prep<0>, dim3((prep + 255) / 256), dim3(256), 0, 0, x, w, e2, n, k, m, h, wd);
+            hipLaunchKernelGGL(convT3x3_s2_edge_mfma<0>, dim3(((h > wd ? h : wd) + 1 + 31) / 32, n * (m / 32), 2), dim3(64), 0, 0, x, e2, y, n, k, m, h, wd);
             return;
         }
         static float* edge = nullptr; static size_t edge_cap = 0;
