@@ -221,6 +221,8 @@ class _FusedConvActFirFn(torch.autograd.Function):
         from . import upfirdn2d as _ufd
         act, alpha, gain, clamp, pads = ctx.cfg
         x, weight, b, f, y0 = ctx.saved_tensors
+        if g is None:   # only the alias was used downstream (also under create_graph: there is nothing of this layer to differentiate)
+            return (g_alias if ctx.needs_input_grad[0] else None), None, None, None, None
         if torch.is_grad_enabled():
             ins = [t for t, need in zip((x, weight, b), ctx.needs_input_grad[:3]) if need and t is not None]
             with torch.enable_grad():
@@ -230,8 +232,6 @@ class _FusedConvActFirFn(torch.autograd.Function):
             if g_alias is not None and ctx.needs_input_grad[0]:
                 out[0] = g_alias if out[0] is None else out[0] + g_alias
             return tuple(out) + (None, None)
-        if g is None:   # only the alias was used downstream
-            return (g_alias if ctx.needs_input_grad[0] else None), None, None, None, None
         lib = custom_ops.get_native()
         g = g.contiguous()
         n, co, h, w = y0.shape
@@ -265,7 +265,11 @@ class _FusedConvActFirFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             tcfg = (True, (1, 1), (1, 1), (0, 0), (1, 1), 1)
             ci = x.shape[1]
+            # In-place use of an incoming gradient: only a tensor that is plainly this node's to consume -- no autograd history (a recorded backward took
+            # the create_graph branch above), not a view into somebody else's storage.  A hook or `retain_grad()` on the alias output would still see
+            # the sum instead of the skip branch's gradient; SGV_ALIAS_ACC=0 restores the out-of-place add for such uses.
             if (accumulate_input_gradients and g_alias is not None and g_alias.is_contiguous() and g_alias.dtype == torch.float32 and dt == 0 and _cg.native_conv_terms in (1, 3)
+                    and not g_alias.requires_grad and g_alias._base is None
                     and lib.sgv_conv3x3_fused_supported(n, co, ci, h, w, 0)):
                 # the data gradient lands IN the gradient the skip branch produced (one fp32 add per element in the convolution's store)
                 d_x = _launch_fused(dz, wc, None, None, None, 1, 0.0, 1.0, -1.0, mode=1, accumulate_into=g_alias)

@@ -5,7 +5,7 @@ import torch.nn.functional as F
 
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
-from util import assert_close
+from util import assert_close, dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -24,11 +24,11 @@ def test_conv3x3_matches_fp64(n, ci, co, h, w, transposed):
     x = (torch.randn([n, ci, h, w], generator=g) + 0.3).to(DEV)
     wt = (torch.randn([ci, co, 3, 3] if transposed else [co, ci, 3, 3], generator=g) / (3 * ci ** 0.5)).to(DEV)
     cfg = (transposed, (1, 1), (1, 1), (0, 0), (1, 1), 1)
-    assert conv2d_gradfix._native_conv_ok(x, wt, cfg)
+    dispatch_assert(conv2d_gradfix._native_conv_ok(x, wt, cfg))
     custom_ops.prof_enable(16)
     y = (conv2d_gradfix.conv_transpose2d if transposed else conv2d_gradfix.conv2d)(x.requires_grad_(True), wt, padding=1)
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv3x3']['launches'] == 1
+    dispatch_assert(custom_ops.prof_collect()['conv3x3']['launches'] == 1)
     ref = (F.conv_transpose2d if transposed else F.conv2d)(x.detach().double().cpu(), wt.double().cpu(), padding=1)
     lib = (F.conv_transpose2d if transposed else F.conv2d)(x.detach(), wt, padding=1)
     l2, mx = _rel(y, ref)
@@ -57,7 +57,7 @@ def test_conv3x3_gradients_first_and_second_order():
     got = run(conv2d_gradfix.conv2d, x, w)
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
-    assert prof['conv3x3']['launches'] >= 4   # forward, dx, and the convolutions inside the double backward
+    dispatch_assert(prof['conv3x3']['launches'] >= 4)   # forward, dx, and the convolutions inside the double backward
     want = run(F.conv2d, xr, wr)
     for a, r, name in zip(got, want, ['y', 'dx', 'dw', 'd2x', 'd2w']):
         assert_close(a, r, atol=3e-5 * r.abs().max().item(), rtol=1e-4, what=name)
@@ -100,12 +100,12 @@ def test_conv3x3_stride2_family_matches_fp64(n, cb, cs, h, w, transposed):
         if cs % 64:
             pytest.skip('c_out % 64')
     cfg = (transposed, (2, 2), (0, 0), (0, 0), (1, 1), 1)
-    assert conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2'
+    dispatch_assert(conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2')
     op, ref_op = (conv2d_gradfix.conv_transpose2d, F.conv_transpose2d) if transposed else (conv2d_gradfix.conv2d, F.conv2d)
     custom_ops.prof_enable(16)
     y = op(x.requires_grad_(True), wt, stride=2)
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv3x3']['launches'] == 1
+    dispatch_assert(custom_ops.prof_collect()['conv3x3']['launches'] == 1)
     ref = ref_op(x.detach().double().cpu(), wt.double().cpu(), stride=2)
     assert y.shape == ref.shape
     l2, mx = _rel(y, ref)
@@ -125,7 +125,7 @@ def test_transposed_stride2_on_small_images_packs_samples(n, ci, co, h, w):
     x = (torch.randn([n, ci, h, w], generator=g) + 0.3).to(DEV)
     wt = (torch.randn([ci, co, 3, 3], generator=g) / (3 * ci ** 0.5)).to(DEV)
     cfg = (True, (2, 2), (0, 0), (0, 0), (1, 1), 1)
-    assert conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2'
+    dispatch_assert(conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2')
     y = conv2d_gradfix._native_conv(x, wt, cfg)
     ref = F.conv_transpose2d(x.double().cpu(), wt.double().cpu(), stride=2)
     assert y.shape == ref.shape
@@ -149,7 +149,7 @@ def test_strided_stride2_on_small_images_packs_samples(n, ci, co, h, w):
     x = (torch.randn([n, ci, 2 * h + 1, 2 * w + 1], generator=g) + 0.3).to(DEV)
     wt = (torch.randn([co, ci, 3, 3], generator=g) / (3 * ci ** 0.5)).to(DEV)
     cfg = (False, (2, 2), (0, 0), (0, 0), (1, 1), 1)
-    assert conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2'
+    dispatch_assert(conv2d_gradfix._native_conv_kind(x, wt, cfg) == 's2')
     y = conv2d_gradfix._native_conv(x, wt, cfg)
     ref = F.conv2d(x.double().cpu(), wt.double().cpu(), stride=2)
     assert y.shape == ref.shape
@@ -178,7 +178,7 @@ def test_conv3x3_stride2_gradients_first_and_second_order():
     custom_ops.prof_enable(256)
     got = run(conv2d_gradfix.conv2d, x, w)
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv3x3']['launches'] >= 4
+    dispatch_assert(custom_ops.prof_collect()['conv3x3']['launches'] >= 4)
     want = run(F.conv2d, xr, wr)
     for a, r, name in zip(got, want, ['y', 'dx', 'dw', 'd2x', 'd2w']):
         assert_close(a, r, atol=3e-5 * r.abs().max().item(), rtol=1e-4, what=name)
@@ -200,7 +200,7 @@ def test_conv3x3_family_vs_oracle(stride, transposed):
     gw, = torch.autograd.grad(y, [wg], dy.to(DEV))
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
-    assert prof['conv3x3']['launches'] == 1 and prof['conv_wrw']['launches'] == 1
+    dispatch_assert(prof['conv3x3']['launches'] == 1 and prof['conv_wrw']['launches'] == 1)
     for got, ref, what in ((y, oracle.conv3x3(x.numpy(), wt.numpy(), stride=stride, transposed=transposed), 'y'),
                            (gw, oracle.conv3x3_weight_grad(dy.numpy(), x.numpy(), stride=stride, transposed=transposed), 'dw')):
         l2, mx = _rel(got.detach(), torch.as_tensor(ref))
@@ -216,6 +216,6 @@ def test_native_kernels_also_serve_no_grad_passes():
         y = conv2d_gradfix.conv2d(x, w, padding=1)
         yt = conv2d_gradfix.conv_transpose2d(x, w, stride=2)
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv3x3']['launches'] == 2
+    dispatch_assert(custom_ops.prof_collect()['conv3x3']['launches'] == 2)
     assert_close(y, F.conv2d(x.double(), w.double(), padding=1), atol=2e-5 * 3, rtol=1e-4)
     assert_close(yt, F.conv_transpose2d(x.double(), w.double(), stride=2), atol=2e-5 * 3, rtol=1e-4)

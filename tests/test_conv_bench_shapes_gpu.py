@@ -24,6 +24,7 @@ import torch
 import oracle
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
+from util import dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -36,11 +37,11 @@ def _cfg(stride, transposed):
 
 def _run(x, w, stride, transposed):
     cfg = _cfg(stride, transposed)
-    assert conv2d_gradfix._native_conv_ok(x, w, cfg), 'the benchmark shape is not served by the hand-written kernel'
+    dispatch_assert(conv2d_gradfix._native_conv_ok(x, w, cfg), 'the benchmark shape is not served by the hand-written kernel')
     custom_ops.prof_enable(16)
     y = conv2d_gradfix._native_conv(x, w, cfg)
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv3x3']['launches'] == 1
+    dispatch_assert(custom_ops.prof_collect()['conv3x3']['launches'] == 1)
     return y
 
 
@@ -157,11 +158,11 @@ def _check_wrw(c_small, c_big, hs, stride, transposed, seed):
     cfg = _cfg(stride, transposed)
 
     def run(dy, x):
-        assert conv2d_gradfix._native_wrw_ok(dy, x, cfg, w_shape), 'the benchmark shape is not served by the hand-written kernel'
+        dispatch_assert(conv2d_gradfix._native_wrw_ok(dy, x, cfg, w_shape), 'the benchmark shape is not served by the hand-written kernel')
         custom_ops.prof_enable(16)
         dw = conv2d_gradfix._native_wrw(dy, x, cfg, w_shape)
         custom_ops.prof_disable()
-        assert custom_ops.prof_collect()['conv_wrw']['launches'] == 1
+        dispatch_assert(custom_ops.prof_collect()['conv_wrw']['launches'] == 1)
         return dw
 
     # (1) random data, sampled channel block

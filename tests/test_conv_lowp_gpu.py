@@ -20,6 +20,7 @@ import torch
 import oracle
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
+from util import dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -35,10 +36,10 @@ def _bf16(t):
 
 def _conv(x, w, transposed):
     cfg = S1T if transposed else S1
-    assert conv2d_gradfix._native_conv_ok(x, w, cfg), 'this 16-bit shape is not served by the hand-written kernel'
+    dispatch_assert(conv2d_gradfix._native_conv_ok(x, w, cfg), 'this 16-bit shape is not served by the hand-written kernel')
     before = custom_ops.kernel_variant_counts().get('conv_lowp', 0)
     y = conv2d_gradfix._native_conv(x, w, cfg)
-    assert custom_ops.kernel_variant_counts().get('conv_lowp', 0) == before + 1
+    dispatch_assert(custom_ops.kernel_variant_counts().get('conv_lowp', 0) == before + 1)
     assert y.dtype == x.dtype
     return y
 
@@ -80,10 +81,10 @@ def test_conv3x3_s1_weight_gradient_16bit_tensors(dtype, n, o, i, h, wd):
     shape = (o, i, 3, 3)
 
     def run(dy, x):
-        assert conv2d_gradfix._native_wrw_ok(dy, x, S1, shape), 'this 16-bit shape is not served by the hand-written kernel'
+        dispatch_assert(conv2d_gradfix._native_wrw_ok(dy, x, S1, shape), 'this 16-bit shape is not served by the hand-written kernel')
         before = custom_ops.kernel_variant_counts().get('wrw_lowp', 0)
         dw = conv2d_gradfix._native_wrw(dy, x, S1, shape)
-        assert custom_ops.kernel_variant_counts().get('wrw_lowp', 0) == before + 1
+        dispatch_assert(custom_ops.kernel_variant_counts().get('wrw_lowp', 0) == before + 1)
         assert dw.dtype == torch.float32
         return dw.double().cpu().numpy()
 
@@ -169,11 +170,11 @@ S2T = (True, (2, 2), (0, 0), (0, 0), (1, 1), 1)
 
 def _conv_s2(x, w, transposed):
     cfg = S2T if transposed else S2
-    assert conv2d_gradfix._native_conv_kind(x, w, cfg) == 's2', 'this 16-bit stride-2 shape is not served by the hand-written kernel'
+    dispatch_assert(conv2d_gradfix._native_conv_kind(x, w, cfg) == 's2', 'this 16-bit stride-2 shape is not served by the hand-written kernel')
     name = 'convT_lowp' if transposed else 'conv_s2_lowp'
     before = custom_ops.kernel_variant_counts().get(name, 0)
     y = conv2d_gradfix._native_conv(x, w, cfg)
-    assert custom_ops.kernel_variant_counts().get(name, 0) == before + 1
+    dispatch_assert(custom_ops.kernel_variant_counts().get(name, 0) == before + 1)
     assert y.dtype == x.dtype
     return y
 
@@ -222,10 +223,10 @@ def test_conv3x3_s2_weight_gradient_16bit_tensors(dtype, transposed, n, cs, cb, 
 
     def run(small, big):
         dy, x = (big, small) if transposed else (small, big)
-        assert conv2d_gradfix._native_wrw_kind(dy, x, cfg, shape) == 's2', 'this 16-bit stride-2 shape is not served by the hand-written kernel'
+        dispatch_assert(conv2d_gradfix._native_wrw_kind(dy, x, cfg, shape) == 's2', 'this 16-bit stride-2 shape is not served by the hand-written kernel')
         before = custom_ops.kernel_variant_counts().get('wrw_s2_lowp', 0)
         dw = conv2d_gradfix._native_wrw(dy, x, cfg, shape)
-        assert custom_ops.kernel_variant_counts().get('wrw_s2_lowp', 0) == before + 1
+        dispatch_assert(custom_ops.kernel_variant_counts().get('wrw_s2_lowp', 0) == before + 1)
         assert dw.dtype == torch.float32
         return dw.double().cpu().numpy()
 
@@ -313,7 +314,7 @@ def test_fused_stride1_layer_on_16bit_activations(dtype, modulated):
     before = custom_ops.kernel_variant_counts()
     y = fused_conv_act.conv3x3_bias_act(x, w, styles=s, dcoefs=d, bias=b, act='lrelu')
     after = custom_ops.kernel_variant_counts()
-    assert after.get('conv_s1_ws_fused', 0) == before.get('conv_s1_ws_fused', 0) + 1 and after.get('conv_lowp', 0) == before.get('conv_lowp', 0) + 1
+    dispatch_assert(after.get('conv_s1_ws_fused', 0) == before.get('conv_s1_ws_fused', 0) + 1 and after.get('conv_lowp', 0) == before.get('conv_lowp', 0) + 1)
     assert y.dtype == dtype
     dy = torch.randn(y.shape, generator=g).to(DEV).to(dtype)
     grads = torch.autograd.grad(y, ins, dy)
@@ -336,11 +337,11 @@ def test_fused_downsampling_layer_on_16bit_activations(dtype):
     before = custom_ops.kernel_variant_counts()
     y = fused_down_act.strided_conv3x3_bias_act(xb, w, bias=b, act='lrelu')
     after = custom_ops.kernel_variant_counts()
-    assert after.get('conv_s2_pairs_fused', 0) == before.get('conv_s2_pairs_fused', 0) + 1 and after.get('conv_s2_lowp', 0) == before.get('conv_s2_lowp', 0) + 1
+    dispatch_assert(after.get('conv_s2_pairs_fused', 0) == before.get('conv_s2_pairs_fused', 0) + 1 and after.get('conv_s2_lowp', 0) == before.get('conv_s2_lowp', 0) + 1)
     assert y.dtype == dtype
     dy = torch.randn(y.shape, generator=g).to(DEV).to(dtype)
     grads = torch.autograd.grad(y, [xb, w, b], dy)
     assert grads[0].dtype == dtype and grads[1].dtype == torch.float32
     _check_layer(f'{dtype} fused down layer', y, grads, [xb, w, b], dy, False, 2)
     after2 = custom_ops.kernel_variant_counts()
-    assert after2.get('convT_lowp', 0) == after.get('convT_lowp', 0) + 1 and after2.get('wrw_s2_lowp', 0) == after.get('wrw_s2_lowp', 0) + 1
+    dispatch_assert(after2.get('convT_lowp', 0) == after.get('convT_lowp', 0) + 1 and after2.get('wrw_s2_lowp', 0) == after.get('wrw_s2_lowp', 0) + 1)

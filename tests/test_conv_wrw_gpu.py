@@ -5,7 +5,7 @@ import torch.nn.functional as F
 
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
-from util import assert_close
+from util import assert_close, dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -23,7 +23,7 @@ def _native(dy, x, terms):
     old = conv2d_gradfix.native_wrw_terms
     conv2d_gradfix.native_wrw_terms = terms
     try:
-        assert conv2d_gradfix._native_wrw_ok(dy, x, (False, (1, 1), (1, 1), (0, 0), (1, 1), 1), (dy.shape[1], x.shape[1], 3, 3))
+        dispatch_assert(conv2d_gradfix._native_wrw_ok(dy, x, (False, (1, 1), (1, 1), (0, 0), (1, 1), 1), (dy.shape[1], x.shape[1], 3, 3)))
         return conv2d_gradfix._native_wrw(dy, x, (False, (1, 1), (1, 1), (0, 0), (1, 1), 1), (dy.shape[1], x.shape[1], 3, 3))
     finally:
         conv2d_gradfix.native_wrw_terms = old
@@ -76,7 +76,7 @@ def test_conv2d_gradfix_uses_it_and_stays_twice_differentiable():
     y = conv2d_gradfix.conv2d(x, w, padding=1)
     gw, = torch.autograd.grad(y.sin().sum(), [w], create_graph=True)
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv_wrw']['launches'] == 1
+    dispatch_assert(custom_ops.prof_collect()['conv_wrw']['launches'] == 1)
     xr, wr = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
     gwr, = torch.autograd.grad(F.conv2d(xr, wr, padding=1).sin().sum(), [wr], create_graph=True)
     assert_close(gw, gwr, atol=2e-5 * gwr.abs().max().item(), rtol=1e-5, what='dw')
@@ -116,7 +116,7 @@ def test_wrw_stride2_family(n, cs, cb, h, w, transposed):
     big = (torch.randn([n, cb, 2 * h + 1, 2 * w + 1], generator=g) * 1.5 + 0.25).to(DEV)
     cfg = (transposed, (2, 2), (0, 0), (0, 0), (1, 1), 1)
     x, dy = (small, big) if transposed else (big, small)
-    assert conv2d_gradfix._native_wrw_kind(dy, x, cfg, (cs, cb, 3, 3)) == 's2'
+    dispatch_assert(conv2d_gradfix._native_wrw_kind(dy, x, cfg, (cs, cb, 3, 3)) == 's2')
     got = conv2d_gradfix._native_wrw(dy, x, cfg, (cs, cb, 3, 3))
     wz = torch.zeros([cs, cb, 3, 3], dtype=torch.float64, requires_grad=True)
     xd, dyd = x.double().cpu(), dy.double().cpu()

@@ -5,7 +5,7 @@ import torch
 import oracle
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import gemm, modulation, time_encode
-from util import Golden, assert_close, assert_bit_equal
+from util import Golden, assert_close, assert_bit_equal, dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -144,7 +144,7 @@ def test_conv2d_resample_routes_whole_tile_1x1_to_mfma_gemm_with_second_order_gr
     custom_ops.prof_enable(256)
     y = conv2d_resample.conv2d_resample(x, w, f=f, down=2)
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['gemm']['launches'] == 1
+    dispatch_assert(custom_ops.prof_collect()['gemm']['launches'] == 1)
     xr, wr = x.detach().double().requires_grad_(True), w.detach().double().requires_grad_(True)
     yr = torch.nn.functional.conv2d(upfirdn2d.upfirdn2d(xr, f, down=2, padding=1, impl='ref'), wr)
     assert_close(y, yr, atol=1e-5 * max(1.0, yr.abs().max().item()), rtol=1e-5)
@@ -304,7 +304,7 @@ def test_reference_time_encoder_golden_on_gpu():
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
     # two trajectory convolutions + (periods | phases | left aligners) + right aligners on the dense-layer kernel, then the fused sin/cos/lerp tail
-    assert prof['fc']['launches'] == 4 and prof['gemm']['launches'] == 0 and prof['time_encode']['launches'] == 1 and prof['bias_act']['launches'] == 0, prof
+    dispatch_assert(prof['fc']['launches'] == 4 and prof['gemm']['launches'] == 0 and prof['time_encode']['launches'] == 1 and prof['bias_act']['launches'] == 0, prof)
     assert_close(out['motion_v'], G.t('motion_v'), atol=1e-3, rtol=1e-3, what='motion_v')
     # gradients of every encoder parameter through the kernels' backward forms vs the float64 CPU evaluation of the same module
     enc64 = MotionMappingNetwork(gcfg).double()
@@ -664,7 +664,7 @@ def test_bf16x3_gemm_member_serves_the_large_dense_products():
     bias = torch.randn([512], generator=g).to(DEV)
     before = custom_ops.kernel_variant_counts()['gemm_bf16x3']
     c = gemm.matmul_nt(a, b, bias)
-    assert custom_ops.kernel_variant_counts()['gemm_bf16x3'] - before == 1
+    dispatch_assert(custom_ops.kernel_variant_counts()['gemm_bf16x3'] - before == 1)
     ref = a.double() @ b.double().t() + bias.double()
     assert (c.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
     ai, bi = torch.randint(-2, 3, a.shape, generator=g).float().to(DEV), torch.randint(-2, 3, b.shape, generator=g).float().to(DEV)

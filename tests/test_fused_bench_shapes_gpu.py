@@ -23,6 +23,7 @@ import torch
 import oracle
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import conv2d_gradfix, fused_conv_act, fused_down_act, fused_fir_act, upfirdn2d
+from util import dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -37,7 +38,7 @@ def _one_conv_launch(fn):
     custom_ops.prof_enable(16)
     out = fn()
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv3x3']['launches'] == 1, 'the fused layer must be ONE convolution-family launch'
+    dispatch_assert(custom_ops.prof_collect()['conv3x3']['launches'] == 1, 'the fused layer must be ONE convolution-family launch')
     return out
 
 
@@ -211,7 +212,7 @@ def test_fused_fir_epilogue_modes_1_and_2_at_benchmark_shape():
     y = fused_fir_act.fir_bias_act(x, f, scale=sc, bias=b, padding=1, fir_gain=4, act='lrelu')
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
-    assert prof['upfirdn2d_lanes']['launches'] == 1 and prof['bias_act']['launches'] == 0 and prof['modulate']['launches'] == 0, 'forward must be ONE kernel'
+    dispatch_assert(prof['upfirdn2d_lanes']['launches'] == 1 and prof['bias_act']['launches'] == 0 and prof['modulate']['launches'] == 0, 'forward must be ONE kernel')
     assert y.shape == (N, c, 256, 256)
     yc = fused_fir_act.fir_bias_act_composed(x, f, scale=sc, bias=b, padding=1, fir_gain=4, act='lrelu')
     assert torch.equal(y, yc), 'mode 1 differs from the three-pass composition of this library (fp32: same operations, same order)'
@@ -225,7 +226,7 @@ def test_fused_fir_epilogue_modes_1_and_2_at_benchmark_shape():
     gx, gs, gb = torch.autograd.grad(y, [x, sc, b], dy)
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
-    assert prof['upfirdn2d_lanes']['launches'] == 1 and prof['bias_act']['launches'] == 0, 'backward must be ONE kernel'
+    dispatch_assert(prof['upfirdn2d_lanes']['launches'] == 1 and prof['bias_act']['launches'] == 0, 'backward must be ONE kernel')
     cx, cs_, cb_ = torch.autograd.grad(yc, [x, sc, b], dy)
     assert torch.equal(gx, cx), 'mode 2: input gradient differs from the composition'
     for got, want, name in ((gs, cs_, 'scale'), (gb, cb_, 'bias')):

@@ -7,6 +7,7 @@ import torch
 import oracle
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import fused_conv_act
+from util import dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -58,7 +59,7 @@ def test_fused_layer_forward_and_gradients_vs_oracle(n, ci, co, h, w, modulated,
     y = fused_conv_act.conv3x3_bias_act(xg, wg, styles=sg, dcoefs=dg, bias=bg, act=act, gain=gain, clamp=clamp)
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
-    assert prof['conv3x3']['launches'] == 1 and prof['bias_act']['launches'] == 0 and prof['modulate']['launches'] == 0, 'the forward pass must be ONE kernel'
+    dispatch_assert(prof['conv3x3']['launches'] == 1 and prof['bias_act']['launches'] == 0 and prof['modulate']['launches'] == 0, 'the forward pass must be ONE kernel')
     y_ref, grads_ref = _oracle_grads(x, wt, s, d, b, dy, act, gain, clamp, y_mask=y.detach().double().cpu())
     # error scale = the un-clamped activation range: the convolution's rounding (4e-6 of ITS scale) passes straight through the epilogue,
     # while a clamp shrinks max |y|
@@ -139,7 +140,7 @@ def test_fused_down_layer_forward_and_gradients_vs_oracle(n, ci, co, hs, ws, act
     y = fused_down_act.strided_conv3x3_bias_act(xg, wg, bias=bg, act=act, gain=gain, clamp=clamp, residual=rg.clone() if rg is not None else None)
     custom_ops.prof_disable()
     prof = custom_ops.prof_collect()
-    assert prof['conv3x3']['launches'] == 1 and prof.get('bias_act', {}).get('launches', 0) == 0, 'the forward pass must be ONE kernel'
+    dispatch_assert(prof['conv3x3']['launches'] == 1 and prof.get('bias_act', {}).get('launches', 0) == 0, 'the forward pass must be ONE kernel')
 
     y0 = torch.from_numpy(oracle.conv3x3(xb.double().numpy(), wt.double().numpy(), stride=2))
     a_ref = oracle.bias_act(y0, b.double() if b is not None else None, act=act, gain=gain, clamp=clamp)
@@ -232,7 +233,7 @@ def test_layer_then_fir_matches_the_composition(n, ci, co, h, w, act, clamp):
         err = _rel(a, r.double().cpu())
         assert err < 5e-4, f'd{name}: {err:.2e}'
     if w + 1 >= 129 or True:
-        assert prof.get('modulate', {}).get('launches', 0) == 0, 'no separate activation-gradient pass'
+        dispatch_assert(prof.get('modulate', {}).get('launches', 0) == 0, 'no separate activation-gradient pass')
 
     def r1(fn):
         yy = fn(x, wt, b, f, pads, act=act, gain=gain, clamp=clamp)
@@ -266,7 +267,7 @@ def test_layer_then_fir_sums_the_input_gradients_inside_the_data_gradient_kernel
     custom_ops.prof_enable(64)
     got = torch.autograd.grad(loss(True), [x, wt, b])
     custom_ops.prof_disable()
-    assert custom_ops.prof_collect()['conv3x3']['launches'] == 2          # forward and data gradient (the weight gradient is its own family)
+    dispatch_assert(custom_ops.prof_collect()['conv3x3']['launches'] == 2)          # forward and data gradient (the weight gradient is its own family)
     with fused_conv_act.composition_only():
         want = torch.autograd.grad(loss(False), [x, wt, b])
     for a, r, name in zip(got, want, 'xwb'):

@@ -28,6 +28,24 @@ class Golden:
         return [k for k in self.data.files if k.startswith(prefix)]
 
 
+def fast_paths_expected():
+    """False when a SGV_* dispatch switch is set in the environment (SGV_S2_WS=0, SGV_FUSED_CONV=0, SGV_CONV_TERMS=0, ...): the suite is then
+    exercising a fallback path, and assertions that pin WHICH kernel served a call do not apply."""
+    return not any(k.startswith('SGV_') and k not in ('SGV_NO_BUILD', 'SGV_TORCH_PROFILE') for k in os.environ)
+
+
+def dispatch_assert(cond, msg=''):
+    """Assert that the default dispatch took the expected kernel (launch counts, kernel variants, `supported` predicates).  With a fallback
+    switch set the expectation does not hold by construction: the test is skipped from this point on, so a fallback run of the suite is green
+    where the numerics hold and lists what it could not pin."""
+    if cond:
+        return
+    if not fast_paths_expected():
+        import pytest
+        pytest.skip('a SGV_* switch is set; this test pins the default kernel dispatch' + (f' ({msg})' if msg else ''))
+    raise AssertionError(msg)
+
+
 def max_abs(a, b):
     return (a.double().cpu() - b.double().cpu()).abs().max().item() if a.numel() else 0.0
 
