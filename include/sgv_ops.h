@@ -275,6 +275,14 @@ int sgv_conv3x3_wrw_s2_supported(int32_t n, int32_t c_small, int32_t c_big, int3
  * Shapes: c_in % 16 == 0, c_out % 64 == 0, and either w % 32 == 0 && h % 16 == 0 or whole 16x16 / 8x8 images (n % 2 resp. n % 8 == 0).
  * fp32 tensors, arithmetic as sgv_conv3x3_wrw (terms = 3: bf16x3 fp32 emulation; 1: bf16 products).  `workspace` is
  * sgv_conv3x3_workspace_bytes() of device scratch for the re-laid-out weights (owned by the caller, written per call).
+ *
+ * `dtype` = SGV_F16 / SGV_BF16 (every member of the 3x3 family: sgv_conv3x3[_fused], sgv_conv3x3_s2[_fused], sgv_conv3x3_wrw[_scaled],
+ * sgv_conv3x3_wrw_s2): x and y (dy and x; act_out) are 16-bit tensors, the weight, the scales, the bias and the weight gradient stay fp32 -- the
+ * mixed-precision blocks of the reference (`num_fp16_res`, networks.py:227,461; `weight.to(x.dtype)` networks.py:67) with fp32 master weights
+ * handed in as they are.  Needs terms = 1: every value is ONE bf16 operand of the matrix pipe (a bf16 as it is, an fp16 or fp32 weight rounded to
+ * nearest even), fp32 accumulate, one rounding on the store.  Shapes: the big-image forms only (w % 32 == 0; stride 2 also w in {16, 8} on the small
+ * grid; strided form c_out % 128 == 0); no `accumulate` (the residual add is an fp32 atomic).  Tolerance against fp32: 1e-2 of the result's scale
+ * (tests/test_conv_lowp_gpu.py; exact on bf16-representable integer data).
  */
 typedef struct sgv_conv3x3_params {
     const void* x;        /* [n, c_in, h, w] */

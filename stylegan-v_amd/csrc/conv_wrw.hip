@@ -42,6 +42,26 @@ int scatter_flush() {   // SGV_WRW_FLUSH=scatter: the element-per-lane atomics i
     return v;
 }
 
+void init_s2_once() {
+    std::call_once(g_once, [] {
+        hipError_t e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        const char* env = getenv("SGV_WRW_S2_WS");
+        g_use_s2_ws = !(env && env[0] == '0');
+        g_attr_err = e;
+    });
+}
+
 }  // namespace
 
 extern "C" int sgv_conv3x3_wrw_supported(int32_t n, int32_t c_out, int32_t c_in, int32_t h, int32_t w, int dtype) {
@@ -130,6 +150,7 @@ extern "C" int sgv_conv3x3_wrw_scaled(const sgv_conv_wrw_params* p, const float*
 }
 
 extern "C" int sgv_conv3x3_wrw_s2_supported(int32_t n, int32_t c_small, int32_t c_big, int32_t h, int32_t w, int dtype) {
+    if (io16(dtype)) { init_s2_once(); if (!g_use_s2_ws) return 0; }   // 16-bit tensors: the producer / consumer kernel only
     return supported_s2(n, c_small, c_big, h, w, dtype) ? 1 : 0;
 }
 
@@ -143,23 +164,7 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms must be 1 or 3");
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: 16-bit tensors need terms = 1 (one bf16 operand per value)");
     if (((uintptr_t)p->dy) & (io16(dtype) ? 7 : 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: the small tensor must be aligned to four elements");
-    std::call_once(g_once, [] {
-        hipError_t e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
-        const char* env = getenv("SGV_WRW_S2_WS");
-        g_use_s2_ws = !(env && env[0] == '0');
-        g_attr_err = e;
-    });
+    init_s2_once();
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));
     if (io16(dtype) && !g_use_s2_ws) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_s2: 16-bit tensors need the producer / consumer kernel (SGV_WRW_S2_WS != 0)");
     hipStream_t stream = (hipStream_t)stream_;

@@ -71,7 +71,9 @@ def test_conv3x3_unsupported_shapes_use_the_vendor_library():
     assert lib.sgv_conv3x3_supported(4, 3, 64, 32, 32, 0) == 0    # c_in % 16
     assert lib.sgv_conv3x3_supported(4, 64, 48, 32, 32, 0) == 0   # c_out % 64
     assert lib.sgv_conv3x3_supported(4, 64, 64, 24, 32, 0) == 0   # H % 16
-    assert lib.sgv_conv3x3_supported(4, 64, 64, 32, 32, 2) == 0   # bf16 tensors
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 32, 32, 2) == 1   # bf16 tensors: the producer / consumer kernel (tests/test_conv_lowp_gpu.py)
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 16, 16, 2) == 0   # ... which the 16x16 / 8x8 form is not
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 32, 32, 3) == 0   # fp64
     x = torch.randn([3, 64, 16, 16], device=DEV)
     w = torch.randn([64, 64, 3, 3], device=DEV, requires_grad=True)
     before = custom_ops.launch_count()

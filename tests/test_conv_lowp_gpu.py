@@ -112,6 +112,7 @@ def test_scaled_weight_gradient_16bit_tensors(dtype):
     dy = torch.randint(-3, 4, [n, o, h, wd], generator=g).to(DEV).to(dtype)
     x = torch.randint(-3, 4, [n, i, h, wd], generator=g).to(DEV).to(dtype)
     s = torch.randint(1, 4, [n, i], generator=g).float().to(DEV)
+    dispatch_assert(conv2d_gradfix._native_wrw_kind(dy, x, S1, (o, i, 3, 3)) == 's1', 'this 16-bit shape is not served by the hand-written kernel')
     dw = conv2d_gradfix._native_wrw(dy, x, S1, (o, i, 3, 3), x_scale=s)
     want = oracle.conv3x3_weight_grad(dy.double().cpu().numpy(), (x.double() * s.double()[:, :, None, None]).cpu().numpy())
     assert np.array_equal(dw.double().cpu().numpy(), want)
@@ -133,6 +134,7 @@ def test_conv3x3_s1_16bit_at_the_benchmark_shape(dtype):
         ref = oracle.conv3x3(xi[f:f + 1, :, lo:hi].double().cpu().numpy(), wi.double().cpu().numpy())[:, :, r0 - lo:r0 - lo + 6]
         assert torch.equal(y[f:f + 1, :, r0:r0 + 6].cpu(), torch.from_numpy(ref).to(dtype))
     dyi = torch.randint(-2, 3, [n, c, r, r], generator=g, device=DEV).to(dtype)
+    dispatch_assert(conv2d_gradfix._native_wrw_kind(dyi, xi, S1, (c, c, 3, 3)) == 's1', 'this 16-bit shape is not served by the hand-written kernel')
     dw = conv2d_gradfix._native_wrw(dyi, xi, S1, (c, c, 3, 3))
     dw32 = conv2d_gradfix._native_wrw(dyi.float(), xi.float(), S1, (c, c, 3, 3))
     assert torch.equal(dw, dw32)
@@ -144,7 +146,7 @@ def test_autograd_with_fp32_master_weight(dtype):
     g = torch.Generator().manual_seed(3)
     x = torch.randn([2, 64, 32, 32], generator=g).to(DEV).to(dtype).requires_grad_(True)
     w = (torch.randn([64, 64, 3, 3], generator=g) / 24).to(DEV).requires_grad_(True)
-    assert conv2d_gradfix.cast_weight(w, x) is w
+    dispatch_assert(conv2d_gradfix.cast_weight(w, x) is w, 'fp32 master weights reach the 16-bit kernels as they are')
     y = conv2d_gradfix.conv2d(x, w, padding=1)
     assert y.dtype == dtype
     dy = torch.randn(y.shape, generator=g).to(DEV).to(dtype)
@@ -260,6 +262,7 @@ def test_conv3x3_s2_16bit_at_the_benchmark_shape(dtype):
     assert torch.equal(y, conv2d_gradfix._native_conv(big.float(), w, S2).to(dtype))
     yt = _conv_s2(small, w, True)
     assert torch.equal(yt, conv2d_gradfix._native_conv(small.float(), w, S2T).to(dtype))
+    dispatch_assert(conv2d_gradfix._native_wrw_kind(small, big, S2, (128, 64, 3, 3)) == 's2', 'this 16-bit stride-2 shape is not served by the hand-written kernel')
     dw = conv2d_gradfix._native_wrw(small, big, S2, (128, 64, 3, 3))
     assert torch.equal(dw, conv2d_gradfix._native_wrw(small.float(), big.float(), S2, (128, 64, 3, 3)))
 

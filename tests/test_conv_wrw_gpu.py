@@ -94,7 +94,9 @@ def test_unsupported_shapes_fall_back_to_the_vendor_library():
     assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 24, 24, 0) == 0    # W not 8, 16 or a multiple of 32
     assert lib.sgv_conv3x3_wrw_supported(4, 64, 3, 32, 32, 0) == 0     # fromRGB-like channel counts
     assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 48, 32, 0) == 0    # H > 32 and not a multiple of 32
-    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 32, 32, 1) == 0    # fp16
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 32, 32, 1) == 1    # fp16 tensors, fp32 gradient (tests/test_conv_lowp_gpu.py)
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 16, 16, 1) == 0    # ... not the packed-sample form
+    assert lib.sgv_conv3x3_wrw_supported(4, 64, 64, 32, 32, 3) == 0    # fp64
     x = torch.randn([2, 64, 4, 4], device=DEV, requires_grad=True)
     w = torch.randn([64, 64, 3, 3], device=DEV, requires_grad=True)
     custom_ops.prof_enable(64)
@@ -142,6 +144,7 @@ def test_weight_gradient_with_input_scale_equals_scaling_first():
     x = torch.randn([n, ci, h, w], generator=g).cuda()
     s = (torch.randn([n, ci], generator=g) * 0.5 + 1).cuda()
     cfg = (False, (1, 1), (1, 1), (0, 0), (1, 1), 1)
+    dispatch_assert(conv2d_gradfix.wrw_input_scale and conv2d_gradfix._native_wrw_kind(dy, x, cfg, (co, ci, 3, 3)) == 's1', 'the producer / consumer weight-gradient kernel takes the input scale')
     a = conv2d_gradfix._native_wrw(dy, x, cfg, (co, ci, 3, 3), x_scale=s)
     b = conv2d_gradfix._native_wrw(dy, x * s[:, :, None, None], cfg, (co, ci, 3, 3))
     assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item()     # atomics: the accumulation order over workgroups differs run to run

@@ -8,7 +8,7 @@ import oracle
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import bias_act as ba
 from stylegan_v_amd.torch_utils.ops import upfirdn2d as ufd
-from util import Golden, assert_bit_equal, assert_close
+from util import Golden, assert_bit_equal, assert_close, dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -124,7 +124,7 @@ def test_upfirdn2d_row_walker_shapes_bit_exact(cfg, dtype):
                 hot = (up, down, padding[0], padding[2]) in ((1, 1, 1, 1), (1, 1, 2, 2), (2, 1, 2, 2), (1, 2, 1, 1))
                 assert kind in ((2, 3) if hot else (1,)), 'unexpected kernel selection'  # 3 = LDS tile, 2 = lane-exchange, 1 = row walker
                 if up == 1 and down == 1 and hot and ow % 4 in (0, 1) and ow > 4 and shape[3] >= 4:
-                    assert kind == 3, 'the FIR geometries with whole output quads go to the tile kernel'
+                    dispatch_assert(kind == 3, 'the FIR geometries with whole output quads go to the tile kernel')
                 y = ufd.upfirdn2d(xg, fg, up=up, down=down, padding=padding, flip_filter=flip, gain=gain)
                 ref = oracle.upfirdn2d(x, f, up=up, down=down, padding=padding, flip_filter=flip, gain=gain)
                 assert_bit_equal(y, ref, what=f'{cfg} {shape} filter#{fi} flip={flip} {dtype} kind={kind}')
