@@ -45,7 +45,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-PMC_FILES = ['r02_pmc_bench_step_FETCH_WRITE.json', 'r01_pmc_bench_step_v2_FETCH_WRITE.json']   # newest first
+PMC_FILES = ['r03_pmc_bench_step_FETCH_WRITE.json', 'r02_pmc_bench_step_FETCH_WRITE.json', 'r01_pmc_bench_step_v2_FETCH_WRITE.json']   # newest first
 
 
 def pmc_traffic(prefixes, dword_read_prefixes=()):
@@ -79,7 +79,7 @@ def pmc_traffic_conv_family():
                         'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
 
 
-def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_fir_asm')):
+def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_fir_asm', 'upfirdn2d_tile')):
     return pmc_traffic(tuple(prefixes))
 
 
