@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-C=${SGV_COMMIT:-unknown}
+C=${SGV_COMMIT:-b96bbeb}
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 > gpurun_out/r03_final_tests.log 2>&1; echo "pytest rc=$?"; grep -v amdgpu.ids gpurun_out/r03_final_tests.log | grep -E "passed|failed|FAILED|rror" | cut -c1-260 | tail -12
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -2 | tee gpurun_out/r03_smoke.log
 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 2> gpurun_out/r03_bench_final.err | tail -1 > gpurun_out/r03_bench_final.json; echo "bench rc=$?"
