@@ -67,6 +67,29 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
             return e;
         }();
         if (attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
+        // Persistent form (gemm_bf16x3_stream_kernel: two workgroups per CU walk the tiles, the next tile's first chunk in flight across the epilogue)
+        // wherever the launch has more tiles than resident workgroups; SGV_GEMM_STREAM=0 keeps one workgroup per tile.
+        static const bool allow_stream = !(getenv("SGV_GEMM_STREAM") && getenv("SGV_GEMM_STREAM")[0] == '0');
+        static const int resident = [] {
+            int dev = 0, cus = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+            return 2 * cus;
+        }();
+        const int64_t total_tiles = (int64_t)gp.tiles_m * gp.tiles_n * p->batch * ks;
+        if (allow_stream && total_tiles > resident && total_tiles <= INT32_MAX) {
+            static const hipError_t attr_err_s = [] {
+                hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16x3_stream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16x3_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                return e;
+            }();
+            if (attr_err_s != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err_s));
+            const dim3 sgrid((unsigned)(resident & ~7));
+            if (p->trans_b) hipLaunchKernelGGL(gemm_bf16x3_stream_kernel<1>, sgrid, dim3(256), X3_LDS_BYTES, stream, gp, (int)total_tiles);
+            else hipLaunchKernelGGL(gemm_bf16x3_stream_kernel<0>, sgrid, dim3(256), X3_LDS_BYTES, stream, gp, (int)total_tiles);
+            sgv_note_variant(SGV_V_gemm_bf16x3_stream);
+            return sgv_check_launch("gemm_bf16x3_stream_kernel");
+        }
         if (p->trans_b) hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, grid, dim3(256), X3_LDS_BYTES, stream, gp);
         else hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, dim3(256), X3_LDS_BYTES, stream, gp);
         sgv_note_variant(SGV_V_gemm_bf16x3);

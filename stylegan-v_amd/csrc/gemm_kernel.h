@@ -381,4 +381,166 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// gemm_bf16x3_stream_kernel: the same tile, arithmetic and LDS layout as gemm_bf16x3_kernel, as PERSISTENT workgroups (two per CU) that walk a flat
+// sequence of (tile, chunk) pairs.  The skip / 1x1 products of the discriminator have K = 64 ... 512, i.e. 2 ... 16 chunks per tile: launched as one
+// workgroup per tile every tile pays its own memory latency (first chunk's loads -> LDS -> MFMA -> stores, nothing of the next tile in flight meanwhile),
+// and the 64 -> 128 @ 128^2 product -- 1.2 GB of operands for 26 GFLOP -- ran at 2.6-2.8 TB/s (profiles/r03_gemm_bench.log).  Here the loads of the next
+// tile's first chunk are issued with the last chunk of the current tile and stay in flight across its MFMAs and its 64 epilogue stores.
+// Workgroup b of G takes the tiles L, L + G, L + 2G ... with L = (b % 8) * (G / 8) + b / 8: the workgroups of one XCD (b % 8) take consecutive tiles,
+// so that the tiles_m workgroups that read the same B panel share an L2.
+template <int TRANS_B>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params p, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) gu32x4 x3_lds[];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    const int lr = lane & 31, lk = lane >> 5;
+    const int f_row = t >> 1, f_half = t & 1;
+    const int g_col = t & 127, g_pair = t >> 7;
+    const int G = (int)gridDim.x;
+    const int logical = (G & 7) == 0 ? ((int)blockIdx.x & 7) * (G >> 3) + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
+
+    struct tile_ctx { const float* a_src; const float* b_src; float* C; const float* RES; int m0, n0; };
+    auto decode = [&](int tile) {
+        const int per_y = p.tiles_m * p.tiles_n;
+        const int y = tile / per_y, r = tile - y * per_y;
+        const int tn = r / p.tiles_m, tm = r - tn * p.tiles_m;   // M fastest: consecutive tiles share the B panel
+        const int batch = y / p.ksplit, slice = y - batch * p.ksplit;
+        const float* A = p.a + batch * p.stride_a + (int64_t)slice * p.k;
+        const float* B = p.b + batch * p.stride_b + (TRANS_B ? (int64_t)slice * p.k : (int64_t)slice * p.k * p.ldb);
+        tile_ctx c;
+        c.m0 = tm * BM; c.n0 = tn * BN;
+        c.C = p.c + (int64_t)y * p.stride_c;
+        c.RES = p.residual ? p.residual + (int64_t)y * p.stride_c : nullptr;
+        c.a_src = A + (int64_t)min(c.m0 + f_row, p.m - 1) * p.lda + f_half * 16;
+        c.b_src = TRANS_B ? B + (int64_t)(c.n0 + f_row) * p.ldb + f_half * 16 : B + (int64_t)(g_pair * 16) * p.ldb + c.n0 + g_col;
+        return c;
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    float ra[16], rb[16];
+    auto load_chunk = [&](const tile_ctx& c, int k0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float4 v = *(const float4*)(c.a_src + k0 + 4 * q);
+            ra[4 * q] = v.x; ra[4 * q + 1] = v.y; ra[4 * q + 2] = v.z; ra[4 * q + 3] = v.w;
+        }
+        if (TRANS_B) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float4 v = *(const float4*)(c.b_src + k0 + 4 * q);
+                rb[4 * q] = v.x; rb[4 * q + 1] = v.y; rb[4 * q + 2] = v.z; rb[4 * q + 3] = v.w;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) rb[e] = c.b_src[(int64_t)(k0 + e) * p.ldb];
+        }
+    };
+    auto store_chunk = [&](int stage) {
+        gu32x4* as = x3_lds + stage * X3_STAGE_WORDS;
+        gu32x4* bs = as + X3_PLANES * X3_PITCH;
+#pragma unroll
+        for (int o = 0; o < 2; o++) {
+            gu32x4 hi, lo;
+            x3_split8(ra + 8 * o, hi, lo);
+            as[(0 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = hi;
+            as[(1 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = lo;
+            x3_split8(rb + 8 * o, hi, lo);
+            if (TRANS_B) {
+                bs[(0 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = hi;
+                bs[(1 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = lo;
+            } else {
+                bs[(0 * 4 + 2 * g_pair + o) * X3_PITCH + g_col] = hi;
+                bs[(1 * 4 + 2 * g_pair + o) * X3_PITCH + g_col] = lo;
+            }
+        }
+    };
+
+    int tile = logical;
+    if (tile >= total_tiles) return;
+    tile_ctx ct = decode(tile);
+    load_chunk(ct, 0);
+    int cur = 0;
+    for (;;) {
+        const int next = tile + G;
+        const bool more = next < total_tiles;
+        const tile_ctx nt = more ? decode(next) : ct;
+        for (int k0 = 0; k0 < p.k; k0 += X3_BK) {
+            store_chunk(cur);
+            __syncthreads();     // stage `cur` is complete; the other stage's readers finished before their own barrier of the previous chunk
+            if (k0 + X3_BK < p.k) load_chunk(ct, k0 + X3_BK);
+            else if (more) load_chunk(nt, 0);     // the next tile's first chunk: in flight across the MFMAs below and the epilogue stores
+            const gu32x4* as = x3_lds + cur * X3_STAGE_WORDS;
+            const gu32x4* bs = as + X3_PLANES * X3_PITCH;
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                gu32x4 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; i++) {
+                    ah[i] = as[(0 * 4 + 2 * s + lk) * X3_PITCH + wm + 32 * i + lr];
+                    al[i] = as[(1 * 4 + 2 * s + lk) * X3_PITCH + wm + 32 * i + lr];
+                    bh[i] = bs[(0 * 4 + 2 * s + lk) * X3_PITCH + wn + 32 * i + lr];
+                    bl[i] = bs[(1 * 4 + 2 * s + lk) * X3_PITCH + wn + 32 * i + lr];
+                }
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, al[i]), __builtin_bit_cast(gbf16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, ah[i]), __builtin_bit_cast(gbf16x8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, ah[i]), __builtin_bit_cast(gbf16x8, bh[j]), acc[i][j], 0, 0, 0);
+            }
+            cur ^= 1;
+        }
+
+        // Epilogue (as gemm_bf16x3_kernel); the accumulators are cleared for the next tile as they are stored.
+        const bool full_m = ct.m0 + BM <= p.m;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int col = ct.n0 + wn + j * 32 + lr;
+                const float bcol = (p.bias_mode == 1) ? p.bias[col] : 0.f;
+                float rv[16];
+                if (ct.RES) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int row = ct.m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                        rv[e] = (full_m || row < p.m) ? ct.RES[(int64_t)row * p.ldc + col] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int row = ct.m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
+                    float v = acc[i][j][e] + bcol;
+                    acc[i][j][e] = 0.f;
+                    if (!full_m && row >= p.m) continue;
+                    if (p.bias_mode == 2) v += p.bias[row];
+                    if (ct.RES) v += rv[e];
+                    ct.C[(int64_t)row * p.ldc + col] = v;
+                }
+            }
+        if (!more) break;
+        tile = next;
+        ct = nt;
+    }
+}
+
+
 }  // namespace sgv_gemm

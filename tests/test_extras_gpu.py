@@ -656,6 +656,69 @@ def test_bf16x3_gemm_member_serves_the_1x1_convolutions(n, cin, cout, hw):
     assert torch.equal(yi.double(), yi64) and torch.equal(gxi.double(), rxi) and torch.equal(gwi.double(), rwi), 'integer data must be exact'
 
 
+@pytest.mark.parametrize('n,cin,cout,hw', [(5, 64, 128, 128), (9, 128, 256, 64), (3, 128, 64, 128), (7, 32, 192, 128)])
+def test_bf16x3_stream_gemm_walks_tiles_persistently(n, cin, cout, hw):
+    """gemm_bf16x3_stream_kernel (csrc/gemm_kernel.h): launches with more tiles than resident workgroups (2 per CU) run as persistent workgroups that
+    prefetch the next tile's first chunk across the epilogue.  Tile counts that are not a multiple of the grid (uneven tails), two m-tiles per B panel
+    (XCD-aware order), rows that are not a multiple of the tile (64 / 192), bias + residual in the store: against float64 `conv2d` (< 1e-5, the
+    family's bound) and EXACT on small-integer data (pins tile decoding, the cross-tile register hand-over and the accumulator reset)."""
+    g = torch.Generator().manual_seed(n + cin + cout + hw)
+    x = torch.randn([n, cin, hw, hw], generator=g).to(DEV)
+    w = (torch.randn([cout, cin, 1, 1], generator=g) / cin ** 0.5).to(DEV)
+    b = torch.randn([cout], generator=g).to(DEV)
+    res = torch.randn([n, cout, hw, hw], generator=g).to(DEV)
+    dy = torch.randn([n, cout, hw, hw], generator=g).to(DEV)
+    before = custom_ops.kernel_variant_counts()
+    xg, wg = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y = gemm.conv1x1(xg, wg, b, residual=res)
+    gx, = torch.autograd.grad(y, [xg], dy)
+    after = custom_ops.kernel_variant_counts()
+    resident = 2 * torch.cuda.get_device_properties(0).multi_processor_count
+    want = sum(1 for rows in (cout, cin) if -(-rows // 128) * (hw * hw // 128) * n > resident)     # launches with more tiles than resident workgroups
+    assert want >= 1
+    dispatch_assert(after['gemm_bf16x3_stream'] - before['gemm_bf16x3_stream'] == want, 'launches with more tiles than resident workgroups must take the persistent member')
+    x64, w64 = x.double().requires_grad_(True), w.double()
+    y64 = torch.nn.functional.conv2d(x64, w64, b.double()) + res.double()
+    rx, = torch.autograd.grad(y64, [x64], dy.double())
+    for got, ref, name in ((y, y64, 'y'), (gx, rx, 'dx')):
+        err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-5, f'{name}: relative error {err:.2e} vs float64'
+    xi = torch.randint(-3, 4, x.shape, generator=g).float().to(DEV)
+    wi = torch.randint(-2, 3, w.shape, generator=g).float().to(DEV)
+    dyi = torch.randint(-1, 2, dy.shape, generator=g).float().to(DEV)
+    xig = xi.clone().requires_grad_(True)
+    yi = gemm.conv1x1(xig, wi)
+    gxi, = torch.autograd.grad(yi, [xig], dyi)
+    xi64 = xi.double().requires_grad_(True)
+    yi64 = torch.nn.functional.conv2d(xi64, wi.double())
+    rxi, = torch.autograd.grad(yi64, [xi64], dyi.double())
+    assert torch.equal(yi.double(), yi64) and torch.equal(gxi.double(), rxi), 'integer data must be exact'
+    with torch.no_grad():
+        assert torch.equal(gemm.conv1x1(x, w, b, residual=res), y.detach()), 'the persistent walk must be deterministic'
+
+
+def test_bf16x3_stream_gemm_trans_b_and_split_k():
+    """The k-contiguous B member (x @ w.T: [8320, 256] x [1024, 256]^T = 520 tiles; rows that are not a multiple of the tile) and a split-K launch
+    (640 slices of a [128, 128] weight gradient) through the persistent form."""
+    g = torch.Generator().manual_seed(11)
+    a = torch.randint(-2, 3, [8320, 256], generator=g).float().to(DEV)
+    b = torch.randint(-2, 3, [1024, 256], generator=g).float().to(DEV)
+    before = custom_ops.kernel_variant_counts()['gemm_bf16x3_stream']
+    c = gemm.matmul_nt(a, b)
+    dispatch_assert(custom_ops.kernel_variant_counts()['gemm_bf16x3_stream'] - before == 1)
+    assert torch.equal(c.double(), a.double() @ b.double().t())
+    ar, br = torch.randn([8320 - 40, 256], generator=g).to(DEV), torch.randn([1024, 256], generator=g).to(DEV)
+    ref = ar.double() @ br.double().t()
+    assert (gemm.matmul_nt(ar, br).double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
+    # split K: the per-slice products are separate tiles of the flat sequence (40 samples x 16 slices of k = 256)
+    dy = torch.randint(-1, 2, [40, 128, 64, 64], generator=g).float().to(DEV)
+    x = torch.randint(-2, 3, [40, 128, 64, 64], generator=g).float().to(DEV)
+    before = custom_ops.kernel_variant_counts()['gemm_bf16x3_stream']
+    dw = gemm.conv1x1_weight_grad(dy, x)
+    dispatch_assert(custom_ops.kernel_variant_counts()['gemm_bf16x3_stream'] - before == 1)
+    assert torch.equal(dw.double(), torch.einsum('nop,nip->oi', dy.double().flatten(2), x.double().flatten(2)))
+
+
 def test_bf16x3_gemm_member_serves_the_large_dense_products():
     """matmul_nt with split K (the unfolded trajectory convolutions: [2112, 5632] x [5632, 512]) and rows that are not a multiple of the tile."""
     g = torch.Generator().manual_seed(4)
