@@ -363,16 +363,24 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         const size_t prep = convT3x3_s2_edge_we_floats(p->c_in, p->c_out) + (size_t)p->n * p->c_in * p->h;
         const size_t prep_io = prep + (size_t)p->n * p->c_in * p->w;   // 16-bit tensors: the last input row is gathered as fp32 as well
         const dim3 eg((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2);
+        // input channels split over the 4 (c_in % 32 == 0) or 2 waves of a workgroup; SGV_CONVT_EDGE_KSPLIT=0: one wave per block
+        static const bool ksplit = !(getenv("SGV_CONVT_EDGE_KSPLIT") && getenv("SGV_CONVT_EDGE_KSPLIT")[0] == '0');
+        const int nw = !ksplit ? 1 : (p->c_in % 32 == 0 ? 4 : 2);
+#define SGV_EDGE_MFMA(IOV, XPTR) \
+        if (nw == 4) hipLaunchKernelGGL((convT3x3_s2_edge_mfma<IOV, 4>), eg, dim3(256), 0, stream, XPTR, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w); \
+        else if (nw == 2) hipLaunchKernelGGL((convT3x3_s2_edge_mfma<IOV, 2>), eg, dim3(128), 0, stream, XPTR, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w); \
+        else hipLaunchKernelGGL((convT3x3_s2_edge_mfma<IOV, 1>), eg, dim3(64), 0, stream, XPTR, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w);
         if (io == 0) {
             hipLaunchKernelGGL(convT3x3_s2_edge_prep<0>, dim3((unsigned)((prep + 255) / 256)), dim3(256), 0, stream, p->x, p->weight, edge, p->n, p->c_in, p->c_out, p->h, p->w);
-            hipLaunchKernelGGL(convT3x3_s2_edge_mfma<0>, eg, dim3(64), 0, stream, (const float*)p->x, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+            SGV_EDGE_MFMA(0, (const float*)p->x)
         } else if (io == 1) {
             hipLaunchKernelGGL(convT3x3_s2_edge_prep<1>, dim3((unsigned)((prep_io + 255) / 256)), dim3(256), 0, stream, p->x, p->weight, edge, p->n, p->c_in, p->c_out, p->h, p->w);
-            hipLaunchKernelGGL(convT3x3_s2_edge_mfma<1>, eg, dim3(64), 0, stream, (const float*)nullptr, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+            SGV_EDGE_MFMA(1, (const float*)nullptr)
         } else {
             hipLaunchKernelGGL(convT3x3_s2_edge_prep<2>, dim3((unsigned)((prep_io + 255) / 256)), dim3(256), 0, stream, p->x, p->weight, edge, p->n, p->c_in, p->c_out, p->h, p->w);
-            hipLaunchKernelGGL(convT3x3_s2_edge_mfma<2>, eg, dim3(64), 0, stream, (const float*)nullptr, edge, p->y, p->n, p->c_in, p->c_out, p->h, p->w);
+            SGV_EDGE_MFMA(2, (const float*)nullptr)
         }
+#undef SGV_EDGE_MFMA
     }
     sgv_note_variant(SGV_V_convT_edge_mfma);
     return sgv_check_launch("convT3x3_s2_edge_mfma");

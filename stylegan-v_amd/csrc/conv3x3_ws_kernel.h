@@ -58,8 +58,18 @@ __device__ __forceinline__ f32x16 ws_mma(u32x4 a, u32x4 b, f32x16 c) {
 // PRIO: s_setprio level of the consumer waves (the producers' VALU-heavy split competes for the SIMD's issue slots).
 // IO: element format of x and y (sgv_io16.h): 0 fp32; 1 bf16 / 2 fp16 tensors (TERMS = 1: one bf16 operand per value, fp32 accumulate, 16-bit stores;
 //     weights, scales and the bias stay fp32) -- the mixed-precision blocks of the reference (networks.py:227,461), same loads count, same waits.
-template <int TERMS, int PRO, int EPI, int ABL = 0, int PRIO = 1, int IO = 0>
+//      6 = 1 + 4, 7 = 1 + 3 (consumer loop alone, without its stores / without its operand reads); 8 / 9: as 5, but only the weight DMA / only the x loads are dropped.
+// ORD: order of the consumers' 216 MFMAs per chunk.  0: tap-major (for every tap its four rows: 12 operand reads per 24 MFMAs).  1: column-major with ROW
+//      REUSE -- for kx = 0..2 the six input rows j = 0..5 of the wave are read once each and serve every (output row r, ky) with r + ky = j
+//      (6 / 12 / 18 / 18 / 12 / 6 MFMAs per row), the three weight taps (ky, kx) of the column stay in registers and are refilled for the next column as
+//      their last use passes: 72 instead of 108 ds_read_b128 per chunk.  The consumer loop is LDS-read bound (profiles/r03_conv_lab_ws_ablations.log: the loop alone
+//      0.81 ms with its operand reads, 0.60 ms without them, on every layer shape) -- but NOT by their number: measured equal or 1-4 % slower than the
+//      tap-major order on every shape (profiles/r03_conv_lab_ws_row_reuse.log; consumers alone 0.806 vs 0.808 ms).  The 0.60 ms of the no-read ablation is the
+//      matrix pipe on constant operands (no data toggling, 2.2 GHz); on real data the part holds ~1.85 GHz and the loop alone is at 89 % of that ceiling.
+//      Kept as a lab variant (default 0); same products, a different summation order (kx outermost) than the 4-wave kernel.
+template <int TERMS, int PRO, int EPI, int ABL = 0, int PRIO = 1, int IO = 0, int ORD = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
+    constexpr bool A_IDLE = ABL == 1 || ABL == 6 || ABL == 7, A_NOSTORE = ABL == 4 || ABL == 6, A_NOREAD = ABL == 3 || ABL == 7;
     static_assert(IO == 0 || TERMS == 1, "16-bit tensors are multiplied as single bf16 operands");
     using namespace sgv_io;
     const conv_params& p = pp.c;
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();   // image 0 ready
         for (int q = 0; q < total; q++) {
-            if (q + 1 < total && ABL != 1 && ABL != 5) dma_w(q + 1, lds + ((q + 1) & 1) * WS_IMAGE_WORDS);   // free since the previous barrier
+            if (q + 1 < total && !A_IDLE && ABL != 5 && ABL != 8) dma_w(q + 1, lds + ((q + 1) & 1) * WS_IMAGE_WORDS);   // free since the previous barrier
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
         }
@@ -212,9 +222,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         };
         // iteration q: start the loads of chunk q+2 into `ld`, then split / write chunk q+1 (in `st`, loaded one iteration ago) into image (q+1) & 1
         auto step = [&](int q, xset& ld, xset& st) {
-            const bool more = q + 2 < total && ABL != 1 && ABL != 5;
+            const bool more = q + 2 < total && !A_IDLE && ABL != 5 && ABL != 9;
             if (more) load_x(q + 2, ld);
-            if (q + 1 < total && ABL != 1) {
+            if (q + 1 < total && !A_IDLE) {
                 u32x4* img = lds + ((q + 1) & 1) * WS_IMAGE_WORDS;    // last read by the consumers in iteration q-1, i.e. before the previous barrier
                 arrive(st, more);
                 store_x(img, st);
@@ -226,8 +236,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
 
         xset s0, s1;
         load_x(0, s0);
-        if (total > 1) load_x(1, s1);
-        arrive(s0, total > 1);
+        if (total > 1 && !A_IDLE) load_x(1, s1);     // (lab: a set that is never consumed must not be loaded -- its registers are unprotected)
+        arrive(s0, total > 1 && !A_IDLE);
         store_x(lds, s0);
         put_ep(0, lds, s0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -264,11 +274,73 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         const int a_lane = (ln >> 5) * TM + (ln & 31);                              // + ((hl * 9 + tap) * 2) * TM + hf * 32
         const int b_lane = ((ln >> 5) * RIN + 4 * wave) * PIN + (ln & 31);          // + (r + ky) * PIN + kx (+ 2 * XS_PLANE for lo)
 
+        if (ORD == 1) {
+            // ---- column-major with row reuse: 18 row steps (kx, j); A[ky] = the weights of tap (ky, kx) for both m halves, B = input row j at column offset kx ----
+            u32x4 A[3][2][2];    // [ky][half][hl]
+            u32x4 B[2][2];       // [buffer][hl]
+            auto fetch_A = [&](int ky, int kx) {
+                const int tap = ky * 3 + kx;
+                if (A_NOREAD) { for (int hf = 0; hf < 2; hf++) for (int hl = 0; hl < 2; hl++) A[ky][hf][hl] = u32x4{(unsigned)ln, 2u, 3u, 4u}; return; }
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    A[ky][hf][0] = ws[a_lane + ((0 * 9 + tap) * 2) * TM + hf * 32];
+                    if (TERMS > 1) A[ky][hf][1] = ws[a_lane + ((1 * 9 + tap) * 2) * TM + hf * 32];
+                }
+            };
+            auto fetch_B = [&](int buf, int j, int kx) {
+                if (A_NOREAD) { for (int hl = 0; hl < 2; hl++) B[buf][hl] = u32x4{5u, (unsigned)ln, 7u, 8u}; return; }
+                const int pos = b_lane + j * PIN + kx;
+                B[buf][0] = xs[pos];
+                if (TERMS > 1) B[buf][1] = xs[2 * XS_PLANE + pos];
+            };
+            constexpr int RA = TERMS > 1 ? 4 : 2, RB = TERMS > 1 ? 2 : 1;   // ds_read_b128 per weight tap / per input row
+            fetch_B(0, 0, 0);
+            fetch_A(0, 0);
+            fetch_A(1, 0);
+            fetch_A(2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, RB + 3 * RA, 0);   // the operands of the first rows come first, as one group
+#pragma unroll
+            for (int s = 0; s < 18; s++) {
+                const int kx = s / 6, j = s % 6, bb = s & 1;
+                int reads = 0;
+                if (s + 1 < 18) { fetch_B(bb ^ 1, (s + 1) % 6, (s + 1) / 6); reads += RB; }
+                // the tap whose last use was the previous row step is refilled for the next column: ky = 0 after j = 3, ky = 1 after j = 4, ky = 2 after j = 5
+                if (j == 4 && kx < 2) { fetch_A(0, kx + 1); reads += RA; }
+                if (j == 5 && kx < 2) { fetch_A(1, kx + 1); reads += RA; }
+                if (j == 0 && kx > 0) { fetch_A(2, kx); reads += RA; }
+                const int ky_lo = j > 3 ? j - 3 : 0, ky_hi = j < 2 ? j : 2;     // (r, ky) with r = j - ky in 0..3
+                if (TERMS > 1) {
+#pragma unroll
+                    for (int ky = ky_lo; ky <= ky_hi; ky++)
+#pragma unroll
+                        for (int hf = 0; hf < 2; hf++)
+                            acc[j - ky][hf] = ws_mma<ABL>(A[ky][hf][1], B[bb][0], acc[j - ky][hf]);
+#pragma unroll
+                    for (int ky = ky_lo; ky <= ky_hi; ky++)
+#pragma unroll
+                        for (int hf = 0; hf < 2; hf++)
+                            acc[j - ky][hf] = ws_mma<ABL>(A[ky][hf][0], B[bb][1], acc[j - ky][hf]);
+                }
+#pragma unroll
+                for (int ky = ky_lo; ky <= ky_hi; ky++)
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++)
+                        acc[j - ky][hf] = ws_mma<ABL>(A[ky][hf][0], B[bb][0], acc[j - ky][hf]);
+                const int MF = (TERMS > 1 ? 6 : 2) * (ky_hi - ky_lo + 1);
+#pragma unroll
+                for (int i = 0; i < MF; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                    // 1 MFMA
+                    if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
+                }
+                if (reads > MF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                if (reads > MF + 1) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        } else {
         // 18 half-taps (tap, row pair); the operands of step s+1 are fetched before the 12 MFMAs of step s are issued
         u32x4 a[2][2][2];    // [buffer][half][hl]
         u32x4 b[2][2][2];    // [buffer][row][hl]
         auto fetch_a = [&](int buf, int tap) {
-            if (ABL == 3) { for (int hf = 0; hf < 2; hf++) for (int hl = 0; hl < 2; hl++) a[buf][hf][hl] = u32x4{(unsigned)ln, 2u, 3u, 4u}; return; }
+            if (A_NOREAD) { for (int hf = 0; hf < 2; hf++) for (int hl = 0; hl < 2; hl++) a[buf][hf][hl] = u32x4{(unsigned)ln, 2u, 3u, 4u}; return; }
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
                 a[buf][hf][0] = ws[a_lane + ((0 * 9 + tap) * 2) * TM + hf * 32];
@@ -276,7 +348,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
             }
         };
         auto fetch_b = [&](int buf, int tap, int rh) {
-            if (ABL == 3) { for (int r = 0; r < 2; r++) for (int hl = 0; hl < 2; hl++) b[buf][r][hl] = u32x4{5u, (unsigned)ln, 7u, 8u}; return; }
+            if (A_NOREAD) { for (int r = 0; r < 2; r++) for (int hl = 0; hl < 2; hl++) b[buf][r][hl] = u32x4{5u, (unsigned)ln, 7u, 8u}; return; }
             const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -322,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // 1 DS read
             }
         }
+        }
 
         if (c == chunks - 1) {
             // C layout: col (pixel) = lane & 31, row (m) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5): 128-B contiguous stores
@@ -354,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                                     v = fmaxf(__builtin_fmaf(v, c0[ei], c1[ei]), __builtin_fmaf(v, c2[ei], c3[ei]));
                                     if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
                                 }
-                                if (ABL == 4) asm volatile("" :: "v"(v));
+                                if (A_NOSTORE) asm volatile("" :: "v"(v));
                                 else if (IO != 0) out_store<IO>(p.y, yoff + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
                                 else if (pp.accumulate) atomicAdd(yb + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
                                 else yb[(size_t)(m0 + ei) * plane + (size_t)r * p.w] = v;

@@ -474,9 +474,11 @@ __global__ __launch_bounds__(256) void convT3x3_s2_edge_prep(const void* x, cons
 
 typedef float f32x16e __attribute__((ext_vector_type(16)));
 
-// grid = (ceil((max(H, W) + 1) / 32), n * (m / 32), 2 strips), 64 threads.
-template <int IO>
-__global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, const float* edge, void* y, int n, int k, int m, int h, int wd) {
+// grid = (ceil((max(H, W) + 1) / 32), n * (m / 32), 2 strips), 64 * NW threads: the NW waves of a workgroup each take k / NW input channels of the same
+// 32 x 32 output block and are summed through LDS by wave 0.  (A wave's k loop is a serial chain of load -> MFMA steps, k / 8 of them, and the grid has
+// only a few waves per SIMD: with one wave per block the 512-channel layers took 0.23 ms per call for 0.4 % of the layer's flops -- latency, not work.)
+template <int IO, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void convT3x3_s2_edge_mfma(const float* x, const float* edge, void* y, int n, int k, int m, int h, int wd) {
     const int strip = blockIdx.z;
     const int ls = strip == 0 ? wd : h;               // source line length
     const int lo = strip == 0 ? 2 * wd + 1 : 2 * h;   // outputs of the strip
@@ -484,7 +486,8 @@ __global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, cons
     if (2 * i0 >= lo) return;
     const int mts = m / 32;
     const int nn = blockIdx.y / mts, m0 = (blockIdx.y % mts) * 32;
-    const int lane = threadIdx.x, l32 = lane & 31, g = lane >> 5;
+    const int lane = threadIdx.x & 63, l32 = lane & 31, g = lane >> 5;
+    const int kw = NW > 1 ? (int)(threadIdx.x >> 6) : 0, kper = k / NW, kb = kw * kper;     // this wave's channels: kb .. kb + kper (host: kper % 8 == 0)
     const int i = i0 + l32;
     const bool vb = i < ls, vm = i >= 1 && i - 1 < ls;
     const size_t plane = (size_t)h * wd;
@@ -493,17 +496,17 @@ __global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, cons
     const float* xs = strip == 0 ? (IO ? edge + convT3x3_s2_edge_we_floats(k, m) + (size_t)n * k * h + (size_t)nn * k * wd : x + (size_t)nn * k * plane + (size_t)(h - 1) * wd)
                                  : edge + convT3x3_s2_edge_we_floats(k, m) + (size_t)nn * k * h;
     const size_t kstep = strip == 0 ? (IO ? (size_t)wd : plane) : (size_t)h;
-    const float* pb = xs + (vb ? i : 0) + (size_t)g * kstep;
-    const float* pm = xs + (vm ? i - 1 : 0) + (size_t)g * kstep;
+    const float* pb = xs + (vb ? i : 0) + (size_t)(kb + g) * kstep;
+    const float* pm = xs + (vm ? i - 1 : 0) + (size_t)(kb + g) * kstep;
     const size_t tk = (size_t)k * m;                  // floats per tap
-    const float* pw = edge + (size_t)strip * 3 * tk + (size_t)g * m + m0 + l32;
+    const float* pw = edge + (size_t)strip * 3 * tk + (size_t)(kb + g) * m + m0 + l32;
     const size_t wk = (size_t)2 * m, xk = 2 * kstep;
 
     f32x16e acc_e, acc_o;
 #pragma unroll
     for (int e = 0; e < 16; e++) { acc_e[e] = 0.f; acc_o[e] = 0.f; }
     constexpr int U = 4;   // k pairs in flight (k is a multiple of 16)
-    for (int k0 = 0; k0 < k; k0 += 2 * U) {
+    for (int k0 = 0; k0 < kper; k0 += 2 * U) {
         float a0[U], a1[U], a2[U], b[U], bm[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
@@ -520,6 +523,19 @@ __global__ __launch_bounds__(64) void convT3x3_s2_edge_mfma(const float* x, cons
             acc_e = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[u], bm[u], acc_e, 0, 0, 0);
         }
         pw += U * wk; pb += U * xk; pm += U * xk;
+    }
+    if (NW > 1) {
+        __shared__ float red[NW > 1 ? NW - 1 : 1][32][64];     // [wave - 1][accumulator word][lane]: conflict-free
+        if (kw > 0) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) { red[kw - 1][e][lane] = acc_e[e]; red[kw - 1][16 + e][lane] = acc_o[e]; }
+        }
+        __syncthreads();
+        if (kw > 0) return;
+#pragma unroll
+        for (int w2 = 0; w2 < NW - 1; w2++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) { acc_e[e] += red[w2][e][lane]; acc_o[e] += red[w2][16 + e][lane]; }
     }
     const int hout = 2 * h + 1, wout = 2 * wd + 1;
     const int pe = 2 * i, po = 2 * i + 1;

@@ -656,7 +656,7 @@ def test_bf16x3_gemm_member_serves_the_1x1_convolutions(n, cin, cout, hw):
     assert torch.equal(yi.double(), yi64) and torch.equal(gxi.double(), rxi) and torch.equal(gwi.double(), rwi), 'integer data must be exact'
 
 
-@pytest.mark.parametrize('n,cin,cout,hw', [(5, 64, 128, 128), (9, 128, 256, 64), (3, 128, 64, 128), (7, 32, 192, 128)])
+@pytest.mark.parametrize('n,cin,cout,hw', [(5, 64, 128, 128), (9, 128, 256, 64), (5, 128, 64, 128), (7, 32, 192, 128)])
 def test_bf16x3_stream_gemm_walks_tiles_persistently(n, cin, cout, hw):
     """gemm_bf16x3_stream_kernel (csrc/gemm_kernel.h): launches with more tiles than resident workgroups (2 per CU) run as persistent workgroups that
     prefetch the next tile's first chunk across the epilogue.  Tile counts that are not a multiple of the grid (uneven tails), two m-tiles per B panel

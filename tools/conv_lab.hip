@@ -251,13 +251,14 @@ int main(int argc, char** argv) {
             CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
             CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
             CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 0, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
+            CK(hipFuncSetAttribute((const void*)conv3x3_ws_kernel<3, 0, 0, 0, 1, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
             attr2 = true;
         }
         for (int round = 0; round < 3; round++) for (int v = 0; v < 7; v++) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
             CK(hipEventRecord(e0));
             for (int r = 0; r < reps; r++) {
-                if (v == 0) hipLaunchKernelGGL(conv3x3_kernel<3>, dim3(256), dim3(256), LDS_BYTES, 0, p0);
+                if (v == 0) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 0, 0, 0, 1, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);   // tap-major consumer order (ORD = 0)
                 else if (v == 1) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
                 else if (v == 2) hipLaunchKernelGGL((conv3x3_ws_kernel<3, 1, 1>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
                 else if (v == 3) hipLaunchKernelGGL((conv3x3_ws_kernel<1, 0, 0>), dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
@@ -269,13 +270,13 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
             best[v] = fminf(best[v], ms);
         }
-        printf("%-12s 4-wave %7.3f ms %6.1f TF | ws %7.3f ms %6.1f TF | ws+PRO+EPI %7.3f ms | ws terms=1 %7.3f ms %6.1f TF   (max |diff| ws vs 4-wave %.2e)\n", s.name,
+        printf("%-12s ws ORD=0 %7.3f ms %6.1f TF | ws %7.3f ms %6.1f TF | ws+PRO+EPI %7.3f ms | ws terms=1 %7.3f ms %6.1f TF   (max |diff| ws vs 4-wave %.2e)\n", s.name,
                best[0], flops / best[0] / 1e9, best[1], flops / best[1] / 1e9, best[2], best[3], flops / best[3] / 1e9, md);
         printf("%-12s    EPI only %7.3f ms | PRO only %7.3f ms | EPI without its stores %7.3f ms\n", s.name, best[4], best[5], best[6]);
         fflush(stdout);
         CK(hipFree(x)); CK(hipFree(w)); CK(hipFree(y)); CK(hipFree(wprep)); CK(hipFree(xsc)); CK(hipFree(osc)); CK(hipFree(bias));
     }
-    if (ablate) for (int si : {1, 3}) {   // ---- producer / consumer kernel: ablations and consumer priority (timing only where ABL != 0) ----
+    if (ablate) for (int si : {0, 1, 2, 3}) {   // ---- producer / consumer kernel: ablations and consumer priority (timing only where ABL != 0) ----
         auto& s = shapes[si];
         const size_t na = (size_t)s.n * s.c * s.r * s.r, nw = (size_t)s.c * s.c * 9;
         float *x, *w, *y; u32x4* wprep;
@@ -287,12 +288,16 @@ int main(int argc, char** argv) {
         pp.c.tiles = s.n * (s.r / TROWS) * (s.r / SEG) * (s.c / TM); pp.c.grid = 256;
         typedef void (*kern_t)(conv_ws_params);
         struct { const char* name; kern_t k; } abl[] = {
-            {"full", conv3x3_ws_kernel<3, 0, 0, 0, 0>}, {"full, consumer prio 1", conv3x3_ws_kernel<3, 0, 0, 0, 1>}, {"full, consumer prio 3", conv3x3_ws_kernel<3, 0, 0, 0, 3>},
-            {"producers idle (barriers only)", conv3x3_ws_kernel<3, 0, 0, 1, 0>}, {"no MFMAs (reads + barriers)", conv3x3_ws_kernel<3, 0, 0, 2, 0>},
-            {"no operand reads (MFMAs + barriers)", conv3x3_ws_kernel<3, 0, 0, 3, 0>}, {"no epilogue stores", conv3x3_ws_kernel<3, 0, 0, 4, 0>},
-            {"producers without global loads / DMA", conv3x3_ws_kernel<3, 0, 0, 5, 0>}, {"producers idle + no operand reads", nullptr} };
+            {"full (consumer prio 1)", conv3x3_ws_kernel<3, 0, 0, 0, 1>},
+            {"producers idle (barriers only)", conv3x3_ws_kernel<3, 0, 0, 1, 1>}, {"no MFMAs (reads + barriers)", conv3x3_ws_kernel<3, 0, 0, 2, 1>},
+            {"no operand reads (MFMAs + barriers)", conv3x3_ws_kernel<3, 0, 0, 3, 1>}, {"no epilogue stores", conv3x3_ws_kernel<3, 0, 0, 4, 1>},
+            {"producers without global loads / DMA", conv3x3_ws_kernel<3, 0, 0, 5, 1>}, {"producers idle + no stores", conv3x3_ws_kernel<3, 0, 0, 6, 1>},
+            {"producers idle + no operand reads", conv3x3_ws_kernel<3, 0, 0, 7, 1>}, {"no weight DMA (x loads kept)", conv3x3_ws_kernel<3, 0, 0, 8, 1>},
+            {"no x loads (weight DMA kept)", conv3x3_ws_kernel<3, 0, 0, 9, 1>} };
+        int ai = -1;
         for (auto& a : abl) {
-            if (!a.k) continue;
+            ai++;
+            if (!a.k || (argc > 4 && atoi(argv[4]) != ai)) continue;
             CK(hipFuncSetAttribute((const void*)a.k, hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES));
             hipLaunchKernelGGL(a.k, dim3(256), dim3(512), WS_LDS_BYTES, 0, pp);
             CK(hipDeviceSynchronize());
