@@ -150,7 +150,12 @@ template <typename T> __device__ __forceinline__ uint16_t narrow(float v) { T t;
 // Load N contiguous elements starting at p (element-aligned only) into dst[0..N) as fp32.
 template <typename T, int N> struct row_loader {
     static __device__ __forceinline__ void run(const T* p, float* dst) {
-        if constexpr (N >= 4) {
+        if constexpr (N >= 8 && sizeof(T) == 2) {     // eight 16-bit elements: one 16-byte request per lane (the tile kernel's CPL = 8 form)
+            typename vec_of<T, 8>::type v = *(const typename vec_of<T, 8>::type*)p;
+#pragma unroll
+            for (int i = 0; i < 8; i++) dst[i] = widen<T>(v[i]);
+            row_loader<T, N - 8>::run(p + 8, dst + 8);
+        } else if constexpr (N >= 4) {
             typename vec_of<T, 4>::type v = *(const typename vec_of<T, 4>::type*)p;
             if constexpr (sizeof(T) == 4) { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
             else { dst[0] = widen<T>(v[0]); dst[1] = widen<T>(v[1]); dst[2] = widen<T>(v[2]); dst[3] = widen<T>(v[3]); }
@@ -937,7 +942,7 @@ struct tile_params {
 };
 
 constexpr int TILE_ROWS = 16, TILE_IN_ROWS = TILE_ROWS + 3;
-inline int tile_lds_floats(int lpr_log2) { return TILE_IN_ROWS * (64 >> lpr_log2) * ((4 << lpr_log2) + 8); }
+inline int tile_lds_floats(int lpr_log2, int cpl = 4) { return TILE_IN_ROWS * (64 >> lpr_log2) * ((cpl << lpr_log2) + 8); }
 
 // WIDE: one plane per wave row (lpr_log2 == 6): the LDS pitches are compile-time constants (the instantiation of the >= 129-column calls, which
 // carry most of the bytes; the run-time-pitch form spent ~30 % more instructions on addresses and measured 6-8 % below tools/ufd_lab.hip V6).
@@ -946,9 +951,14 @@ inline int tile_lds_floats(int lpr_log2) { return TILE_IN_ROWS * (64 >> lpr_log2
 //     SGV_TILE_EXP=8, profiles/r03_ufd_tile_bisect.log).
 // F44: the filter is a dense 4 x 4 fp32 array (what setup_filter produces): its 16 taps are ONE s_load_dwordx16 issued with the kernel arguments;
 //     sixteen separately addressed scalar loads (any size <= 4 x 4, any strides: F44 = false) cost 3-4 % on the same call.
-template <typename T, int XTRA, int EPI, bool WIDE, bool NT, bool F44>
+// CPL: output columns per lane.  4 for fp32 (one 16-byte request per lane and row).  8 for the 16-bit formats (round 3, second part): with four columns a
+//     16-bit lane asks for 8 bytes per row and the pass ran at the fp32 ELEMENT rate, i.e. half the bytes per second (bf16 [96,64,257,257]: 855 us
+//     against 913 us in fp32, profiles/r03_bench_step_lowp_bf16_kernel_stats.csv); with eight it issues the same 16-byte requests as the fp32 form.
+//     The LDS tile holds fp32 either way (19 rows x (64 x CPL + 8) floats).
+template <typename T, int XTRA, int EPI, bool WIDE, bool NT, bool F44, int CPL = 4>
 __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
-    constexpr int NH = 3 + XTRA, NOUT = 4 + XTRA;
+    constexpr int NH = 3 + XTRA, NOUT = CPL + XTRA;
+    static_assert(CPL == 4 || CPL == 8, "4 or 8 output columns per lane");
     extern __shared__ __attribute__((aligned(16))) float tile_lds[];
     typedef float f4v __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
@@ -960,8 +970,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     const int sub = WIDE ? lane : lane & (lpr - 1), slot = WIDE ? 0 : lane >> p.lpr_log2;
     const int plane = WIDE ? pg : pg * (64 >> p.lpr_log2) + slot;
     const bool plane_ok = plane < p.planes;
-    const int seg_pitch = 4 * lpr + 8;                        // floats of one plane's row in LDS: 4 per lane + the halo words (16-byte aligned)
-    const int row_pitch = WIDE ? 264 : (64 >> p.lpr_log2) * seg_pitch;
+    const int seg_pitch = CPL * lpr + 8;                      // floats of one plane's row in LDS: CPL per lane + the halo words (16-byte aligned)
+    const int row_pitch = WIDE ? 64 * CPL + 8 : (64 >> p.lpr_log2) * seg_pitch;
     float ff[4][4];
     if constexpr (F44) {
 #pragma unroll
@@ -971,32 +981,33 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     }
     const T* xp = (const T*)p.x + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w;
     T* yp = (T*)p.y + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
-    const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of 4
-    const int ox = (cg * 64 + sub) * 4;
+    const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of CPL
+    const int ox = (cg * 64 + sub) * CPL;
     const int ix0 = ox - p.pad_x;
-    const int base = min(max(ix0, 0), p.in_w - 4);              // the 4-column load window, clamped into the row
-    const int sh = base - ix0;                                  // how far it moved (|sh| <= 3 for lanes that own live columns)
-    const bool cols_dead = !plane_ok || ix0 >= p.in_w || ix0 + 3 < 0;
-    const int ixh = (cg * 64 + lpr) * 4 - p.pad_x + sub;        // lanes sub < NH of a plane row: the columns right of its last lane's block
+    const int base = min(max(ix0, 0), p.in_w - CPL);            // the CPL-column load window, clamped into the row
+    const int sh = base - ix0;                                  // how far it moved: pad_x for the lane at ox = 0, -over_u for the lane that overhangs the row's end
+    const int over_u = (((-p.pad_x - p.in_w) % CPL) + CPL) % CPL;   // ix0 + CPL - in_w of that lane (ox is a multiple of CPL): wave-uniform, 0 = no such lane
+    const bool cols_dead = !plane_ok || ix0 >= p.in_w || ix0 + CPL - 1 < 0;
+    const int ixh = (cg * 64 + lpr) * CPL - p.pad_x + sub;      // lanes sub < NH of a plane row: the columns right of its last lane's block
     const bool halo_ok = plane_ok && sub < NH && ixh >= 0 && ixh < p.in_w;
     const int ixh_c = min(max(ixh, 0), p.in_w - 1);
     const int oy0 = rt * TILE_ROWS;
     const int iy0 = oy0 - p.pad_y;
     const bool st_vec = plane_ok && ox < n_main;
-    const bool st_xtra = XTRA && plane_ok && ox + 4 == p.out_w - 1;
+    const bool st_xtra = XTRA && plane_ok && ox + CPL == p.out_w - 1;
 
     // ---- load phase: rows wave, wave + 4, ... of the 19; everything is issued before anything is used ----
     constexpr int RPW = (TILE_IN_ROWS + 3) / 4;
-    float m[RPW][4], h[RPW];
+    float m[RPW][CPL], h[RPW];
 #pragma unroll
     for (int k = 0; k < RPW; k++) {
         const int r = wave + 4 * k;
         const T* row = xp + (size_t)min(max(iy0 + r, 0), p.in_h - 1) * p.in_w;
 #pragma unroll
-        for (int i = 0; i < 4; i++) m[k][i] = 0.f;
+        for (int i = 0; i < CPL; i++) m[k][i] = 0.f;
         h[k] = 0.f;
         if (r < TILE_IN_ROWS) {
-            row_loader<T, 4>::run(row + base, m[k]);
+            row_loader<T, CPL>::run(row + base, m[k]);
             if (sub < NH) h[k] = sgv_traits<T>::load(row + ixh_c);
         }
     }
@@ -1009,8 +1020,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
             for (int v = 0; v < NOUT; v++) yo[k][v] = 0.f;
             const int oy = min(oy0 + 4 * wave + k, p.out_h - 1);
             const T* yr = yrp + (size_t)oy * p.out_w + ox;
-            if (st_vec) row_loader<T, 4>::run(yr, yo[k]);
-            if constexpr (XTRA) { if (st_xtra) yo[k][4] = sgv_traits<T>::load(yr + 4); }
+            if (st_vec) row_loader<T, CPL>::run(yr, yo[k]);
+            if constexpr (XTRA) { if (st_xtra) yo[k][CPL] = sgv_traits<T>::load(yr + CPL); }
         }
     }
     // Any other filter: the taps AFTER the row loads have been issued, through the scalar cache (every index is wave-uniform).  (The lanes kernel's
@@ -1034,32 +1045,47 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
         if (r >= TILE_IN_ROWS) continue;
         const int iy = iy0 + r;
         const bool row_ok = iy >= 0 && iy < p.in_h;
-        f4v o;
+        // Undo the clamp: column ix0 + i = loaded[i - sh] where that exists, else 0 (padding).  Only the first lane of a plane row (sh = pad_x) and the one
+        // lane whose window overhangs the row's end (sh = -over_u) moved, and both amounts are wave-uniform: a uniform branch picks the shift, every
+        // element costs one select per side (the per-lane chain over |sh| = 1..3 cost six -- and covered overhangs up to 3 only, short of what
+        // CPL = 8 can meet on rows whose column blocks do not fill the lanes).
+        float o[CPL];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {   // undo the clamp: column ix0 + i = loaded[i - sh] where that exists, else 0 (padding)
-            float v = m[k][i];
+        for (int i = 0; i < CPL; i++) o[i] = m[k][i];
+#if !(defined(SGV_TILE_ABL) && (SGV_TILE_ABL & 2))  // lab build: without the selects
 #pragma unroll
-            for (int d = 1; d <= 3; d++) {
-                if (i - d >= 0) v = (sh == d) ? m[k][i - d] : v; else v = (sh == d) ? 0.f : v;
-                if (i + d < 4) v = (sh == -d) ? m[k][i + d] : v; else v = (sh == -d) ? 0.f : v;
+        for (int d = 1; d <= 3; d++)
+            if (p.pad_x == d) {
+#pragma unroll
+                for (int i = 0; i < CPL; i++) o[i] = (sh > 0) ? (i - d >= 0 ? m[k][i - d] : 0.f) : o[i];
             }
-            o[i] = (row_ok && !cols_dead) ? v : 0.f;
-        }
+#pragma unroll
+        for (int d = 1; d < CPL; d++)
+            if (over_u == d) {
+#pragma unroll
+                for (int i = 0; i < CPL; i++) o[i] = (sh < 0) ? (i + d < CPL ? m[k][i + d] : 0.f) : o[i];
+            }
+#endif
+#pragma unroll
+        for (int i = 0; i < CPL; i++) o[i] = (row_ok && !cols_dead) ? o[i] : 0.f;
         float* lrow = tile_lds + r * row_pitch + slot * seg_pitch;
-        *(f4v*)(lrow + 4 * sub) = o;
-        if (sub < 8) lrow[4 * lpr + sub] = (row_ok && halo_ok) ? h[k] : 0.f;     // halo words; the rest of the 8 are zero
+#pragma unroll
+        for (int q = 0; q < CPL / 4; q++) *(f4v*)(lrow + CPL * sub + 4 * q) = f4v{o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]};
+        if (sub < 8) lrow[CPL * lpr + sub] = (row_ok && halo_ok) ? h[k] : 0.f;   // halo words; the rest of the 8 are zero
     }
     __syncthreads();
 
     // ---- compute phase: output rows 4 wave .. 4 wave + 3 from LDS rows 4 wave .. 4 wave + 6 ----
-    float win[7][8];
+    float win[7][CPL + 4];
 #pragma unroll
     for (int r = 0; r < 7; r++) {
-        const float* lrow = tile_lds + (4 * wave + r) * row_pitch + slot * seg_pitch + 4 * sub;
-        const f4v a = *(const f4v*)lrow;
-        const f4v b = *(const f4v*)(lrow + 4);
+        const float* lrow = tile_lds + (4 * wave + r) * row_pitch + slot * seg_pitch + CPL * sub;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { win[r][i] = a[i]; win[r][4 + i] = b[i]; }
+        for (int q = 0; q < CPL / 4 + 1; q++) {     // its own CPL columns and the next four
+            const f4v a = *(const f4v*)(lrow + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; i++) win[r][4 * q + i] = a[i];
+        }
     }
     float ep_sc = 1.f, ep_bi = 0.f;
     if constexpr (EPI == 1) {
@@ -1072,14 +1098,39 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
         const int oy = oy0 + 4 * wave + k;
         if (oy >= p.out_h) break;   // wave-uniform
         float o[NOUT];
+        // The 16 multiply-adds of an output, for two neighbouring outputs at a time: v_pk_fma_f32 (two fp32 FMAs per lane and instruction; hipcc keeps a
+        // copy of the window row shifted by one column for the odd taps).  Every output still sees its own chain in the reference's tap order -- the
+        // results are bit-identical to the scalar form -- at half the FMA issue slots: on 16-bit tensors the pass is bound by its VALU work, not by HBM
+        // (profiles/r03_ufd_tile_valu_ablation.log: bf16 2.9 TB/s, 3.35 without the multiply-adds, fp32 unchanged at 5.5).
+        float fir[NOUT];
+#if defined(SGV_TILE_ABL) && (SGV_TILE_ABL & 1)     // lab build (tools/gpu_recipes): the pass without its 16 multiply-adds per output
 #pragma unroll
-        for (int v = 0; v < NOUT; v++) {
+        for (int v = 0; v < NOUT; v++) fir[v] = win[k + 1][v + 1] * ff[1][1];
+#else
+        typedef float f2v __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int v2 = 0; v2 < NOUT / 2; v2++) {
+            f2v acc2 = {0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    acc2 = __builtin_elementwise_fma(f2v{win[k + j][2 * v2 + i], win[k + j][2 * v2 + i + 1]}, f2v{ff[j][i], ff[j][i]}, acc2);
+            fir[2 * v2] = acc2[0];
+            fir[2 * v2 + 1] = acc2[1];
+        }
+        if constexpr (NOUT & 1) {
             float acc = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
-                for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[k + j][v + i], ff[j][i], acc);
-            float t = acc * p.gain;
+                for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[k + j][NOUT - 1 + i], ff[j][i], acc);
+            fir[NOUT - 1] = acc;
+        }
+#endif
+#pragma unroll
+        for (int v = 0; v < NOUT; v++) {
+            float t = fir[v] * p.gain;
             if constexpr (EPI == 1) {   // bias -> activation -> gain -> clamp, the operation order of bias_act.cu:51-142 (grad 0); identical to the lanes kernel's
                 t = t * ep_sc;
                 t = t + ep_bi;
@@ -1095,13 +1146,13 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
                 g *= p.ep_gain;
                 if (p.ep_clamp >= 0.f) g = (yref > -p.ep_clamp & yref < p.ep_clamp) ? g : 0.f;
                 t = g;
-                if (v < 4 ? st_vec : st_xtra) sum_g += t;
+                if (v < CPL ? st_vec : st_xtra) sum_g += t;
             }
             o[v] = t;
         }
         T* yr = yp + (size_t)oy * p.out_w + ox;
-        if (st_vec) { if (NT) store_vec_nt<T, 4>(yr, o); else store_vec_plain<T, 4>(yr, o); }
-        if constexpr (XTRA) { if (st_xtra) sgv_traits<T>::store(yr + 4, o[4]); }
+        if (st_vec) { if (NT) store_vec_nt<T, CPL>(yr, o); else store_vec_plain<T, CPL>(yr, o); }
+        if constexpr (XTRA) { if (st_xtra) sgv_traits<T>::store(yr + CPL, o[CPL]); }
     }
     if constexpr (EPI == 3) {   // reduce over the lanes of a plane row, then one atomic per plane and wave
 #pragma unroll
@@ -1302,7 +1353,7 @@ bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan, cons
 }
 
 // ---- upfirdn2d_tile_kernel: planning and launch ----
-bool tile_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2, int* col_groups, int* xtra) {
+bool tile_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2, int* col_groups, int* xtra, int* cpl_out = nullptr) {
     static const int tile_on = []() { const char* e = getenv("SGV_UFD_TILE"); return e ? atoi(e) : 1; }();   // SGV_UFD_TILE=0: the strip-walking kernels of rounds 1-2
     if (!tile_on || dtype == SGV_F64) return false;
     if (p->up_x != 1 || p->up_y != 1 || p->down_x != 1 || p->down_y != 1 || p->f_w > 4 || p->f_h > 4) return false;
@@ -1312,7 +1363,14 @@ bool tile_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2, int*
     const int xt = (p->out_w > 4 && p->out_w % 4 == 1) ? 1 : 0;
     const int n_main = xt ? p->out_w - 1 : p->out_w;
     if (n_main % 4 != 0) return false;
-    const int cbs = n_main / 4;
+    // 16-bit tensors: eight columns per lane (16-byte requests) where the row divides -- SGV_UFD_TILE_CPL8=1; off by default: measured equal (fused
+    // modes) or 6 % slower (plain pass) than four columns in the mixed-precision step (profiles/r03_ufd_tile_cpl8_ab.log): the 16-bit pass runs at the
+    // fp32 pass's OUTPUT-ELEMENT rate (0.7 T/s) whatever the request size, and neither halving its FMA instructions (v_pk_fma_f32) nor the select
+    // chain moved it (profiles/r03_ufd_tile_pkfma.log)
+    static const int cpl8_on = []() { const char* e = getenv("SGV_UFD_TILE_CPL8"); return e ? atoi(e) : 0; }();
+    const int cpl = (cpl8_on && cpl_out && (dtype == SGV_F16 || dtype == SGV_BF16) && n_main % 8 == 0 && n_main >= 32 && p->in_w >= 8) ? 8 : 4;
+    if (cpl_out) *cpl_out = cpl;
+    const int cbs = n_main / cpl;
     if (cbs <= 32) {
         int l = 2;
         while ((1 << l) < cbs) l++;
@@ -1324,27 +1382,33 @@ bool tile_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2, int*
     return true;
 }
 
-template <typename T, int X, int E>
-void launch_tile_xe(const tile_params& tp, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
+template <typename T, int X, int E, int CPL>
+void launch_tile_xec(const tile_params& tp, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
     // dense 4 x 4 filters get the specialised forms (WIDE x NT); any other filter the general one
-    if (!f44) { hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, false, false>), grid, dim3(256), lds, stream, tp); return; }
+    if (!f44) { hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, false, false, CPL>), grid, dim3(256), lds, stream, tp); return; }
     if (tp.lpr_log2 == 6) {
-        if (tp.nt_store) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, true, true, true>), grid, dim3(256), lds, stream, tp);
-        else hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, true, false, true>), grid, dim3(256), lds, stream, tp);
+        if (tp.nt_store) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, true, true, true, CPL>), grid, dim3(256), lds, stream, tp);
+        else hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, true, false, true, CPL>), grid, dim3(256), lds, stream, tp);
     } else {
-        if (tp.nt_store) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, true, true>), grid, dim3(256), lds, stream, tp);
-        else hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, false, true>), grid, dim3(256), lds, stream, tp);
+        if (tp.nt_store) hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, true, true, CPL>), grid, dim3(256), lds, stream, tp);
+        else hipLaunchKernelGGL((upfirdn2d_tile_kernel<T, X, E, false, false, true, CPL>), grid, dim3(256), lds, stream, tp);
     }
 }
 
-template <typename T>
-void launch_tile_t(const tile_params& tp, int xtra, int epi, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
-    if (epi == 0) { if (xtra) launch_tile_xe<T, 1, 0>(tp, f44, grid, lds, stream); else launch_tile_xe<T, 0, 0>(tp, f44, grid, lds, stream); }
-    else if (epi == 1) { if (xtra) launch_tile_xe<T, 1, 1>(tp, f44, grid, lds, stream); else launch_tile_xe<T, 0, 1>(tp, f44, grid, lds, stream); }
-    else { if (xtra) launch_tile_xe<T, 1, 3>(tp, f44, grid, lds, stream); else launch_tile_xe<T, 0, 3>(tp, f44, grid, lds, stream); }
+template <typename T, int X, int E>
+void launch_tile_xe(const tile_params& tp, int cpl, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
+    if constexpr (sizeof(T) == 2) { if (cpl == 8) { launch_tile_xec<T, X, E, 8>(tp, f44, grid, lds, stream); return; } }
+    launch_tile_xec<T, X, E, 4>(tp, f44, grid, lds, stream);
 }
 
-int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dtype, int lpr_log2, int col_groups, int xtra, hipStream_t stream) {
+template <typename T>
+void launch_tile_t(const tile_params& tp, int xtra, int epi, int cpl, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
+    if (epi == 0) { if (xtra) launch_tile_xe<T, 1, 0>(tp, cpl, f44, grid, lds, stream); else launch_tile_xe<T, 0, 0>(tp, cpl, f44, grid, lds, stream); }
+    else if (epi == 1) { if (xtra) launch_tile_xe<T, 1, 1>(tp, cpl, f44, grid, lds, stream); else launch_tile_xe<T, 0, 1>(tp, cpl, f44, grid, lds, stream); }
+    else { if (xtra) launch_tile_xe<T, 1, 3>(tp, cpl, f44, grid, lds, stream); else launch_tile_xe<T, 0, 3>(tp, cpl, f44, grid, lds, stream); }
+}
+
+int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dtype, int lpr_log2, int col_groups, int xtra, int cpl, hipStream_t stream) {
     tile_params tp{};
     tp.x = p->x; tp.f = p->f; tp.y = p->y; tp.flip = p->flip; tp.gain = p->gain;
     tp.in_w = p->in_w; tp.in_h = p->in_h; tp.out_w = p->out_w; tp.out_h = p->out_h; tp.planes = p->in_c * p->in_n;
@@ -1363,13 +1427,13 @@ int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dt
     const int ppw = 64 >> lpr_log2;
     const int64_t blocks = (int64_t)((tp.planes + ppw - 1) / ppw) * col_groups * tp.row_tiles;
     if (blocks > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: too many workgroups");
-    const size_t lds = (size_t)tile_lds_floats(lpr_log2) * sizeof(float);
+    const size_t lds = (size_t)tile_lds_floats(lpr_log2, cpl) * sizeof(float);
     const dim3 grid((unsigned)blocks);
     const bool f44 = p->f_w == 4 && p->f_h == 4 && p->f_sw == 1 && p->f_sh == 4;
     if (!f44) tp.nt_store = 0;      // the general-filter form has one (plain-store) instantiation
-    if (dtype == SGV_F32) launch_tile_t<float>(tp, xtra, epi, f44, grid, lds, stream);
-    else if (dtype == SGV_F16) launch_tile_t<sgv_half_t>(tp, xtra, epi, f44, grid, lds, stream);
-    else launch_tile_t<sgv_bf16_t>(tp, xtra, epi, f44, grid, lds, stream);
+    if (dtype == SGV_F32) launch_tile_t<float>(tp, xtra, epi, 4, f44, grid, lds, stream);
+    else if (dtype == SGV_F16) launch_tile_t<sgv_half_t>(tp, xtra, epi, cpl, f44, grid, lds, stream);
+    else launch_tile_t<sgv_bf16_t>(tp, xtra, epi, cpl, f44, grid, lds, stream);
     sgv_note_variant(epi == 0 ? SGV_V_ufd_tile : epi == 1 ? SGV_V_ufd_tile_fused1 : SGV_V_ufd_tile_fused3);
     return sgv_check_launch("upfirdn2d_tile_kernel");
 }
@@ -1450,10 +1514,10 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
     const double bytes = ((double)p->in_w * p->in_h + (double)p->out_w * p->out_h) * p->in_c * p->in_n * sgv_dtype_size(dtype);
 
     {
-        int lpr_log2, col_groups, xtra;
-        if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra)) {   // every up = down = 1 FIR pass: the LDS-tile kernel
+        int lpr_log2, col_groups, xtra, cpl;
+        if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra, &cpl)) {   // every up = down = 1 FIR pass: the LDS-tile kernel
             sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
-            return launch_tile(p, nullptr, dtype, lpr_log2, col_groups, xtra, stream);
+            return launch_tile(p, nullptr, dtype, lpr_log2, col_groups, xtra, cpl, stream);
         }
     }
     lanes_plan lplan;
@@ -1509,10 +1573,10 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
     const double es0 = (double)sgv_dtype_size(dtype);
     const double nin0 = (double)p->in_w * p->in_h * p->in_c * p->in_n, nout0 = (double)p->out_w * p->out_h * p->in_c * p->in_n;
     if (e->mode == 1 || e->mode == 3) {
-        int lpr_log2, col_groups, xtra;
-        if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra)) {
+        int lpr_log2, col_groups, xtra, cpl;
+        if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra, &cpl)) {
             sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, nin0 * es0 + (e->mode == 3 ? 2.0 * nout0 : nout0) * es0);
-            return launch_tile(p, e, dtype, lpr_log2, col_groups, xtra, stream);
+            return launch_tile(p, e, dtype, lpr_log2, col_groups, xtra, cpl, stream);
         }
     }
     lanes_plan lplan;

@@ -100,7 +100,11 @@ ROWS_CONFIGS = [
     (2, 1, [1, 2, 1, 2], 1), (2, 1, [3, 0, 2, 1], 1), (1, 2, [2, 0, 0, 2], 1), (1, 1, [0, 3, -1, 2], 1), (1, 2, [-1, 3, 2, -2], 2),
 ]
 ROWS_SHAPES = [(1, 1, 5, 5), (2, 3, 9, 9), (1, 2, 16, 16), (3, 5, 17, 33), (1, 2, 64, 63), (2, 2, 37, 129), (1, 3, 19, 131), (1, 1, 65, 255),
-               (2, 1, 31, 256), (1, 2, 33, 257), (1, 1, 12, 258), (1, 1, 9, 261), (1, 1, 40, 513), (1, 1, 7, 1025), (1, 1, 3, 300), (1, 1, 1, 140)]
+               (2, 1, 31, 256), (1, 2, 33, 257), (1, 1, 12, 258), (1, 1, 9, 261), (1, 1, 40, 513), (1, 1, 7, 1025), (1, 1, 3, 300), (1, 1, 1, 140),
+               # output rows of 40 / 72 / 192 / 200 / 320 (+1) / 1000 columns in the two FIR geometries: column blocks that do not fill the lanes of a plane
+               # row -- the 16-bit tile kernel's eight-column lanes meet a window that overhangs the row's end by up to seven columns there
+               (1, 2, 7, 41), (1, 1, 5, 73), (2, 1, 6, 193), (1, 1, 9, 201), (1, 1, 5, 322), (1, 1, 4, 1001), (1, 2, 7, 39), (1, 1, 5, 191), (1, 1, 6, 199),
+               (1, 1, 5, 320)]
 
 
 @pytest.mark.parametrize('cfg', ROWS_CONFIGS)
