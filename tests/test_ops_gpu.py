@@ -134,6 +134,21 @@ def test_upfirdn2d_row_walker_shapes_bit_exact(cfg, dtype):
                 assert_bit_equal(y, ref, what=f'{cfg} {shape} filter#{fi} flip={flip} {dtype} kind={kind}')
 
 
+def test_upfirdn2d_tile_kernel_eight_columns_per_lane_form_in_a_child_process():
+    """SGV_UFD_TILE_CPL8=1 (read once per process): the 16-bit tile kernel with eight output columns per lane, an opt-in form -- the width sweep above,
+    bf16 and fp16, bit-exact against the oracle in a child interpreter that has the switch set."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get('SGV_UFD_TILE_CPL8') == '1':
+        pytest.skip('already inside the child')
+    env = dict(os.environ, SGV_UFD_TILE_CPL8='1')
+    res = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-k', 'row_walker_shapes', '-p', 'no:cacheprovider'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert ' passed' in res.stdout
+
+
 SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466, 0.787641141030194,
         0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578, 0.0017677118642428036, -0.007800708325034148]
 
