@@ -163,6 +163,57 @@ def time_encode(periods, phases, al, ar, freqs, phase_scales, t, t_left, t_right
 
 
 # ----------------------------------------------------------------------------------------------
+# Differentiable float64 restatements in plain torch ops (comparators of the gradient / second-order tests: autograd differentiates the
+# definition itself, nothing of the product package is involved).
+
+
+def demod_coefs_torch(weight, styles, eps=1e-8):
+    """networks.py:57-62 the reference's way -- w[N,O,I,kh,kw] = W * s, d = rsqrt(sum w^2 + eps) -- as a differentiable torch expression."""
+    w = weight.unsqueeze(0) * styles.reshape(styles.shape[0], 1, -1, 1, 1)
+    return (w.square().sum(dim=[2, 3, 4]) + eps).rsqrt()
+
+
+def dense(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear', normalize=False, act_gain=None, alpha=0.2):
+    """FullyConnectedLayer.forward (layers.py:126-137: w = weight * weight_gain, b = bias * bias_gain, x @ w.t() + b, bias_act) behind the optional
+    normalize_2nd_moment of the mapping network (layers.py:22-25); activations 'linear' and 'lrelu' (bias_act.py:26,29: lrelu slope 0.2, gain sqrt 2)."""
+    if normalize:
+        x = x * (x.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
+    y = x.matmul((weight * weight_gain).t())
+    if bias is not None:
+        y = y + (bias * bias_gain).unsqueeze(0)
+    assert act in ('linear', 'lrelu')
+    gain = act_gain if act_gain is not None else (1.0 if act == 'linear' else float(np.sqrt(2.0)))
+    if act == 'lrelu':
+        y = torch.nn.functional.leaky_relu(y, alpha)
+    return y * gain if gain != 1 else y
+
+
+def affine_resample(x, theta, out_hw):
+    """The geometric resampling of AugmentPipe (augment.py:295-297): affine_grid(align_corners=False) + bilinear grid_sample with zero padding, written
+    out as four gathers (torch's own grid_sample has no second derivative -- the reason the reference carries grid_sample_gradfix.py): differentiable to
+    any order in x.  Sampling positions per the ATen definition: output pixel centre (2j + 1) / Wo - 1 in [-1, 1], source index ((g + 1) * W - 1) / 2."""
+    n, c, h, w = x.shape
+    ho, wo = out_hw
+    xs = (2 * torch.arange(wo, dtype=x.dtype, device=x.device) + 1) / wo - 1
+    ys = (2 * torch.arange(ho, dtype=x.dtype, device=x.device) + 1) / ho - 1
+    base = torch.stack([xs.reshape(1, wo).expand(ho, wo), ys.reshape(ho, 1).expand(ho, wo), torch.ones([ho, wo], dtype=x.dtype, device=x.device)], dim=-1)  # [Ho, Wo, 3]
+    g = torch.einsum('hwk,nik->nhwi', base, theta.to(x.dtype))      # [N, Ho, Wo, 2] = (gx, gy)
+    ix = ((g[..., 0] + 1) * w - 1) / 2
+    iy = ((g[..., 1] + 1) * h - 1) / 2
+    x0, y0 = torch.floor(ix), torch.floor(iy)
+    fx, fy = ix - x0, iy - y0
+    flat = x.reshape(n, c, h * w)
+    out = 0
+    for dy, wy in ((0, 1 - fy), (1, fy)):
+        for dx, wx in ((0, 1 - fx), (1, fx)):
+            xc, yc = x0 + dx, y0 + dy
+            ok = ((xc >= 0) & (xc <= w - 1) & (yc >= 0) & (yc <= h - 1)).to(x.dtype)
+            idx = (yc.clamp(0, h - 1) * w + xc.clamp(0, w - 1)).long().reshape(n, 1, ho * wo).expand(n, c, ho * wo)
+            out = out + torch.gather(flat, 2, idx).reshape(n, c, ho, wo) * (wx * wy * ok).unsqueeze(1)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
 # 3x3 convolutions.  The reference leaves them to ATen / cuDNN (call sites: conv2d_gradfix.py:35-43 `conv2d` /
 # `conv_transpose2d`, :100-118 data gradient, :140-170 weight gradient; conv2d_resample.py:113-137 for the stride-2 forms) --
 # third-party arithmetic pinned by the reference only as "pytorch 1.7.1 / 1.9" (environment.yaml:9-11), no tests or golden

@@ -6,6 +6,7 @@ import torch
 
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import fc
+import oracle
 from util import dispatch_assert
 
 pytestmark = pytest.mark.gpu
@@ -38,7 +39,7 @@ def test_dense_forward_and_gradients_vs_fp64(m, k, n, act, bias, normalize):
         assert custom_ops.launch_count() - before == 2, 'backward must be two kernels (data gradient; weight + bias gradient)'
     x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
     b64 = b.double().requires_grad_(True) if bias else None
-    yr = fc.dense_ref(x64, w64, b64, wg, bg, act, normalize)
+    yr = oracle.dense(x64, w64, b64, wg, bg, act, normalize)
     want = torch.autograd.grad(yr, [t for t in (x64, w64, b64) if t is not None], dy.double())
     assert _rel(y.detach(), yr.detach()) < 5e-6
     for a, r, name in zip(got, want, ['dx', 'dw', 'db'] if bias else ['dx', 'dw']):
@@ -55,7 +56,7 @@ def test_dense_second_order_and_fallbacks():
         y = fn(x, w, b, 0.125, 1.0, 'lrelu')
         (gx,) = torch.autograd.grad(y.sum(), x, create_graph=True)
         return torch.autograd.grad(gx.square().sum(), [w])
-    got, want = r1(fc.dense), r1(fc.dense_ref)
+    got, want = r1(fc.dense), r1(oracle.dense)
     assert _rel(got[0], want[0]) < 1e-5
     # 3-D inputs, 16-bit tensors and other activations take the torch composition
     y = fc.dense(x.half(), w.half(), b.half(), act='lrelu')
@@ -117,7 +118,7 @@ def test_dense_with_thousands_of_rows_runs_on_the_tiled_gemm(m, k, n, act):
     custom_ops.prof_disable()
     dispatch_assert(custom_ops.prof_collect()['gemm']['launches'] == 3, 'forward, data gradient and weight gradient are tiled-GEMM launches')
     x64, w64, b64 = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
-    yr = fc.dense_ref(x64, w64, b64, wg, bg, act, False, 1)
+    yr = oracle.dense(x64, w64, b64, wg, bg, act, False, 1)
     want = torch.autograd.grad(yr, [x64, w64, b64], dy.double(), create_graph=True)
     assert _rel(y.detach(), yr.detach()) < 1e-5      # split-bf16 products (tiled GEMM): 4.4e-6 of the result's scale
     for a, r, name in zip(got, want, ['dx', 'dw', 'db']):

@@ -144,3 +144,35 @@ def test_conv3x3_oracle_vs_aten_float64(stride, transposed):
     dw, = torch.autograd.grad(y, wt, dy)
     got_dw = oracle.conv3x3_weight_grad(dy.numpy(), x.numpy(), stride=stride, transposed=transposed)
     assert np.abs(got_dw - dw.numpy()).max() < 1e-11
+
+
+def test_differentiable_comparators_are_pinned():
+    """oracle.dense / demod_coefs_torch / affine_resample (the float64 torch restatements the gradient and second-order GPU tests differentiate):
+    dense against the reference's FullyConnectedLayer formula written out with its own operations (layers.py:126-137; the golden `networks.npz` pins the
+    layers built from it end to end), the demodulation coefficients against the numpy restatement that materialises w[N,O,I,kh,kw] (networks.py:57-62),
+    the resampler against the ATen entry points the reference calls (augment.py:295-297: affine_grid + grid_sample, bilinear, zeros, align_corners False)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn([7, 16], generator=g, dtype=torch.float64)
+    w = torch.randn([5, 16], generator=g, dtype=torch.float64)
+    b = torch.randn([5], generator=g, dtype=torch.float64)
+    for act in ('linear', 'lrelu'):
+        want = torch.addmm((b * 2.0).unsqueeze(0), x, (w * 0.3).t())
+        if act == 'lrelu':
+            want = torch.nn.functional.leaky_relu(want, 0.2) * np.sqrt(2)
+        assert_close(oracle.dense(x, w, b, 0.3, 2.0, act), want, atol=1e-12, rtol=1e-12, what=f'dense {act}')
+    xn = x * (x.square().mean(dim=1, keepdim=True) + 1e-8).rsqrt()
+    assert_close(oracle.dense(x, w, None, 0.3, 1.0, 'linear', True), xn @ (w * 0.3).t(), atol=1e-12, rtol=1e-12, what='dense normalize')
+    wt = torch.randn([6, 5, 3, 3], generator=g, dtype=torch.float64)
+    s = torch.randn([4, 5], generator=g, dtype=torch.float64)
+    assert_close(oracle.demod_coefs_torch(wt, s), oracle.modulated_demod_coefs(wt, s), atol=1e-12, rtol=1e-12, what='demod coefs')
+    img = torch.randn([2, 3, 9, 11], generator=g, dtype=torch.float64)
+    theta = torch.tensor([[0.9, 0.2, 0.05], [-0.15, 1.1, -0.1]], dtype=torch.float64).repeat(2, 1, 1) + 0.3 * torch.randn([2, 2, 3], generator=g, dtype=torch.float64)
+    for out in ((8, 10), (13, 7)):
+        grid = torch.nn.functional.affine_grid(theta, [2, 3, *out], align_corners=False)
+        want = torch.nn.functional.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+        assert_close(oracle.affine_resample(img, theta, out), want, atol=1e-12, rtol=1e-12, what=f'affine_resample {out}')
+    xi = img.clone().requires_grad_(True)
+    y = oracle.affine_resample(xi, theta, (8, 10))
+    (gx,) = torch.autograd.grad(y.square().sum(), xi, create_graph=True)
+    (g2,) = torch.autograd.grad(gx.square().sum(), xi)
+    assert torch.isfinite(g2).all() and g2.abs().sum() > 0      # twice differentiable (torch's grid_sample is not)
