@@ -22,7 +22,8 @@ The single JSON line carries, besides the contract fields:
   roofline_upfirdn2d  the same for the upfirdn2d lane-exchange kernel against the HBM roofline (second half of BASELINE.json's metric)
   kernels       the same accounting for every native kernel family
   cpu_baseline  the same training step on the host CPU through the plain-PyTorch op path (a restatement
-                of the reference's CPU fallback ops), on a bounded sample (1 video = 3 frames per step)
+                of the reference's CPU fallback ops), on a bounded sample (1 video = 3 frames per step): one main iteration and one R1 iteration are timed
+                and weighted by the schedule (Dreg every 16th)
 """
 import argparse
 import json
@@ -96,15 +97,22 @@ def cpu_baseline(res, frames, seconds_cap):
     torch.set_num_threads(threads)
     g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=res, batch_size=1, num_gpus=1, fp32=True, num_frames_per_video=frames)
     ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=1, world_size=1, ddp=False)
-    t0 = time.time()
-    ts.step()  # iteration 0 runs all four phases (incl. the R1 double backward)
-    first = time.time() - t0
-    done, spent = 1, first
-    while spent + first * 0.6 < seconds_cap and done < 4:
+    # The schedule's own mix (training_loop.py:238-252, 351-389): Gmain + Dmain every iteration, Dreg (R1, double backward) every 16th, Greg every 4th (a no-op at
+    # pl_weight 0).  One iteration of each kind is timed -- iteration 1 (main phases only), then iteration 16 (main + Dreg) while the budget allows -- and the
+    # rate is frames / (t_main + (t_16 - t_main) / 16); timing only iteration 0, as rounds 1-2 did, charged the CPU the R1 pass on every iteration.
+    ts.batch_idx = 1
+    t1 = time.time()
+    phases_main = ts.step()
+    t_main = time.time() - t1
+    spent, t_reg, phases_reg = t_main, None, None
+    if spent + 2.6 * t_main < seconds_cap * 1.6:
+        ts.batch_idx = 16
         t1 = time.time()
-        ts.step()
-        spent += time.time() - t1
-        done += 1
+        phases_reg = ts.step()
+        t_reg = time.time() - t1
+        spent += t_reg
+    per_iter = t_main + (max(t_reg - t_main, 0.0) / 16.0 if t_reg is not None else 0.0)
+    done = 1 if t_reg is None else 2
     model = ''
     try:
         with open('/proc/cpuinfo') as fh:
@@ -114,8 +122,11 @@ def cpu_baseline(res, frames, seconds_cap):
                     break
     except OSError:
         pass
-    return dict(value=done * frames / spent, unit='img/s', cores=threads, host_cores=cores, host_logical_cpus=os.cpu_count(), kind='port', cpu=model,
-                sample=f'{done} training iteration(s) at batch 1 video x {frames} frames, {res}x{res}, fp32 (iteration 0 includes Greg+Dreg), {spent:.1f} s')
+    return dict(value=frames / per_iter, unit='img/s', cores=threads, host_cores=cores, host_logical_cpus=os.cpu_count(), kind='port', cpu=model,
+                seconds_main_iteration=t_main, seconds_reg_iteration=t_reg,
+                sample=f'{done} training iteration(s) at batch 1 video x {frames} frames, {res}x{res}, fp32: iteration 1 ({"+".join(phases_main)}) {t_main:.1f} s'
+                       + (f', iteration 16 ({"+".join(phases_reg)}) {t_reg:.1f} s; rate = frames / (t_main + (t_16 - t_main) / 16)' if t_reg is not None
+                          else '; the R1 iteration did not fit the budget and is not charged') + f'; {spent:.1f} s of CPU time')
 
 
 def synthesis_workload(args, world, rank, device):
@@ -236,16 +247,22 @@ def main():
     ap.add_argument('--clips-gpu', type=int, default=1, help='g1024 / g256: clips per GPU and step (configs[4]: 8 clips over 8 GPUs)')
     ap.add_argument('--no-prof', action='store_true', help='skip the per-launch HIP-event accounting')
     ap.add_argument('--clean-steps', type=int, default=-1, help='steps of the un-instrumented repeat of the timed window (value_no_prof); -1 = --steps, 0 disables it')
-    ap.add_argument('--ada-steps', type=int, default=8, help="steps of the aug=ada companion measurement (the reference's default augmentation, bgc pipeline); 0 disables it")
-    ap.add_argument('--bf16-steps', type=int, default=6, help='steps of the bf16-products companion measurement (fp32 tensors, one bf16 MFMA per product); 0 disables it')
-    ap.add_argument('--strict-steps', type=int, default=8, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
-    ap.add_argument('--lowp-steps', type=int, default=8, help="steps of the mixed-precision companion (bf16 tensors in the blocks >= 32^2: the reference's num_fp16_res=4 with bf16, BASELINE config 4); 0 disables it")
-    ap.add_argument('--pl-steps', type=int, default=8, help='steps of the path-length-regularisation companion (F=1, pl_weight=2); 0 disables it')
+    ap.add_argument('--ada-steps', type=int, default=None, help="steps of the aug=ada companion measurement (the reference's default augmentation, bgc pipeline); 0 disables it")
+    ap.add_argument('--bf16-steps', type=int, default=None, help='steps of the bf16-products companion measurement (fp32 tensors, one bf16 MFMA per product); 0 disables it')
+    ap.add_argument('--strict-steps', type=int, default=None, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
+    ap.add_argument('--lowp-steps', type=int, default=None, help="steps of the mixed-precision companion (bf16 tensors in the blocks >= 32^2: the reference's num_fp16_res=4 with bf16, BASELINE config 4); 0 disables it")
+    ap.add_argument('--pl-steps', type=int, default=None, help='steps of the path-length-regularisation companion (F=1, pl_weight=2); 0 disables it')
     ap.add_argument('--aug', choices=['noaug', 'ada'], default='noaug', help="discriminator augmentation: the reference's default is ada (bgc pipeline, adaptive p)")
     ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs (single GPU; pays off at small per-GPU batches)')
     ap.add_argument('--lowp', choices=['none', 'fp16', 'bf16'], default='none',
                     help='mixed precision in the 4 highest resolutions (reference: fp16; BASELINE config 4: bf16). Default: full fp32')
     args = ap.parse_args()
+    # Companion measurements (same models, other arithmetic / augmentation / regulariser): part of the default single-GPU line; a multi-GPU run measures the
+    # scaling of the headline step and leaves them out unless they are asked for (each builds and warms up further models on every rank).
+    multi = args.gpus > 1
+    for name, dflt in (('ada_steps', 8), ('bf16_steps', 6), ('strict_steps', 8), ('lowp_steps', 8), ('pl_steps', 8)):
+        if getattr(args, name) is None:
+            setattr(args, name, 0 if multi else dflt)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         # plain `python bench.py --gpus N`: re-launch as N ranks (one per GPU) under torch.distributed.run; rank 0 prints the line
