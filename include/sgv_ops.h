@@ -50,6 +50,8 @@
  *   sgv_multi_nan_to_num_f32
  *                      <- the `misc.nan_to_num(param.grad, nan=0, posinf=1e5, neginf=-1e5, out=param.grad)` loop of
  *                          src/training/training_loop.py:384-386 as one launch over the whole gradient list
+ *   sgv_multi_scale_f32 <- the equalised learning-rate products `self.weight * (self.weight_gain * self.lr_multiplier)` /
+ *                          `self.bias * self.lr_multiplier` of every Conv2dLayer of a module (src/training/layers.py:184-185) and of their gradients
  *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail src/training/motion.py:201-212
  *   sgv_affine_resample <- `affine_grid` + `grid_sample` of the ADA geometric execution src/training/augment.py:297-300 and its backward
  *                          src/torch_utils/ops/grid_sample_gradfix.py:45-83
@@ -454,6 +456,13 @@ int sgv_fc(const sgv_fc_params* p, void* stream);
  * sanitising loop of src/training/training_loop.py:384-386.  `tensors` / `numels` are HOST arrays of `count` device pointers / element
  * counts; the table is passed in the kernel arguments, nothing is copied or allocated. */
 int sgv_multi_nan_to_num_f32(float* const* tensors, const int64_t* numels, int32_t count, float nan, float posinf, float neginf, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * dst[i] = src[i] * scales[i] over a LIST of dense fp32 tensors in one launch per 64 tensors: the equalised learning-rate scaling of a module's
+ * convolution weights and biases (src/training/layers.py:184-185: `w = self.weight * (self.weight_gain * self.lr_multiplier)`,
+ * `b = self.bias * self.lr_multiplier`, evaluated per layer and again per gradient by the reference).  `src` / `dst` / `numels` / `scales` are HOST
+ * arrays of `count` entries; the table travels in the kernel arguments (capture-safe).  src[i] and dst[i] may be the same tensor. */
+int sgv_multi_scale_f32(const float* const* src, float* const* dst, const int64_t* numels, const float* scales, int32_t count, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Per-launch timing (bench.py roofline leg).  When enabled, every sgv_* launch is bracketed by

@@ -16,7 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, fc, fused_conv_act, fused_down_act, pointwise, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, eqlr, fc, fused_conv_act, fused_down_act, pointwise, upfirdn2d
 
 
 @misc.profiled_function
@@ -135,8 +135,18 @@ class Conv2dLayer(torch.nn.Module):
             # (conv(x, w) + b) * g == conv(x, w * g) + b * g: the gain of a linear, un-clamped layer (the discriminator's skip branches, gain
             # sqrt(0.5)) rides on the weights instead of costing a pass over the output and another over its gradient
             fold, act_gain = act_gain, 1.0
-        w = self.weight * (self.weight_gain * self.lr_multiplier * fold)
-        b = self.bias.to(x.dtype) * (self.lr_multiplier * fold) if self.bias is not None else None
+        ws, bs = self.weight_gain * self.lr_multiplier * fold, self.lr_multiplier * fold
+        self.__dict__['_eqlr_scales'] = (ws, bs)     # what the next eqlr.batched block of the enclosing network prepares for this layer
+        w = eqlr.lookup(self.weight, ws)
+        if w is None:
+            w = self.weight * ws
+        b = None
+        if self.bias is not None:
+            b = eqlr.lookup(self.bias, bs) if x.dtype == self.bias.dtype else None
+            if b is None:
+                b = self.bias.to(x.dtype)
+                if bs != 1.0:     # (a product with 1.0 is the identity bit for bit: no launch for it)
+                    b = b * bs
         return w, b, act_gain, clamp
 
     @staticmethod

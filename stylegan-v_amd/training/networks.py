@@ -29,7 +29,7 @@ import numpy as np
 import torch
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, fma, fused_conv_act, fused_fir_act, modulation, pointwise, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, eqlr, fma, fused_conv_act, fused_fir_act, modulation, pointwise, upfirdn2d
 from .layers import Conv2dLayer, FullyConnectedLayer, GenInput, MappingNetwork, TemporalDifferenceEncoder
 from .motion import MotionMappingNetwork
 
@@ -473,9 +473,10 @@ class Discriminator(torch.nn.Module):
             if self.cfg.dummy_c:
                 c = c * 0.0
         x = None
-        for res in self.block_resolutions:
-            if res == self.cfg.concat_res:
-                x = x.reshape(-1, frames * x.shape[1], *x.shape[2:])  # [B*F, C, h, w] -> [B, F*C, h, w]
-            x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
-        cmap = self.mapping(None, c) if c.shape[1] > 0 else None
-        return {'image_logits': self.b4(x, img, cmap).squeeze(1)}
+        with eqlr.batched(self, Conv2dLayer):   # the equalised-lr products of all convolution layers as one launch (and one for their gradients)
+            for res in self.block_resolutions:
+                if res == self.cfg.concat_res:
+                    x = x.reshape(-1, frames * x.shape[1], *x.shape[2:])  # [B*F, C, h, w] -> [B, F*C, h, w]
+                x, img = getattr(self, f'b{res}')(x, img, **block_kwargs)
+            cmap = self.mapping(None, c) if c.shape[1] > 0 else None
+            return {'image_logits': self.b4(x, img, cmap).squeeze(1)}
