@@ -49,14 +49,14 @@ def log(*a):
 PMC_FILES = ['r03_pmc_bench_step_FETCH_WRITE.json', 'r02_pmc_bench_step_FETCH_WRITE.json', 'r01_pmc_bench_step_v2_FETCH_WRITE.json']   # newest first
 
 
-def pmc_traffic(prefixes, dword_read_prefixes=()):
+def pmc_traffic(prefixes, dword_read_prefixes=(), files=None):
     """HBM-side (L2 miss) bytes per launch of a kernel family from the newest committed rocprofv3 PMC summary
     (tools/pmc_summary.py over separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command: bench.py cannot
     collect counters on itself).  gfx950 correction per MI355X_MICROARCH.md: FETCH_SIZE counts half of a wide coalesced read,
     so reads are doubled for kernels that read with 16-B loads (calibrated on a float4 copy,
     profiles/r01_pmc_headline_call_FETCH_WRITE.json); kernels reading with dword loads are taken as is; WRITE_SIZE is exact.
     Returns (bytes per launch or None, description of the source incl. the commit the counters were collected on)."""
-    for fname in PMC_FILES:
+    for fname in (files or PMC_FILES):
         path = os.path.join(ROOT, 'profiles', fname)
         try:
             with open(path) as fh:
@@ -80,8 +80,8 @@ def pmc_traffic_conv_family():
                         'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
 
 
-def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_fir_asm', 'upfirdn2d_tile')):
-    return pmc_traffic(tuple(prefixes))
+def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_fir_asm', 'upfirdn2d_tile'), files=None):
+    return pmc_traffic(tuple(prefixes), files=files)
 
 
 def cpu_baseline(res, frames, seconds_cap):
@@ -195,11 +195,12 @@ def synthesis_workload(args, world, rank, device):
         if 'upfirdn2d_lanes' in fam:
             r = fam['upfirdn2d_lanes']
             achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
+            pmc_g = pmc_traffic_per_launch(files=[f'r03_pmc_{args.workload}_FETCH_WRITE.json'])     # this workload's own counter passes, when committed
             roofline = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel (the FIR / 2x up-sampling chain of the synthesis network)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS,
-                            unit='GB/s', frac=achieved / HBM_PEAK_GBPS, frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=None, launches=r['launches'],
+                            unit='GB/s', frac=achieved / HBM_PEAK_GBPS, frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_g[0], traffic_source=pmc_g[1] + ' (reads x2, gfx950 correction)', launches=r['launches'],
                             launches_per_forward=r['launches'] / args.steps, algorithmic_bytes_per_forward=r['bytes'] / args.steps, avg_launch_us=1e3 * r['ms'] / r['launches'],
                             share_of_forward_time=r['ms'] / (1e3 * elapsed),
-                            note='size-weighted over every upfirdn2d launch of the timed forwards (HIP events recorded by the C ABI on the launch stream); no PMC pass for this workload')
+                            note='size-weighted over every upfirdn2d launch of the timed forwards (HIP events recorded by the C ABI on the launch stream)')
             by_size = [dict(algorithmic_MB=b / 1e6, launches=n, avg_us=1e3 * ms / n, GBps=b * n / (ms * 1e-3) / 1e9, share_of_family_time=ms / r['ms']) for b, (n, ms) in sorted(sizes.items(), reverse=True)]
         cpu = None
         if world == 1 and args.cpu_seconds > 0:

@@ -27,10 +27,16 @@ int small_samples(int n, int h, int w) {
 bool io16(int dtype) { return dtype == SGV_BF16 || dtype == SGV_F16; }
 
 // 16-bit tensors (bf16 / fp16 activations, fp32 weights): the producer / consumer kernels only (images >= 32 pixels), single bf16 operands (terms = 1)
+// Output channels: whole 64-channel tiles; the producer / consumer kernels (images >= 32 pixels) also take a half-full last tile (m % 32 == 0: the 32-channel
+// layers of the 1024^2 synthesis network, BASELINE configs[4]) -- its upper 32 rows are zero weights and are not stored.  SGV_CONV_M32=0 switches that off.
+int tiles_m(int m) { return (m + TM - 1) / TM; }
+bool half_tiles_on() { static const bool on = !(getenv("SGV_CONV_M32") && getenv("SGV_CONV_M32")[0] == '0'); return on; }
+
 bool supported(int n, int k, int m, int h, int w, int dtype) {
-    if (!((dtype == SGV_F32 || io16(dtype)) && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && (int64_t)n * std::max(k, m) * h * w <= INT32_MAX)) return false;
-    if (w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0) return true;
-    return dtype == SGV_F32 && small_samples(n, h, w) > 0;
+    if (!((dtype == SGV_F32 || io16(dtype)) && n >= 1 && k >= KC && k % KC == 0 && m >= 32 && m % 32 == 0 && (int64_t)n * std::max(k, m) * h * w <= INT32_MAX)) return false;
+    const bool whole = m % TM == 0;
+    if (w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0) return whole || half_tiles_on();
+    return whole && dtype == SGV_F32 && small_samples(n, h, w) > 0;
 }
 
 std::once_flag g_attr_once;
@@ -103,8 +109,9 @@ void init_once() {
     if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) g_cus = prop.multiProcessorCount;
 }
 
-bool supported_s2(int n, int k, int m, int h, int w, int dtype) {   // h, w: the small (H x W) grid
-    return (dtype == SGV_F32 || io16(dtype)) && n >= 1 && k >= KC && k % KC == 0 && m >= TM && m % TM == 0 && w >= SEG && w % SEG == 0 && h >= S_ROWS && h % S_ROWS == 0 &&
+bool supported_s2(int n, int k, int m, int h, int w, int dtype, int mode = 0) {   // h, w: the small (H x W) grid; mode 2 (transposed, producer / consumer kernel): also m % 32 == 0
+    const bool m_ok = m >= TM && m % TM == 0 ? true : (mode == 2 && g_s2_ws && g_edge_mfma && half_tiles_on() && m >= 32 && m % 32 == 0);
+    return (dtype == SGV_F32 || io16(dtype)) && n >= 1 && k >= KC && k % KC == 0 && m_ok && w >= SEG && w % SEG == 0 && h >= S_ROWS && h % S_ROWS == 0 &&
            (int64_t)n * std::max(k, m) * (2 * h + 1) * (2 * w + 1) <= INT32_MAX;
 }
 
@@ -128,7 +135,7 @@ extern "C" int sgv_conv3x3_supported(int32_t n, int32_t c_in, int32_t c_out, int
 }
 
 extern "C" int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out) {
-    return (int64_t)c_in * c_out * 9 * 4;   // bf16 hi + lo per weight
+    return (int64_t)c_in * ((c_out + TM - 1) / TM * TM) * 9 * 4;   // bf16 hi + lo per weight, whole 64-row tiles
 }
 
 namespace {
@@ -153,7 +160,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "%s: hipFuncSetAttribute failed: %s", who, hipGetErrorString(g_attr_err));
     hipStream_t stream = (hipStream_t)stream_;
 
-    const int words = (p->c_out / TM) * (p->c_in / KC) * 9 * 2 * TM;
+    const int words = tiles_m(p->c_out) * (p->c_in / KC) * 9 * 2 * TM;
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
                        p->terms);
     int rc = sgv_check_launch("conv3x3_prep_weights");
@@ -163,7 +170,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     kp.x = (const float*)p->x; kp.wprep = (const u32x4*)p->workspace; kp.y = (float*)p->y;
     kp.n = p->n; kp.k = p->c_in; kp.m = p->c_out; kp.h = p->h; kp.w = p->w;
     const int small = big_image(p->h, p->w) ? 0 : small_samples(p->n, p->h, p->w);
-    kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * (p->c_out / TM);
+    kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * tiles_m(p->c_out);
     kp.grid = std::min(kp.tiles, g_cus);
     const double elems = (double)p->n * p->h * p->w;
     const double es = io16(dtype) ? 2.0 : 4.0;
@@ -179,7 +186,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
         sgv_note_variant(SGV_V_conv_small);
         return sgv_check_launch("conv3x3_small_kernel");
     }
-    if (ep || g_use_ws || io16(dtype)) {
+    if (ep || g_use_ws || io16(dtype) || p->c_out % TM != 0) {     // (half-full m tiles: the producer / consumer kernel only)
         conv_ws_params wp{};
         wp.c = kp;
         int pro = 0, epi = 0;
@@ -225,7 +232,7 @@ extern "C" int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, 
 }
 
 extern "C" int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode) {
-    int64_t bytes = (int64_t)c_in * c_out * 10 * 4;   // nine taps, ten in the tap-pair layout of conv3x3_s2_pairs_kernel
+    int64_t bytes = (int64_t)c_in * ((c_out + TM - 1) / TM * TM) * 10 * 4;   // nine taps, ten in the tap-pair layout of conv3x3_s2_pairs_kernel; whole 64-row tiles
     if (mode == 2) bytes += (int64_t)convT3x3_s2_edge_floats(n, c_in, c_out, h, w) * 4;
     return bytes;
 }
@@ -239,7 +246,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     std::call_once(g_attr_once, init_once);
     if (p->mode != 0 && p->mode != 2) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: mode must be 0 (strided convolution) or 2 (transposed convolution)");
     const bool packed = g_s2_ws && supported_s2_packed(p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
-    if ((!packed && !supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype)) || !s2_mode_ok(p->c_out, p->h, p->mode, dtype))
+    if ((!packed && !supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype, p->mode)) || !s2_mode_ok(p->c_out, p->h, p->mode, dtype))
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs c_in %% 16 == 0, c_out %% 64 == 0, W %% 32 == 0, H %% 8 == 0 on the HxW grid; 16-bit tensors: the strided form with c_out %% 128 == 0, the transposed form with the MFMA edge strips (got n=%d c_in=%d c_out=%d h=%d w=%d mode=%d dtype=%d)",
                         p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms must be 1 or 3");
@@ -265,7 +272,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         hipLaunchKernelGGL(conv3x3_prep_weights_pairs, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->terms);
         rc = sgv_check_launch("conv3x3_prep_weights_pairs");
     } else {
-        const int words = (p->c_out / TM) * (p->c_in / KC) * 9 * 2 * TM;
+        const int words = tiles_m(p->c_out) * (p->c_in / KC) * 9 * 2 * TM;
         hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
                            p->terms);
         rc = sgv_check_launch("conv3x3_prep_weights");
@@ -314,7 +321,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     }
     if (io) {
         const int ss = packed ? 32 / p->w : 1;
-        kp.tiles = ss == 1 ? p->n * (p->h / TW_ROWS) * (p->w / SEG) * (p->c_out / TM) : (p->n / ss) * (p->h / TW_ROWS) * (p->c_out / TM);
+        kp.tiles = ss == 1 ? p->n * (p->h / TW_ROWS) * (p->w / SEG) * tiles_m(p->c_out) : (p->n / ss) * (p->h / TW_ROWS) * (p->c_out / TM);
         kp.grid = std::min(kp.tiles, g_cus);
 #define SGV_TW_GO(SS, IO) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<1, 0, SS, IO>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(SS), stream, kp)
 #define SGV_TW_S(IO) do { if (ss == 1) SGV_TW_GO(1, IO); else if (ss == 2) SGV_TW_GO(2, IO); else SGV_TW_GO(4, IO); } while (0)
@@ -334,7 +341,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
             else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
         }
     } else if (g_s2_ws) {
-        kp.tiles = p->n * (p->h / TW_ROWS) * (p->w / SEG) * (p->c_out / TM);
+        kp.tiles = p->n * (p->h / TW_ROWS) * (p->w / SEG) * tiles_m(p->c_out);
         kp.grid = std::min(kp.tiles, g_cus);
         if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_ws_kernel<1>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL(convT3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
@@ -359,7 +366,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     // last output row (oy = 2H) and column (ox = 2W): 0.4 % of the flops on the fp32 matrix pipe, after one pass that lays the six weight taps
     // and the last input column out contiguously
     {
-        float* edge = (float*)((char*)p->workspace + (size_t)p->c_in * p->c_out * 10 * 4);
+        float* edge = (float*)((char*)p->workspace + (size_t)p->c_in * (tiles_m(p->c_out) * TM) * 10 * 4);
         const size_t prep = convT3x3_s2_edge_we_floats(p->c_in, p->c_out) + (size_t)p->n * p->c_in * p->h;
         const size_t prep_io = prep + (size_t)p->n * p->c_in * p->w;   // 16-bit tensors: the last input row is gathered as fp32 as well
         const dim3 eg((unsigned)((std::max(p->h, p->w) + 1 + 31) / 32), (unsigned)(p->n * (p->c_out / 32)), 2);
@@ -397,7 +404,7 @@ extern "C" int sgv_conv3x3_s2_fused(const sgv_conv3x3_params* p, const sgv_conv3
 
 extern "C" int sgv_conv3x3_s2_supported_mode(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode, int dtype) {
     std::call_once(g_attr_once, init_once);
-    return (supported_s2(n, c_in, c_out, h, w, dtype) || (g_s2_ws && supported_s2_packed(n, c_in, c_out, h, w, mode, dtype))) && s2_mode_ok(c_out, h, mode, dtype) ? 1 : 0;
+    return (supported_s2(n, c_in, c_out, h, w, dtype, mode) || (g_s2_ws && supported_s2_packed(n, c_in, c_out, h, w, mode, dtype))) && s2_mode_ok(c_out, h, mode, dtype) ? 1 : 0;
 }
 
 extern "C" int sgv_conv3x3_s2_fused_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {

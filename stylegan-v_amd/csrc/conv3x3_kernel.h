@@ -85,7 +85,7 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nblocks) {
 }
 
 __device__ __forceinline__ tile_pos decode_tile(const conv_params& p, int tile, int trows = TROWS) {
-    const int mts = p.m / TM, segs = p.w / SEG, rbs = p.h / trows;
+    const int mts = (p.m + TM - 1) / TM, segs = p.w / SEG, rbs = p.h / trows;   // (a last m tile may be half full: m % 32 == 0, conv3x3_ws_kernel only)
     tile_pos tp;
     tp.mt = tile % mts;
     int r = tile / mts;
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
 __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x4* out, int m_total, int k_total, int mode, int terms) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // one 16-B output word (8 k) of the hi plane
     const int chunks = k_total / KC;
-    const int total = (m_total / TM) * chunks * 9 * 2 * TM;
+    const int total = ((m_total + TM - 1) / TM) * chunks * 9 * 2 * TM;     // rows beyond m_total (a half-full last tile) are zero weights
     if (idx >= total) return;
     int r = idx;
     const int mi = r % TM; r /= TM;
@@ -446,7 +446,8 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; j++)
-        v[j] = mode == 0 ? w[(((size_t)m * k_total + k0 + j) * 3 + ky) * 3 + kx]
+        v[j] = m >= m_total ? 0.f
+             : mode == 0 ? w[(((size_t)m * k_total + k0 + j) * 3 + ky) * 3 + kx]
              : mode == 1 ? w[(((size_t)(k0 + j) * m_total + m) * 3 + (2 - ky)) * 3 + (2 - kx)]
                          : w[(((size_t)(k0 + j) * m_total + m) * 3 + ky) * 3 + kx];
     u32x4 hi, lo;

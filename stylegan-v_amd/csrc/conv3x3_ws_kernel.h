@@ -154,7 +154,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 // the tile's output scale and bias (consumed by put_ep with the tile's LAST chunk) travel with every chunk's set as two more counted
                 // loads: as plain C++ loads inside put_ep the compiler put `s_waitcnt vmcnt(0)` in front of their use, which drained the chunk
                 // prefetch queue once per tile (64-channel layers: 4 chunks per tile)
-                const int m = tp.mt * TM + (pt & (TM - 1));
+                const int m = min(tp.mt * TM + (pt & (TM - 1)), p.m - 1);     // (a half-full last m tile: its upper rows are never stored)
                 const float* po = pp.oscale ? pp.oscale + (size_t)tp.n * p.m + m : (const float*)p.x;
                 const float* pb = pp.bias ? pp.bias + m : (const float*)p.x;
                 asm volatile("global_load_dword %0, %1, off" : "=v"(r.ep0) : "v"(po) : "memory");
@@ -411,10 +411,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
             auto store_tile = [&](auto clamped) {
                 constexpr bool CLAMP = decltype(clamped)::value;
                 const float clamp_hi = pp.clamp;
+                const int m_left = p.m - tp.mt * TM;     // output channels of this tile that exist: 64, or 32 in a half-full last tile (wave-uniform)
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
 #pragma unroll
                     for (int e4 = 0; e4 < 4; e4++) {
+                        if (hf * 32 >= m_left) {     // the padded half: zero weights in, nothing out
+#pragma unroll
+                            for (int r = 0; r < 4; r++)
+#pragma unroll
+                                for (int ei = 0; ei < 4; ei++) acc[r][hf][4 * e4 + ei] = 0.f;
+                            continue;
+                        }
                         const int m0 = hf * 32 + 8 * e4 + 4 * g;
                         f32x4 c0, c1, c2, c3;
                         if (EPI == 1) { c0 = *(const f32x4*)(ep + m0); c1 = *(const f32x4*)(ep + TM + m0); c2 = *(const f32x4*)(ep + 2 * TM + m0); c3 = *(const f32x4*)(ep + 3 * TM + m0); }

@@ -614,7 +614,7 @@ constexpr int TW_LDS_BYTES = tw_lds_bytes(1);
 
 template <int S>
 __device__ __forceinline__ tile_pos decode_tile_tw(const s2_params& p, int tile) {   // tp.n = first sample of the tile
-    const int mts = p.m / TM, rbs = p.h / TW_ROWS;
+    const int mts = (p.m + TM - 1) / TM, rbs = p.h / TW_ROWS;     // (a last m tile may be half full: m % 32 == 0)
     tile_pos tp;
     tp.mt = tile % mts;
     int r = tile / mts;
@@ -824,6 +824,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
             asm volatile("" : "+v"(le));
             const int g = le >> 5;
             const size_t yb = ((size_t)(tp.n + (le & 31) / SW) * p.m + tp.mt * TM) * plane_out + (size_t)(2 * (tp.y0 + wave)) * wout + 2 * (tp.x0 + (le & 31) % SW);
+            const int m_left = p.m - tp.mt * TM;     // 64, or 32 in a half-full last m tile (wave-uniform): the padded half has zero weights and is not stored
 #pragma unroll
             for (int a2 = 0; a2 < 2; a2++)
 #pragma unroll
@@ -832,6 +833,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
                     for (int e = 0; e < 16; e++) {
                         const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
                         const size_t qd = yb + (size_t)m * plane_out + (size_t)a2 * wout;
+                        if (hf * 32 >= m_left) { acc[a2 * 2 + 0][hf][e] = 0.f; acc[a2 * 2 + 1][hf][e] = 0.f; continue; }
                         if (ABL == 8 || ABL == 10) { asm volatile("" :: "v"(acc[a2 * 2 + 0][hf][e])); asm volatile("" :: "v"(acc[a2 * 2 + 1][hf][e])); }   // lab: no stores
                         else {
                             out_store<IO>(p.y, qd, acc[a2 * 2 + 0][hf][e]);

@@ -80,7 +80,13 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     assert lib.sgv_conv3x3_supported(31, 512, 512, 16, 16, F32) == 0
     assert lib.sgv_conv3x3_supported(96, 512, 512, 4, 4, F32) == 0
     assert lib.sgv_conv3x3_supported(96, 3, 64, 256, 256, F32) == 0
-    assert lib.sgv_conv3x3_supported(96, 64, 32, 256, 256, F32) == 0
+    assert lib.sgv_conv3x3_supported(96, 64, 48, 256, 256, F32) == 0
+    # ... or c_out % 32 on the big-image (producer / consumer) kernel: a half-full last tile (the 32-channel layers of the 1024^2 synthesis network)
+    assert lib.sgv_conv3x3_supported(16, 64, 32, 1024, 1024, F32) == 1
+    assert lib.sgv_conv3x3_supported(96, 32, 96, 256, 256, custom_ops.SGV_BF16) == 1
+    assert lib.sgv_conv3x3_supported(96, 512, 32, 16, 16, F32) == 0
+    assert lib.sgv_conv3x3_fused_supported(16, 32, 32, 1024, 1024, F32) == 1
+    assert lib.sgv_conv3x3_workspace_bytes(64, 32) == 64 * 64 * 9 * 4      # whole 64-row tiles
     # 16-bit tensors (fp32 weights and accumulate): the producer / consumer kernel of the big images only
     assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, F16) == 1
     assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, custom_ops.SGV_BF16) == 1
@@ -92,6 +98,8 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 8, 32, F32) == 1
     assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 16, 16, F32) == 0
     assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 12, 32, F32) == 0
+    assert lib.sgv_conv3x3_s2_supported_mode(16, 64, 32, 512, 512, 2, F32) == 1      # transposed form: c_out % 32 (half-full last tile)
+    assert lib.sgv_conv3x3_s2_supported_mode(16, 64, 32, 512, 512, 0, F32) == 0      # the strided form keeps whole tiles
     ws_strided = lib.sgv_conv3x3_s2_workspace_bytes(4, 64, 128, 16, 32, 0)
     ws_transposed = lib.sgv_conv3x3_s2_workspace_bytes(4, 64, 128, 16, 32, 2)
     assert ws_strided == 64 * 128 * 10 * 4   # ten taps: the tap-pair layout of the strided kernel pads the ninth pair

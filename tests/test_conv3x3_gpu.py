@@ -17,7 +17,8 @@ def _rel(a, ref):
 
 
 @pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (1, 16, 128, 16, 64), (3, 128, 64, 48, 32), (1, 80, 192, 32, 96), (5, 32, 64, 16, 32),
-                                          (4, 64, 128, 16, 16), (6, 32, 64, 16, 16), (16, 48, 64, 8, 8), (8, 128, 192, 8, 8)])
+                                          (4, 64, 128, 16, 16), (6, 32, 64, 16, 16), (16, 48, 64, 8, 8), (8, 128, 192, 8, 8),
+                                          (2, 32, 32, 32, 64), (1, 64, 32, 16, 32), (2, 48, 96, 32, 32), (3, 32, 32, 16, 32)])     # c_out % 32: a half-full last tile
 @pytest.mark.parametrize('transposed', [False, True])
 def test_conv3x3_matches_fp64(n, ci, co, h, w, transposed):
     g = torch.Generator().manual_seed(n + ci + co + h)
@@ -69,7 +70,9 @@ def test_conv3x3_unsupported_shapes_use_the_vendor_library():
     assert lib.sgv_conv3x3_supported(4, 64, 64, 8, 8, 0) == 0     # 8x8 images in groups of 8
     assert lib.sgv_conv3x3_supported(4, 64, 64, 4, 4, 0) == 0
     assert lib.sgv_conv3x3_supported(4, 3, 64, 32, 32, 0) == 0    # c_in % 16
-    assert lib.sgv_conv3x3_supported(4, 64, 48, 32, 32, 0) == 0   # c_out % 64
+    assert lib.sgv_conv3x3_supported(4, 64, 48, 32, 32, 0) == 0   # c_out % 32
+    assert lib.sgv_conv3x3_supported(4, 64, 32, 32, 32, 0) == 1   # a half-full last tile on the producer / consumer kernel ...
+    assert lib.sgv_conv3x3_supported(4, 64, 32, 16, 16, 0) == 0   # ... which the 16x16 / 8x8 form is not
     assert lib.sgv_conv3x3_supported(4, 64, 64, 24, 32, 0) == 0   # H % 16
     assert lib.sgv_conv3x3_supported(4, 64, 64, 32, 32, 2) == 1   # bf16 tensors: the producer / consumer kernel (tests/test_conv_lowp_gpu.py)
     assert lib.sgv_conv3x3_supported(4, 64, 64, 16, 16, 2) == 0   # ... which the 16x16 / 8x8 form is not
@@ -85,7 +88,7 @@ def test_conv3x3_unsupported_shapes_use_the_vendor_library():
     assert not conv2d_gradfix._native_conv_ok(torch.randn([2, 64, 32, 32], device=DEV), w, (False, (1, 1), (0, 0), (0, 0), (1, 1), 1))
 
 
-@pytest.mark.parametrize('n,cb,cs,h,w', [(2, 64, 64, 8, 32), (1, 16, 128, 16, 64), (3, 128, 64, 24, 32), (1, 32, 64, 8, 96)])
+@pytest.mark.parametrize('n,cb,cs,h,w', [(2, 64, 64, 8, 32), (1, 16, 128, 16, 64), (3, 128, 64, 24, 32), (1, 32, 64, 8, 96), (2, 96, 32, 8, 32), (2, 32, 48, 16, 64)])
 @pytest.mark.parametrize('transposed', [False, True])
 def test_conv3x3_stride2_family_matches_fp64(n, cb, cs, h, w, transposed):
     """cb channels on the (2h+1)x(2w+1) side, cs on the h x w side: strided maps big -> small, transposed small -> big."""
@@ -94,8 +97,8 @@ def test_conv3x3_stride2_family_matches_fp64(n, cb, cs, h, w, transposed):
     if transposed:
         x = (torch.randn([n, cs, h, w], generator=g) + 0.3).to(DEV)
         wt = (torch.randn([cs, cb, 3, 3], generator=g) / (3 * cs ** 0.5)).to(DEV)
-        if cb % 64:
-            pytest.skip('c_out % 64')
+        if cb % 32:
+            pytest.skip('c_out % 32')      # (the transposed producer / consumer kernel takes a half-full last tile)
     else:
         x = (torch.randn([n, cb, hb, wb], generator=g) + 0.3).to(DEV)
         wt = (torch.randn([cs, cb, 3, 3], generator=g) / (3 * cb ** 0.5)).to(DEV)

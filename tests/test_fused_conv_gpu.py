@@ -42,7 +42,7 @@ def _rel(a, ref):
     return (a.double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-30)
 
 
-@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (3, 48, 128, 16, 64), (1, 128, 64, 48, 32)])
+@pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (3, 48, 128, 16, 64), (1, 128, 64, 48, 32), (2, 32, 32, 32, 64), (1, 64, 96, 16, 32)])     # (the last two: c_out % 32)
 @pytest.mark.parametrize('modulated,act,clamp', [(True, 'lrelu', None), (True, 'lrelu', 0.8), (False, 'lrelu', None), (True, 'linear', None), (False, 'linear', None)])
 def test_fused_layer_forward_and_gradients_vs_oracle(n, ci, co, h, w, modulated, act, clamp):
     g = torch.Generator().manual_seed(n * 7 + ci + co + h)
