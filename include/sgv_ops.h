@@ -274,7 +274,8 @@ int sgv_conv3x3_wrw_s2_supported(int32_t n, int32_t c_small, int32_t c_big, int3
  *   mode 0:  y[n,m,Y,X] = sum_{k,ky,kx} weight[m][k][ky][kx]     * x[n,k,Y+ky-1,X+kx-1]     weight: [c_out, c_in, 3, 3]
  *   mode 1:  y[n,m,Y,X] = sum_{k,ky,kx} weight[k][m][2-ky][2-kx] * x[n,k,Y+ky-1,X+kx-1]     weight: [c_in, c_out, 3, 3]
  *            (= conv_transpose2d(x, weight, stride 1, padding 1): the gradient w.r.t. the input of the mode-0 layer)
- * Shapes: c_in % 16 == 0, c_out % 64 == 0, and either w % 32 == 0 && h % 16 == 0 or whole 16x16 / 8x8 images (n % 2 resp. n % 8 == 0).
+ * Shapes: c_in % 16 == 0, c_out % 64 == 0, and either w % 32 == 0 && h % 16 == 0 or whole 16x16 / 8x8 images (n % 2 resp. n % 8 == 0); on the
+ * w % 32 == 0 && h % 16 == 0 images also c_out % 32 == 0 (a half-full last 64-row tile; sgv_conv3x3_workspace_bytes counts whole tiles).
  * fp32 tensors, arithmetic as sgv_conv3x3_wrw (terms = 3: bf16x3 fp32 emulation; 1: bf16 products).  `workspace` is
  * sgv_conv3x3_workspace_bytes() of device scratch for the re-laid-out weights (owned by the caller, written per call).
  *
@@ -302,7 +303,8 @@ typedef struct sgv_conv3x3_params {
  *   mode 0:  y[n,m,Y,X]        = sum_{k,ky,kx} weight[m][k][ky][kx] * x[n,k,2Y+ky,2X+kx]      x big -> y small (conv2d, stride 2)
  *   mode 2:  y[n,m,2Y+ky,2X+kx] += weight[k][m][ky][kx] * x[n,k,Y,X]                          x small -> y big (conv_transpose2d, stride 2)
  * These are the convolutions either side of the FIR in the reference's down- and up-sampling layers
- * (conv2d_resample.py:113-137) and each other's data gradients.
+ * (conv2d_resample.py:113-137) and each other's data gradients.  Shapes: sgv_conv3x3_s2_supported_mode (c_in % 16, c_out % 64 -- mode 2 also
+ * c_out % 32 --, w % 32, h % 8 on the small grid, or w in {16, 8} with packed samples).
  */
 int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream);
 int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream);

@@ -144,7 +144,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: params is NULL", who);
     if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: NULL pointer", who);
     if (!supported(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32 / bf16 / fp16 tensors, c_in %% 16 == 0, c_out %% 64 == 0, and W %% 32 == 0, H %% 16 == 0 (fp32 also: 16x16 / 8x8 images) (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32 / bf16 / fp16 tensors, c_in %% 16 == 0, c_out %% 32 == 0, and W %% 32 == 0, H %% 16 == 0 (fp32 with c_out %% 64 == 0 also: 16x16 / 8x8 images) (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
                         who, p->n, p->c_in, p->c_out, p->h, p->w, dtype);
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: 16-bit tensors need terms = 1 (one bf16 operand per value)", who);
     if (io16(dtype) && ep && ep->accumulate) return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: accumulate needs fp32 tensors", who);
@@ -247,7 +247,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     if (p->mode != 0 && p->mode != 2) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: mode must be 0 (strided convolution) or 2 (transposed convolution)");
     const bool packed = g_s2_ws && supported_s2_packed(p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
     if ((!packed && !supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype, p->mode)) || !s2_mode_ok(p->c_out, p->h, p->mode, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs c_in %% 16 == 0, c_out %% 64 == 0, W %% 32 == 0, H %% 8 == 0 on the HxW grid; 16-bit tensors: the strided form with c_out %% 128 == 0, the transposed form with the MFMA edge strips (got n=%d c_in=%d c_out=%d h=%d w=%d mode=%d dtype=%d)",
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs c_in %% 16 == 0, c_out %% 64 == 0 (transposed form: %% 32), W %% 32 == 0, H %% 8 == 0 on the HxW grid; 16-bit tensors: the strided form with c_out %% 128 == 0, the transposed form with the MFMA edge strips (got n=%d c_in=%d c_out=%d h=%d w=%d mode=%d dtype=%d)",
                         p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
     if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms must be 1 or 3");
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: 16-bit tensors need terms = 1 (one bf16 operand per value)");
