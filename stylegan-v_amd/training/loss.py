@@ -11,6 +11,7 @@ StyleGAN-V config disables it (``pl_weight: 0``).  The same ``RuntimeError`` sur
 """
 
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -33,6 +34,11 @@ class StyleGAN2Loss:
         loss_kwargs = getattr(getattr(cfg, 'model', None), 'loss_kwargs', None)
         self.video_consistent_aug = bool(loss_kwargs.get('video_consistent_aug', False)) if hasattr(loss_kwargs, 'get') else False
         self.frames = cfg.sampling.num_frames_per_video
+        # SGV_D_CONCAT=1 (off by default; `d_concat`): the Dmain phase runs the discriminator ONCE on [generated clips, real clips] instead of twice --
+        # the same two loss terms, the same gradients (their sum), half the launches of the phase, twice the batch for the small-resolution layers, and no
+        # second accumulation pass over every parameter gradient.  The only cross-sample operation of D, the minibatch-std layer, keeps its groups inside
+        # each half (MinibatchStdLayer.segments).  Equivalence: tests/test_networks.py (CPU).
+        self.d_concat = os.environ.get('SGV_D_CONCAT', '0') == '1'
 
     def run_G(self, z, c, t, sync):
         with misc.ddp_sync(self.G_mapping, sync):
@@ -44,6 +50,18 @@ class StyleGAN2Loss:
         with misc.ddp_sync(self.G_synthesis, sync):
             img = self.G_synthesis(ws, t=t, c=c)
         return img, ws
+
+    @contextlib.contextmanager
+    def _mbstd_segments(self, segments):
+        from .networks import MinibatchStdLayer
+        layers = [m for m in self.D.modules() if isinstance(m, MinibatchStdLayer)]
+        for m in layers:
+            m.segments = segments
+        try:
+            yield
+        finally:
+            for m in layers:
+                m.segments = 1
 
     def run_D(self, img, c, t, sync):
         if self.augment_pipe is not None:
@@ -85,6 +103,18 @@ class StyleGAN2Loss:
             loss_pl = (pl_lengths - pl_mean).square() * self.pl_weight
             (gen_img[:, 0, 0, 0] * 0 + loss_pl).mean().mul(gain).backward()
             out['G/reg'] = loss_pl.detach().mean()
+
+        if do_Dmain and not do_Dr1 and self.d_concat and len(gen_z) == len(real_c):
+            with torch.no_grad():
+                gen_img, _ = self.run_G(gen_z, gen_c, gen_t, sync=False)
+            with self._mbstd_segments(2):
+                logits = self.run_D(torch.cat([gen_img, real_img.detach()]), torch.cat([gen_c, real_c]), torch.cat([gen_t, real_t]), sync=sync)['image_logits']
+            logits_gen, logits_real = logits[:len(gen_z)], logits[len(gen_z):]
+            loss_Dgen, loss_Dreal = F.softplus(logits_gen), F.softplus(-logits_real)
+            out['signs_real'] = logits_real.detach().sign().mean()
+            out['D/loss'] = (loss_Dgen + loss_Dreal).detach().mean()
+            (loss_Dgen.mean() + loss_Dreal.mean()).mul(gain).backward()
+            return out
 
         loss_Dgen = 0
         if do_Dmain:  # minimise logits of generated clips (G frozen)

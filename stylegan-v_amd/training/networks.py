@@ -386,11 +386,21 @@ class MinibatchStdLayer(torch.nn.Module):
     def __init__(self, group_size, num_channels=1):
         super().__init__()
         self.group_size, self.num_channels = group_size, num_channels
+        self.segments = 1   # > 1: the batch is that many independent batches back to back (loss.py: generated + real clips in one pass); groups never straddle them
 
     def forward(self, x):
         n, c, h, w = x.shape
-        g = min(self.group_size, n) if self.group_size is not None else n
         f = self.num_channels
+        s = self.segments if self.segments > 1 and n % self.segments == 0 else 1
+        if s > 1:
+            ns = n // s
+            g = min(self.group_size, ns) if self.group_size is not None else ns
+            y = x.reshape(s, g, -1, f, c // f, h, w)       # [S, G, ns/G, F, c, H, W]: sample s*ns + r*(ns/G) + m is member r of group m of segment s, as below
+            y = y - y.mean(dim=1, keepdim=True)
+            y = (y.square().mean(dim=1) + 1e-8).sqrt()     # [S, ns/G, F, c, H, W]
+            y = y.mean(dim=[3, 4, 5]).reshape(s, -1, f, 1, 1)
+            return torch.cat([x, y.repeat(1, g, 1, h, w).reshape(n, f, h, w)], dim=1)
+        g = min(self.group_size, n) if self.group_size is not None else n
         y = x.reshape(g, -1, f, c // f, h, w)          # [G, n/G, F, c, H, W]
         y = y - y.mean(dim=0)
         y = (y.square().mean(dim=0) + 1e-8).sqrt()     # std over the group
