@@ -220,7 +220,7 @@ __global__ __launch_bounds__(256) void scale_dot_kernel(const T* __restrict__ a,
 extern "C" int sgv_act_grad_scale_t(const void* dy, const void* y, const float* d, void* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
                                     float gain, float clamp, int dtype, void* stream_) {
     if (!dy || !y || !out) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: NULL pointer");
-    if (planes < 1 || hw < 1 || planes > 65535) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: needs 1 <= planes <= 65535, hw >= 1");
+    if (planes < 1 || hw < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: needs planes >= 1, hw >= 1");
     if ((int64_t)planes * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "act_grad_scale: tensors are too large");
     if (act != 1 && act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "act_grad_scale: act must be 1 (linear) or 3 (lrelu)");
     const size_t es = sgv_dtype_size(dtype);
@@ -228,10 +228,20 @@ extern "C" int sgv_act_grad_scale_t(const void* dy, const void* y, const float* 
     hipStream_t stream = (hipStream_t)stream_;
     sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * (double)es);
     const int vec_ok = (hw % (16 / (int)es) == 0) && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
-    dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)planes);
-    if (dtype == SGV_F32) hipLaunchKernelGGL(act_grad_scale_kernel<float>, grid, dim3(256), 0, stream, (const float*)dy, (const float*)y, d, (float*)out, sums, planes, hw, act, alpha, gain, clamp, vec_ok);
-    else if (dtype == SGV_F16) hipLaunchKernelGGL(act_grad_scale_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)dy, (const sgv_half_t*)y, d, (sgv_half_t*)out, sums, planes, hw, act, alpha, gain, clamp, vec_ok);
-    else hipLaunchKernelGGL(act_grad_scale_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)dy, (const sgv_bf16_t*)y, d, (sgv_bf16_t*)out, sums, planes, hw, act, alpha, gain, clamp, vec_ok);
+    // blockIdx.y is limited to 65535: the planes go in slabs (one launch up to 65,535 planes = 127 frames of a 512-channel layer; more than that -- the
+    // Dmain phase as one pass over generated + real clips, larger per-GPU batches -- takes further launches on the following planes)
+    for (int p0 = 0; p0 < planes; p0 += 65535) {
+        const int np = std::min(65535, planes - p0);
+        const size_t off = (size_t)p0 * hw * es;
+        const char *dyp = (const char*)dy + off, *yp = (const char*)y + off;
+        char* op = (char*)out + off;
+        const float* dp = d ? d + p0 : nullptr;
+        float* sp = sums ? sums + p0 : nullptr;     // (the kernel's second row sits `planes` behind the first: the total, not the slab)
+        dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)np);
+        if (dtype == SGV_F32) hipLaunchKernelGGL(act_grad_scale_kernel<float>, grid, dim3(256), 0, stream, (const float*)dyp, (const float*)yp, dp, (float*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok);
+        else if (dtype == SGV_F16) hipLaunchKernelGGL(act_grad_scale_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)dyp, (const sgv_half_t*)yp, dp, (sgv_half_t*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok);
+        else hipLaunchKernelGGL(act_grad_scale_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)dyp, (const sgv_bf16_t*)yp, dp, (sgv_bf16_t*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok);
+    }
     return sgv_check_launch("act_grad_scale_kernel");
 }
 
@@ -242,17 +252,23 @@ extern "C" int sgv_act_grad_scale(const float* dy, const float* y, const float* 
 
 extern "C" int sgv_scale_dot_t(const void* a, const void* b, const float* s, void* out, float* dot, int32_t planes, int32_t hw, int dtype, void* stream_) {
     if (!a || !b || !s || !out || !dot) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: NULL pointer");
-    if (planes < 1 || hw < 1 || planes > 65535) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: needs 1 <= planes <= 65535, hw >= 1");
+    if (planes < 1 || hw < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: needs planes >= 1, hw >= 1");
     if ((int64_t)planes * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "scale_dot: tensors are too large");
     const size_t es = sgv_dtype_size(dtype);
     if (es == 0 || dtype == SGV_F64) return sgv_fail(SGV_ERR_UNSUPPORTED, "scale_dot: unsupported dtype %d", dtype);
     hipStream_t stream = (hipStream_t)stream_;
     sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * (double)es);
     const int vec_ok = (hw % (16 / (int)es) == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0);
-    dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)planes);
-    if (dtype == SGV_F32) hipLaunchKernelGGL(scale_dot_kernel<float>, grid, dim3(256), 0, stream, (const float*)a, (const float*)b, s, (float*)out, dot, hw, vec_ok);
-    else if (dtype == SGV_F16) hipLaunchKernelGGL(scale_dot_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)a, (const sgv_half_t*)b, s, (sgv_half_t*)out, dot, hw, vec_ok);
-    else hipLaunchKernelGGL(scale_dot_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)a, (const sgv_bf16_t*)b, s, (sgv_bf16_t*)out, dot, hw, vec_ok);
+    for (int p0 = 0; p0 < planes; p0 += 65535) {     // blockIdx.y <= 65535: planes in slabs, as act_grad_scale
+        const int np = std::min(65535, planes - p0);
+        const size_t off = (size_t)p0 * hw * es;
+        const char *ap = (const char*)a + off, *bp = (const char*)b + off;
+        char* op = (char*)out + off;
+        dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)np);
+        if (dtype == SGV_F32) hipLaunchKernelGGL(scale_dot_kernel<float>, grid, dim3(256), 0, stream, (const float*)ap, (const float*)bp, s + p0, (float*)op, dot + p0, hw, vec_ok);
+        else if (dtype == SGV_F16) hipLaunchKernelGGL(scale_dot_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)ap, (const sgv_half_t*)bp, s + p0, (sgv_half_t*)op, dot + p0, hw, vec_ok);
+        else hipLaunchKernelGGL(scale_dot_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)ap, (const sgv_bf16_t*)bp, s + p0, (sgv_bf16_t*)op, dot + p0, hw, vec_ok);
+    }
     return sgv_check_launch("scale_dot_kernel");
 }
 

@@ -3,6 +3,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import pointwise, conv2d_resample
 from util import assert_close
 
@@ -129,3 +130,28 @@ def test_fused_fromrgb_tail_is_bit_identical_to_the_two_pass_composition(act, cl
         return list(g) + [t for t in gg if t is not None]
     for a, r in zip(r1(fused), r1(composed)):
         assert_close(a, r, atol=1e-4, rtol=1e-4)
+
+
+def test_act_grad_scale_and_scale_dot_beyond_65535_planes():
+    """More planes than blockIdx.y holds (192 frames of a 512-channel layer: the Dmain phase as one pass, larger per-GPU batches): the launch goes in slabs
+    of 65,535 planes -- activation gradient, its two per-plane sums, input gradient and per-plane dot against the same formulas in torch."""
+    lib = custom_ops.get_native()
+    dev = torch.device('cuda')
+    g = torch.Generator().manual_seed(3)
+    planes, hw = 70001, 16
+    dy, y = torch.randn([planes, hw], generator=g).to(dev), torch.randn([planes, hw], generator=g).to(dev)
+    d = (torch.rand([planes], generator=g) + 0.5).to(dev)
+    out = torch.empty_like(dy)
+    sums = torch.zeros([2, planes], device=dev)
+    alpha, gain = 0.2, 2 ** 0.5
+    with torch.cuda.device(dev):
+        custom_ops.check(lib.sgv_act_grad_scale(dy.data_ptr(), y.data_ptr(), d.data_ptr(), out.data_ptr(), sums.data_ptr(), planes, hw, 3, alpha, gain, -1.0,
+                                                torch.cuda.current_stream().cuda_stream), lib)
+    dz = torch.where(y > 0, dy, dy * alpha) * gain
+    assert torch.allclose(out, dz * d[:, None], rtol=1e-6, atol=1e-6)
+    assert torch.allclose(sums[0], dz.sum(1), rtol=1e-5, atol=1e-5) and torch.allclose(sums[1], (dy * y).sum(1), rtol=1e-5, atol=1e-5)
+    a, b = torch.randn([planes, hw], generator=g).to(dev), torch.randn([planes, hw], generator=g).to(dev)
+    o2, dot = torch.empty_like(a), torch.zeros([planes], device=dev)
+    with torch.cuda.device(dev):
+        custom_ops.check(lib.sgv_scale_dot(a.data_ptr(), b.data_ptr(), d.data_ptr(), o2.data_ptr(), dot.data_ptr(), planes, hw, torch.cuda.current_stream().cuda_stream), lib)
+    assert torch.allclose(o2, a * d[:, None], rtol=1e-6, atol=1e-6) and torch.allclose(dot, (a * b).sum(1), rtol=1e-5, atol=1e-5)
