@@ -391,7 +391,8 @@ class MinibatchStdLayer(torch.nn.Module):
     def forward(self, x):
         n, c, h, w = x.shape
         f = self.num_channels
-        s = self.segments if self.segments > 1 and n % self.segments == 0 else 1
+        seg = getattr(self, 'segments', 1)     # (modules unpickled from before the attribute existed)
+        s = seg if seg > 1 and n % seg == 0 else 1
         if s > 1:
             ns = n // s
             g = min(self.group_size, ns) if self.group_size is not None else ns
