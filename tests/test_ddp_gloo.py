@@ -65,6 +65,16 @@ def _worker(rank, world, port, out_dir):
         for phase in ('Gmain', 'Dmain', 'Dreg'):
             torch.manual_seed(77 + rank)  # rank-local RNG stream for the in-forward randn
             res[phase] = _phase_grads(ts, phase, real[sl], real_t[sl], z[sl], t[sl])
+        # Dmain as ONE discriminator pass over [generated, real] clips (loss.d_concat, off by default): a single synchronised backward must leave the same
+        # all-reduced gradients as the reference's two passes (the first un-synchronised, the second synchronised)
+        ts.loss.d_concat = True
+        torch.manual_seed(77 + rank)
+        one_pass = _phase_grads(ts, 'Dmain', real[sl], real_t[sl], z[sl], t[sl])
+        ts.loss.d_concat = False
+        assert set(one_pass) == set(res['Dmain'])
+        for name, g1 in one_pass.items():
+            want = res['Dmain'][name]
+            assert (g1 - want).abs().max().item() <= 2e-5 * (want.abs().max().item() + 1e-6), f'Dmain as one pass differs under DDP: {name}'
         # the wrapper-free form used under hipGraph replay (one flat all-reduce behind the backward pass) gives the same averaged gradients
         tm = _make(world, rank, batch_gpu=2, ddp=True, ddp_manual=True)
         assert tm.ddp_manual and not isinstance(tm.loss.D, torch.nn.parallel.DistributedDataParallel)
