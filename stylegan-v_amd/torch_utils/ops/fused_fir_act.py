@@ -11,6 +11,9 @@ order).  Anything the fused kernel does not cover -- CPU tensors, other paddings
 composition of the three ops, which is the definition of the result.
 """
 
+import contextlib
+import os
+
 import torch
 
 from .. import custom_ops
@@ -21,8 +24,23 @@ from . import upfirdn2d as _ufd
 from .upfirdn2d import _DTYPE_CODES
 
 enabled = True  # module switch.  Second order: passes known to be differentiated twice (path-length regularisation, R1; training/loss.py) run under
-                # ``fused_conv_act.composition_only()`` and take the composition; a fused node whose gradient is differentiated anyway
-                # (``create_graph=True``) switches its backward to the composition on the saved inputs -- gradients of any order exist.
+                # ``fused_conv_act.composition_only()`` and take the composition.
+# A fused node whose gradient is differentiated WITHOUT that announcement (``create_graph=True``) can switch its backward to the composition on the saved
+# inputs -- but only if the forward kept its input, the (2H+3)^2 output of the up-sampling convolution, alive: one extra largest-resolution activation
+# per up-layer for every ordinary training step.  So that is opt-in (`second_order_support()` / SGV_FIR_FUSED_SECOND_ORDER=1); without it the
+# node is once-differentiable and says so.
+keep_inputs_for_second_order = os.environ.get('SGV_FIR_FUSED_SECOND_ORDER', '0') == '1'
+
+
+@contextlib.contextmanager
+def second_order_support(on=True):
+    """Fused nodes created inside keep their inputs so that `create_graph=True` differentiates the composition instead of raising."""
+    global keep_inputs_for_second_order
+    prev, keep_inputs_for_second_order = keep_inputs_for_second_order, bool(on)
+    try:
+        yield
+    finally:
+        keep_inputs_for_second_order = prev
 
 
 def fir_bias_act_composed(x, f, scale=None, bias=None, padding=1, fir_gain=1, act='lrelu', alpha=None, gain=None, clamp=None, flip_filter=False):
@@ -63,15 +81,24 @@ class _FusedFirBiasActFn(torch.autograd.Function):
         ctx.x_shape = x.shape
         ctx.has_scale, ctx.has_bias = scale is not None, bias is not None
         ctx.scale_shape = scale.shape if scale is not None else None
-        # x, scale and bias themselves (with their history) serve the create_graph path of backward; holding x alive costs memory, not bandwidth
-        ctx.save_for_backward(y, f, sc, bi, x_in, scale, bias)
+        # x, scale and bias themselves (with their history) serve the create_graph path of backward -- kept only on request (see above)
+        ctx.keeps_inputs = keep_inputs_for_second_order
+        if ctx.keeps_inputs:
+            ctx.save_for_backward(y, f, sc, bi, x_in, scale, bias)
+        else:
+            ctx.save_for_backward(y, f, sc, bi)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         pads, fir_gain, flip, act, alpha, gain, clamp = ctx.cfg
-        y, f, sc, bi, x_in, scale, bias = ctx.saved_tensors
+        y, f, sc, bi = ctx.saved_tensors[:4]
         if torch.is_grad_enabled():
+            if not ctx.keeps_inputs:
+                raise RuntimeError('fir_bias_act: this fused node is differentiated twice (create_graph=True) but did not keep its inputs; run the pass under '
+                                   'fused_conv_act.composition_only() (as the R1 / path-length passes of training/loss.py do) or create the node under '
+                                   'fused_fir_act.second_order_support() / SGV_FIR_FUSED_SECOND_ORDER=1')
+            x_in, scale, bias = ctx.saved_tensors[4:]
             # create_graph=True (this gradient is differentiated again, e.g. a path-length or R1 pass that did not announce itself through
             # `composition_only()`): differentiate the composition on the saved inputs instead -- one extra forward, gradients of any order.
             ins = [t for t, need in zip((x_in, scale, bias), (ctx.needs_input_grad[0], ctx.needs_input_grad[2], ctx.needs_input_grad[3])) if need and t is not None]

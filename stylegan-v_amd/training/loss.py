@@ -51,17 +51,10 @@ class StyleGAN2Loss:
             img = self.G_synthesis(ws, t=t, c=c)
         return img, ws
 
-    @contextlib.contextmanager
-    def _mbstd_segments(self, segments):
-        from .networks import MinibatchStdLayer
-        layers = [m for m in self.D.modules() if isinstance(m, MinibatchStdLayer)]
-        for m in layers:
-            m.segments = segments
-        try:
-            yield
-        finally:
-            for m in layers:
-                m.segments = 1
+    @staticmethod
+    def _mbstd_segments(segments):
+        from .networks import minibatch_std_segments
+        return minibatch_std_segments(segments)     # thread-local: scoped to this pass of this thread
 
     def run_D(self, img, c, t, sync):
         if self.augment_pipe is not None:

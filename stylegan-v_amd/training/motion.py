@@ -11,6 +11,7 @@ built: ``gen_strategy='conv'`` and ``fourier=True`` (configs/model/stylegan-v.ya
 """
 
 import contextlib
+import threading
 import math
 
 import numpy as np
@@ -68,7 +69,17 @@ class AlignedTimeEncoder(torch.nn.Module):
                                interp_weights.reshape(-1).float())
 
 
-_t_bound = []   # innermost `frame_times_bounded_by` bound; a module-level stack, NOT module state: it neither survives pickling nor reaches G_ema
+# innermost `frame_times_bounded_by` bound of the CALLING THREAD: a stack in thread-local storage, NOT module state -- it neither survives pickling nor
+# reaches G_ema, and an evaluation / generation thread that uses a generator while a training phase holds a bound does not inherit it
+# (it keeps the reference's t.max() sizing and is not clamped)
+_tls = threading.local()
+
+
+def _bound_stack():
+    stack = getattr(_tls, 't_bound', None)
+    if stack is None:
+        stack = _tls.t_bound = []
+    return stack
 
 
 @contextlib.contextmanager
@@ -76,11 +87,12 @@ def frame_times_bounded_by(bound):
     """Promise that every frame time `t` handed to a MotionMappingNetwork inside the block is <= `bound` (a training loop that draws
     t < max_num_frames by construction).  `get_max_traj_len` then skips the reference's `t.max().item()` device->host read
     (src/training/motion.py:97-100); the trajectory gather clamps its index so that a broken promise cannot read out of bounds."""
-    _t_bound.append(float(bound))
+    stack = _bound_stack()
+    stack.append(float(bound))
     try:
         yield
     finally:
-        _t_bound.pop()
+        stack.pop()
 
 
 class MotionMappingNetwork(torch.nn.Module):
@@ -98,6 +110,7 @@ class MotionMappingNetwork(torch.nn.Module):
         self.num_additional_codes = (k - 1) * 2  # the two valid convolutions eat (k-1) codes each
 
     def get_max_traj_len(self, t):
+        _t_bound = _bound_stack()
         if _t_bound:     # inside `frame_times_bounded_by`: no device->host read of t.max() (a pipeline stall per pass, illegal under hipGraph capture)
             max_t = max(self.cfg.sampling.max_num_frames - 1, _t_bound[-1])
         else:
@@ -128,7 +141,7 @@ class MotionMappingNetwork(torch.nn.Module):
             trajs = self.conv(x.permute(0, 2, 1)).permute(0, 2, 1)  # [B, L - 2(k-1), v_dim]
 
         left_idx = (t / dist).floor().long()
-        if _t_bound:   # nothing compared t with the promised bound on the host: keep both gathers inside the trajectory whatever t holds
+        if _bound_stack():   # nothing compared t with the promised bound on the host: keep both gathers inside the trajectory whatever t holds
             left_idx = left_idx.clamp(0, trajs.shape[1] - 2)
         rows = torch.arange(b, device=c.device).unsqueeze(1).expand(-1, f)
         u_left = trajs[rows, left_idx]

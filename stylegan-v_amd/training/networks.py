@@ -22,8 +22,10 @@ Shapes the kernels do not serve (4x4 layers, odd channel counts, 16-bit tensors)
 every convolution to cuDNN.
 """
 
+import contextlib
 import math
 import os
+import threading
 
 import numpy as np
 import torch
@@ -380,18 +382,34 @@ class DiscriminatorBlock(torch.nn.Module):
         return x, img
 
 
+_mbstd_tls = threading.local()
+
+
+@contextlib.contextmanager
+def minibatch_std_segments(segments):
+    """Every MinibatchStdLayer called by THIS thread inside the block treats its batch as `segments` independent batches back to back
+    (thread-local: a concurrent evaluation pass through the same discriminator is not affected)."""
+    prev = getattr(_mbstd_tls, 'segments', None)
+    _mbstd_tls.segments = int(segments)
+    try:
+        yield
+    finally:
+        _mbstd_tls.segments = prev
+
+
 class MinibatchStdLayer(torch.nn.Module):
     """Appends, per group of `group_size` samples, the channel/pixel-averaged std over the group as extra feature map(s)."""
 
     def __init__(self, group_size, num_channels=1):
         super().__init__()
         self.group_size, self.num_channels = group_size, num_channels
-        self.segments = 1   # > 1: the batch is that many independent batches back to back (loss.py: generated + real clips in one pass); groups never straddle them
+        self.segments = 1   # > 1: the batch is that many independent batches back to back; groups never straddle them.  A pass that needs it for ONE call
+                            # (loss.py: generated + real clips in one discriminator pass) uses `minibatch_std_segments`, which is thread-local
 
     def forward(self, x):
         n, c, h, w = x.shape
         f = self.num_channels
-        seg = getattr(self, 'segments', 1)     # (modules unpickled from before the attribute existed)
+        seg = getattr(_mbstd_tls, 'segments', None) or getattr(self, 'segments', 1)     # (modules unpickled from before the attribute existed)
         s = seg if seg > 1 and n % seg == 0 else 1
         if s > 1:
             ns = n // s

@@ -25,6 +25,72 @@ from .loss import StyleGAN2Loss
 from .networks import Discriminator, Generator
 
 
+class _HipGraph:
+    """One captured hipGraph (torch.cuda.CUDAGraph).  `capture(fn)` records fn's launches without executing them and returns fn's result (static
+    output tensors); tensors fn allocates -- the gradients a backward pass binds to `p.grad` -- live in the graph's private pool and are rewritten in
+    place by every `replay()`."""
+
+    def __init__(self, pool=None):
+        self.graph, self._pool = torch.cuda.CUDAGraph(), pool
+
+    def capture(self, fn):
+        # thread_local: the RCCL watchdog thread of an initialised process group queries events while this thread captures, which the
+        # default (global) capture mode treats as an error in the OTHER thread (observed: segmentation fault in capture_end)
+        kw = dict(pool=self._pool) if self._pool is not None else {}
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local', **kw):
+            return fn()
+
+    def pool(self):
+        return self.graph.pool()
+
+    def replay(self):
+        self.graph.replay()
+
+
+class _EmulatedGraph:
+    """Host-side stand-in for `_HipGraph` (``use_graphs='emulate'``; any device): keeps the one property of a replayed graph that the surrounding
+    Python has to get right -- a replay rewrites the tensors that were bound to `p.grad` AT CAPTURE TIME and never touches the `p.grad` attributes
+    themselves, whatever eager phases did to them in between (`opt.zero_grad(set_to_none=True)` of a reg phase un-binds or re-binds them).  It is
+    what lets the world-size-2 gloo test (tests/test_ddp_gloo.py) run the graph schedule's gradient all-reduce on CPU.
+    `capture(fn, executes=True)` runs fn once with the training state put back afterwards (a real capture executes nothing) and remembers the
+    gradient tensors fn left bound; `replay()` runs fn again on the side, copies the fresh gradients into those tensors and restores the
+    attributes.  A graph captured with `reads_grads_of=<grad graph>` (the update graph) runs fn with `p.grad` bound to that graph's tensors."""
+
+    def __init__(self, params, state_fn, reads_grads_of=None):
+        self.params, self.state_fn, self.src = list(params), state_fn, reads_grads_of
+        self.fn, self.bufs = None, None
+
+    def capture(self, fn):
+        self.fn = fn
+        if self.src is not None:          # update graph: nothing to discover
+            return None
+        saved = [t.clone() for t in self.state_fn()]
+        out = fn()
+        with torch.no_grad():
+            for t, s0 in zip(self.state_fn(), saved):
+                t.copy_(s0)
+        self.bufs = [p.grad for p in self.params]     # bound like after a real capture
+        return out
+
+    def pool(self):
+        return None
+
+    def replay(self):
+        bound = [p.grad for p in self.params]
+        if self.src is not None:
+            for p, g in zip(self.params, self.src.bufs):
+                p.grad = g
+            self.fn()
+        else:
+            self.out = self.fn()
+            with torch.no_grad():
+                for p, buf in zip(self.params, self.bufs):
+                    if buf is not None:
+                        buf.copy_(p.grad)
+        for p, g in zip(self.params, bound):
+            p.grad = g
+
+
 def build_models(g_kwargs, d_kwargs, device, seed=0):
     torch.manual_seed(seed)
     G = Generator(**g_kwargs).train().requires_grad_(False).to(device)
@@ -70,7 +136,8 @@ class TrainStep:
         # (`_allreduce_gradients`; same mean as DDP's buckets, not overlapped with the backward -- ~1.5 ms against a 58 ms step): torch's DDP
         # reducer under stream capture crashed `capture_end` on ROCm 7.2 / torch 2.10 even with its synchronisation switched off.
         self.ddp = (world_size > 1) if ddp is None else ddp
-        self.use_graphs = bool(use_graphs) and self.device.type == 'cuda'
+        self.emulate_graphs = use_graphs == 'emulate'
+        self.use_graphs = self.emulate_graphs or (bool(use_graphs) and self.device.type == 'cuda')
         self.ddp_manual = self.ddp and (self.use_graphs if ddp_manual is None else bool(ddp_manual))
         modules = dict(G_mapping=self.G.mapping, G_synthesis=self.G.synthesis, D=self.D)
         if self.ddp and not self.ddp_manual:
@@ -97,6 +164,8 @@ class TrainStep:
         # torch's fused multi-tensor Adam on the GPU (same update rule as the reference's torch.optim.Adam, training_loop.py:245-251; one launch per
         # parameter group instead of ~12 multi-tensor passes)
         adam_kw = dict(fused=True) if self.device.type == 'cuda' else {}
+        if self.emulate_graphs:
+            adam_kw = {}
         for name, module, interval in (('G', self.G, train_cfg.G_reg_interval), ('D', self.D, train_cfg.D_reg_interval)):
             if interval is None:
                 opt = torch.optim.Adam(module.parameters(), lr=train_cfg.lr, betas=tuple(train_cfg.betas), eps=1e-8, **adam_kw)
@@ -117,10 +186,11 @@ class TrainStep:
         # runs un-synchronised, one flat RCCL all-reduce of the gradients follows the replay) and with ADA (the pipe pads by its static
         # worst-case margin while graphs are on, so that nothing is read back to the host).
         self._graphs = {}
-        if self.use_graphs:
+        if self.use_graphs and not self.emulate_graphs:
             for phase in self.phases:
                 for group in phase['opt'].param_groups:
                     group['capturable'] = True
+        if self.use_graphs:
             if self.augment_pipe is not None:
                 self.augment_pipe.static_margin = True
 
@@ -176,10 +246,13 @@ class TrainStep:
         self._phase_update(phase)
         return losses
 
-    def _allreduce_gradients(self, phase):
+    def _allreduce_gradients(self, phase, grads=None):
         """Average the phase module's gradients over the ranks as ONE flat all-reduce (what DDP's buckets do during backward in the eager path).
-        Used behind a replayed hipGraph, whose backward pass ran with DDP's own synchronisation off."""
-        grads = [p.grad for p in phase['module'].parameters() if p.grad is not None]
+        Used behind a replayed hipGraph, whose backward pass ran with DDP's own synchronisation off.  `grads`: the tensors to reduce -- a replayed
+        phase passes the gradient buffers of its capture (`entry['grads']`): `p.grad` only points at them until the next eager phase on the same
+        optimiser re-binds it (Greg / Dreg call `zero_grad(set_to_none=True)`), while the captured update graph keeps reading the buffers."""
+        if grads is None:
+            grads = [p.grad for p in phase['module'].parameters() if p.grad is not None]
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
@@ -207,38 +280,46 @@ class TrainStep:
         entry = self._graphs.get(name)
         if entry is None:
             static = dict(real_img=real_img.clone(), real_c=real_c.clone(), real_t=real_t.clone(), gen_z=gen_z.clone(), gen_c=gen_c.clone(), gen_t=gen_t.clone())
-            tensors, opt_before = self._training_state(phase)
-            saved = [t.clone() for t in tensors]
-            saved_opt = {(id(p), k): v.clone() for p, k, v in opt_before}
-            side = torch.cuda.Stream(device=self.device)
-            side.wait_stream(torch.cuda.current_stream(self.device))
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    self._phase_gradients(phase, False, **static)
-                    self._phase_update(phase)
-                with torch.no_grad():
-                    for t, s0 in zip(tensors, saved):
-                        t.copy_(s0)
-                    for p, k, v in self._training_state(phase)[1]:      # in place: the capture below records these tensors' addresses
-                        s0 = saved_opt.get((id(p), k))
-                        v.copy_(s0) if s0 is not None else v.zero_()
-            torch.cuda.current_stream(self.device).wait_stream(side)
-            g_grad, g_upd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            # thread_local: the RCCL watchdog thread of an initialised process group queries events while this thread captures, which the
-            # default (global) capture mode treats as an error in the OTHER thread (observed: segmentation fault in capture_end)
-            with torch.cuda.graph(g_grad, capture_error_mode='thread_local'):
-                out = self._phase_gradients(phase, False, **static)
-            with torch.cuda.graph(g_upd, pool=g_grad.pool(), capture_error_mode='thread_local'):
-                self._phase_update(phase)
-            entry = self._graphs[name] = dict(grad=g_grad, update=g_upd, static=static, out=out)
+            if not self.emulate_graphs:
+                tensors, opt_before = self._training_state(phase)
+                saved = [t.clone() for t in tensors]
+                saved_opt = {(id(p), k): v.clone() for p, k, v in opt_before}
+                side = torch.cuda.Stream(device=self.device)
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._phase_gradients(phase, False, **static)
+                        self._phase_update(phase)
+                    with torch.no_grad():
+                        for t, s0 in zip(tensors, saved):
+                            t.copy_(s0)
+                        for p, k, v in self._training_state(phase)[1]:      # in place: the capture below records these tensors' addresses
+                            s0 = saved_opt.get((id(p), k))
+                            v.copy_(s0) if s0 is not None else v.zero_()
+                torch.cuda.current_stream(self.device).wait_stream(side)
+            params = list(phase['module'].parameters())
+            if self.emulate_graphs:
+                g_grad = _EmulatedGraph(params, lambda: self._training_state(phase)[0])
+                g_upd = _EmulatedGraph(params, None, reads_grads_of=g_grad)
+            else:
+                g_grad = _HipGraph()
+            out = g_grad.capture(lambda: self._phase_gradients(phase, False, **static))
+            # the gradient tensors of THIS capture: what every later replay rewrites, what the update graph reads, and therefore what the
+            # all-reduce between the two must reduce (`p.grad` stops pointing at them after the first eager reg phase)
+            grads = [p.grad for p in params if p.grad is not None]
+            if not self.emulate_graphs:
+                g_upd = _HipGraph(pool=g_grad.pool())
+            g_upd.capture(lambda: self._phase_update(phase))
+            entry = self._graphs[name] = dict(grad=g_grad, update=g_upd, static=static, out=out, grads=grads)
         else:
             for key, val in (('real_img', real_img), ('real_c', real_c), ('real_t', real_t), ('gen_z', gen_z), ('gen_c', gen_c), ('gen_t', gen_t)):
                 entry['static'][key].copy_(val)
         entry['grad'].replay()
         if self.ddp_manual:
-            self._allreduce_gradients(phase)
+            self._allreduce_gradients(phase, grads=entry['grads'])
         entry['update'].replay()
-        return {k: v.clone() for k, v in entry['out'].items()}
+        out = getattr(entry['grad'], 'out', None) or entry['out']      # (the emulated graph returns each replay's own result)
+        return {k: v.clone() for k, v in out.items()}
 
     # -- one iteration ----------------------------------------------------------------------------
     def step(self, real_img=None, real_t=None):

@@ -19,14 +19,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _make(world, rank, batch_gpu, ddp, ddp_manual=None):
+def _make(world, rank, batch_gpu, ddp, ddp_manual=None, use_graphs=False, reg_intervals=(4, 16)):
     from stylegan_v_amd.training import config as cfgs
     from stylegan_v_amd.training.train_step import TrainStep
     g_kwargs, d_kwargs = cfgs.small_test_model_kwargs(res=32)
     # D's minibatch-std groups must not straddle ranks for the equivalence: group size 2 with 2 videos per rank
-    train_cfg = cfgs.Config(r1_gamma=1.0, lr=0.0025, betas=(0.0, 0.99), ema_kimg=1.0, ema_rampup=0.05, G_reg_interval=4, D_reg_interval=16,
-                            pl_weight=0.0)
-    return TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=batch_gpu, world_size=world, rank=rank, seed=0, ddp=ddp, ddp_manual=ddp_manual)
+    train_cfg = cfgs.Config(r1_gamma=1.0, lr=0.0025, betas=(0.0, 0.99), ema_kimg=1.0, ema_rampup=0.05, G_reg_interval=reg_intervals[0],
+                            D_reg_interval=reg_intervals[1], pl_weight=0.0)
+    return TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=batch_gpu, world_size=world, rank=rank, seed=0, ddp=ddp, ddp_manual=ddp_manual,
+                     use_graphs=use_graphs)
 
 
 def _phase_grads(ts, phase, real_img, real_t, z, t):
@@ -155,3 +156,54 @@ def _worker_entry(rank, world, port, out_dir):
     import stylegan_v_amd.training.motion as motion
     _patch_motion_noise(motion)
     _worker(rank, world, port, out_dir)
+
+
+def _graph_worker(rank, world, port, out_dir):
+    """The hipGraph schedule under DDP (TrainStep._run_phase_graph with the host-side graph stand-in `use_graphs='emulate'`): Gmain / Dmain replayed,
+    Greg / Dreg eager on the SAME optimisers every second iteration -- so from iteration 1 on `p.grad` no longer points at the captured gradient
+    buffers.  Ranks must stay bit-consistent and follow the eager manual-all-reduce schedule."""
+    sys.path.insert(0, ROOT)
+    import stylegan_v_amd.training.motion as motion
+    _patch_motion_noise(motion)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from stylegan_v_amd.torch_utils import misc
+        tg = _make(world, rank, batch_gpu=2, ddp=True, use_graphs='emulate', reg_intervals=(2, 2))
+        te = _make(world, rank, batch_gpu=2, ddp=True, ddp_manual=True, reg_intervals=(2, 2))
+        assert tg.use_graphs and tg.ddp_manual and te.ddp_manual and not te.use_graphs
+        te.G.load_state_dict(tg.G.state_dict()); te.D.load_state_dict(tg.D.state_dict()); te.G_ema.load_state_dict(tg.G_ema.state_dict())
+        g = torch.Generator().manual_seed(500 + rank)       # rank-specific data: un-reduced gradients would differ between the ranks
+        schedule = []
+        for it in range(5):
+            real = torch.rand([2, 3, 3, 32, 32], generator=g) * 2 - 1
+            real_t = torch.sort(torch.rand([2, 3], generator=g) * 30, dim=1).values
+            schedule.append(tuple(tg.step(real.clone(), real_t.clone())))
+            assert tuple(te.step(real.clone(), real_t.clone())) == schedule[-1]
+            misc.check_ddp_consistency(tg.G, ignore_regex=r'.*\.w_avg')
+            misc.check_ddp_consistency(tg.D)
+            for (name, a), (_, b) in zip(list(tg.G.named_parameters()) + list(tg.D.named_parameters()), list(te.G.named_parameters()) + list(te.D.named_parameters())):
+                err = (a - b).abs().max().item()
+                assert err <= 1e-5 * (b.abs().max().item() + 1e-3), f'iteration {it}: {name} differs from the eager schedule by {err:.3e}'
+        assert schedule == [('Gmain', 'Greg', 'Dmain', 'Dreg'), ('Gmain', 'Dmain')] * 2 + [('Gmain', 'Greg', 'Dmain', 'Dreg')]
+        assert set(tg._graphs) == {'Gmain', 'Dmain'}
+        # the property the emulation exists for: after an eager reg phase the live `p.grad` tensors are NOT the captured buffers
+        stale = sum(int(p.grad is not buf) for p, buf in zip(tg.D.parameters(), tg._graphs['Dmain']['grad'].bufs) if buf is not None)
+        assert stale > 0, 'the schedule never re-bound p.grad: the test does not exercise the captured-buffer all-reduce'
+        open(os.path.join(out_dir, f'graph_rank{rank}.ok'), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_graph_schedule_allreduces_the_captured_gradient_buffers(tmp_path):
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=540)
+        assert p.exitcode == 0, f'rank process failed with exit code {p.exitcode}'
+    assert (tmp_path / 'graph_rank0.ok').exists() and (tmp_path / 'graph_rank1.ok').exists()

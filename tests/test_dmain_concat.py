@@ -3,7 +3,7 @@ as the reference's two passes (src/training/loss.py:122-151); the minibatch-std 
 import torch
 
 from stylegan_v_amd.training import config as cfgs
-from stylegan_v_amd.training.networks import MinibatchStdLayer
+from stylegan_v_amd.training.networks import MinibatchStdLayer, _mbstd_tls, minibatch_std_segments
 from stylegan_v_amd.training.train_step import TrainStep
 
 
@@ -17,6 +17,14 @@ def test_minibatch_std_segments_equal_separate_batches():
         got = layer(torch.cat([a, b]))
         assert torch.allclose(got, want, rtol=0, atol=1e-6)
         layer.segments = 1
+        assert torch.equal(layer(a), want[:n])
+        with minibatch_std_segments(2):          # the per-pass, thread-local form loss.py uses
+            assert torch.equal(layer(torch.cat([a, b])), got)
+            seen = []
+            import threading
+            th = threading.Thread(target=lambda: seen.append(torch.equal(layer(a), want[:n])))   # another thread is not affected
+            th.start(); th.join()
+            assert seen == [True]
         assert torch.equal(layer(a), want[:n])
 
 
@@ -43,7 +51,7 @@ def test_dmain_as_one_pass_has_the_two_pass_gradients():
         return out, [p.grad.clone() for p in ts.D.parameters()]
     want, gw = run(False)
     got, gg = run(True)
-    assert all(m.segments == 1 for m in ts.D.modules() if isinstance(m, MinibatchStdLayer)), 'the segment hint must not outlive the pass'
+    assert getattr(_mbstd_tls, 'segments', None) is None and all(m.segments == 1 for m in ts.D.modules() if isinstance(m, MinibatchStdLayer)), 'the segment hint must not outlive the pass'
     assert torch.allclose(got['D/loss'], want['D/loss'], rtol=1e-6) and torch.equal(got['signs_real'], want['signs_real'])
     for a, r in zip(gg, gw):
         assert torch.allclose(a, r, rtol=1e-4, atol=1e-5 * max(r.abs().max().item(), 1e-8))
@@ -51,3 +59,24 @@ def test_dmain_as_one_pass_has_the_two_pass_gradients():
     ts.loss.d_concat = True
     out = ts.loss.accumulate_gradients('Dreg', real, c, real_t, gen_z, c, gen_t, sync=True, gain=16)
     assert 'r1_penalty' in out
+
+
+def test_frame_time_bound_is_scoped_to_the_calling_thread():
+    """motion.frame_times_bounded_by (the training passes' promise that replaces the reference's t.max().item() read, motion.py:97-100) lives in
+    thread-local storage: a generation thread using a generator meanwhile keeps the reference's sizing from t.max()."""
+    import threading
+    from stylegan_v_amd.training import motion
+    g_kwargs, _ = cfgs.small_test_model_kwargs(res=32)
+    torch.manual_seed(0)
+    from stylegan_v_amd.training.networks import Generator
+    G = Generator(**g_kwargs).eval()
+    enc = G.synthesis.motion_encoder
+    far = torch.tensor([[0.0, 100.0, 300.0]])
+    want = enc.get_max_traj_len(far)
+    seen = {}
+    with motion.frame_times_bounded_by(31.0):
+        inside = enc.get_max_traj_len(far)                      # this thread: sized from the promised bound, not from t
+        th = threading.Thread(target=lambda: seen.setdefault('other', enc.get_max_traj_len(far)))
+        th.start(); th.join()
+    assert seen['other'] == want and inside < want
+    assert enc.get_max_traj_len(far) == want

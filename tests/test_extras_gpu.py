@@ -274,8 +274,13 @@ def test_fused_fir_bias_act_is_twice_differentiable(shape):
         y = fn(x, f, scale=s, bias=b, padding=1, fir_gain=4, act='lrelu', clamp=2.0)
         gx, gs = torch.autograd.grad((y * v).sum(), [x, s], create_graph=True)
         return torch.autograd.grad(gx.square().sum() + gs.square().sum(), [x, s, b], allow_unused=True)
+    # opt-in: by default the node does not keep the pre-FIR tensor alive and says so when it is differentiated twice unannounced
+    assert not fused_fir_act.keep_inputs_for_second_order
+    with pytest.raises(RuntimeError, match='composition_only'):
+        second_order(fused_fir_act.fir_bias_act)
     before = custom_ops.kernel_variant_counts()
-    got = second_order(fused_fir_act.fir_bias_act)
+    with fused_fir_act.second_order_support():
+        got = second_order(fused_fir_act.fir_bias_act)
     after = custom_ops.kernel_variant_counts()
     fused1 = ('ufd_lanes_fused1', 'ufd_fir_asm_fused1', 'ufd_tile_fused1')
     assert sum(after[k] - before[k] for k in fused1) == 1, 'the forward pass ran the fused kernel'
