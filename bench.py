@@ -39,7 +39,8 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); measured float4-copy ceiling 6290 GB/s
 HBM_COPY_GBPS = 6290.0
-MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md); the fp32-input MFMA peaks at 157.3
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA peak (MI355X_MICROARCH.md); the fp32-input MFMA peaks at 157.3
+MFMAS_PER_PRODUCT = {1: 1, 3: 3, 4: 3}   # conv2d_gradfix.native_conv_terms -> 16-bit MFMAs per fp32 product
 
 
 def log(*a):
@@ -441,7 +442,7 @@ def main():
     # bf16-products companion (BASELINE config 4 says "bf16 compute"): the same step, fp32 tensors and fp32 accumulation, but ONE bf16 MFMA per
     # product in the 3x3 family (terms = 1: operands rounded to bf16, rel-L2 2e-3 per convolution) instead of the three of the split.
     bf16c = None
-    if args.bf16_steps > 0 and lowp is None and default_terms == (3, 3):
+    if args.bf16_steps > 0 and lowp is None and default_terms in ((3, 3), (4, 4)):
         conv2d_gradfix.native_conv_terms = conv2d_gradfix.native_wrw_terms = 1
         try:
             ts.batch_idx = 0
@@ -550,7 +551,9 @@ def main():
             torch.cuda.empty_cache()
 
     F32_LABEL = 'f32' if conv2d_gradfix.native_conv_terms == 0 and conv2d_gradfix.native_wrw_terms == 0 else \
-        'fp32 I/O + fp32 accumulate everywhere; 3x3 convolution products are 2-way-bf16-split (hi/lo, 3 MFMAs per product: 16-bit mantissa operands, 4e-6 rel. error vs fp64; NOT strict fp32 -- see value_strict_fp32)'
+        ('f32 (fp32 tensors and accumulators; 3x3 / dense products as block-scaled 2-way fp16 splits on the matrix pipe: 22-bit operands, ~1e-7 rel. error vs fp64 = '
+         'the class of the vendor fp32 convolutions, tests/test_conv_f16split_gpu.py)' if default_terms == (4, 4) else
+         'fp32 I/O + fp32 accumulate everywhere; 3x3 convolution products are 2-way-bf16-split (hi/lo, 3 MFMAs per product: 16-bit mantissa operands, 4e-6 rel. error vs fp64; NOT strict fp32 -- see value_strict_fp32)')
     if rank == 0:
         kernels = {}
         roofline = None
@@ -580,14 +583,15 @@ def main():
             # lines reported under `roofline` (stride 1 + stride 2 + transposed + 16^2 / 8^2 + edge-strip members, flop-weighted).
             def mfma_roofline(e, terms, kernel, traffic):
                 achieved = e['flops'] / (e['ms'] * 1e-3) / 1e12
+                terms = MFMAS_PER_PRODUCT.get(terms, 3)        # MFMAs per product: 3 for both 2-way splits (terms = 3: bf16, terms = 4: block-scaled fp16)
                 peak = MFMA_BF16_PEAK_TFLOPS / terms
                 return dict(kernel=kernel, bound='mfma', achieved=achieved, peak=peak, unit='TFLOP/s', frac=achieved / peak, traffic=traffic[0],
                             traffic_source=traffic[1] + ' (L2-miss bytes: Infinity-Cache hits included)',
                             algorithmic_bytes_per_launch=e['bytes'] / e['launches'], launches=e['launches'],
                             avg_launch_us=1e3 * e['ms'] / e['launches'], algorithmic_flops_per_launch=e['flops'] / e['launches'],
                             executed_bf16_TFLOPs=achieved * terms, bf16_dense_peak_TFLOPs=MFMA_BF16_PEAK_TFLOPS, fp32_mfma_peak_TFLOPs=157.3,
-                            note=f'algorithmic flops = 2*N*H*W*Cin*Cout*9 (fp32-equivalent); the kernel issues {terms} bf16 MFMAs per product (hi/lo split, fp32 accumulate), '
-                                 f'so its ceiling is the bf16 dense peak / {terms}; all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1}), flop-weighted')
+                            note=f'algorithmic flops = 2*N*H*W*Cin*Cout*9 (fp32-equivalent); the kernel issues {terms} 16-bit MFMAs per product (hi/lo split, fp32 accumulate), '
+                                 f'so its ceiling is the 16-bit dense peak / {terms}; all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1}), flop-weighted')
             roofline_family = None
             if prof['conv3x3']['launches']:
                 roofline_family = mfma_roofline(prof['conv3x3'], conv2d_gradfix.native_conv_terms,

@@ -70,7 +70,7 @@
 extern "C" {
 #endif
 
-#define SGV_VERSION 100 /* major*100 + minor */
+#define SGV_VERSION 101 /* major*100 + minor */
 
 /* element types (the reference dispatches double/float/half: upfirdn2d.cpp:59, bias_act.cpp:76;
  * bf16 is this library's extension) */
@@ -255,7 +255,10 @@ typedef struct sgv_conv_wrw_params {
     const void* x;  /* [n, c_in, h, w] */
     float* dw;
     int32_t n, c_out, c_in, h, w;
-    int32_t terms;
+    int32_t terms;          /* 1, 3, or 4 (block-scaled fp16 split: fp32-grade, see sgv_absmax) */
+    const float* dy_amax;   /* terms = 4: device pointers to ONE fp32 each, upper bounds of max |dy| and max |x| */
+    const float* x_amax;
+    const float* x_amax2;   /* terms = 4, sgv_conv3x3_wrw_scaled only, optional: a bound of |x_scale| (the operand is x * x_scale) */
 } sgv_conv_wrw_params;
 
 int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* stream);
@@ -295,7 +298,9 @@ typedef struct sgv_conv3x3_params {
     int64_t workspace_bytes;
     int32_t n, c_in, c_out, h, w;
     int32_t mode;
-    int32_t terms;
+    int32_t terms;         /* 1 bf16 products, 3 bf16 split (bf16x3), 4 block-scaled fp16 split (fp32-grade; see below) */
+    const float* x_amax;   /* terms = 4: device pointer to ONE fp32 >= max |x| (sgv_absmax writes one); ignored otherwise */
+    const float* x_amax2;  /* terms = 4, optional: a second factor of the bound (sgv_conv3x3_fused with x_scale: a bound of |x_scale|); NULL: 1 */
 } sgv_conv3x3_params;
 
 /*
@@ -308,6 +313,17 @@ typedef struct sgv_conv3x3_params {
  */
 int sgv_conv3x3(const sgv_conv3x3_params* p, int dtype, void* stream);
 int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream);
+
+/*
+ * terms = 4 -- fp32-grade products on the 16-bit matrix pipe (every member of the 3x3 family; csrc/sgv_split.h).  The reference's config-3
+ * arithmetic is strict fp32 (`torch.backends.cudnn.allow_tf32 = False`, src/training/training_loop.py:129,141-142).  Each operand tensor is scaled by
+ * a power of two that puts its largest magnitude just below fp16's maximum, split into two fp16 terms (22 significant bits) and multiplied with
+ * three MFMAs into fp32 accumulators, like terms = 3; the result is scaled back exactly.  The scale comes from a BOUND of the tensor's
+ * magnitude that the caller passes as a device pointer (`x_amax`, `dy_amax`): any value >= max |x|, tight within ~2^10.  sgv_absmax computes
+ * max |x| itself in one streaming pass (out[0] = max |x|; accumulate != 0: max with the value already there); weights are bounded by the library.
+ * A bound smaller than the data overflows fp16 (inf / NaN in the result).
+ */
+int sgv_absmax(const void* x, int64_t numel, int dtype, float* out, int32_t accumulate, void* stream);
 
 /*
  * sgv_conv3x3 with the element-wise steps that surround the convolution of a stride-1 SynthesisLayer / Conv2dLayer folded in
@@ -415,7 +431,11 @@ typedef struct sgv_gemm_params {
                                              discriminator block's two branches (networks.py:343-345) formed in the skip convolution's store */
     int32_t exact_fp32;                   /* 0: products as 2-way bf16 splits on the bf16 matrix pipe (3 MFMAs per product, fp32 accumulate, 4.4e-6 relative error:
                                              the arithmetic of the 3x3 family) where the shape allows (n % 128 == 0, k % 32 == 0, 16-byte aligned rows);
-                                             1: always v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain over k).  SGV_GEMM_TERMS=0 forces 1 for the process */
+                                             1: always v_mfma_f32_32x32x2_f32 (bitwise an fmaf chain over k).  SGV_GEMM_TERMS=0 forces 1 for the process;
+                                             2: the split members with block-scaled fp16 operands (fp32-grade, see sgv_absmax; needs a_amax / b_amax) where the
+                                                shape allows, the exact pipe elsewhere */
+    const float* a_amax;                  /* exact_fp32 = 2: device pointers to ONE fp32 each, upper bounds of max |A| / max |B| over the whole tensors */
+    const float* b_amax;
 } sgv_gemm_params;
 
 int sgv_gemm_f32(const sgv_gemm_params* p, void* stream);
@@ -485,7 +505,8 @@ enum sgv_kernel_family {
     SGV_K_CONV3X3 = 9,          /* every 3x3 convolution launch except the >= 32 pixel stride-1 kernel */
     SGV_K_CONV3X3_S1 = 10,      /* conv3x3_ws_kernel (stride 1, forward and data gradient, images >= 32 pixels): the step's dominant kernel */
     SGV_K_FC = 11,              /* sgv_fc (dense layers; the tiled GEMM keeps SGV_K_GEMM) */
-    SGV_K_COUNT = 12
+    SGV_K_ABSMAX = 12,          /* sgv_absmax: the magnitude-bound passes of the block-scaled fp16 split (timed, not counted by sgv_launch_count) */
+    SGV_K_COUNT = 13
 };
 typedef struct sgv_prof_entry {
     int64_t launches;

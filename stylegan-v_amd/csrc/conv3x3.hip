@@ -49,10 +49,12 @@ bool g_use_ws = true;   // SGV_CONV_WS=0: the 4-wave kernel of conv3x3_kernel.h 
 bool big_image(int h, int w) { return w >= SEG && w % SEG == 0 && h >= TROWS && h % TROWS == 0; }
 
 typedef void (*ws_kernel_t)(conv_ws_params);
-// [terms == 3][PRO][EPI]
-const ws_kernel_t g_ws_kernels[2][2][2] = {
+// [terms: 1 | 3 | 4][PRO][EPI]
+const ws_kernel_t g_ws_kernels[3][2][2] = {
     {{conv3x3_ws_kernel<1, 0, 0>, conv3x3_ws_kernel<1, 0, 1>}, {conv3x3_ws_kernel<1, 1, 0>, conv3x3_ws_kernel<1, 1, 1>}},
-    {{conv3x3_ws_kernel<3, 0, 0>, conv3x3_ws_kernel<3, 0, 1>}, {conv3x3_ws_kernel<3, 1, 0>, conv3x3_ws_kernel<3, 1, 1>}}};
+    {{conv3x3_ws_kernel<3, 0, 0>, conv3x3_ws_kernel<3, 0, 1>}, {conv3x3_ws_kernel<3, 1, 0>, conv3x3_ws_kernel<3, 1, 1>}},
+    {{conv3x3_ws_kernel<4, 0, 0>, conv3x3_ws_kernel<4, 0, 1>}, {conv3x3_ws_kernel<4, 1, 0>, conv3x3_ws_kernel<4, 1, 1>}}};
+int terms_index(int terms) { return terms == 1 ? 0 : terms == 3 ? 1 : 2; }
 // 16-bit tensors: [bf16 | fp16][PRO][EPI]
 const ws_kernel_t g_ws_kernels_io[2][2][2] = {
     {{conv3x3_ws_kernel<1, 0, 0, 0, 1, 1>, conv3x3_ws_kernel<1, 0, 1, 0, 1, 1>}, {conv3x3_ws_kernel<1, 1, 0, 0, 1, 1>, conv3x3_ws_kernel<1, 1, 1, 0, 1, 1>}},
@@ -65,13 +67,15 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<3, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<16>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<8>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<16>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-    for (int t = 0; t < 2; t++) for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) {
+    for (int t = 0; t < 3; t++) for (int a = 0; a < 2; a++) for (int b = 0; b < 2; b++) {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)g_ws_kernels[t][a][b], hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)g_ws_kernels_io[t][a][b], hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
+        if (e == hipSuccess && t < 2) e = hipFuncSetAttribute((const void*)g_ws_kernels_io[t][a][b], hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS_BYTES);
     }
     g_attr_err = e;
     const char* env = getenv("SGV_CONV_WS");
@@ -80,6 +84,12 @@ void init_once() {
     g_s2_ws = !(env && env[0] == '0');
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_ws_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, S2W_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<4, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(2));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<4, 0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(4));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<4, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, TW_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_ws_kernel<1, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, tw_lds_bytes(2));
@@ -92,6 +102,7 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<3, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, P2_LDS_BYTES);
 #define SGV_P2_ATTR(T, E, SS) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<T, 0, E, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds_bytes(SS));
     SGV_P2_ATTR(1, 0, 2) SGV_P2_ATTR(3, 0, 2) SGV_P2_ATTR(1, 1, 2) SGV_P2_ATTR(3, 1, 2) SGV_P2_ATTR(1, 0, 4) SGV_P2_ATTR(3, 0, 4) SGV_P2_ATTR(1, 1, 4) SGV_P2_ATTR(3, 1, 4)
+    SGV_P2_ATTR(4, 0, 2) SGV_P2_ATTR(4, 1, 2) SGV_P2_ATTR(4, 0, 4) SGV_P2_ATTR(4, 1, 4)
 #undef SGV_P2_ATTR
 #define SGV_P2_ATTR_IO(E, SS) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, 0, E, SS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds_bytes(SS)); \
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_pairs_kernel<1, 0, E, SS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, p2_lds_bytes(SS));
@@ -130,13 +141,40 @@ bool s2_mode_ok(int c_out, int h, int mode, int dtype) { return !io16(dtype) || 
 
 }  // namespace
 
+// max |x| of a dense tensor as one fp32 in device memory: the bound the block-scaled fp16 split (terms = 4, sgv_split.h) scales an operand by
+extern "C" int sgv_absmax(const void* x, int64_t numel, int dtype, float* out, int32_t accumulate, void* stream_) {
+    if (!out || (!x && numel > 0) || numel < 0) return sgv_fail(SGV_ERR_INVALID_ARG, "absmax: NULL pointer or negative size");
+    if (dtype != SGV_F32 && dtype != SGV_F16 && dtype != SGV_BF16) return sgv_fail(SGV_ERR_UNSUPPORTED, "absmax: fp32 / fp16 / bf16 tensors only");
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!accumulate && hipMemsetAsync(out, 0, 4, stream) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "absmax: hipMemsetAsync failed");
+    if (numel == 0) return SGV_OK;
+    const unsigned blocks = (unsigned)std::min<int64_t>((numel + 1023) / 1024, 2048);
+    sgv_launch_scope scope(SGV_K_ABSMAX, stream, (double)numel * (dtype == SGV_F32 ? 4.0 : 2.0), 0.0, false);
+    if (dtype == SGV_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (size_t)numel, (unsigned*)out);
+    else if (dtype == SGV_F16) hipLaunchKernelGGL(absmax_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)x, (size_t)numel, (unsigned*)out);
+    else hipLaunchKernelGGL(absmax_kernel<__bf16>, dim3(blocks), dim3(256), 0, stream, (const __bf16*)x, (size_t)numel, (unsigned*)out);
+    return sgv_check_launch("absmax_kernel");
+}
+
 extern "C" int sgv_conv3x3_supported(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int dtype) {
     return supported(n, c_in, c_out, h, w, dtype) ? 1 : 0;
 }
 
+// 16-bit hi + lo per weight, whole 64-row tiles; the last 16 bytes hold the weight's bound for the block-scaled split (terms = 4)
+constexpr int64_t AMAX_TAIL = 16;
 extern "C" int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out) {
-    return (int64_t)c_in * ((c_out + TM - 1) / TM * TM) * 9 * 4;   // bf16 hi + lo per weight, whole 64-row tiles
+    return (int64_t)c_in * ((c_out + TM - 1) / TM * TM) * 9 * 4 + AMAX_TAIL;
 }
+
+namespace {
+// terms = 4: max |w| into the workspace tail (cleared first), for the weight preparation and the kernel's epilogue
+int weight_amax(const float* w, size_t numel, float* slot, hipStream_t stream) {
+    if (hipMemsetAsync(slot, 0, 4, stream) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3: hipMemsetAsync failed");
+    const unsigned blocks = (unsigned)std::min<size_t>((numel + 1023) / 1024, 256);
+    hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(256), 0, stream, w, numel, (unsigned*)slot);
+    return sgv_check_launch("absmax_kernel (weights)");
+}
+}  // namespace
 
 namespace {
 
@@ -147,12 +185,13 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
         return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32 / bf16 / fp16 tensors, c_in %% 16 == 0, c_out %% 32 == 0, and W %% 32 == 0, H %% 16 == 0 (fp32 with c_out %% 64 == 0 also: 16x16 / 8x8 images) (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
                         who, p->n, p->c_in, p->c_out, p->h, p->w, dtype);
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: 16-bit tensors need terms = 1 (one bf16 operand per value)", who);
+    if (p->terms == 4 && !p->x_amax) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: terms = 4 (block-scaled fp16 split) needs x_amax, a device pointer to an upper bound of max |x| (sgv_absmax)", who);
     if (io16(dtype) && ep && ep->accumulate) return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: accumulate needs fp32 tensors", who);
     if (ep && !big_image(p->h, p->w)) return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: the fused form needs W %% 32 == 0 and H %% 16 == 0 (got h=%d w=%d)", who, p->h, p->w);
     if (ep && (ep->act != 1 && ep->act != 3)) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: act must be 1 (linear) or 3 (lrelu)", who);
     if (ep && (!(ep->gain > 0.f) || (ep->act == 3 && !(ep->alpha >= 0.f && ep->alpha <= 1.f)))) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: needs gain > 0 and 0 <= alpha <= 1", who);
     if (p->mode != 0 && p->mode != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: mode must be 0 (forward) or 1 (data gradient)", who);
-    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: terms must be 1 or 3", who);
+    if (p->terms != 1 && p->terms != 3 && p->terms != 4) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: terms must be 1, 3 or 4", who);
     if (p->workspace_bytes < sgv_conv3x3_workspace_bytes(p->c_in, p->c_out)) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: workspace is too small", who);
     if ((((uintptr_t)p->x) | ((uintptr_t)p->y) | ((uintptr_t)p->workspace)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: x, y and workspace must be 16-byte aligned", who);
     if (ep && ep->x_scale && (((uintptr_t)ep->x_scale) & 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: x_scale must be 16-byte aligned", who);
@@ -161,14 +200,18 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     hipStream_t stream = (hipStream_t)stream_;
 
     const int words = tiles_m(p->c_out) * (p->c_in / KC) * 9 * 2 * TM;
+    float* w_amax = (float*)((char*)p->workspace + sgv_conv3x3_workspace_bytes(p->c_in, p->c_out) - AMAX_TAIL);
+    int rc = SGV_OK;
+    if (p->terms == 4 && (rc = weight_amax(p->weight, (size_t)p->c_in * p->c_out * 9, w_amax, stream)) != SGV_OK) return rc;
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
-                       p->terms);
-    int rc = sgv_check_launch("conv3x3_prep_weights");
+                       p->terms, (const float*)w_amax);
+    rc = sgv_check_launch("conv3x3_prep_weights");
     if (rc != SGV_OK) return rc;
 
     conv_params kp{};
     kp.x = (const float*)p->x; kp.wprep = (const u32x4*)p->workspace; kp.y = (float*)p->y;
     kp.n = p->n; kp.k = p->c_in; kp.m = p->c_out; kp.h = p->h; kp.w = p->w;
+    if (p->terms == 4) { kp.x_amax = p->x_amax; kp.x_amax2 = p->x_amax2; kp.w_amax = w_amax; }
     const int small = big_image(p->h, p->w) ? 0 : small_samples(p->n, p->h, p->w);
     kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * tiles_m(p->c_out);
     kp.grid = std::min(kp.tiles, g_cus);
@@ -178,15 +221,17 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     if (small) {
         if (p->w == 16) {
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
-            else hipLaunchKernelGGL((conv3x3_small_kernel<3, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
+            else if (p->terms == 3) hipLaunchKernelGGL((conv3x3_small_kernel<3, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
+            else hipLaunchKernelGGL((conv3x3_small_kernel<4, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
         } else {
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
-            else hipLaunchKernelGGL((conv3x3_small_kernel<3, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
+            else if (p->terms == 3) hipLaunchKernelGGL((conv3x3_small_kernel<3, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
+            else hipLaunchKernelGGL((conv3x3_small_kernel<4, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
         }
         sgv_note_variant(SGV_V_conv_small);
         return sgv_check_launch("conv3x3_small_kernel");
     }
-    if (ep || g_use_ws || io16(dtype) || p->c_out % TM != 0) {     // (half-full m tiles: the producer / consumer kernel only)
+    if (ep || g_use_ws || io16(dtype) || p->c_out % TM != 0 || p->terms == 4) {     // (half-full m tiles, the block-scaled split: the producer / consumer kernel only)
         conv_ws_params wp{};
         wp.c = kp;
         int pro = 0, epi = 0;
@@ -201,10 +246,12 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
             hipLaunchKernelGGL(g_ws_kernels_io[dtype == SGV_F16][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
             sgv_note_variant(SGV_V_conv_lowp);
             if (pro || epi) sgv_note_variant(SGV_V_conv_s1_ws_fused);
+            if (p->c_out % TM != 0) sgv_note_variant(SGV_V_conv_s1_half_tile);
             return sgv_check_launch("conv3x3_ws_kernel (16-bit tensors)");
         }
-        hipLaunchKernelGGL(g_ws_kernels[p->terms == 3][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
+        hipLaunchKernelGGL(g_ws_kernels[terms_index(p->terms)][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
         sgv_note_variant((pro || epi) ? SGV_V_conv_s1_ws_fused : (ep && ep->accumulate) ? SGV_V_conv_s1_ws_accumulate : SGV_V_conv_s1_ws);
+        if (p->c_out % TM != 0) sgv_note_variant(SGV_V_conv_s1_half_tile);     // (the last 64-row tile is half full: the 32-channel layers at 1024^2)
         return sgv_check_launch("conv3x3_ws_kernel");
     }
     if (p->terms == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
@@ -234,7 +281,7 @@ extern "C" int sgv_conv3x3_s2_supported(int32_t n, int32_t c_in, int32_t c_out, 
 extern "C" int64_t sgv_conv3x3_s2_workspace_bytes(int32_t n, int32_t c_in, int32_t c_out, int32_t h, int32_t w, int32_t mode) {
     int64_t bytes = (int64_t)c_in * ((c_out + TM - 1) / TM * TM) * 10 * 4;   // nine taps, ten in the tap-pair layout of conv3x3_s2_pairs_kernel; whole 64-row tiles
     if (mode == 2) bytes += (int64_t)convT3x3_s2_edge_floats(n, c_in, c_out, h, w) * 4;
-    return bytes;
+    return (bytes + 15) / 16 * 16 + AMAX_TAIL;       // + the weight's bound for the block-scaled split (terms = 4)
 }
 
 namespace {
@@ -249,8 +296,10 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     if ((!packed && !supported_s2(p->n, p->c_in, p->c_out, p->h, p->w, dtype, p->mode)) || !s2_mode_ok(p->c_out, p->h, p->mode, dtype))
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs c_in %% 16 == 0, c_out %% 64 == 0 (transposed form: %% 32), W %% 32 == 0, H %% 8 == 0 on the HxW grid; 16-bit tensors: the strided form with c_out %% 128 == 0, the transposed form with the MFMA edge strips (got n=%d c_in=%d c_out=%d h=%d w=%d mode=%d dtype=%d)",
                         p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
-    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms must be 1 or 3");
+    if (p->terms != 1 && p->terms != 3 && p->terms != 4) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms must be 1, 3 or 4");
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: 16-bit tensors need terms = 1 (one bf16 operand per value)");
+    if (p->terms == 4 && !p->x_amax) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms = 4 (block-scaled fp16 split) needs x_amax, a device pointer to an upper bound of max |x| (sgv_absmax)");
+    if (p->terms == 4 && (!g_s2_ws || (p->mode == 2 && !g_edge_mfma))) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: terms = 4 is served by the producer / consumer kernels only (SGV_S2_WS / SGV_CONVT_EDGE_MFMA are off)");
     if (io16(dtype) && ep && ep->accumulate) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2_fused: accumulate needs fp32 tensors");
     const int io = dtype == SGV_BF16 ? 1 : dtype == SGV_F16 ? 2 : 0;
     if (p->workspace_bytes < sgv_conv3x3_s2_workspace_bytes(p->n, p->c_in, p->c_out, p->h, p->w, p->mode)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: workspace is too small");
@@ -266,15 +315,18 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         if (!(ep->gain > 0.f) || (ep->act == 3 && !(ep->alpha >= 0.f && ep->alpha <= 1.f))) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: needs gain > 0 and 0 <= alpha <= 1");
         if (ep->bias && (((uintptr_t)ep->bias) & 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: bias must be 16-byte aligned");
     }
-    int rc;
+    int rc = SGV_OK;
+    float* w_amax = (float*)((char*)p->workspace + sgv_conv3x3_s2_workspace_bytes(p->n, p->c_in, p->c_out, p->h, p->w, p->mode) - AMAX_TAIL);
+    if (p->terms == 4 && (rc = weight_amax(p->weight, (size_t)p->c_in * p->c_out * 9, w_amax, stream)) != SGV_OK) return rc;
     if (pairs) {
         const int words = (p->c_out / P2_TM) * (p->c_in / P2_KC) * 10 * P2_TM;
-        hipLaunchKernelGGL(conv3x3_prep_weights_pairs, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->terms);
+        hipLaunchKernelGGL(conv3x3_prep_weights_pairs, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->terms,
+                           (const float*)w_amax);
         rc = sgv_check_launch("conv3x3_prep_weights_pairs");
     } else {
         const int words = tiles_m(p->c_out) * (p->c_in / KC) * 9 * 2 * TM;
         hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
-                           p->terms);
+                           p->terms, (const float*)w_amax);
         rc = sgv_check_launch("conv3x3_prep_weights");
     }
     if (rc != SGV_OK) return rc;
@@ -282,6 +334,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     s2_params kp{};
     kp.x = (const float*)p->x; kp.wprep = (const u32x4*)p->workspace; kp.y = (float*)p->y;
     kp.n = p->n; kp.k = p->c_in; kp.m = p->c_out; kp.h = p->h; kp.w = p->w;
+    if (p->terms == 4) { kp.x_amax = p->x_amax; kp.w_amax = w_amax; }
     kp.tiles = p->n * (p->h / S_ROWS) * (p->w / SEG) * (p->c_out / TM);
     kp.grid = std::min(kp.tiles, g_cus);
     const double small_px = (double)p->n * p->h * p->w, big_px = (double)p->n * (2 * p->h + 1) * (2 * p->w + 1);
@@ -297,8 +350,8 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
 #define SGV_P2_S(T, E, IO) do { if (ss == 1) SGV_P2_GO(T, E, 1, IO); else if (ss == 2) SGV_P2_GO(T, E, 2, IO); else SGV_P2_GO(T, E, 4, IO); } while (0)
         if (io == 1) { if (ep) SGV_P2_S(1, 1, 1); else SGV_P2_S(1, 0, 1); }
         else if (io == 2) { if (ep) SGV_P2_S(1, 1, 2); else SGV_P2_S(1, 0, 2); }
-        else if (ep) { if (p->terms == 1) SGV_P2_S(1, 1, 0); else SGV_P2_S(3, 1, 0); }
-        else { if (p->terms == 1) SGV_P2_S(1, 0, 0); else SGV_P2_S(3, 0, 0); }
+        else if (ep) { if (p->terms == 1) SGV_P2_S(1, 1, 0); else if (p->terms == 3) SGV_P2_S(3, 1, 0); else SGV_P2_S(4, 1, 0); }
+        else { if (p->terms == 1) SGV_P2_S(1, 0, 0); else if (p->terms == 3) SGV_P2_S(3, 0, 0); else SGV_P2_S(4, 0, 0); }
 #undef SGV_P2_S
 #undef SGV_P2_GO
         if (io) sgv_note_variant(SGV_V_conv_s2_lowp);
@@ -309,7 +362,8 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         kp.tiles = p->n * (p->h / S2W_ROWS) * (p->w / SEG) * (p->c_out / TM);
         kp.grid = std::min(kp.tiles, g_cus);
         if (p->terms == 1) hipLaunchKernelGGL(conv3x3_s2_ws_kernel<1>, dim3((unsigned)kp.grid), dim3(512), S2W_LDS_BYTES, stream, kp);
-        else hipLaunchKernelGGL(conv3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(512), S2W_LDS_BYTES, stream, kp);
+        else if (p->terms == 3) hipLaunchKernelGGL(conv3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(512), S2W_LDS_BYTES, stream, kp);
+        else hipLaunchKernelGGL(conv3x3_s2_ws_kernel<4>, dim3((unsigned)kp.grid), dim3(512), S2W_LDS_BYTES, stream, kp);
         sgv_note_variant(SGV_V_conv_s2_ws);
         return sgv_check_launch("conv3x3_s2_ws_kernel");
     }
@@ -335,21 +389,25 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         kp.grid = std::min(kp.tiles, g_cus);
         if (ss == 2) {
             if (p->terms == 1) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<1, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
-            else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
+            else if (p->terms == 3) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
+            else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<4, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
         } else {
             if (p->terms == 1) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<1, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
-            else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
+            else if (p->terms == 3) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
+            else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<4, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
         }
     } else if (g_s2_ws) {
         kp.tiles = p->n * (p->h / TW_ROWS) * (p->w / SEG) * tiles_m(p->c_out);
         kp.grid = std::min(kp.tiles, g_cus);
         if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_ws_kernel<1>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
-        else hipLaunchKernelGGL(convT3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
+        else if (p->terms == 3) hipLaunchKernelGGL(convT3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
+        else hipLaunchKernelGGL(convT3x3_s2_ws_kernel<4>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
     } else {
         if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL(convT3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
     }
     sgv_note_variant(packed ? SGV_V_convT_ws_packed : g_s2_ws ? SGV_V_convT_ws : SGV_V_convT_1role);
+    if (p->c_out % TM != 0) sgv_note_variant(SGV_V_convT_half_tile);
     rc = sgv_check_launch("convT3x3_s2_kernel");
     if (rc != SGV_OK) return rc;
     if (!g_edge_mfma) {

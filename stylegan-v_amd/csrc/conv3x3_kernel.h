@@ -23,6 +23,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sgv_split.h"
+
 namespace sgv_conv {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -51,6 +53,11 @@ struct conv_params {
     int n, k, m, h, w;
     int tiles;             // n * (h/16) * (w/32) * (m/64)
     int grid;              // persistent workgroups
+    // TERMS = 4 (block-scaled fp16 split, sgv_split.h): device pointers to upper bounds of max |x| (optionally a second factor: x * styles) and of
+    // max |weight| (written by sgv_absmax_kernel in front of the weight preparation); NULL otherwise
+    const float* x_amax;
+    const float* x_amax2;
+    const float* w_amax;
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -295,6 +302,8 @@ struct small_stage { f32x4 xa[8]; u32x4 wv[9]; };
 template <int TERMS, int SW>
 __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
     typedef small_cfg<SW> C;
+    const int ex = operand_exponent<TERMS>(p.x_amax, p.x_amax2), ew = operand_exponent<TERMS>(p.w_amax);
+    const float xS = split_scale(ex);
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];
     u32x4* xs = lds;
     u32x4* ws = lds + C::XS;
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = s.xa[j][px];
             u32x4 hi, lo;
-            split8(v, hi, lo);
+            split8t<TERMS>(v, xS, hi, lo);
             xs[a_pos + px] = hi;
             if (TERMS > 1) xs[2 * C::PLANE + a_pos + px] = lo;
         }
@@ -391,18 +400,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
                 for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][1]), __builtin_bit_cast(bf16x8, b_hi[r]), acc[r][hf], 0, 0, 0);
+                        acc[r][hf] = mma16<TERMS>(a[hf][1], b_hi[r], acc[r][hf]);
 #pragma unroll
                 for (int r = 0; r < 4; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_lo[r]), acc[r][hf], 0, 0, 0);
+                        acc[r][hf] = mma16<TERMS>(a[hf][0], b_lo[r], acc[r][hf]);
             }
 #pragma unroll
             for (int r = 0; r < 4; r++)
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
-                    acc[r][hf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[hf][0]), __builtin_bit_cast(bf16x8, b_hi[r]), acc[r][hf], 0, 0, 0);
+                    acc[r][hf] = mma16<TERMS>(a[hf][0], b_hi[r], acc[r][hf]);
         }
 
         if (c == chunks - 1) {
@@ -414,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-                        yb[(size_t)m * plane] = acc[r][hf][e];
+                        yb[(size_t)m * plane] = TERMS == 4 ? __builtin_ldexpf(acc[r][hf][e], unscale_exponent(ex, ew)) : acc[r][hf][e];
                         acc[r][hf][e] = 0.f;
                     }
             }
@@ -431,7 +440,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
 // mode 0: wgt(m,k,ky,kx) = w[m][k][ky][kx]            (forward;  w is [M, K, 3, 3])
 // mode 1: wgt(m,k,ky,kx) = w[k][m][2-ky][2-kx]        (data gradient of the same layer; w is [K, M, 3, 3])
 // mode 2: wgt(m,k,ky,kx) = w[k][m][ky][kx]            (transposed convolution;         w is [K, M, 3, 3])
-__global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x4* out, int m_total, int k_total, int mode, int terms) {
+// terms = 4: fp16 hi/lo of w * 2^(14 - e), e from the bound `w_amax` (sgv_split.h).
+__global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x4* out, int m_total, int k_total, int mode, int terms, const float* w_amax = nullptr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // one 16-B output word (8 k) of the hi plane
     const int chunks = k_total / KC;
     const int total = ((m_total + TM - 1) / TM) * chunks * 9 * 2 * TM;     // rows beyond m_total (a half-full last tile) are zero weights
@@ -451,10 +461,36 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x
              : mode == 1 ? w[(((size_t)(k0 + j) * m_total + m) * 3 + (2 - ky)) * 3 + (2 - kx)]
                          : w[(((size_t)(k0 + j) * m_total + m) * 3 + ky) * 3 + kx];
     u32x4 hi, lo;
-    split8(v, hi, lo);
+    if (terms == 4) split8t<4>(v, split_scale(amax_exponent(*w_amax)), hi, lo);
+    else split8(v, hi, lo);
     const size_t base = ((size_t)mt * chunks + c) * WS_WORDS;
     out[base + ((0 * 9 + tap) * 2 + oct) * TM + mi] = hi;
     if (terms > 1) out[base + ((1 * 9 + tap) * 2 + oct) * TM + mi] = lo;
+}
+
+
+// max |v| of a tensor as an fp32 bit pattern (non-negative floats order like unsigned integers); NaN / inf propagate as the largest patterns.
+// `out` must hold 0 (or a previous bound to extend) on entry.
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T* x, size_t n, unsigned* out) {
+    unsigned m = 0u;
+    const size_t stride = (size_t)gridDim.x * 256 * 4;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+        if constexpr (sizeof(T) == 4) {
+            if (i + 4 <= n && (((uintptr_t)x) & 15) == 0) {
+                const u32x4 v = *(const u32x4*)((const unsigned*)x + i);
+#pragma unroll
+                for (int j = 0; j < 4; j++) m = max(m, v[j] & 0x7fffffffu);
+            } else {
+                for (size_t j = i; j < n && j < i + 4; j++) m = max(m, ((const unsigned*)x)[j] & 0x7fffffffu);
+            }
+        } else {   // 16-bit elements: widen the bit pattern (bf16: << 16; fp16 is converted by the caller's instantiation)
+            for (size_t j = i; j < n && j < i + 4; j++) m = max(m, __builtin_bit_cast(unsigned, (float)x[j]) & 0x7fffffffu);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 }  // namespace sgv_conv

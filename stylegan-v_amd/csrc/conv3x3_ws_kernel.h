@@ -47,10 +47,10 @@ struct conv_ws_params {
 //      c0 = oscale * gain, c1 = bias * gain, c2 = c0 * alpha, c3 = c1 * alpha prepared per tile by the producers (valid for gain > 0,
 //      0 <= alpha <= 1; alpha = 1 is the linear activation): 3 VALU operations per output in the consumer, which is what the MFMA waves
 //      can afford.  Differs from the three-pass composition (networks.py:70-71 + bias_act.cu:39-146) by fused-multiply-add rounding only.
-template <int ABL>
+template <int ABL, int TERMS = 3>
 __device__ __forceinline__ f32x16 ws_mma(u32x4 a, u32x4 b, f32x16 c) {
     if (ABL == 2) { asm volatile("" :: "v"(a), "v"(b)); return c; }   // lab ablation: keep the operand reads, drop the MFMA
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+    return mma16<TERMS>(a, b, c);      // bf16 operands; fp16 ones for the block-scaled split (TERMS = 4, sgv_split.h)
 }
 
 // ABL (tools/conv_lab.hip only; results are wrong by construction): 1 producers only keep the barrier protocol (consumer-only speed), 2 no MFMAs
@@ -67,6 +67,7 @@ __device__ __forceinline__ f32x16 ws_mma(u32x4 a, u32x4 b, f32x16 c) {
 //      tap-major order on every shape (profiles/r03_conv_lab_ws_row_reuse.log; consumers alone 0.806 vs 0.808 ms).  The 0.60 ms of the no-read ablation is the
 //      matrix pipe on constant operands (no data toggling, 2.2 GHz); on real data the part holds ~1.85 GHz and the loop alone is at 89 % of that ceiling.
 //      Kept as a lab variant (default 0); same products, a different summation order (kx outermost) than the 4-wave kernel.
+// TERMS: 1 bf16 products, 3 bf16 split, 4 block-scaled fp16 split (fp32-grade; sgv_split.h) -- same LDS images, same MFMA count as 3.
 template <int TERMS, int PRO, int EPI, int ABL = 0, int PRIO = 1, int IO = 0, int ORD = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
     constexpr bool A_IDLE = ABL == 1 || ABL == 6 || ABL == 7, A_NOSTORE = ABL == 4 || ABL == 6, A_NOREAD = ABL == 3 || ABL == 7;
@@ -78,6 +79,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int chunks = p.k / KC;
     const size_t plane = (size_t)p.h * p.w;
+    // TERMS = 4: the operands' block exponents (wave-uniform; read before any counted asm load is in flight)
+    const int ex = operand_exponent<TERMS>(p.x_amax, p.x_amax2), ew = operand_exponent<TERMS>(p.w_amax);
+    const float xS = split_scale(ex);
+    const int eu = unscale_exponent(ex, ew);
 
     // flat sequence of (tile, chunk) pairs of this workgroup: q -> tile = first + (q / chunks) * grid, chunk = q % chunks
     const int first = xcd_swizzle(blockIdx.x, gridDim.x);
@@ -178,7 +183,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = ok ? (PRO == 1 ? v[j] * r.sc[j >> 2][j & 3] : v[j]) : 0.f;
             u32x4 hi, lo;
-            split8(v, hi, lo);
+            split8t<TERMS>(v, xS, hi, lo);
             xs[pos] = hi;
             if (TERMS > 1) xs[2 * XS_PLANE + pos] = lo;
         };
@@ -212,7 +217,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         auto put_ep = [&](int q, u32x4* img, const xset& r) {   // the tile's epilogue vectors ride with its LAST chunk (r: that chunk's set)
             if (EPI == 0 || (q % chunks) != chunks - 1 || pt >= TM) return;
             float* ep = (float*)(img + XS_WORDS + WS_WORDS);
-            const float c0 = (pp.oscale ? r.ep0 : 1.f) * pp.gain;
+            float c0 = (pp.oscale ? r.ep0 : 1.f) * pp.gain;
+            if (TERMS == 4) c0 = __builtin_ldexpf(c0, eu);      // the accumulators carry both operands' block scales
             const float c1 = (pp.bias ? r.ep1 : 0.f) * pp.gain;
             const float al = pp.act == 3 ? pp.alpha : 1.f;
             ep[pt] = c0;
@@ -314,18 +320,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                     for (int ky = ky_lo; ky <= ky_hi; ky++)
 #pragma unroll
                         for (int hf = 0; hf < 2; hf++)
-                            acc[j - ky][hf] = ws_mma<ABL>(A[ky][hf][1], B[bb][0], acc[j - ky][hf]);
+                            acc[j - ky][hf] = ws_mma<ABL, TERMS>(A[ky][hf][1], B[bb][0], acc[j - ky][hf]);
 #pragma unroll
                     for (int ky = ky_lo; ky <= ky_hi; ky++)
 #pragma unroll
                         for (int hf = 0; hf < 2; hf++)
-                            acc[j - ky][hf] = ws_mma<ABL>(A[ky][hf][0], B[bb][1], acc[j - ky][hf]);
+                            acc[j - ky][hf] = ws_mma<ABL, TERMS>(A[ky][hf][0], B[bb][1], acc[j - ky][hf]);
                 }
 #pragma unroll
                 for (int ky = ky_lo; ky <= ky_hi; ky++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[j - ky][hf] = ws_mma<ABL>(A[ky][hf][0], B[bb][0], acc[j - ky][hf]);
+                        acc[j - ky][hf] = ws_mma<ABL, TERMS>(A[ky][hf][0], B[bb][0], acc[j - ky][hf]);
                 const int MF = (TERMS > 1 ? 6 : 2) * (ky_hi - ky_lo + 1);
 #pragma unroll
                 for (int i = 0; i < MF; i++) {
@@ -372,18 +378,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[2 * rh + r][hf] = ws_mma<ABL>(a[ab][hf][1], b[bb][r][0], acc[2 * rh + r][hf]);
+                        acc[2 * rh + r][hf] = ws_mma<ABL, TERMS>(a[ab][hf][1], b[bb][r][0], acc[2 * rh + r][hf]);
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[2 * rh + r][hf] = ws_mma<ABL>(a[ab][hf][0], b[bb][r][1], acc[2 * rh + r][hf]);
+                        acc[2 * rh + r][hf] = ws_mma<ABL, TERMS>(a[ab][hf][0], b[bb][r][1], acc[2 * rh + r][hf]);
             }
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
-                    acc[2 * rh + r][hf] = ws_mma<ABL>(a[ab][hf][0], b[bb][r][0], acc[2 * rh + r][hf]);
+                    acc[2 * rh + r][hf] = ws_mma<ABL, TERMS>(a[ab][hf][0], b[bb][r][0], acc[2 * rh + r][hf]);
             // pin the interleave: one operand read of step s+1 behind each of the first MFMAs of step s (the MFMA issues every 32 cycles,
             // a ds_read_b128 costs one issue slot), so the reads are spread over the step and nothing is fetched earlier than needed
             constexpr int MF = TERMS > 1 ? 12 : 4;
@@ -431,6 +437,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
 #pragma unroll
                             for (int ei = 0; ei < 4; ei++) {
                                 float v = acc[r][hf][4 * e4 + ei];
+                                if (TERMS == 4 && EPI != 1) v = __builtin_ldexpf(v, eu);
                                 if (EPI == 1) {
                                     v = fmaxf(__builtin_fmaf(v, c0[ei], c1[ei]), __builtin_fmaf(v, c2[ei], c3[ei]));
                                     if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);

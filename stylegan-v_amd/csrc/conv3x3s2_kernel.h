@@ -40,6 +40,8 @@ struct s2_params {
     int n, k, m, h, w;     // h, w: the SMALL grid (strided: output; transposed: input)
     int tiles, grid;
     int order;             // producer / consumer forms: 1 = a workgroup runs all m tiles of a spatial tile back to back
+    const float* x_amax;   // TERMS = 4 (block-scaled fp16 split, sgv_split.h; producer / consumer forms): bounds of max |x| and max |weight|
+    const float* w_amax;
 };
 
 __device__ __forceinline__ tile_pos decode_tile_s2(const s2_params& p, int tile, int rows) {

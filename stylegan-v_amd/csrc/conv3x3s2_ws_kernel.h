@@ -47,6 +47,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_ws_kernel(s2_params p) {
     const int chunks = p.k / KC;
     const int win = 2 * p.w + 1;
     const size_t plane_in = (size_t)(2 * p.h + 1) * win, plane_out = (size_t)p.h * p.w;
+    const int ex = operand_exponent<TERMS>(p.x_amax), ew = operand_exponent<TERMS>(p.w_amax);   // TERMS = 4: block exponents (sgv_split.h)
+    const float xS = split_scale(ex);
+    const int eu = unscale_exponent(ex, ew);
 
     // order 0: tile i of the launch goes to workgroup i % grid (the m tiles of one x tile run side by side on neighbouring CUs of an XCD);
     // order 1: a workgroup takes a spatial tile and runs all its m tiles back to back (x re-read by the same CU: L2-resident by construction)
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_ws_kernel(s2_params p) {
         };
         auto put = [&](u32x4* xs, int pos, const float* v) {
             u32x4 hi, lo;
-            split8(v, hi, lo);
+            split8t<TERMS>(v, xS, hi, lo);
             xs[pos] = hi;
             if (TERMS > 1) xs[2 * S2W_XS_PLANE + pos] = lo;
         };
@@ -214,12 +217,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_ws_kernel(s2_params p) {
             if (tap + 2 < 9) fetch((tap + 2) % 3, tap + 2);
             if (TERMS > 1) {
 #pragma unroll
-                for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0)>(a[bb][hf][1], b[bb][0], acc[hf]);
+                for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0), TERMS>(a[bb][hf][1], b[bb][0], acc[hf]);
 #pragma unroll
-                for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0)>(a[bb][hf][0], b[bb][1], acc[hf]);
+                for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0), TERMS>(a[bb][hf][0], b[bb][1], acc[hf]);
             }
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0)>(a[bb][hf][0], b[bb][0], acc[hf]);
+            for (int hf = 0; hf < 2; hf++) acc[hf] = ws_mma<(ABL == 4 ? 2 : 0), TERMS>(a[bb][hf][0], b[bb][0], acc[hf]);
             constexpr int MF = TERMS > 1 ? 6 : 2;
             const int reads = tap + 2 < 9 ? RD : 0;
 #pragma unroll
@@ -242,7 +245,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_ws_kernel(s2_params p) {
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-                    yb[(size_t)m * plane_out] = acc[hf][e];
+                    yb[(size_t)m * plane_out] = TERMS == 4 ? __builtin_ldexpf(acc[hf][e], eu) : acc[hf][e];
                     acc[hf][e] = 0.f;
                 }
         }
@@ -281,7 +284,7 @@ constexpr int p2_lds_bytes(int s) { return 2 * p2_image_words(s) * 16; }
 constexpr int P2_LDS_BYTES = p2_lds_bytes(1);
 
 // fp32 [M, K, 3, 3] -> bf16 hi/lo in [m tile of 128][chunk of 8 k][hl][pair][tap in pair][128 m][8 k]; tap 9 is zero.
-__global__ __launch_bounds__(256) void conv3x3_prep_weights_pairs(const float* w, u32x4* out, int m_total, int k_total, int terms) {
+__global__ __launch_bounds__(256) void conv3x3_prep_weights_pairs(const float* w, u32x4* out, int m_total, int k_total, int terms, const float* w_amax = nullptr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     const int chunks = k_total / P2_KC;
     const int total = (m_total / P2_TM) * chunks * 10 * P2_TM;
@@ -296,7 +299,8 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights_pairs(const float* w
 #pragma unroll
     for (int j = 0; j < 8; j++) v[j] = tap < 9 ? w[((size_t)m * k_total + k0 + j) * 9 + tap] : 0.f;
     u32x4 hi, lo;
-    split8(v, hi, lo);
+    if (terms == 4) split8t<4>(v, split_scale(amax_exponent(*w_amax)), hi, lo);
+    else split8(v, hi, lo);
     const size_t base = ((size_t)mt * chunks + c) * P2_WS_WORDS;
     out[base + (0 * 10 + tap) * P2_TM + mi] = hi;
     if (terms > 1) out[base + (1 * 10 + tap) * P2_TM + mi] = lo;
@@ -344,6 +348,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
     const int chunks = p.k / P2_KC;
     const int win = 2 * p.w + 1;
     const size_t plane_in = (size_t)(2 * p.h + 1) * win, plane_out = (size_t)p.h * p.w;
+    const int ex = operand_exponent<TERMS>(p.x_amax), ew = operand_exponent<TERMS>(p.w_amax);   // TERMS = 4: block exponents (sgv_split.h)
+    const float xS = split_scale(ex);
+    const int eu = unscale_exponent(ex, ew);
 
     const int first = xcd_swizzle(blockIdx.x, gridDim.x);
     if (first >= p.tiles) return;
@@ -411,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
         };
         auto put = [&](u32x4* xs, int pos, const float* v) {
             u32x4 hi, lo;
-            split8(v, hi, lo);
+            split8t<TERMS>(v, xS, hi, lo);
             xs[pos] = hi;
             if (TERMS > 1) xs[P2_XS_PLANE + pos] = lo;
         };
@@ -512,16 +519,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
-                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0>(a[bb][mq][1], b[bb][r][0], acc[r][mq]);
+                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, TERMS>(a[bb][mq][1], b[bb][r][0], acc[r][mq]);
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
-                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0>(a[bb][mq][0], b[bb][r][1], acc[r][mq]);
+                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, TERMS>(a[bb][mq][0], b[bb][r][1], acc[r][mq]);
             }
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
-                for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0>(a[bb][mq][0], b[bb][r][0], acc[r][mq]);
+                for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, TERMS>(a[bb][mq][0], b[bb][r][0], acc[r][mq]);
             constexpr int MF = TERMS > 1 ? 24 : 8;
             const int reads = pair + 1 < 5 ? RD : 0;
 #pragma unroll
@@ -540,6 +547,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
             const size_t off0 = ((size_t)(tp.n + (le & 31) / SW) * p.m + tp.mt * P2_TM) * plane_out + (size_t)(tp.y0 + 2 * wave) * p.w + tp.x0 + (le & 31) % SW;
             const float al = ep.act == 3 ? ep.alpha : 1.f;
             const float g0 = ep.gain, g1 = ep.gain * al;
+            const float g0s = TERMS == 4 ? __builtin_ldexpf(g0, eu) : g0, g1s = TERMS == 4 ? __builtin_ldexpf(g1, eu) : g1;   // ... on accumulators that carry the block scales
             // all sixteen bias vectors of the tile first (from the LDS copy the DMA wave made with this chunk's weights)
             const float* bias_lds = (const float*)(ws + P2_WS_WORDS);
             f32x4 bvs[4][4];
@@ -567,8 +575,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
                             for (int r = 0; r < 2; r++) {
                                 const size_t idx = (size_t)(m0 + ei) * plane_out + (size_t)r * p.w;
                                 float v = acc[r][mq][4 * e4 + ei];
+                                if (TERMS == 4 && EPI != 1) v = __builtin_ldexpf(v, eu);
                                 if (EPI == 1) {
-                                    v = fmaxf(__builtin_fmaf(v, g0, bv[ei] * g0), __builtin_fmaf(v, g1, bv[ei] * g1));
+                                    v = fmaxf(__builtin_fmaf(v, g0s, bv[ei] * g0), __builtin_fmaf(v, g1s, bv[ei] * g1));
                                     if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
                                     if (ep.act_out) out_store<IO>(ep.act_out, off0 + idx, v);
                                 }
@@ -640,6 +649,9 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
     const int chunks = p.k / KC;
     const int wout = 2 * p.w + 1;
     const size_t plane_in = (size_t)p.h * p.w, plane_out = (size_t)(2 * p.h + 1) * wout;
+    const int ex = operand_exponent<TERMS>(p.x_amax), ew = operand_exponent<TERMS>(p.w_amax);   // TERMS = 4: block exponents (sgv_split.h)
+    const float xS = split_scale(ex);
+    const int eu = unscale_exponent(ex, ew);
 
     const int first = xcd_swizzle(blockIdx.x, gridDim.x);
     if (first >= p.tiles) return;
@@ -703,7 +715,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = ok ? v[j] : 0.f;
             u32x4 hi, lo;
-            split8(v, hi, lo);
+            split8t<TERMS>(v, xS, hi, lo);
             xs[pos] = hi;
             if (TERMS > 1) xs[2 * TW_XS_PLANE + pos] = lo;
         };
@@ -801,12 +813,12 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
             if (tap + 2 < 9) fetch((tap + 2) % 3, tap + 2);
             if (TERMS > 1) {
 #pragma unroll
-                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0>(a[bb][hf][1], b[bb][0], acc[cl][hf]);
+                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, TERMS>(a[bb][hf][1], b[bb][0], acc[cl][hf]);
 #pragma unroll
-                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0>(a[bb][hf][0], b[bb][1], acc[cl][hf]);
+                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, TERMS>(a[bb][hf][0], b[bb][1], acc[cl][hf]);
             }
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0>(a[bb][hf][0], b[bb][0], acc[cl][hf]);
+            for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, TERMS>(a[bb][hf][0], b[bb][0], acc[cl][hf]);
             constexpr int MF = TERMS > 1 ? 6 : 2;
             const int reads = tap + 2 < 9 ? RD : 0;
 #pragma unroll
@@ -836,8 +848,8 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
                         if (hf * 32 >= m_left) { acc[a2 * 2 + 0][hf][e] = 0.f; acc[a2 * 2 + 1][hf][e] = 0.f; continue; }
                         if (ABL == 8 || ABL == 10) { asm volatile("" :: "v"(acc[a2 * 2 + 0][hf][e])); asm volatile("" :: "v"(acc[a2 * 2 + 1][hf][e])); }   // lab: no stores
                         else {
-                            out_store<IO>(p.y, qd, acc[a2 * 2 + 0][hf][e]);
-                            out_store<IO>(p.y, qd + 1, acc[a2 * 2 + 1][hf][e]);
+                            out_store<IO>(p.y, qd, TERMS == 4 ? __builtin_ldexpf(acc[a2 * 2 + 0][hf][e], eu) : acc[a2 * 2 + 0][hf][e]);
+                            out_store<IO>(p.y, qd + 1, TERMS == 4 ? __builtin_ldexpf(acc[a2 * 2 + 1][hf][e], eu) : acc[a2 * 2 + 1][hf][e]);
                         }
                         acc[a2 * 2 + 0][hf][e] = 0.f;
                         acc[a2 * 2 + 1][hf][e] = 0.f;

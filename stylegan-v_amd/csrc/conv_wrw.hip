@@ -52,6 +52,8 @@ void init_s2_once() {
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, false, 0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void*)wrw3x3_s2_ws_kernel<1, true, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, WRW_S2_WS_LDS_BYTES);
@@ -74,14 +76,16 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
     if (!supported(p->n, p->c_out, p->c_in, p->h, p->w, dtype))
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw: needs fp32, channels %% 64 == 0, W %% 32 == 0 with H <= 32 or H %% 32 == 0, or W in {16, 8} with H <= 32 (got n=%d o=%d i=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_out, p->c_in, p->h, p->w, dtype);
-    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms must be 1 (bf16 products) or 3 (bf16x3 fp32 emulation)");
+    if (p->terms != 1 && p->terms != 3 && p->terms != 4) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms must be 1 (bf16 products), 3 (bf16 split) or 4 (block-scaled fp16 split)");
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: 16-bit tensors need terms = 1 (one bf16 operand per value)");
+    if (p->terms == 4 && (!p->dy_amax || !p->x_amax)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms = 4 needs dy_amax and x_amax, device pointers to upper bounds of max |dy| / max |x| (sgv_absmax)");
     if ((((uintptr_t)p->dy) | ((uintptr_t)p->x)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: dy and x must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     wrw_params kp{};
     kp.dy = (const float*)p->dy; kp.x = (const float*)p->x; kp.dw = p->dw;
     kp.n = p->n; kp.o = p->c_out; kp.i = p->c_in; kp.h = p->h; kp.w = p->w;
     kp.xscale = x_scale;
+    if (p->terms == 4) { kp.dy_amax = p->dy_amax; kp.x_amax = p->x_amax; kp.x_amax2 = x_scale ? p->x_amax2 : nullptr; }
     kp.scatter_flush = scatter_flush();
     kp.tiles_i = p->c_in / TI;
     const int tiles = (p->c_out / TO) * kp.tiles_i;
@@ -110,6 +114,8 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<3, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<3, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
+        if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<4, 1, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1, 0, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)wrw3x3_ws_kernel<1, 1, 0, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, wrw_ws_lds_bytes(1));
         g_ws_attr_err = e2;
@@ -125,13 +131,15 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
     }
     if (pack) {   // the packed form exists in the producer / consumer kernel only
         if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
-        else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        else if (p->terms == 3) hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        else hipLaunchKernelGGL((wrw3x3_ws_kernel<4, 1, 0, true>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
         sgv_note_variant(SGV_V_wrw_s1_ws_packed);
         return sgv_check_launch("wrw3x3_ws_kernel (packed)");
     }
-    if (g_use_ws) {
+    if (g_use_ws || p->terms == 4) {      // (the block-scaled split: the producer / consumer kernel only)
         if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_ws_kernel<1, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
-        else hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        else if (p->terms == 3) hipLaunchKernelGGL((wrw3x3_ws_kernel<3, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
+        else hipLaunchKernelGGL((wrw3x3_ws_kernel<4, 1>), grid, dim3(512), wrw_ws_lds_bytes(1), stream, kp);
         sgv_note_variant(x_scale ? SGV_V_wrw_s1_ws_scaled : SGV_V_wrw_s1_ws);
         return sgv_check_launch("wrw3x3_ws_kernel");
     }
@@ -161,7 +169,8 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     if (!supported_s2(p->n, p->c_out, p->c_in, p->h, p->w, dtype))
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw_s2: needs fp32, channels %% 64 == 0, and on the small HxW grid W %% 32 == 0 with H <= 32 or H %% 32 == 0, or W in {16, 8} with H <= 32 (got n=%d cs=%d cb=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_out, p->c_in, p->h, p->w, dtype);
-    if (p->terms != 1 && p->terms != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms must be 1 or 3");
+    if (p->terms != 1 && p->terms != 3 && p->terms != 4) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms must be 1, 3 or 4");
+    if (p->terms == 4 && (!p->dy_amax || !p->x_amax)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms = 4 needs dy_amax and x_amax, device pointers to upper bounds of max |dy| / max |x| (sgv_absmax)");
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: 16-bit tensors need terms = 1 (one bf16 operand per value)");
     if (((uintptr_t)p->dy) & (io16(dtype) ? 7 : 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: the small tensor must be aligned to four elements");
     init_s2_once();
@@ -172,6 +181,7 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
     kp.small = (const float*)p->dy; kp.big = (const float*)p->x; kp.dw = p->dw;
     kp.n = p->n; kp.cs = p->c_out; kp.cb = p->c_in; kp.h = p->h; kp.w = p->w;
     kp.rows = std::min(p->h, 32);
+    if (p->terms == 4) { kp.small_amax = p->dy_amax; kp.big_amax = p->x_amax; }
     kp.scatter_flush = scatter_flush();
     kp.tiles_b = p->c_in / TI;
     const bool pack = p->w < SEG;
@@ -195,13 +205,15 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
         sgv_note_variant(SGV_V_wrw_s2_lowp);
         return sgv_check_launch("wrw3x3_s2_ws_kernel (16-bit tensors)");
     }
-    if (g_use_s2_ws) {
+    if (g_use_s2_ws || p->terms == 4) {
         if (pack) {
             if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, true>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
-            else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<3, true>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+            else if (p->terms == 3) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<3, true>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+            else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<4, true>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
         } else {
             if (p->terms == 1) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<1, false>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
-            else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<3, false>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+            else if (p->terms == 3) hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<3, false>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
+            else hipLaunchKernelGGL((wrw3x3_s2_ws_kernel<4, false>), grid, dim3(512), WRW_S2_WS_LDS_BYTES, stream, kp);
         }
         sgv_note_variant(pack ? SGV_V_wrw_s2_ws_packed : SGV_V_wrw_s2_ws);
         return sgv_check_launch("wrw3x3_s2_ws_kernel");

@@ -40,6 +40,10 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     gp.stride_a = p->stride_a; gp.stride_b = p->stride_b; gp.stride_c = p->stride_c;
     gp.bias_mode = p->bias_mode;
     gp.residual = p->residual;
+    // exact_fp32 = 2: the split members with block-scaled fp16 operands (fp32-grade); falls back to the exact fp32 pipe where the shape rules them out
+    const bool f16 = p->exact_fp32 == 2;
+    if (f16 && (!p->a_amax || !p->b_amax)) return sgv_fail(SGV_ERR_INVALID_ARG, "gemm: exact_fp32 = 2 (block-scaled fp16 split) needs a_amax and b_amax (sgv_absmax)");
+    gp.a_amax = f16 ? p->a_amax : nullptr; gp.b_amax = f16 ? p->b_amax : nullptr;
     gp.tiles_m = (p->m + BM - 1) / BM;
     gp.tiles_n = (p->n + BN - 1) / BN;
     const double flops = 2.0 * p->m * p->n * p->k * p->batch;
@@ -58,12 +62,14 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     // bf16x3 member (gemm_kernel.h): whole tiles along n, k % 32 == 0, 16-byte aligned k-contiguous rows; any m.  SGV_GEMM_TERMS=0 keeps every
     // product on the exact-fp32 matrix pipe.
     static const bool allow_x3 = !(getenv("SGV_GEMM_TERMS") && getenv("SGV_GEMM_TERMS")[0] == '0');
-    const bool x3 = allow_x3 && !p->exact_fp32 && p->n % BN == 0 && gp.k % X3_BK == 0 && p->lda % 4 == 0 && p->stride_a % 4 == 0 && al16(p->a) && (int64_t)slice_ok(p, ks) &&
+    const bool x3 = allow_x3 && p->exact_fp32 != 1 && p->n % BN == 0 && gp.k % X3_BK == 0 && p->lda % 4 == 0 && p->stride_a % 4 == 0 && al16(p->a) && (int64_t)slice_ok(p, ks) &&
                     (!p->trans_b || (p->ldb % 4 == 0 && p->stride_b % 4 == 0 && al16(p->b)));
     if (x3) {
         static const hipError_t attr_err = [] {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
             if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
             return e;
         }();
         if (attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err));
@@ -81,16 +87,24 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
             static const hipError_t attr_err_s = [] {
                 hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16x3_stream_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
                 if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16x3_stream_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16x3_stream_kernel<0, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_bf16x3_stream_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);
                 return e;
             }();
             if (attr_err_s != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "gemm: hipFuncSetAttribute failed: %s", hipGetErrorString(attr_err_s));
             const dim3 sgrid((unsigned)(resident & ~7));
-            if (p->trans_b) hipLaunchKernelGGL(gemm_bf16x3_stream_kernel<1>, sgrid, dim3(256), X3_LDS_BYTES, stream, gp, (int)total_tiles);
+            if (f16) {
+                if (p->trans_b) hipLaunchKernelGGL((gemm_bf16x3_stream_kernel<1, 4>), sgrid, dim3(256), X3_LDS_BYTES, stream, gp, (int)total_tiles);
+                else hipLaunchKernelGGL((gemm_bf16x3_stream_kernel<0, 4>), sgrid, dim3(256), X3_LDS_BYTES, stream, gp, (int)total_tiles);
+            } else if (p->trans_b) hipLaunchKernelGGL(gemm_bf16x3_stream_kernel<1>, sgrid, dim3(256), X3_LDS_BYTES, stream, gp, (int)total_tiles);
             else hipLaunchKernelGGL(gemm_bf16x3_stream_kernel<0>, sgrid, dim3(256), X3_LDS_BYTES, stream, gp, (int)total_tiles);
             sgv_note_variant(SGV_V_gemm_bf16x3_stream);
             return sgv_check_launch("gemm_bf16x3_stream_kernel");
         }
-        if (p->trans_b) hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, grid, dim3(256), X3_LDS_BYTES, stream, gp);
+        if (f16) {
+            if (p->trans_b) hipLaunchKernelGGL((gemm_bf16x3_kernel<1, 4>), grid, dim3(256), X3_LDS_BYTES, stream, gp);
+            else hipLaunchKernelGGL((gemm_bf16x3_kernel<0, 4>), grid, dim3(256), X3_LDS_BYTES, stream, gp);
+        } else if (p->trans_b) hipLaunchKernelGGL(gemm_bf16x3_kernel<1>, grid, dim3(256), X3_LDS_BYTES, stream, gp);
         else hipLaunchKernelGGL(gemm_bf16x3_kernel<0>, grid, dim3(256), X3_LDS_BYTES, stream, gp);
         sgv_note_variant(SGV_V_gemm_bf16x3);
         return sgv_check_launch("gemm_bf16x3_kernel");

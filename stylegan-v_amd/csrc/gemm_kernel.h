@@ -10,6 +10,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include "sgv_split.h"
 #include <stdint.h>
 
 namespace sgv_gemm {
@@ -32,6 +33,8 @@ struct gemm_params {
     int tiles_m, tiles_n;
     int ksplit;            // >= 1: slices of K per batch entry (k = slice length)
     const float* residual; // added to the result before the store (same layout as c), or NULL
+    const float* a_amax;   // TERMS = 4 (block-scaled fp16 split, sgv_split.h): device pointers to upper bounds of max |A| and max |B| (whole tensors)
+    const float* b_amax;
 };
 
 // [128 rows x BK] block of a row-major [rows, K] matrix (k contiguous): thread t -> row t/4 (+64 per pass), k-quad t%4 (+4 per k-pass).
@@ -246,9 +249,13 @@ __device__ __forceinline__ void x3_split8(const float* v, gu32x4& hi, gu32x4& lo
     }
 }
 
-template <int TRANS_B>
+// TERMS: 3 = bf16 split, 4 = block-scaled fp16 split (fp32-grade; a_amax / b_amax of gemm_params) -- same tile, same LDS layout, same MFMA count.
+template <int TRANS_B, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
     extern __shared__ __attribute__((aligned(16))) gu32x4 x3_lds[];
+    const int ea = sgv_conv::operand_exponent<TERMS>(p.a_amax), eb = sgv_conv::operand_exponent<TERMS>(p.b_amax);
+    const float aS = sgv_conv::split_scale(ea), bS = sgv_conv::split_scale(eb);
+    const int eu = sgv_conv::unscale_exponent(ea, eb);
     const int tile = blockIdx.x;
     const int tm = tile % p.tiles_m;  // M fastest: consecutive workgroups share the B panel
     const int tn = tile / p.tiles_m;
@@ -303,10 +310,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
 #pragma unroll
         for (int o = 0; o < 2; o++) {
             gu32x4 hi, lo;
-            x3_split8(ra + 8 * o, hi, lo);
+            sgv_conv::split8t<TERMS>(ra + 8 * o, aS, hi, lo);
             as[(0 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = hi;
             as[(1 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = lo;
-            x3_split8(rb + 8 * o, hi, lo);
+            sgv_conv::split8t<TERMS>(rb + 8 * o, bS, hi, lo);
             if (TRANS_B) {
                 bs[(0 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = hi;
                 bs[(1 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = lo;
@@ -340,17 +347,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, al[i]), __builtin_bit_cast(gbf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = sgv_conv::mma16<TERMS>(al[i], bh[j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, ah[i]), __builtin_bit_cast(gbf16x8, bl[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = sgv_conv::mma16<TERMS>(ah[i], bl[j], acc[i][j]);
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
                 for (int j = 0; j < 2; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, ah[i]), __builtin_bit_cast(gbf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                    acc[i][j] = sgv_conv::mma16<TERMS>(ah[i], bh[j], acc[i][j]);
         }
         cur ^= 1;
     }
@@ -373,7 +380,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
             for (int e = 0; e < 16; e++) {
                 const int row = m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
                 if (!full_m && row >= p.m) continue;
-                float v = acc[i][j][e] + bcol;
+                float v = (TERMS == 4 ? __builtin_ldexpf(acc[i][j][e], eu) : acc[i][j][e]) + bcol;
                 if (p.bias_mode == 2) v += p.bias[row];
                 if (RES) v += rv[e];
                 C[(int64_t)row * p.ldc + col] = v;
@@ -389,9 +396,12 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
 // tile's first chunk are issued with the last chunk of the current tile and stay in flight across its MFMAs and its 64 epilogue stores.
 // Workgroup b of G takes the tiles L, L + G, L + 2G ... with L = (b % 8) * (G / 8) + b / 8: the workgroups of one XCD (b % 8) take consecutive tiles,
 // so that the tiles_m workgroups that read the same B panel share an L2.
-template <int TRANS_B>
+template <int TRANS_B, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params p, int total_tiles) {
     extern __shared__ __attribute__((aligned(16))) gu32x4 x3_lds[];
+    const int ea = sgv_conv::operand_exponent<TERMS>(p.a_amax), eb = sgv_conv::operand_exponent<TERMS>(p.b_amax);
+    const float aS = sgv_conv::split_scale(ea), bS = sgv_conv::split_scale(eb);
+    const int eu = sgv_conv::unscale_exponent(ea, eb);
     const int t = threadIdx.x;
     const int lane = t & 63, wave = t >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -450,10 +460,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params 
 #pragma unroll
         for (int o = 0; o < 2; o++) {
             gu32x4 hi, lo;
-            x3_split8(ra + 8 * o, hi, lo);
+            sgv_conv::split8t<TERMS>(ra + 8 * o, aS, hi, lo);
             as[(0 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = hi;
             as[(1 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = lo;
-            x3_split8(rb + 8 * o, hi, lo);
+            sgv_conv::split8t<TERMS>(rb + 8 * o, bS, hi, lo);
             if (TRANS_B) {
                 bs[(0 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = hi;
                 bs[(1 * 4 + 2 * f_half + o) * X3_PITCH + f_row] = lo;
@@ -494,17 +504,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params 
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, al[i]), __builtin_bit_cast(gbf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = sgv_conv::mma16<TERMS>(al[i], bh[j], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, ah[i]), __builtin_bit_cast(gbf16x8, bl[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = sgv_conv::mma16<TERMS>(ah[i], bl[j], acc[i][j]);
 #pragma unroll
                 for (int i = 0; i < 2; i++)
 #pragma unroll
                     for (int j = 0; j < 2; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(gbf16x8, ah[i]), __builtin_bit_cast(gbf16x8, bh[j]), acc[i][j], 0, 0, 0);
+                        acc[i][j] = sgv_conv::mma16<TERMS>(ah[i], bh[j], acc[i][j]);
             }
             cur ^= 1;
         }
@@ -528,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params 
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
                     const int row = ct.m0 + wm + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * lk;
-                    float v = acc[i][j][e] + bcol;
+                    float v = (TERMS == 4 ? __builtin_ldexpf(acc[i][j][e], eu) : acc[i][j][e]) + bcol;
                     acc[i][j][e] = 0.f;
                     if (!full_m && row >= p.m) continue;
                     if (p.bias_mode == 2) v += p.bias[row];

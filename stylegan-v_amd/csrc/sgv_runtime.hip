@@ -110,8 +110,8 @@ extern "C" int sgv_prof_collect_records(sgv_prof_record* out, int32_t max_record
     return n;
 }
 
-sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops) : slot(-1), stream(s) {
-    g_launches.fetch_add(1, std::memory_order_relaxed);
+sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count) : slot(-1), stream(s) {
+    if (count) g_launches.fetch_add(1, std::memory_order_relaxed);
     if (!g_prof_on.load(std::memory_order_relaxed)) return;
     int i = g_prof_next.fetch_add(1);
     if (i >= (int)g_prof_pool.size()) return;  // pool exhausted: launch is simply not recorded

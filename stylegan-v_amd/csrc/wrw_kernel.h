@@ -28,7 +28,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "sgv_split.h"
+
 namespace sgv_wrw {
+using sgv_conv::split2;
+using sgv_conv::split8t;
+using sgv_conv::mma16;
+using sgv_conv::operand_exponent;
+using sgv_conv::split_scale;
+using sgv_conv::unscale_exponent;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
@@ -54,6 +62,10 @@ struct wrw_params {
     int units;         // n * (w / 32) * (h / rows)
     const float* xscale;   // [n, i] or NULL: x[n,i,:,:] is multiplied by it on its way into LDS (the styles of a modulated layer, networks.py:66; producer / consumer kernel only)
     int scatter_flush;     // 1: the element-per-lane flush (every lane of an atomic instruction in a different cache line) instead of flush_tile
+    // TERMS = 4 (block-scaled fp16 split, sgv_split.h; producer / consumer kernels): bounds of max |dy|, max |x| (x_amax2: optional second factor, the bound of xscale)
+    const float* dy_amax;
+    const float* x_amax;
+    const float* x_amax2;
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -292,6 +304,8 @@ struct wrw_s2_params {
     int n, cs, cb, h, w;
     int rows, tiles_b, splits, units;
     int scatter_flush;    // as in wrw_params
+    const float* small_amax;   // TERMS = 4 (block-scaled fp16 split, sgv_split.h; producer / consumer kernel): bounds of max |small|, max |big|
+    const float* big_amax;
 };
 
 //

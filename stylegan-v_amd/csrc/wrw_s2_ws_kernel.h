@@ -53,6 +53,9 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
     const int hb = 2 * p.h + 1, wb = 2 * p.w + 1;
     const size_t plane_s = (size_t)p.h * p.w, plane_b = (size_t)hb * wb;
     const int R = p.rows;
+    // TERMS = 4: block exponents of the two operands (sgv_split.h); the accumulators are scaled back once, in front of the flush
+    const int e_s = operand_exponent<TERMS>(p.small_amax), e_b = operand_exponent<TERMS>(p.big_amax);
+    const float sS = split_scale(e_s), bS = split_scale(e_b);
 
     if (wave >= 4) {
         // =========================================== producers ===========================================
@@ -117,23 +120,24 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
             for (int j = 0; j < 4; j++) {
                 const int it = pt + 256 * j, quad = it & 15, ch = it >> 4;
                 const float v0 = px4_get<IO>(r.v[j], 0), v1 = px4_get<IO>(r.v[j], 1), v2 = px4_get<IO>(r.v[j], 2), v3 = px4_get<IO>(r.v[j], 3);
-                const unsigned he = pack_bf16(v0, v2), ho = pack_bf16(v1, v3);
+                unsigned he, ho, le, lo;
+                split2<TERMS>(v0, v2, bS, he, le);     // even columns
+                split2<TERMS>(v1, v3, bS, ho, lo);     // odd columns
                 const int pos = slot * BIG_SLOT + ch * BIG_CH + 2 * quad;
                 *(unsigned*)&bs[pos] = he;
                 *(unsigned*)&bs[pos + RS] = ho;
                 if (TERMS > 1) {
-                    const unsigned le = pack_bf16(v0 - __builtin_bit_cast(float, he << 16), v2 - __builtin_bit_cast(float, he & 0xffff0000u));
-                    const unsigned lo = pack_bf16(v1 - __builtin_bit_cast(float, ho << 16), v3 - __builtin_bit_cast(float, ho & 0xffff0000u));
                     *(unsigned*)&bs[5 * BIG_SLOT + pos] = le;
                     *(unsigned*)&bs[5 * BIG_SLOT + pos + RS] = lo;
                 }
             }
             if (pt < TI * spr) {
                 const float ev = px1_get<IO>(r.e);
-                const unsigned h = pack_bf16(ev, 0.f);
+                unsigned h, l;
+                split2<TERMS>(ev, 0.f, bS, h, l);
                 const int pos = slot * BIG_SLOT + (pt & 63) * BIG_CH + (PACK ? 2 * RS + 2 * (pt >> 6) : 32);
                 bs[pos] = (unsigned short)h;
-                if (TERMS > 1) bs[5 * BIG_SLOT + pos] = (unsigned short)pack_bf16(ev - __builtin_bit_cast(float, h << 16), 0.f);
+                if (TERMS > 1) bs[5 * BIG_SLOT + pos] = (unsigned short)l;
             }
         };
         auto store_small = [&](int buf, const sset& r) {
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = (!PACK || live) ? px4_get<IO>(r.a, k) : 0.f; v[4 + k] = (!PACK || live) ? px4_get<IO>(r.b, k) : 0.f; }
             u32x4 hi, lo;
-            split8(v, hi, lo);
+            split8t<TERMS>(v, sS, hi, lo);
             *(u32x4*)&as[buf * S2W_SMALL + lr * RS + lq] = hi;
             if (TERMS > 1) *(u32x4*)&as[(3 + buf) * S2W_SMALL + lr * RS + lq] = lo;
         };
@@ -290,14 +294,14 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
                 if (TERMS > 1) {
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lo), __builtin_bit_cast(bf16x8, bh[kx]), acc[ky * 3 + kx], 0, 0, 0);
+                        acc[ky * 3 + kx] = mma16<TERMS>(a_lo, bh[kx], acc[ky * 3 + kx]);
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bl[kx]), acc[ky * 3 + kx], 0, 0, 0);
+                        acc[ky * 3 + kx] = mma16<TERMS>(a_hi, bl[kx], acc[ky * 3 + kx]);
                 }
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++)
-                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bh[kx]), acc[ky * 3 + kx], 0, 0, 0);
+                    acc[ky * 3 + kx] = mma16<TERMS>(a_hi, bh[kx], acc[ky * 3 + kx]);
                 constexpr int MF = TERMS > 1 ? 9 : 3;
                 constexpr int RPM = TERMS > 1 ? 2 : 3;   // operand reads behind each of the first MFMAs
 #pragma unroll
@@ -316,6 +320,13 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
         db = (db + R) % 3;
     }
 
+    if (TERMS == 4) {     // the two block scales come off before the sums leave the registers
+        const int eu = unscale_exponent(e_s, e_b);
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[k][e] = __builtin_ldexpf(acc[k][e], eu);
+    }
     // Flush (behind the last row's barrier nobody reads or writes the operand tiles any more).
     flush_tile(acc, (float*)lds_s2w + wave * FLUSH_STAGE_FLOATS, p.dw, p.cb, s0 + wo, b0 + wi);
 }

@@ -68,6 +68,9 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
     const int spr = PACK ? SEG / p.w : 1;     // samples per row step
     const size_t plane = (size_t)p.h * p.w;
     const int R = p.rows;
+    // TERMS = 4: block exponents of the two operands (sgv_split.h); the accumulators are scaled back once, in front of the flush
+    const int e_dy = operand_exponent<TERMS>(p.dy_amax), e_x = operand_exponent<TERMS>(p.x_amax, p.x_amax2);
+    const float dS = split_scale(e_dy), xS = split_scale(e_x);
 
     if (wave >= 4) {
         // =========================================== producers ===========================================
@@ -115,11 +118,9 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         };
         auto touch_x = [&](xrow& r) { px4_pin<IO>(r.a); px4_pin<IO>(r.b); px1_pin<IO>(r.l); px1_pin<IO>(r.r); };
         auto touch_d = [&](drow& r) { px4_pin<IO>(r.a); px4_pin<IO>(r.b); };
-        // one pair of neighbouring pixels -> packed bf16 hi and lo
-        auto pair = [&](float a, float b, unsigned& hi, unsigned& lo) {
-            hi = pack_bf16(a, b);
-            lo = pack_bf16(a - __builtin_bit_cast(float, hi << 16), b - __builtin_bit_cast(float, hi & 0xffff0000u));
-        };
+        // one pair of neighbouring pixels -> packed 16-bit hi and lo (TERMS = 4: the values already carry the block scale, folded into xmul)
+        auto pair = [&](float a, float b, unsigned& hi, unsigned& lo) { split2<TERMS>(a, b, 1.f, hi, lo); };
+        float xmul = 1.f;     // xsc (x block scale) for the current unit: set where xsc is known to have landed
         auto store_x = [&](int row, const xrow& r) {
             if (ABL == 7) return;
             if (ABL == 10 || ABL == 12) {   // no split arithmetic: raw register bits go to LDS
@@ -132,10 +133,10 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
                 return;
             }
             float v[10];
-            v[0] = r.okl ? px1_get<IO>(r.l) * xsc : 0.f;
-            v[9] = r.okr ? px1_get<IO>(r.r) * xsc : 0.f;
+            v[0] = r.okl ? px1_get<IO>(r.l) * xmul : 0.f;
+            v[9] = r.okr ? px1_get<IO>(r.r) * xmul : 0.f;
 #pragma unroll
-            for (int k = 0; k < 4; k++) { v[1 + k] = r.ok ? px4_get<IO>(r.a, k) * xsc : 0.f; v[5 + k] = r.ok ? px4_get<IO>(r.b, k) * xsc : 0.f; }
+            for (int k = 0; k < 4; k++) { v[1 + k] = r.ok ? px4_get<IO>(r.a, k) * xmul : 0.f; v[5 + k] = r.ok ? px4_get<IO>(r.b, k) * xmul : 0.f; }
             // even-start pairs (v1v2, v3v4, v5v6, v7v8) = view 1; odd-start pairs (v0v1, ..., v8v9): view 0 = first four, view 2 = last four
             unsigned eh[4], el[4], oh[5], ol[5];
 #pragma unroll
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = (!PACK || smp_ok) ? px4_get<IO>(r.a, k) : 0.f; v[4 + k] = (!PACK || smp_ok) ? px4_get<IO>(r.b, k) : 0.f; }
             u32x4 hi, lo;
-            split8(v, hi, lo);
+            split8t<TERMS>(v, dS, hi, lo);
             *(u32x4*)(ds + (size_t)buf * WS_DBUF + lr * RS + lq) = hi;
             if (TERMS > 1) *(u32x4*)(ds + (size_t)(3 + buf) * WS_DBUF + lr * RS + lq) = lo;
         };
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the prologue rows (issued during the previous unit's last step)
             touch_x(px0); touch_x(px1); touch_x(px2); touch_d(pd0); touch_d(pd1);
             asm volatile("" : "+v"(xsc));
+            xmul = TERMS == 4 ? xsc * xS : xsc;
             __builtin_amdgcn_s_barrier();                              // A: the consumers are done with the previous unit
             store_x(y0 - 1, px0); store_x(y0, px1); store_x(y0 + 1, px2);
             store_dy(db % 3, pd0);
@@ -345,14 +347,14 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
                 if (TERMS > 1) {
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_lo), __builtin_bit_cast(bf16x8, bh[kx]), acc[ky * 3 + kx], 0, 0, 0);
+                        acc[ky * 3 + kx] = mma16<TERMS>(a_lo, bh[kx], acc[ky * 3 + kx]);
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bl[kx]), acc[ky * 3 + kx], 0, 0, 0);
+                        acc[ky * 3 + kx] = mma16<TERMS>(a_hi, bl[kx], acc[ky * 3 + kx]);
                 }
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++)
-                    acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_hi), __builtin_bit_cast(bf16x8, bh[kx]), acc[ky * 3 + kx], 0, 0, 0);
+                    acc[ky * 3 + kx] = mma16<TERMS>(a_hi, bh[kx], acc[ky * 3 + kx]);
                 constexpr int MF = TERMS > 1 ? 9 : 3;
                 // RPM operand reads behind each of the first MFMAs: the earlier the last read issues, the more MFMAs cover its LDS latency
                 constexpr int RPM = TERMS > 1 ? SGV_WRW_RPM : 3;
@@ -371,6 +373,13 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         db = (db + R) % 3;
     }
 
+    if (TERMS == 4) {     // the two block scales come off before the sums leave the registers
+        const int eu = unscale_exponent(e_dy, e_x);
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[k][e] = __builtin_ldexpf(acc[k][e], eu);
+    }
     // Flush (behind the last row's barrier nobody reads or writes the operand tiles any more).
     if (ABL != 8 && !p.scatter_flush) { flush_tile(acc, (float*)lds_ws + wave * FLUSH_STAGE_FLOATS, p.dw, p.i, o0 + wo, i0 + wi); return; }
     // C layout of the 32x32 MFMA: col (i) = lane & 31, row (o) = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).

@@ -177,7 +177,7 @@ def native_loaded():
 c_void_p, c_int, c_int32, c_int64, c_float, c_double = ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_double
 
 SGV_F32, SGV_F16, SGV_BF16, SGV_F64 = 0, 1, 2, 3
-SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw', 'conv3x3', 'conv3x3_s1', 'fc']
+SGV_K_NAMES = ['upfirdn2d_rows', 'upfirdn2d_generic', 'bias_act', 'modulate', 'time_encode', 'gemm', 'upfirdn2d_lanes', 'pointwise', 'conv_wrw', 'conv3x3', 'conv3x3_s1', 'fc', 'absmax']
 
 
 class Upfirdn2dParams(ctypes.Structure):
@@ -214,12 +214,12 @@ class PointwiseParams(ctypes.Structure):
 
 class ConvWrwParams(ctypes.Structure):
     _fields_ = [('dy', c_void_p), ('x', c_void_p), ('dw', c_void_p), ('n', c_int32), ('c_out', c_int32), ('c_in', c_int32), ('h', c_int32), ('w', c_int32),
-                ('terms', c_int32)]
+                ('terms', c_int32), ('dy_amax', c_void_p), ('x_amax', c_void_p), ('x_amax2', c_void_p)]
 
 
 class Conv3x3Params(ctypes.Structure):
     _fields_ = [('x', c_void_p), ('weight', c_void_p), ('y', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('n', c_int32), ('c_in', c_int32),
-                ('c_out', c_int32), ('h', c_int32), ('w', c_int32), ('mode', c_int32), ('terms', c_int32)]
+                ('c_out', c_int32), ('h', c_int32), ('w', c_int32), ('mode', c_int32), ('terms', c_int32), ('x_amax', c_void_p), ('x_amax2', c_void_p)]
 
 
 class Conv3x3Epilogue(ctypes.Structure):
@@ -244,7 +244,7 @@ class GemmParams(ctypes.Structure):
         ('lda', c_int64), ('ldb', c_int64), ('ldc', c_int64),
         ('trans_b', c_int32), ('batch', c_int32),
         ('stride_a', c_int64), ('stride_b', c_int64), ('stride_c', c_int64),
-        ('bias_mode', c_int32), ('k_split', c_int32), ('residual', c_void_p), ('exact_fp32', c_int32),
+        ('bias_mode', c_int32), ('k_split', c_int32), ('residual', c_void_p), ('exact_fp32', c_int32), ('a_amax', c_void_p), ('b_amax', c_void_p),
     ]
 
 
@@ -285,6 +285,7 @@ ABI_SYMBOLS = {
     'sgv_pointwise_small_gradin': (c_int, [ctypes.POINTER(PointwiseParams), c_void_p, c_int32, c_float, c_float, c_float, c_int, c_void_p]),
     'sgv_pointwise_outer_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int, c_void_p]),
     'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
+    'sgv_absmax': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int32, c_void_p]),
     'sgv_conv3x3': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
     'sgv_conv3x3_s2': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
     'sgv_conv3x3_fused': (c_int, [ctypes.POINTER(Conv3x3Params), ctypes.POINTER(Conv3x3Epilogue), c_int, c_void_p]),

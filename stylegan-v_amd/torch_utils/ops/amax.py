@@ -1,0 +1,53 @@
+"""Magnitude bounds for the block-scaled fp16 split (`terms = 4` of the 3x3 family and the tiled GEMM; csrc/sgv_split.h).
+
+The reference multiplies in strict fp32 (src/training/training_loop.py:129,141-142: ``allow_tf32 = False``).  gfx950 has no fp32-rate matrix
+path, so the fp32-grade arithmetic of this build splits every operand into two fp16 terms of the tensor scaled by a power of two -- and that
+scale needs an upper bound of the tensor's largest magnitude, in device memory (nothing is read back to the host: the launch stays
+hipGraph-capturable).  ``bound(t)`` returns such a bound as a 1-element fp32 tensor:
+
+* a tensor that was produced by a kernel of this library which left a bound behind carries it already (``attach``);
+* otherwise one streaming pass (``sgv_absmax``) computes max |t|;
+* the result is cached ON the tensor object (an attribute dies with the object: no stale entries after the allocator reuses the address) and is
+  dropped when the tensor's version counter moves.  Kernels of this library that write into an existing tensor through its raw pointer
+  (``accumulate`` stores, the in-place residual add) do not move that counter: they call ``invalidate``.
+"""
+
+import torch
+
+from .. import custom_ops
+
+_DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
+_ATTR = '_sgv_amax'
+
+
+def bound(t):
+    """[1] fp32 device tensor >= max |t| for a dense CUDA tensor t (fp32 / fp16 / bf16)."""
+    cached = getattr(t, _ATTR, None)
+    if cached is not None and cached[0] == t._version and cached[1] == t.data_ptr():
+        return cached[2]
+    assert t.is_cuda and t.dtype in _DT
+    tc = t if t.is_contiguous() else t.contiguous()
+    out = torch.empty([1], dtype=torch.float32, device=t.device)
+    lib = custom_ops.get_native()
+    with custom_ops.device_guard(tc):
+        custom_ops.check(lib.sgv_absmax(tc.data_ptr(), tc.numel(), _DT[t.dtype], out.data_ptr(), 0, custom_ops.raw_stream(tc)), lib)
+    attach(t, out)
+    return out
+
+
+def attach(t, amax):
+    """Record a bound that a producing kernel left in `amax` ([1] fp32 device tensor) for tensor t."""
+    try:
+        setattr(t, _ATTR, (t._version, t.data_ptr(), amax))
+    except (AttributeError, RuntimeError):
+        pass
+    return t
+
+
+def invalidate(t):
+    """t was written through its raw pointer: a cached bound no longer holds."""
+    if getattr(t, _ATTR, None) is not None:
+        try:
+            delattr(t, _ATTR)
+        except AttributeError:
+            pass

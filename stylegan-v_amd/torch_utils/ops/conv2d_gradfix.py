@@ -27,6 +27,7 @@ import os
 import torch
 
 from .. import custom_ops
+from . import amax as _amax
 
 enabled = True                     # False -> plain torch.nn.functional calls
 weight_gradients_disabled = False  # set inside no_weight_gradients()
@@ -53,7 +54,7 @@ native_lowp = os.environ.get('SGV_CONV_LOWP', '1') != '0'
 
 def cast_weight(w, x):
     """The weight as conv2d / conv_transpose2d want it for input x: fp32 master weights stay fp32 next to 16-bit GPU activations (native mixed path)."""
-    if native_lowp and enabled and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and w.dtype == torch.float32 and native_conv_terms in (1, 3):
+    if native_lowp and enabled and x.is_cuda and x.dtype in (torch.float16, torch.bfloat16) and w.dtype == torch.float32 and native_conv_terms in (1, 3, 4):
         return w
     return w.to(x.dtype)
 
@@ -134,11 +135,12 @@ class _Conv(torch.autograd.Function):
         return dx, dw, db, None
 
 
-# 3x3 / stride 1 / pad 1 weight gradients on NCHW fp32 run on the bf16 matrix pipe with fp32 emulation (csrc/wrw_kernel.h):
-# 1.5 ms where MIOpen's NHWC implicit GEMM + its three layout transposes take ~6 ms.  wrw_terms = 3 -> bf16x3 (|rel err| ~ 4e-6
-# of the result's scale, tests/test_conv_wrw_gpu.py), 1 -> plain bf16 products, 0 -> always the vendor library.
-native_wrw_terms = int(os.environ.get('SGV_WRW_TERMS', '3'))
-native_conv_terms = int(os.environ.get('SGV_CONV_TERMS', '3'))
+# The 3x3 family on NCHW fp32 tensors runs on the 16-bit matrix pipe with fp32 emulation (csrc/sgv_split.h).  terms = 4 (default since round 4): block-scaled
+# 2-way fp16 split, 22 operand bits, fp32 accumulate -- fp32-grade (~1e-7 of the result's scale against float64, the vendor library's fp32 convolutions sit
+# at 1.4-3.5e-7; tests/test_conv3x3_gpu.py), which is what the reference's `allow_tf32 = False` configuration computes (training_loop.py:129,141-142);
+# 3 -> 2-way bf16 split (16 operand bits, 4.4e-6: inside north_star's 1e-3 but NOT fp32-grade); 1 -> plain bf16 products; 0 -> always the vendor library.
+native_wrw_terms = int(os.environ.get('SGV_WRW_TERMS', '4'))
+native_conv_terms = int(os.environ.get('SGV_CONV_TERMS', '4'))
 native_conv_s2 = os.environ.get('SGV_CONV_S2', '1') != '0'         # stride-2 / transposed members (csrc/conv3x3s2_kernel.h)   # same switch for the forward / data-gradient kernel (csrc/conv3x3_kernel.h)
 
 
@@ -147,7 +149,7 @@ def _native_conv_kind(x, w, cfg):
     csrc/conv3x3_kernel.h), 's2' (3x3 / stride 2 / pad 0 between a (2H+1)x(2W+1) and an HxW tensor, strided or transposed,
     csrc/conv3x3s2_kernel.h) or None (vendor library)."""
     transposed, stride, padding, output_padding, dilation, groups = cfg
-    if native_conv_terms not in (1, 3) or groups != 1 or dilation != (1, 1) or output_padding != (0, 0):
+    if native_conv_terms not in (1, 3, 4) or groups != 1 or dilation != (1, 1) or output_padding != (0, 0):
         return None
     if w.ndim != 4 or tuple(w.shape[2:]) != (3, 3) or not (x.is_cuda and w.is_cuda) or x.dtype not in _DT or w.dtype not in (torch.float32, x.dtype):
         return None
@@ -188,7 +190,8 @@ def _native_conv(x, w, cfg):
         y = torch.empty([n, co, h, wd], dtype=x.dtype, device=x.device)
         ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
         ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
-        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, wd, 1 if transposed else 0, terms)
+        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, wd, 1 if transposed else 0, terms,
+                                     _amax.bound(xc).data_ptr() if terms == 4 else None, None)
         fn = lib.sgv_conv3x3
     else:
         hs, wsm = (h, wd) if transposed else ((h - 1) // 2, (wd - 1) // 2)   # the small grid
@@ -196,7 +199,8 @@ def _native_conv(x, w, cfg):
         mode = 2 if transposed else 0
         ws_bytes = int(lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, wsm, mode))
         ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
-        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, hs, wsm, mode, terms)
+        p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, hs, wsm, mode, terms,
+                                     _amax.bound(xc).data_ptr() if terms == 4 else None, None)
         fn = lib.sgv_conv3x3_s2
     with custom_ops.device_guard(xc):
         custom_ops.check(fn(p, dt, custom_ops.raw_stream(xc)), lib)
@@ -206,7 +210,7 @@ def _native_conv(x, w, cfg):
 def _native_wrw_kind(dy, x, cfg, w_shape):
     """'s1': 3x3 / stride 1 / pad 1; 's2': 3x3 / stride 2 / pad 0 (strided or transposed layer); None: vendor library."""
     transposed, stride, padding, output_padding, dilation, groups = cfg
-    if native_wrw_terms not in (1, 3) or groups != 1 or dilation != (1, 1) or output_padding != (0, 0):
+    if native_wrw_terms not in (1, 3, 4) or groups != 1 or dilation != (1, 1) or output_padding != (0, 0):
         return None
     if tuple(w_shape[2:]) != (3, 3) or not (dy.is_cuda and x.is_cuda) or x.dtype not in _DT or dy.dtype != x.dtype:
         return None
@@ -236,6 +240,13 @@ def _native_wrw_ok(dy, x, cfg, w_shape):
 wrw_input_scale = os.environ.get('SGV_WRW_WS', '1') != '0' and os.environ.get('SGV_WRW_SCALE', '1') != '0'   # the stride-1 producer / consumer kernel can scale its input operand per (sample, channel)
 
 
+def _wrw_bounds(terms, dyc, xc, scale=None):
+    """(dy_amax, x_amax, x_amax2) of ConvWrwParams: device pointers to the operands' magnitude bounds for the block-scaled split (terms = 4)."""
+    if terms != 4:
+        return None, None, None
+    return _amax.bound(dyc).data_ptr(), _amax.bound(xc).data_ptr(), (_amax.bound(scale).data_ptr() if scale is not None else None)
+
+
 def _native_wrw(dy, x, cfg, w_shape, x_scale=None):
     """``x_scale`` ([N, Cin] fp32; stride-1 forward layers only, see ``wrw_input_scale``): the gradient is taken with x * x_scale[:, :, None, None]."""
     lib = custom_ops.get_native()
@@ -248,7 +259,7 @@ def _native_wrw(dy, x, cfg, w_shape, x_scale=None):
         dyc, xc, sc = dy.contiguous(), x.contiguous(), x_scale.contiguous()
         n, ci, h, w = xc.shape
         assert tuple(w_shape[:2]) == (dyc.shape[1], ci) and tuple(sc.shape) == (n, ci) and sc.dtype == torch.float32
-        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, terms)
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, terms, *_wrw_bounds(terms, dyc, xc, sc))
         with custom_ops.device_guard(xc):
             custom_ops.check(lib.sgv_conv3x3_wrw_scaled(p, sc.data_ptr(), dt, custom_ops.raw_stream(xc)), lib)
         return dw
@@ -257,14 +268,14 @@ def _native_wrw(dy, x, cfg, w_shape, x_scale=None):
         dyc, xc = (x.contiguous(), dy.contiguous()) if cfg[0] else (dy.contiguous(), x.contiguous())   # weight is [dyc channels, xc channels, 3, 3]
         n, ci, h, w = xc.shape
         assert tuple(w_shape[:2]) == (dyc.shape[1], ci)
-        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, terms)
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, dyc.shape[1], ci, h, w, terms, *_wrw_bounds(terms, dyc, xc))
         fn = lib.sgv_conv3x3_wrw
     else:   # the weight is [c_small, c_big, 3, 3] for both the strided ([c_out, c_in]) and the transposed ([c_in, c_out]) layer
         small, big = ((x, dy) if cfg[0] else (dy, x))
         dyc, xc = small.contiguous(), big.contiguous()
         n, cs, hs, ws = dyc.shape
         assert tuple(w_shape[:2]) == (cs, xc.shape[1])
-        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, cs, xc.shape[1], hs, ws, terms)
+        p = custom_ops.ConvWrwParams(dyc.data_ptr(), xc.data_ptr(), dw.data_ptr(), n, cs, xc.shape[1], hs, ws, terms, *_wrw_bounds(terms, dyc, xc))
         fn = lib.sgv_conv3x3_wrw_s2
     with custom_ops.device_guard(xc):
         custom_ops.check(fn(p, dt, custom_ops.raw_stream(xc)), lib)

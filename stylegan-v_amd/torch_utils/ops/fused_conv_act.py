@@ -28,6 +28,7 @@ import torch
 
 from .. import custom_ops
 from . import bias_act as _ba
+from . import amax as _amax
 from . import conv2d_gradfix as _cg
 from . import modulation as _mod
 
@@ -71,7 +72,12 @@ def _launch_fused(x, weight, styles, dcoefs, bias, act_idx, alpha, gain, clamp, 
     ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
     ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
     weight = weight.float()
-    p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, mode, _cg.native_conv_terms if dt == 0 else 1)
+    terms = _cg.native_conv_terms if dt == 0 else 1
+    # terms = 4: the operand is x * styles, bounded by the product of the two tensors' bounds (csrc/sgv_split.h)
+    p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, mode, terms,
+                                 _amax.bound(x).data_ptr() if terms == 4 else None, _amax.bound(styles).data_ptr() if (terms == 4 and styles is not None) else None)
+    if accumulate_into is not None:
+        _amax.invalidate(accumulate_into)      # written through its raw pointer below
     e = custom_ops.Conv3x3Epilogue(styles.data_ptr() if styles is not None else None, dcoefs.data_ptr() if dcoefs is not None else None,
                                    bias.data_ptr() if bias is not None else None, act_idx, alpha, gain, clamp, 1 if accumulate_into is not None else 0)
     with custom_ops.device_guard(x):
@@ -155,7 +161,7 @@ class _FusedConvBiasActFn(torch.autograd.Function):
 def _fusable(x, weight, styles, dcoefs, bias, act, alpha, gain, clamp):
     if act == 'linear' and clamp >= 0:   # the reference's linear + clamp gradient is NOT masked where the output saturated (bias_act.py:24 saves no y); keep that
         return False
-    if mode == 0 or _composition_depth > 0 or _cg.native_conv_terms not in (1, 3) or not _cg.enabled:
+    if mode == 0 or _composition_depth > 0 or _cg.native_conv_terms not in (1, 3, 4) or not _cg.enabled:
         return False
     if not (x.is_cuda and x.ndim == 4 and x.dtype in _cg._DT and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)):
         return False
@@ -268,7 +274,7 @@ class _FusedConvActFirFn(torch.autograd.Function):
             # In-place use of an incoming gradient: only a tensor that is plainly this node's to consume -- no autograd history (a recorded backward took
             # the create_graph branch above), not a view into somebody else's storage.  A hook or `retain_grad()` on the alias output would still see
             # the sum instead of the skip branch's gradient; SGV_ALIAS_ACC=0 restores the out-of-place add for such uses.
-            if (accumulate_input_gradients and g_alias is not None and g_alias.is_contiguous() and g_alias.dtype == torch.float32 and dt == 0 and _cg.native_conv_terms in (1, 3)
+            if (accumulate_input_gradients and g_alias is not None and g_alias.is_contiguous() and g_alias.dtype == torch.float32 and dt == 0 and _cg.native_conv_terms in (1, 3, 4)
                     and not g_alias.requires_grad and g_alias._base is None
                     and lib.sgv_conv3x3_fused_supported(n, co, ci, h, w, 0)):
                 # the data gradient lands IN the gradient the skip branch produced (one fp32 add per element in the convolution's store)

@@ -18,6 +18,7 @@ under ``fused_conv_act.composition_only()``.  Parity: tests/test_fused_conv_gpu.
 import torch
 
 from .. import custom_ops
+from . import amax as _amax
 from . import bias_act as _ba
 from . import conv2d_gradfix as _cg
 from . import fused_conv_act as _fca
@@ -47,7 +48,11 @@ def _launch(xb, weight, bias, residual, want_act, act_idx, alpha, gain, clamp):
     a = torch.empty_like(y) if want_act else None
     wsb = int(lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, ws_, 0))
     wsp = torch.empty([wsb], dtype=torch.uint8, device=xb.device)
-    p = custom_ops.Conv3x3Params(xb.data_ptr(), weight.data_ptr(), y.data_ptr(), wsp.data_ptr(), wsb, n, ci, co, hs, ws_, 0, _cg.native_conv_terms if dt == 0 else 1)
+    terms = _cg.native_conv_terms if dt == 0 else 1
+    p = custom_ops.Conv3x3Params(xb.data_ptr(), weight.data_ptr(), y.data_ptr(), wsp.data_ptr(), wsb, n, ci, co, hs, ws_, 0, terms,
+                                 _amax.bound(xb).data_ptr() if terms == 4 else None, None)
+    if residual is not None:
+        _amax.invalidate(residual)      # updated in place through its raw pointer
     e = custom_ops.Conv3x3S2Epilogue(bias.data_ptr() if bias is not None else None, a.data_ptr() if a is not None else None, act_idx, alpha, gain, clamp,
                                      1 if residual is not None else 0)
     with custom_ops.device_guard(xb):
@@ -114,7 +119,7 @@ class _FusedDownFn(torch.autograd.Function):
 def _fusable(xb, weight, bias, residual, act, alpha, gain, clamp):
     if act == 'linear' and clamp >= 0:   # same reference quirk as fused_conv_act: linear + clamp has an unmasked gradient
         return False
-    if _fca.mode == 0 or _fca._composition_depth > 0 or _cg.native_conv_terms not in (1, 3) or not _cg.enabled or not _cg.native_conv_s2:
+    if _fca.mode == 0 or _fca._composition_depth > 0 or _cg.native_conv_terms not in (1, 3, 4) or not _cg.enabled or not _cg.native_conv_s2:
         return False
     if not (xb.is_cuda and xb.ndim == 4 and xb.dtype in _cg._DT and weight.dtype == torch.float32 and tuple(weight.shape[2:]) == (3, 3)):
         return False

@@ -23,7 +23,15 @@ def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0,
     p.residual = residual.data_ptr() if residual is not None else None
     p.m, p.n, p.k, p.lda, p.ldb, p.ldc = m, n, k, lda, ldb, ldc
     p.trans_b, p.batch, p.stride_a, p.stride_b, p.stride_c, p.bias_mode, p.k_split = int(trans_b), batch, sa, sb, sc, bias_mode, k_split
-    p.exact_fp32 = 1 if (exact_fp32 or _gradfix().native_conv_terms == 0) else 0   # the strict-fp32 switch of the 3x3 family covers the dense products too
+    # the arithmetic switch of the 3x3 family covers the dense products too: 0 -> the exact fp32 matrix pipe, 3 -> bf16 split, 4 (default) -> the
+    # block-scaled fp16 split where the tile shape allows it (fp32-grade; bounds of both operands travel as device pointers), exact fp32 elsewhere
+    terms = _gradfix().native_conv_terms
+    p.exact_fp32 = 1 if (exact_fp32 or terms == 0) else (2 if terms == 4 else 0)
+    if p.exact_fp32 == 2 and not (n % 128 == 0 and (k // max(k_split, 1)) % 32 == 0 and lda % 4 == 0):
+        p.exact_fp32 = 1          # a shape the split members do not serve (csrc/gemm.hip): the exact pipe, no bounds needed
+    if p.exact_fp32 == 2:
+        from . import amax as _amax
+        p.a_amax, p.b_amax = _amax.bound(a).data_ptr(), _amax.bound(b).data_ptr()
     with torch.cuda.device_of(c):
         custom_ops.check(lib.sgv_gemm_f32(p, torch.cuda.current_stream(c.device).cuda_stream), lib)
     return c

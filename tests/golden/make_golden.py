@@ -430,6 +430,123 @@ def gen_networks_full():
     save('networks_full', arrays, meta)
 
 
+class _Torch64:
+    """Stand-in for the `torch` global of the reference's model files during a float64 evaluation: their hard-wired `torch.float32` casts
+    (networks.py:227,261,351,461,552; layers.py:74; motion.py:114-116) become float64, everything else is torch."""
+    float32 = torch.float64
+
+    def __getattr__(self, name):
+        return getattr(torch, name)
+
+
+def _reference_in_float64(fn):
+    """Run fn() with the reference's model files computing in float64 (see _Torch64)."""
+    import training.networks as ref_networks, training.layers as ref_layers, training.motion as ref_motion
+    mods = (ref_networks, ref_layers, ref_motion)
+    for m in mods:
+        m.torch = _Torch64()
+    try:
+        return fn()
+    finally:
+        for m in mods:
+            m.torch = torch
+
+
+def _filters_to_float32(mod):
+    for name, buf in mod.named_buffers():        # conv2d_resample.py:86 / upfirdn2d.py:177 want the FIR taps in float32 (exactly representable: k / 64)
+        if name.endswith('resample_filter'):
+            buf.data = buf.data.float()
+
+
+def gen_networks_1024():
+    """BASELINE configs[4] (SkyTimelapse 1024^2; VERDICT r3 missing #3): the reference `Generator` at fmaps = 1 (src/train.py:158: channels 512 x5,
+    256 @ 128^2, 128 @ 256^2, 64 @ 512^2, 32 @ 1024^2), `time_enc.min_period_len = 256` => `motion_z_distance = 256` (configs/model/stylegan-v.yaml:17),
+    one clip x 2 frames through the EVAL path (fused_modconv, noise off; scripts/generate.py:43-145) in float64, name-seeded parameters
+    (tests/util.py:seeded_parameters_).  Stored: ws, motion_v, a strided sample of the image (65,536 values of every channel / resolution phase) and
+    the fp32-vs-fp64 noise of the reference's own evaluation per tensor."""
+    from omegaconf import OmegaConf
+    from training.networks import Generator
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import seeded_parameters_, sample_flat
+    RES = 1024
+    sampling = dict(type='random', num_frames_per_video=3, max_num_frames=1024, total_dists=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048], max_dist=32)
+    gcfg = OmegaConf.create(dict(sampling=sampling, use_noise=False, input=dict(type='temporal'), w_dim=512, z_dim=512, c_dim=0,
+                                 motion=dict(z_dim=512, v_dim=512, motion_z_distance=256, gen_strategy='conv', kernel_size=11, use_fractional_t=True, fourier=True),
+                                 time_enc=dict(cond_type='concat_const', dim=256, min_period_len=256, max_period_len=1024, phase_dropout_std=1.0)))
+    torch.manual_seed(4050)
+    G = Generator(c_dim=0, w_dim=512, img_resolution=RES, img_channels=3, mapping_kwargs=dict(num_layers=2, cfg=gcfg),
+                  synthesis_kwargs=dict(channel_base=32768, channel_max=512, num_fp16_res=0, conv_clamp=None), cfg=gcfg)
+    n_params = sum(p.numel() for p in G.parameters())
+    assert abs(n_params / 1e6 - 37.7) < 0.1, n_params
+    seeded_parameters_(G, 505)
+    G.eval()
+    g = torch.Generator().manual_seed(80)
+    B, F = 1, 2
+    z = torch.randn([B, 512], generator=g)
+    t = torch.tensor([[3.0, 301.0]])          # two frames of one clip, more than one motion-code distance (256) apart
+    traj_len = G.synthesis.motion_encoder.get_max_traj_len(t) + G.synthesis.motion_encoder.num_additional_codes
+    motion_z = torch.randn([B, traj_len, 512], generator=g)
+
+    def evaluate(dt):
+        Gd = G.to(dt)
+        _filters_to_float32(Gd)
+        zz, tt, mz, c = z.to(dt), t.to(dt), motion_z.to(dt), torch.zeros([B, 0], dtype=dt)
+        with torch.no_grad():
+            ws = Gd.mapping(zz, c, skip_w_avg_update=True)
+            mv = Gd.synthesis.motion_encoder(c, tt, motion_z=mz)['motion_v']
+            img = Gd.synthesis(ws, t=tt, c=c, motion_z=mz, noise_mode='const')
+        assert img.shape == (B * F, 3, RES, RES)
+        return dict(ws=sample_flat(ws), motion_v=mv.reshape(-1), img_sample=sample_flat(img, limit=65536),
+                    img_rows=img[:, :, ::128, :].reshape(-1))      # + 8 whole rows per frame and channel: every column phase of the 1024-wide kernels
+
+    r32 = evaluate(torch.float32)
+    r64 = _reference_in_float64(lambda: evaluate(torch.float64))
+    arrays = {'z': z, 't': t, 'motion_z': motion_z}
+    noise = {}
+    for key, v64 in r64.items():
+        noise[key] = float((r32[key].double() - v64).abs().max().item() / max(v64.abs().max().item(), 1e-300))
+        arrays[key] = v64.float()
+    print('fp32-vs-fp64 noise of the reference itself:', noise)
+    save('networks_1024', arrays, dict(B=B, F=F, res=RES, seed_G=505, G_params=n_params, noise=noise, min_period_len=256))
+
+
+def gen_networks_cfg1():
+    """BASELINE configs[0] as written (VERDICT r3 missing #9): `Generator(c_dim=0, w_dim=512, img_resolution=64, img_channels=3,
+    mapping num_layers=8, channel_base=32768, channel_max=512, num_fp16_res=0, conv_clamp=None)` -- cfg=stylegan2 of src/train.py:140,167-174 under
+    the StyleGAN-V generator config -- z ~ N(0,1)[4,512], t = sort(U[0,31))[4,3] (12 frames), every op on the reference's Python fallback path
+    (CPU, fp32: the configuration's own arithmetic).  Training AND eval path; name-seeded parameters; images stored as strided samples."""
+    from omegaconf import OmegaConf
+    from training.networks import Generator
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import seeded_parameters_, sample_flat
+    sampling = dict(type='random', num_frames_per_video=3, max_num_frames=1024, total_dists=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048], max_dist=32)
+    gcfg = OmegaConf.create(dict(sampling=sampling, use_noise=False, input=dict(type='temporal'), w_dim=512, z_dim=512, c_dim=0,
+                                 motion=dict(z_dim=512, v_dim=512, motion_z_distance=16, gen_strategy='conv', kernel_size=11, use_fractional_t=True, fourier=True),
+                                 time_enc=dict(cond_type='concat_const', dim=256, min_period_len=16, max_period_len=1024, phase_dropout_std=1.0)))
+    torch.manual_seed(4051)
+    G = Generator(c_dim=0, w_dim=512, img_resolution=64, img_channels=3, mapping_kwargs=dict(num_layers=8, cfg=gcfg),
+                  synthesis_kwargs=dict(channel_base=32768, channel_max=512, num_fp16_res=0, conv_clamp=None), cfg=gcfg)
+    seeded_parameters_(G, 606)
+    g = torch.Generator().manual_seed(81)
+    B, F = 4, 3
+    z = torch.randn([B, 512], generator=g)
+    c = torch.zeros([B, 0])
+    t = torch.sort(torch.rand([B, F], generator=g) * 31, dim=1).values
+    traj_len = G.synthesis.motion_encoder.get_max_traj_len(t) + G.synthesis.motion_encoder.num_additional_codes
+    motion_z = torch.randn([B, traj_len, 512], generator=g)
+    arrays = {'z': z, 't': t, 'motion_z': motion_z}
+    with torch.no_grad():
+        G.train()
+        ws = G.mapping(z, c, skip_w_avg_update=True)
+        arrays['ws'] = ws
+        arrays['img_train'] = sample_flat(G.synthesis(ws, t=t, c=c, motion_z=motion_z), limit=32768)
+        G.eval()
+        arrays['img_eval'] = sample_flat(G.synthesis(ws, t=t, c=c, motion_z=motion_z, noise_mode='const'), limit=32768)
+        arrays['img_trunc'] = sample_flat(G(z, c, t, truncation_psi=0.7, motion_z=motion_z), limit=32768)
+    save('networks_cfg1', arrays, dict(B=B, F=F, res=64, seed_G=606, mapping_layers=8, channel_base=32768, G_params=sum(p.numel() for p in G.parameters()),
+                                       num_ws=int(G.num_ws)))
+
+
 def gen_augment():
     """ADA `bgc` pipeline (src/training/augment.py) at fixed percentiles of every augmentation parameter (the reference's own
     `debug_percentile` hook makes the transform deterministic), on 3-frame clips folded into 9 channels (loss.py:58-66)."""
@@ -480,5 +597,7 @@ if __name__ == '__main__':
     gen_networks()
     gen_networks_mid()
     gen_networks_full()
+    gen_networks_1024()
+    gen_networks_cfg1()
     gen_augment()
     gen_time_encoder()

@@ -25,7 +25,7 @@ def test_header_functions_all_exported_and_bound():
 
 def test_version_and_error_string():
     lib = custom_ops.get_native()
-    assert lib.sgv_version() == 100
+    assert lib.sgv_version() == 101     # 1.01: terms = 4 (block-scaled fp16 split), sgv_absmax, the *_amax fields of the convolution / GEMM parameter blocks
     assert isinstance(lib.sgv_last_error(), bytes)
     assert lib.sgv_launch_count() >= 0
 
@@ -61,11 +61,11 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(custom_ops.Upfirdn2dParams) == 176
     assert ctypes.sizeof(custom_ops.BiasActParams) == 80
     assert ctypes.sizeof(custom_ops.TimeEncodeParams) == 96
-    assert ctypes.sizeof(custom_ops.GemmParams) == 128
+    assert ctypes.sizeof(custom_ops.GemmParams) == 144
     assert ctypes.sizeof(custom_ops.ProfEntry) == 32
     assert ctypes.sizeof(custom_ops.PointwiseParams) == 56
-    assert ctypes.sizeof(custom_ops.ConvWrwParams) == 48
-    assert ctypes.sizeof(custom_ops.Conv3x3Params) == 72
+    assert ctypes.sizeof(custom_ops.ConvWrwParams) == 72
+    assert ctypes.sizeof(custom_ops.Conv3x3Params) == 88
 
 
 def test_convolution_family_shape_rules_and_validation_without_gpu():
@@ -86,13 +86,13 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     assert lib.sgv_conv3x3_supported(96, 32, 96, 256, 256, custom_ops.SGV_BF16) == 1
     assert lib.sgv_conv3x3_supported(96, 512, 32, 16, 16, F32) == 0
     assert lib.sgv_conv3x3_fused_supported(16, 32, 32, 1024, 1024, F32) == 1
-    assert lib.sgv_conv3x3_workspace_bytes(64, 32) == 64 * 64 * 9 * 4      # whole 64-row tiles
+    assert lib.sgv_conv3x3_workspace_bytes(64, 32) == 64 * 64 * 9 * 4 + 16      # whole 64-row tiles + the weight bound of the block-scaled split
     # 16-bit tensors (fp32 weights and accumulate): the producer / consumer kernel of the big images only
     assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, F16) == 1
     assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, custom_ops.SGV_BF16) == 1
     assert lib.sgv_conv3x3_supported(96, 512, 512, 16, 16, F16) == 0
     assert lib.sgv_conv3x3_supported(96, 64, 64, 256, 256, custom_ops.SGV_F64) == 0
-    assert lib.sgv_conv3x3_workspace_bytes(64, 128) == 64 * 128 * 9 * 4
+    assert lib.sgv_conv3x3_workspace_bytes(64, 128) == 64 * 128 * 9 * 4 + 16
     # stride 2 (h, w = the small grid): W % 32, H % 8
     assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 128, 128, F32) == 1
     assert lib.sgv_conv3x3_s2_supported(96, 64, 128, 8, 32, F32) == 1
@@ -102,7 +102,7 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     assert lib.sgv_conv3x3_s2_supported_mode(16, 64, 32, 512, 512, 0, F32) == 0      # the strided form keeps whole tiles
     ws_strided = lib.sgv_conv3x3_s2_workspace_bytes(4, 64, 128, 16, 32, 0)
     ws_transposed = lib.sgv_conv3x3_s2_workspace_bytes(4, 64, 128, 16, 32, 2)
-    assert ws_strided == 64 * 128 * 10 * 4   # ten taps: the tap-pair layout of the strided kernel pads the ninth pair
+    assert ws_strided == 64 * 128 * 10 * 4 + 16   # ten taps: the tap-pair layout of the strided kernel pads the ninth pair
     assert ws_transposed == ws_strided + 4 * (4 * 64 * (16 + 32) + 2 * 64 * 3 * 128)   # + edge lines + edge weights
     # weight gradients: channels % 64
     assert lib.sgv_conv3x3_wrw_supported(96, 64, 64, 256, 256, F32) == 1
@@ -121,6 +121,8 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     p.h = 16
     p.terms = 2
     assert lib.sgv_conv3x3(p, F32, None) == -1 and b'terms' in lib.sgv_last_error()
+    p.terms = 4                                    # the block-scaled split needs the operand's bound
+    assert lib.sgv_conv3x3(p, F32, None) == -1 and b'x_amax' in lib.sgv_last_error()
     p.terms, p.workspace_bytes = 3, 16
     assert lib.sgv_conv3x3(p, F32, None) == -1 and b'workspace' in lib.sgv_last_error()
     p.mode, p.workspace_bytes = 1, 1 << 30
@@ -131,6 +133,9 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     q.n, q.c_out, q.c_in, q.h, q.w, q.terms = 2, 64, 64, 32, 24, 3
     assert lib.sgv_conv3x3_wrw(q, F32, None) == -3 and b'W % 32' in lib.sgv_last_error()
     assert lib.sgv_conv3x3_wrw_s2(q, F32, None) == -3
+    q.w, q.terms = 32, 4
+    assert lib.sgv_conv3x3_wrw(q, F32, None) == -1 and b'dy_amax' in lib.sgv_last_error()
+    assert lib.sgv_absmax(None, 4, F32, None, 0, None) == -1
     r = custom_ops.PointwiseParams()
     assert lib.sgv_pointwise_small(r, F32, None) == -1
     assert lib.sgv_bias_act_db(custom_ops.BiasActParams(), None, 1, F32, None) == -1 and b'db is NULL' in lib.sgv_last_error()

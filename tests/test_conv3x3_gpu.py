@@ -1,4 +1,5 @@
-"""3x3 stride-1 convolution forward / data gradient on the bf16 matrix pipe with fp32 emulation (csrc/conv3x3_kernel.h) vs fp64."""
+"""3x3 convolution family (stride 1, stride 2, transposed; csrc/conv3x3*_kernel.h) on the 16-bit matrix pipe with fp32 emulation vs fp64 -- every test under
+both arithmetics: the block-scaled fp16 split (terms = 4, the default: fp32-grade, <= 5e-7) and the bf16 split (terms = 3: <= 1e-5)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -9,6 +10,19 @@ from util import assert_close, dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
+
+
+@pytest.fixture(params=[4, 3], ids=['f16split', 'bf16split'], autouse=True)
+def arithmetic(request):
+    saved = (conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms)
+    conv2d_gradfix.native_conv_terms = conv2d_gradfix.native_wrw_terms = request.param
+    yield request.param
+    conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms = saved
+
+
+def _tol():
+    """rel-L2 / max-norm bound against float64: MIOpen-class (its fp32 convolutions: 1.4-3.5e-7) for the fp16 split, 1e-5 for the bf16 split."""
+    return 5e-7 if conv2d_gradfix.native_conv_terms == 4 else 1e-5
 
 
 def _rel(a, ref):
@@ -34,8 +48,8 @@ def test_conv3x3_matches_fp64(n, ci, co, h, w, transposed):
     lib = (F.conv_transpose2d if transposed else F.conv2d)(x.detach(), wt, padding=1)
     l2, mx = _rel(y, ref)
     l2_lib, mx_lib = _rel(lib, ref)
-    print(f'bf16x3 rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
-    assert l2 < 1e-5 and mx < 1e-5
+    print(f'terms {conv2d_gradfix.native_conv_terms}: rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
+    assert l2 < _tol() and mx < 2 * _tol(), (l2, mx, l2_lib, mx_lib)
     # exact on small integers (hi/lo split is exact, products and sums fit fp32): catches any tap / channel / pixel mix-up
     xi = torch.randint(-3, 4, x.shape, generator=g).float().to(DEV)
     wi = torch.randint(-2, 3, wt.shape, generator=g).float().to(DEV)
@@ -115,8 +129,8 @@ def test_conv3x3_stride2_family_matches_fp64(n, cb, cs, h, w, transposed):
     assert y.shape == ref.shape
     l2, mx = _rel(y, ref)
     l2_lib, mx_lib = _rel(ref_op(x.detach(), wt, stride=2), ref)
-    print(f'bf16x3 s2 rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
-    assert l2 < 1e-5 and mx < 1e-5
+    print(f'terms {conv2d_gradfix.native_conv_terms} s2: rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
+    assert l2 < _tol() and mx < 2 * _tol(), (l2, mx, l2_lib, mx_lib)
     xi = torch.randint(-3, 4, x.shape, generator=g).float().to(DEV)
     wi = torch.randint(-2, 3, wt.shape, generator=g).float().to(DEV)
     assert torch.equal(conv2d_gradfix._native_conv(xi, wi, cfg).cpu().double(), ref_op(xi.double().cpu(), wi.double().cpu(), stride=2))
@@ -135,7 +149,7 @@ def test_transposed_stride2_on_small_images_packs_samples(n, ci, co, h, w):
     ref = F.conv_transpose2d(x.double().cpu(), wt.double().cpu(), stride=2)
     assert y.shape == ref.shape
     l2, mx = _rel(y, ref)
-    assert l2 < 1e-5 and mx < 1e-5
+    assert l2 < _tol() and mx < 2 * _tol(), (l2, mx)
     xi = torch.randint(-3, 4, x.shape, generator=g).float()
     xi[1::2] = 0                                                     # every second sample is zero: its output must be exactly zero
     wi = torch.randint(-2, 3, wt.shape, generator=g).float()
@@ -159,7 +173,7 @@ def test_strided_stride2_on_small_images_packs_samples(n, ci, co, h, w):
     ref = F.conv2d(x.double().cpu(), wt.double().cpu(), stride=2)
     assert y.shape == ref.shape
     l2, mx = _rel(y, ref)
-    assert l2 < 1e-5 and mx < 1e-5
+    assert l2 < _tol() and mx < 2 * _tol(), (l2, mx)
     xi = torch.randint(-3, 4, x.shape, generator=g).float()
     xi[1::2] = 0
     wi = torch.randint(-2, 3, wt.shape, generator=g).float()
@@ -209,7 +223,7 @@ def test_conv3x3_family_vs_oracle(stride, transposed):
     for got, ref, what in ((y, oracle.conv3x3(x.numpy(), wt.numpy(), stride=stride, transposed=transposed), 'y'),
                            (gw, oracle.conv3x3_weight_grad(dy.numpy(), x.numpy(), stride=stride, transposed=transposed), 'dw')):
         l2, mx = _rel(got.detach(), torch.as_tensor(ref))
-        assert l2 < 1e-5 and mx < 1e-5, (what, l2, mx)
+        assert l2 < _tol() and mx < 2 * _tol(), (what, l2, mx)
 
 
 def test_native_kernels_also_serve_no_grad_passes():

@@ -37,24 +37,27 @@ def _rel(a, ref):
 @pytest.mark.parametrize('n,o,i,h,w', [(2, 64, 64, 32, 32), (1, 64, 128, 64, 64), (2, 128, 64, 64, 96), (3, 64, 64, 8, 32), (1, 192, 64, 96, 32), (2, 64, 64, 1, 32),
                                        # images 16 / 8 pixels wide: 2 / 4 samples share a 32-pixel row step (incl. batches that leave the last group short)
                                        (4, 64, 64, 16, 16), (3, 128, 64, 16, 16), (1, 64, 64, 16, 16), (8, 64, 128, 8, 8), (5, 64, 64, 8, 8), (2, 64, 64, 4, 8), (7, 64, 64, 32, 16)])
-def test_wrw_bf16x3_matches_fp64_as_well_as_the_vendor_fp32_kernel(n, o, i, h, w):
+@pytest.mark.parametrize('terms', [4, 3])
+def test_wrw_bf16x3_matches_fp64_as_well_as_the_vendor_fp32_kernel(n, o, i, h, w, terms):
+    """terms = 4 (block-scaled fp16 split, the default): fp32-grade, <= 5e-7 of the result's scale; terms = 3 (bf16 split): <= 1e-5."""
     g = torch.Generator().manual_seed(n * 100 + o + i + h)
     dy = torch.randn([n, o, h, w], generator=g).to(DEV)
     x = (torch.randn([n, i, h, w], generator=g) * 1.5 + 0.25).to(DEV)
     ref = _ref_dw(dy, x)
-    got = _native(dy, x, 3)
+    got = _native(dy, x, terms)
     assert got.shape == ref.shape and got.dtype == torch.float32
     l2, mx = _rel(got, ref)
     # vendor fp32 kernel on the same inputs, for scale
     w_like = x.new_empty(ref.shape)
     _, dw_lib, _ = torch.ops.aten.convolution_backward(dy, x, w_like, None, (1, 1), (1, 1), (1, 1), False, (0, 0), 1, [False, True, False])
     l2_lib, mx_lib = _rel(dw_lib, ref)
-    print(f'bf16x3 rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
-    assert l2 < 1e-5 and mx < 1e-5, (l2, mx, l2_lib, mx_lib)   # north_star tolerance is 1e-3; fp32 round-off of this sum is ~1e-6
+    print(f'terms {terms}: rel-L2 {l2:.2e} max {mx:.2e} | MIOpen fp32 rel-L2 {l2_lib:.2e} max {mx_lib:.2e}')
+    tol = 5e-7 if terms == 4 else 1e-5     # (weight gradients sum n * h * w products in fp32 with atomics across workgroups: the summation itself costs ~1e-7)
+    assert l2 < tol and mx < 2 * tol, (l2, mx, l2_lib, mx_lib)
     # asymmetric structure check: exact small integers survive the split exactly -> bit-exact result
     dyi = torch.randint(-3, 4, dy.shape, generator=g).float().to(DEV)
     xi = torch.randint(-3, 4, x.shape, generator=g).float().to(DEV)
-    assert torch.equal(_native(dyi, xi, 3).cpu().double(), _ref_dw(dyi, xi))
+    assert torch.equal(_native(dyi, xi, terms).cpu().double(), _ref_dw(dyi, xi))
 
 
 def test_wrw_single_term_is_plain_bf16():
@@ -111,8 +114,10 @@ def test_unsupported_shapes_fall_back_to_the_vendor_library():
                                           # small grid 16 / 8 pixels wide (big 33 / 17): 2 / 4 samples per row step, incl. a short last group
                                           (4, 64, 64, 16, 16), (3, 64, 128, 16, 16), (8, 128, 64, 8, 8), (5, 64, 64, 8, 8), (1, 64, 64, 4, 8)])
 @pytest.mark.parametrize('transposed', [False, True])
-def test_wrw_stride2_family(n, cs, cb, h, w, transposed):
+@pytest.mark.parametrize('terms', [4, 3])
+def test_wrw_stride2_family(n, cs, cb, h, w, transposed, terms, monkeypatch):
     """Weight gradient of the strided (big -> small) and of the transposed (small -> big) 3x3 layer."""
+    monkeypatch.setattr(conv2d_gradfix, 'native_wrw_terms', terms)
     g = torch.Generator().manual_seed(n + cs + cb + h)
     small = torch.randn([n, cs, h, w], generator=g).to(DEV)
     big = (torch.randn([n, cb, 2 * h + 1, 2 * w + 1], generator=g) * 1.5 + 0.25).to(DEV)
@@ -125,8 +130,9 @@ def test_wrw_stride2_family(n, cs, cb, h, w, transposed):
     y = F.conv_transpose2d(xd, wz, stride=2) if transposed else F.conv2d(xd, wz, stride=2)
     ref = torch.autograd.grad(y, wz, dyd)[0]
     l2, mx = _rel(got, ref)
-    print(f'bf16x3 wrw-s2 rel-L2 {l2:.2e} max {mx:.2e}')
-    assert l2 < 1e-5 and mx < 1e-5
+    print(f'terms {terms} wrw-s2 rel-L2 {l2:.2e} max {mx:.2e}')
+    tol = 5e-7 if terms == 4 else 1e-5
+    assert l2 < tol and mx < 2 * tol, (l2, mx)
     si = torch.randint(-3, 4, small.shape, generator=g).float().to(DEV)
     bi = torch.randint(-3, 4, big.shape, generator=g).float().to(DEV)
     xi, dyi = (si, bi) if transposed else (bi, si)
