@@ -324,6 +324,13 @@ int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream);
  * A bound smaller than the data overflows fp16 (inf / NaN in the result).
  */
 int sgv_absmax(const void* x, int64_t numel, int dtype, float* out, int32_t accumulate, void* stream);
+/* The same bound as a free by-product of the kernel that WRITES the tensor: sgv_amax_sink(out) arms a one-shot side output for the NEXT sgv_* call of
+ * this thread; if that call's kernel supports it (the LDS-tile forms of sgv_upfirdn2d / sgv_upfirdn2d_fused modes 1 and 3, sgv_act_grad_scale[_t],
+ * sgv_scale_channels, sgv_pointwise_act -- all on fp32 tensors) out[0] = max |output| after it, and sgv_amax_sink_consumed() returns 1; any other
+ * call leaves `out` untouched, disarms the sink and sgv_amax_sink_consumed() returns 0 (the caller then runs sgv_absmax on the result).  Thread-local;
+ * nothing else in the library is stateful. */
+int sgv_amax_sink(float* out);
+int sgv_amax_sink_consumed(void);
 
 /*
  * sgv_conv3x3 with the element-wise steps that surround the convolution of a stride-1 SynthesisLayer / Conv2dLayer folded in

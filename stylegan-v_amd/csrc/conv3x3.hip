@@ -148,7 +148,8 @@ extern "C" int sgv_absmax(const void* x, int64_t numel, int dtype, float* out, i
     hipStream_t stream = (hipStream_t)stream_;
     if (!accumulate && hipMemsetAsync(out, 0, 4, stream) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "absmax: hipMemsetAsync failed");
     if (numel == 0) return SGV_OK;
-    const unsigned blocks = (unsigned)std::min<int64_t>((numel + 1023) / 1024, 2048);
+    const int64_t epv = dtype == SGV_F32 ? 4 : 8;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / epv + 1023) / 1024, 4096));     // four 16-byte vectors per lane and pass
     sgv_launch_scope scope(SGV_K_ABSMAX, stream, (double)numel * (dtype == SGV_F32 ? 4.0 : 2.0), 0.0, false);
     if (dtype == SGV_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (size_t)numel, (unsigned*)out);
     else if (dtype == SGV_F16) hipLaunchKernelGGL(absmax_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)x, (size_t)numel, (unsigned*)out);
@@ -170,7 +171,7 @@ namespace {
 // terms = 4: max |w| into the workspace tail (cleared first), for the weight preparation and the kernel's epilogue
 int weight_amax(const float* w, size_t numel, float* slot, hipStream_t stream) {
     if (hipMemsetAsync(slot, 0, 4, stream) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3: hipMemsetAsync failed");
-    const unsigned blocks = (unsigned)std::min<size_t>((numel + 1023) / 1024, 256);
+    const unsigned blocks = (unsigned)std::max<size_t>(1, std::min<size_t>((numel / 4 + 1023) / 1024, 256));
     hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(256), 0, stream, w, numel, (unsigned*)slot);
     return sgv_check_launch("absmax_kernel (weights)");
 }

@@ -22,6 +22,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "sgv_split.h"
 
@@ -470,27 +471,44 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x
 
 
 // max |v| of a tensor as an fp32 bit pattern (non-negative floats order like unsigned integers); NaN / inf propagate as the largest patterns.
-// `out` must hold 0 (or a previous bound to extend) on entry.
+// `out` must hold 0 (or a previous bound to extend) on entry.  A streaming read: every lane keeps four 16-byte loads in flight, the grid covers the
+// tensor once (up to 4096 workgroups, grid-stride beyond); one atomic per wave, and only where the wave's maximum exceeds what is already there.
+__device__ __forceinline__ void absmax_commit(unsigned m, unsigned* out) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void absmax_kernel(const T* x, size_t n, unsigned* out) {
     unsigned m = 0u;
-    const size_t stride = (size_t)gridDim.x * 256 * 4;
-    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
-        if constexpr (sizeof(T) == 4) {
-            if (i + 4 <= n && (((uintptr_t)x) & 15) == 0) {
-                const u32x4 v = *(const u32x4*)((const unsigned*)x + i);
+    constexpr int EPV = 16 / sizeof(T);                       // elements per 16-byte vector
+    const size_t head = min(n, (size_t)(((16 - ((uintptr_t)x & 15)) & 15) / sizeof(T)));   // elements in front of the first 16-byte boundary
+    const u32x4* v = (const u32x4*)(x + head);
+    const size_t nv = (n - head) / EPV;
+    auto fold = [&](u32x4 w) {
 #pragma unroll
-                for (int j = 0; j < 4; j++) m = max(m, v[j] & 0x7fffffffu);
-            } else {
-                for (size_t j = i; j < n && j < i + 4; j++) m = max(m, ((const unsigned*)x)[j] & 0x7fffffffu);
+        for (int j = 0; j < 4; j++) {
+            if constexpr (sizeof(T) == 4) m = max(m, w[j] & 0x7fffffffu);
+            else if constexpr (std::is_same<T, __bf16>::value) m = max(m, max((w[j] << 16) & 0x7fffffffu, w[j] & 0x7fff0000u));   // a bf16 IS the upper half of the fp32 pattern
+            else {
+                const f16x2 hh = __builtin_bit_cast(f16x2, w[j]);
+                m = max(m, max(__builtin_bit_cast(unsigned, (float)hh[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, (float)hh[1]) & 0x7fffffffu));
             }
-        } else {   // 16-bit elements: widen the bit pattern (bf16: << 16; fp16 is converted by the caller's instantiation)
-            for (size_t j = i; j < n && j < i + 4; j++) m = max(m, __builtin_bit_cast(unsigned, (float)x[j]) & 0x7fffffffu);
         }
+    };
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += 4 * stride) {
+        const bool k1 = i + stride < nv, k2 = i + 2 * stride < nv, k3 = i + 3 * stride < nv;
+        const u32x4 w0 = v[i], w1 = v[k1 ? i + stride : i], w2 = v[k2 ? i + 2 * stride : i], w3 = v[k3 ? i + 3 * stride : i];
+        fold(w0); fold(w1); fold(w2); fold(w3);
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if (blockIdx.x == 0 && threadIdx.x < 64) {                 // the unaligned head and the tail shorter than a vector: at most 2 * EPV - 2 elements
+        const size_t tail0 = head + nv * EPV;
+        const size_t k = threadIdx.x < head ? threadIdx.x : tail0 + (threadIdx.x - head);
+        if (k < n && (threadIdx.x < head || k >= tail0)) m = max(m, __builtin_bit_cast(unsigned, (float)x[k]) & 0x7fffffffu);
+    }
+    absmax_commit(m, out);
 }
 
 }  // namespace sgv_conv

@@ -59,19 +59,26 @@ template <typename T> struct vec16 {
 } __attribute__((aligned(16)));
 
 // Vector path: hw % N == 0 so a 16-B vector never straddles two planes.
+// y_amax (fp32 tensors, or NULL): max |y| as a by-product for the block-scaled split of the convolution that reads y (sgv_amax_sink)
 template <typename T>
 __global__ __launch_bounds__(256) void scale_channels_vec_kernel(const T* __restrict__ x, const float* __restrict__ s,
-                                                                 T* __restrict__ y, int nvec, int hw) {
+                                                                 T* __restrict__ y, int nvec, int hw, float* y_amax) {
     constexpr int N = vec16<T>::N;
     const vec16<T>* xv = (const vec16<T>*)x;
     vec16<T>* yv = (vec16<T>*)y;
+    unsigned amx = 0u;
     for (int vi = blockIdx.x * blockDim.x + threadIdx.x; vi < nvec; vi += gridDim.x * blockDim.x) {
         const float sc = s[(vi * N) / hw];
         vec16<T> v = xv[vi], o;
 #pragma unroll
-        for (int k = 0; k < N; k++) sgv_traits<T>::store(&o.e[k], sgv_traits<T>::load(&v.e[k]) * sc);
+        for (int k = 0; k < N; k++) {
+            const float r = sgv_traits<T>::load(&v.e[k]) * sc;
+            sgv_traits<T>::store(&o.e[k], r);
+            if constexpr (sizeof(T) == 4) amx = sgv_amax_fold(amx, r);
+        }
         yv[vi] = o;
     }
+    if constexpr (sizeof(T) == 4) { if (y_amax) sgv_amax_commit(amx, y_amax); }
 }
 
 template <typename T>
@@ -82,14 +89,15 @@ __global__ __launch_bounds__(256) void scale_channels_scalar_kernel(const T* __r
 }
 
 template <typename T>
-void launch_scale(const void* x, const float* s, void* y, int total, int hw, hipStream_t stream) {
+void launch_scale(const void* x, const float* s, void* y, int total, int hw, hipStream_t stream, sgv_launch_scope& scope) {
     constexpr int N = vec16<T>::N;
     const bool vec_ok = (hw % N == 0) && (((uintptr_t)x | (uintptr_t)y) % 16 == 0);
+    float* y_amax = (vec_ok && sizeof(T) == 4) ? scope.take_amax_sink() : nullptr;
     int work = vec_ok ? total / N : total;
     int blocks = (work + 255) / 256;  // one vector per lane, grid covers the tensor (see bias_act.hip)
     if (blocks < 1) blocks = 1;
     if (vec_ok)
-        hipLaunchKernelGGL(scale_channels_vec_kernel<T>, dim3(blocks), dim3(256), 0, stream, (const T*)x, s, (T*)y, work, hw);
+        hipLaunchKernelGGL(scale_channels_vec_kernel<T>, dim3(blocks), dim3(256), 0, stream, (const T*)x, s, (T*)y, work, hw, y_amax);
     else
         hipLaunchKernelGGL(scale_channels_scalar_kernel<T>, dim3(blocks), dim3(256), 0, stream, (const T*)x, s, (T*)y, total, hw);
 }
@@ -141,7 +149,7 @@ void launch_plane_dot(const void* a, const void* b, float* out, int planes, int 
 template <typename T>
 __global__ __launch_bounds__(256) void act_grad_scale_kernel(const T* __restrict__ dy, const T* __restrict__ y, const float* __restrict__ d,
                                                              T* __restrict__ out, float* __restrict__ sums, int planes, int hw, int act, float alpha, float gain,
-                                                             float clamp, int vec_ok) {
+                                                             float clamp, int vec_ok, float* out_amax) {
     constexpr int N = vec16<T>::N;
     const int plane = blockIdx.y;
     const int p0 = blockIdx.x * PD_CHUNK, p1 = min(hw, p0 + PD_CHUNK);
@@ -150,13 +158,16 @@ __global__ __launch_bounds__(256) void act_grad_scale_kernel(const T* __restrict
     T* op = out + (size_t)plane * hw;
     const float dsc = d ? d[plane] : 1.f;
     float sg = 0.f, sgv = 0.f;
+    unsigned amx = 0u;      // fp32 tensors: max |out| as a by-product (out_amax, sgv_amax_sink)
     auto one = [&](float g, float yy) {
         float dz = ((act == 3 && !(yy > 0.f)) ? g * alpha : g) * gain;
         float gv = g * yy;
         if (clamp >= 0.f && !(yy > -clamp & yy < clamp)) { dz = 0.f; gv = 0.f; }
         sg += dz;
         sgv += gv;
-        return dz * dsc;
+        const float r = dz * dsc;
+        if constexpr (sizeof(T) == 4) amx = sgv_amax_fold(amx, r);
+        return r;
     };
     if (vec_ok) {
         for (int i = p0 + threadIdx.x * N; i < p1; i += 256 * N) {
@@ -169,6 +180,7 @@ __global__ __launch_bounds__(256) void act_grad_scale_kernel(const T* __restrict
     } else {
         for (int i = p0 + threadIdx.x; i < p1; i += 256) sgv_traits<T>::store(op + i, one(sgv_traits<T>::load(gp + i), sgv_traits<T>::load(yp + i)));
     }
+    if constexpr (sizeof(T) == 4) { if (out_amax) sgv_amax_commit(amx, out_amax); }
     if (!sums) return;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgv += __shfl_xor(sgv, off, 64); }
@@ -228,6 +240,7 @@ extern "C" int sgv_act_grad_scale_t(const void* dy, const void* y, const float* 
     hipStream_t stream = (hipStream_t)stream_;
     sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * (double)es);
     const int vec_ok = (hw % (16 / (int)es) == 0) && (((uintptr_t)dy | (uintptr_t)y | (uintptr_t)out) % 16 == 0);
+    float* out_amax = dtype == SGV_F32 ? scope.take_amax_sink() : nullptr;
     // blockIdx.y is limited to 65535: the planes go in slabs (one launch up to 65,535 planes = 127 frames of a 512-channel layer; more than that -- the
     // Dmain phase as one pass over generated + real clips, larger per-GPU batches -- takes further launches on the following planes)
     for (int p0 = 0; p0 < planes; p0 += 65535) {
@@ -238,9 +251,9 @@ extern "C" int sgv_act_grad_scale_t(const void* dy, const void* y, const float* 
         const float* dp = d ? d + p0 : nullptr;
         float* sp = sums ? sums + p0 : nullptr;     // (the kernel's second row sits `planes` behind the first: the total, not the slab)
         dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)np);
-        if (dtype == SGV_F32) hipLaunchKernelGGL(act_grad_scale_kernel<float>, grid, dim3(256), 0, stream, (const float*)dyp, (const float*)yp, dp, (float*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok);
-        else if (dtype == SGV_F16) hipLaunchKernelGGL(act_grad_scale_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)dyp, (const sgv_half_t*)yp, dp, (sgv_half_t*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok);
-        else hipLaunchKernelGGL(act_grad_scale_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)dyp, (const sgv_bf16_t*)yp, dp, (sgv_bf16_t*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok);
+        if (dtype == SGV_F32) hipLaunchKernelGGL(act_grad_scale_kernel<float>, grid, dim3(256), 0, stream, (const float*)dyp, (const float*)yp, dp, (float*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok, out_amax);
+        else if (dtype == SGV_F16) hipLaunchKernelGGL(act_grad_scale_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)dyp, (const sgv_half_t*)yp, dp, (sgv_half_t*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok, nullptr);
+        else hipLaunchKernelGGL(act_grad_scale_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)dyp, (const sgv_bf16_t*)yp, dp, (sgv_bf16_t*)op, sp, planes, hw, act, alpha, gain, clamp, vec_ok, nullptr);
     }
     return sgv_check_launch("act_grad_scale_kernel");
 }
@@ -332,9 +345,9 @@ extern "C" int sgv_scale_channels(const void* x, const float* s, void* y, int32_
     const int total = n * c * hw;
     sgv_launch_scope scope(SGV_K_MODULATE, stream, 2.0 * total * es + (double)n * c * 4.0);
     switch (dtype) {
-        case SGV_F32: launch_scale<float>(x, s, y, total, hw, stream); break;
-        case SGV_F16: launch_scale<sgv_half_t>(x, s, y, total, hw, stream); break;
-        case SGV_BF16: launch_scale<sgv_bf16_t>(x, s, y, total, hw, stream); break;
+        case SGV_F32: launch_scale<float>(x, s, y, total, hw, stream, scope); break;
+        case SGV_F16: launch_scale<sgv_half_t>(x, s, y, total, hw, stream, scope); break;
+        case SGV_BF16: launch_scale<sgv_bf16_t>(x, s, y, total, hw, stream, scope); break;
         case SGV_F64: return sgv_fail(SGV_ERR_UNSUPPORTED, "scale_channels: fp64 not supported");
     }
     return sgv_check_launch("scale_channels_kernel");

@@ -61,6 +61,7 @@ struct pw_params {
     float alpha, gain, clamp;
     // many2few prologue (sgv_pointwise_small_gradin): x is a gradient dy and is turned into pw_act_grad(dy, yref) on its way in
     const void* yref;
+    float* y_amax;           // few2many with epilogue, fp32: max |y| as a by-product (sgv_amax_sink: fromRGB's output feeds a 3x3 convolution), or NULL
 };
 
 // MS == 1: grid = (ceil(hw/4/256), n), lane -> pixel quad, every lane walks all M planes.
@@ -130,36 +131,41 @@ template <typename T, int F, int EPI = 0>
 __global__ __launch_bounds__(256) void pw_few2many_kernel(pw_params p) {
     const int n = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q * 4 >= p.hw) return;
-    const T* x = (const T*)p.x + (size_t)n * F * p.hw + (size_t)q * 4;
-    const float* w = p.w + n * p.w_stride_n;   // [cm][F]
-    float v[F][4];
+    unsigned amx = 0u;
+    if (q * 4 < p.hw) {
+        const T* x = (const T*)p.x + (size_t)n * F * p.hw + (size_t)q * 4;
+        const float* w = p.w + n * p.w_stride_n;   // [cm][F]
+        float v[F][4];
 #pragma unroll
-    for (int f = 0; f < F; f++) load4<T>(x + (size_t)f * p.hw, v[f]);
-    T* y = (T*)p.y + (size_t)n * p.cm * p.hw + (size_t)q * 4;
-    const int mz0 = blockIdx.z * p.m_per_z, mz1 = min(p.cm, mz0 + p.m_per_z);
+        for (int f = 0; f < F; f++) load4<T>(x + (size_t)f * p.hw, v[f]);
+        T* y = (T*)p.y + (size_t)n * p.cm * p.hw + (size_t)q * 4;
+        const int mz0 = blockIdx.z * p.m_per_z, mz1 = min(p.cm, mz0 + p.m_per_z);
 #pragma unroll 4
-    for (int m = mz0; m < mz1; m++) {
-        float o[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int m = mz0; m < mz1; m++) {
+            float o[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int f = 0; f < F; f++) {
-            const float wf = w[m * F + f];
+            for (int f = 0; f < F; f++) {
+                const float wf = w[m * F + f];
 #pragma unroll
-            for (int i = 0; i < 4; i++) o[i] = __builtin_fmaf(v[f][i], wf, o[i]);
-        }
-        if (EPI) {
-            const float bm = p.bias ? p.bias[m] : 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                float t = o[i] + bm;
-                if (p.act == 3) t = (t > 0.f) ? t : t * p.alpha;
-                t *= p.gain;
-                if (p.clamp >= 0.f) t = (t > -p.clamp & t < p.clamp) ? t : (t >= 0.f) ? p.clamp : -p.clamp;
-                o[i] = t;
+                for (int i = 0; i < 4; i++) o[i] = __builtin_fmaf(v[f][i], wf, o[i]);
             }
+            if (EPI) {
+                const float bm = p.bias ? p.bias[m] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    float t = o[i] + bm;
+                    if (p.act == 3) t = (t > 0.f) ? t : t * p.alpha;
+                    t *= p.gain;
+                    if (p.clamp >= 0.f) t = (t > -p.clamp & t < p.clamp) ? t : (t >= 0.f) ? p.clamp : -p.clamp;
+                    o[i] = t;
+                    if constexpr (sizeof(T) == 4) amx = sgv_amax_fold(amx, t);
+                }
+            }
+            store4<T>(y + (size_t)m * p.hw, o);
         }
-        store4<T>(y + (size_t)m * p.hw, o);
     }
+    // every lane of the wave arrives here (lanes beyond the image carry 0): the wave reduction needs them all
+    if constexpr (EPI && sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
 }
 
 struct outer_params {
@@ -334,9 +340,10 @@ extern "C" int sgv_pointwise_act(const sgv_pointwise_params* p, const float* bia
     if (dtype != SGV_F32) return sgv_fail(SGV_ERR_UNSUPPORTED, "pointwise_act: fp32 only (a 16-bit composition rounds between the two steps)");
     if (act != 1 && act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "pointwise_act: act must be 1 (linear) or 3 (lrelu)");
     hipStream_t stream = (hipStream_t)stream_;
-    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, bias, act, alpha, gain, clamp, nullptr};
+    pw_params pp{p->x, p->w, p->y, p->n, p->c_many, p->c_few, p->hw, p->w_stride_n, p->c_many, bias, act, alpha, gain, clamp, nullptr, nullptr};
     const double bytes = (double)(p->c_many + p->c_few) * p->n * p->hw * 4.0;
     sgv_launch_scope scope(SGV_K_POINTWISE, stream, bytes, 2.0 * p->c_many * p->c_few * (double)p->n * p->hw);
+    pp.y_amax = scope.take_amax_sink();
     rc = launch_pw<float>(1, pp, stream);
     if (rc != SGV_OK) return rc;
     return sgv_check_launch("pointwise kernel");

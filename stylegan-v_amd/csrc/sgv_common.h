@@ -72,7 +72,20 @@ struct sgv_launch_scope {
     ~sgv_launch_scope();
     int slot;
     hipStream_t stream;
+    // The one-shot magnitude-bound side output armed by sgv_amax_sink() for THIS call (moved out of the thread's slot by the constructor, so that a call
+    // that cannot serve it leaves it unserved instead of handing it to a later one).  A launcher that supports it calls take_amax_sink(): the pointer
+    // (cleared to 0.0f on the stream, ready for the kernel's atomicMax of |output| bit patterns), or NULL when nothing was armed.
+    float* amax_sink;
+    float* take_amax_sink();
 };
+
+// |v| folded into a running maximum as an fp32 bit pattern; at kernel end one wave reduction and (only where it raises the value) one atomic per wave
+__device__ __forceinline__ unsigned sgv_amax_fold(unsigned m, float v) { return max(m, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
+__device__ __forceinline__ void sgv_amax_commit(unsigned m, float* sink) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load((unsigned*)sink, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned*)sink, m);
+}
 
 // Kernel variants (sgv_variant_count / sgv_variant_name of the public header): which member of a family a call took.
 #define SGV_VARIANTS(X) \

@@ -110,7 +110,27 @@ extern "C" int sgv_prof_collect_records(sgv_prof_record* out, int32_t max_record
     return n;
 }
 
-sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count) : slot(-1), stream(s) {
+static thread_local float* g_amax_sink = nullptr;     // armed by sgv_amax_sink(), moved into the next launch scope of this thread
+static thread_local int g_amax_consumed = 0;
+
+extern "C" int sgv_amax_sink(float* out) {
+    g_amax_sink = out;
+    g_amax_consumed = 0;
+    return SGV_OK;
+}
+extern "C" int sgv_amax_sink_consumed(void) { return g_amax_consumed; }
+
+float* sgv_launch_scope::take_amax_sink() {
+    float* p = amax_sink;
+    amax_sink = nullptr;
+    if (!p) return nullptr;
+    if (hipMemsetAsync(p, 0, 4, stream) != hipSuccess) return nullptr;
+    g_amax_consumed = 1;
+    return p;
+}
+
+sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count) : slot(-1), stream(s), amax_sink(g_amax_sink) {
+    g_amax_sink = nullptr;
     if (count) g_launches.fetch_add(1, std::memory_order_relaxed);
     if (!g_prof_on.load(std::memory_order_relaxed)) return;
     int i = g_prof_next.fetch_add(1);

@@ -939,6 +939,7 @@ struct tile_params {
     int ep_act;
     float ep_alpha, ep_gain, ep_clamp;
     int chans;
+    float* y_amax;          // fp32 tensors: max |y| as a by-product (sgv_amax_sink), or NULL
 };
 
 constexpr int TILE_ROWS = 16, TILE_IN_ROWS = TILE_ROWS + 3;
@@ -1093,6 +1094,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
         if (plane_ok && p.ep_bias) ep_bi = p.ep_bias[plane % p.chans];
     }
     float sum_g = 0.f;
+    unsigned amx = 0u;          // fp32 tensors: running max |stored value| (one VALU operation per output beside 16 multiply-adds; the pass is HBM-bound)
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int oy = oy0 + 4 * wave + k;
@@ -1149,6 +1151,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
                 if (v < CPL ? st_vec : st_xtra) sum_g += t;
             }
             o[v] = t;
+            if constexpr (sizeof(T) == 4) { if (v < CPL ? st_vec : st_xtra) amx = sgv_amax_fold(amx, t); }
         }
         T* yr = yp + (size_t)oy * p.out_w + ox;
         if (st_vec) { if (NT) store_vec_nt<T, CPL>(yr, o); else store_vec_plain<T, CPL>(yr, o); }
@@ -1160,6 +1163,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
             if (off < lpr) sum_g += __shfl_xor(sum_g, off, 64);
         if (sub == 0 && plane_ok && oy0 + 4 * wave < p.out_h) atomicAdd(p.ep_sum_g + plane, sum_g);
     }
+    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
 }
 
 typedef void (*lanes_fn)(lanes_params);
@@ -1408,8 +1412,9 @@ void launch_tile_t(const tile_params& tp, int xtra, int epi, int cpl, bool f44, 
     else { if (xtra) launch_tile_xe<T, 1, 3>(tp, cpl, f44, grid, lds, stream); else launch_tile_xe<T, 0, 3>(tp, cpl, f44, grid, lds, stream); }
 }
 
-int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dtype, int lpr_log2, int col_groups, int xtra, int cpl, hipStream_t stream) {
+int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dtype, int lpr_log2, int col_groups, int xtra, int cpl, hipStream_t stream, sgv_launch_scope& scope) {
     tile_params tp{};
+    tp.y_amax = dtype == SGV_F32 ? scope.take_amax_sink() : nullptr;
     tp.x = p->x; tp.f = p->f; tp.y = p->y; tp.flip = p->flip; tp.gain = p->gain;
     tp.in_w = p->in_w; tp.in_h = p->in_h; tp.out_w = p->out_w; tp.out_h = p->out_h; tp.planes = p->in_c * p->in_n;
     tp.f_w = p->f_w; tp.f_h = p->f_h; tp.f_sw = p->f_sw; tp.f_sh = p->f_sh;
@@ -1517,7 +1522,7 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
         int lpr_log2, col_groups, xtra, cpl;
         if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra, &cpl)) {   // every up = down = 1 FIR pass: the LDS-tile kernel
             sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
-            return launch_tile(p, nullptr, dtype, lpr_log2, col_groups, xtra, cpl, stream);
+            return launch_tile(p, nullptr, dtype, lpr_log2, col_groups, xtra, cpl, stream, scope);
         }
     }
     lanes_plan lplan;
@@ -1576,7 +1581,7 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
         int lpr_log2, col_groups, xtra, cpl;
         if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra, &cpl)) {
             sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, nin0 * es0 + (e->mode == 3 ? 2.0 * nout0 : nout0) * es0);
-            return launch_tile(p, e, dtype, lpr_log2, col_groups, xtra, cpl, stream);
+            return launch_tile(p, e, dtype, lpr_log2, col_groups, xtra, cpl, stream, scope);
         }
     }
     lanes_plan lplan;

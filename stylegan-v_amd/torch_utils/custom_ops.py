@@ -286,6 +286,8 @@ ABI_SYMBOLS = {
     'sgv_pointwise_outer_act': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int, c_void_p]),
     'sgv_pointwise_outer': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_absmax': (c_int, [c_void_p, c_int64, c_int, c_void_p, c_int32, c_void_p]),
+    'sgv_amax_sink': (c_int, [c_void_p]),
+    'sgv_amax_sink_consumed': (c_int, []),
     'sgv_conv3x3': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
     'sgv_conv3x3_s2': (c_int, [ctypes.POINTER(Conv3x3Params), c_int, c_void_p]),
     'sgv_conv3x3_fused': (c_int, [ctypes.POINTER(Conv3x3Params), ctypes.POINTER(Conv3x3Epilogue), c_int, c_void_p]),

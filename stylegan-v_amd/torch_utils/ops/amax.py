@@ -51,3 +51,29 @@ def invalidate(t):
             delattr(t, _ATTR)
         except AttributeError:
             pass
+
+
+def tracking():
+    """True while the convolution family multiplies block-scaled fp16 splits (terms = 4): producers then leave their output's bound behind."""
+    import sys
+    cg = sys.modules.get(__package__ + '.conv2d_gradfix')
+    return cg is not None and (cg.native_conv_terms == 4 or cg.native_wrw_terms == 4)
+
+
+def launch_tracking(out, call):
+    """Run `call()` -- exactly ONE sgv_* launch that writes the fp32 tensor `out` -- with the library's one-shot bound side output armed
+    (sgv_amax_sink): a kernel that supports it leaves max |out| behind for free and the bound is attached to `out`; any other kernel leaves the
+    tensor without one (the consumer then runs `bound`, one streaming pass).  Returns what `call` returns."""
+    if not (out.is_cuda and out.dtype == torch.float32 and tracking()):
+        return call()
+    lib = custom_ops.get_native()
+    buf = torch.empty([1], dtype=torch.float32, device=out.device)
+    lib.sgv_amax_sink(buf.data_ptr())
+    try:
+        rc = call()
+    finally:
+        taken = lib.sgv_amax_sink_consumed()
+        lib.sgv_amax_sink(None)
+    if taken:
+        attach(out, buf)
+    return rc

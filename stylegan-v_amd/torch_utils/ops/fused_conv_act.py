@@ -123,10 +123,10 @@ class _FusedConvBiasActFn(torch.autograd.Function):
         dzd = torch.empty_like(y)     # gradient w.r.t. the convolution result: bias_act gradient times dcoefs
         dt = _cg._DT[y.dtype]
         dy = dy.to(y.dtype)
-        with custom_ops.device_guard(dy):
-            custom_ops.check(lib.sgv_act_grad_scale_t(dy.data_ptr(), y.data_ptr(), d.data_ptr() if d is not None else None, dzd.data_ptr(),
-                                                      sums.data_ptr() if sums is not None else None, n * co, h * w,
-                                                      _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, dt, stream), lib)
+        with custom_ops.device_guard(dy):   # (dzd feeds two convolutions: the kernel leaves its magnitude bound behind, ops/amax.py)
+            custom_ops.check(_amax.launch_tracking(dzd, lambda: lib.sgv_act_grad_scale_t(
+                dy.data_ptr(), y.data_ptr(), d.data_ptr() if d is not None else None, dzd.data_ptr(), sums.data_ptr() if sums is not None else None, n * co, h * w,
+                _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, dt, stream)), lib)
         d_x = d_w = d_s = d_d = d_b = None
         if b is not None and ctx.needs_input_grad[4]:
             d_b = sums[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
@@ -250,7 +250,7 @@ class _FusedConvActFirFn(torch.autograd.Function):
         sums = torch.zeros([n * co], dtype=torch.float32, device=g.device)
         e = custom_ops.FirEpilogue(3, None, None, y0.data_ptr(), sums.data_ptr(), None, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
         with custom_ops.device_guard(g):
-            rc = lib.sgv_upfirdn2d_fused(_ffa._ufd_params(g, f, dz, bpads, True, 1.0), e, dt, custom_ops.raw_stream(g))
+            rc = _amax.launch_tracking(dz, lambda: lib.sgv_upfirdn2d_fused(_ffa._ufd_params(g, f, dz, bpads, True, 1.0), e, dt, custom_ops.raw_stream(g)))
         need_db = b is not None and ctx.needs_input_grad[2]
         d_x = d_w = d_b = None
         if rc == 0:
@@ -260,8 +260,9 @@ class _FusedConvActFirFn(torch.autograd.Function):
             gy = _ufd.upfirdn2d(g, f, padding=list(bpads), flip_filter=True)
             s2 = torch.zeros([2, n * co], dtype=torch.float32, device=g.device) if need_db else None
             with custom_ops.device_guard(g):
-                custom_ops.check(lib.sgv_act_grad_scale_t(gy.data_ptr(), y0.data_ptr(), None, dz.data_ptr(), s2.data_ptr() if s2 is not None else None, n * co, h * w,
-                                                          _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, dt, custom_ops.raw_stream(g)), lib)
+                custom_ops.check(_amax.launch_tracking(dz, lambda: lib.sgv_act_grad_scale_t(
+                    gy.data_ptr(), y0.data_ptr(), None, dz.data_ptr(), s2.data_ptr() if s2 is not None else None, n * co, h * w,
+                    _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, dt, custom_ops.raw_stream(g))), lib)
             if need_db:
                 d_b = s2[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
         else:

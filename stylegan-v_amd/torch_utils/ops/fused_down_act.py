@@ -100,8 +100,9 @@ class _FusedDownFn(torch.autograd.Function):
             dz = torch.empty_like(a)
             dy = dy.to(a.dtype)
             with custom_ops.device_guard(dy):
-                custom_ops.check(lib.sgv_act_grad_scale_t(dy.data_ptr(), a.data_ptr(), None, dz.data_ptr(), sums.data_ptr() if sums is not None else None, n * co, h * w,
-                                                          _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, _cg._DT[a.dtype], custom_ops.raw_stream(dy)), lib)
+                custom_ops.check(_amax.launch_tracking(dz, lambda: lib.sgv_act_grad_scale_t(
+                    dy.data_ptr(), a.data_ptr(), None, dz.data_ptr(), sums.data_ptr() if sums is not None else None, n * co, h * w,
+                    _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp, _cg._DT[a.dtype], custom_ops.raw_stream(dy))), lib)
             if need_db:
                 d_b = sums[0].reshape(n, co).sum(0).to(ctx.bias_dtype)
             wc = weight.contiguous()

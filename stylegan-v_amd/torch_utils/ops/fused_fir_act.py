@@ -76,7 +76,8 @@ class _FusedFirBiasActFn(torch.autograd.Function):
         e = custom_ops.FirEpilogue(1, sc.data_ptr() if sc is not None else None, bi.data_ptr() if bi is not None else None, None, None, None,
                                    _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
         with custom_ops.device_guard(x):
-            custom_ops.check(lib.sgv_upfirdn2d_fused(_ufd_params(x, f, y, pads, flip, fir_gain), e, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
+            from . import amax as _amax      # (y feeds the layer's next convolution: the kernel leaves its magnitude bound behind)
+            custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_upfirdn2d_fused(_ufd_params(x, f, y, pads, flip, fir_gain), e, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x))), lib)
         ctx.cfg = cfg
         ctx.x_shape = x.shape
         ctx.has_scale, ctx.has_bias = scale is not None, bias is not None

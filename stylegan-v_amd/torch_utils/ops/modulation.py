@@ -83,7 +83,8 @@ class _ScaleChannelsFn(torch.autograd.Function):
         y = torch.empty_like(xc)
         if xc.numel():
             with custom_ops.device_guard(xc):
-                custom_ops.check(lib.sgv_scale_channels(xc.data_ptr(), sc.data_ptr(), y.data_ptr(), n, c, hw, _DTYPE_CODES[xc.dtype], _stream(xc)), lib)
+                from . import amax as _amax
+                custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_scale_channels(xc.data_ptr(), sc.data_ptr(), y.data_ptr(), n, c, hw, _DTYPE_CODES[xc.dtype], _stream(xc))), lib)
         ctx.save_for_backward(x, s)
         return y
 

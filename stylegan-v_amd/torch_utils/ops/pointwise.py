@@ -112,8 +112,9 @@ class _PointwiseActFn(torch.autograd.Function):
         y = torch.empty([n, co, h, wd], dtype=torch.float32, device=xc.device)
         p = custom_ops.PointwiseParams(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), n, co, ci, h * wd, 0, 1)
         with custom_ops.device_guard(xc):
-            custom_ops.check(lib.sgv_pointwise_act(p, bc.data_ptr() if bc is not None else None, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp,
-                                                   _DTYPE_CODES[xc.dtype], custom_ops.raw_stream(xc)), lib)
+            from . import amax as _amax      # (fromRGB's output feeds a 3x3 convolution: the kernel leaves its magnitude bound behind)
+            custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_pointwise_act(p, bc.data_ptr() if bc is not None else None, _ba.activation_funcs[act].cuda_idx,
+                                                                                    alpha, gain, clamp, _DTYPE_CODES[xc.dtype], custom_ops.raw_stream(xc))), lib)
         ctx.cfg = cfg
         ctx.save_for_backward(x, w, b, y)
         return y

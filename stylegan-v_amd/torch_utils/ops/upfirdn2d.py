@@ -156,7 +156,8 @@ def _native_call(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain)
                                    int(bool(flip)), float(gain), w, h, c, n, xs[3], xs[2], xs[1], xs[0], fw, fh, fs[1], fs[0],
                                    ow, oh, ys[3], ys[2], ys[1], ys[0])
     with custom_ops.device_guard(x):
-        custom_ops.check(lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
+        from . import amax as _amax      # (a FIR output usually feeds a convolution: the LDS-tile kernel leaves its magnitude bound behind)
+        custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x))), lib)
     return y
 
 
