@@ -50,6 +50,7 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     const double bytes = 4.0 * ((double)p->m * p->k * (p->stride_a ? p->batch : 1) + (double)p->n * p->k * (p->stride_b ? p->batch : 1) +
                                 (double)p->m * p->n * p->batch);
     sgv_launch_scope scope(SGV_K_GEMM, stream, bytes, flops);
+    gp.c_amax = ks == 1 ? scope.take_amax_sink() : nullptr;      // (K slices are partial sums: no bound of the result there)
     dim3 grid((unsigned)(gp.tiles_m * gp.tiles_n), (unsigned)(p->batch * ks));
     // Fast path (tools/gemm_lab.hip, profiles/r01_gemm_lab.log): whole tiles, 16-B aligned rows -> no bounds/alignment branches in
     // the K loop; 1x1 convolutions run bk16 + double-buffered LDS at 2 workgroups/CU, x @ w.T runs bk32.

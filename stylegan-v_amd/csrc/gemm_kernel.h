@@ -11,6 +11,7 @@
 
 #include <hip/hip_runtime.h>
 #include "sgv_split.h"
+#include "sgv_common.h"
 #include <stdint.h>
 
 namespace sgv_gemm {
@@ -35,6 +36,7 @@ struct gemm_params {
     const float* residual; // added to the result before the store (same layout as c), or NULL
     const float* a_amax;   // TERMS = 4 (block-scaled fp16 split, sgv_split.h): device pointers to upper bounds of max |A| and max |B| (whole tensors)
     const float* b_amax;
+    float* c_amax;         // max |C| as a by-product of the store (sgv_amax_sink: a skip convolution's output is the next block's input), or NULL
 };
 
 // [128 rows x BK] block of a row-major [rows, K] matrix (k contiguous): thread t -> row t/4 (+64 per pass), k-quad t%4 (+4 per k-pass).
@@ -182,6 +184,7 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
     }
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+    unsigned amx = 0u;
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -205,8 +208,10 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
                 if (p.bias_mode == 2) v += p.bias[row];
                 if (RES) v += rv[e];
                 C[(int64_t)row * p.ldc + col] = v;
+                amx = sgv_amax_fold(amx, v);
             }
         }
+    if (p.c_amax) sgv_amax_commit(amx, p.c_amax);
 }
 
 
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
     }
 
     // Epilogue (as gemm_f32_kernel).  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
+    unsigned amx = 0u;
     const bool full_m = m0 + BM <= p.m;
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -384,8 +390,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
                 if (p.bias_mode == 2) v += p.bias[row];
                 if (RES) v += rv[e];
                 C[(int64_t)row * p.ldc + col] = v;
+                amx = sgv_amax_fold(amx, v);
             }
         }
+    if (p.c_amax) sgv_amax_commit(amx, p.c_amax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -475,7 +483,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params 
     };
 
     int tile = logical;
-    if (tile >= total_tiles) return;
+    if (tile >= total_tiles) return;      // (whole workgroups: every wave that continues is complete)
+    unsigned amx = 0u;
     tile_ctx ct = decode(tile);
     load_chunk(ct, 0);
     int cur = 0;
@@ -544,12 +553,14 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params 
                     if (p.bias_mode == 2) v += p.bias[row];
                     if (ct.RES) v += rv[e];
                     ct.C[(int64_t)row * p.ldc + col] = v;
+                    amx = sgv_amax_fold(amx, v);
                 }
             }
         if (!more) break;
         tile = next;
         ct = nt;
     }
+    if (p.c_amax) sgv_amax_commit(amx, p.c_amax);
 }
 
 

@@ -33,7 +33,12 @@ def _launch(a, b, bias, c, m, n, k, lda, ldb, ldc, trans_b, batch=1, sa=0, sb=0,
         from . import amax as _amax
         p.a_amax, p.b_amax = _amax.bound(a).data_ptr(), _amax.bound(b).data_ptr()
     with torch.cuda.device_of(c):
-        custom_ops.check(lib.sgv_gemm_f32(p, torch.cuda.current_stream(c.device).cuda_stream), lib)
+        from . import amax as _amax
+        stream = torch.cuda.current_stream(c.device).cuda_stream
+        if k_split == 1:      # the store knows the result: it leaves the magnitude bound of c behind (the next layer's convolutions need it)
+            custom_ops.check(_amax.launch_tracking(c, lambda: lib.sgv_gemm_f32(p, stream)), lib)
+        else:
+            custom_ops.check(lib.sgv_gemm_f32(p, stream), lib)
     return c
 
 
