@@ -301,6 +301,8 @@ typedef struct sgv_conv3x3_params {
     int32_t terms;         /* 1 bf16 products, 3 bf16 split (bf16x3), 4 block-scaled fp16 split (fp32-grade; see below) */
     const float* x_amax;   /* terms = 4: device pointer to ONE fp32 >= max |x| (sgv_absmax writes one); ignored otherwise */
     const float* x_amax2;  /* terms = 4, optional: a second factor of the bound (sgv_conv3x3_fused with x_scale: a bound of |x_scale|); NULL: 1 */
+    const float* w_amax;   /* terms = 4, optional: a bound of max |weight| the caller already has (a weight is bounded once per optimiser step, not once per
+                              launch); NULL: the library runs its own pass over the weight */
 } sgv_conv3x3_params;
 
 /*
@@ -325,7 +327,7 @@ int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream);
  */
 int sgv_absmax(const void* x, int64_t numel, int dtype, float* out, int32_t accumulate, void* stream);
 /* The same bound as a free by-product of the kernel that WRITES the tensor: sgv_amax_sink(out) arms a one-shot side output for the NEXT sgv_* call of
- * this thread; if that call's kernel supports it (the LDS-tile forms of sgv_upfirdn2d / sgv_upfirdn2d_fused modes 1 and 3, sgv_act_grad_scale[_t],
+ * this thread (out[0] must hold 0.0f, or a bound to extend, when that call's kernel runs); if that call's kernel supports it (the LDS-tile forms of sgv_upfirdn2d / sgv_upfirdn2d_fused modes 1 and 3, sgv_act_grad_scale[_t],
  * sgv_scale_channels, sgv_pointwise_act -- all on fp32 tensors) out[0] = max |output| after it, and sgv_amax_sink_consumed() returns 1; any other
  * call leaves `out` untouched, disarms the sink and sgv_amax_sink_consumed() returns 0 (the caller then runs sgv_absmax on the result).  Thread-local;
  * nothing else in the library is stateful. */

@@ -149,7 +149,7 @@ extern "C" int sgv_absmax(const void* x, int64_t numel, int dtype, float* out, i
     if (!accumulate && hipMemsetAsync(out, 0, 4, stream) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "absmax: hipMemsetAsync failed");
     if (numel == 0) return SGV_OK;
     const int64_t epv = dtype == SGV_F32 ? 4 : 8;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / epv + 1023) / 1024, 4096));     // four 16-byte vectors per lane and pass
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / epv + 2047) / 2048, 2048));     // >= eight 16-byte vectors per lane (four per pass)
     sgv_launch_scope scope(SGV_K_ABSMAX, stream, (double)numel * (dtype == SGV_F32 ? 4.0 : 2.0), 0.0, false);
     if (dtype == SGV_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (size_t)numel, (unsigned*)out);
     else if (dtype == SGV_F16) hipLaunchKernelGGL(absmax_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)x, (size_t)numel, (unsigned*)out);
@@ -201,11 +201,15 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     hipStream_t stream = (hipStream_t)stream_;
 
     const int words = tiles_m(p->c_out) * (p->c_in / KC) * 9 * 2 * TM;
-    float* w_amax = (float*)((char*)p->workspace + sgv_conv3x3_workspace_bytes(p->c_in, p->c_out) - AMAX_TAIL);
+    const float* w_amax = p->w_amax;          // the caller's bound of the weight, or our own pass into the workspace tail
     int rc = SGV_OK;
-    if (p->terms == 4 && (rc = weight_amax(p->weight, (size_t)p->c_in * p->c_out * 9, w_amax, stream)) != SGV_OK) return rc;
+    if (p->terms == 4 && !w_amax) {
+        float* slot = (float*)((char*)p->workspace + sgv_conv3x3_workspace_bytes(p->c_in, p->c_out) - AMAX_TAIL);
+        if ((rc = weight_amax(p->weight, (size_t)p->c_in * p->c_out * 9, slot, stream)) != SGV_OK) return rc;
+        w_amax = slot;
+    }
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
-                       p->terms, (const float*)w_amax);
+                       p->terms, w_amax);
     rc = sgv_check_launch("conv3x3_prep_weights");
     if (rc != SGV_OK) return rc;
 
@@ -317,17 +321,21 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         if (ep->bias && (((uintptr_t)ep->bias) & 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2_fused: bias must be 16-byte aligned");
     }
     int rc = SGV_OK;
-    float* w_amax = (float*)((char*)p->workspace + sgv_conv3x3_s2_workspace_bytes(p->n, p->c_in, p->c_out, p->h, p->w, p->mode) - AMAX_TAIL);
-    if (p->terms == 4 && (rc = weight_amax(p->weight, (size_t)p->c_in * p->c_out * 9, w_amax, stream)) != SGV_OK) return rc;
+    const float* w_amax = p->w_amax;
+    if (p->terms == 4 && !w_amax) {
+        float* slot = (float*)((char*)p->workspace + sgv_conv3x3_s2_workspace_bytes(p->n, p->c_in, p->c_out, p->h, p->w, p->mode) - AMAX_TAIL);
+        if ((rc = weight_amax(p->weight, (size_t)p->c_in * p->c_out * 9, slot, stream)) != SGV_OK) return rc;
+        w_amax = slot;
+    }
     if (pairs) {
         const int words = (p->c_out / P2_TM) * (p->c_in / P2_KC) * 10 * P2_TM;
         hipLaunchKernelGGL(conv3x3_prep_weights_pairs, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->terms,
-                           (const float*)w_amax);
+                           w_amax);
         rc = sgv_check_launch("conv3x3_prep_weights_pairs");
     } else {
         const int words = tiles_m(p->c_out) * (p->c_in / KC) * 9 * 2 * TM;
         hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
-                           p->terms, (const float*)w_amax);
+                           p->terms, w_amax);
         rc = sgv_check_launch("conv3x3_prep_weights");
     }
     if (rc != SGV_OK) return rc;

@@ -471,17 +471,13 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x
 
 
 // max |v| of a tensor as an fp32 bit pattern (non-negative floats order like unsigned integers); NaN / inf propagate as the largest patterns.
-// `out` must hold 0 (or a previous bound to extend) on entry.  A streaming read: every lane keeps four 16-byte loads in flight, the grid covers the
-// tensor once (up to 4096 workgroups, grid-stride beyond); one atomic per wave, and only where the wave's maximum exceeds what is already there.
-__device__ __forceinline__ void absmax_commit(unsigned m, unsigned* out) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
-}
-
+// `out` must hold 0 (or a previous bound to extend) on entry.  A streaming read: every lane keeps four 16-byte loads in flight, up to 2048 workgroups
+// walk the tensor grid-stride (long-lived waves: few commits); one no-return atomic per wave, and only where the wave's maximum exceeds what was there
+// when it started.
 template <typename T>
 __global__ __launch_bounds__(256) void absmax_kernel(const T* x, size_t n, unsigned* out) {
     unsigned m = 0u;
+    const unsigned seen = __builtin_nontemporal_load(out);   // what is there already, fetched with the first vectors (no dependent load at the wave's end)
     constexpr int EPV = 16 / sizeof(T);                       // elements per 16-byte vector
     const size_t head = min(n, (size_t)(((16 - ((uintptr_t)x & 15)) & 15) / sizeof(T)));   // elements in front of the first 16-byte boundary
     const u32x4* v = (const u32x4*)(x + head);
@@ -508,7 +504,9 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* x, size_t n, unsig
         const size_t k = threadIdx.x < head ? threadIdx.x : tail0 + (threadIdx.x - head);
         if (k < n && (threadIdx.x < head || k >= tail0)) m = max(m, __builtin_bit_cast(unsigned, (float)x[k]) & 0x7fffffffu);
     }
-    absmax_commit(m, out);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m > seen) atomicMax(out, m);
 }
 
 }  // namespace sgv_conv

@@ -74,17 +74,24 @@ struct sgv_launch_scope {
     hipStream_t stream;
     // The one-shot magnitude-bound side output armed by sgv_amax_sink() for THIS call (moved out of the thread's slot by the constructor, so that a call
     // that cannot serve it leaves it unserved instead of handing it to a later one).  A launcher that supports it calls take_amax_sink(): the pointer
-    // (cleared to 0.0f on the stream, ready for the kernel's atomicMax of |output| bit patterns), or NULL when nothing was armed.
+    // (it holds 0.0f -- or a bound to extend -- by the caller's contract: the kernel folds max |output| into it with atomicMax), or NULL when nothing was armed.
     float* amax_sink;
     float* take_amax_sink();
 };
 
-// |v| folded into a running maximum as an fp32 bit pattern; at kernel end one wave reduction and (only where it raises the value) one atomic per wave
+// |v| folded into a running maximum as an fp32 bit pattern.  Protocol of a kernel with a bound side output `sink` (may be NULL):
+//   const unsigned seen = sgv_amax_begin(sink);     at the START: the value already there, fetched while the kernel's own loads are in flight
+//   amx = sgv_amax_fold(amx, v);                    per stored value (one VALU operation)
+//   sgv_amax_commit(amx, sink, seen);               at the end, by EVERY lane of the wave: wave reduction, then ONE no-return atomic per wave -- and only
+//                                                   where the wave's maximum exceeds what it saw at its start (a dependent load here instead would add a
+//                                                   memory round trip to the life of every short-lived wave of a streaming kernel: measured -20..-40 %)
+// The sink must hold 0 (or a bound to extend) when the kernel starts.
+__device__ __forceinline__ unsigned sgv_amax_begin(const float* sink) { return sink ? __builtin_nontemporal_load((const unsigned*)sink) : 0xffffffffu; }
 __device__ __forceinline__ unsigned sgv_amax_fold(unsigned m, float v) { return max(m, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
-__device__ __forceinline__ void sgv_amax_commit(unsigned m, float* sink) {
+__device__ __forceinline__ void sgv_amax_commit(unsigned m, float* sink, unsigned seen) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m > __hip_atomic_load((unsigned*)sink, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned*)sink, m);
+    if ((threadIdx.x & 63) == 0 && m > seen) atomicMax((unsigned*)sink, m);
 }
 
 // Kernel variants (sgv_variant_count / sgv_variant_name of the public header): which member of a family a call took.

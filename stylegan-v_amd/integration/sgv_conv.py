@@ -21,7 +21,7 @@ _i32, _i64, _vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p
 
 class _Conv(ctypes.Structure):   # struct sgv_conv3x3_params
     _fields_ = [('x', _vp), ('weight', _vp), ('y', _vp), ('workspace', _vp), ('workspace_bytes', _i64)] + \
-               [(k, _i32) for k in ('n', 'c_in', 'c_out', 'h', 'w', 'mode', 'terms')] + [('x_amax', _vp), ('x_amax2', _vp)]
+               [(k, _i32) for k in ('n', 'c_in', 'c_out', 'h', 'w', 'mode', 'terms')] + [('x_amax', _vp), ('x_amax2', _vp), ('w_amax', _vp)]
 
 
 class _Wrw(ctypes.Structure):    # struct sgv_conv_wrw_params
@@ -88,7 +88,7 @@ def conv3x3(x, w, transposed, stride, terms=4):
         nbytes, fn = lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, ws, mode), lib.sgv_conv3x3_s2
     scratch = torch.empty([nbytes], dtype=torch.uint8, device=x.device)
     bx = _bound(x) if terms == 4 else None
-    _run(fn, _Conv(x.data_ptr(), w.data_ptr(), y.data_ptr(), scratch.data_ptr(), nbytes, n, ci, co, hs, ws, mode, terms, bx.data_ptr() if bx is not None else None, None), x)
+    _run(fn, _Conv(x.data_ptr(), w.data_ptr(), y.data_ptr(), scratch.data_ptr(), nbytes, n, ci, co, hs, ws, mode, terms, bx.data_ptr() if bx is not None else None, None, None), x)
     return y
 
 

@@ -219,7 +219,7 @@ class ConvWrwParams(ctypes.Structure):
 
 class Conv3x3Params(ctypes.Structure):
     _fields_ = [('x', c_void_p), ('weight', c_void_p), ('y', c_void_p), ('workspace', c_void_p), ('workspace_bytes', c_int64), ('n', c_int32), ('c_in', c_int32),
-                ('c_out', c_int32), ('h', c_int32), ('w', c_int32), ('mode', c_int32), ('terms', c_int32), ('x_amax', c_void_p), ('x_amax2', c_void_p)]
+                ('c_out', c_int32), ('h', c_int32), ('w', c_int32), ('mode', c_int32), ('terms', c_int32), ('x_amax', c_void_p), ('x_amax2', c_void_p), ('w_amax', c_void_p)]
 
 
 class Conv3x3Epilogue(ctypes.Structure):

@@ -20,6 +20,24 @@ _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 _ATTR = '_sgv_amax'
 
 
+_ARENA = 4096
+_arenas = {}       # device index -> [zeroed fp32 tensor, slots handed out]
+
+
+def zero_slot(device):
+    """A 1-element fp32 device tensor that holds 0.0f: what the bound kernels fold max |v| into (atomicMax of the bit pattern).  Slots are carved from a
+    zeroed arena -- one fill launch per 4,096 bounds instead of one clearing command per bound (~600 per training step) -- and never handed out twice;
+    a view keeps its arena alive.  While a hipGraph is being captured every slot is its own `zeros` (the fill is then a node of THAT graph, so every
+    replay starts from zero; an arena cleared outside the graph would only ever grow)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros([1], dtype=torch.float32, device=device)
+    a = _arenas.get(device.index)
+    if a is None or a[1] >= _ARENA:
+        a = _arenas[device.index] = [torch.zeros([_ARENA], dtype=torch.float32, device=device), 0]
+    a[1] += 1
+    return a[0][a[1] - 1:a[1]]
+
+
 def bound(t):
     """[1] fp32 device tensor >= max |t| for a dense CUDA tensor t (fp32 / fp16 / bf16)."""
     cached = getattr(t, _ATTR, None)
@@ -27,10 +45,10 @@ def bound(t):
         return cached[2]
     assert t.is_cuda and t.dtype in _DT
     tc = t if t.is_contiguous() else t.contiguous()
-    out = torch.empty([1], dtype=torch.float32, device=t.device)
+    out = zero_slot(t.device)
     lib = custom_ops.get_native()
     with custom_ops.device_guard(tc):
-        custom_ops.check(lib.sgv_absmax(tc.data_ptr(), tc.numel(), _DT[t.dtype], out.data_ptr(), 0, custom_ops.raw_stream(tc)), lib)
+        custom_ops.check(lib.sgv_absmax(tc.data_ptr(), tc.numel(), _DT[t.dtype], out.data_ptr(), 1, custom_ops.raw_stream(tc)), lib)
     attach(t, out)
     return out
 
@@ -67,7 +85,7 @@ def launch_tracking(out, call):
     if not (out.is_cuda and out.dtype == torch.float32 and tracking()):
         return call()
     lib = custom_ops.get_native()
-    buf = torch.empty([1], dtype=torch.float32, device=out.device)
+    buf = zero_slot(out.device)
     lib.sgv_amax_sink(buf.data_ptr())
     try:
         rc = call()

@@ -191,7 +191,7 @@ def _native_conv(x, w, cfg):
         ws_bytes = int(lib.sgv_conv3x3_workspace_bytes(ci, co))
         ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
         p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, wd, 1 if transposed else 0, terms,
-                                     _amax.bound(xc).data_ptr() if terms == 4 else None, None)
+                                     _amax.bound(xc).data_ptr() if terms == 4 else None, None, _amax.bound(wc).data_ptr() if terms == 4 else None)
         fn = lib.sgv_conv3x3
     else:
         hs, wsm = (h, wd) if transposed else ((h - 1) // 2, (wd - 1) // 2)   # the small grid
@@ -200,7 +200,7 @@ def _native_conv(x, w, cfg):
         ws_bytes = int(lib.sgv_conv3x3_s2_workspace_bytes(n, ci, co, hs, wsm, mode))
         ws = torch.empty([ws_bytes], dtype=torch.uint8, device=x.device)
         p = custom_ops.Conv3x3Params(xc.data_ptr(), wc.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, hs, wsm, mode, terms,
-                                     _amax.bound(xc).data_ptr() if terms == 4 else None, None)
+                                     _amax.bound(xc).data_ptr() if terms == 4 else None, None, _amax.bound(wc).data_ptr() if terms == 4 else None)
         fn = lib.sgv_conv3x3_s2
     with custom_ops.device_guard(xc):
         custom_ops.check(fn(p, dt, custom_ops.raw_stream(xc)), lib)

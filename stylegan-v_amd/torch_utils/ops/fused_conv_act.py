@@ -75,7 +75,8 @@ def _launch_fused(x, weight, styles, dcoefs, bias, act_idx, alpha, gain, clamp, 
     terms = _cg.native_conv_terms if dt == 0 else 1
     # terms = 4: the operand is x * styles, bounded by the product of the two tensors' bounds (csrc/sgv_split.h)
     p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, mode, terms,
-                                 _amax.bound(x).data_ptr() if terms == 4 else None, _amax.bound(styles).data_ptr() if (terms == 4 and styles is not None) else None)
+                                 _amax.bound(x).data_ptr() if terms == 4 else None, _amax.bound(styles).data_ptr() if (terms == 4 and styles is not None) else None,
+                                 _amax.bound(weight).data_ptr() if terms == 4 else None)
     if accumulate_into is not None:
         _amax.invalidate(accumulate_into)      # written through its raw pointer below
     e = custom_ops.Conv3x3Epilogue(styles.data_ptr() if styles is not None else None, dcoefs.data_ptr() if dcoefs is not None else None,

@@ -50,7 +50,7 @@ def _launch(xb, weight, bias, residual, want_act, act_idx, alpha, gain, clamp):
     wsp = torch.empty([wsb], dtype=torch.uint8, device=xb.device)
     terms = _cg.native_conv_terms if dt == 0 else 1
     p = custom_ops.Conv3x3Params(xb.data_ptr(), weight.data_ptr(), y.data_ptr(), wsp.data_ptr(), wsb, n, ci, co, hs, ws_, 0, terms,
-                                 _amax.bound(xb).data_ptr() if terms == 4 else None, None)
+                                 _amax.bound(xb).data_ptr() if terms == 4 else None, None, _amax.bound(weight).data_ptr() if terms == 4 else None)
     if residual is not None:
         _amax.invalidate(residual)      # updated in place through its raw pointer
     e = custom_ops.Conv3x3S2Epilogue(bias.data_ptr() if bias is not None else None, a.data_ptr() if a is not None else None, act_idx, alpha, gain, clamp,

@@ -65,7 +65,7 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(custom_ops.ProfEntry) == 32
     assert ctypes.sizeof(custom_ops.PointwiseParams) == 56
     assert ctypes.sizeof(custom_ops.ConvWrwParams) == 72
-    assert ctypes.sizeof(custom_ops.Conv3x3Params) == 88
+    assert ctypes.sizeof(custom_ops.Conv3x3Params) == 96
 
 
 def test_convolution_family_shape_rules_and_validation_without_gpu():

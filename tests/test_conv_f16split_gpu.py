@@ -46,7 +46,8 @@ def test_absmax_is_the_maximum_magnitude(dtype):
         for t in (base[:-1], base[1:]):                    # 16-byte aligned start, and a view that is not
             out = torch.full([1], 123.0, device=DEV)
             custom_ops.check(lib.sgv_absmax(t.data_ptr(), t.numel(), code, out.data_ptr(), 0, custom_ops.raw_stream(t)), lib)
-            assert out.item() == t.float().abs().max().item(), (numel, dtype)
+            want = t.float().abs().max().item()
+            assert out.item() == want, (numel, dtype, t.data_ptr() % 16, out.item(), want, int(t.float().abs().argmax()))
     # accumulate keeps a larger previous bound; an empty tensor leaves zero; inf / NaN come out as non-finite bounds
     t = torch.randn([1000], generator=g).to(dtype).to(DEV)
     out = torch.full([1], 77.0, device=DEV)
