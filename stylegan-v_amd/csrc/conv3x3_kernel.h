@@ -474,25 +474,26 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x
 // `out` must hold 0 (or a previous bound to extend) on entry.  A streaming read: every lane keeps four 16-byte loads in flight, up to 2048 workgroups
 // walk the tensor grid-stride (long-lived waves: few commits); one no-return atomic per wave, and only where the wave's maximum exceeds what was there
 // when it started.
+// largest |element| of one dword of a tensor of T, as an fp32 bit pattern
+template <typename T> __device__ __forceinline__ unsigned absmax_word(unsigned w);
+template <> __device__ __forceinline__ unsigned absmax_word<float>(unsigned w) { return w & 0x7fffffffu; }
+template <> __device__ __forceinline__ unsigned absmax_word<__bf16>(unsigned w) { return max((w << 16) & 0x7fffffffu, w & 0x7fff0000u); }   // a bf16 IS the upper half of the fp32 pattern
+template <> __device__ __forceinline__ unsigned absmax_word<_Float16>(unsigned w) {
+    const f16x2 hh = __builtin_bit_cast(f16x2, w);
+    return max(__builtin_bit_cast(unsigned, (float)hh[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, (float)hh[1]) & 0x7fffffffu);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void absmax_kernel(const T* x, size_t n, unsigned* out) {
     unsigned m = 0u;
-    const unsigned seen = __builtin_nontemporal_load(out);   // what is there already, fetched with the first vectors (no dependent load at the wave's end)
+    // what is there already, fetched with the first vectors (no dependent load at the wave's end) and past the CU's L1 (a stale zero from an earlier
+    // wave's line would make every wave issue its atomic: measured 10x slower)
+    const unsigned seen = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int EPV = 16 / sizeof(T);                       // elements per 16-byte vector
     const size_t head = min(n, (size_t)(((16 - ((uintptr_t)x & 15)) & 15) / sizeof(T)));   // elements in front of the first 16-byte boundary
     const u32x4* v = (const u32x4*)(x + head);
     const size_t nv = (n - head) / EPV;
-    auto fold = [&](u32x4 w) {
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            if constexpr (sizeof(T) == 4) m = max(m, w[j] & 0x7fffffffu);
-            else if constexpr (std::is_same<T, __bf16>::value) m = max(m, max((w[j] << 16) & 0x7fffffffu, w[j] & 0x7fff0000u));   // a bf16 IS the upper half of the fp32 pattern
-            else {
-                const f16x2 hh = __builtin_bit_cast(f16x2, w[j]);
-                m = max(m, max(__builtin_bit_cast(unsigned, (float)hh[0]) & 0x7fffffffu, __builtin_bit_cast(unsigned, (float)hh[1]) & 0x7fffffffu));
-            }
-        }
-    };
+    auto fold = [&](u32x4 w) { m = max(max(m, absmax_word<T>(w[0])), max(max(absmax_word<T>(w[1]), absmax_word<T>(w[2])), absmax_word<T>(w[3]))); };
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nv; i += 4 * stride) {
         const bool k1 = i + stride < nv, k2 = i + 2 * stride < nv, k3 = i + 3 * stride < nv;

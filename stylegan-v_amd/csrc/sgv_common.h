@@ -86,7 +86,11 @@ struct sgv_launch_scope {
 //                                                   where the wave's maximum exceeds what it saw at its start (a dependent load here instead would add a
 //                                                   memory round trip to the life of every short-lived wave of a streaming kernel: measured -20..-40 %)
 // The sink must hold 0 (or a bound to extend) when the kernel starts.
-__device__ __forceinline__ unsigned sgv_amax_begin(const float* sink) { return sink ? __builtin_nontemporal_load((const unsigned*)sink) : 0xffffffffu; }
+// (an AGENT-scope load goes past the CU's L1: a line cached there by an earlier wave would stay at the initial zero for the whole kernel, every wave would
+//  then issue its atomic, and ~10^5 atomics on one address serialise in L2 -- measured 10x on the streaming kernels)
+__device__ __forceinline__ unsigned sgv_amax_begin(const float* sink) {
+    return sink ? __hip_atomic_load((const unsigned*)sink, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
+}
 __device__ __forceinline__ unsigned sgv_amax_fold(unsigned m, float v) { return max(m, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
 __device__ __forceinline__ void sgv_amax_commit(unsigned m, float* sink, unsigned seen) {
 #pragma unroll
