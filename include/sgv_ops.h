@@ -327,10 +327,13 @@ int sgv_conv3x3_s2(const sgv_conv3x3_params* p, int dtype, void* stream);
  */
 int sgv_absmax(const void* x, int64_t numel, int dtype, float* out, int32_t accumulate, void* stream);
 /* The same bound as a free by-product of the kernel that WRITES the tensor: sgv_amax_sink(out) arms a one-shot side output for the NEXT sgv_* call of
- * this thread (out[0] must hold 0.0f, or a bound to extend, when that call's kernel runs); if that call's kernel supports it (the LDS-tile forms of sgv_upfirdn2d / sgv_upfirdn2d_fused modes 1 and 3, sgv_act_grad_scale[_t],
+ * this thread.  `out` is a block of 1 + SGV_AMAX_SINK_SLOTS floats that must hold zeros when that call's kernels run: the producer's waves fold their
+ * maxima into the slots behind out[0] (spread, so that ~10^6 short-lived waves do not queue on one address), a one-workgroup kernel launched by the
+ * same call folds the slots into out[0].  If that call's kernel supports it (the LDS-tile forms of sgv_upfirdn2d / sgv_upfirdn2d_fused modes 1 and 3, sgv_act_grad_scale[_t],
  * sgv_scale_channels, sgv_pointwise_act -- all on fp32 tensors) out[0] = max |output| after it, and sgv_amax_sink_consumed() returns 1; any other
  * call leaves `out` untouched, disarms the sink and sgv_amax_sink_consumed() returns 0 (the caller then runs sgv_absmax on the result).  Thread-local;
  * nothing else in the library is stateful. */
+#define SGV_AMAX_SINK_SLOTS 4096
 int sgv_amax_sink(float* out);
 int sgv_amax_sink_consumed(void);
 

@@ -149,7 +149,7 @@ extern "C" int sgv_absmax(const void* x, int64_t numel, int dtype, float* out, i
     if (!accumulate && hipMemsetAsync(out, 0, 4, stream) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "absmax: hipMemsetAsync failed");
     if (numel == 0) return SGV_OK;
     const int64_t epv = dtype == SGV_F32 ? 4 : 8;
-    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / epv + 2047) / 2048, 2048));     // >= eight 16-byte vectors per lane (four per pass)
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>((numel / epv + 1023) / 1024, 1024));     // four 16-byte vectors per lane and pass; <= 1024 workgroups (four per CU)
     sgv_launch_scope scope(SGV_K_ABSMAX, stream, (double)numel * (dtype == SGV_F32 ? 4.0 : 2.0), 0.0, false);
     if (dtype == SGV_F32) hipLaunchKernelGGL(absmax_kernel<float>, dim3(blocks), dim3(256), 0, stream, (const float*)x, (size_t)numel, (unsigned*)out);
     else if (dtype == SGV_F16) hipLaunchKernelGGL(absmax_kernel<_Float16>, dim3(blocks), dim3(256), 0, stream, (const _Float16*)x, (size_t)numel, (unsigned*)out);

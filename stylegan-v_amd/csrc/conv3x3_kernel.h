@@ -471,9 +471,8 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x
 
 
 // max |v| of a tensor as an fp32 bit pattern (non-negative floats order like unsigned integers); NaN / inf propagate as the largest patterns.
-// `out` must hold 0 (or a previous bound to extend) on entry.  A streaming read: every lane keeps four 16-byte loads in flight, up to 2048 workgroups
-// walk the tensor grid-stride (long-lived waves: few commits); one no-return atomic per wave, and only where the wave's maximum exceeds what was there
-// when it started.
+// `out` must hold 0 (or a previous bound to extend) on entry.  A streaming read: every lane keeps four 16-byte loads in flight, up to 1024 workgroups
+// walk the tensor grid-stride; one no-return atomic per workgroup.
 // largest |element| of one dword of a tensor of T, as an fp32 bit pattern
 template <typename T> __device__ __forceinline__ unsigned absmax_word(unsigned w);
 template <> __device__ __forceinline__ unsigned absmax_word<float>(unsigned w) { return w & 0x7fffffffu; }
@@ -486,9 +485,6 @@ template <> __device__ __forceinline__ unsigned absmax_word<_Float16>(unsigned w
 template <typename T>
 __global__ __launch_bounds__(256) void absmax_kernel(const T* x, size_t n, unsigned* out) {
     unsigned m = 0u;
-    // what is there already, fetched with the first vectors (no dependent load at the wave's end) and past the CU's L1 (a stale zero from an earlier
-    // wave's line would make every wave issue its atomic: measured 10x slower)
-    const unsigned seen = __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     constexpr int EPV = 16 / sizeof(T);                       // elements per 16-byte vector
     const size_t head = min(n, (size_t)(((16 - ((uintptr_t)x & 15)) & 15) / sizeof(T)));   // elements in front of the first 16-byte boundary
     const u32x4* v = (const u32x4*)(x + head);
@@ -507,7 +503,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const T* x, size_t n, unsig
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m > seen) atomicMax(out, m);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(part[0], part[1]), max(part[2], part[3]));
+        if (m) atomicMax(out, m);          // one no-return atomic per workgroup: <= 1024 per launch
+    }
 }
 
 }  // namespace sgv_conv

@@ -185,7 +185,6 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
 
     // Epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
     unsigned amx = 0u;
-    const unsigned seen = sgv_amax_begin(p.c_amax);
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -212,7 +211,7 @@ __global__ __launch_bounds__(256, MINWG) void gemm_f32_kernel(gemm_params p) {
                 amx = sgv_amax_fold(amx, v);
             }
         }
-    if (p.c_amax) sgv_amax_commit(amx, p.c_amax, seen);
+    if (p.c_amax) sgv_amax_commit(amx, p.c_amax);
 }
 
 
@@ -370,7 +369,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
 
     // Epilogue (as gemm_f32_kernel).  C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5).
     unsigned amx = 0u;
-    const unsigned seen = sgv_amax_begin(p.c_amax);
     const bool full_m = m0 + BM <= p.m;
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -395,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(gemm_params p) {
                 amx = sgv_amax_fold(amx, v);
             }
         }
-    if (p.c_amax) sgv_amax_commit(amx, p.c_amax, seen);
+    if (p.c_amax) sgv_amax_commit(amx, p.c_amax);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------------
@@ -487,7 +485,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params 
     int tile = logical;
     if (tile >= total_tiles) return;      // (whole workgroups: every wave that continues is complete)
     unsigned amx = 0u;
-    const unsigned seen = sgv_amax_begin(p.c_amax);
     tile_ctx ct = decode(tile);
     load_chunk(ct, 0);
     int cur = 0;
@@ -563,7 +560,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params 
         tile = next;
         ct = nt;
     }
-    if (p.c_amax) sgv_amax_commit(amx, p.c_amax, seen);
+    if (p.c_amax) sgv_amax_commit(amx, p.c_amax);
 }
 
 

@@ -67,7 +67,6 @@ __global__ __launch_bounds__(256) void scale_channels_vec_kernel(const T* __rest
     const vec16<T>* xv = (const vec16<T>*)x;
     vec16<T>* yv = (vec16<T>*)y;
     unsigned amx = 0u;
-    const unsigned seen = sgv_amax_begin(y_amax);
     for (int vi = blockIdx.x * blockDim.x + threadIdx.x; vi < nvec; vi += gridDim.x * blockDim.x) {
         const float sc = s[(vi * N) / hw];
         vec16<T> v = xv[vi], o;
@@ -79,7 +78,7 @@ __global__ __launch_bounds__(256) void scale_channels_vec_kernel(const T* __rest
         }
         yv[vi] = o;
     }
-    if constexpr (sizeof(T) == 4) { if (y_amax) sgv_amax_commit(amx, y_amax, seen); }
+    if constexpr (sizeof(T) == 4) { if (y_amax) sgv_amax_commit(amx, y_amax); }
 }
 
 template <typename T>
@@ -160,7 +159,6 @@ __global__ __launch_bounds__(256) void act_grad_scale_kernel(const T* __restrict
     const float dsc = d ? d[plane] : 1.f;
     float sg = 0.f, sgv = 0.f;
     unsigned amx = 0u;      // fp32 tensors: max |out| as a by-product (out_amax, sgv_amax_sink)
-    const unsigned seen = sgv_amax_begin(out_amax);
     auto one = [&](float g, float yy) {
         float dz = ((act == 3 && !(yy > 0.f)) ? g * alpha : g) * gain;
         float gv = g * yy;
@@ -182,7 +180,7 @@ __global__ __launch_bounds__(256) void act_grad_scale_kernel(const T* __restrict
     } else {
         for (int i = p0 + threadIdx.x; i < p1; i += 256) sgv_traits<T>::store(op + i, one(sgv_traits<T>::load(gp + i), sgv_traits<T>::load(yp + i)));
     }
-    if constexpr (sizeof(T) == 4) { if (out_amax) sgv_amax_commit(amx, out_amax, seen); }
+    if constexpr (sizeof(T) == 4) { if (out_amax) sgv_amax_commit(amx, out_amax); }
     if (!sums) return;
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { sg += __shfl_xor(sg, off, 64); sgv += __shfl_xor(sgv, off, 64); }

@@ -132,7 +132,6 @@ __global__ __launch_bounds__(256) void pw_few2many_kernel(pw_params p) {
     const int n = blockIdx.y;
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned amx = 0u;
-    const unsigned seen = sgv_amax_begin(EPI ? p.y_amax : nullptr);
     if (q * 4 < p.hw) {
         const T* x = (const T*)p.x + (size_t)n * F * p.hw + (size_t)q * 4;
         const float* w = p.w + n * p.w_stride_n;   // [cm][F]
@@ -166,7 +165,7 @@ __global__ __launch_bounds__(256) void pw_few2many_kernel(pw_params p) {
         }
     }
     // every lane of the wave arrives here (lanes beyond the image carry 0): the wave reduction needs them all
-    if constexpr (EPI && sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax, seen); }
+    if constexpr (EPI && sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
 }
 
 struct outer_params {

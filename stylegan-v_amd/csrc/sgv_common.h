@@ -76,26 +76,27 @@ struct sgv_launch_scope {
     // that cannot serve it leaves it unserved instead of handing it to a later one).  A launcher that supports it calls take_amax_sink(): the pointer
     // (it holds 0.0f -- or a bound to extend -- by the caller's contract: the kernel folds max |output| into it with atomicMax), or NULL when nothing was armed.
     float* amax_sink;
+    float* amax_taken;      // the sink a kernel of this call writes its partial maxima to: the destructor folds them into [0]
     float* take_amax_sink();
 };
 
 // |v| folded into a running maximum as an fp32 bit pattern.  Protocol of a kernel with a bound side output `sink` (may be NULL):
-//   const unsigned seen = sgv_amax_begin(sink);     at the START: the value already there, fetched while the kernel's own loads are in flight
-//   amx = sgv_amax_fold(amx, v);                    per stored value (one VALU operation)
-//   sgv_amax_commit(amx, sink, seen);               at the end, by EVERY lane of the wave: wave reduction, then ONE no-return atomic per wave -- and only
-//                                                   where the wave's maximum exceeds what it saw at its start (a dependent load here instead would add a
-//                                                   memory round trip to the life of every short-lived wave of a streaming kernel: measured -20..-40 %)
-// The sink must hold 0 (or a bound to extend) when the kernel starts.
-// (an AGENT-scope load goes past the CU's L1: a line cached there by an earlier wave would stay at the initial zero for the whole kernel, every wave would
-//  then issue its atomic, and ~10^5 atomics on one address serialise in L2 -- measured 10x on the streaming kernels)
-__device__ __forceinline__ unsigned sgv_amax_begin(const float* sink) {
-    return sink ? __hip_atomic_load((const unsigned*)sink, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
-}
+//   amx = sgv_amax_fold(amx, v);        per stored value (one VALU operation)
+//   sgv_amax_commit(amx, sink);         at the end, by EVERY lane of the wave: wave reduction, then ONE no-return atomic per wave into one of
+//                                       SGV_AMAX_SLOTS partial slots behind sink[0] (sink[1 + wave id % SLOTS]).
+// A streaming kernel with one 16-byte vector per lane has ~10^6 waves per launch: with a single target address -- even behind a "read it first, add only
+// if larger" filter -- those requests queue on ONE L2 channel and cost the kernel 40-70 % (measured, profiles/r04 call 2 / 4); spread over 4,096 slots
+// (128 cache lines) they disappear in the kernel's own traffic.  The launch scope (sgv_launch_scope) folds the slots into sink[0] with a one-workgroup
+// kernel behind the producer.  The sink block (1 + SGV_AMAX_SLOTS floats) must hold zeros when the producer starts.
+constexpr int SGV_AMAX_SLOTS = 4096;
 __device__ __forceinline__ unsigned sgv_amax_fold(unsigned m, float v) { return max(m, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); }
-__device__ __forceinline__ void sgv_amax_commit(unsigned m, float* sink, unsigned seen) {
+__device__ __forceinline__ void sgv_amax_commit(unsigned m, float* sink) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    if ((threadIdx.x & 63) == 0 && m > seen) atomicMax((unsigned*)sink, m);
+    if ((threadIdx.x & 63) == 0 && m) {
+        const unsigned wid = ((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        atomicMax((unsigned*)sink + 1 + (wid & (SGV_AMAX_SLOTS - 1)), m);
+    }
 }
 
 // Kernel variants (sgv_variant_count / sgv_variant_name of the public header): which member of a family a call took.

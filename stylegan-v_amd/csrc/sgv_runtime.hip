@@ -125,10 +125,21 @@ float* sgv_launch_scope::take_amax_sink() {
     amax_sink = nullptr;
     if (!p) return nullptr;
     g_amax_consumed = 1;
+    amax_taken = p;
     return p;
 }
 
-sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count) : slot(-1), stream(s), amax_sink(g_amax_sink) {
+// sink[0] = max(sink[0], sink[1 .. SGV_AMAX_SLOTS]): one workgroup, behind the producing kernel on its stream
+__global__ __launch_bounds__(256) void sgv_amax_reduce_kernel(unsigned* sink) {
+    unsigned m = 0u;
+#pragma unroll
+    for (int i = 0; i < SGV_AMAX_SLOTS / 256; i++) m = max(m, sink[1 + i * 256 + threadIdx.x]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(sink, m);
+}
+
+sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count) : slot(-1), stream(s), amax_sink(g_amax_sink), amax_taken(nullptr) {
     g_amax_sink = nullptr;
     if (count) g_launches.fetch_add(1, std::memory_order_relaxed);
     if (!g_prof_on.load(std::memory_order_relaxed)) return;
@@ -145,5 +156,6 @@ sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, doub
 }
 
 sgv_launch_scope::~sgv_launch_scope() {
+    if (amax_taken) hipLaunchKernelGGL(sgv_amax_reduce_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)amax_taken);   // (inside the call's event bracket)
     if (slot >= 0) { (void)hipEventRecord(g_prof_pool[slot].stop, stream); g_scope_slot = -1; }
 }

@@ -1095,7 +1095,6 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     }
     float sum_g = 0.f;
     unsigned amx = 0u;          // fp32 tensors: running max |stored value| (one VALU operation per output beside 16 multiply-adds; the pass is HBM-bound)
-    const unsigned seen = sgv_amax_begin(sizeof(T) == 4 ? p.y_amax : nullptr);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int oy = oy0 + 4 * wave + k;
@@ -1164,7 +1163,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
             if (off < lpr) sum_g += __shfl_xor(sum_g, off, 64);
         if (sub == 0 && plane_ok && oy0 + 4 * wave < p.out_h) atomicAdd(p.ep_sum_g + plane, sum_g);
     }
-    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax, seen); }
+    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
 }
 
 typedef void (*lanes_fn)(lanes_params);

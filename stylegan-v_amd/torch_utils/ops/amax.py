@@ -22,6 +22,22 @@ _ATTR = '_sgv_amax'
 
 _ARENA = 4096
 _arenas = {}       # device index -> [zeroed fp32 tensor, slots handed out]
+SINK_SLOTS = 4096              # SGV_AMAX_SINK_SLOTS of include/sgv_ops.h
+_SINK_BLOCK = SINK_SLOTS + 64  # floats per sink block (1 + slots, padded to a 256-byte multiple)
+_SINKS_PER_ARENA = 64
+_sink_arenas = {}  # device index -> [zeroed fp32 tensor, blocks handed out]
+
+
+def zero_sink(device):
+    """A zeroed block for the library's bound side output (sgv_amax_sink): [0] receives the bound, [1 .. SINK_SLOTS] the producer's partial maxima.
+    Carved from a zeroed arena like `zero_slot` (one 1-MiB fill per 64 sinks)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros([_SINK_BLOCK], dtype=torch.float32, device=device)
+    a = _sink_arenas.get(device.index)
+    if a is None or a[1] >= _SINKS_PER_ARENA:
+        a = _sink_arenas[device.index] = [torch.zeros([_SINKS_PER_ARENA * _SINK_BLOCK], dtype=torch.float32, device=device), 0]
+    a[1] += 1
+    return a[0][(a[1] - 1) * _SINK_BLOCK:a[1] * _SINK_BLOCK]
 
 
 def zero_slot(device):
@@ -85,7 +101,7 @@ def launch_tracking(out, call):
     if not (out.is_cuda and out.dtype == torch.float32 and tracking()):
         return call()
     lib = custom_ops.get_native()
-    buf = zero_slot(out.device)
+    buf = zero_sink(out.device)
     lib.sgv_amax_sink(buf.data_ptr())
     try:
         rc = call()
@@ -93,5 +109,5 @@ def launch_tracking(out, call):
         taken = lib.sgv_amax_sink_consumed()
         lib.sgv_amax_sink(None)
     if taken:
-        attach(out, buf)
+        attach(out, buf[0:1])
     return rc

@@ -257,12 +257,16 @@ def test_producers_leave_the_bound_of_their_output_behind():
     y = _with_terms(3, lambda: upfirdn2d.upfirdn2d(x, f, padding=1))
     assert getattr(y, '_sgv_amax', None) is None
     # the C ABI contract: armed, served or not, disarmed either way
-    out = torch.full([1], -1.0, device=DEV)
+    out = torch.full([amax.SINK_SLOTS + 1], -1.0, device=DEV)
     t = torch.randn([4096], generator=g).to(DEV)
     lib.sgv_amax_sink(out.data_ptr())
     custom_ops.check(lib.sgv_absmax(t.data_ptr(), t.numel(), 0, torch.empty([1], device=DEV).data_ptr(), 0, custom_ops.raw_stream(t)), lib)    # not a producer
-    assert lib.sgv_amax_sink_consumed() == 0 and out.item() == -1.0
+    assert lib.sgv_amax_sink_consumed() == 0 and bool((out == -1.0).all())
     y = torch.empty_like(t)
     s1 = torch.ones([1], device=DEV)
     custom_ops.check(lib.sgv_scale_channels(t.data_ptr(), s1.data_ptr(), y.data_ptr(), 1, 1, 4096, 0, custom_ops.raw_stream(t)), lib)          # the sink was disarmed by the call before
-    assert lib.sgv_amax_sink_consumed() == 0 and out.item() == -1.0
+    assert lib.sgv_amax_sink_consumed() == 0 and bool((out == -1.0).all())
+    out.zero_()
+    lib.sgv_amax_sink(out.data_ptr())                                                                                                          # armed for THIS call
+    custom_ops.check(lib.sgv_scale_channels(t.data_ptr(), s1.data_ptr(), y.data_ptr(), 1, 1, 4096, 0, custom_ops.raw_stream(t)), lib)
+    assert lib.sgv_amax_sink_consumed() == 1 and out[0].item() == t.abs().max().item() and int((out[1:] > 0).sum()) >= 1
