@@ -60,6 +60,8 @@ def bound(t):
     if cached is not None and cached[0] == t._version and cached[1] == t.data_ptr():
         return cached[2]
     assert t.is_cuda and t.dtype in _DT
+    if _trace is not None:
+        _trace_pass(t)
     tc = t if t.is_contiguous() else t.contiguous()
     out = zero_slot(t.device)
     lib = custom_ops.get_native()
@@ -67,6 +69,35 @@ def bound(t):
         custom_ops.check(lib.sgv_absmax(tc.data_ptr(), tc.numel(), _DT[t.dtype], out.data_ptr(), 1, custom_ops.raw_stream(tc)), lib)
     attach(t, out)
     return out
+
+
+# SGV_AMAX_TRACE=1: which call sites still need a separate pass (tensor shape x caller), printed at exit -- the work list for further producer fusion
+_trace = {} if __import__('os').environ.get('SGV_AMAX_TRACE') == '1' else None
+
+
+def _trace_pass(t):
+    import sys
+    f = sys._getframe(2)
+    chain = []
+    while f is not None and len(chain) < 3:
+        chain.append(f'{f.f_code.co_name}:{f.f_lineno}')
+        f = f.f_back
+    key = (tuple(t.shape), ' < '.join(chain))
+    e = _trace.setdefault(key, [0, 0])
+    e[0] += 1
+    e[1] += t.numel() * t.element_size()
+
+
+if _trace is not None:
+    import atexit
+
+    def _dump():
+        import sys
+        rows = sorted(_trace.items(), key=lambda kv: -kv[1][1])
+        print('[amax trace] separate bound passes: %d launches, %.1f GB' % (sum(v[0] for _, v in rows), sum(v[1] for _, v in rows) / 1e9), file=sys.stderr)
+        for (shape, who), (n, nbytes) in rows[:40]:
+            print('  %6d x %-26s %8.1f MB  %s' % (n, str(list(shape)), nbytes / 1e6, who), file=sys.stderr)
+    atexit.register(_dump)
 
 
 def attach(t, amax):
