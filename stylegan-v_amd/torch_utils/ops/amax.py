@@ -142,3 +142,42 @@ def launch_tracking(out, call):
     if taken:
         attach(out, buf[0:1])
     return rc
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Bounds that follow from another bound.  |FIR(x)| <= gain * sum|taps| * max|x| for every geometry of upfirdn2d (zero insertion only drops terms):
+# a FIR output whose kernel has no side output (the lane-exchange kernels of the 2x up / down passes) inherits gain * sum|taps| x the bound of its
+# input -- one 1-element multiply instead of a pass over the tensor.  For the normalised [1,3,3,1] low-pass that factor is 1 (down) or 4 (up, gain 4:
+# loose by the zero insertion, far inside the ~2^10 a bound may be loose by, csrc/sgv_split.h).
+
+_tap_sums = {}       # (data_ptr, version) of a filter tensor -> sum |taps| (read back ONCE per filter tensor; never while a hipGraph is being captured)
+
+
+def cached(t):
+    """The bound a producer or an earlier request left on t, or None."""
+    c = getattr(t, _ATTR, None)
+    return c[2] if (c is not None and c[0] == t._version and c[1] == t.data_ptr()) else None
+
+
+def inherit_through_fir(y, x, f2d, gain):
+    """Give y = upfirdn2d(x, f2d, gain=gain, ...) the bound gain * sum|f2d| * bound(x) if x has one and y has none yet."""
+    if not (y.is_cuda and y.dtype == torch.float32 and tracking()) or cached(y) is not None:
+        return
+    bx = cached(x)
+    if bx is None:
+        return
+    key = (f2d.data_ptr(), f2d._version)
+    tap_sum = _tap_sums.get(key)
+    if tap_sum is None:
+        if torch.cuda.is_current_stream_capturing():
+            return
+        tap_sum = _tap_sums[key] = float(f2d.abs().sum())
+    attach(y, bx * (abs(float(gain)) * tap_sum * 1.0000005))      # (a hair above: the FIR's own roundings)
+
+
+def share(alias, t):
+    """`alias` is another tensor object over t's memory (an autograd node handing its input on): it carries t's bound."""
+    b = cached(t)
+    if b is not None and alias.data_ptr() == t.data_ptr():
+        attach(alias, b)
+    return alias

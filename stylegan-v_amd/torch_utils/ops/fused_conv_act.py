@@ -220,7 +220,7 @@ class _FusedConvActFirFn(torch.autograd.Function):
         ctx.save_for_backward(x, weight, bias, f, y0)
         # second output: x itself, for the layer input's OTHER consumer (the residual block's skip branch).  Its gradient then arrives here
         # as g_alias and the data-gradient convolution adds into it in its store, instead of autograd adding two full tensors afterwards.
-        return xb, x.view_as(x)
+        return xb, _amax.share(x.view_as(x), x)
 
     @staticmethod
     def backward(ctx, g, g_alias=None):

@@ -175,7 +175,8 @@ class _FirDownAliasFn(torch.autograd.Function):
         ctx.cfg = cfg
         ctx.in_shape = tuple(x.shape)
         ctx.save_for_backward(f)
-        return y, x.view_as(x)
+        from . import amax as _amax
+        return y, _amax.share(x.view_as(x), x)
 
     @staticmethod
     def backward(ctx, g_y, g_alias=None):

@@ -158,6 +158,7 @@ def _native_call(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain)
     with custom_ops.device_guard(x):
         from . import amax as _amax      # (a FIR output usually feeds a convolution: the LDS-tile kernel leaves its magnitude bound behind)
         custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x))), lib)
+        _amax.inherit_through_fir(y, x, f2d, gain)      # (a kernel without the side output: the bound follows from the input's, if that is known)
     return y
 
 

@@ -34,11 +34,13 @@ class StyleGAN2Loss:
         loss_kwargs = getattr(getattr(cfg, 'model', None), 'loss_kwargs', None)
         self.video_consistent_aug = bool(loss_kwargs.get('video_consistent_aug', False)) if hasattr(loss_kwargs, 'get') else False
         self.frames = cfg.sampling.num_frames_per_video
-        # SGV_D_CONCAT=1 (off by default; `d_concat`): the Dmain phase runs the discriminator ONCE on [generated clips, real clips] instead of twice --
+        # `d_concat` (on by default since round 4; SGV_D_CONCAT=0 restores the reference's two passes): the Dmain phase runs the discriminator ONCE on
+        # [generated clips, real clips] instead of twice (src/training/loss.py:122-151) --
         # the same two loss terms, the same gradients (their sum), half the launches of the phase, twice the batch for the small-resolution layers, and no
         # second accumulation pass over every parameter gradient.  The only cross-sample operation of D, the minibatch-std layer, keeps its groups inside
-        # each half (MinibatchStdLayer.segments).  Equivalence: tests/test_networks.py (CPU).
-        self.d_concat = os.environ.get('SGV_D_CONCAT', '0') == '1'
+        # each half (networks.minibatch_std_segments).  Equivalence: tests/test_dmain_concat.py (CPU), tests/test_ddp_gloo.py (under DDP); the whole -m gpu
+        # suite ran with it (tools/gpu_recipes/r04_call6.sh).  Measured: 8 videos/GPU with graphs +7.4 %, 32 videos/GPU +2.4 % (profiles/r03_d_concat_ab.log).
+        self.d_concat = os.environ.get('SGV_D_CONCAT', '1') != '0'
 
     def run_G(self, z, c, t, sync):
         with misc.ddp_sync(self.G_mapping, sync):

@@ -251,6 +251,16 @@ def test_producers_leave_the_bound_of_their_output_behind():
         up = upfirdn2d.upfirdn2d(x, f, up=2, padding=[2, 1, 2, 1], gain=4)
         assert getattr(up, '_sgv_amax', None) is None
         assert amax.bound(up).item() == up.abs().max().item()
+        # ... unless the input's bound is known: then the output inherits gain * sum|taps| x that bound (no pass; |FIR(x)| <= gain * sum|f| * max|x|)
+        bx = amax.bound(x).item()
+        up2 = upfirdn2d.upfirdn2d(x, f, up=2, padding=[2, 1, 2, 1], gain=4)
+        dn = upfirdn2d.upfirdn2d(x[:, :, :64, :64].contiguous(), f, down=2, padding=1)
+        assert up2.abs().max().item() <= amax.cached(up2).item() <= 4.001 * bx
+        assert amax.cached(dn) is None                 # (that slice is a new tensor without a bound)
+        xs = x[:, :, :64, :64].contiguous()
+        amax.bound(xs)
+        dn = upfirdn2d.upfirdn2d(xs, f, down=2, padding=1)
+        assert dn.abs().max().item() <= amax.cached(dn).item() <= 1.001 * xs.abs().max().item()
     _with_terms(4, run)
     # with another arithmetic nothing is tracked
     x = torch.randn([1, 4, 33, 33], generator=g).to(DEV)

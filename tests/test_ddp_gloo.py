@@ -58,6 +58,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
         ts = _make(world, rank, batch_gpu=2, ddp=True)
+        ts.loss.d_concat = False          # the reference's two discriminator passes first (src/training/loss.py:122-151); the one-pass form is compared with them below
         real, real_t, z, t = _inputs()
         sl = slice(rank * 2, rank * 2 + 2)
         # motion noise is drawn inside G: fix it per video so both runs see the same trajectories
@@ -66,7 +67,7 @@ def _worker(rank, world, port, out_dir):
         for phase in ('Gmain', 'Dmain', 'Dreg'):
             torch.manual_seed(77 + rank)  # rank-local RNG stream for the in-forward randn
             res[phase] = _phase_grads(ts, phase, real[sl], real_t[sl], z[sl], t[sl])
-        # Dmain as ONE discriminator pass over [generated, real] clips (loss.d_concat, off by default): a single synchronised backward must leave the same
+        # Dmain as ONE discriminator pass over [generated, real] clips (loss.d_concat): a single synchronised backward must leave the same
         # all-reduced gradients as the reference's two passes (the first un-synchronised, the second synchronised)
         ts.loss.d_concat = True
         torch.manual_seed(77 + rank)
@@ -79,6 +80,7 @@ def _worker(rank, world, port, out_dir):
         # the wrapper-free form used under hipGraph replay (one flat all-reduce behind the backward pass) gives the same averaged gradients
         tm = _make(world, rank, batch_gpu=2, ddp=True, ddp_manual=True)
         assert tm.ddp_manual and not isinstance(tm.loss.D, torch.nn.parallel.DistributedDataParallel)
+        tm.loss.d_concat = False
         tm.G.load_state_dict(ts.G.state_dict()); tm.D.load_state_dict(ts.D.state_dict())
         for phase in ('Gmain', 'Dmain', 'Dreg'):
             torch.manual_seed(77 + rank)
@@ -119,6 +121,7 @@ def test_ddp_two_ranks_match_single_process(tmp_path, monkeypatch):
 
     _patch_motion_noise(motion)
     ts = _make(1, 0, batch_gpu=4, ddp=False)
+    ts.loss.d_concat = False
     real, real_t, z, t = _inputs()
     # D's minibatch-std layer groups sample k with sample k + N/G (networks.py:506): order the single-process batch so
     # that its groups are exactly the per-rank groups {0,1} and {2,3}.

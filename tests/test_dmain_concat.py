@@ -1,4 +1,4 @@
-"""SGV_D_CONCAT (loss.py `d_concat`, off by default): the Dmain phase as ONE discriminator pass over [generated, real] clips -- same losses, same gradients
+"""SGV_D_CONCAT (loss.py `d_concat`, on by default since round 4): the Dmain phase as ONE discriminator pass over [generated, real] clips -- same losses, same gradients
 as the reference's two passes (src/training/loss.py:122-151); the minibatch-std layer keeps its groups inside each half."""
 import torch
 

@@ -503,6 +503,24 @@ def test_train_step_graphs_with_ddp_and_ada_on_an_nccl_group_of_one():
     assert res.returncode == 0 and 'OK' in res.stdout.split(), f'rc={res.returncode}\n{res.stdout[-2000:]}\n{res.stderr[-4000:]}'   # (RCCL prints its version banner after it)
 
 
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs of one node (RCCL over xGMI); the 1-GPU test box skips it')
+def test_graph_schedule_over_rccl_with_two_ranks():
+    """tests/ddp_nccl_worker.py on two ranks: the hipGraph schedule with a real RCCL all-reduce, ranks bit-consistent after every iteration incl. the
+    ones behind an eager reg phase (the case ADVICE r3 found broken; the CPU stand-in is tests/test_ddp_gloo.py)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'ddp_nccl_worker.py')
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = str(sock.getsockname()[1])
+    procs = [subprocess.Popen([sys.executable, worker, str(r), '2', port], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (out, err)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f'OK rank {r}' in out, f'rank {r}: rc={p.returncode}\n{out[-2000:]}\n{err[-4000:]}'
+
+
 def test_multi_tensor_nan_to_num_matches_torch_per_tensor():
     """sgv_multi_nan_to_num_f32 (training_loop.py:384-386 as one launch): 200 tensors of ragged sizes incl. empty, unaligned views and tails."""
     from stylegan_v_amd.torch_utils import misc

@@ -15,7 +15,11 @@ import sys
 def main():
     root, out_path = sys.argv[1], sys.argv[2]
     commit = sys.argv[3] if len(sys.argv) > 3 else os.environ.get('SGV_COMMIT', 'unknown')
-    out = {'commit': commit}
+    # `csrc_digest`: md5 over the kernel sources the counters were collected on (custom_ops.source_digest) -- bench.py refuses a file whose digest is not
+    # the one of the library it is timing (there is no .git on the GPU box to compare commits with)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from stylegan_v_amd.torch_utils import custom_ops
+    out = {'commit': commit, 'csrc_digest': custom_ops.source_digest()}
     for c in ('FETCH_SIZE', 'WRITE_SIZE'):
         fs = glob.glob(os.path.join(root, f'pmc_bench_{c}', '*', '*counter_collection.csv'))
         agg = collections.defaultdict(lambda: [0, 0.0])
