@@ -156,6 +156,8 @@ sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, doub
 }
 
 sgv_launch_scope::~sgv_launch_scope() {
-    if (amax_taken) hipLaunchKernelGGL(sgv_amax_reduce_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)amax_taken);   // (inside the call's event bracket)
     if (slot >= 0) { (void)hipEventRecord(g_prof_pool[slot].stop, stream); g_scope_slot = -1; }
+    // the one-workgroup fold of the partial maxima: behind the producer on its stream, outside the call's event bracket (the bracket times the op's own
+    // kernel for the roofline tables; the fold is ~3 us of a single workgroup)
+    if (amax_taken) hipLaunchKernelGGL(sgv_amax_reduce_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)amax_taken);
 }
