@@ -83,3 +83,32 @@ def test_affine_resample_kernel_vs_two_op_formulation(shape, out):
     want = run(x0.double().requires_grad_(True), theta.double(), v.double(), oracle.affine_resample)
     for a, r, name in zip(got, want, ['y', 'dx', 'd2x']):
         assert_close(a, r, atol=2e-4 * max(1.0, r.abs().max().item()), rtol=1e-4, what=name)
+
+
+@pytest.mark.gpu
+def test_affine_resample_adjoint_gather_form_covers_every_map():
+    """The adjoint as a gather over the source pixels (csrc/resample.hip, round 4): rotations / mirrors / anisotropic scales / strong down-scaling, more
+    channels than one register pass holds, and samples whose map is too anisotropic or singular for the small candidate box (the atomics kernel takes
+    those) -- all in ONE batch, against the float64 two-op formulation; and <S x, v> == <x, S^T v> to fp32 rounding (an exact adjoint of the forward)."""
+    import math
+    g = torch.Generator().manual_seed(7)
+    thetas = []
+    for ang, sx, sy, tx, ty in ((0.0, 1.0, 1.0, 0.0, 0.0), (0.7, 1.0, 1.0, 0.1, -0.2), (math.pi / 2, 1.0, 1.0, 0.0, 0.0), (2.4, 0.6, 1.5, 0.3, 0.1), (0.3, -1.0, 1.0, 0.0, 0.0),
+                                (0.2, 2.5, 2.2, 0.0, 0.0), (1.1, 0.35, 0.4, -0.1, 0.2), (0.4, 9.0, 0.9, 0.0, 0.0), (0.0, 0.0, 1.0, 0.0, 0.0), (0.9, 1e-4, 1e-4, 0.0, 0.0)):
+        c, s_ = math.cos(ang), math.sin(ang)
+        thetas.append([[sx * c, -sy * s_, tx], [sx * s_, sy * c, ty]])
+    theta = torch.tensor(thetas)
+    n, ch, h, w, out = theta.shape[0], 14, 37, 45, (50, 41)
+    x0 = torch.randn([n, ch, h, w], generator=g)
+    v = torch.randn([n, ch, *out], generator=g)
+    xg = x0.cuda().requires_grad_(True)
+    y = resample.affine_resample(xg, theta.cuda(), out)
+    (gx,) = torch.autograd.grad(y, xg, v.cuda())
+    xr = x0.double().requires_grad_(True)
+    yr = oracle.affine_resample(xr, theta.double(), out)
+    (gr,) = torch.autograd.grad(yr, xr, v.double())
+    assert_close(y, yr, atol=2e-5 * yr.abs().max().item(), rtol=1e-5, what='S x')
+    for i in range(n):
+        assert_close(gx[i], gr[i], atol=3e-5 * max(gr[i].abs().max().item(), 1.0), rtol=1e-5, what=f'S^T v, sample {i} (theta {thetas[i]})')
+    lhs, rhs = (y.double().cpu() * v.double()).sum().item(), (x0.double() * gx.double().cpu()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
