@@ -13,6 +13,14 @@ Organisation (not the reference's): every augmentation is one row of a table -- 
 how the parameter becomes a matrix) -- and ``forward`` folds the rows; the resampling step goes through ``affine_resample`` below,
 which on the GPU is a hand-written gather kernel with its adjoint (csrc/resample.hip) instead of affine_grid + grid_sample, and stays
 differentiable to any order (R1 runs through this path on real images).
+
+Where the parameters live (round 4): the per-sample parameters are a few hundred bytes, but drawing and composing them on the device costs ~260 launches per call
+(`torch.full` per constant matrix entry, a `bmm` per composition, one RNG launch per draw: 790 launches and 2.6 ms of device time per training iteration,
+profiles/r04_c11_*), and the padding margin has to come back to the host for the tensor sizes.  With ``host_params`` (default outside hipGraph capture) the same
+table is folded on the HOST with CPU tensors -- same distributions, same order of composition, the margin is a host value, no device -> host read -- and the
+three results (theta [n,2,3], colour matrix [n,3,3] + offset [n,3]) go to the device in pinned, non-blocking copies.  ``p`` stays a device buffer that ADA adapts on
+the device; its host mirror is refreshed only when the buffer has changed (once per `ada_interval` iterations: the one read the reference's loop also does,
+training_loop.py:407-410).  Under capture (``static_margin``) everything stays on the device as before.
 """
 
 import math
@@ -20,7 +28,7 @@ import math
 import numpy as np
 import torch
 
-from ..torch_utils.ops import resample, upfirdn2d
+from ..torch_utils.ops import pointwise, resample, upfirdn2d
 
 SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466, 0.787641141030194,
         0.3379294217276218, -0.07263752278646252, -0.021060292512300564, 0.04472490177066578, 0.0017677118642428036, -0.007800708325034148]
@@ -68,6 +76,9 @@ class AugmentPipe(torch.nn.Module):
         # margin back from the device.  Same result (extra padding is never sampled), no device -> host sync, static shapes: what hipGraph
         # capture needs.  The price is a padded image of (3w - 2) x (3h - 2) instead of typically (w + 12) x (h + 12).
         self.static_margin = False
+        # True: draw / compose the per-sample parameters on the host and upload the results (module docstring).  Only takes effect for CUDA images outside capture.
+        self.host_params = True
+        self._p_host = None      # (id of the buffer's storage, its version, 0-d CPU tensor)
         self._const = {}
 
     def _c(self, key, device, make):
@@ -76,6 +87,29 @@ class AugmentPipe(torch.nn.Module):
         if k not in self._const:
             self._const[k] = make().to(device)
         return self._const[k]
+
+    def _param_device(self, images):
+        if self.host_params and images.is_cuda and not self.static_margin and not torch.cuda.is_current_stream_capturing():
+            return torch.device('cpu')
+        return images.device
+
+    def _p_on(self, device):
+        """`p` where the parameters are drawn: the buffer itself, or its host mirror (re-read only after the buffer changed)."""
+        if self.p.device == device:
+            return self.p
+        key = (self.p.data_ptr(), self.p._version)
+        if self._p_host is None or self._p_host[0] != key:
+            self._p_host = (key, self.p.detach().to(device))       # one device -> host read per change of p
+        return self._p_host[1]
+
+    @staticmethod
+    def _upload(t, device):
+        """A small host tensor to the device without blocking the host (pinned staging block from the caching host allocator)."""
+        if t.device == device:
+            return t
+        buf = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+        buf.copy_(t)
+        return buf.to(device, non_blocking=True)
 
     # -- parameter draws ------------------------------------------------------------------------------------------------------
     def _draw(self, name, shape, kind, neutral, device, pct, prob=None):
@@ -92,14 +126,14 @@ class AugmentPipe(torch.nn.Module):
         if pct is not None:
             return v
         gate_shape = [shape[0]] + [1] * (len(shape) - 1)
-        keep = torch.rand(gate_shape, device=device) < (self.mult[name] * self.p if prob is None else prob)
+        keep = torch.rand(gate_shape, device=device) < (self.mult[name] * self._p_on(device) if prob is None else prob)
         return torch.where(keep, v, torch.full_like(v, neutral))
 
     def forward(self, images, debug_percentile=None):
         assert isinstance(images, torch.Tensor) and images.ndim == 4
         n, ch, h, w = images.shape
-        dev, pct, on = images.device, debug_percentile, self.mult
-        like = images
+        dev, pct, on = self._param_device(images), debug_percentile, self.mult     # dev: where the parameters are drawn and composed
+        like = torch.empty(0, device=dev)
 
         # ---- inverse geometric transform G_inv (maps output pixels to input pixels), composed left to right (augment.py:185-268) ----
         g_inv, geometric = None, False
@@ -120,7 +154,7 @@ class AugmentPipe(torch.nn.Module):
         if on['scale'] > 0:
             s = torch.exp2(self._draw('scale', [n], 'normal', 0, dev, pct) * self.scale_std)
             push(_scale(1 / s, 1 / s, like))
-        p_rot = 1 - torch.sqrt((1 - on['rotate'] * self.p).clamp(0, 1))   # P(pre OR post) = p
+        p_rot = 1 - torch.sqrt((1 - on['rotate'] * self._p_on(dev)).clamp(0, 1))   # P(pre OR post) = p
         if on['rotate'] > 0:
             th = self._draw('rotate', [n], 'uniform', 0, dev, pct, prob=p_rot) * math.pi * self.rotate_max
             push(_rotate(th, like))                                    # inverse of a rotation by -theta
@@ -166,9 +200,16 @@ class AugmentPipe(torch.nn.Module):
             if ch % 3 == 0:                       # RGB, or F frames of one video folded into 3F channels (loss.py:58-66): the same matrix for every frame
                 f = ch // 3
                 cm = c_mat.repeat_interleave(f, dim=0) if f > 1 else c_mat
-                flat = (cm[:, :3, :3] @ flat.reshape(n * f, 3, h * w) + cm[:, :3, 3:]).reshape(n, ch, h * w)
+                cw, cb = self._upload(cm[:, :3, :3].contiguous(), images.device), self._upload(cm[:, :3, 3:].contiguous(), images.device)
+                if images.is_cuda and images.dtype == torch.float32:
+                    # 3 -> 3 channels with per-sample weights: the streaming kernel ToRGB uses (csrc/pointwise.hip) instead of a batched 3x3 GEMM
+                    # (rocBLAS: 0.42 ms per call on 150 MB, 10x its HBM time; profiles/r04_c8_ada_step_kernel_stats.csv)
+                    y = pointwise.pointwise_conv(images.reshape(n * f, 3, h, w), cw)
+                    flat = (y + cb.reshape(n * f, 3, 1, 1)) if y.requires_grad else y.add_(cb.reshape(n * f, 3, 1, 1))
+                else:
+                    flat = cw @ flat.reshape(n * f, 3, h * w) + cb
             elif ch == 1:
-                cm = c_mat[:, :3, :].mean(dim=1, keepdim=True)
+                cm = self._upload(c_mat[:, :3, :].mean(dim=1, keepdim=True).contiguous(), images.device)
                 flat = flat * cm[:, :, :3].sum(dim=2, keepdim=True) + cm[:, :, 3:]
             else:
                 raise ValueError('Image must be RGB (3 channels) or L (1 channel)')
@@ -178,7 +219,7 @@ class AugmentPipe(torch.nn.Module):
     # -- geometric execution (augment.py:270-300) -----------------------------------------------------------------------------------
     def _resample(self, images, g_inv):
         n, ch, h, w = images.shape
-        dev = images.device
+        dev = g_inv.device                                                     # the parameters' device (the host with `host_params`): the margin read below is free there
         cx, cy = (w - 1) / 2, (h - 1) / 2
         pad = self.Hz_geom.shape[0] // 4
         if self.static_margin:
@@ -192,14 +233,14 @@ class AugmentPipe(torch.nn.Module):
             margin = margin.clamp(min=0).minimum(self._c(('mmax', w, h), dev, lambda: torch.tensor([w - 1, h - 1] * 2, dtype=torch.float32)))
             mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().tolist())     # one device -> host read per call, as in the reference (:283)
         images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
-        g_inv = _translate((mx0 - mx1) / 2, (my0 - my1) / 2, images) @ g_inv
+        g_inv = _translate((mx0 - mx1) / 2, (my0 - my1) / 2, g_inv) @ g_inv
         images = upfirdn2d.upsample2d(images, self.Hz_geom, up=2)
-        s2, s2i = _scale(2, 2, images), _scale(0.5, 0.5, images)
+        s2, s2i = _scale(2, 2, g_inv), _scale(0.5, 0.5, g_inv)
         g_inv = s2 @ g_inv @ s2i
-        g_inv = _translate(-0.5, -0.5, images) @ g_inv @ _translate(0.5, 0.5, images)
+        g_inv = _translate(-0.5, -0.5, g_inv) @ g_inv @ _translate(0.5, 0.5, g_inv)
         out_h, out_w = (h + pad * 2) * 2, (w + pad * 2) * 2
-        g_inv = _scale(2 / images.shape[3], 2 / images.shape[2], images) @ g_inv @ _scale(out_w / 2, out_h / 2, images)
-        images = resample.affine_resample(images, g_inv[:, :2, :], (out_h, out_w))
+        g_inv = _scale(2 / images.shape[3], 2 / images.shape[2], g_inv) @ g_inv @ _scale(out_w / 2, out_h / 2, g_inv)
+        images = resample.affine_resample(images, self._upload(g_inv[:, :2, :].contiguous(), images.device), (out_h, out_w))
         return upfirdn2d.downsample2d(images, self.Hz_geom, down=2, padding=-pad * 2, flip_filter=True)
 
 

@@ -112,3 +112,35 @@ def test_affine_resample_adjoint_gather_form_covers_every_map():
         assert_close(gx[i], gr[i], atol=3e-5 * max(gr[i].abs().max().item(), 1.0), rtol=1e-5, what=f'S^T v, sample {i} (theta {thetas[i]})')
     lhs, rhs = (y.double().cpu() * v.double()).sum().item(), (x0.double() * gx.double().cpu()).sum().item()
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+
+
+@pytest.mark.gpu
+def test_host_side_parameters_match_device_side_parameters_and_follow_p():
+    """`host_params` (round 4: the parameter table folded on the host, results uploaded) gives the clip the device-side composition gives, at every
+    golden percentile; the colour step then runs on the streaming 3 -> 3 kernel.  And the host mirror of `p` follows the device buffer: after ADA
+    moves p from 0 to 1 the very next call augments."""
+    x0 = AUG.t('x', device='cuda')
+    host, dev = AugmentPipe(**BGC).cuda(), AugmentPipe(**BGC).cuda()
+    dev.host_params = False
+    assert host.host_params and host._param_device(x0) == torch.device('cpu') and dev._param_device(x0) == x0.device
+    for pct in AUG.meta['percentiles']:
+        xa, xb = x0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        before = custom_ops.launch_count()
+        ya = host(xa, debug_percentile=pct)
+        launches_host = custom_ops.launch_count() - before
+        yb = dev(xb, debug_percentile=pct)
+        assert launches_host >= 6            # up (2) + resample + down (2) + colour
+        assert_close(ya, yb, atol=2e-5, rtol=2e-5, what=f'host- vs device-side parameters at percentile {pct}')
+        v = torch.randn_like(ya)
+        (ga,), (gb,) = torch.autograd.grad((ya * v).sum(), xa), torch.autograd.grad((yb * v).sum(), xb)
+        assert_close(ga, gb, atol=2e-4, rtol=2e-4, what=f'input gradient, host- vs device-side parameters at percentile {pct}')
+    torch.manual_seed(3)
+    host.p.copy_(torch.zeros([]))
+    x = torch.rand([8, 9, 32, 32], device='cuda') * 2 - 1
+    assert (host(x) - x).abs().max() < 5e-5
+    host.p.copy_(torch.ones([]))             # (what ada_update does: an in-place write of the device buffer)
+    assert (host(x) - x).abs().max() > 0.05
+    assert float(host._p_on(torch.device('cpu'))) == 1.0
+    with torch.no_grad():                    # no-grad calls add the colour offset in place
+        y = host(x)
+    assert torch.isfinite(y).all()
