@@ -54,6 +54,7 @@
  *                          `self.bias * self.lr_multiplier` of every Conv2dLayer of a module (src/training/layers.py:184-185) and of their gradients
  *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail src/training/motion.py:201-212
  *   sgv_affine_resample <- `affine_grid` + `grid_sample` of the ADA geometric execution src/training/augment.py:297-300 and its backward
+ *   sgv_ada_geometric  <- reflect pad + upsample2d + affine_grid / grid_sample + downsample2d of augment.py:270-300 in one pass (forward)
  *                          src/torch_utils/ops/grid_sample_gradfix.py:45-83
  *   sgv_prof_*, sgv_launch_count, sgv_variant_count, sgv_variant_name
  *                      <- no reference counterpart: per-launch HIP-event timing and launch / kernel-variant counters used by
@@ -70,7 +71,7 @@
 extern "C" {
 #endif
 
-#define SGV_VERSION 101 /* major*100 + minor */
+#define SGV_VERSION 102 /* major*100 + minor */
 
 /* element types (the reference dispatches double/float/half: upfirdn2d.cpp:59, bias_act.cpp:76;
  * bf16 is this library's extension) */
@@ -390,6 +391,17 @@ int64_t sgv_conv3x3_workspace_bytes(int32_t c_in, int32_t c_out);
  * theta is [n, 2, 3] in affine_grid's normalised coordinates. */
 int sgv_affine_resample(const float* src, float* dst, const float* theta, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho, int32_t wo,
                         int32_t adjoint, void* stream);
+
+/* The whole geometric execution of AugmentPipe.forward (src/training/augment.py:270-300) as one kernel, forward direction, fp32 NCHW:
+ *   y = upfirdn2d.downsample2d( grid_sample( upfirdn2d.upsample2d( pad(x, [mx0, mx1, my0, my1], 'reflect'), Hz, up=2 ), affine_grid(theta) ), Hz, down=2,
+ *                               padding=-6, flip_filter=True )                                      x, y [n, c, h, w]
+ * with the 12-tap `Hz_geom` filter (`filter12`: HOST pointer, the taps travel as launch arguments) and theta [n, 2, 3] (DEVICE) exactly what
+ * sgv_affine_resample would get for the resampling step: the map from the (2 (h + 6)) x (2 (w + 6)) resampled image to the up-sampled padded image
+ * (2 (h + my0 + my1)) x (2 (w + mx0 + mx1)), both in affine_grid's normalised coordinates.  The padded, up-sampled and resampled images are never
+ * written.  Margins in [0, size - 1] (the reference clamps there, augment.py:281-282).  Any affine map (a sample whose tile footprints do not fit
+ * the staging buffers takes a direct form in the same launch). */
+int sgv_ada_geometric(const float* x, float* y, const float* theta, const float* filter12, int32_t n, int32_t c, int32_t h, int32_t w,
+                      int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * AlignedTimeEncoder element-wise tail (motion.py:201-212), fp32:

@@ -167,6 +167,235 @@ __global__ __launch_bounds__(256) void affine_resample_adjoint_scatter_rest_kern
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// The whole geometric execution of the ADA pipeline as ONE kernel (forward direction):
+//
+//     y = down2( resample_theta( up2( reflect_pad(x, margin) ) ) )          src/training/augment.py:270-300
+//
+// with the 12-tap filter both FIR steps use (`Hz_geom`, sym6; up: gain 4, zero phase padding [6,5]; down: `flip_filter`, padding -2 * (12 / 4)).  The
+// four-pass composition moves 1.6 GB per 32 clips (reflect pad 75 -> 83 MB, up-sampled 331 MB, resampled 316 MB, written and read back once each; 1.04 ms at the rates
+// its kernels reach); the algorithm's own bytes are x in, y out: 150 MB.  A workgroup owns a 16 x 16 tile of y for one sample and walks the channels:
+//   1. the 42 x 42 block of resampled ("hi-res") pixels the tile's down-sampling FIR reads maps, under the sample's affine map, onto a parallelogram of the
+//      up-sampled padded image; its bounding box (<= GEO_BMAX^2: rotations by any angle at scales <= 1.15) fixes the box of PADDED-image pixels the up-sampling FIR
+//      needs ((box / 2 + 6)^2), which is read from x with the reflection resolved in the index (the padded image never exists; positions outside it are zeros, as
+//      upfirdn2d's own zero padding makes them);
+//   2. up-sampling, separable, in LDS (one thread makes the even and the odd output of an input position: 7 LDS reads for 12 FMAs);
+//   3. the bilinear taps with `affine_resample_kernel`'s own arithmetic (same taps, same weights), from LDS;
+//   4. down-sampling, separable, in LDS; 256 stores.
+// A sample whose box does not fit (strong zoom-out: > 1.6 source pixels per output pixel) takes the direct form of step 1-3 in the same launch: each hi-res pixel evaluates
+// its four up-sampled taps from x (4 x 36 FMAs through L1 / L2) -- 20x the arithmetic, any map.
+// The margin arrives by value: the batch's measured margin (host-side parameters) or the static worst case w - 1 / h - 1 (hipGraph capture) -- here it costs nothing
+// either way, the padded image being virtual.  Backward passes keep the four-pass composition (ops/resample.py).
+
+constexpr int GEO_TO = 16;                    // output tile
+constexpr int GEO_HI = 2 * GEO_TO + 10;       // hi-res rows / columns a tile's down-sampling reads
+constexpr int GEO_BMAX = 72;                  // largest staged box of up-sampled pixels (even)
+constexpr int GEO_PMAX = GEO_BMAX / 2 + 6;    // ... and of padded-image pixels under it
+
+struct geom_params {
+    const float* x;
+    float* y;
+    const float* theta;                       // [n, 2, 3]: hi-res (normalised) -> up-sampled padded image (normalised), what affine_resample gets
+    int n, c, h, w;
+    int mx0, mx1, my0, my1;                   // reflect-padding margin
+    float fe[6], fo[6];                       // up-sampling phases: even output 2i = sum_t fe[t] P[i + t - 3], odd output 2i + 1 = sum_t fo[t] P[i + t - 2]  (gain 2 folded)
+    float fd[12];                             // down-sampling taps: out[o] = sum_m fd[m] hi[2o + 1 + m]
+};
+
+__device__ __forceinline__ int geo_reflect(int r, int n) { r = r < 0 ? -r : r; return r >= n ? 2 * (n - 1) - r : r; }
+
+// value of the padded image at (qy, qx) in padded coordinates: reflected source pixel, or zero outside the padded extent
+__device__ __forceinline__ float geo_padded(const geom_params& p, const float* plane, int qy, int qx) {
+    if (qx < 0 || qx >= p.w + p.mx0 + p.mx1 || qy < 0 || qy >= p.h + p.my0 + p.my1) return 0.f;
+    return plane[(size_t)geo_reflect(qy - p.my0, p.h) * p.w + geo_reflect(qx - p.mx0, p.w)];
+}
+
+// one up-sampled pixel straight from x (direct form)
+__device__ float geo_upsampled_direct(const geom_params& p, const float* plane, int uy, int ux) {
+    const int wu = 2 * (p.w + p.mx0 + p.mx1), hu = 2 * (p.h + p.my0 + p.my1);
+    if (ux < 0 || ux >= wu || uy < 0 || uy >= hu) return 0.f;
+    const bool ox = ux & 1, oy = uy & 1;
+    const int bx = (ux >> 1) - 3 + (ux & 1), by = (uy >> 1) - 3 + (uy & 1);
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 6; r++) {
+        float row = 0.f;
+#pragma unroll
+        for (int t = 0; t < 6; t++) row = __builtin_fmaf(ox ? p.fo[t] : p.fe[t], geo_padded(p, plane, by + r, bx + t), row);
+        acc = __builtin_fmaf(oy ? p.fo[r] : p.fe[r], row, acc);
+    }
+    return acc;
+}
+
+// one hi-res pixel in the direct form: the four bilinear taps, each an up-sampled pixel evaluated from x
+__device__ float geo_hi_direct(const geom_params& p, const float* plane, float ix, float iy) {
+    const float lim = 1e7f;
+    ix = fminf(fmaxf(ix, -lim), lim); iy = fminf(fmaxf(iy, -lim), lim);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float tx = ix - fx, ty = iy - fy;
+    const int x0 = (int)fx, y0 = (int)fy;
+    float v = 0.f;
+    v = __builtin_fmaf((1.f - tx) * (1.f - ty), geo_upsampled_direct(p, plane, y0, x0), v);
+    v = __builtin_fmaf(tx * (1.f - ty), geo_upsampled_direct(p, plane, y0, x0 + 1), v);
+    v = __builtin_fmaf((1.f - tx) * ty, geo_upsampled_direct(p, plane, y0 + 1, x0), v);
+    v = __builtin_fmaf(tx * ty, geo_upsampled_direct(p, plane, y0 + 1, x0 + 1), v);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void ada_geometric_forward_kernel(geom_params p) {
+    __shared__ float s_pin[GEO_PMAX * (GEO_PMAX + 1)];
+    __shared__ float s_t[GEO_PMAX * GEO_BMAX];            // horizontally up-sampled rows; later the hi-res block + its horizontally down-sampled form
+    __shared__ float s_u[GEO_BMAX * (GEO_BMAX + 1)];
+    float* s_hi = s_t;                                      // [GEO_HI][GEO_HI + 1]
+    float* s_dh = s_t + GEO_HI * (GEO_HI + 1);              // [GEO_HI][GEO_TO]
+    static_assert(GEO_HI * (GEO_HI + 1) + GEO_HI * GEO_TO <= GEO_PMAX * GEO_BMAX, "the hi-res block shares the row buffer");
+
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z;
+    const int ox0 = blockIdx.x * GEO_TO, oy0 = blockIdx.y * GEO_TO;
+    const int wp = p.w + p.mx0 + p.mx1, hp = p.h + p.my0 + p.my1, wu = 2 * wp, hu = 2 * hp;
+    const int wo = 2 * (p.w + 6), ho = 2 * (p.h + 6);
+    const int X0 = 2 * ox0 + 1, Y0 = 2 * oy0 + 1;           // first hi-res column / row of the tile
+    const float* th = p.theta + (size_t)n * 6;
+    const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+
+    // affine_resample_kernel's arithmetic for one hi-res pixel
+    auto source = [&](int X, int Y, float& ix, float& iy) {
+        const float xn = (2 * X + 1) / (float)wo - 1.f, yn = (2 * Y + 1) / (float)ho - 1.f;
+        const float gx = t0 * xn + t1 * yn + t2, gy = t3 * xn + t4 * yn + t5;
+        ix = ((gx + 1.f) * wu - 1.f) * 0.5f;
+        iy = ((gy + 1.f) * hu - 1.f) * 0.5f;
+    };
+    // bounding box of the taps of the tile's hi-res block (extremes of an affine map sit on the corners; one pixel of slack for rounding)
+    float cx[4], cy[4];
+    source(X0, Y0, cx[0], cy[0]);
+    source(X0 + GEO_HI - 1, Y0, cx[1], cy[1]);
+    source(X0, Y0 + GEO_HI - 1, cx[2], cy[2]);
+    source(X0 + GEO_HI - 1, Y0 + GEO_HI - 1, cx[3], cy[3]);
+    const float lim = 1e7f;
+    const float xmin = fmaxf(-lim, fminf(fminf(cx[0], cx[1]), fminf(cx[2], cx[3]))), xmax = fminf(lim, fmaxf(fmaxf(cx[0], cx[1]), fmaxf(cx[2], cx[3])));
+    const float ymin = fmaxf(-lim, fminf(fminf(cy[0], cy[1]), fminf(cy[2], cy[3]))), ymax = fminf(lim, fmaxf(fmaxf(cy[0], cy[1]), fmaxf(cy[2], cy[3])));
+    const int ux0 = ((int)floorf(xmin) - 1) & ~1, uy0 = ((int)floorf(ymin) - 1) & ~1;       // even: an input position makes the box's columns 2k, 2k + 1
+    const int bw = (((int)floorf(xmax) + 2 - ux0 + 1) + 1) & ~1, bh = (((int)floorf(ymax) + 2 - uy0 + 1) + 1) & ~1;
+    const bool staged = bw <= GEO_BMAX && bh <= GEO_BMAX && bw > 0 && bh > 0 && xmin > -lim && ymin > -lim && xmax < lim && ymax < lim;
+    const int pw = bw / 2 + 6, ph = bh / 2 + 6;             // padded-image box under the up-sampled box
+    const int px0 = (ux0 >> 1) - 3, py0 = (uy0 >> 1) - 3;
+
+    // this thread's hi-res pixels (the same for every channel): LDS offset of the first tap and the two fractions; offset < 0: outside the hi-res image -> 0
+    constexpr int PER = (GEO_HI * GEO_HI + 255) / 256;
+    int s_off[PER];
+    float s_tx[PER], s_ty[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int s = tid + k * 256;
+        s_off[k] = -1; s_tx[k] = 0.f; s_ty[k] = 0.f;
+        if (s < GEO_HI * GEO_HI) {
+            const int ly = s / GEO_HI, lx = s - ly * GEO_HI;
+            if (X0 + lx < wo && Y0 + ly < ho) {
+                float ix, iy;
+                source(X0 + lx, Y0 + ly, ix, iy);
+                const float fx = floorf(ix), fy = floorf(iy);
+                s_tx[k] = ix - fx; s_ty[k] = iy - fy;
+                if (staged) s_off[k] = ((int)fy - uy0) * (GEO_BMAX + 1) + ((int)fx - ux0);
+            }
+        }
+    }
+
+    for (int ch = 0; ch < p.c; ch++) {
+        const float* plane = p.x + ((size_t)n * p.c + ch) * p.h * p.w;
+        if (staged) {
+            // 1. padded-image box (reflection in the index, zeros outside the padded extent)
+            for (int e = tid; e < ph * pw; e += 256) {
+                const int r = e / pw, cidx = e - r * pw;
+                s_pin[r * (GEO_PMAX + 1) + cidx] = geo_padded(p, plane, py0 + r, px0 + cidx);
+            }
+            __syncthreads();
+            // 2a. up-sample along x: input position k of row r makes columns 2k and 2k + 1
+            for (int e = tid; e < ph * (bw / 2); e += 256) {
+                const int r = e / (bw / 2), k = e - r * (bw / 2);
+                const float* q = s_pin + r * (GEO_PMAX + 1) + k;
+                float v[7];
+#pragma unroll
+                for (int t = 0; t < 7; t++) v[t] = q[t];
+                float ev = 0.f, od = 0.f;
+#pragma unroll
+                for (int t = 0; t < 6; t++) { ev = __builtin_fmaf(p.fe[t], v[t], ev); od = __builtin_fmaf(p.fo[t], v[t + 1], od); }
+                s_t[r * GEO_BMAX + 2 * k] = ev;
+                s_t[r * GEO_BMAX + 2 * k + 1] = od;
+            }
+            __syncthreads();
+            // 2b. ... along y; zeros outside the up-sampled image (upfirdn2d crops there)
+            for (int e = tid; e < (bh / 2) * bw; e += 256) {
+                const int k = e / bw, j = e - k * bw;
+                float v[7];
+#pragma unroll
+                for (int t = 0; t < 7; t++) v[t] = s_t[(k + t) * GEO_BMAX + j];
+                float ev = 0.f, od = 0.f;
+#pragma unroll
+                for (int t = 0; t < 6; t++) { ev = __builtin_fmaf(p.fe[t], v[t], ev); od = __builtin_fmaf(p.fo[t], v[t + 1], od); }
+                const bool inx = ux0 + j >= 0 && ux0 + j < wu;
+                const int uy = uy0 + 2 * k;
+                s_u[(2 * k) * (GEO_BMAX + 1) + j] = inx && uy >= 0 && uy < hu ? ev : 0.f;
+                s_u[(2 * k + 1) * (GEO_BMAX + 1) + j] = inx && uy + 1 >= 0 && uy + 1 < hu ? od : 0.f;
+            }
+            __syncthreads();
+        }
+        // 3. bilinear taps -> hi-res block
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const int s = tid + k * 256;
+                if (s < GEO_HI * GEO_HI) {
+                    const int ly = s / GEO_HI, lx = s - ly * GEO_HI;
+                    float v = 0.f;
+                    if (s_off[k] >= 0) {
+                        const float* q = s_u + s_off[k];
+                        const float tx = s_tx[k], ty = s_ty[k];
+                        v = __builtin_fmaf((1.f - tx) * (1.f - ty), q[0], v);
+                        v = __builtin_fmaf(tx * (1.f - ty), q[1], v);
+                        v = __builtin_fmaf((1.f - tx) * ty, q[GEO_BMAX + 1], v);
+                        v = __builtin_fmaf(tx * ty, q[GEO_BMAX + 2], v);
+                    }
+                    s_hi[ly * (GEO_HI + 1) + lx] = v;
+                }
+            }
+        } else {
+#pragma unroll 1
+            for (int s = tid; s < GEO_HI * GEO_HI; s += 256) {
+                const int ly = s / GEO_HI, lx = s - ly * GEO_HI;
+                float v = 0.f;
+                if (X0 + lx < wo && Y0 + ly < ho) {
+                    float ix, iy;
+                    source(X0 + lx, Y0 + ly, ix, iy);
+                    v = geo_hi_direct(p, plane, ix, iy);
+                }
+                s_hi[ly * (GEO_HI + 1) + lx] = v;
+            }
+        }
+        __syncthreads();
+        // 4a. down-sample along x
+        for (int e = tid; e < GEO_HI * GEO_TO; e += 256) {
+            const int r = e / GEO_TO, o = e - r * GEO_TO;
+            const float* q = s_hi + r * (GEO_HI + 1) + 2 * o;
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < 12; m++) acc = __builtin_fmaf(p.fd[m], q[m], acc);
+            s_dh[r * GEO_TO + o] = acc;
+        }
+        __syncthreads();
+        // 4b. ... along y, store
+        {
+            const int oy = tid / GEO_TO, ox = tid - oy * GEO_TO;
+            float acc = 0.f;
+#pragma unroll
+            for (int m = 0; m < 12; m++) acc = __builtin_fmaf(p.fd[m], s_dh[(2 * oy + m) * GEO_TO + ox], acc);
+            if (ox0 + ox < p.w && oy0 + oy < p.h) p.y[((size_t)n * p.c + ch) * p.h * p.w + (size_t)(oy0 + oy) * p.w + ox0 + ox] = acc;
+        }
+        __syncthreads();      // s_dh / s_hi are rewritten by the next channel's step 2a
+    }
+}
+
 }  // namespace
 
 extern "C" int sgv_affine_resample(const float* src, float* dst, const float* theta, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho, int32_t wo,
@@ -194,4 +423,26 @@ extern "C" int sgv_affine_resample(const float* src, float* dst, const float* th
     hipLaunchKernelGGL(affine_resample_adjoint_gather_kernel, sgrid, dim3(256), 0, stream, p);
     hipLaunchKernelGGL(affine_resample_adjoint_scatter_rest_kernel, grid, dim3(256), 0, stream, p);
     return sgv_check_launch("affine_resample_adjoint_gather_kernel");
+}
+
+extern "C" int sgv_ada_geometric(const float* x, float* y, const float* theta, const float* filter12, int32_t n, int32_t c, int32_t h, int32_t w,
+                                 int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, void* stream_) {
+    if (!x || !y || !theta || !filter12) return sgv_fail(SGV_ERR_INVALID_ARG, "ada_geometric: NULL pointer");
+    if (n < 1 || c < 1 || h < 2 || w < 2) return sgv_fail(SGV_ERR_INVALID_ARG, "ada_geometric: sizes must be positive (images of at least 2x2)");
+    if (mx0 < 0 || mx1 < 0 || my0 < 0 || my1 < 0 || mx0 > w - 1 || mx1 > w - 1 || my0 > h - 1 || my1 > h - 1)
+        return sgv_fail(SGV_ERR_INVALID_ARG, "ada_geometric: the reflect margin must lie in [0, size - 1]");
+    if (n > 65535 || (h + GEO_TO - 1) / GEO_TO > 65535) return sgv_fail(SGV_ERR_TOO_LARGE, "ada_geometric: batch / height too large");
+    if ((int64_t)n * c * h * w > INT32_MAX || (int64_t)3 * w > (1 << 24) || (int64_t)3 * h > (1 << 24)) return sgv_fail(SGV_ERR_TOO_LARGE, "ada_geometric: tensors are too large");
+    geom_params p{};
+    p.x = x; p.y = y; p.theta = theta;
+    p.n = n; p.c = c; p.h = h; p.w = w;
+    p.mx0 = mx0; p.mx1 = mx1; p.my0 = my0; p.my1 = my1;
+    // host-readable filter: 12 taps (the caller passes a host pointer: the taps are launch arguments)
+    for (int t = 0; t < 6; t++) { p.fe[t] = 2.f * filter12[11 - 2 * t]; p.fo[t] = 2.f * filter12[10 - 2 * t]; }
+    for (int m = 0; m < 12; m++) p.fd[m] = filter12[m];
+    hipStream_t stream = (hipStream_t)stream_;
+    sgv_launch_scope scope(SGV_K_POINTWISE, stream, 8.0 * n * c * (double)h * w);
+    dim3 grid((unsigned)((w + GEO_TO - 1) / GEO_TO), (unsigned)((h + GEO_TO - 1) / GEO_TO), (unsigned)n);
+    hipLaunchKernelGGL(ada_geometric_forward_kernel, grid, dim3(256), 0, stream, p);
+    return sgv_check_launch("ada_geometric_forward_kernel");
 }

@@ -306,6 +306,7 @@ ABI_SYMBOLS = {
     'sgv_conv3x3_wrw_supported': (c_int, [c_int32, c_int32, c_int32, c_int32, c_int32, c_int]),
     'sgv_time_encode': (c_int, [ctypes.POINTER(TimeEncodeParams), c_void_p]),
     'sgv_affine_resample': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'sgv_ada_geometric': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_gemm_f32': (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
     'sgv_fc': (c_int, [ctypes.POINTER(FcParams), c_void_p]),
     'sgv_multi_nan_to_num_f32': (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int32, c_float, c_float, c_float, c_void_p]),

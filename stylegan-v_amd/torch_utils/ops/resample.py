@@ -55,3 +55,39 @@ def affine_resample(x, theta, out_hw):
     if enabled and x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and not theta.requires_grad:
         return _AffineMap.apply(x, theta, out_hw, None)
     return affine_resample_ref(x, theta.to(x.dtype), out_hw)
+
+
+def ada_geometric_ref(x, theta, f, margin):
+    """The four-pass composition of AugmentPipe's geometric execution (augment.py:270-300) the fused kernel replaces; ``theta`` is the map the resampling
+    step gets, ``margin`` = (mx0, mx1, my0, my1), ``f`` the 12-tap filter."""
+    from . import upfirdn2d
+    n, c, h, w = x.shape
+    pad = f.shape[0] // 4
+    mx0, mx1, my0, my1 = margin
+    y = torch.nn.functional.pad(x, [mx0, mx1, my0, my1], mode='reflect')
+    y = upfirdn2d.upsample2d(y, f, up=2)
+    y = affine_resample(y, theta, ((h + pad * 2) * 2, (w + pad * 2) * 2))
+    return upfirdn2d.downsample2d(y, f, down=2, padding=-pad * 2, flip_filter=True)
+
+
+def ada_geometric_fused_ok(x, f):
+    """One-kernel forward (csrc/resample.hip `ada_geometric_forward_kernel`): fp32 CUDA images that nothing will differentiate, the 12-tap filter."""
+    return (enabled and x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and f.ndim == 1 and f.shape[0] == 12 and min(x.shape[2:]) >= 2
+            and not (x.requires_grad and torch.is_grad_enabled()) and x.shape[0] <= 65535)
+
+
+def ada_geometric(x, theta, f, margin, f_host=None):
+    """y = down2(resample(up2(reflect_pad(x)))) -- ONE launch when ``ada_geometric_fused_ok`` (no gradient: backward passes keep the composition, whose
+    nodes differentiate to any order).  ``f_host``: the filter's taps as a list of floats (they travel as launch arguments; read back once otherwise)."""
+    margin = tuple(int(m) for m in margin)
+    if not ada_geometric_fused_ok(x, f) or theta.requires_grad:
+        return ada_geometric_ref(x, theta, f, margin)
+    import ctypes
+    lib = custom_ops.get_native()
+    taps = (ctypes.c_float * 12)(*(f_host if f_host is not None else f.detach().cpu().tolist()))
+    xc, th = x.detach().contiguous(), theta.detach().contiguous().float()
+    n, c, h, w = xc.shape
+    y = torch.empty_like(xc)
+    with custom_ops.device_guard(xc):
+        custom_ops.check(lib.sgv_ada_geometric(xc.data_ptr(), y.data_ptr(), th.data_ptr(), ctypes.addressof(taps), n, c, h, w, *margin, custom_ops.raw_stream(xc)), lib)
+    return y

@@ -72,12 +72,14 @@ class AugmentPipe(torch.nn.Module):
         self.xint_max, self.scale_std, self.rotate_max, self.aniso_std, self.xfrac_std = xint_max, scale_std, rotate_max, aniso_std, xfrac_std
         self.brightness_std, self.contrast_std, self.hue_max, self.saturation_std = brightness_std, contrast_std, hue_max, saturation_std
         self.register_buffer('Hz_geom', upfirdn2d.setup_filter(SYM6))
+        self._hz_taps = self.Hz_geom.tolist()
         # True: reflect-pad by the worst-case margin (w - 1, h - 1: what the margin below is clamped to anyway) instead of reading the batch's
         # margin back from the device.  Same result (extra padding is never sampled), no device -> host sync, static shapes: what hipGraph
         # capture needs.  The price is a padded image of (3w - 2) x (3h - 2) instead of typically (w + 12) x (h + 12).
         self.static_margin = False
         # True: draw / compose the per-sample parameters on the host and upload the results (module docstring).  Only takes effect for CUDA images outside capture.
         self.host_params = True
+        self.fused_geometric = True   # forward-only calls: the geometric execution as one kernel (ops/resample.py ada_geometric)
         self._p_host = None      # (id of the buffer's storage, its version, 0-d CPU tensor)
         self._const = {}
 
@@ -232,16 +234,27 @@ class AugmentPipe(torch.nn.Module):
             margin = margin + self._c(('moff', w, h, pad), dev, lambda: torch.tensor([pad * 2 - cx, pad * 2 - cy] * 2, dtype=torch.float32))
             margin = margin.clamp(min=0).minimum(self._c(('mmax', w, h), dev, lambda: torch.tensor([w - 1, h - 1] * 2, dtype=torch.float32)))
             mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().tolist())     # one device -> host read per call, as in the reference (:283)
-        images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
+        # the map the resampling step gets (augment.py:285-296): the padded, then 2x up-sampled image -> the (size + 2 pad) * 2 resampled image
+        wu, hu = (w + mx0 + mx1) * 2, (h + my0 + my1) * 2
         g_inv = _translate((mx0 - mx1) / 2, (my0 - my1) / 2, g_inv) @ g_inv
-        images = upfirdn2d.upsample2d(images, self.Hz_geom, up=2)
         s2, s2i = _scale(2, 2, g_inv), _scale(0.5, 0.5, g_inv)
         g_inv = s2 @ g_inv @ s2i
         g_inv = _translate(-0.5, -0.5, g_inv) @ g_inv @ _translate(0.5, 0.5, g_inv)
         out_h, out_w = (h + pad * 2) * 2, (w + pad * 2) * 2
-        g_inv = _scale(2 / images.shape[3], 2 / images.shape[2], g_inv) @ g_inv @ _scale(out_w / 2, out_h / 2, g_inv)
-        images = resample.affine_resample(images, self._upload(g_inv[:, :2, :].contiguous(), images.device), (out_h, out_w))
+        g_inv = _scale(2 / wu, 2 / hu, g_inv) @ g_inv @ _scale(out_w / 2, out_h / 2, g_inv)
+        theta = self._upload(g_inv[:, :2, :].contiguous(), images.device)
+        if self.fused_geometric and resample.ada_geometric_fused_ok(images, self.Hz_geom):
+            # reflect pad -> up -> resample -> down as ONE kernel: no padded / up-sampled / resampled image in memory (csrc/resample.hip); calls that
+            # will be differentiated (the generator's phase, R1) keep the composition below, whose nodes differentiate to any order
+            return resample.ada_geometric(images, theta, self.Hz_geom, (mx0, mx1, my0, my1), f_host=self._filter_taps())
+        images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
+        images = upfirdn2d.upsample2d(images, self.Hz_geom, up=2)
+        images = resample.affine_resample(images, theta, (out_h, out_w))
         return upfirdn2d.downsample2d(images, self.Hz_geom, down=2, padding=-pad * 2, flip_filter=True)
+
+    def _filter_taps(self):
+        """`Hz_geom` as host floats (launch arguments of the fused kernel); a constant of the pipeline, read at construction."""
+        return self._hz_taps
 
 
 def ada_update(augment_pipe, sign_real_mean, batch_size, interval=4, target=0.6, kimg=500):

@@ -25,7 +25,7 @@ def test_header_functions_all_exported_and_bound():
 
 def test_version_and_error_string():
     lib = custom_ops.get_native()
-    assert lib.sgv_version() == 101     # 1.01: terms = 4 (block-scaled fp16 split), sgv_absmax, the *_amax fields of the convolution / GEMM parameter blocks
+    assert lib.sgv_version() == 102     # 1.01: terms = 4 (block-scaled fp16 split), sgv_absmax, the *_amax fields of the convolution / GEMM parameter blocks; 1.02: sgv_ada_geometric
     assert isinstance(lib.sgv_last_error(), bytes)
     assert lib.sgv_launch_count() >= 0
 
@@ -136,6 +136,7 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     q.w, q.terms = 32, 4
     assert lib.sgv_conv3x3_wrw(q, F32, None) == -1 and b'dy_amax' in lib.sgv_last_error()
     assert lib.sgv_absmax(None, 4, F32, None, 0, None) == -1
+    assert lib.sgv_ada_geometric(addr, addr, addr, addr, 1, 1, 8, 8, 8, 0, 0, 0, None) == -1 and b'margin' in lib.sgv_last_error()
     r = custom_ops.PointwiseParams()
     assert lib.sgv_pointwise_small(r, F32, None) == -1
     assert lib.sgv_bias_act_db(custom_ops.BiasActParams(), None, 1, F32, None) == -1 and b'db is NULL' in lib.sgv_last_error()

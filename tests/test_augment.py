@@ -144,3 +144,60 @@ def test_host_side_parameters_match_device_side_parameters_and_follow_p():
     with torch.no_grad():                    # no-grad calls add the colour offset in place
         y = host(x)
     assert torch.isfinite(y).all()
+
+
+def _maps():
+    """Inverse maps G_inv (pixel coordinates about the image centre, as AugmentPipe composes them) covering what ADA draws and what it does not."""
+    import math
+    out = []
+    for ang, sx, sy, tx, ty in ((0.0, 1.0, 1.0, 0.0, 0.0), (0.7, 1.0, 1.0, 3.0, -2.0), (math.pi / 2, 1.0, 1.0, 0.0, 0.0), (math.pi / 4, 1.1, 1.1, 0.0, 0.0), (0.3, -1.0, 1.0, 0.0, 0.0),
+                                (2.4, 0.6, 1.5, 5.5, 1.25), (0.2, 1.7, 1.9, 0.0, 0.0), (1.1, 3.0, 2.5, -4.0, 2.0), (0.0, 1.0, 1.0, 40.0, -33.0), (0.9, 1e-3, 1e-3, 0.0, 0.0),
+                                (0.0, 0.45, 0.5, 0.5, 0.5), (0.1, 6.0, 0.2, 0.0, 0.0)):
+        c, s_ = math.cos(ang), math.sin(ang)
+        out.append([[sx * c, -sy * s_, tx], [sx * s_, sy * c, ty], [0.0, 0.0, 1.0]])
+    return torch.tensor(out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,static', [((12, 9, 64, 64), False), ((12, 3, 40, 56), False), ((12, 2, 37, 23), False), ((12, 3, 48, 32), True)])
+def test_geometric_execution_as_one_kernel_matches_the_four_pass_composition(shape, static):
+    """reflect pad -> 2x up -> affine resample -> 2x down as ONE launch (csrc/resample.hip `ada_geometric_forward_kernel`, forward-only calls) against the
+    four-pass composition it replaces, on maps that keep the tile footprint inside the staging buffers (identity, rotations, mirror, mild scales), maps that do
+    not (zoom-out by 1.7 .. 6: the direct form in the same launch), translations that push the taps outside the padded image, a degenerate scale; image sizes
+    that are not multiples of the tile; the measured margin and the static worst-case margin (what hipGraph capture uses)."""
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).cuda()
+    g_inv = _maps()
+    fused, comp = AugmentPipe(**BGC).cuda(), AugmentPipe(**BGC).cuda()
+    comp.fused_geometric = False
+    fused.static_margin = comp.static_margin = static
+    if static:
+        g_inv = g_inv.cuda()                      # (static margin = the capture path: parameters on the device)
+    with torch.no_grad():
+        before = custom_ops.launch_count()
+        ya = fused._resample(x, g_inv)
+        assert custom_ops.launch_count() - before == 1, 'the forward-only call is one launch'
+        before = custom_ops.launch_count()
+        yb = comp._resample(x, g_inv)
+        assert custom_ops.launch_count() - before >= 4
+    assert ya.shape == yb.shape == x.shape
+    for i in range(shape[0]):
+        assert_close(ya[i], yb[i], atol=3e-5 * max(1.0, yb[i].abs().max().item()), rtol=1e-5, what=f'sample {i} (G_inv {g_inv[i].tolist()})')
+    # a call that will be differentiated keeps the composition (and so its gradients of any order)
+    xg = x.clone().requires_grad_(True)
+    before = custom_ops.launch_count()
+    yg = fused._resample(xg, g_inv)
+    assert custom_ops.launch_count() - before >= 4 and yg.requires_grad
+
+
+@pytest.mark.gpu
+def test_augment_pipe_forward_only_matches_reference_gpu():
+    """The no-grad call (what the discriminator's phases make: fused geometric kernel + streaming colour kernel) against the reference goldens."""
+    pipe = AugmentPipe(**BGC).cuda()
+    x0 = AUG.t('x', device='cuda')
+    with torch.no_grad():
+        for i, pct in enumerate(AUG.meta['percentiles']):
+            before = custom_ops.launch_count()
+            y = pipe(x0, debug_percentile=pct)
+            assert custom_ops.launch_count() - before == 2          # geometric execution + colour
+            assert_close(y, AUG.t(f'y{i}', device='cuda'), atol=1e-4, rtol=1e-4, what=f'forward-only augmented clip at percentile {pct}')
