@@ -254,6 +254,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
             if (p->c_out % TM != 0) sgv_note_variant(SGV_V_conv_s1_half_tile);
             return sgv_check_launch("conv3x3_ws_kernel (16-bit tensors)");
         }
+        wp.y_amax = scope.take_amax_sink();      // (fp32 tensors here)
         hipLaunchKernelGGL(g_ws_kernels[terms_index(p->terms)][pro][epi], dim3((unsigned)kp.grid), dim3(512), WS_LDS_BYTES, stream, wp);
         sgv_note_variant((pro || epi) ? SGV_V_conv_s1_ws_fused : (ep && ep->accumulate) ? SGV_V_conv_s1_ws_accumulate : SGV_V_conv_s1_ws);
         if (p->c_out % TM != 0) sgv_note_variant(SGV_V_conv_s1_half_tile);     // (the last 64-row tile is half full: the 32-channel layers at 1024^2)

@@ -40,6 +40,7 @@ struct conv_ws_params {
     int act;               // 1 linear, 3 lrelu  (bias_act.cu activation indices)
     float alpha, gain, clamp;   // clamp < 0: none
     int accumulate;        // y += result (one no-return fp32 atomic per element) instead of y = result
+    float* y_amax;         // fp32 tensors: max |stored value| as a by-product (sgv_amax_sink; with `accumulate`: of the INCREMENT), or NULL
 };
 
 // PRO: 0 plain x, 1 x * xscale[n,k].
@@ -269,6 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
     if (PRIO > 0) __builtin_amdgcn_s_setprio(PRIO);
     __builtin_amdgcn_s_barrier();   // image 0 ready
     asm volatile("" ::: "memory");
+    unsigned amx = 0;               // max |stored value| of this lane's tiles (bit pattern; IO == 0 only)
     for (int q = 0; q < total; q++) {
         const u32x4* xs = lds + (q & 1) * WS_IMAGE_WORDS;
         const u32x4* ws = xs + XS_WORDS;
@@ -442,6 +444,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                                     v = fmaxf(__builtin_fmaf(v, c0[ei], c1[ei]), __builtin_fmaf(v, c2[ei], c3[ei]));
                                     if (CLAMP) v = __builtin_amdgcn_fmed3f(v, -clamp_hi, clamp_hi);
                                 }
+                                if (IO == 0) amx = sgv_amax_fold(amx, v);
                                 if (A_NOSTORE) asm volatile("" :: "v"(v));
                                 else if (IO != 0) out_store<IO>(p.y, yoff + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
                                 else if (pp.accumulate) atomicAdd(yb + (size_t)(m0 + ei) * plane + (size_t)r * p.w, v);
@@ -458,6 +461,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    if (IO == 0 && pp.y_amax) sgv_amax_commit(amx, pp.y_amax);     // (the four consumer waves; whole waves)
 }
 
 }  // namespace sgv_conv

@@ -352,6 +352,7 @@ struct lanes_params {
     int ep_act;             // 1 linear, 3 lrelu
     float ep_alpha, ep_gain, ep_clamp;
     int chans;
+    float* y_amax;          // fp32 tensors: max |y| as a by-product (sgv_amax_sink; positions a lane computes but does not store count too: still an upper bound), or NULL
 };
 
 template <typename T, int N> __device__ __forceinline__ void store_vec_nt(T* p, const float* v) {
@@ -620,6 +621,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
     const bool store_vec = plane_ok && (ox0 + VEC <= n_main);
     const bool store_any = plane_ok && ox0 < n_main;
     const bool store_xtra = XTRA && plane_ok && (ox0 + VEC == p.out_w - 1);
+    unsigned amx = 0;
 
     for (int oy = oy_a; oy < oy_b; oy += G * DEPTH) {
 #pragma unroll
@@ -675,6 +677,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
                         const bool stored = v < VEC ? (store_vec || (store_any && ox0 + v < n_main)) : store_xtra;
                         if (stored) sum_g += out[v];
                     }
+                    if constexpr (sizeof(T) == 4 && EPI != 1) amx = sgv_amax_fold(amx, out[v]);   // (EPI 1: the tile / asm kernels serve the forward epilogue; one more live register spills here)
                 }
                 T* yrow = yplane + (size_t)(oyd + u) * p.out_w + ox0;
                 if (store_vec) {
@@ -702,6 +705,7 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
             if (p.ep_sum_gv) atomicAdd(p.ep_sum_gv + plane, sum_gv);
         }
     }
+    if constexpr (sizeof(T) == 4 && EPI != 1) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1335,7 +1339,7 @@ bool plan_lanes(const sgv_upfirdn2d_params* p, int dtype, lanes_plan* plan, cons
     static const int lds_env = []() { const char* e = getenv("SGV_LANES_LDS"); return e ? atoi(e) : 1; }();
     lp.lds_share = lds_env;
     lp.ep_scale = nullptr; lp.ep_bias = nullptr; lp.ep_yref = nullptr; lp.ep_sum_g = nullptr; lp.ep_sum_gv = nullptr;
-    lp.ep_act = 1; lp.ep_alpha = 0.f; lp.ep_gain = 1.f; lp.ep_clamp = -1.f; lp.chans = p->in_c;
+    lp.ep_act = 1; lp.ep_alpha = 0.f; lp.ep_gain = 1.f; lp.ep_clamp = -1.f; lp.chans = p->in_c; lp.y_amax = nullptr;
     if (epi) {
         lp.ep_scale = epi->scale; lp.ep_bias = epi->bias; lp.ep_yref = epi->yref; lp.ep_sum_g = epi->sum_g; lp.ep_sum_gv = epi->sum_gv;
         lp.ep_act = epi->act; lp.ep_alpha = epi->alpha; lp.ep_gain = epi->gain; lp.ep_clamp = epi->clamp;
@@ -1529,6 +1533,7 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
     if (plan_lanes(p, dtype, &lplan)) {
         sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
         if (fir_asm_geometry(p, dtype)) return launch_fir_asm(p, lplan.lp, 0, stream);   // the hot FIR geometry at >= 129 output columns: asm row loads, counted waits
+        lplan.lp.y_amax = dtype == SGV_F32 ? scope.take_amax_sink() : nullptr;
         hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
         sgv_note_variant(lplan.lp.lpr_log2 < 6 ? SGV_V_ufd_lanes_seg : SGV_V_ufd_lanes);
         return sgv_check_launch("upfirdn2d_lanes_kernel");
@@ -1592,6 +1597,7 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
     const double bytes = (e->mode == 2 ? 2.0 * nin : nin) * es + (e->mode >= 3 ? 2.0 * nout : nout) * es;
     sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
     if (e->mode == 1 && fir_asm_geometry(p, dtype)) return launch_fir_asm(p, lplan.lp, 1, stream);   // wide forward epilogue: the asm-load kernel
+    lplan.lp.y_amax = (dtype == SGV_F32 && e->mode != 1) ? scope.take_amax_sink() : nullptr;
     hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
     sgv_note_variant(SGV_V_ufd_lanes_fused1 + (e->mode - 1));
     return sgv_check_launch("upfirdn2d_lanes_kernel (fused)");

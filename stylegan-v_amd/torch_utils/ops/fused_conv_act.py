@@ -77,12 +77,22 @@ def _launch_fused(x, weight, styles, dcoefs, bias, act_idx, alpha, gain, clamp, 
     p = custom_ops.Conv3x3Params(x.data_ptr(), weight.data_ptr(), y.data_ptr(), ws.data_ptr(), ws_bytes, n, ci, co, h, w, mode, terms,
                                  _amax.bound(x).data_ptr() if terms == 4 else None, _amax.bound(styles).data_ptr() if (terms == 4 and styles is not None) else None,
                                  _amax.bound(weight).data_ptr() if terms == 4 else None)
+    old_bound = None
     if accumulate_into is not None:
+        old_bound = _amax.cached(accumulate_into)
         _amax.invalidate(accumulate_into)      # written through its raw pointer below
     e = custom_ops.Conv3x3Epilogue(styles.data_ptr() if styles is not None else None, dcoefs.data_ptr() if dcoefs is not None else None,
                                    bias.data_ptr() if bias is not None else None, act_idx, alpha, gain, clamp, 1 if accumulate_into is not None else 0)
     with custom_ops.device_guard(x):
-        custom_ops.check(lib.sgv_conv3x3_fused(p, e, dt, custom_ops.raw_stream(x)), lib)
+        # the store leaves max |stored value| behind (the producer / consumer kernel's epilogue): the bound of a fresh result -- or, with `accumulate_into`, of the
+        # increment: |old + increment| <= bound(old) + bound(increment), one 1-element add instead of a pass over the sum (the skip GEMM's gradients read it)
+        custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_conv3x3_fused(p, e, dt, custom_ops.raw_stream(x))), lib)
+    if accumulate_into is not None:
+        inc = _amax.cached(y)
+        if inc is not None and old_bound is not None:
+            _amax.attach(y, old_bound + inc)
+        else:
+            _amax.invalidate(y)
     return y
 
 

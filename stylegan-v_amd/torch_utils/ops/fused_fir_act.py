@@ -17,6 +17,7 @@ import os
 import torch
 
 from .. import custom_ops
+from . import amax as _amax
 from . import bias_act as _ba
 from . import fused_conv_act as _fca
 from . import modulation as _mod
@@ -76,7 +77,7 @@ class _FusedFirBiasActFn(torch.autograd.Function):
         e = custom_ops.FirEpilogue(1, sc.data_ptr() if sc is not None else None, bi.data_ptr() if bi is not None else None, None, None, None,
                                    _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
         with custom_ops.device_guard(x):
-            from . import amax as _amax      # (y feeds the layer's next convolution: the kernel leaves its magnitude bound behind)
+            # (y feeds the layer's next convolution: the kernel leaves its magnitude bound behind)
             custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_upfirdn2d_fused(_ufd_params(x, f, y, pads, flip, fir_gain), e, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x))), lib)
         ctx.cfg = cfg
         ctx.x_shape = x.shape
@@ -123,7 +124,9 @@ class _FusedFirBiasActFn(torch.autograd.Function):
         e = custom_ops.FirEpilogue(2, sc.data_ptr() if sc is not None else None, None, y.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(),
                                    _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
         with custom_ops.device_guard(dy):
-            custom_ops.check(lib.sgv_upfirdn2d_fused(_ufd_params(dy, f, dx, bpads, not flip, fir_gain), e, _DTYPE_CODES[dy.dtype], custom_ops.raw_stream(dy)), lib)
+            # (dx feeds the data-gradient and weight-gradient convolutions of the layer in front: the kernel leaves its magnitude bound behind)
+            custom_ops.check(_amax.launch_tracking(dx, lambda: lib.sgv_upfirdn2d_fused(_ufd_params(dy, f, dx, bpads, not flip, fir_gain), e, _DTYPE_CODES[dy.dtype],
+                                                                                      custom_ops.raw_stream(dy))), lib)
         d_scale = d_bias = None
         sum_g, sum_gv = sums[0].reshape(n, c), sums[1].reshape(n, c)
         if ctx.has_bias and ctx.needs_input_grad[3]:
