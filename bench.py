@@ -374,6 +374,12 @@ def main():
                 fh.write('\n\n%-90s %8s %12s %12s\n' % ('name (all ops and kernels of 2 steps, by call count)', 'calls', 'cpu ms', 'device ms'))
                 for e in avgs[:300]:
                     fh.write('%-90s %8d %12.3f %12.3f\n' % (e.key[:90], e.count, e.cpu_time_total / 1e3, getattr(e, 'device_time_total', getattr(e, 'cuda_time_total', 0.0)) / 1e3))
+                # the element-wise / copy / reduction ops of torch itself, by input shape: which tensors still take a separate pass
+                fh.write('\n\n%-24s %-110s %6s %10s\n' % ('torch op (2 steps)', 'input shapes', 'calls', 'device ms'))
+                rows = [e for e in prof_t.key_averages(group_by_input_shape=True)
+                        if e.key in ('aten::add_', 'aten::add', 'aten::mul', 'aten::mul_', 'aten::copy_', 'aten::clone', 'aten::sum', 'aten::cat', 'aten::fill_', 'aten::div', 'aten::sub', 'aten::pow', 'aten::mean')]
+                for e in sorted(rows, key=lambda e: -getattr(e, 'device_time_total', 0.0))[:60]:
+                    fh.write('%-24s %-110s %6d %10.3f\n' % (e.key, str(e.input_shapes)[:110], e.count, getattr(e, 'device_time_total', 0.0) / 1e3))
         ts.batch_idx = 0
     # Per-launch HIP events (two event packets around every native launch, ~2,500 launches per step) cost 2.5-4 % of the step when they are
     # recorded on every step (same box: 549-559 img/s with, 572-574 without; profiles/r02_bench_prof_overhead.log).  They are therefore recorded on

@@ -113,7 +113,10 @@ def sample_frame_times(sampling, batch, generator=None, device='cpu'):
         cols.append(offset + span)
     for _ in range(nf - 2):
         cols.append(offset + 1 + torch.rand([batch], generator=g) * (span - 1).clamp(min=0))
-    return torch.stack(cols, dim=1).sort(dim=1).values.to(device)
+    times = torch.stack(cols, dim=1).sort(dim=1).values
+    if torch.device(device).type == 'cuda':      # pinned + non-blocking: a pageable upload waits for the stream to drain (a host <-> device sync per phase)
+        return times.pin_memory().to(device, non_blocking=True)
+    return times.to(device)
 
 
 class TrainStep:
@@ -129,6 +132,9 @@ class TrainStep:
         self.res, self.img_channels = g_kwargs['img_resolution'], g_kwargs['img_channels']
         self.z_dim = self.G.z_dim
         self.gen = torch.Generator().manual_seed(seed * world_size + rank)  # rank-specific latents (training_loop.py:137-139)
+        # the synthetic clips and the latents are drawn ON the device (the reference draws z there, training_loop.py:339; its clips arrive from pinned, prefetched
+        # loader batches): a CPU draw + pageable upload of 19 MB per iteration is 59 ms of host time and a host <-> device sync at every iteration's start
+        self.dev_gen = torch.Generator(device=device).manual_seed(seed * world_size + rank) if torch.device(device).type == 'cuda' else self.gen
         self.batch_size = batch_gpu * world_size
 
         # Multi-GPU: DDP wrappers only add the gradient all-reduce; parameters stay shared with the raw modules.  With hipGraph replay the
@@ -214,11 +220,11 @@ class TrainStep:
     # -- synthetic inputs -------------------------------------------------------------------------
     def synthetic_real_batch(self):
         """uint8-like noise frames scaled as training_loop.py:335: [batch_gpu, F, C, H, W] in [-1, 1]."""
-        raw = torch.randint(0, 256, [self.batch_gpu, self.frames, self.img_channels, self.res, self.res], generator=self.gen, dtype=torch.uint8)
-        return raw.to(self.device).to(torch.float32) / 127.5 - 1
+        raw = torch.randint(0, 256, [self.batch_gpu, self.frames, self.img_channels, self.res, self.res], generator=self.dev_gen, dtype=torch.uint8, device=self.device)
+        return raw.to(torch.float32) / 127.5 - 1
 
     def _latents(self):
-        z = torch.randn([self.batch_gpu, self.z_dim], generator=self.gen).to(self.device)
+        z = torch.randn([self.batch_gpu, self.z_dim], generator=self.dev_gen, device=self.device)
         c = torch.zeros([self.batch_gpu, 0], device=self.device)
         t = sample_frame_times(self.sampling, self.batch_gpu, generator=self.gen, device=self.device)
         return z, c, t
