@@ -227,7 +227,7 @@ def synthesis_workload(args, world, rank, device):
         if 'upfirdn2d_lanes' in fam:
             r = fam['upfirdn2d_lanes']
             achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-            pmc_g = pmc_traffic_per_launch(files=[f'r03_pmc_{args.workload}_FETCH_WRITE.json'])     # this workload's own counter passes, when committed
+            pmc_g = pmc_traffic_per_launch(files=[f'r04_pmc_{args.workload}_FETCH_WRITE.json'])     # this workload's own counter passes, when committed
             roofline = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel (the FIR / 2x up-sampling chain of the synthesis network)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS,
                             unit='GB/s', frac=achieved / HBM_PEAK_GBPS, frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_g[0], traffic_source=pmc_g[1] + ' (reads x2, gfx950 correction)', launches=r['launches'],
                             launches_per_forward=r['launches'] / args.steps, algorithmic_bytes_per_forward=r['bytes'] / args.steps, avg_launch_us=1e3 * r['ms'] / r['launches'],
@@ -254,7 +254,7 @@ def synthesis_workload(args, world, rank, device):
                     if res == 1024 else f'FFS-config generator forward {res}x{res}, {clips} videos x {frames} frames per GPU and step, eval mode, fp32')
         out = dict(metric=f'G synthesis images/sec at {res}^2 ({frames}-frame clips)', value=clips * frames * world * args.steps / elapsed, unit='img/s', n_gpus=world, steps=args.steps,
                    warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
-                   dtype='fp32 I/O + fp32 accumulate; 3x3 convolution products are 2-way-bf16-split where the hand-written kernels serve the channel counts (>= 64 output channels), vendor fp32 below',
+                   dtype='f32 (fp32 tensors + accumulators; 3x3 products = block-scaled 2-way fp16 split on MFMA, vendor-fp32 class, on every layer the hand-written kernels serve (c_out % 32 == 0); vendor fp32 below)',
                    data='synthetic',
                    config=dict(workload=workload, clips_per_gpu=clips, frames_per_clip=frames, parallelism=f'replicas x{world} (no collective)',
                                native_launches_per_forward=(custom_ops.launch_count() - launches0) / (2 * args.steps if not args.no_prof else args.steps)),
