@@ -294,7 +294,9 @@ def main():
     # Companion measurements (same models, other arithmetic / augmentation / regulariser): part of the default single-GPU line; a multi-GPU run measures the
     # scaling of the headline step and leaves them out unless they are asked for (each builds and warms up further models on every rank).
     multi = args.gpus > 1
-    for name, dflt in (('ada_steps', 8), ('bf16_steps', 6), ('strict_steps', 8), ('lowp_steps', 8), ('pl_steps', 8), ('split3_steps', 8)):
+    # 10 steps each from iteration 0: one R1 iteration in ten, the share the 20-step headline window has (an R1 iteration costs ~2x a plain one: with 8 steps a
+    # companion would carry 1/8 and read 1.5 % low against the headline); the PL companion a whole period of its schedule (Greg every 4th, Dreg every 16th)
+    for name, dflt in (('ada_steps', 10), ('bf16_steps', 10), ('strict_steps', 10), ('lowp_steps', 10), ('pl_steps', 16), ('split3_steps', 10)):
         if getattr(args, name) is None:
             setattr(args, name, 0 if multi else dflt)
 

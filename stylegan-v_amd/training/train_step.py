@@ -218,6 +218,11 @@ class TrainStep:
         self.loss.video_consistent_aug = augment == 'ada'
 
     # -- synthetic inputs -------------------------------------------------------------------------
+    def reseed_inputs(self, seed):
+        """Restart the streams the latents, frame times and synthetic clips are drawn from (two runs that are to see the same inputs)."""
+        self.gen = torch.Generator().manual_seed(seed)
+        self.dev_gen = torch.Generator(device=self.device).manual_seed(seed) if self.device.type == 'cuda' else self.gen
+
     def synthetic_real_batch(self):
         """uint8-like noise frames scaled as training_loop.py:335: [batch_gpu, F, C, H, W] in [-1, 1]."""
         raw = torch.randint(0, 256, [self.batch_gpu, self.frames, self.img_channels, self.res, self.res], generator=self.dev_gen, dtype=torch.uint8, device=self.device)

@@ -110,8 +110,12 @@ def test_affine_resample_adjoint_gather_form_covers_every_map():
     assert_close(y, yr, atol=2e-5 * yr.abs().max().item(), rtol=1e-5, what='S x')
     for i in range(n):
         assert_close(gx[i], gr[i], atol=3e-5 * max(gr[i].abs().max().item(), 1.0), rtol=1e-5, what=f'S^T v, sample {i} (theta {thetas[i]})')
-    lhs, rhs = (y.double().cpu() * v.double()).sum().item(), (x0.double() * gx.double().cpu()).sum().item()
-    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+    # <S x, v> == <x, S^T v>: both sides are sums of ~3e5 products of O(1) values that cancel to O(1) -- the fp32 roundings of y and gx enter at
+    # ~1e-7 x sqrt(sum of squared terms), and the atomics kernel of the degenerate samples adds in a different order from run to run (measured spread of
+    # lhs - rhs: 7e-5 .. 1e-4 with the terms' root-sum-square at ~5e2; profiles/r04_c18_adjoint_repeats.log), so the bound is relative to that scale
+    terms = y.double().cpu() * v.double()
+    lhs, rhs = terms.sum().item(), (x0.double() * gx.double().cpu()).sum().item()
+    assert abs(lhs - rhs) <= 2e-6 * terms.square().sum().sqrt().item()
 
 
 @pytest.mark.gpu

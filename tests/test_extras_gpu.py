@@ -461,7 +461,7 @@ def test_hipgraph_capture_iteration_applies_exactly_one_update():
     from stylegan_v_amd.training.train_step import sample_frame_times
     real_t = sample_frame_times(eager.sampling, eager.batch_gpu, device='cuda')
     for ts in (eager, graphed):
-        ts.gen = torch.Generator().manual_seed(1234)      # the same latents on both sides
+        ts.reseed_inputs(1234)                            # the same latents on both sides
         ts.batch_idx = 1                                  # an iteration without the regularisation phases: Gmain, Dmain only
         torch.manual_seed(7)                              # the device generator draws the motion noise / phase dropout
         assert ts.step(real_img=real, real_t=real_t) == ['Gmain', 'Dmain']
@@ -575,7 +575,7 @@ def test_path_length_regularisation_step_runs_with_the_fused_epilogues_on():
     before = custom_ops.kernel_variant_counts()
     outs = []
     for ts, fused in ((a, True), (b, False)):
-        ts.gen = torch.Generator().manual_seed(99)
+        ts.reseed_inputs(99)
         torch.manual_seed(5)
         fused_fir_act.enabled = fused
         try:
