@@ -54,7 +54,7 @@ constexpr int FC_WAVES = 16;     // at most
 // FC_UNROLL = k steps whose loads are issued together
 template <int AK, int BK, int FC_UNROLL>
 __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
-    extern __shared__ float red[];          // [waves - 1][32 * 32]
+    extern __shared__ float red[];          // [max(waves - 1, 1)][32 * 32]
     __shared__ float rowstat[32];
     const int waves = blockDim.x >> 6;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -127,25 +127,35 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
         v += __shfl_xor(v, 32, 64);
         if (lane < 32) atomicAdd(&rowstat[lane], v);
     }
-    // C layout of the 32x32 MFMA: col (n) = lane & 31, row (m) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
-    if (wave > 0) {
+    // C layout of the 32x32 MFMA: col (n) = lane & 31, row (m) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5).  Every wave parks its partial tile in LDS; then ALL
+    // threads share the cross-wave sum and the epilogue, one output element per thread and pass.  With the sum on wave 0 alone (16 elements x 15 LDS reads per
+    // lane) the tail of a K = 512 launch outlasted its k loop: 19.4 -> 13.6 us per launch over the 118 dense launches of a training iteration, 2.28 -> 1.59 ms
+    // (profiles/r04_c19_fc_epilogue_ab.json).
+    // (waves - 1 slots -- 60 KiB at sixteen waves, inside the default dynamic-LDS limit -- : waves 1.. park theirs, wave 0 adds its own into slot 0 behind the
+    // first barrier; a single-wave launch keeps everything in registers' place: slot 0 is then its only tile)
+    const int slots = waves > 1 ? waves - 1 : 1;
+    if (wave > 0 || waves == 1) {
 #pragma unroll
-        for (int e = 0; e < 16; e++) red[(wave - 1) * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kk) * 32 + r] = acc0[e];
+        for (int e = 0; e < 16; e++) red[(waves == 1 ? 0 : wave - 1) * 1024 + ((e & 3) + 8 * (e >> 2) + 4 * kk) * 32 + r] = acc0[e];
     }
     __syncthreads();
-    if (wave != 0) return;
-    if (p.colsum && blockIdx.x == 0 && lane < 32 && m0 + lane < p.m) p.colsum[m0 + lane] = rowstat[lane] * p.bgain;
-    const float bias = (p.bias && b_ok) ? p.bias[bn] * p.bgain : 0.f;
+    if (wave == 0 && waves > 1) {
 #pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int ml = (e & 3) + 8 * (e >> 2) + 4 * kk;
-        float v = acc0[e];
-        for (int w = 0; w < waves - 1; w++) v += red[w * 1024 + ml * 32 + r];
+        for (int e = 0; e < 16; e++) red[((e & 3) + 8 * (e >> 2) + 4 * kk) * 32 + r] += acc0[e];
+    }
+    if (waves > 1) __syncthreads();
+    if (p.colsum && blockIdx.x == 0 && t < 32 && m0 + t < p.m) p.colsum[m0 + t] = rowstat[t] * p.bgain;
+    for (int idx = t; idx < 1024; idx += (int)blockDim.x) {
+        const int ml = idx >> 5, rr = idx & 31;
+        const int cn = n0 + rr;
+        float v = red[idx];
+        for (int w = 1; w < slots; w++) v += red[w * 1024 + idx];
         if (p.normalize) v *= 1.0f / sqrtf(rowstat[ml] / (float)p.k + 1e-8f);
+        const float bias = (p.bias && cn < p.n) ? p.bias[cn] * p.bgain : 0.f;
         v = v * p.wgain + bias;
         if (p.epilogue_act) v = ((p.act == 3 && !(v > 0.f)) ? v * p.alpha : v) * p.gain;
-        if (m0 + ml < p.m && b_ok) {
-            float* cq = p.c + bz * p.scb + (size_t)(m0 + ml) * p.scm + (size_t)bn * p.scn;
+        if (m0 + ml < p.m && cn < p.n) {
+            float* cq = p.c + bz * p.scb + (size_t)(m0 + ml) * p.scm + (size_t)cn * p.scn;
             *cq = p.accumulate ? *cq + v : v;
         }
     }
@@ -168,10 +178,12 @@ static int sgv_fc_launch(const sgv_fc_params* q, hipStream_t stream, bool accoun
     // motion network's conv1d layers 359 -> 631 us in the data-gradient form), kept for the lab only
     static const int unroll_env = [] { const char* e = getenv("SGV_FC_UNROLL"); return e ? atoi(e) : 1; }();
     static const int waves_env = [] { const char* e = getenv("SGV_FC_WAVES"); return e ? atoi(e) : 0; }();     // 0: follow K
-    const int unroll = unroll_env == 1 ? 1 : 4;
     const int steps = (q->k + 7) / 8;
+    // (all k steps of a wave in flight at once for K <= 512 -- SGV_FC_UNROLL=4 -- measured no better with either epilogue: 1.72 vs 1.60 ms of dense layers per
+    // iteration, profiles/r04_c19_fc_epilogue_ab.json)
+    const int unroll = unroll_env == 1 ? 1 : 4;
     const int waves = waves_env > 0 ? std::min(waves_env, sgv_fck::FC_WAVES) : std::max(1, std::min(sgv_fck::FC_WAVES, (steps + unroll - 1) / unroll));
-    const size_t lds = (size_t)(waves - 1) * 1024 * sizeof(float);
+    const size_t lds = (size_t)std::max(waves - 1, 1) * 1024 * sizeof(float);
     dim3 grid((unsigned)((q->n + 31) / 32), (unsigned)((q->m + 31) / 32), (unsigned)batch), block(waves * 64);
     const bool ak = q->a_stride_k == 1, bk = q->b_stride_k == 1;
     auto go = [&] {
