@@ -47,6 +47,7 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+TIMED_FAMILIES = ('conv3x3_s1', 'upfirdn2d_lanes')      # kernel families whose launches are bracketed by HIP events inside the timed region
 PMC_FILES = ['r04_pmc_bench_step_FETCH_WRITE.json']   # collected by tools/gpu_recipes/pmc_fetch_write_passes.sh (separate --pmc passes of this command)
 
 
@@ -383,44 +384,53 @@ def main():
                 for e in sorted(rows, key=lambda e: -getattr(e, 'device_time_total', 0.0))[:60]:
                     fh.write('%-24s %-110s %6d %10.3f\n' % (e.key, str(e.input_shapes)[:110], e.count, getattr(e, 'device_time_total', 0.0) / 1e3))
         ts.batch_idx = 0
-    # Per-launch HIP events (two event packets around every native launch, ~2,500 launches per step) cost 2.5-4 % of the step when they are
-    # recorded on every step (same box: 549-559 img/s with, 572-574 without; profiles/r02_bench_prof_overhead.log).  They are therefore recorded on
-    # the SECOND HALF of the timed steps only: with the default 20 steps that is steps 10-19, which hold one R1 iteration in ten like the whole
-    # window (steps 0 and 16), so the kernel mix of the sample is the mix of the window.  `value` is still the wall time of all K steps.
+    # Per-launch HIP events (two event packets around a native launch) cost 2.5-4 % of the step when every one of the ~550 launches per iteration carries them on
+    # every step (profiles/r02_bench_prof_overhead.log), 1.2-1.4 % on half of the steps (round 4: 580.4 vs 588.5 img/s).  Inside the timed region they are therefore
+    # recorded (i) on the SECOND HALF of the timed steps only -- with the default 20 steps that is steps 10-19, which hold one R1 iteration in ten like the whole
+    # window (steps 0 and 16), so the kernel mix of the sample is the mix of the window -- and (ii) for the two kernel families the roofline objects are about
+    # (TIMED_FAMILIES: the dominant stride-1 3x3 kernel and the upfirdn2d family, ~120 launches per iteration).  The full per-family / per-variant tables come from
+    # a fully instrumented pass of their own behind the timed region.  `value` is the wall time of all K steps.
     prof_from = args.steps // 2
     barrier()
     t0 = time.perf_counter()
     phases_run = {}
     for i_step in range(args.steps):
         if not args.no_prof and i_step == prof_from:
+            custom_ops.prof_families(TIMED_FAMILIES)      # inside the timed region: the dominant kernel and the FIR family only (all 554 launches per iteration: 1.4 % of the step)
             custom_ops.prof_enable(1 << 17)
         for name in ts.step():
             phases_run[name] = phases_run.get(name, 0) + 1
     barrier()
     elapsed = time.perf_counter() - t0
     launches = custom_ops.launch_count() - launches0
-    prof = None
-    ufd_by_size = None
-    by_variant = None
-    if not args.no_prof:
+    def collect_tables():
+        """Stop recording and fold the per-launch records: per family, per kernel variant, and the upfirdn2d launches grouped by size."""
         custom_ops.prof_disable()
         records = custom_ops.prof_collect_records(1 << 17, with_variant=True)
-        prof = {name: dict(launches=0, ms=0.0, bytes=0.0, flops=0.0) for name in custom_ops.SGV_K_NAMES}
-        sizes = {}
-        by_variant = {}
+        custom_ops.prof_families(None)
+        table = {name: dict(launches=0, ms=0.0, bytes=0.0, flops=0.0) for name in custom_ops.SGV_K_NAMES}
+        sizes, variants_ = {}, {}
         for fam, ms, nbytes, nflops, variant in records:
-            e = prof[fam]
+            e = table[fam]
             e['launches'] += 1; e['ms'] += ms; e['bytes'] += nbytes; e['flops'] += nflops
-            v = by_variant.setdefault(variant or fam, dict(launches=0, ms=0.0, bytes=0.0, flops=0.0))
+            v = variants_.setdefault(variant or fam, dict(launches=0, ms=0.0, bytes=0.0, flops=0.0))
             v['launches'] += 1; v['ms'] += ms; v['bytes'] += nbytes; v['flops'] += nflops
             if fam == 'upfirdn2d_lanes':
                 g = sizes.setdefault(int(nbytes), [0, 0.0])
                 g[0] += 1; g[1] += ms
         for key in ('launches', 'ms', 'bytes', 'flops'):      # 'conv3x3' is the whole family incl. its largest member 'conv3x3_s1' (as custom_ops.prof_collect)
-            prof['conv3x3'][key] += prof['conv3x3_s1'][key]
+            table['conv3x3'][key] += table['conv3x3_s1'][key]
         # the upfirdn2d launches of the sample grouped by their algorithmic byte count (= by layer size and fused mode): where the size-weighted mean comes from
-        ufd_by_size = [dict(algorithmic_MB=b / 1e6, launches=n, avg_us=1e3 * ms / n, GBps=b * n / (ms * 1e-3) / 1e9, share_of_family_time=ms / max(prof['upfirdn2d_lanes']['ms'], 1e-9))
-                       for b, (n, ms) in sorted(sizes.items(), reverse=True)]
+        by_size = [dict(algorithmic_MB=b / 1e6, launches=n, avg_us=1e3 * ms / n, GBps=b * n / (ms * 1e-3) / 1e9, share_of_family_time=ms / max(table['upfirdn2d_lanes']['ms'], 1e-9))
+                   for b, (n, ms) in sorted(sizes.items(), reverse=True)]
+        return table, variants_, by_size
+
+    prof = None
+    prof_timed = None          # the families recorded INSIDE the timed region (TIMED_FAMILIES): what `roofline` / `roofline_upfirdn2d` are computed from
+    ufd_by_size = None
+    by_variant = None
+    if not args.no_prof:
+        prof_timed, _, ufd_by_size = collect_tables()
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
     multi_gpu = None
@@ -447,7 +457,7 @@ def main():
     frames_total = global_batch * args.frames * args.steps
     value = frames_total / elapsed
 
-    # The same K steps once more WITHOUT the per-launch event recording (`value` carries the recorder's own cost on half of its steps, 1.5-2 %):
+    # The same K steps once more WITHOUT any per-launch event recording (`value` carries the recorder's cost for two kernel families on half of its steps):
     # same schedule start, same bracket, MAX over ranks -> `value_no_prof`.
     value_no_prof = None
     if not args.no_prof and args.clean_steps != 0:
@@ -464,6 +474,22 @@ def main():
         value_no_prof = dict(value=global_batch * args.frames * k_clean / float(t_c.item()), ms_per_step=1e3 * float(t_c.item()) / k_clean, steps=k_clean)
     elif args.no_prof:
         value_no_prof = dict(value=value, ms_per_step=1e3 * elapsed / args.steps, steps=args.steps)
+    # The full per-family / per-variant tables (`kernels`, `kernels_by_variant`, `roofline_conv_family`): every launch bracketed, in a pass of its own over the
+    # same schedule positions as the recorded half of the timed window (iterations prof_from .. steps - 1), outside every timed region.
+    if not args.no_prof:
+        ts.batch_idx = prof_from
+        barrier()
+        custom_ops.prof_enable(1 << 17)
+        for _ in range(args.steps - prof_from):
+            ts.step()
+        barrier()
+        prof, by_variant, _ = collect_tables()
+        for fam in TIMED_FAMILIES:              # the two families of the timed region keep their in-region figures in the family table
+            if prof_timed[fam]['launches']:
+                for key in ('launches', 'ms', 'bytes', 'flops'):
+                    if fam == 'conv3x3_s1':
+                        prof['conv3x3'][key] += prof_timed[fam][key] - prof[fam][key]
+                    prof[fam][key] = prof_timed[fam][key]
 
     # Strict-fp32 companion (the reference's fp32 mode is allow_tf32=False, training_loop.py:129,141-142): the same step with every
     # 3x3 convolution on the vendor library's fp32 kernels instead of the split-bf16 matrix-pipe kernels.  Same schedule start

@@ -541,6 +541,9 @@ typedef struct sgv_prof_entry {
 
 int sgv_prof_enable(int32_t max_records); /* allocates the event pool (host side only) */
 int sgv_prof_disable(void);
+/* Bracket only the launches of the families whose bit (1 << enum sgv_kernel_family) is set; 0 = all (the default).  bench.py times the dominant kernels inside
+ * its timed region with two families enabled (two events per launch of 554 launches per iteration cost 1.4 % of the step) and the full table in a pass of its own. */
+int sgv_prof_families(uint64_t mask);
 int sgv_prof_collect(sgv_prof_entry* out /* [SGV_K_COUNT] */); /* syncs events, resets pool */
 /* The same, launch by launch (in launch order) instead of summed per family: fills at most `max_records` entries, returns the number of recorded
  * launches (which may exceed max_records), or a negative SGV_ERR_* code.  Resets the pool like sgv_prof_collect. */

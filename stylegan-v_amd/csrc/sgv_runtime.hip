@@ -49,6 +49,7 @@ static std::mutex g_prof_mu;
 static std::vector<prof_record> g_prof_pool;
 static std::atomic<int> g_prof_next{0};
 static std::atomic<bool> g_prof_on{false};
+static std::atomic<uint64_t> g_prof_mask{~0ull};     // bit f: launches of family f are bracketed
 static void prof_note_variant(int v) {
     const int i = g_scope_slot;
     if (i >= 0 && i < (int)g_prof_pool.size() && g_prof_pool[i].variant < 0) g_prof_pool[i].variant = v;   // the first note of a call names it
@@ -70,6 +71,11 @@ extern "C" int sgv_prof_enable(int32_t max_records) {
 
 extern "C" int sgv_prof_disable(void) {
     g_prof_on = false;
+    return SGV_OK;
+}
+
+extern "C" int sgv_prof_families(uint64_t mask) {
+    g_prof_mask = mask ? mask : ~0ull;
     return SGV_OK;
 }
 
@@ -142,7 +148,7 @@ __global__ __launch_bounds__(256) void sgv_amax_reduce_kernel(unsigned* sink) {
 sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count) : slot(-1), stream(s), amax_sink(g_amax_sink), amax_taken(nullptr) {
     g_amax_sink = nullptr;
     if (count) g_launches.fetch_add(1, std::memory_order_relaxed);
-    if (!g_prof_on.load(std::memory_order_relaxed)) return;
+    if (!g_prof_on.load(std::memory_order_relaxed) || !((g_prof_mask.load(std::memory_order_relaxed) >> family) & 1ull)) return;
     int i = g_prof_next.fetch_add(1);
     if (i >= (int)g_prof_pool.size()) return;  // pool exhausted: launch is simply not recorded
     prof_record& r = g_prof_pool[i];

@@ -313,6 +313,7 @@ ABI_SYMBOLS = {
     'sgv_multi_scale_f32': (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_float), c_int32, c_void_p]),
     'sgv_prof_enable': (c_int, [c_int32]),
     'sgv_prof_disable': (c_int, []),
+    'sgv_prof_families': (c_int, [ctypes.c_uint64]),
     'sgv_prof_collect': (c_int, [ctypes.POINTER(ProfEntry)]),
     'sgv_prof_collect_records': (c_int, [ctypes.POINTER(ProfRecord), c_int32]),
     'sgv_launch_count': (c_int64, []),
@@ -390,6 +391,14 @@ def prof_enable(max_records=1 << 16):
 
 def prof_disable():
     check(get_native().sgv_prof_disable())
+
+
+def prof_families(names=None):
+    """Bracket only the launches of the named kernel families (SGV_K_NAMES); None / empty: all of them (the default)."""
+    mask = 0
+    for name in names or ():
+        mask |= 1 << SGV_K_NAMES.index(name)
+    check(get_native().sgv_prof_families(mask))
 
 
 def prof_collect_records(max_records=1 << 16, with_variant=False):
