@@ -219,11 +219,27 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     if (p->terms == 4) { kp.x_amax = p->x_amax; kp.x_amax2 = p->x_amax2; kp.w_amax = w_amax; }
     const int small = big_image(p->h, p->w) ? 0 : small_samples(p->n, p->h, p->w);
     kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * tiles_m(p->c_out);
+    if (small) {
+        // fewer tiles than half the CUs: share every tile's input channels out over 2 / 4 / 8 workgroups (partial sums meet in a zeroed y through atomics).
+        // SGV_CONV_SMALL_KSPLIT = 1 switches it off, 2 / 4 / 8 forces a split wherever the chunk count allows it.
+        static const int forced = [] { const char* e = getenv("SGV_CONV_SMALL_KSPLIT"); return e ? atoi(e) : 0; }();
+        const int chunks = p->c_in / KC;
+        int ks = 1;
+        if (forced > 1) { if (chunks % forced == 0) ks = forced; }
+        else if (forced == 0) {
+            for (int cand = 8; cand > 1; cand >>= 1)
+                if (chunks % cand == 0 && chunks / cand >= 2 && (int64_t)kp.tiles * cand <= 2 * g_cus) { ks = cand; break; }
+        }
+        kp.ksplit = ks;
+        kp.tiles *= ks;
+    }
     kp.grid = std::min(kp.tiles, g_cus);
     const double elems = (double)p->n * p->h * p->w;
     const double es = io16(dtype) ? 2.0 : 4.0;
     sgv_launch_scope scope(small ? SGV_K_CONV3X3 : SGV_K_CONV3X3_S1, stream, es * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9);
     if (small) {
+        if (kp.ksplit > 1 && hipMemsetAsync(p->y, 0, (size_t)p->n * p->c_out * p->h * p->w * sizeof(float), stream) != hipSuccess)
+            return sgv_fail(SGV_ERR_LAUNCH, "conv3x3: clearing y for the split-K small-image kernel failed");
         if (p->w == 16) {
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
             else if (p->terms == 3) hipLaunchKernelGGL((conv3x3_small_kernel<3, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);

@@ -59,6 +59,8 @@ struct conv_params {
     const float* x_amax;
     const float* x_amax2;
     const float* w_amax;
+    int ksplit;            // conv3x3_small_kernel: the input channels of a tile are shared out over `ksplit` workgroups (tiles counts them), which ADD their partial
+                           // sums into a zeroed y with no-return fp32 atomics; 0 / 1: one workgroup per tile, plain stores
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
@@ -361,22 +363,25 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
         ypix[r] = q;   // pixel index inside the tile: sample = q / SW^2, offset inside the sample plane = q % SW^2
     }
 
+    // Few tiles (a rank's 24 ... 96 frames at 8^2: 24 ... 96 tiles for 256 CUs): a tile's K loop is shared out over `ksplit` workgroups -- unit u is K slice
+    // u % ksplit of tile u / ksplit -- and the partial sums meet in y through atomics (the launcher zeroes y first).
+    const int ksplit = p.ksplit > 1 ? p.ksplit : 1, cps = chunks / ksplit;
     int tile = xcd_swizzle(blockIdx.x, gridDim.x);
     if (tile >= p.tiles) return;
-    int mt = tile % mts, n0 = (tile / mts) * C::S;
-    int c = 0;
+    int mt = (tile / ksplit) % mts, n0 = ((tile / ksplit) / mts) * C::S;
+    int c = (tile % ksplit) * cps, c_end = c + cps;
     __syncthreads();   // zero fill complete
     {
         small_stage s;
-        load_chunk(n0, mt, 0, s);
+        load_chunk(n0, mt, c, s);
         store_chunk(s);
         __syncthreads();
     }
     while (true) {
         int ntile = tile, nc = c + 1;
-        if (nc == chunks) { nc = 0; ntile = tile + p.grid; }
+        if (nc == c_end) { ntile = tile + p.grid; nc = (ntile % ksplit) * cps; }
         const bool more = ntile < p.tiles;
-        const int nmt = ntile % mts, nn0 = (ntile / mts) * C::S;
+        const int nmt = (ntile / ksplit) % mts, nn0 = ((ntile / ksplit) / mts) * C::S;
         small_stage s;
         if (more) load_chunk(nn0, nmt, nc, s);
 
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
                     acc[r][hf] = mma16<TERMS>(a[hf][0], b_hi[r], acc[r][hf]);
         }
 
-        if (c == chunks - 1) {
+        if (c == c_end - 1) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 float* yb = p.y + ((size_t)(n0 + ypix[r] / PLANE_PX) * p.m + mt * TM) * plane + ypix[r] % PLANE_PX;
@@ -424,7 +429,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
-                        yb[(size_t)m * plane] = TERMS == 4 ? __builtin_ldexpf(acc[r][hf][e], unscale_exponent(ex, ew)) : acc[r][hf][e];
+                        const float v = TERMS == 4 ? __builtin_ldexpf(acc[r][hf][e], unscale_exponent(ex, ew)) : acc[r][hf][e];
+                        if (ksplit > 1) atomicAdd(yb + (size_t)m * plane, v);
+                        else yb[(size_t)m * plane] = v;
                         acc[r][hf][e] = 0.f;
                     }
             }
@@ -434,6 +441,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
         store_chunk(s);
         __syncthreads();
         tile = ntile; c = nc; mt = nmt; n0 = nn0;
+        if (c == (tile % ksplit) * cps) c_end = c + cps;      // a new unit starts: its own K slice
     }
 }
 

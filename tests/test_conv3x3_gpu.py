@@ -32,6 +32,7 @@ def _rel(a, ref):
 
 @pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (1, 16, 128, 16, 64), (3, 128, 64, 48, 32), (1, 80, 192, 32, 96), (5, 32, 64, 16, 32),
                                           (4, 64, 128, 16, 16), (6, 32, 64, 16, 16), (16, 48, 64, 8, 8), (8, 128, 192, 8, 8),
+                                          (8, 512, 128, 8, 8), (24, 256, 64, 16, 16), (12, 384, 192, 16, 16),     # few tiles, many chunks: K shared out over 8 / 8 / 4 workgroups (atomics)
                                           (2, 32, 32, 32, 64), (1, 64, 32, 16, 32), (2, 48, 96, 32, 32), (3, 32, 32, 16, 32)])     # c_out % 32: a half-full last tile
 @pytest.mark.parametrize('transposed', [False, True])
 def test_conv3x3_matches_fp64(n, ci, co, h, w, transposed):
