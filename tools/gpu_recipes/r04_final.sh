@@ -13,7 +13,7 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_bench_$c -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-prof $OFF > $GRAFT_REPO_ROOT/$OUT/pmc_bench_$c.log 2>&1 )
 done
-python tools/pmc_summary.py $OUT $OUT/r04_pmc_bench_step_FETCH_WRITE.json "e9087f8" > $OUT/pmc_summary.log 2>&1; tail -2 $OUT/pmc_summary.log | cut -c1-300
+python tools/pmc_summary.py $OUT $OUT/r04_pmc_bench_step_FETCH_WRITE.json "39d8a60" > $OUT/pmc_summary.log 2>&1; tail -2 $OUT/pmc_summary.log | cut -c1-300
 cp $OUT/r04_pmc_bench_step_FETCH_WRITE.json profiles/
 rm -rf $OUT/pmc_bench_FETCH_SIZE $OUT/pmc_bench_WRITE_SIZE
 # 3. the driver's command
@@ -34,7 +34,7 @@ SGV_CONV_TERMS=1 SGV_WRW_TERMS=1 timeout 300 python bench.py --batch-gpu 8 --gra
 for c in FETCH_SIZE WRITE_SIZE; do
   ( cd /tmp && timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$OUT/g1024/pmc_bench_$c -- python $GRAFT_REPO_ROOT/bench.py --workload g1024 --steps 2 --warmup 1 --cpu-seconds 0 --no-prof > $GRAFT_REPO_ROOT/$OUT/pmc_g1024_$c.log 2>&1 )
 done
-python tools/pmc_summary.py $OUT/g1024 $OUT/r04_pmc_g1024_FETCH_WRITE.json "e9087f8" > $OUT/pmc_summary_g1024.log 2>&1
+python tools/pmc_summary.py $OUT/g1024 $OUT/r04_pmc_g1024_FETCH_WRITE.json "39d8a60" > $OUT/pmc_summary_g1024.log 2>&1
 cp $OUT/r04_pmc_g1024_FETCH_WRITE.json profiles/ 2>/dev/null
 rm -rf $OUT/g1024
 timeout 400 python bench.py --workload g1024 --cpu-seconds 10 > $OUT/bench_g1024.json 2> $OUT/bench_g1024.err
