@@ -49,17 +49,25 @@ def _launch(a, sam, sak, b, sbk, sbn, c, scm, scn, m, n, k, a_ref=None, bias=Non
         custom_ops.check(lib.sgv_fc(p, custom_ops.raw_stream(c)), lib)
 
 
+def _rows(x):
+    """x as the kernel can address it without a copy: rows of contiguous floats at any 16-byte-multiple stride (`ws[:, i]` of the [N, num_ws, w_dim] style
+    tensor: 26 affines per synthesis pass each made their own contiguous copy before), else a contiguous copy."""
+    if x.dim() == 2 and x.stride(1) == 1 and x.stride(0) >= x.shape[1] and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+        return x
+    return x.contiguous()
+
+
 class _DenseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, cfg):
         wgain, bgain, act, normalize, again = cfg
         spec = _ba.activation_funcs[act]
-        xc, wc = x.contiguous(), weight.contiguous()
+        xc, wc = _rows(x), weight.contiguous()
         bc = bias.contiguous().float() if bias is not None else None
         m, k = xc.shape
         n = wc.shape[0]
         y = torch.empty([m, n], dtype=torch.float32, device=x.device)
-        _launch(xc, k, 1, wc, 1, k, y, n, 1, m, n, k, bias=bc, normalize=normalize, act=spec.cuda_idx, alpha=float(spec.def_alpha), gain=again,
+        _launch(xc, xc.stride(0), 1, wc, 1, k, y, n, 1, m, n, k, bias=bc, normalize=normalize, act=spec.cuda_idx, alpha=float(spec.def_alpha), gain=again,
                 wgain=wgain, bgain=bgain, epilogue_act=True)
         ctx.cfg = cfg
         ctx.save_for_backward(x, weight, bias, y)
@@ -79,7 +87,7 @@ class _DenseFn(torch.autograd.Function):
                 grads = iter(torch.autograd.grad(y2, ins, dy, create_graph=torch.is_grad_enabled(), allow_unused=True))
             return tuple(next(grads) if (need and t is not None) else None for t, need in zip((x, weight, bias), ctx.needs_input_grad[:3])) + (None,)
         spec = _ba.activation_funcs[act]
-        dyc, xc, wc = dy.contiguous(), x.contiguous(), weight.contiguous()
+        dyc, xc, wc = dy.contiguous(), _rows(x), weight.contiguous()
         m, k = xc.shape
         n = wc.shape[0]
         common = dict(a_ref=y, act=spec.cuda_idx, alpha=float(spec.def_alpha), gain=again, wgain=wgain)
@@ -90,7 +98,7 @@ class _DenseFn(torch.autograd.Function):
         if ctx.needs_input_grad[1] or (bias is not None and ctx.needs_input_grad[2]):
             dw = torch.empty([n, k], dtype=torch.float32, device=dy.device)
             rowsum = torch.empty([n], dtype=torch.float32, device=dy.device) if bias is not None and ctx.needs_input_grad[2] else None
-            _launch(dyc, 1, n, xc, k, 1, dw, k, 1, n, k, m, rowsum=rowsum, bgain=bgain, **common)   # dW[n,k] = sum_m dz[m,n] x[m,k]; db[n] = bg * sum_m dz[m,n]
+            _launch(dyc, 1, n, xc, xc.stride(0), 1, dw, k, 1, n, k, m, rowsum=rowsum, bgain=bgain, **common)   # dW[n,k] = sum_m dz[m,n] x[m,k]; db[n] = bg * sum_m dz[m,n]
             if rowsum is not None:
                 db = rowsum.to(bias.dtype)
         return dx, dw, db, None

@@ -133,3 +133,25 @@ def test_dense_with_thousands_of_rows_runs_on_the_tiled_gemm(m, k, n, act):
         g2 = torch.autograd.grad(got[0].square().sum(), [wgt])[0]
         g2r = torch.autograd.grad(want[0].square().sum(), [w64])[0]
         assert _rel(g2, g2r) < 1e-4
+
+
+def test_row_strided_input_is_read_in_place():
+    """`ws[:, i]` of the [N, num_ws, w_dim] style tensor (rows of contiguous floats, row stride num_ws * w_dim) goes to the kernel as it is -- forward and
+    weight gradient address it through the row stride, no contiguous copy -- and gives what the copy gives, bit for bit."""
+    g = torch.Generator().manual_seed(31)
+    ws = torch.randn([96, 14, 512], generator=g).to(DEV)
+    w = (torch.randn([256, 512], generator=g) / 512 ** 0.5).to(DEV).requires_grad_(True)
+    b = torch.randn([256], generator=g).to(DEV).requires_grad_(True)
+    outs = []
+    for x in (ws[:, 5], ws[:, 5].contiguous()):
+        x = x.detach().requires_grad_(True) if x.is_contiguous() else x.requires_grad_(True)
+        assert fc._rows(x) is x
+        y = fc.dense(x, w, b, weight_gain=0.7, bias_gain=1.0, act='linear')
+        gx, gw, gb = torch.autograd.grad(y.square().sum(), [x, w, b])
+        outs.append((y, gx, gw, gb))
+    for name, a, c in zip(('y', 'dx', 'dW', 'db'), *outs):
+        if name == 'db':      # (the bias gradient's row sums meet through LDS atomics: the order of the additions varies from launch to launch)
+            assert torch.allclose(a, c, rtol=2e-6, atol=0)
+        else:
+            assert torch.equal(a, c), name
+    assert fc._rows(ws[:, :, 5]) is not ws[:, :, 5]          # a column of the trailing dimension is not rows of contiguous floats: copied
