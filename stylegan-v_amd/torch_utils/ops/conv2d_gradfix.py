@@ -144,6 +144,21 @@ native_conv_terms = int(os.environ.get('SGV_CONV_TERMS', '4'))
 native_conv_s2 = os.environ.get('SGV_CONV_S2', '1') != '0'         # stride-2 / transposed members (csrc/conv3x3s2_kernel.h)   # same switch for the forward / data-gradient kernel (csrc/conv3x3_kernel.h)
 
 
+_selftested = set()      # device indices whose producer / consumer kernels passed the load-time self-test (ops/selftest.py)
+
+
+def _selftest(t):
+    """First native 3x3 launch of the process on t's device: the asm-load kernels prove themselves on exact integer data first (ops/selftest.py)."""
+    if not t.is_cuda:
+        return
+    idx = t.device.index or 0
+    if idx in _selftested:
+        return
+    from . import selftest
+    if selftest.run(t.device) in ('ok', 'fallback', 'off'):     # ('running': the test's own launches; 'deferred': a hipGraph is being captured)
+        _selftested.add(idx)
+
+
 def _native_conv_kind(x, w, cfg):
     """Which hand-written kernel serves this convolution: 's1' (3x3 / stride 1 / pad 1, forward or data gradient,
     csrc/conv3x3_kernel.h), 's2' (3x3 / stride 2 / pad 0 between a (2H+1)x(2W+1) and an HxW tensor, strided or transposed,
@@ -176,6 +191,7 @@ def _native_conv_ok(x, w, cfg):
 
 
 def _native_conv(x, w, cfg):
+    _selftest(x)
     lib = custom_ops.get_native()
     kind = _native_conv_kind(x, w, cfg)
     transposed = cfg[0]
@@ -249,6 +265,7 @@ def _wrw_bounds(terms, dyc, xc, scale=None):
 
 def _native_wrw(dy, x, cfg, w_shape, x_scale=None):
     """``x_scale`` ([N, Cin] fp32; stride-1 forward layers only, see ``wrw_input_scale``): the gradient is taken with x * x_scale[:, :, None, None]."""
+    _selftest(x)
     lib = custom_ops.get_native()
     kind = _native_wrw_kind(dy, x, cfg, w_shape)
     dt = _DT[x.dtype]

@@ -63,6 +63,7 @@ def _launch_fused(x, weight, styles, dcoefs, bias, act_idx, alpha, gain, clamp, 
     """mode 0: forward (weight [O,I,3,3]); mode 1: data gradient of that layer (x is the output-side tensor, the result has I channels).
     ``accumulate_into``: an existing fp32 tensor of the result's shape that receives  += result  instead of a fresh output.
     x may be fp16 / bf16 (the mixed-precision blocks): the result has x's format, the weight / scales / bias stay fp32 (single bf16 operands, fp32 accumulate)."""
+    _cg._selftest(x)
     lib = custom_ops.get_native()
     n, ci, h, w = x.shape
     co = weight.shape[0] if mode == 0 else weight.shape[1]

@@ -37,6 +37,7 @@ def strided_conv3x3_bias_act_composed(xb, weight, bias=None, act='lrelu', alpha=
 def _launch(xb, weight, bias, residual, want_act, act_idx, alpha, gain, clamp):
     """`residual` (dense fp32, or None) is updated in place and returned: the reference's `y.add_(x)`.  xb may be fp16 / bf16 (no residual then):
     the result has its format; weight and bias stay fp32."""
+    _cg._selftest(xb)
     lib = custom_ops.get_native()
     n, ci, hb, wb = xb.shape
     co = weight.shape[0]

@@ -755,3 +755,34 @@ def test_bf16x3_gemm_member_serves_the_large_dense_products():
     assert (c.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-5
     ai, bi = torch.randint(-2, 3, a.shape, generator=g).float().to(DEV), torch.randint(-2, 3, b.shape, generator=g).float().to(DEV)
     assert torch.equal(gemm.matmul_nt(ai, bi).double(), ai.double() @ bi.double().t())
+
+
+def test_load_time_selftest_of_the_asm_load_kernels(monkeypatch):
+    """ops/selftest.py: the producer / consumer members of the 3x3 family (inline-asm loads, hand-counted waits) are run once per
+    process and device on exact integer data and must EQUAL torch's CPU convolution; a mismatch stops the product (or, on request, moves the family to
+    the vendor library) instead of training on wrong numbers."""
+    from stylegan_v_amd.torch_utils.ops import conv2d_gradfix, selftest
+    dev = torch.device('cuda', torch.cuda.current_device())
+    monkeypatch.setattr(selftest, '_state', {})
+    monkeypatch.delenv('SGV_SELFTEST', raising=False)
+    before = custom_ops.launch_count()
+    assert selftest.run(dev) == 'ok'
+    assert custom_ops.launch_count() - before >= 7, 'forward / data-gradient / strided / transposed forms and three weight gradients'
+    assert selftest.run(dev) == 'ok' and custom_ops.launch_count() - before < 40        # once per process and device
+    # a kernel that returns something else: refuse ...
+    good = selftest._reference
+    monkeypatch.setattr(selftest, '_reference', lambda x, w, cfg: good(x, w, cfg) + (1.0 if cfg[0] and cfg[1] == (2, 2) else 0.0))
+    monkeypatch.setattr(selftest, '_state', {})
+    with pytest.raises(RuntimeError, match='transposed stride 2'):
+        selftest.run(dev)
+    # ... or, on request, carry on with the vendor library
+    monkeypatch.setenv('SGV_SELFTEST', 'fallback')
+    saved = (conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms)
+    try:
+        assert selftest.run(dev) == 'fallback'
+        assert (conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms) == (0, 0)
+    finally:
+        conv2d_gradfix.native_conv_terms, conv2d_gradfix.native_wrw_terms = saved
+    monkeypatch.setenv('SGV_SELFTEST', '0')
+    monkeypatch.setattr(selftest, '_state', {})
+    assert selftest.run(dev) == 'off'
