@@ -25,3 +25,16 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope='session', autouse=True)
+def _selftest_before_the_first_gpu_test():
+    """The load-time self-test of the asm-load convolution kernels (ops/selftest.py) runs on the first native convolution of a process; tests that count
+    launches or pin kernel variants would see its eight launches inside whichever of them comes first.  Run it here, once, ahead of every test."""
+    import torch
+    if torch.cuda.is_available():
+        from stylegan_v_amd.torch_utils import custom_ops
+        from stylegan_v_amd.torch_utils.ops import conv2d_gradfix
+        if custom_ops.is_built():
+            conv2d_gradfix._selftest(torch.zeros(1, device='cuda'))
+    yield

@@ -31,7 +31,7 @@ class Golden:
 def fast_paths_expected():
     """False when a SGV_* dispatch switch is set in the environment (SGV_S2_WS=0, SGV_FUSED_CONV=0, SGV_CONV_TERMS=0, ...): the suite is then
     exercising a fallback path, and assertions that pin WHICH kernel served a call do not apply."""
-    return not any(k.startswith('SGV_') and k not in ('SGV_NO_BUILD', 'SGV_TORCH_PROFILE') for k in os.environ)
+    return not any(k.startswith('SGV_') and k not in ('SGV_NO_BUILD', 'SGV_TORCH_PROFILE', 'SGV_ERROR_TABLE_DIR', 'SGV_COMMIT', 'SGV_AMAX_TRACE', 'SGV_SELFTEST') for k in os.environ)
 
 
 def dispatch_assert(cond, msg=''):
