@@ -183,7 +183,7 @@ def _fusable(x, weight, styles, dcoefs, bias, act, alpha, gain, clamp):
         return False
     n, ci, h, w = x.shape
     co = weight.shape[0]
-    if weight.shape[1] != ci or n * max(ci, co) > 65535:
+    if weight.shape[1] != ci or n * max(ci, co) > 65535 * 16:      # (planes: the element-wise backward kernels take them in slabs of 65,535; plane_dot up to 16 slabs)
         return False
     for t, c in ((styles, ci), (dcoefs, co)):
         if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != (n, c)):

@@ -93,6 +93,33 @@ def test_fused_layer_is_twice_differentiable_through_the_composition():
             assert _rel(a, r.double().cpu()) < 1e-4
 
 
+def test_fused_layer_beyond_65535_planes():
+    """More than 65,535 (sample, channel) planes -- 43+ videos x 3 frames per GPU at 512 channels -- used to send the layer to the composition (a guard left from
+    the days when the element-wise backward kernels put the planes on blockIdx.y in one launch; they take them in slabs now): the fused node serves them, and
+    gives what the composition gives."""
+    g = torch.Generator().manual_seed(8)
+    n, c = 136, 512
+    assert n * c > 65535
+    x = torch.randn([n, c, 16, 32], generator=g).to(DEV).requires_grad_(True)
+    wt = (torch.randn([c, c, 3, 3], generator=g) / (3 * c ** 0.5)).to(DEV).requires_grad_(True)
+    b = (torch.randn([c], generator=g) * 0.1).to(DEV).requires_grad_(True)
+    s = (torch.randn([n, c], generator=g) * 0.3 + 1).to(DEV).requires_grad_(True)
+    d = (torch.rand([n, c], generator=g) + 0.5).to(DEV).requires_grad_(True)
+    v = torch.randn([n, c, 16, 32], generator=g).to(DEV)
+
+    def run():
+        y = fused_conv_act.conv3x3_bias_act(x, wt, styles=s, dcoefs=d, bias=b, act='lrelu')
+        return (y,) + torch.autograd.grad((y * v).sum(), [x, wt, b, s, d])
+    before = custom_ops.kernel_variant_counts()
+    got = run()
+    after = custom_ops.kernel_variant_counts()
+    dispatch_assert(after['conv_s1_ws_fused'] - before['conv_s1_ws_fused'] >= 1, 'the fused kernel did not serve the layer')
+    with fused_conv_act.composition_only():
+        want = run()
+    for name, a, r in zip(('y', 'dx', 'dw', 'db', 'dstyles', 'ddcoefs'), got, want):
+        assert _rel(a, r.double().cpu()) < 1e-4, name
+
+
 def test_fused_layer_no_grad_pass_and_fallbacks():
     g = torch.Generator().manual_seed(6)
     x = torch.randn([2, 64, 32, 32], generator=g).to(DEV)
