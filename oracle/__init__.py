@@ -4,4 +4,4 @@ Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg;
 product package.
 """
 from .oracle import (build, upfirdn2d, bias_act, upfirdn2d_out_size, modulated_demod_coefs, time_encode, conv3x3, conv3x3_weight_grad,  # noqa: F401
-                     demod_coefs_torch, dense, affine_resample)
+                     demod_coefs_torch, dense, affine_resample, ada_geometric)

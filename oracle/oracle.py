@@ -213,6 +213,30 @@ def affine_resample(x, theta, out_hw):
     return out
 
 
+def ada_geometric(x, theta, taps, margin):
+    """The geometric execution block of AugmentPipe.forward (src/training/augment.py:284-303) in float64, given what the block receives: the image batch
+    x [N,C,H,W], the margin (mx0, mx1, my0, my1) of :282, the 12 `Hz_geom` taps and theta = G_inv[:, :2, :] as passed to `affine_grid` at :299 (the map
+    from the (2 (H + 6)) x (2 (W + 6)) resampled image to the up-sampled padded image, normalised coordinates).  Steps, each by its definition:
+      reflect pad          torch.nn.functional.pad(mode='reflect')                                            :284
+      2x up-sampling       upfirdn2d.upsample2d(f=Hz_geom, up=2): padding [6, 5], gain 4 (upfirdn2d.py:308-343)    :288
+      resampling           affine_grid(align_corners=False) + bilinear grid_sample, zeros outside            :299-300
+      2x down-sampling     upfirdn2d.downsample2d(f=Hz_geom, down=2, padding=-6, flip_filter=True)             :303
+    The FIR steps go through this module's C restatement of upfirdn2d_kernel_large (`upfirdn2d` above), the resampling through `affine_resample`."""
+    x = torch.as_tensor(np.asarray(x, dtype=np.float64))
+    f = torch.as_tensor(np.asarray(taps, dtype=np.float32))       # the reference's filters are fp32 whatever the image format (upfirdn2d.cpp:20-21); 1-D: two passes
+    assert f.ndim == 1 and f.shape[0] % 4 == 0
+    fw = f.shape[0]
+    pad = fw // 4
+    mx0, mx1, my0, my1 = (int(m) for m in margin)
+    n, c, h, w = x.shape
+    xp = torch.nn.functional.pad(x, [mx0, mx1, my0, my1], mode='reflect')
+    p0, p1 = (fw + 2 - 1) // 2, (fw - 2) // 2                     # upsample2d's padding for up = 2 (upfirdn2d.py:336-341)
+    up = upfirdn2d(xp, f, up=2, padding=[p0, p1, p0, p1], gain=4.0)
+    hi = affine_resample(up, torch.as_tensor(np.asarray(theta, dtype=np.float64)), ((h + 2 * pad) * 2, (w + 2 * pad) * 2))
+    q0, q1 = -2 * pad + (fw - 2 + 1) // 2, -2 * pad + (fw - 2) // 2  # downsample2d's padding for down = 2 plus the block's -2 * Hz_pad (upfirdn2d.py:375-380)
+    return upfirdn2d(hi, f, down=2, padding=[q0, q1, q0, q1], flip_filter=True).numpy()
+
+
 # ----------------------------------------------------------------------------------------------
 # 3x3 convolutions.  The reference leaves them to ATen / cuDNN (call sites: conv2d_gradfix.py:35-43 `conv2d` /
 # `conv_transpose2d`, :100-118 data gradient, :140-170 weight gradient; conv2d_resample.py:113-137 for the stride-2 forms) --

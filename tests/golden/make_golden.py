@@ -566,6 +566,48 @@ def gen_augment():
     save('augment', arrays, dict(percentiles=pcts, pipe='bgc'))
 
 
+def gen_ada_geometric():
+    """The geometric execution block of AugmentPipe.forward (src/training/augment.py:270-303) on its own: given inverse maps G_inv, the reference's own helpers
+    (`matrix`, `translate2d`, `scale2d`, `scale2d_inv`, `translate2d_inv`) and ops (`upfirdn2d.upsample2d` / `downsample2d`, `affine_grid`,
+    `grid_sample_gradfix.grid_sample`) are called in the order of :272-303; the fixture holds the inputs (x, G_inv), the intermediate contract values the
+    one-kernel form receives (margin, theta = G_inv[:, :2, :] of :299) and the output."""
+    import math
+    from training import augment as A
+    from torch_utils.ops import grid_sample_gradfix as R_gs
+    g = torch.Generator().manual_seed(41)
+    n, ch, h, w = 6, 3, 40, 48
+    x = torch.rand([n, ch, h, w], generator=g) * 2 - 1
+    maps = []
+    for ang, sx, sy, tx, ty in ((0.0, 1.0, 1.0, 0.0, 0.0), (0.6, 1.1, 0.9, 2.0, -1.5), (math.pi / 2, 1.0, 1.0, 0.0, 0.0), (2.2, 0.7, 1.3, 0.5, 0.25), (0.3, -1.0, 1.0, 0.0, 3.0), (0.2, 1.9, 1.7, 0.0, 0.0)):
+        c, s_ = math.cos(ang), math.sin(ang)
+        maps.append([[sx * c, -sy * s_, tx], [sx * s_, sy * c, ty], [0.0, 0.0, 1.0]])
+    G_inv = torch.tensor(maps)
+    pipe = A.AugmentPipe(xflip=1)                       # for its Hz_geom buffer
+    Hz = pipe.Hz_geom
+    dev = x.device
+    cx, cy = (w - 1) / 2, (h - 1) / 2
+    cp = A.matrix([-cx, -cy, 1], [cx, -cy, 1], [cx, cy, 1], [-cx, cy, 1], device=dev)
+    cp = G_inv @ cp.t()
+    Hz_pad = Hz.shape[0] // 4
+    margin = cp[:, :2, :].permute(1, 0, 2).flatten(1)
+    margin = torch.cat([-margin, margin]).max(dim=1).values
+    margin = margin + torch.tensor([Hz_pad * 2 - cx, Hz_pad * 2 - cy] * 2)
+    margin = margin.max(torch.tensor([0.0, 0.0] * 2)).min(torch.tensor([w - 1.0, h - 1.0] * 2))
+    mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32))
+    images = torch.nn.functional.pad(input=x, pad=[mx0, mx1, my0, my1], mode='reflect')
+    G = A.translate2d((mx0 - mx1) / 2, (my0 - my1) / 2) @ G_inv
+    images = R_ufd.upsample2d(x=images, f=Hz, up=2)
+    G = A.scale2d(2, 2, device=dev) @ G @ A.scale2d_inv(2, 2, device=dev)
+    G = A.translate2d(-0.5, -0.5, device=dev) @ G @ A.translate2d_inv(-0.5, -0.5, device=dev)
+    shape = [n, ch, (h + Hz_pad * 2) * 2, (w + Hz_pad * 2) * 2]
+    G = A.scale2d(2 / images.shape[3], 2 / images.shape[2], device=dev) @ G @ A.scale2d_inv(2 / shape[3], 2 / shape[2], device=dev)
+    theta = G[:, :2, :]
+    grid = torch.nn.functional.affine_grid(theta=theta, size=shape, align_corners=False)
+    images = R_gs.grid_sample(images, grid)
+    y = R_ufd.downsample2d(x=images, f=Hz, down=2, padding=-Hz_pad * 2, flip_filter=True)
+    save('ada_geometric', dict(x=x, G_inv=G_inv, theta=theta, y=y, taps=Hz), dict(margin=[mx0, mx1, my0, my1], note='margin order: mx0, mx1, my0, my1 (the pad call of augment.py:284)'))
+
+
 def gen_time_encoder():
     """AlignedTimeEncoder + motion-code gather in float64 for a tight kernel tolerance."""
     from training.motion import MotionMappingNetwork
@@ -600,4 +642,5 @@ if __name__ == '__main__':
     gen_networks_1024()
     gen_networks_cfg1()
     gen_augment()
+    gen_ada_geometric()
     gen_time_encoder()

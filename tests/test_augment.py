@@ -205,3 +205,41 @@ def test_augment_pipe_forward_only_matches_reference_gpu():
             y = pipe(x0, debug_percentile=pct)
             assert custom_ops.launch_count() - before == 2          # geometric execution + colour
             assert_close(y, AUG.t(f'y{i}', device='cuda'), atol=1e-4, rtol=1e-4, what=f'forward-only augmented clip at percentile {pct}')
+
+
+GEO = Golden('ada_geometric')
+
+
+def test_oracle_geometric_execution_matches_the_reference():
+    """oracle.ada_geometric (float64 restatement of augment.py:284-303 from the same margin and theta) against the reference's own evaluation of that block
+    (tests/golden/ada_geometric.npz, make_golden.py gen_ada_geometric): the reference computes in fp32, so the bound is fp32 rounding through three filters."""
+    got = oracle.ada_geometric(GEO.t('x').numpy(), GEO.t('theta').numpy(), GEO.t('taps').numpy(), GEO.meta['margin'])
+    want = GEO.t('y').double().numpy()
+    assert got.shape == want.shape
+    assert abs(got - want).max() <= 2e-5 * max(1.0, abs(want).max())
+
+
+def test_geometric_execution_from_the_inverse_maps_matches_the_reference_cpu():
+    """AugmentPipe._resample (margin, matrix bookkeeping of augment.py:272-296, then the four-pass composition) from the fixture's G_inv: the margin, theta and
+    output the reference produced."""
+    pipe = AugmentPipe(**BGC)
+    x, g_inv = GEO.t('x'), GEO.t('G_inv')
+    y = pipe._resample(x, g_inv)
+    assert_close(y, GEO.t('y'), atol=2e-5, rtol=2e-5, what='geometric execution (composition, CPU)')
+    y2 = resample.ada_geometric_ref(x, GEO.t('theta'), pipe.Hz_geom, GEO.meta['margin'])
+    assert_close(y2, GEO.t('y'), atol=2e-5, rtol=2e-5, what='composition from the fixture margin and theta')
+
+
+@pytest.mark.gpu
+def test_geometric_execution_as_one_kernel_matches_the_reference_gpu():
+    """sgv_ada_geometric against the REFERENCE's evaluation of the block (fixture: identity, rotations, mirror, anisotropic scales, a zoom-out that takes the
+    direct form), from the fixture's margin and theta and from the pipe's own bookkeeping."""
+    x = GEO.t('x', device='cuda')
+    pipe = AugmentPipe(**BGC).cuda()
+    want = GEO.t('y', device='cuda')
+    with torch.no_grad():
+        before = custom_ops.launch_count()
+        y = resample.ada_geometric(x, GEO.t('theta', device='cuda'), pipe.Hz_geom, GEO.meta['margin'])
+        assert custom_ops.launch_count() - before == 1
+        assert_close(y, want, atol=3e-5, rtol=3e-5, what='one-kernel geometric execution vs the reference')
+        assert_close(pipe._resample(x, GEO.t('G_inv')), want, atol=3e-5, rtol=3e-5, what='pipe bookkeeping + one kernel vs the reference')
