@@ -47,6 +47,79 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def _round_floats(o, sig=6):
+    """Floats to `sig` significant digits (the compact line must survive an 8 KB tail: 17-digit floats are a third of it)."""
+    if isinstance(o, float):
+        return float(f'{o:.{sig}g}')
+    if isinstance(o, dict):
+        return {k: _round_floats(v, sig) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_round_floats(v, sig) for v in o]
+    return o
+
+
+ROOFLINE_KEYS = ('kernel', 'bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'algorithmic_bytes_per_launch', 'algorithmic_flops_per_launch', 'launches', 'avg_launch_us',
+                 'frac_of_measured_copy_peak')
+CPU_KEYS = ('value', 'unit', 'cores', 'kind', 'cpu', 'sample')
+COMPACT_LIMIT = 6000     # bytes; the driver keeps an 8 KB tail of stdout (VERDICT r4: the 21.8 KB line of round 4 did not parse)
+
+
+def compact_line(out, detail_path=None):
+    """The ONE JSON line of the contract, built from the full result `out`: contract keys, `dtype`, `config`, the `roofline` objects (numbers only),
+    `cpu_baseline` and the companion values as scalars.  Everything else (per-variant / per-size / per-family tables, the companions' details, notes and
+    provenance strings) goes to the side file `detail_path` and to stderr.  Guaranteed < COMPACT_LIMIT bytes: optional parts are dropped in a fixed
+    order if a future field makes it grow, and the contract keys alone are a few hundred bytes."""
+    def pick(d, keys):
+        return None if d is None else {k: d[k] for k in keys if k in d}
+    line = {k: out.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
+    cfg = dict(out.get('config') or {})
+    line['config'] = {k: cfg[k] for k in ('workload', 'videos_per_gpu', 'frames_per_video', 'clips_per_gpu', 'frames_per_clip', 'global_batch_videos', 'parallelism', 'phases_run',
+                                          'hip_graphs', 'conv_terms', 'native_launches_per_step') if k in cfg}
+    line['roofline'] = pick(out.get('roofline'), ROOFLINE_KEYS)
+    cpu = pick(out.get('cpu_baseline'), CPU_KEYS)
+    if cpu and len(str(cpu.get('sample', ''))) > 400:
+        cpu['sample'] = cpu['sample'][:397] + '...'
+    line['cpu_baseline'] = cpu
+    optional = [('roofline_upfirdn2d', pick(out.get('roofline_upfirdn2d'), ROOFLINE_KEYS)), ('roofline_conv_family', pick(out.get('roofline_conv_family'), ROOFLINE_KEYS))]
+    optional += [(k, out[k]) for k in sorted(out) if k.startswith('value_') and not isinstance(out[k], (dict, list))]
+    if out.get('multi_gpu'):
+        optional.append(('multi_gpu', out['multi_gpu']))
+    optional.append(('detail', detail_path))
+    for k, v in optional:
+        line[k] = v
+    line = _round_floats(line)
+    text = json.dumps(line, separators=(',', ':'))
+    for k, _ in reversed(optional):            # never reached with today's fields (~2.5 KB); the limit is a hard guarantee all the same
+        if len(text) < COMPACT_LIMIT:
+            break
+        line.pop(k, None)
+        text = json.dumps(line, separators=(',', ':'))
+    assert len(text) < COMPACT_LIMIT, len(text)
+    return text
+
+
+def emit(out):
+    """Write the full result to bench_detail.json (repo root; also gpurun_out/ when it exists, which travels back from the GPU box) and to stderr, then
+    print the compact contract line as the LAST line of stdout."""
+    name = 'bench_detail.json'
+    paths = [os.path.join(ROOT, name)]
+    if os.path.isdir(os.path.join(ROOT, 'gpurun_out')):
+        paths.append(os.path.join(ROOT, 'gpurun_out', name))
+    full = json.dumps(out)
+    written = None
+    for path in paths:
+        try:
+            with open(path, 'w') as fh:
+                fh.write(full + '\n')
+            written = written or os.path.relpath(path, ROOT)
+        except OSError as err:
+            log(f'[bench] could not write {path}: {err}')
+    log('[bench] full result (tables, companions, provenance):')
+    log(full)
+    sys.stdout.flush()
+    print(compact_line(out, written), flush=True)
+
+
 TIMED_FAMILIES = ('conv3x3_s1', 'upfirdn2d_lanes')      # kernel families whose launches are bracketed by HIP events inside the timed region
 PMC_FILES = ['r04_pmc_bench_step_FETCH_WRITE.json']   # collected by tools/gpu_recipes/pmc_fetch_write_passes.sh (separate --pmc passes of this command)
 
@@ -89,7 +162,7 @@ def pmc_traffic_conv_family():
                         'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
 
 
-def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_fir_asm', 'upfirdn2d_tile'), files=None):
+def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_tile'), files=None):
     return pmc_traffic(tuple(prefixes), files=files)
 
 
@@ -260,7 +333,7 @@ def synthesis_workload(args, world, rank, device):
                    config=dict(workload=workload, clips_per_gpu=clips, frames_per_clip=frames, parallelism=f'replicas x{world} (no collective)',
                                native_launches_per_forward=(custom_ops.launch_count() - launches0) / (2 * args.steps if not args.no_prof else args.steps)),
                    value_no_prof=clips * frames * world * args.steps / clean, roofline=roofline, upfirdn2d_by_size=by_size, kernels=kernels, cpu_baseline=cpu)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
@@ -679,7 +752,7 @@ def main():
             r = prof['upfirdn2d_lanes']
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-                roofline_ufd = dict(kernel='upfirdn2d_lanes_kernel / upfirdn2d_fir_asm_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
+                roofline_ufd = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
                                     frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch()[0], launches=r['launches'],
                                     traffic_source=pmc_traffic_per_launch()[1] + ' (reads x2, gfx950 correction)',
                                     avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
@@ -756,11 +829,11 @@ def main():
                                upfirdn2d_in_step_frac=roofline_ufd['frac'] if roofline_ufd else None),
                    multi_gpu=multi_gpu, value_bf16_split=split3['value'] if split3 else None, bf16_split=split3,
                    value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof,
-                   value_strict_fp32=value if (default_terms in ((0, 0), (4, 4)) and lowp is None) else None,     # the headline IS the fp32-grade number since round 4
+                   value_fp32_grade=value if (default_terms in ((0, 0), (4, 4)) and lowp is None) else None,     # the headline's products are fp32-GRADE (22-bit split operands, 2.7e-7), not strict fp32: the strict-fp32 figure is value_vendor_fp32_convs
                    value_vendor_fp32_convs=strict['value'] if strict else None, vendor_fp32_convs=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
                    value_lowp_bf16=lowpc['value'] if lowpc else None, lowp_bf16=lowpc,
                    roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, upfirdn2d_by_size=ufd_by_size, kernels=kernels, kernels_by_variant=variants, cpu_baseline=cpu)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

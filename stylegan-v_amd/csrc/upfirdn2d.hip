@@ -342,7 +342,6 @@ struct lanes_params {
     int plane_groups;  // SEG: groups of planes sharing a wave; otherwise == planes
     int nt_store;      // stream the output past the caches (tensors larger than the Infinity Cache)
     int lds_share;     // hand the vertical halo rows from wave to wave through LDS
-    int pad;           // upfirdn2d_fir_asm_kernel only: pad_x0 == pad_y0
     // fused epilogue / prologue (EPI != 0), see sgv_fir_epilogue in include/sgv_ops.h
     const float* ep_scale;  // [planes] or NULL
     const float* ep_bias;   // [chans] or NULL
@@ -706,204 +705,6 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
         }
     }
     if constexpr (sizeof(T) == 4 && EPI != 1) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Dedicated instantiation of the hot FIR geometry -- fp32, up = down = 1, 4x4 filter, pad_x0 = pad_y0 = P (1 or 2), out = in + 2P - 3 on both
-// axes, out_w % 4 in {0, 1}: the pass after an up-sampling convolution (2r+1 -> 2r) and the pass in front of a strided one (r -> r+1) -- with
-// the row loads as inline asm and counted waits.  EPI = 0: plain upfirdn2d; EPI = 1: with the synthesis layer's forward epilogue
-// (sgv_upfirdn2d_fused mode 1: * dcoefs[n,c] + bias[c] -> lrelu -> gain -> clamp, evaluated exactly like the lanes kernel's).
-//
-// Same walk as the lanes kernel (a wave owns a 16-row strip of one plane, a lane 4 (+1) output columns, neighbours' columns by DPP, the wave's
-// right halo by one masked dword load + v_readlane, 4-row window in registers, taps in SGPRs, non-temporal stores).  The difference is WHEN the
-// loads are waited for: hipcc puts `s_waitcnt vmcnt(0)` directly behind a row load written in C++ (the value is merged with the zero row inside the
-// same conditional block), so in the lanes kernel nothing is in flight while the previous rows are filtered and only occupancy hides the memory
-// latency.  Here every row issues exactly two loads (16 B main + halo dword; out-of-range rows load a clamped row and are zeroed on use, edge
-// lanes load a window clamped into the row and shift it back with selects) into one of two register sets that are never copied, and the wait in
-// front of a set's use allows the loads issued since into the other set to stay outstanding (loads return in order; the stores and anything
-// else issued in between only make the wait stricter): two row groups in flight across the arithmetic and the stores (tools/ufd_lab.hip V4).
-//
-// Round 3 -- the read over-fetch (PMC: 1.42x the input bytes in round 2, profiles/r02_pmc_bench_step_FETCH_WRITE.json) had two sources:
-//   * the walk prefetched the row group BEHIND its strip (4 rows nobody used per 16-row strip: 23 rows loaded for 16 produced).  The four
-//     groups of a strip are now unrolled and the last one issues nothing;
-//   * the three rows that two vertically adjacent strips share were loaded by both.  A workgroup is now the four strips of a 64-row block of ONE
-//     plane; every wave parks its three prologue rows (raw, as loaded) in LDS, one barrier, and the wave above takes its last three rows from
-//     there instead of from memory (HAND; the hand-off of upfirdn2d_lanes_kernel above): 67 rows loaded per 64 produced.
-// Tap order per output: ascending row, then ascending column, one fmaf chain -- the reference loop's order, bit-identical to the oracle.
-template <int XTRA, int EPI, bool HAND>
-__global__ __launch_bounds__(256) void upfirdn2d_fir_asm_kernel(lanes_params p) {
-    constexpr int PF = 4;                                     // rows per group; a strip = 4 groups = 16 rows, a workgroup = 4 strips
-    constexpr int NEED = 7 + XTRA, NH = 3 + XTRA, NOUT = 4 + XTRA;
-    const int lane = threadIdx.x & 63;
-    const int wslot = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int macro = blockIdx.x % p.strips;                  // p.strips = 64-row blocks per plane here
-    const int cg = (blockIdx.x / p.strips) % p.col_groups;
-    const int pl = blockIdx.x / (p.strips * p.col_groups);    // < p.planes by construction of the grid; wave-uniform
-    const int oy_a = macro * 64 + wslot * 16, oy_b = min(oy_a + 16, p.out_h);
-    const bool active = oy_a < p.out_h;
-    const bool lower = HAND && wslot < 3 && oy_a + 16 < p.out_h;   // the wave below exists: its three prologue rows are this strip's last three
-    float ff[4][4];
-    {   // lane t < 16 fetches tap (t/4, t%4); v_readlane broadcasts the 16 values into SGPRs (same indexing as the lanes kernel)
-        const int ta = (lane >> 2) & 3, tb = lane & 3;
-        float t = 0.f;
-        if (lane < 16) {
-            const int fa = p.flip ? ta : 3 - ta, fb = p.flip ? tb : 3 - tb;
-            t = p.f[fa * p.f_sh + fb * p.f_sw];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) ff[a][b] = lane_bcast(t, a * 4 + b);
-    }
-    // epilogue scalars through the scalar cache (pl is wave-uniform): a vector load here would make hipcc drain the asm loads at its first use
-    float ep_sc = 1.f, ep_bi = 0.f;
-    if constexpr (EPI == 1) {
-        if (p.ep_scale) ep_sc = p.ep_scale[pl];
-        if (p.ep_bias) ep_bi = p.ep_bias[pl % p.chans];
-    }
-    auto epi_fwd = [&](float u) {   // bias -> activation -> gain -> clamp, the operation order of bias_act.cu:51-142 (grad 0); identical to the lanes kernel's
-        float t = u * ep_sc;
-        t = t + ep_bi;
-        if (p.ep_act == 3) t = (t > 0.f) ? t : t * p.ep_alpha;
-        t *= p.ep_gain;
-        if (p.ep_clamp >= 0.f) t = (t > -p.ep_clamp & t < p.ep_clamp) ? t : (t >= 0.f) ? p.ep_clamp : -p.ep_clamp;
-        return t;
-    };
-    const float* xp = (const float*)p.x + (size_t)pl * p.in_h * p.in_w;
-    float* yp = (float*)p.y + (size_t)pl * p.out_h * p.out_w;
-    const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of 4
-    const int ox = cg * 256 + lane * 4;
-    const int ix0 = ox - p.pad;
-    const int base = min(max(ix0, 0), p.in_w - 4);              // the 4-column load window, clamped into the row
-    const int sh = base - ix0;                                  // how far it moved (|sh| <= 3 for lanes that own live columns)
-    const bool cols_dead = ix0 >= p.in_w || ix0 + 3 < 0;
-    const int ixh = cg * 256 + 256 - p.pad + lane;              // lanes 0 .. NH-1: the columns right of lane 63's block
-    const bool halo_ok = lane < NH && ixh >= 0 && ixh < p.in_w;
-    const int ixh_c = min(max(ixh, 0), p.in_w - 1);
-    const bool st_vec = ox < n_main;                            // whole vectors only (n_main % 4 == 0)
-    const bool st_xtra = XTRA && ox + 4 == p.out_w - 1;
-    const int iy0 = oy_a - p.pad;
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    struct raw { f4v m; float h; };
-    __shared__ f4v park_m[HAND ? 4 * 3 * 64 : 1];
-    __shared__ float park_h[HAND ? 4 * 3 * 64 : 1];
-    auto issue = [&](int iy, raw& r) {   // always two loads
-        const float* row = xp + (size_t)min(max(iy, 0), p.in_h - 1) * p.in_w;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r.m) : "v"(row + base) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(r.h) : "v"(row + ixh_c) : "memory");
-    };
-    auto pin = [&](raw& r) {   // first use of a set behind its counted wait: pin its registers there
-        asm volatile("" : "+v"(r.m));
-        asm volatile("" : "+v"(r.h));
-    };
-    auto expand = [&](int iy, const raw& r, float* dst) {
-        const bool row_ok = iy >= 0 && iy < p.in_h;
-        float m[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {   // undo the clamp: m[i] = column ix0 + i = loaded[i - sh] where that exists, else 0 (padding)
-            float v = r.m[i];
-#pragma unroll
-            for (int d = 1; d <= 3; d++) {
-                if (i - d >= 0) v = (sh == d) ? r.m[i - d] : v; else v = (sh == d) ? 0.f : v;
-                if (i + d < 4) v = (sh == -d) ? r.m[i + d] : v; else v = (sh == -d) ? 0.f : v;
-            }
-            m[i] = (row_ok && !cols_dead) ? v : 0.f;
-        }
-        const float hv = (row_ok && halo_ok) ? r.h : 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; i++) dst[i] = m[i];
-#pragma unroll
-        for (int i = 0; i < NH; i++) dst[4 + i] = dpp_wave_shl1(m[i], lane_bcast(hv, i));
-    };
-    float win[4][NEED];
-    // Two register sets used alternately and never copied: the compiler believes an asm load's result is there at once, so nothing may read, move
-    // or re-allocate these registers between the load and the pin behind the counted wait.
-    raw pr[3], sa[PF], sb[PF];
-    int iy = iy0 + 3;
-    if (active) {
-#pragma unroll
-        for (int r = 0; r < 3; r++) issue(iy0 + r, pr[r]);
-#pragma unroll
-        for (int k = 0; k < PF; k++) issue(iy + k, sa[k]);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // the prologue rows have landed; group 0's eight loads stay in flight
-#pragma unroll
-        for (int r = 0; r < 3; r++) pin(pr[r]);
-        if constexpr (HAND) {
-            if (wslot > 0) {
-#pragma unroll
-                for (int r = 0; r < 3; r++) { park_m[(wslot * 3 + r) * 64 + lane] = pr[r].m; park_h[(wslot * 3 + r) * 64 + lane] = pr[r].h; }
-            }
-        }
-    }
-    if constexpr (HAND) {
-        // a bare s_barrier behind the LDS writes' own counter: __syncthreads() would also drain the eight global loads in flight
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    }
-    if (!active) return;
-#pragma unroll
-    for (int r = 0; r < 3; r++) expand(iy0 + r, pr[r], win[1 + r]);
-    auto rows = [&](int oy, raw* cur) {   // the four rows of one group: slide the window, filter, store
-#pragma unroll
-        for (int k = 0; k < PF; k++) {
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int i = 0; i < NEED; i++) win[r][i] = win[r + 1][i];
-            expand(iy + k, cur[k], win[3]);
-            if (oy + k >= oy_b) continue;   // wave-uniform
-            float o[NOUT];
-#pragma unroll
-            for (int v = 0; v < NOUT; v++) {
-                float acc = 0.f;
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-#pragma unroll
-                    for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[j][v + i], ff[j][i], acc);
-                o[v] = acc * p.gain;
-                if constexpr (EPI == 1) o[v] = epi_fwd(o[v]);
-            }
-            float* yr = yp + (size_t)(oy + k) * p.out_w + ox;
-            if (st_vec) { if (p.nt_store) store_vec_nt<float, 4>(yr, o); else store_vec_plain<float, 4>(yr, o); }
-            if constexpr (XTRA) { if (st_xtra) yr[4] = o[4]; }
-        }
-        iy += PF;
-    };
-    // groups 0 (rows 3..6 of the strip's 19 input rows), 1 (7..10), 2 (11..14), 3 (15..18); the loads of group g+1 are issued before group g is used
-#pragma unroll
-    for (int k = 0; k < PF; k++) issue(iy + PF + k, sb[k]);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < PF; k++) pin(sa[k]);
-    rows(oy_a, sa);
-#pragma unroll
-    for (int k = 0; k < PF; k++) issue(iy + PF + k, sa[k]);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#pragma unroll
-    for (int k = 0; k < PF; k++) pin(sb[k]);
-    rows(oy_a + PF, sb);
-    if (lower) {   // wave-uniform: only row 15 comes from memory, rows 16..18 are the lower wave's parked prologue rows
-        issue(iy + PF, sb[0]);
-        asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-#pragma unroll
-        for (int k = 0; k < PF; k++) issue(iy + PF + k, sb[k]);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    }
-#pragma unroll
-    for (int k = 0; k < PF; k++) pin(sa[k]);
-    rows(oy_a + 2 * PF, sa);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // nothing is prefetched behind the strip
-    if (lower) {
-        pin(sb[0]);
-#pragma unroll
-        for (int r = 0; r < 3; r++) { sb[1 + r].m = park_m[((wslot + 1) * 3 + r) * 64 + lane]; sb[1 + r].h = park_h[((wslot + 1) * 3 + r) * 64 + lane]; }
-    } else {
-#pragma unroll
-        for (int k = 0; k < PF; k++) pin(sb[k]);
-    }
-    rows(oy_a + 3 * PF, sb);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1447,36 +1248,6 @@ int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dt
     return sgv_check_launch("upfirdn2d_tile_kernel");
 }
 
-// upfirdn2d_fir_asm_kernel serves: fp32, up = down = 1, 4x4 filter, pad 1 or 2 on both axes with the matching output size, >= 129 output columns
-bool fir_asm_geometry(const sgv_upfirdn2d_params* p, int dtype) {
-    static const int fir_asm = []() { const char* e = getenv("SGV_FIR_ASM"); return e ? atoi(e) : 1; }();
-    const int n_main = p->out_w % 4 == 1 ? p->out_w - 1 : p->out_w;
-    return fir_asm && dtype == SGV_F32 && p->up_x == 1 && p->up_y == 1 && p->down_x == 1 && p->down_y == 1 && p->f_w == 4 && p->f_h == 4 &&
-           p->pad_x0 == p->pad_y0 && (p->pad_x0 == 1 || p->pad_x0 == 2) && p->out_w == p->in_w + 2 * p->pad_x0 - 3 && p->out_h == p->in_h + 2 * p->pad_y0 - 3 &&
-           n_main % 4 == 0 && n_main > 128 && p->in_w >= 4 && (((uintptr_t)p->y) & 3) == 0;
-}
-
-// one workgroup = the four 16-row strips of a 64-row block of one plane and one 256-column group
-int launch_fir_asm(const sgv_upfirdn2d_params* p, lanes_params lp, int epi, hipStream_t stream) {
-    static const int hand = []() { const char* e = getenv("SGV_FIR_LDS"); return e ? atoi(e) : 1; }();   // SGV_FIR_LDS=0: every strip loads its own halo rows
-    const int n_main = p->out_w % 4 == 1 ? p->out_w - 1 : p->out_w;
-    lp.pad = p->pad_x0;
-    lp.col_groups = (n_main + 255) / 256;
-    lp.strip_h = 16;
-    lp.strips = (p->out_h + 63) / 64;
-    const int64_t blocks = (int64_t)lp.planes * lp.col_groups * lp.strips;
-    if (blocks > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: too many workgroups");
-    const dim3 grid((unsigned)blocks);
-    const int xtra = p->out_w % 4 == 1;
-#define SGV_FIR_GO(X, E) do { if (hand) hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<X, E, true>), grid, dim3(256), 0, stream, lp); \
-                              else hipLaunchKernelGGL((upfirdn2d_fir_asm_kernel<X, E, false>), grid, dim3(256), 0, stream, lp); } while (0)
-    if (epi == 1) { if (xtra) SGV_FIR_GO(1, 1); else SGV_FIR_GO(0, 1); }
-    else { if (xtra) SGV_FIR_GO(1, 0); else SGV_FIR_GO(0, 0); }
-#undef SGV_FIR_GO
-    sgv_note_variant(epi ? SGV_V_ufd_fir_asm_fused1 : SGV_V_ufd_fir_asm);
-    return sgv_check_launch("upfirdn2d_fir_asm_kernel");
-}
-
 int validate(const sgv_upfirdn2d_params* p, int dtype) {
 
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: params is NULL");
@@ -1532,7 +1303,6 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
     lanes_plan lplan;
     if (plan_lanes(p, dtype, &lplan)) {
         sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
-        if (fir_asm_geometry(p, dtype)) return launch_fir_asm(p, lplan.lp, 0, stream);   // the hot FIR geometry at >= 129 output columns: asm row loads, counted waits
         lplan.lp.y_amax = dtype == SGV_F32 ? scope.take_amax_sink() : nullptr;
         hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
         sgv_note_variant(lplan.lp.lpr_log2 < 6 ? SGV_V_ufd_lanes_seg : SGV_V_ufd_lanes);
@@ -1596,7 +1366,6 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
     const double nin = (double)p->in_w * p->in_h * p->in_c * p->in_n, nout = (double)p->out_w * p->out_h * p->in_c * p->in_n;
     const double bytes = (e->mode == 2 ? 2.0 * nin : nin) * es + (e->mode >= 3 ? 2.0 * nout : nout) * es;
     sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
-    if (e->mode == 1 && fir_asm_geometry(p, dtype)) return launch_fir_asm(p, lplan.lp, 1, stream);   // wide forward epilogue: the asm-load kernel
     lplan.lp.y_amax = (dtype == SGV_F32 && e->mode != 1) ? scope.take_amax_sink() : nullptr;
     hipLaunchKernelGGL(lplan.fn, dim3((unsigned)lplan.blocks), dim3((unsigned)lplan.threads), 0, stream, lplan.lp);
     sgv_note_variant(SGV_V_ufd_lanes_fused1 + (e->mode - 1));

@@ -90,7 +90,7 @@ def _build_file_lock():
 # (csrc/conv3x3_ws_kernel.h, wrw_ws_kernel.h, conv3x3s2_ws_kernel.h, upfirdn2d.hip): correct as long as the compiler neither copies nor spills the
 # destination registers before the wait nor adds vector-memory operations of its own in between.  The bit-exact GPU tests pin that for the compiler
 # they ran with; another compiler build is announced so that `pytest -m gpu` (tests/test_conv*_gpu.py, test_ops_gpu.py) is re-run before the library
-# is trusted (SGV_CONV_WS=0 SGV_WRW_WS=0 SGV_S2_WS=0 SGV_WRW_S2_WS=0 SGV_UFD_TILE=0 SGV_FIR_ASM=0 select the compiler-scheduled forms meanwhile).
+# is trusted (SGV_CONV_WS=0 SGV_WRW_WS=0 SGV_S2_WS=0 SGV_WRW_S2_WS=0 SGV_UFD_TILE=0 select the compiler-scheduled forms meanwhile).
 VALIDATED_COMPILERS = ('roc-7.2.0',)
 
 

@@ -282,7 +282,7 @@ def test_fused_fir_bias_act_is_twice_differentiable(shape):
     with fused_fir_act.second_order_support():
         got = second_order(fused_fir_act.fir_bias_act)
     after = custom_ops.kernel_variant_counts()
-    fused1 = ('ufd_lanes_fused1', 'ufd_fir_asm_fused1', 'ufd_tile_fused1')
+    fused1 = ('ufd_lanes_fused1', 'ufd_tile_fused1')
     assert sum(after[k] - before[k] for k in fused1) == 1, 'the forward pass ran the fused kernel'
     want = second_order(fused_fir_act.fir_bias_act_composed)
     with fused_conv_act.composition_only():
@@ -584,7 +584,7 @@ def test_path_length_regularisation_step_runs_with_the_fused_epilogues_on():
             fused_fir_act.enabled = True
         outs.append({k: float(v) for k, v in ts.last_losses.items()})
     after = custom_ops.kernel_variant_counts()
-    assert sum(after[k] - before[k] for k in ('ufd_lanes_fused1', 'ufd_fir_asm_fused1', 'ufd_tile_fused1')) > 0 and fused_fir_act.enabled, 'Gmain of the PL run must keep the fused epilogue'
+    assert sum(after[k] - before[k] for k in ('ufd_lanes_fused1', 'ufd_tile_fused1')) > 0 and fused_fir_act.enabled, 'Gmain of the PL run must keep the fused epilogue'
     for k in ('G/loss', 'G/reg', 'D/loss', 'D/reg'):
         assert abs(outs[0][k] - outs[1][k]) <= 2e-3 * max(1.0, abs(outs[1][k])), (k, outs)
     for (name, pa), (_, pb) in zip(a.G.named_parameters(), b.G.named_parameters()):
