@@ -637,7 +637,17 @@ __device__ __forceinline__ tile_pos decode_tile_tw(const s2_params& p, int tile)
 // (profiles/r03_s2_lab_store_burst.log: the tile-end stores cost the 64 <- 128 channel layer 21 %, and pairing the even / odd columns into one 8-byte store
 // or starting the workgroups staggered changes nothing -- the burst is HBM-write bound, 128 KiB per CU and tile at ~11 B/clk/CU).
 // IO: element format of x / y (sgv_io16.h; 16-bit tensors with TERMS = 1): 8-byte aligned dwordx2 loads, two 2-byte stores per accumulator pair.
-template <int TERMS, int ABL = 0, int S = 1, int IO = 0>
+// CM (tools/convT_lab.hip; the product instantiates 0): which accumulator tiles a consumer wave owns.
+//   0: ONE input row x 4 parity classes x both 32-channel halves of the 64 output channels.  Per tap 4 weight reads + 2 pixel reads feed 6 MFMAs
+//      (44 ds_read_b128 per 54 MFMAs and chunk).
+//   1 (round 5): TWO input rows x 4 classes x ONE half (wave = row pair * 2 + half); the six pixel operands of the pair (input rows r0-1 .. r0+1, columns
+//      x and x-1) stay in registers for the chunk and a tap's weights are read once for both rows: 30 reads per 54 MFMAs, the stride-1 kernel's ratio.
+//   2: as 1, and the first two pixel operands of the next chunk are read before the barrier (the x part of image q + 1 is complete by then).
+//   Measured (profiles/r05_c1_convT_lab.log, fp16 split): the consumer loop alone gains 4-5 % from 1 (0.522 vs 0.549 ms on 512 -> 256 channels) and
+//   nothing more from 2; the WHOLE kernel is 3-9 % slower with 1 and within +-3 % with 2 (0.873 / 0.753 / 0.707 ms against 0.901 / 0.751 / 0.683): the
+//   operand reads are not what the loop waits for.  The same log splits the kernel's time: consumers alone 0.55-0.68 ms, producers + DMA + stores alone
+//   0.41-0.86, everything but the stores 0.62-0.64, the tile-end stores 0.06 (256 channels out) - 0.26 ms (64 channels out, 1.6 GB).
+template <int TERMS, int ABL = 0, int S = 1, int IO = 0, int CM = 0>
 __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
     using namespace sgv_io;
     static_assert(IO == 0 || TERMS == 1, "16-bit tensors are single bf16 operands");
@@ -767,6 +777,124 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
     }
 
     // =========================================== consumers ===========================================
+    if constexpr (CM >= 1) {
+    f32x16 acc[2][4];   // [row of the pair][class a*2+b]
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int cl = 0; cl < 4; cl++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[r][cl][e] = 0.f;
+    const int rp = wave >> 1, hf = wave & 1;      // wave-uniform: input rows 2 rp, 2 rp + 1 of the tile; output channels 32 hf .. 32 hf + 31 of its 64
+    u32x4 B[3][2][2];    // [jj][dx][hl]: pixel operands of LDS rows 2 rp + jj at columns x - dx
+    u32x4 A[3][2];       // [buffer][hl]: the tap's weights for this wave's half, fetched two taps ahead
+
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_barrier();   // images 0 and 1 ready
+    asm volatile("" ::: "memory");
+    if (CM == 2 && ABL != 6) {
+        const int b0 = ((lane >> 5) * TW_RIN + 2 * rp) * TW_PW + ((lane & 31) / SW) * (SW + 1) + (lane & 31) % SW + 1;
+#pragma unroll
+        for (int jj = 1; jj <= 2; jj++) {
+            B[jj][0][0] = lds[b0 + jj * TW_PW];
+            if (TERMS > 1) B[jj][0][1] = lds[2 * TW_XS_PLANE + b0 + jj * TW_PW];
+        }
+    }
+    for (int q = 0; q < total; q++) {
+        const u32x4* xs = image(q);
+        const u32x4* ws = xs + TW_XS_WORDS;
+        const int c = q % chunks;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int a_lane = (ln >> 5) * TM + hf * 32 + (ln & 31);                                                    // + ((hl * 9 + tap) * 2) * TM
+        const int b_lane = ((ln >> 5) * TW_RIN + 2 * rp) * TW_PW + ((ln & 31) / SW) * (SW + 1) + (ln & 31) % SW + 1;   // + jj * PW - dx: LDS row 2 rp + jj = tile row 2 rp - 1 + jj
+
+        if (ABL != 6) {
+        auto fetch_b = [&](const u32x4* img, int jj, int dx) {
+            const int pos = b_lane + jj * TW_PW - dx;
+            B[jj][dx][0] = img[pos];
+            if (TERMS > 1) B[jj][dx][1] = img[2 * TW_XS_PLANE + pos];
+        };
+        auto fetch_a = [&](int buf, int tap) {
+            if (TERMS > 1) A[buf][1] = ws[a_lane + ((1 * 9 + tap) * 2) * TM];
+            A[buf][0] = ws[a_lane + ((0 * 9 + tap) * 2) * TM];
+        };
+        constexpr int RD = TERMS > 1 ? 2 : 1;   // reads per operand
+        // in the order of first use: tap 0 (ky = 0, kx = 0) needs rows jj = 1, 2 at dx = 0 and its weights
+        if (CM == 1) { fetch_b(xs, 1, 0); fetch_b(xs, 2, 0); }     // CM = 2: fetched behind the previous chunk's last taps (below; chunk 0: in front of the loop)
+        fetch_a(0, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, (CM == 1 ? 3 : 1) * RD, 0);
+#pragma unroll
+        for (int tap = 0; tap < 9; tap++) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int cl = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+            const int dx = kx == 2 ? 1 : 0;
+            const int j0 = ky == 2 ? 0 : 1;          // row r of the pair reads LDS row jj = j0 + r
+            const int bb = tap % 3;
+            int reads = 0;
+            // the weights of the next tap but one, and the remaining pixel operands a tap or more ahead of their first use: (1,1), (2,1) for tap 2;
+            // (0,0) for tap 6, (0,1) for tap 8
+            if (tap == 0) { fetch_a(1, 1); reads += RD; }
+            if (tap == 0) { fetch_b(xs, 1, 1); reads += RD; }
+            if (tap == 1) { fetch_b(xs, 2, 1); reads += RD; }
+            if (tap == 2) { fetch_b(xs, 0, 0); reads += RD; }
+            if (tap == 3) { fetch_b(xs, 0, 1); reads += RD; }
+            if (tap + 2 < 9) { fetch_a((tap + 2) % 3, tap + 2); reads += RD; }
+            if (CM == 2) {
+                // The x part of image q + 1 has been complete since the previous barrier (three images: the producers are filling q + 2), so the first two pixel
+                // operands of the NEXT chunk are read behind this chunk's last taps, into registers whose last use has passed -- (2,0) after tap 5, (1,0)
+                // after tap 7 -- and the first MFMA behind the barrier waits for its weights only (the DMA wave guarantees those at the barrier, not earlier).
+                // Behind the last chunk this reads an image nobody filled: allocated LDS, values never used.
+                if (tap == 6) { fetch_b(image(q + 1), 2, 0); reads += RD; }
+                if (tap == 8) { fetch_b(image(q + 1), 1, 0); reads += RD; }
+            }
+            if (TERMS > 1) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, TERMS>(A[bb][1], B[j0 + r][dx][0], acc[r][cl]);
+#pragma unroll
+                for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, TERMS>(A[bb][0], B[j0 + r][dx][1], acc[r][cl]);
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, TERMS>(A[bb][0], B[j0 + r][dx][0], acc[r][cl]);
+            constexpr int MF = TERMS > 1 ? 6 : 2;
+#pragma unroll
+            for (int i = 0; i < MF; i++) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        }
+        }
+
+        if (c == chunks - 1) {
+            const tile_pos tp = decode_tile_tw<S>(p, tile_of(q));
+            int le = lane;
+            asm volatile("" : "+v"(le));
+            const int g = le >> 5;
+            const size_t yb = ((size_t)(tp.n + (le & 31) / SW) * p.m + tp.mt * TM + hf * 32) * plane_out + (size_t)(2 * (tp.y0 + 2 * rp)) * wout + 2 * (tp.x0 + (le & 31) % SW);
+            const bool live = hf * 32 < p.m - tp.mt * TM;     // (wave-uniform) the upper half of a half-full last m tile has zero weights and is not stored
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+#pragma unroll
+                for (int a2 = 0; a2 < 2; a2++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const int m = (e & 3) + 8 * (e >> 2) + 4 * g;
+                        const size_t qd = yb + (size_t)m * plane_out + (size_t)(2 * r + a2) * wout;
+                        if (ABL == 8 || ABL == 10) { asm volatile("" :: "v"(acc[r][a2 * 2 + 0][e])); asm volatile("" :: "v"(acc[r][a2 * 2 + 1][e])); }   // lab: no stores
+                        else if (live) {
+                            out_store<IO>(p.y, qd, TERMS == 4 ? __builtin_ldexpf(acc[r][a2 * 2 + 0][e], eu) : acc[r][a2 * 2 + 0][e]);
+                            out_store<IO>(p.y, qd + 1, TERMS == 4 ? __builtin_ldexpf(acc[r][a2 * 2 + 1][e], eu) : acc[r][a2 * 2 + 1][e]);
+                        }
+                        acc[r][a2 * 2 + 0][e] = 0.f;
+                        acc[r][a2 * 2 + 1][e] = 0.f;
+                    }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    }
+    return;
+    }
     f32x16 acc[4][2];   // [class a*2+b][m half]
 #pragma unroll
     for (int cl = 0; cl < 4; cl++)
