@@ -26,7 +26,8 @@ int small_samples(int n, int h, int w) {
 
 bool io16(int dtype) { return dtype == SGV_BF16 || dtype == SGV_F16; }
 
-// 16-bit tensors (bf16 / fp16 activations, fp32 weights): the producer / consumer kernels only (images >= 32 pixels), single bf16 operands (terms = 1)
+// 16-bit tensors (bf16 / fp16 activations, fp32 weights): the producer / consumer kernels only (images >= 32 pixels), single 16-bit operands (terms = 1: bf16 tensors as
+// bf16, fp16 tensors as fp16 on the f16 MFMA -- operand_format of sgv_split.h)
 // Output channels: whole 64-channel tiles; the producer / consumer kernels (images >= 32 pixels) also take a half-full last tile (m % 32 == 0: the 32-channel
 // layers of the 1024^2 synthesis network, BASELINE configs[4]) -- its upper 32 rows are zero weights and are not stored.  SGV_CONV_M32=0 switches that off.
 int tiles_m(int m) { return (m + TM - 1) / TM; }
@@ -185,7 +186,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     if (!supported(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
         return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32 / bf16 / fp16 tensors, c_in %% 16 == 0, c_out %% 32 == 0, and W %% 32 == 0, H %% 16 == 0 (fp32 with c_out %% 64 == 0 also: 16x16 / 8x8 images) (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
                         who, p->n, p->c_in, p->c_out, p->h, p->w, dtype);
-    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: 16-bit tensors need terms = 1 (one bf16 operand per value)", who);
+    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: 16-bit tensors need terms = 1 (one 16-bit operand per value: bf16, or fp16 for fp16 tensors)", who);
     if (p->terms == 4 && !p->x_amax) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: terms = 4 (block-scaled fp16 split) needs x_amax, a device pointer to an upper bound of max |x| (sgv_absmax)", who);
     if (io16(dtype) && ep && ep->accumulate) return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: accumulate needs fp32 tensors", who);
     if (ep && !big_image(p->h, p->w)) return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: the fused form needs W %% 32 == 0 and H %% 16 == 0 (got h=%d w=%d)", who, p->h, p->w);
@@ -209,7 +210,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
         w_amax = slot;
     }
     hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
-                       p->terms, w_amax);
+                       dtype == SGV_F16 ? 2 : p->terms, w_amax);       // fp16 tensors: fp16 operands (format 2 of sgv_split.h)
     rc = sgv_check_launch("conv3x3_prep_weights");
     if (rc != SGV_OK) return rc;
 
@@ -319,7 +320,7 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: needs c_in %% 16 == 0, c_out %% 64 == 0 (transposed form: %% 32), W %% 32 == 0, H %% 8 == 0 on the HxW grid; 16-bit tensors: the strided form with c_out %% 128 == 0, the transposed form with the MFMA edge strips (got n=%d c_in=%d c_out=%d h=%d w=%d mode=%d dtype=%d)",
                         p->n, p->c_in, p->c_out, p->h, p->w, p->mode, dtype);
     if (p->terms != 1 && p->terms != 3 && p->terms != 4) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms must be 1, 3 or 4");
-    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: 16-bit tensors need terms = 1 (one bf16 operand per value)");
+    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: 16-bit tensors need terms = 1 (one 16-bit operand per value: bf16, or fp16 for fp16 tensors)");
     if (p->terms == 4 && !p->x_amax) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_s2: terms = 4 (block-scaled fp16 split) needs x_amax, a device pointer to an upper bound of max |x| (sgv_absmax)");
     if (p->terms == 4 && (!g_s2_ws || (p->mode == 2 && !g_edge_mfma))) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2: terms = 4 is served by the producer / consumer kernels only (SGV_S2_WS / SGV_CONVT_EDGE_MFMA are off)");
     if (io16(dtype) && ep && ep->accumulate) return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_s2_fused: accumulate needs fp32 tensors");
@@ -346,13 +347,13 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
     }
     if (pairs) {
         const int words = (p->c_out / P2_TM) * (p->c_in / P2_KC) * 10 * P2_TM;
-        hipLaunchKernelGGL(conv3x3_prep_weights_pairs, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->terms,
-                           w_amax);
+        hipLaunchKernelGGL(conv3x3_prep_weights_pairs, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in,
+                           dtype == SGV_F16 ? 2 : p->terms, w_amax);
         rc = sgv_check_launch("conv3x3_prep_weights_pairs");
     } else {
         const int words = tiles_m(p->c_out) * (p->c_in / KC) * 9 * 2 * TM;
         hipLaunchKernelGGL(conv3x3_prep_weights, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream, p->weight, (u32x4*)p->workspace, p->c_out, p->c_in, p->mode,
-                           p->terms, w_amax);
+                           dtype == SGV_F16 ? 2 : p->terms, w_amax);
         rc = sgv_check_launch("conv3x3_prep_weights");
     }
     if (rc != SGV_OK) return rc;

@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
 // mode 0: wgt(m,k,ky,kx) = w[m][k][ky][kx]            (forward;  w is [M, K, 3, 3])
 // mode 1: wgt(m,k,ky,kx) = w[k][m][2-ky][2-kx]        (data gradient of the same layer; w is [K, M, 3, 3])
 // mode 2: wgt(m,k,ky,kx) = w[k][m][ky][kx]            (transposed convolution;         w is [K, M, 3, 3])
-// terms = 4: fp16 hi/lo of w * 2^(14 - e), e from the bound `w_amax` (sgv_split.h).
+// terms = 4: fp16 hi/lo of w * 2^(14 - e), e from the bound `w_amax` (sgv_split.h); terms = 2: w rounded to fp16 (the operand format of fp16 tensors).
 __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x4* out, int m_total, int k_total, int mode, int terms, const float* w_amax = nullptr) {
     const int idx = blockIdx.x * 256 + threadIdx.x;   // one 16-B output word (8 k) of the hi plane
     const int chunks = k_total / KC;
@@ -471,10 +471,11 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights(const float* w, u32x
                          : w[(((size_t)(k0 + j) * m_total + m) * 3 + ky) * 3 + kx];
     u32x4 hi, lo;
     if (terms == 4) split8t<4>(v, split_scale(amax_exponent(*w_amax)), hi, lo);
+    else if (terms == 2) split8t<2>(v, 1.f, hi, lo);      // fp16 tensors: the weights rounded to fp16 (networks.py:50-52)
     else split8(v, hi, lo);
     const size_t base = ((size_t)mt * chunks + c) * WS_WORDS;
     out[base + ((0 * 9 + tap) * 2 + oct) * TM + mi] = hi;
-    if (terms > 1) out[base + ((1 * 9 + tap) * 2 + oct) * TM + mi] = lo;
+    if (terms > 2) out[base + ((1 * 9 + tap) * 2 + oct) * TM + mi] = lo;
 }
 
 

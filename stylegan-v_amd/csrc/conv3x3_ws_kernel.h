@@ -71,6 +71,7 @@ __device__ __forceinline__ f32x16 ws_mma(u32x4 a, u32x4 b, f32x16 c) {
 // TERMS: 1 bf16 products, 3 bf16 split, 4 block-scaled fp16 split (fp32-grade; sgv_split.h) -- same LDS images, same MFMA count as 3.
 template <int TERMS, int PRO, int EPI, int ABL = 0, int PRIO = 1, int IO = 0, int ORD = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
+    constexpr int F = sgv_conv::operand_format<TERMS, IO>();      // operand format of the products (sgv_split.h): TERMS, or 2 = fp16 operands for fp16 tensors
     constexpr bool A_IDLE = ABL == 1 || ABL == 6 || ABL == 7, A_NOSTORE = ABL == 4 || ABL == 6, A_NOREAD = ABL == 3 || ABL == 7;
     static_assert(IO == 0 || TERMS == 1, "16-bit tensors are multiplied as single bf16 operands");
     using namespace sgv_io;
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = ok ? (PRO == 1 ? v[j] * r.sc[j >> 2][j & 3] : v[j]) : 0.f;
             u32x4 hi, lo;
-            split8t<TERMS>(v, xS, hi, lo);
+            split8t<F>(v, xS, hi, lo);
             xs[pos] = hi;
             if (TERMS > 1) xs[2 * XS_PLANE + pos] = lo;
         };
@@ -322,18 +323,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                     for (int ky = ky_lo; ky <= ky_hi; ky++)
 #pragma unroll
                         for (int hf = 0; hf < 2; hf++)
-                            acc[j - ky][hf] = ws_mma<ABL, TERMS>(A[ky][hf][1], B[bb][0], acc[j - ky][hf]);
+                            acc[j - ky][hf] = ws_mma<ABL, F>(A[ky][hf][1], B[bb][0], acc[j - ky][hf]);
 #pragma unroll
                     for (int ky = ky_lo; ky <= ky_hi; ky++)
 #pragma unroll
                         for (int hf = 0; hf < 2; hf++)
-                            acc[j - ky][hf] = ws_mma<ABL, TERMS>(A[ky][hf][0], B[bb][1], acc[j - ky][hf]);
+                            acc[j - ky][hf] = ws_mma<ABL, F>(A[ky][hf][0], B[bb][1], acc[j - ky][hf]);
                 }
 #pragma unroll
                 for (int ky = ky_lo; ky <= ky_hi; ky++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[j - ky][hf] = ws_mma<ABL, TERMS>(A[ky][hf][0], B[bb][0], acc[j - ky][hf]);
+                        acc[j - ky][hf] = ws_mma<ABL, F>(A[ky][hf][0], B[bb][0], acc[j - ky][hf]);
                 const int MF = (TERMS > 1 ? 6 : 2) * (ky_hi - ky_lo + 1);
 #pragma unroll
                 for (int i = 0; i < MF; i++) {
@@ -380,18 +381,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[2 * rh + r][hf] = ws_mma<ABL, TERMS>(a[ab][hf][1], b[bb][r][0], acc[2 * rh + r][hf]);
+                        acc[2 * rh + r][hf] = ws_mma<ABL, F>(a[ab][hf][1], b[bb][r][0], acc[2 * rh + r][hf]);
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++)
-                        acc[2 * rh + r][hf] = ws_mma<ABL, TERMS>(a[ab][hf][0], b[bb][r][1], acc[2 * rh + r][hf]);
+                        acc[2 * rh + r][hf] = ws_mma<ABL, F>(a[ab][hf][0], b[bb][r][1], acc[2 * rh + r][hf]);
             }
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
-                    acc[2 * rh + r][hf] = ws_mma<ABL, TERMS>(a[ab][hf][0], b[bb][r][0], acc[2 * rh + r][hf]);
+                    acc[2 * rh + r][hf] = ws_mma<ABL, F>(a[ab][hf][0], b[bb][r][0], acc[2 * rh + r][hf]);
             // pin the interleave: one operand read of step s+1 behind each of the first MFMAs of step s (the MFMA issues every 32 cycles,
             // a ds_read_b128 costs one issue slot), so the reads are spread over the step and nothing is fetched earlier than needed
             constexpr int MF = TERMS > 1 ? 12 : 4;

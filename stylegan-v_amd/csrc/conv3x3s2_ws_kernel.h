@@ -300,10 +300,11 @@ __global__ __launch_bounds__(256) void conv3x3_prep_weights_pairs(const float* w
     for (int j = 0; j < 8; j++) v[j] = tap < 9 ? w[((size_t)m * k_total + k0 + j) * 9 + tap] : 0.f;
     u32x4 hi, lo;
     if (terms == 4) split8t<4>(v, split_scale(amax_exponent(*w_amax)), hi, lo);
+    else if (terms == 2) split8t<2>(v, 1.f, hi, lo);      // fp16 tensors: the weights rounded to fp16
     else split8(v, hi, lo);
     const size_t base = ((size_t)mt * chunks + c) * P2_WS_WORDS;
     out[base + (0 * 10 + tap) * P2_TM + mi] = hi;
-    if (terms > 1) out[base + (1 * 10 + tap) * P2_TM + mi] = lo;
+    if (terms > 2) out[base + (1 * 10 + tap) * P2_TM + mi] = lo;
 }
 
 template <int S>
@@ -337,6 +338,7 @@ struct s2_epilogue {
 // load instructions (dwordx2 at 2-byte aligned addresses instead of dwordx4 at 4-byte aligned ones), so the counted waits are those of the fp32 form.
 template <int TERMS, int ABL = 0, int EPI = 0, int S = 1, int IO = 0>
 __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s2_epilogue ep) {
+    constexpr int F = sgv_conv::operand_format<TERMS, IO>();      // operand format of the products (sgv_split.h): TERMS, or 2 = fp16 operands for fp16 tensors
     using namespace sgv_io;
     static_assert(IO == 0 || TERMS == 1, "16-bit tensors are single bf16 operands");
     constexpr int PW = p2_pw(S), P2_XS_PLANE = P2_RIN * 2 * PW, P2_XS_WORDS = 2 * P2_XS_PLANE, P2_IMAGE_WORDS = p2_image_words(S);
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
         };
         auto put = [&](u32x4* xs, int pos, const float* v) {
             u32x4 hi, lo;
-            split8t<TERMS>(v, xS, hi, lo);
+            split8t<F>(v, xS, hi, lo);
             xs[pos] = hi;
             if (TERMS > 1) xs[P2_XS_PLANE + pos] = lo;
         };
@@ -519,16 +521,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2_pairs_kernel(s2_params p, s
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
-                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, TERMS>(a[bb][mq][1], b[bb][r][0], acc[r][mq]);
+                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, F>(a[bb][mq][1], b[bb][r][0], acc[r][mq]);
 #pragma unroll
                 for (int r = 0; r < 2; r++)
 #pragma unroll
-                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, TERMS>(a[bb][mq][0], b[bb][r][1], acc[r][mq]);
+                    for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, F>(a[bb][mq][0], b[bb][r][1], acc[r][mq]);
             }
 #pragma unroll
             for (int r = 0; r < 2; r++)
 #pragma unroll
-                for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, TERMS>(a[bb][mq][0], b[bb][r][0], acc[r][mq]);
+                for (int mq = 0; mq < 4; mq++) acc[r][mq] = ws_mma<0, F>(a[bb][mq][0], b[bb][r][0], acc[r][mq]);
             constexpr int MF = TERMS > 1 ? 24 : 8;
             const int reads = pair + 1 < 5 ? RD : 0;
 #pragma unroll
@@ -649,6 +651,7 @@ __device__ __forceinline__ tile_pos decode_tile_tw(const s2_params& p, int tile)
 //   0.41-0.86, everything but the stores 0.62-0.64, the tile-end stores 0.06 (256 channels out) - 0.26 ms (64 channels out, 1.6 GB).
 template <int TERMS, int ABL = 0, int S = 1, int IO = 0, int CM = 0>
 __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
+    constexpr int F = sgv_conv::operand_format<TERMS, IO>();      // operand format of the products (sgv_split.h): TERMS, or 2 = fp16 operands for fp16 tensors
     using namespace sgv_io;
     static_assert(IO == 0 || TERMS == 1, "16-bit tensors are single bf16 operands");
     constexpr int TW_PW = tw_pw(S), TW_XS_PLANE = TW_RIN * TW_PW, TW_XS_WORDS = 4 * TW_XS_PLANE, TW_IMAGE_WORDS = tw_image_words(S);
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
 #pragma unroll
             for (int j = 0; j < 8; j++) v[j] = ok ? v[j] : 0.f;
             u32x4 hi, lo;
-            split8t<TERMS>(v, xS, hi, lo);
+            split8t<F>(v, xS, hi, lo);
             xs[pos] = hi;
             if (TERMS > 1) xs[2 * TW_XS_PLANE + pos] = lo;
         };
@@ -850,12 +853,12 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
             }
             if (TERMS > 1) {
 #pragma unroll
-                for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, TERMS>(A[bb][1], B[j0 + r][dx][0], acc[r][cl]);
+                for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, F>(A[bb][1], B[j0 + r][dx][0], acc[r][cl]);
 #pragma unroll
-                for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, TERMS>(A[bb][0], B[j0 + r][dx][1], acc[r][cl]);
+                for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, F>(A[bb][0], B[j0 + r][dx][1], acc[r][cl]);
             }
 #pragma unroll
-            for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, TERMS>(A[bb][0], B[j0 + r][dx][0], acc[r][cl]);
+            for (int r = 0; r < 2; r++) acc[r][cl] = ws_mma<0, F>(A[bb][0], B[j0 + r][dx][0], acc[r][cl]);
             constexpr int MF = TERMS > 1 ? 6 : 2;
 #pragma unroll
             for (int i = 0; i < MF; i++) {
@@ -941,12 +944,12 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
             if (tap + 2 < 9) fetch((tap + 2) % 3, tap + 2);
             if (TERMS > 1) {
 #pragma unroll
-                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, TERMS>(a[bb][hf][1], b[bb][0], acc[cl][hf]);
+                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, F>(a[bb][hf][1], b[bb][0], acc[cl][hf]);
 #pragma unroll
-                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, TERMS>(a[bb][hf][0], b[bb][1], acc[cl][hf]);
+                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, F>(a[bb][hf][0], b[bb][1], acc[cl][hf]);
             }
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, TERMS>(a[bb][hf][0], b[bb][0], acc[cl][hf]);
+            for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, F>(a[bb][hf][0], b[bb][0], acc[cl][hf]);
             constexpr int MF = TERMS > 1 ? 6 : 2;
             const int reads = tap + 2 < 9 ? RD : 0;
 #pragma unroll

@@ -77,7 +77,7 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
         return sgv_fail(SGV_ERR_UNSUPPORTED, "conv3x3_wrw: needs fp32, channels %% 64 == 0, W %% 32 == 0 with H <= 32 or H %% 32 == 0, or W in {16, 8} with H <= 32 (got n=%d o=%d i=%d h=%d w=%d dtype=%d)",
                         p->n, p->c_out, p->c_in, p->h, p->w, dtype);
     if (p->terms != 1 && p->terms != 3 && p->terms != 4) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms must be 1 (bf16 products), 3 (bf16 split) or 4 (block-scaled fp16 split)");
-    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: 16-bit tensors need terms = 1 (one bf16 operand per value)");
+    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: 16-bit tensors need terms = 1 (one 16-bit operand per value: bf16, or fp16 for fp16 tensors)");
     if (p->terms == 4 && (!p->dy_amax || !p->x_amax)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms = 4 needs dy_amax and x_amax, device pointers to upper bounds of max |dy| / max |x| (sgv_absmax)");
     if ((((uintptr_t)p->dy) | ((uintptr_t)p->x)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: dy and x must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
@@ -171,7 +171,7 @@ extern "C" int sgv_conv3x3_wrw_s2(const sgv_conv_wrw_params* p, int dtype, void*
                         p->n, p->c_out, p->c_in, p->h, p->w, dtype);
     if (p->terms != 1 && p->terms != 3 && p->terms != 4) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms must be 1, 3 or 4");
     if (p->terms == 4 && (!p->dy_amax || !p->x_amax)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: terms = 4 needs dy_amax and x_amax, device pointers to upper bounds of max |dy| / max |x| (sgv_absmax)");
-    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: 16-bit tensors need terms = 1 (one bf16 operand per value)");
+    if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: 16-bit tensors need terms = 1 (one 16-bit operand per value: bf16, or fp16 for fp16 tensors)");
     if (((uintptr_t)p->dy) & (io16(dtype) ? 7 : 15)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_s2: the small tensor must be aligned to four elements");
     init_s2_once();
     if (g_attr_err != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "conv3x3_wrw_s2: hipFuncSetAttribute failed: %s", hipGetErrorString(g_attr_err));

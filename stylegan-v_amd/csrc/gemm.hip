@@ -18,6 +18,8 @@
 #include "sgv_common.h"
 #include "gemm_kernel.h"
 #include <stdlib.h>
+#include <mutex>
+#include <set>
 
 using namespace sgv_gemm;
 
@@ -65,6 +67,42 @@ extern "C" int sgv_gemm_f32(const sgv_gemm_params* p, void* stream_) {
     static const bool allow_x3 = !(getenv("SGV_GEMM_TERMS") && getenv("SGV_GEMM_TERMS")[0] == '0');
     const bool x3 = allow_x3 && p->exact_fp32 != 1 && p->n % BN == 0 && gp.k % X3_BK == 0 && p->lda % 4 == 0 && p->stride_a % 4 == 0 && al16(p->a) && (int64_t)slice_ok(p, ks) &&
                     (!p->trans_b || (p->ldb % 4 == 0 && p->stride_b % 4 == 0 && al16(p->b)));
+    // W-stationary member (conv1x1_wstat_kernel): a 1x1 convolution on NCHW (shared A, n-contiguous B) whose weight matrix fits LDS -- the 64 <-> 128 and
+    // 128 <-> 256 channel skip products and their data gradients; SGV_GEMM_WSTAT=0 keeps them on the tiled members.
+    static const bool allow_wstat = !(getenv("SGV_GEMM_WSTAT") && getenv("SGV_GEMM_WSTAT")[0] == '0');
+    if (x3 && allow_wstat && !p->trans_b && p->stride_a == 0 && ks == 1 && p->bias_mode != 1 && p->m % 32 == 0 && p->k % 16 == 0 && p->n % 32 == 0) {
+        const int mt = p->m / 32, kst = p->k / 16;
+        const int64_t blocks = (int64_t)p->batch * (p->n / 32);
+        typedef void (*wstat_fn)(gemm_params, int, int);
+        wstat_fn fn = nullptr;
+#define SGV_WSTAT(MT_, KS_) if (mt == MT_ && kst == KS_) fn = f16 ? (wstat_fn)conv1x1_wstat_kernel<4, MT_, KS_> : (wstat_fn)conv1x1_wstat_kernel<3, MT_, KS_>;
+        SGV_WSTAT(4, 4) SGV_WSTAT(2, 8) SGV_WSTAT(8, 8) SGV_WSTAT(4, 16)
+#undef SGV_WSTAT
+        static const int cus = [] {
+            int dev = 0, n = 256;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) n = prop.multiProcessorCount;
+            return n;
+        }();
+        if (fn && blocks >= 8 * cus && blocks <= INT32_MAX && p->ldb < (1 << 26) && p->ldc < (1 << 26)) {   // (the prologue reads the whole weight matrix per workgroup; 32-bit lane offsets)
+            const int lds = wstat_lds_bytes(mt, kst);
+            static std::mutex mu;
+            static std::set<const void*> prepared;
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                if (!prepared.count((const void*)fn)) {
+                    if (hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "gemm: hipFuncSetAttribute failed");
+                    prepared.insert((const void*)fn);
+                }
+            }
+            // 32-KiB weight images (130-148 registers): two workgroups of six waves per CU = three waves per SIMD; 128-KiB images: one workgroup of eight
+            if (lds <= 64 * 1024) hipLaunchKernelGGL(fn, dim3((unsigned)(2 * cus)), dim3(384), lds, stream, gp, p->n / 32, (int)blocks);
+            else
+            hipLaunchKernelGGL(fn, dim3((unsigned)cus), dim3(512), lds, stream, gp, p->n / 32, (int)blocks);
+            sgv_note_variant(SGV_V_conv1x1_wstat);
+            return sgv_check_launch("conv1x1_wstat_kernel");
+        }
+    }
     if (x3) {
         static const hipError_t attr_err = [] {
             hipError_t e = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, X3_LDS_BYTES);

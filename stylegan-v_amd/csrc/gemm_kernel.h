@@ -564,4 +564,111 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_stream_kernel(gemm_params 
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// conv1x1_wstat_kernel: the 1x1 convolution of an NCHW activation, C[b][M, N] = W[M, K] * X[b][K, N] (M = c_out, K = c_in, N = H * W), for the shapes whose
+// weight matrix fits the CU's LDS -- the discriminator's 64 -> 128 and 128 -> 256 skip products (networks.py:452) and their data gradients (W^T).
+//
+// These products are streams: 1.4-5 flop per byte, 1.2 GB through HBM for 26 GFLOP.  In the tiled members above every 128 x 128 tile stages BOTH operands through
+// LDS behind barriers -- the activation is loaded into registers, split, written to LDS in the transposed layout, read back by four waves in lock step, and a
+// tile's loads, MFMAs and 64 stores per wave run one after the other: 2.3-3.2 TB/s (profiles/r04_bench_driver_cmd.json: 8.2 ms per training step).  Here the
+// roles follow the data:
+//   * W (at most 128 KiB as fp16 / bf16 hi + lo) is split ONCE per workgroup into LDS, in MFMA A-operand order, and stays there: the workgroups are persistent;
+//   * X never touches LDS.  The MFMA's B operand wants, per lane, 8 consecutive k (channels) of one column (pixel): lane l loads pixel n0 + (l & 31) of the
+//     channels 16 s + 8 (l >> 5) + j, j = 0..7 -- dword loads that are coalesced across the half-wave (128 B of one channel row) -- and splits them in
+//     registers.  The loads of a 32-pixel block are issued 32 (four k steps) at a time, two such groups in flight;
+//   * a wave owns a 32-pixel block x all M rows (M / 32 accumulator tiles) and walks blocks grid-stride; the waves of a workgroup take neighbouring blocks.  There
+//     is no barrier after the prologue: a wave that waits for its loads leaves its SIMD to the other waves' MFMAs and stores.
+// Algorithmic bytes: 4 (K + M) N per sample; every byte crosses HBM once (M <= 256 here: one slab).
+// Store: C/D layout of the 32 x 32 MFMA -- 128 contiguous bytes per half-wave and register; bias per row, residual and the magnitude bound as the tiled members.
+template <int TERMS, int MT, int KS>
+__global__ __launch_bounds__(512, 2) void conv1x1_wstat_kernel(gemm_params p, int px_blocks, int total_blocks) {
+    constexpr int M = 32 * MT;
+    extern __shared__ __attribute__((aligned(16))) gu32x4 ws_lds[];     // [hl][k step][octet][M rows] of 16-byte words (8 k each)
+    const int ea = sgv_conv::operand_exponent<TERMS>(p.a_amax), eb = sgv_conv::operand_exponent<TERMS>(p.b_amax);
+    const float aS = sgv_conv::split_scale(ea), bS = sgv_conv::split_scale(eb);
+    const int eu = sgv_conv::unscale_exponent(ea, eb);
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6), nw = (int)blockDim.x >> 6;
+    const int lr = lane & 31, lk = lane >> 5;
+
+    // prologue: the whole weight matrix, split, into LDS (rows of 8 k: two 16-byte loads)
+    for (int idx = t; idx < KS * 2 * M; idx += (int)blockDim.x) {
+        const int row = idx % M, oct = (idx / M) & 1, ks = idx / (2 * M);
+        const float4 v0 = *(const float4*)(p.a + (int64_t)row * p.lda + ks * 16 + oct * 8);
+        const float4 v1 = *(const float4*)(p.a + (int64_t)row * p.lda + ks * 16 + oct * 8 + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        gu32x4 hi, lo;
+        sgv_conv::split8t<TERMS>(v, aS, hi, lo);
+        ws_lds[((0 * KS + ks) * 2 + oct) * M + row] = hi;
+        ws_lds[((1 * KS + ks) * 2 + oct) * M + row] = lo;
+    }
+    __syncthreads();
+
+    unsigned amx = 0u;
+    const int G = (int)gridDim.x;
+    // addresses = wave-uniform row pointer (SGPR pair) + one 32-bit lane offset: per-load 64-bit vector addresses would cost two registers per load in flight
+    const int ldb = (int)p.ldb, ldc = (int)p.ldc;                 // (host-checked: 8 * ldb and 36 * ldc elements fit 31 bits of bytes)
+    const int x_lane = 8 * lk * ldb + lr, c_lane = 4 * lk * ldc + lr;
+    for (int blk = (int)blockIdx.x * nw + wave; blk < total_blocks; blk += G * nw) {
+        const int b = blk / px_blocks, n0 = (blk - b * px_blocks) * 32;
+        const float* src = p.b + (int64_t)b * p.stride_b + n0;          // wave-uniform
+        // k steps in groups of four (32 loads per lane); two groups in flight: group g + 1 is issued before group g is multiplied
+        constexpr int GS = KS < 4 ? KS : 4, NG = KS / GS;
+        float xv[2][GS][8];
+        auto load_group = [&](int g, int buf) {
+#pragma unroll
+            for (int s4 = 0; s4 < GS; s4++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) xv[buf][s4][j] = (src + (int64_t)((g * GS + s4) * 16 + j) * ldb)[x_lane];
+        };
+        f32x16 acc[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[mt][e] = 0.f;
+        load_group(0, 0);
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            if (g + 1 < NG) load_group(g + 1, (g + 1) & 1);
+#pragma unroll
+            for (int s4 = 0; s4 < GS; s4++) {
+                const int ks = g * GS + s4;
+                gu32x4 bh, bl;
+                sgv_conv::split8t<TERMS>(xv[g & 1][s4], bS, bh, bl);
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++) {
+                    const gu32x4 ah = ws_lds[((0 * KS + ks) * 2 + lk) * M + mt * 32 + lr];
+                    const gu32x4 al = ws_lds[((1 * KS + ks) * 2 + lk) * M + mt * 32 + lr];
+                    acc[mt] = sgv_conv::mma16<TERMS>(al, bh, acc[mt]);
+                    acc[mt] = sgv_conv::mma16<TERMS>(ah, bl, acc[mt]);
+                    acc[mt] = sgv_conv::mma16<TERMS>(ah, bh, acc[mt]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keeps the loads of group g + 2 and the weight reads of later groups behind this group's products (registers)
+        }
+        float* C = p.c + (int64_t)b * p.stride_c + n0;                  // wave-uniform
+        const float* RES = p.residual ? p.residual + (int64_t)b * p.stride_c + n0 : nullptr;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++) {
+            float rv[16];
+            if (RES) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) rv[e] = (RES + (int64_t)(mt * 32 + (e & 3) + 8 * (e >> 2)) * ldc)[c_lane];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int row = mt * 32 + (e & 3) + 8 * (e >> 2);        // + 4 * lk: in c_lane
+                float v = TERMS == 4 ? __builtin_ldexpf(acc[mt][e], eu) : acc[mt][e];
+                if (p.bias_mode == 2) v += p.bias[row + 4 * lk];
+                if (RES) v += rv[e];
+                (C + (int64_t)row * ldc)[c_lane] = v;
+                amx = sgv_amax_fold(amx, v);
+            }
+        }
+    }
+    if (p.c_amax) sgv_amax_commit(amx, p.c_amax);
+}
+constexpr int wstat_lds_bytes(int mt, int ks) { return 2 * ks * 2 * 32 * mt * 16; }
+
+
 }  // namespace sgv_gemm

@@ -1,6 +1,6 @@
 // Operand formats of the matrix-pipe convolution / GEMM kernels (TERMS template parameter of every member of the 3x3 family and of the tiled GEMM):
 //
-//   TERMS = 1   one bf16 operand per value                              (16-bit tensors; "bf16 products")
+//   TERMS = 1   one bf16 operand per value                              (bf16 tensors; "bf16 products" on fp32 tensors); fp16 tensors: one fp16 operand (format 2 below)
 //   TERMS = 3   2-way bf16 split  v = hi + lo, 3 MFMAs per product      (16 mantissa bits per operand: 4.4e-6 of the result's scale, NOT fp32-grade)
 //   TERMS = 4   2-way fp16 split of the BLOCK-SCALED value, 3 MFMAs     (22 mantissa bits per operand: fp32-grade -- the default since round 4)
 //
@@ -58,10 +58,20 @@ __device__ __forceinline__ unsigned sp_pack_f16(float a, float b) {
     return __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2));       // RNE (fp16 denormals kept)
 }
 
+// Operand format of a kernel instantiation: its TERMS, except that 16-bit tensors (TERMS = 1) whose elements ARE fp16 (IO = 2 of sgv_io16.h) are multiplied
+// as fp16 operands on v_mfma_f32_32x32x16_f16 -- format 2, one product, no scale, no rounding of the activations at all (their 11 significant bits; the fp32 master
+// weights are rounded to fp16 as the reference rounds them, networks.py:50-52 `w.to(x.dtype)`) -- instead of being rounded to bf16's 8 (rounds 1-4: 2e-3 per convolution).
+template <int TERMS, int IO>
+constexpr int operand_format() { return (TERMS == 1 && IO == 2) ? 2 : TERMS; }
+
 // two neighbouring values -> one dword of the hi plane and one of the lo plane
 template <int TERMS>
 __device__ __forceinline__ void split2(float a, float b, float S, unsigned& hi, unsigned& lo) {
-    if constexpr (TERMS == 4) {
+    if constexpr (TERMS == 2) {
+        // a product formed in fp32 on the way in (x * styles) may leave fp16's range: saturate like the reference's clamp would (conv_clamp = 256 bounds x)
+        hi = sp_pack_f16(__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f));
+        lo = 0u;
+    } else if constexpr (TERMS == 4) {
         a *= S; b *= S;
         const unsigned h = sp_pack_f16(a, b);
         const f16x2 hh = __builtin_bit_cast(f16x2, h);
@@ -89,7 +99,7 @@ __device__ __forceinline__ void split8t(const float* v, float S, sp_u32x4& hi, s
 // D = A (32 x 16) * B (16 x 32) + C on the 16-bit matrix pipe: bf16 operands, or fp16 ones for the block-scaled split
 template <int TERMS>
 __device__ __forceinline__ sp_f32x16 mma16(sp_u32x4 a, sp_u32x4 b, sp_f32x16 c) {
-    if constexpr (TERMS == 4) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    if constexpr (TERMS == 4 || TERMS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sp_bf16x8, a), __builtin_bit_cast(sp_bf16x8, b), c, 0, 0, 0);
 }
 

@@ -34,6 +34,7 @@ constexpr int WRW_S2_WS_LDS_BYTES = (2 * 5 * BIG_SLOT + 2 * 3 * S2W_SMALL) * 2;
 // IO: element format of the two activation tensors (sgv_io16.h; 16-bit tensors with TERMS = 1; dw stays fp32): the same load instructions at half the width.
 template <int TERMS, bool PACK = false, int ABL = 0, int IO = 0>
 __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
+    constexpr int F = sgv_conv::operand_format<TERMS, IO>();      // operand format of the products (sgv_split.h): TERMS, or 2 = fp16 operands for fp16 tensors
     using namespace sgv_io;
     static_assert(IO == 0 || TERMS == 1, "16-bit tensors are single bf16 operands");
     constexpr int ES = fmt<IO>::ES;
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
                 const int it = pt + 256 * j, quad = it & 15, ch = it >> 4;
                 const float v0 = px4_get<IO>(r.v[j], 0), v1 = px4_get<IO>(r.v[j], 1), v2 = px4_get<IO>(r.v[j], 2), v3 = px4_get<IO>(r.v[j], 3);
                 unsigned he, ho, le, lo;
-                split2<TERMS>(v0, v2, bS, he, le);     // even columns
-                split2<TERMS>(v1, v3, bS, ho, lo);     // odd columns
+                split2<F>(v0, v2, bS, he, le);     // even columns
+                split2<F>(v1, v3, bS, ho, lo);     // odd columns
                 const int pos = slot * BIG_SLOT + ch * BIG_CH + 2 * quad;
                 *(unsigned*)&bs[pos] = he;
                 *(unsigned*)&bs[pos + RS] = ho;
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
             if (pt < TI * spr) {
                 const float ev = px1_get<IO>(r.e);
                 unsigned h, l;
-                split2<TERMS>(ev, 0.f, bS, h, l);
+                split2<F>(ev, 0.f, bS, h, l);
                 const int pos = slot * BIG_SLOT + (pt & 63) * BIG_CH + (PACK ? 2 * RS + 2 * (pt >> 6) : 32);
                 bs[pos] = (unsigned short)h;
                 if (TERMS > 1) bs[5 * BIG_SLOT + pos] = (unsigned short)l;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = (!PACK || live) ? px4_get<IO>(r.a, k) : 0.f; v[4 + k] = (!PACK || live) ? px4_get<IO>(r.b, k) : 0.f; }
             u32x4 hi, lo;
-            split8t<TERMS>(v, sS, hi, lo);
+            split8t<F>(v, sS, hi, lo);
             *(u32x4*)&as[buf * S2W_SMALL + lr * RS + lq] = hi;
             if (TERMS > 1) *(u32x4*)&as[(3 + buf) * S2W_SMALL + lr * RS + lq] = lo;
         };
@@ -294,14 +295,14 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_s2_ws_kernel(wrw_s2_params p) {
                 if (TERMS > 1) {
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = mma16<TERMS>(a_lo, bh[kx], acc[ky * 3 + kx]);
+                        acc[ky * 3 + kx] = mma16<F>(a_lo, bh[kx], acc[ky * 3 + kx]);
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = mma16<TERMS>(a_hi, bl[kx], acc[ky * 3 + kx]);
+                        acc[ky * 3 + kx] = mma16<F>(a_hi, bl[kx], acc[ky * 3 + kx]);
                 }
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++)
-                    acc[ky * 3 + kx] = mma16<TERMS>(a_hi, bh[kx], acc[ky * 3 + kx]);
+                    acc[ky * 3 + kx] = mma16<F>(a_hi, bh[kx], acc[ky * 3 + kx]);
                 constexpr int MF = TERMS > 1 ? 9 : 3;
                 constexpr int RPM = TERMS > 1 ? 2 : 3;   // operand reads behind each of the first MFMAs
 #pragma unroll

@@ -46,6 +46,7 @@ constexpr int WRW_WS_LDS_BYTES = wrw_ws_lds_bytes(3);
 //     loads per item -- dwordx4 -> dwordx2, halo dword -> ushort -- so every counted wait below holds for all formats.
 template <int TERMS, int VIEWS = 1, int ABL = 0, bool PACK = false, int IO = 0>
 __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
+    constexpr int F = sgv_conv::operand_format<TERMS, IO>();      // operand format of the products (sgv_split.h): TERMS, or 2 = fp16 operands for fp16 tensors
     static_assert(!PACK || VIEWS == 1, "packed samples: single-view form only");
     static_assert(IO == 0 || TERMS == 1, "16-bit tensors are multiplied as single bf16 operands");
     using namespace sgv_io;
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
         auto touch_x = [&](xrow& r) { px4_pin<IO>(r.a); px4_pin<IO>(r.b); px1_pin<IO>(r.l); px1_pin<IO>(r.r); };
         auto touch_d = [&](drow& r) { px4_pin<IO>(r.a); px4_pin<IO>(r.b); };
         // one pair of neighbouring pixels -> packed 16-bit hi and lo (TERMS = 4: the values already carry the block scale, folded into xmul)
-        auto pair = [&](float a, float b, unsigned& hi, unsigned& lo) { split2<TERMS>(a, b, 1.f, hi, lo); };
+        auto pair = [&](float a, float b, unsigned& hi, unsigned& lo) { split2<F>(a, b, 1.f, hi, lo); };
         float xmul = 1.f;     // xsc (x block scale) for the current unit: set where xsc is known to have landed
         auto store_x = [&](int row, const xrow& r) {
             if (ABL == 7) return;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
 #pragma unroll
             for (int k = 0; k < 4; k++) { v[k] = (!PACK || smp_ok) ? px4_get<IO>(r.a, k) : 0.f; v[4 + k] = (!PACK || smp_ok) ? px4_get<IO>(r.b, k) : 0.f; }
             u32x4 hi, lo;
-            split8t<TERMS>(v, dS, hi, lo);
+            split8t<F>(v, dS, hi, lo);
             *(u32x4*)(ds + (size_t)buf * WS_DBUF + lr * RS + lq) = hi;
             if (TERMS > 1) *(u32x4*)(ds + (size_t)(3 + buf) * WS_DBUF + lr * RS + lq) = lo;
         };
@@ -347,14 +348,14 @@ __global__ __launch_bounds__(512, 2) void wrw3x3_ws_kernel(wrw_params p) {
                 if (TERMS > 1) {
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = mma16<TERMS>(a_lo, bh[kx], acc[ky * 3 + kx]);
+                        acc[ky * 3 + kx] = mma16<F>(a_lo, bh[kx], acc[ky * 3 + kx]);
 #pragma unroll
                     for (int kx = 0; kx < 3; kx++)
-                        acc[ky * 3 + kx] = mma16<TERMS>(a_hi, bl[kx], acc[ky * 3 + kx]);
+                        acc[ky * 3 + kx] = mma16<F>(a_hi, bl[kx], acc[ky * 3 + kx]);
                 }
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++)
-                    acc[ky * 3 + kx] = mma16<TERMS>(a_hi, bh[kx], acc[ky * 3 + kx]);
+                    acc[ky * 3 + kx] = mma16<F>(a_hi, bh[kx], acc[ky * 3 + kx]);
                 constexpr int MF = TERMS > 1 ? 9 : 3;
                 // RPM operand reads behind each of the first MFMAs: the earlier the last read issues, the more MFMAs cover its LDS latency
                 constexpr int RPM = TERMS > 1 ? SGV_WRW_RPM : 3;

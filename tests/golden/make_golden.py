@@ -325,6 +325,70 @@ def gen_networks_mid():
     save('networks_mid', arrays, meta)
 
 
+def gen_networks_fp16():
+    """The models of `networks_mid` (128 channels, 128^2, 2 videos x 3 frames, name-seeded parameters, same inputs) in the reference's MIXED PRECISION:
+    num_fp16_res = 2, conv_clamp = 256 (train.py:173-174 sets 4 / 256 at 256^2; here the blocks at 64^2 and 128^2 hold fp16 activations and hand
+    `w.to(torch.float16)` to the convolution, networks.py:50-52,227,461), executed by the reference itself on CPU.  What the fp16 tensor path of
+    this library is compared with -- next to the fp32 run of the same models in networks_mid.npz."""
+    from omegaconf import OmegaConf
+    from training.networks import Generator, Discriminator
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import seeded_parameters_, sample_flat
+    RES, CH = 128, 128
+    sampling = dict(type='random', num_frames_per_video=3, max_num_frames=64, total_dists=[1, 2, 4, 8, 16, 32], max_dist=32, name='random3_max32')
+    gcfg = OmegaConf.create(dict(sampling=sampling, use_noise=False, input=dict(type='temporal'), w_dim=64, z_dim=64, c_dim=0,
+                                 motion=dict(z_dim=24, v_dim=24, motion_z_distance=4, gen_strategy='conv', kernel_size=5, use_fractional_t=True, fourier=True),
+                                 time_enc=dict(cond_type='concat_const', dim=8, min_period_len=4, max_period_len=64, phase_dropout_std=1.0)))
+    dcfg = OmegaConf.create(dict(sampling=sampling, concat_res=16, num_frames_div_factor=2, dummy_c=False))
+    torch.manual_seed(4048)
+    G = Generator(c_dim=0, w_dim=64, img_resolution=RES, img_channels=3, mapping_kwargs=dict(num_layers=2, cfg=gcfg),
+                  synthesis_kwargs=dict(channel_base=RES * CH, channel_max=CH, num_fp16_res=2, conv_clamp=256), cfg=gcfg)
+    D = Discriminator(c_dim=0, img_resolution=RES, img_channels=3, channel_base=RES * CH, channel_max=CH, num_fp16_res=2, conv_clamp=256,
+                      mapping_kwargs=dict(num_layers=2), epilogue_kwargs=dict(mbstd_group_size=2), cfg=dcfg)
+    seeded_parameters_(G, 101)
+    seeded_parameters_(D, 202)
+    g = torch.Generator().manual_seed(78)
+    B, F = 2, 3
+    z = torch.randn([B, 64], generator=g)
+    c = torch.zeros([B, 0])
+    t = torch.sort(torch.rand([B, F], generator=g) * 40, dim=1).values
+    traj_len = G.synthesis.motion_encoder.get_max_traj_len(t) + G.synthesis.motion_encoder.num_additional_codes
+    motion_z = torch.randn([B, traj_len, 24], generator=g)
+    arrays = {'z': z, 't': t, 'motion_z': motion_z}
+    G.train(); D.train()
+    ws = G.mapping(z, c, skip_w_avg_update=True)
+    arrays['ws'] = ws
+    img_train = G.synthesis(ws, t=t, c=c, motion_z=motion_z)
+    arrays['img_train'] = img_train
+    real = torch.rand([B * F, 3, RES, RES], generator=g) * 2 - 1
+    arrays['real'] = real.half()      # exactly representable on both sides: the test reads it back as float32
+    real = real.half().float()
+    arrays['logits_fake'] = D(img_train.detach(), c, t)['image_logits']
+    G.zero_grad(); D.zero_grad()
+    img = G.synthesis(G.mapping(z, c, skip_w_avg_update=True), t=t, c=c, motion_z=motion_z)
+    loss_g = torch.nn.functional.softplus(-D(img, c, t)['image_logits']).mean()
+    loss_g.backward()
+    arrays['loss_Gmain'] = loss_g
+    for name, p in G.named_parameters():
+        arrays['gradG.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p))
+    G.zero_grad(); D.zero_grad()
+    real_tmp = real.clone().requires_grad_(True)
+    logits_real = D(real_tmp, c, t)['image_logits']
+    (r1_grads,) = torch.autograd.grad(logits_real.sum(), real_tmp, create_graph=True)
+    r1 = r1_grads.square().sum([1, 2, 3])
+    loss_d = (torch.nn.functional.softplus(-logits_real) + (r1 * 0.5).view(-1, F).mean(dim=1)).mean()
+    loss_d.backward()
+    arrays['logits_real'] = logits_real
+    arrays['r1_penalty'] = r1
+    arrays['loss_Dreal_r1'] = loss_d
+    for name, p in D.named_parameters():
+        arrays['gradD.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p))
+    meta = dict(B=B, F=F, res=RES, channels=CH, w_dim=64, z_dim=64, seed_G=101, seed_D=202,
+                G_params=sum(p.numel() for p in G.parameters()), D_params=sum(p.numel() for p in D.parameters()))
+    meta.update(num_fp16_res=2, conv_clamp=256)
+    save('networks_fp16', arrays, meta)
+
+
 def gen_networks_full():
     """Third module golden: the benchmark's own models -- FFS 256^2, cfg=auto (fmaps 0.5: channels 512,512,512,512,256,128,64; mapping depth 2;
     src/train.py:138-200, configs/model/stylegan-v.yaml), 2 videos x 3 frames.  Parameters are drawn on both sides with
@@ -638,6 +702,7 @@ if __name__ == '__main__':
     gen_conv_ops()
     gen_networks()
     gen_networks_mid()
+    gen_networks_fp16()
     gen_networks_full()
     gen_networks_1024()
     gen_networks_cfg1()

@@ -679,12 +679,23 @@ def test_bf16x3_gemm_member_serves_the_1x1_convolutions(n, cin, cout, hw):
     assert torch.equal(yi.double(), yi64) and torch.equal(gxi.double(), rxi) and torch.equal(gwi.double(), rwi), 'integer data must be exact'
 
 
-@pytest.mark.parametrize('n,cin,cout,hw', [(5, 64, 128, 128), (9, 128, 256, 64), (5, 128, 64, 128), (7, 32, 192, 128)])
-def test_bf16x3_stream_gemm_walks_tiles_persistently(n, cin, cout, hw):
-    """gemm_bf16x3_stream_kernel (csrc/gemm_kernel.h): launches with more tiles than resident workgroups (2 per CU) run as persistent workgroups that
-    prefetch the next tile's first chunk across the epilogue.  Tile counts that are not a multiple of the grid (uneven tails), two m-tiles per B panel
-    (XCD-aware order), rows that are not a multiple of the tile (64 / 192), bias + residual in the store: against float64 `conv2d` (< 1e-5, the
-    family's bound) and EXACT on small-integer data (pins tile decoding, the cross-tile register hand-over and the accumulator reset)."""
+def _conv1x1_member(rows, k, hw, n):
+    """Which member of the GEMM family serves C[n][rows, hw*hw] = W[rows, k] * X[n][k, hw*hw] (csrc/gemm.hip): the W-stationary kernel where the weight matrix is one
+    of its LDS images and the launch has >= 8 blocks of 32 pixels per CU, the persistent tiled form where there are more tiles than resident workgroups."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    if rows % 32 == 0 and (rows // 32, k // 16) in ((4, 4), (2, 8), (8, 8), (4, 16)) and k % 16 == 0 and n * hw * hw // 32 >= 8 * cus:
+        return 'conv1x1_wstat'
+    return 'gemm_bf16x3_stream' if -(-rows // 128) * (hw * hw // 128) * n > 2 * cus else 'gemm_bf16x3'
+
+
+@pytest.mark.parametrize('n,cin,cout,hw', [(2, 64, 128, 128), (9, 128, 256, 64), (17, 128, 64, 64), (7, 32, 192, 128), (9, 64, 128, 128), (5, 128, 64, 128), (37, 128, 256, 64),
+                                           (37, 256, 128, 64)])
+def test_conv1x1_members_persistent_tiles_and_stationary_weights(n, cin, cout, hw):
+    """gemm_bf16x3_stream_kernel (persistent workgroups that prefetch the next tile's first chunk across the epilogue) and conv1x1_wstat_kernel (the weight matrix
+    split once per workgroup into LDS, the activation straight from global memory into MFMA operand registers, a wave per 32-pixel block) of csrc/gemm_kernel.h.
+    Block / tile counts that are not a multiple of the grid (uneven tails), rows that are not a multiple of the tile (64 / 192), all four weight images of the
+    stationary member (128 x 64, 64 x 128, 256 x 128, 128 x 256), bias + residual in the store: against float64 `conv2d` (< 1e-5, the family's bound; the
+    default arithmetic measures 3e-7) and EXACT on small-integer data (pins block / tile decoding, operand layouts, the accumulator reset)."""
     g = torch.Generator().manual_seed(n + cin + cout + hw)
     x = torch.randn([n, cin, hw, hw], generator=g).to(DEV)
     w = (torch.randn([cout, cin, 1, 1], generator=g) / cin ** 0.5).to(DEV)
@@ -696,10 +707,12 @@ def test_bf16x3_stream_gemm_walks_tiles_persistently(n, cin, cout, hw):
     y = gemm.conv1x1(xg, wg, b, residual=res)
     gx, = torch.autograd.grad(y, [xg], dy)
     after = custom_ops.kernel_variant_counts()
-    resident = 2 * torch.cuda.get_device_properties(0).multi_processor_count
-    want = sum(1 for rows in (cout, cin) if -(-rows // 128) * (hw * hw // 128) * n > resident)     # launches with more tiles than resident workgroups
-    assert want >= 1
-    dispatch_assert(after['gemm_bf16x3_stream'] - before['gemm_bf16x3_stream'] == want, 'launches with more tiles than resident workgroups must take the persistent member')
+    want = {}
+    for rows, k in ((cout, cin), (cin, cout)):          # forward, data gradient
+        m = _conv1x1_member(rows, k, hw, n)
+        want[m] = want.get(m, 0) + 1
+    for name in ('conv1x1_wstat', 'gemm_bf16x3_stream', 'gemm_bf16x3'):
+        dispatch_assert(after[name] - before[name] == want.get(name, 0), f'{name}: {after[name] - before[name]} launches, expected {want.get(name, 0)}')
     x64, w64 = x.double().requires_grad_(True), w.double()
     y64 = torch.nn.functional.conv2d(x64, w64, b.double()) + res.double()
     rx, = torch.autograd.grad(y64, [x64], dy.double())
