@@ -259,7 +259,7 @@ typedef struct sgv_conv_wrw_params {
     int32_t terms;          /* 1, 3, or 4 (block-scaled fp16 split: fp32-grade, see sgv_absmax) */
     const float* dy_amax;   /* terms = 4: device pointers to ONE fp32 each, upper bounds of max |dy| and max |x| */
     const float* x_amax;
-    const float* x_amax2;   /* terms = 4, sgv_conv3x3_wrw_scaled only, optional: a bound of |x_scale| (the operand is x * x_scale) */
+    const float* x_amax2;   /* terms = 4, sgv_conv3x3_wrw_scaled only, REQUIRED there: a bound of |x_scale| (the operand is x * x_scale; a bound of x alone overflows fp16) */
 } sgv_conv_wrw_params;
 
 int sgv_conv3x3_wrw(const sgv_conv_wrw_params* p, int dtype, void* stream);
@@ -301,7 +301,7 @@ typedef struct sgv_conv3x3_params {
     int32_t mode;
     int32_t terms;         /* 1 bf16 products, 3 bf16 split (bf16x3), 4 block-scaled fp16 split (fp32-grade; see below) */
     const float* x_amax;   /* terms = 4: device pointer to ONE fp32 >= max |x| (sgv_absmax writes one); ignored otherwise */
-    const float* x_amax2;  /* terms = 4, optional: a second factor of the bound (sgv_conv3x3_fused with x_scale: a bound of |x_scale|); NULL: 1 */
+    const float* x_amax2;  /* terms = 4: a second factor of the bound -- REQUIRED with x_scale (sgv_conv3x3_fused: a bound of |x_scale|), ignored without; */
     const float* w_amax;   /* terms = 4, optional: a bound of max |weight| the caller already has (a weight is bounded once per optimiser step, not once per
                               launch); NULL: the library runs its own pass over the weight */
 } sgv_conv3x3_params;

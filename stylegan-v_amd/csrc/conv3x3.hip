@@ -217,6 +217,8 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     conv_params kp{};
     kp.x = (const float*)p->x; kp.wprep = (const u32x4*)p->workspace; kp.y = (float*)p->y;
     kp.n = p->n; kp.k = p->c_in; kp.m = p->c_out; kp.h = p->h; kp.w = p->w;
+    if (p->terms == 4 && ep && ep->x_scale && !p->x_amax2)
+        return sgv_fail(SGV_ERR_INVALID_ARG, "%s: terms = 4 with x_scale needs x_amax2, a device pointer to an upper bound of max |x_scale| (the operand is x * x_scale)", who);
     if (p->terms == 4) { kp.x_amax = p->x_amax; kp.x_amax2 = p->x_amax2; kp.w_amax = w_amax; }
     const int small = big_image(p->h, p->w) ? 0 : small_samples(p->n, p->h, p->w);
     kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * tiles_m(p->c_out);

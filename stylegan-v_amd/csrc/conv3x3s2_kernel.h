@@ -444,7 +444,7 @@ __global__ __launch_bounds__(128) void convT3x3_s2_edge_kernel(const float* edge
 // address-unit bound (0.25 ms per layer); the prep kernel lays both out once:  edge = we[strip][tap][k][m] (2*3*K*M floats), col[n][k][H].
 __host__ __device__ inline size_t convT3x3_s2_edge_we_floats(int k, int m) { return (size_t)2 * 3 * k * m; }
 
-// IO != 0 (16-bit x, sgv_io16.h): the weights are rounded to bf16 like the main kernel's operands, and the last input ROW is gathered as fp32 too
+// IO != 0 (16-bit x, sgv_io16.h): the weights are rounded to the tensor's format (bf16 / fp16) like the main kernel's operands, and the last input ROW is gathered as fp32 too
 // (row[n][k][W] behind col[n][k][H]) so that the strip kernel reads fp32 lines for both strips.
 template <int IO>
 __global__ __launch_bounds__(256) void convT3x3_s2_edge_prep(const void* x, const float* w, float* edge, int n, int k, int m, int h, int wd) {
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(256) void convT3x3_s2_edge_prep(const void* x, cons
     auto ld = [&](size_t e) -> float {
         if constexpr (IO == 0) return ((const float*)x)[e];
         else if constexpr (IO == 1) return __builtin_bit_cast(float, (unsigned)((const uint16_t*)x)[e] << 16);
-        else return __builtin_bit_cast(float, pack_bf16((float)((const _Float16*)x)[e], 0.f) << 16);   // the operand the main kernel multiplies
+        else return (float)((const _Float16*)x)[e];      // fp16 tensors are multiplied as they are (operand_format of sgv_split.h)
     };
     if (idx < n_w) {
         size_t j = idx;
@@ -461,7 +461,8 @@ __global__ __launch_bounds__(256) void convT3x3_s2_edge_prep(const void* x, cons
         const int kk = j % k; j /= k;
         const int tap = j % 3; const int strip = j / 3;
         float v = w[((size_t)kk * m + mm) * 9 + (strip == 0 ? 6 + tap : 3 * tap + 2)];
-        if (IO) v = __builtin_bit_cast(float, pack_bf16(v, 0.f) << 16);
+        if (IO == 1) v = __builtin_bit_cast(float, pack_bf16(v, 0.f) << 16);
+        if (IO == 2) v = (float)(_Float16)v;
         edge[idx] = v;
     } else if (idx < n_w + n_col) {
         const size_t j = idx - n_w;

@@ -79,6 +79,9 @@ static int conv3x3_wrw_impl(const sgv_conv_wrw_params* p, const float* x_scale, 
     if (p->terms != 1 && p->terms != 3 && p->terms != 4) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms must be 1 (bf16 products), 3 (bf16 split) or 4 (block-scaled fp16 split)");
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: 16-bit tensors need terms = 1 (one 16-bit operand per value: bf16, or fp16 for fp16 tensors)");
     if (p->terms == 4 && (!p->dy_amax || !p->x_amax)) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: terms = 4 needs dy_amax and x_amax, device pointers to upper bounds of max |dy| / max |x| (sgv_absmax)");
+    if (p->terms == 4 && x_scale && !p->x_amax2)
+        return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw_scaled: terms = 4 with x_scale needs x_amax2, a device pointer to an upper bound of max |x_scale| (the operand is x * x_scale: "
+                                             "scaled by the bound of x alone, any |x_scale| > 2 overflows the fp16 split)");
     if ((((uintptr_t)p->dy) | ((uintptr_t)p->x)) & 15) return sgv_fail(SGV_ERR_INVALID_ARG, "conv3x3_wrw: dy and x must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
     wrw_params kp{};

@@ -10,6 +10,10 @@ hipGraph-capturable).  ``bound(t)`` returns such a bound as a 1-element fp32 ten
 * the result is cached ON the tensor object (an attribute dies with the object: no stale entries after the allocator reuses the address) and is
   dropped when the tensor's version counter moves.  Kernels of this library that write into an existing tensor through its raw pointer
   (``accumulate`` stores, the in-place residual add) do not move that counter: they call ``invalidate``.
+* a replayed hipGraph writes tensors (the parameters of a captured Adam step, every captured activation) without moving any version counter and without
+  running this module at all: ``graph_replayed()`` -- called by the step after every replay -- advances an epoch that is part of every cache entry,
+  so no bound computed before a replay is trusted after it (the eager Greg / Dreg phases of a captured schedule used to multiply with a
+  weight bound taken before the latest replayed update; only the split's 2x headroom covered it).
 """
 
 import torch
@@ -18,6 +22,14 @@ from .. import custom_ops
 
 _DT = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}
 _ATTR = '_sgv_amax'
+_TAPS_ATTR = '_sgv_tap_sum'
+_epoch = 0         # advanced by graph_replayed(): cache entries of an older epoch are stale
+
+
+def graph_replayed():
+    """A hipGraph was replayed: tensors it writes changed behind every version counter.  Drops every cached bound (lazily: by epoch)."""
+    global _epoch
+    _epoch += 1
 
 
 _ARENA = 4096
@@ -57,7 +69,7 @@ def zero_slot(device):
 def bound(t):
     """[1] fp32 device tensor >= max |t| for a dense CUDA tensor t (fp32 / fp16 / bf16)."""
     cached = getattr(t, _ATTR, None)
-    if cached is not None and cached[0] == t._version and cached[1] == t.data_ptr():
+    if cached is not None and cached[0] == t._version and cached[1] == t.data_ptr() and cached[3] == _epoch:
         return cached[2]
     assert t.is_cuda and t.dtype in _DT
     if _trace is not None:
@@ -103,7 +115,7 @@ if _trace is not None:
 def attach(t, amax):
     """Record a bound that a producing kernel left in `amax` ([1] fp32 device tensor) for tensor t."""
     try:
-        setattr(t, _ATTR, (t._version, t.data_ptr(), amax))
+        setattr(t, _ATTR, (t._version, t.data_ptr(), amax, _epoch))
     except (AttributeError, RuntimeError):
         pass
     return t
@@ -150,28 +162,45 @@ def launch_tracking(out, call):
 # input -- one 1-element multiply instead of a pass over the tensor.  For the normalised [1,3,3,1] low-pass that factor is 1 (down) or 4 (up, gain 4:
 # loose by the zero insertion, far inside the ~2^10 a bound may be loose by, csrc/sgv_split.h).
 
-_tap_sums = {}       # (data_ptr, version) of a filter tensor -> sum |taps| (read back ONCE per filter tensor; never while a hipGraph is being captured)
+# sum |taps| of a filter is read back ONCE per filter TENSOR OBJECT and kept on it (never while a hipGraph is being captured).  Not in a table keyed by the
+# address: a temporary filter's block is handed out again by the caching allocator, and a different filter at the same address with the same version
+# would inherit the old sum -- too small a bound overflows the fp16 split.
 
 
 def cached(t):
     """The bound a producer or an earlier request left on t, or None."""
     c = getattr(t, _ATTR, None)
-    return c[2] if (c is not None and c[0] == t._version and c[1] == t.data_ptr()) else None
+    return c[2] if (c is not None and c[0] == t._version and c[1] == t.data_ptr() and c[3] == _epoch) else None
+
+
+def set_tap_sum(f, value):
+    """Record sum |taps| of filter tensor f without reading it back (a caller that knows it)."""
+    try:
+        setattr(f, _TAPS_ATTR, (f._version, f.data_ptr(), float(value)))
+    except (AttributeError, RuntimeError):
+        pass
 
 
 def inherit_through_fir(y, x, f2d, gain):
-    """Give y = upfirdn2d(x, f2d, gain=gain, ...) the bound gain * sum|f2d| * bound(x) if x has one and y has none yet."""
+    """Give y = upfirdn2d(x, f2d, gain=gain, ...) the bound gain * sum|f2d| * bound(x) if x has one and y has none yet.  `f2d`: the filter tensor OBJECT the
+    tap sum is remembered on -- the caller's own tensor (a module buffer), not a per-call view of it: a fresh object has no record, and every miss is a
+    read-back (a host / device synchronisation)."""
     if not (y.is_cuda and y.dtype == torch.float32 and tracking()) or cached(y) is not None:
         return
     bx = cached(x)
     if bx is None:
         return
-    key = (f2d.data_ptr(), f2d._version)
-    tap_sum = _tap_sums.get(key)
-    if tap_sum is None:
+    rec = getattr(f2d, _TAPS_ATTR, None)
+    if rec is not None and rec[0] == f2d._version and rec[1] == f2d.data_ptr():
+        tap_sum = rec[2]
+    else:
         if torch.cuda.is_current_stream_capturing():
             return
-        tap_sum = _tap_sums[key] = float(f2d.abs().sum())
+        tap_sum = float(f2d.abs().sum())
+        try:
+            setattr(f2d, _TAPS_ATTR, (f2d._version, f2d.data_ptr(), tap_sum))
+        except (AttributeError, RuntimeError):
+            pass
     attach(y, bx * (abs(float(gain)) * tap_sum * 1.0000005))      # (a hair above: the FIR's own roundings)
 
 

@@ -127,8 +127,9 @@ def _upfirdn2d_ref(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1):
 # Native path.
 
 
-def _native_call(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain):
-    """One ``sgv_upfirdn2d`` launch on x's current stream.  Allocates and returns y."""
+def _native_call(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain, f_src=None):
+    """One ``sgv_upfirdn2d`` launch on x's current stream.  Allocates and returns y.  ``f_src``: the caller's filter tensor when ``f2d`` is a fresh view of
+    it (a separable pass): what the sum of its taps is remembered on (ops/amax.py)."""
     lib = custom_ops.get_native()
     if x.dtype not in _DTYPE_CODES:
         raise RuntimeError(f'upfirdn2d: unsupported dtype {x.dtype}')
@@ -158,7 +159,7 @@ def _native_call(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain)
     with custom_ops.device_guard(x):
         from . import amax as _amax      # (a FIR output usually feeds a convolution: the LDS-tile kernel leaves its magnitude bound behind)
         custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x))), lib)
-        _amax.inherit_through_fir(y, x, f2d, gain)      # (a kernel without the side output: the bound follows from the input's, if that is known)
+        _amax.inherit_through_fir(y, x, f2d if f_src is None else f_src, gain)      # (a kernel without the side output: the bound follows from the input's, if that is known)
     return y
 
 
@@ -175,13 +176,15 @@ class _Upfirdn2dFn(torch.autograd.Function):
         upx, upy, downx, downy, px0, px1, py0, py1, flip, gain = cfg
         if f is None:
             f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+            from . import amax as _amax
+            _amax.set_tap_sum(f, 1.0)      # (known without reading the temporary back)
         assert isinstance(f, torch.Tensor) and f.ndim in (1, 2)
         if f.ndim == 2:
             y = _native_call(x, f, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain)
         else:  # separable taps: horizontal pass then vertical pass, gain split evenly (upfirdn2d.py:239-240)
             g = float(np.sqrt(gain))
-            y = _native_call(x, f.unsqueeze(0), upx, 1, downx, 1, px0, px1, 0, 0, flip, g)
-            y = _native_call(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, py0, py1, flip, g)
+            y = _native_call(x, f.unsqueeze(0), upx, 1, downx, 1, px0, px1, 0, 0, flip, g, f_src=f)      # (sum |taps| of a view = that of f: remembered on f)
+            y = _native_call(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, py0, py1, flip, g, f_src=f)
         ctx.cfg = cfg
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.fsize = _get_filter_size(f)

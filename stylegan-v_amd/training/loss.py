@@ -40,6 +40,9 @@ class StyleGAN2Loss:
         # second accumulation pass over every parameter gradient.  The only cross-sample operation of D, the minibatch-std layer, keeps its groups inside
         # each half (networks.minibatch_std_segments).  Equivalence: tests/test_dmain_concat.py (CPU), tests/test_ddp_gloo.py (under DDP); the whole -m gpu
         # suite ran with it (tools/gpu_recipes/r04_call6.sh).  Measured: 8 videos/GPU with graphs +7.4 %, 32 videos/GPU +2.4 % (profiles/r03_d_concat_ab.log).
+        # Cost: about twice the peak activation memory of the phase (see the fallback below); with aug=ada the augmentation parameters of both halves come
+        # from ONE draw of 2B samples, so the random stream differs from the two-pass schedule's (same distributions; AugmentPipe.host_params also draws on
+        # the host generator when the step is eager and on the device generator under capture: eager and captured runs of one seed are not sample-identical).
         self.d_concat = os.environ.get('SGV_D_CONCAT', '1') != '0'
 
     def run_G(self, z, c, t, sync):
@@ -102,14 +105,26 @@ class StyleGAN2Loss:
         if do_Dmain and not do_Dr1 and self.d_concat and len(gen_z) == len(real_c):
             with torch.no_grad():
                 gen_img, _ = self.run_G(gen_z, gen_c, gen_t, sync=False)
-            with self._mbstd_segments(2):
-                logits = self.run_D(torch.cat([gen_img, real_img.detach()]), torch.cat([gen_c, real_c]), torch.cat([gen_t, real_t]), sync=sync)['image_logits']
-            logits_gen, logits_real = logits[:len(gen_z)], logits[len(gen_z):]
-            loss_Dgen, loss_Dreal = F.softplus(logits_gen), F.softplus(-logits_real)
-            out['signs_real'] = logits_real.detach().sign().mean()
-            out['D/loss'] = (loss_Dgen + loss_Dreal).detach().mean()
-            (loss_Dgen.mean() + loss_Dreal.mean()).mul(gain).backward()
-            return out
+            # One pass holds the autograd state of BOTH halves at once -- about twice the peak activation memory of the reference's schedule (loss.py:122-151
+            # runs and differentiates the generated half before the real half exists).  A configuration that fits under two passes must not fail under one:
+            # an out-of-memory error in the forward pass (nothing has been accumulated yet) switches this loss back to two passes for good.
+            logits = None
+            try:
+                with self._mbstd_segments(2):
+                    logits = self.run_D(torch.cat([gen_img, real_img.detach()]), torch.cat([gen_c, real_c]), torch.cat([gen_t, real_t]), sync=sync)['image_logits']
+            except torch.cuda.OutOfMemoryError:
+                if torch.cuda.is_current_stream_capturing():
+                    raise
+                self.d_concat = False
+                torch.cuda.empty_cache()
+                print('[sgv] Dmain as one discriminator pass over [generated, real] ran out of memory: two passes from here on (SGV_D_CONCAT=0)', flush=True)
+            if logits is not None:
+                logits_gen, logits_real = logits[:len(gen_z)], logits[len(gen_z):]
+                loss_Dgen, loss_Dreal = F.softplus(logits_gen), F.softplus(-logits_real)
+                out['signs_real'] = logits_real.detach().sign().mean()
+                out['D/loss'] = (loss_Dgen + loss_Dreal).detach().mean()
+                (loss_Dgen.mean() + loss_Dreal.mean()).mul(gain).backward()
+                return out
 
         loss_Dgen = 0
         if do_Dmain:  # minimise logits of generated clips (G frozen)

@@ -329,6 +329,10 @@ class TrainStep:
         if self.ddp_manual:
             self._allreduce_gradients(phase, grads=entry['grads'])
         entry['update'].replay()
+        # the replays rewrote the phase's parameters (and every captured activation) behind the tensors' version counters: no magnitude bound taken
+        # before this point may be trusted by a later eager phase (Greg / Dreg run eagerly between captured main phases)
+        from ..torch_utils.ops import amax as _amax
+        _amax.graph_replayed()
         out = getattr(entry['grad'], 'out', None) or entry['out']      # (the emulated graph returns each replay's own result)
         return {k: v.clone() for k, v in out.items()}
 

@@ -399,7 +399,7 @@ def gen_networks_full():
     from omegaconf import OmegaConf
     from training.networks import Generator, Discriminator
     sys.path.insert(0, os.path.dirname(HERE))
-    from util import seeded_parameters_, sample_flat
+    from util import seeded_parameters_, sample_flat, bucket_sketch
     RES = 256
     sampling = dict(type='random', num_frames_per_video=3, max_num_frames=1024, total_dists=[1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024, 2048], max_dist=32)
     gcfg = OmegaConf.create(dict(sampling=sampling, use_noise=False, input=dict(type='temporal'), w_dim=512, z_dim=512, c_dim=0,
@@ -464,6 +464,10 @@ def gen_networks_full():
         out['loss_Gmain'] = loss_g
         for name, p in Gd.named_parameters():
             out['gradG.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p), limit=1024)
+        # whole-tensor sketches of the ten largest gradient tensors of each network (samples of 1,024 elements leave 99.96 % of a
+        # 2.4 M-element gradient unexamined): 8,192 bucket sums, every element in exactly one
+        for name, p in sorted(Gd.named_parameters(), key=lambda kv: -kv[1].numel())[:10]:
+            out['sketchG.' + name] = bucket_sketch(p.grad)
         Gd.zero_grad(); Dd.zero_grad()
         real_tmp = real.to(dt).requires_grad_(True)
         logits_real = Dd(real_tmp, c, tt)['image_logits']
@@ -474,6 +478,8 @@ def gen_networks_full():
         out['logits_real'], out['r1_penalty'], out['loss_Dreal_r1'] = logits_real, r1, loss_d
         for name, p in Dd.named_parameters():
             out['gradD.' + name] = sample_flat(p.grad if p.grad is not None else torch.zeros_like(p), limit=1024)
+        for name, p in sorted(Dd.named_parameters(), key=lambda kv: -kv[1].numel())[:10]:
+            out['sketchD.' + name] = bucket_sketch(p.grad)
         return {k: v.detach().clone() for k, v in out.items()}
 
     r32 = evaluate(torch.float32)
@@ -486,7 +492,7 @@ def gen_networks_full():
         if key == 'img_train':
             arrays[key] = v64.float().half()       # whole image at fp16 resolution (0.6 MB instead of 4.7); `img_train_sample` carries fp32 samples
         else:
-            arrays[key] = v64 if key.startswith('grad') else v64.float()
+            arrays[key] = v64 if key.startswith(('grad', 'sketch')) else v64.float()
     meta = dict(B=B, F=F, res=RES, w_dim=512, z_dim=512, seed_G=303, seed_D=404, real_seed=1079, noise=noise,
                 G_params=sum(p.numel() for p in G.parameters()), D_params=sum(p.numel() for p in D.parameters()))
     worst = sorted(noise.items(), key=lambda kv: -kv[1])[:8]

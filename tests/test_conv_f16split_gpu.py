@@ -296,3 +296,37 @@ def test_producers_leave_the_bound_of_their_output_behind():
     lib.sgv_amax_sink(out.data_ptr())                                                                                                          # armed for THIS call
     custom_ops.check(lib.sgv_scale_channels(t.data_ptr(), s1.data_ptr(), y.data_ptr(), 1, 1, 4096, 0, custom_ops.raw_stream(t)), lib)
     assert lib.sgv_amax_sink_consumed() == 1 and out[0].item() == t.abs().max().item() and int((out[1:] > 0).sum()) >= 1
+
+
+def test_scaled_operand_without_a_bound_of_the_scale_is_refused(monkeypatch):
+    """terms = 4 with x_scale: the operand is x * x_scale, so a bound of x alone is not a bound of the operand (any |x_scale| > 2 would overflow the fp16
+    split silently).  The C ABI refuses the call instead (the header used to advertise x_amax2 = NULL as allowed)."""
+    if conv2d_gradfix.native_wrw_terms != 4 or not conv2d_gradfix.wrw_input_scale:
+        pytest.skip('the default arithmetic is not the block-scaled fp16 split')
+    g = torch.Generator().manual_seed(1)
+    dy = torch.randn([2, 64, 32, 32], generator=g).to(DEV)
+    x = torch.randn([2, 64, 32, 32], generator=g).to(DEV)
+    s = (torch.rand([2, 64], generator=g) * 8).to(DEV)
+    good = conv2d_gradfix._native_wrw(dy, x, S1, (64, 64, 3, 3), x_scale=s)
+    ref = torch.nn.grad.conv2d_weight(x.double() * s.double()[:, :, None, None], (64, 64, 3, 3), dy.double(), padding=1)
+    assert _rel(good, ref)[0] < 1e-6
+    monkeypatch.setattr(conv2d_gradfix, '_wrw_bounds', lambda terms, dyc, xc, scale=None: (amax.bound(dyc).data_ptr(), amax.bound(xc).data_ptr(), None))
+    with pytest.raises(RuntimeError, match='x_amax2'):
+        conv2d_gradfix._native_wrw(dy, x, S1, (64, 64, 3, 3), x_scale=s)
+
+
+def test_bounds_do_not_survive_a_graph_replay():
+    """A replayed hipGraph rewrites tensors behind their version counters (the captured Adam step: the parameters).  `amax.graph_replayed()` -- called by
+    TrainStep after every replay -- must make every bound taken before it stale."""
+    w = torch.randn([64, 64, 3, 3], device=DEV)
+    b0 = amax.bound(w)
+    assert amax.cached(w) is b0
+    w.data_ptr()                      # (no version bump: what a replay looks like to the host)
+    with torch.no_grad():
+        torch.cuda.current_stream().synchronize()
+    amax.graph_replayed()
+    assert amax.cached(w) is None, 'a bound taken before a replay must not be trusted after it'
+    w.detach().mul_(4.0)              # the weights grew across a power of two
+    amax.graph_replayed()
+    b1 = amax.bound(w)
+    assert b1.item() >= w.abs().max().item() and b1.item() > 2 * b0.item()
