@@ -17,10 +17,11 @@ using namespace sgv_conv;
 
 namespace {
 
-// small square images (16x16, 8x8): conv3x3_small_kernel packs 2 resp. 8 whole samples into a tile
+// small square images (16x16, 8x8, 4x4): conv3x3_small_kernel packs 2 / 8 / 32 whole samples into a tile; a last tile may be partly filled
 int small_samples(int n, int h, int w) {
-    if (h == 16 && w == 16 && n % small_cfg<16>::S == 0) return small_cfg<16>::S;
-    if (h == 8 && w == 8 && n % small_cfg<8>::S == 0) return small_cfg<8>::S;
+    if (h == 16 && w == 16 && n >= 1) return small_cfg<16>::S;
+    if (h == 8 && w == 8 && n >= 1) return small_cfg<8>::S;
+    if (h == 4 && w == 4 && n >= 1) return small_cfg<4>::S;
     return 0;
 }
 
@@ -70,6 +71,9 @@ void init_once() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<3, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<8>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<4, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<16>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<4, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<8>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<4>::LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_small_kernel<4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, small_cfg<4>::LDS);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv3x3_s2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, S_LDS_BYTES);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)convT3x3_s2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
@@ -184,7 +188,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: params is NULL", who);
     if (!p->x || !p->weight || !p->y || !p->workspace) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: NULL pointer", who);
     if (!supported(p->n, p->c_in, p->c_out, p->h, p->w, dtype))
-        return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32 / bf16 / fp16 tensors, c_in %% 16 == 0, c_out %% 32 == 0, and W %% 32 == 0, H %% 16 == 0 (fp32 with c_out %% 64 == 0 also: 16x16 / 8x8 images) (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
+        return sgv_fail(SGV_ERR_UNSUPPORTED, "%s: needs fp32 / bf16 / fp16 tensors, c_in %% 16 == 0, c_out %% 32 == 0, and W %% 32 == 0, H %% 16 == 0 (fp32 with c_out %% 64 == 0 also: 16x16 / 8x8 / 4x4 images) (got n=%d c_in=%d c_out=%d h=%d w=%d dtype=%d)",
                         who, p->n, p->c_in, p->c_out, p->h, p->w, dtype);
     if (io16(dtype) && p->terms != 1) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: 16-bit tensors need terms = 1 (one 16-bit operand per value: bf16, or fp16 for fp16 tensors)", who);
     if (p->terms == 4 && !p->x_amax) return sgv_fail(SGV_ERR_INVALID_ARG, "%s: terms = 4 (block-scaled fp16 split) needs x_amax, a device pointer to an upper bound of max |x| (sgv_absmax)", who);
@@ -221,7 +225,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
         return sgv_fail(SGV_ERR_INVALID_ARG, "%s: terms = 4 with x_scale needs x_amax2, a device pointer to an upper bound of max |x_scale| (the operand is x * x_scale)", who);
     if (p->terms == 4) { kp.x_amax = p->x_amax; kp.x_amax2 = p->x_amax2; kp.w_amax = w_amax; }
     const int small = big_image(p->h, p->w) ? 0 : small_samples(p->n, p->h, p->w);
-    kp.tiles = small ? (p->n / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * tiles_m(p->c_out);
+    kp.tiles = small ? ((p->n + small - 1) / small) * (p->c_out / TM) : p->n * (p->h / TROWS) * (p->w / SEG) * tiles_m(p->c_out);
     if (small) {
         // fewer tiles than half the CUs: share every tile's input channels out over 2 / 4 / 8 workgroups (partial sums meet in a zeroed y through atomics).
         // SGV_CONV_SMALL_KSPLIT = 1 switches it off, 2 / 4 / 8 forces a split wherever the chunk count allows it.
@@ -247,10 +251,14 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
             else if (p->terms == 3) hipLaunchKernelGGL((conv3x3_small_kernel<3, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
             else hipLaunchKernelGGL((conv3x3_small_kernel<4, 16>), dim3((unsigned)kp.grid), dim3(256), small_cfg<16>::LDS, stream, kp);
-        } else {
+        } else if (p->w == 8) {
             if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
             else if (p->terms == 3) hipLaunchKernelGGL((conv3x3_small_kernel<3, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
             else hipLaunchKernelGGL((conv3x3_small_kernel<4, 8>), dim3((unsigned)kp.grid), dim3(256), small_cfg<8>::LDS, stream, kp);
+        } else {      // 4 x 4: the first generator block and the discriminator's epilogue (networks.py:518-576), 32 samples per tile
+            if (p->terms == 1) hipLaunchKernelGGL((conv3x3_small_kernel<1, 4>), dim3((unsigned)kp.grid), dim3(256), small_cfg<4>::LDS, stream, kp);
+            else if (p->terms == 3) hipLaunchKernelGGL((conv3x3_small_kernel<3, 4>), dim3((unsigned)kp.grid), dim3(256), small_cfg<4>::LDS, stream, kp);
+            else hipLaunchKernelGGL((conv3x3_small_kernel<4, 4>), dim3((unsigned)kp.grid), dim3(256), small_cfg<4>::LDS, stream, kp);
         }
         sgv_note_variant(SGV_V_conv_small);
         return sgv_check_launch("conv3x3_small_kernel");

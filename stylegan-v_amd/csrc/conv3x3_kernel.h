@@ -286,8 +286,9 @@ __global__ __launch_bounds__(256, RW == 4 ? 1 : 2) void conv3x3_kernel(conv_para
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Small square images (SW x SW, SW = 16 or 8: the 16^2 / 8^2 blocks).  Same MFMA mapping, but the 512 pixels of a workgroup
-// tile are S = 512 / SW^2 WHOLE images (2 at 16^2, 8 at 8^2): a 32-pixel MFMA column block is 32 / SW consecutive image rows.
+// Small square images (SW x SW, SW = 16, 8 or 4: the 16^2 / 8^2 / 4^2 blocks).  Same MFMA mapping, but the 512 pixels of a workgroup
+// tile are S = 512 / SW^2 WHOLE images (2 at 16^2, 8 at 8^2, 32 at 4^2): a 32-pixel MFMA column block is 32 / SW consecutive image rows.
+// The batch need not be a multiple of S (round 5): samples beyond it are zero images that are never stored.
 // Every halo position of the LDS image (row -1, row SW, column -1, column SW of each sample) is zero padding: it is cleared
 // once at kernel start and never written again; per 16-channel chunk each thread loads exactly one (8 channels x 4 pixels) item.
 template <int SW> struct small_cfg {
@@ -323,9 +324,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
     const int a_pos = (a_oct * C::RINS + a_s * (SW + 2) + a_y + 1) * C::PINS + 1 + 4 * a_quad;
 
     auto load_chunk = [&](int n0, int mt, int c, small_stage& s) {
-        const float* q = p.x + ((size_t)(n0 + a_s) * p.k + c * KC + 8 * a_oct) * plane + a_y * SW + 4 * a_quad;
+        const bool live = n0 + a_s < p.n;      // (a last tile may hold fewer than S samples)
+        const float* q = p.x + ((size_t)(live ? n0 + a_s : n0) * p.k + c * KC + 8 * a_oct) * plane + a_y * SW + 4 * a_quad;
 #pragma unroll
-        for (int j = 0; j < 8; j++) s.xa[j] = *(const f32x4*)(q + j * plane);
+        for (int j = 0; j < 8; j++) s.xa[j] = live ? *(const f32x4*)(q + j * plane) : f32x4{0.f, 0.f, 0.f, 0.f};
         const u32x4* wq = p.wprep + ((size_t)mt * chunks + c) * WS_WORDS + t;
 #pragma unroll
         for (int j = 0; j < 9; j++) s.wv[j] = wq[j * 256];
@@ -423,15 +425,18 @@ __global__ __launch_bounds__(256, 1) void conv3x3_small_kernel(conv_params p) {
         if (c == c_end - 1) {
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                float* yb = p.y + ((size_t)(n0 + ypix[r] / PLANE_PX) * p.m + mt * TM) * plane + ypix[r] % PLANE_PX;
+                const bool live = n0 + ypix[r] / PLANE_PX < p.n;
+                float* yb = p.y + ((size_t)(live ? n0 + ypix[r] / PLANE_PX : n0) * p.m + mt * TM) * plane + ypix[r] % PLANE_PX;
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++)
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const int m = hf * 32 + (e & 3) + 8 * (e >> 2) + 4 * g;
                         const float v = TERMS == 4 ? __builtin_ldexpf(acc[r][hf][e], unscale_exponent(ex, ew)) : acc[r][hf][e];
-                        if (ksplit > 1) atomicAdd(yb + (size_t)m * plane, v);
-                        else yb[(size_t)m * plane] = v;
+                        if (live) {
+                            if (ksplit > 1) atomicAdd(yb + (size_t)m * plane, v);
+                            else yb[(size_t)m * plane] = v;
+                        }
                         acc[r][hf][e] = 0.f;
                     }
             }

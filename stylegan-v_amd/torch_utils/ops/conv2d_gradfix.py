@@ -63,7 +63,27 @@ def _pair(v):
     return (int(v), int(v)) if isinstance(v, int) else tuple(int(i) for i in v)
 
 
+small_image_channel_pad = os.environ.get('SGV_CONV_SMALL_PAD', '1') != '0'
+
+
+def _pad_small_image_channels(x, w, stride, padding, dilation, groups):
+    """3x3 / stride 1 / pad 1 on 4^2 ... 16^2 fp32 images whose input channel count is not a multiple of 64 while the output's is -- the discriminator's epilogue
+    convolution, 512 + 1 minibatch-std channels at 4 x 4 (networks.py:518-576) -- gets zero channels up to the next multiple: the native small-image kernel
+    (c_in % 16 == 0) then serves the convolution and, with c_in as its output-channel count (% 64 == 0), the data gradient too.  The copies are a few MB; autograd
+    differentiates through the padding.  SGV_CONV_SMALL_PAD=0 leaves such layers to the vendor library."""
+    if not (small_image_channel_pad and native_conv_terms in (1, 3, 4) and x.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and w.ndim == 4):
+        return x, w
+    ci, h, wd = x.shape[1], x.shape[2], x.shape[3]
+    if not (tuple(w.shape[2:]) == (3, 3) and _pair(stride) == (1, 1) and _pair(padding) == (1, 1) and _pair(dilation) == (1, 1) and int(groups) == 1 and h == wd and h in (4, 8, 16)
+            and w.shape[1] == ci and ci % 64 != 0 and ci > 64 and w.shape[0] % 64 == 0):
+        return x, w
+    pad = 64 - ci % 64
+    return torch.nn.functional.pad(x, (0, 0, 0, 0, 0, pad)), torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad))
+
+
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    if enabled and input.ndim == 4:
+        input, weight = _pad_small_image_channels(input, weight, stride, padding, dilation, groups)
     if _use_custom(input):
         cfg = (False, _pair(stride), _pair(padding), (0, 0), _pair(dilation), int(groups))
         return _Conv.apply(input, weight, bias, cfg)

@@ -77,8 +77,9 @@ def test_convolution_family_shape_rules_and_validation_without_gpu():
     assert lib.sgv_conv3x3_supported(96, 16, 512, 32, 32, F32) == 1
     assert lib.sgv_conv3x3_supported(96, 512, 512, 16, 16, F32) == 1
     assert lib.sgv_conv3x3_supported(32, 512, 512, 8, 8, F32) == 1
-    assert lib.sgv_conv3x3_supported(31, 512, 512, 16, 16, F32) == 0
-    assert lib.sgv_conv3x3_supported(96, 512, 512, 4, 4, F32) == 0
+    assert lib.sgv_conv3x3_supported(31, 512, 512, 16, 16, F32) == 1      # (round 5: a partly filled last tile)
+    assert lib.sgv_conv3x3_supported(96, 512, 512, 4, 4, F32) == 1        # (round 5: 4 x 4 images, 32 per tile)
+    assert lib.sgv_conv3x3_supported(96, 512, 512, 4, 8, F32) == 0
     assert lib.sgv_conv3x3_supported(96, 3, 64, 256, 256, F32) == 0
     assert lib.sgv_conv3x3_supported(96, 64, 48, 256, 256, F32) == 0
     # ... or c_out % 32 on the big-image (producer / consumer) kernel: a half-full last tile (the 32-channel layers of the 1024^2 synthesis network)

@@ -33,6 +33,8 @@ def _rel(a, ref):
 @pytest.mark.parametrize('n,ci,co,h,w', [(2, 64, 64, 32, 32), (1, 16, 128, 16, 64), (3, 128, 64, 48, 32), (1, 80, 192, 32, 96), (5, 32, 64, 16, 32),
                                           (4, 64, 128, 16, 16), (6, 32, 64, 16, 16), (16, 48, 64, 8, 8), (8, 128, 192, 8, 8),
                                           (8, 512, 128, 8, 8), (24, 256, 64, 16, 16), (12, 384, 192, 16, 16),     # few tiles, many chunks: K shared out over 8 / 8 / 4 workgroups (atomics)
+                                          (32, 64, 64, 4, 4), (96, 512, 512, 4, 4), (64, 576, 512, 4, 4), (8, 128, 64, 4, 4), (37, 48, 128, 4, 4),    # 4 x 4: 32 samples per tile (round 5)
+                                          (3, 64, 64, 16, 16), (5, 32, 128, 8, 8), (13, 64, 64, 8, 8),     # a partly filled last tile
                                           (2, 32, 32, 32, 64), (1, 64, 32, 16, 32), (2, 48, 96, 32, 32), (3, 32, 32, 16, 32)])     # c_out % 32: a half-full last tile
 @pytest.mark.parametrize('transposed', [False, True])
 def test_conv3x3_matches_fp64(n, ci, co, h, w, transposed):
@@ -81,9 +83,11 @@ def test_conv3x3_gradients_first_and_second_order():
 
 def test_conv3x3_unsupported_shapes_use_the_vendor_library():
     lib = custom_ops.get_native()
-    assert lib.sgv_conv3x3_supported(3, 64, 64, 16, 16, 0) == 0   # 16x16 images come in pairs
-    assert lib.sgv_conv3x3_supported(4, 64, 64, 8, 8, 0) == 0     # 8x8 images in groups of 8
-    assert lib.sgv_conv3x3_supported(4, 64, 64, 4, 4, 0) == 0
+    assert lib.sgv_conv3x3_supported(3, 64, 64, 16, 16, 0) == 1   # (round 5: a last tile may be partly filled -- 16x16 images need not come in pairs)
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 8, 8, 0) == 1
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 4, 4, 0) == 1     # 4 x 4: 32 samples per tile
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 4, 8, 0) == 0     # square images only
+    assert lib.sgv_conv3x3_supported(4, 64, 64, 2, 2, 0) == 0
     assert lib.sgv_conv3x3_supported(4, 3, 64, 32, 32, 0) == 0    # c_in % 16
     assert lib.sgv_conv3x3_supported(4, 64, 48, 32, 32, 0) == 0   # c_out % 32
     assert lib.sgv_conv3x3_supported(4, 64, 32, 32, 32, 0) == 1   # a half-full last tile on the producer / consumer kernel ...
@@ -92,7 +96,7 @@ def test_conv3x3_unsupported_shapes_use_the_vendor_library():
     assert lib.sgv_conv3x3_supported(4, 64, 64, 32, 32, 2) == 1   # bf16 tensors: the producer / consumer kernel (tests/test_conv_lowp_gpu.py)
     assert lib.sgv_conv3x3_supported(4, 64, 64, 16, 16, 2) == 0   # ... which the 16x16 / 8x8 form is not
     assert lib.sgv_conv3x3_supported(4, 64, 64, 32, 32, 3) == 0   # fp64
-    x = torch.randn([3, 64, 16, 16], device=DEV)
+    x = torch.randn([3, 64, 12, 12], device=DEV)
     w = torch.randn([64, 64, 3, 3], device=DEV, requires_grad=True)
     before = custom_ops.launch_count()
     y = conv2d_gradfix.conv2d(x, w, padding=1)
@@ -239,3 +243,26 @@ def test_native_kernels_also_serve_no_grad_passes():
     dispatch_assert(custom_ops.prof_collect()['conv3x3']['launches'] == 2)
     assert_close(y, F.conv2d(x.double(), w.double(), padding=1), atol=2e-5 * 3, rtol=1e-4)
     assert_close(yt, F.conv_transpose2d(x.double(), w.double(), stride=2), atol=2e-5 * 3, rtol=1e-4)
+
+
+def test_small_images_with_odd_channel_counts_are_zero_padded_onto_the_native_kernel():
+    """The discriminator's epilogue convolution (networks.py:518-576: 512 + 1 minibatch-std channels at 4 x 4) has c_in = 513: conv2d_gradfix pads x and w with zero
+    channels up to a multiple of 64, so that the convolution AND its data gradient (c_out of the transposed form) run on conv3x3_small_kernel instead of the
+    vendor library; gradients flow back through the padding (first and second order)."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn([32, 513, 4, 4], generator=g).to(DEV).requires_grad_(True)
+    w = (torch.randn([512, 513, 3, 3], generator=g) / 68).to(DEV).requires_grad_(True)
+    before = custom_ops.kernel_variant_counts()['conv_small']
+    y = conv2d_gradfix.conv2d(x, w, padding=1)
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    dx, dw = torch.autograd.grad(y, [x, w], dy, create_graph=True)
+    dispatch_assert(custom_ops.kernel_variant_counts()['conv_small'] - before == 2, 'forward and data gradient must take the 4 x 4 kernel')
+    (d2,) = torch.autograd.grad(dx.square().sum(), [w])
+    xr, wr = x.detach().double().cpu().requires_grad_(True), w.detach().double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, wr, padding=1)
+    dxr, dwr = torch.autograd.grad(yr, [xr, wr], dy.double().cpu(), create_graph=True)
+    (d2r,) = torch.autograd.grad(dxr.square().sum(), [wr])
+    assert y.shape == yr.shape and dx.shape == xr.shape and dw.shape == wr.shape
+    for got, ref, name in ((y, yr, 'y'), (dx, dxr, 'dx'), (dw, dwr, 'dw'), (d2, d2r, 'd2w')):
+        l2, mx = _rel(got.detach(), ref.detach())
+        assert l2 < 5e-6 and mx < 2e-5, (name, l2, mx)
