@@ -424,21 +424,14 @@ int conv3x3_s2_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_s2_epilogue* 
         const int ss = 32 / p->w;
         kp.tiles = (p->n / ss) * (p->h / TW_ROWS) * (p->c_out / TM);
         kp.grid = std::min(kp.tiles, g_cus);
-        if (ss == 2) {
-            if (p->terms == 1) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<1, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
-            else if (p->terms == 3) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
-            else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<4, 0, 2>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(2), stream, kp);
-        } else {
-            if (p->terms == 1) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<1, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
-            else if (p->terms == 3) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<3, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
-            else hipLaunchKernelGGL((convT3x3_s2_ws_kernel<4, 0, 4>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(4), stream, kp);
-        }
+#define SGV_TW_T(T, SS) hipLaunchKernelGGL((convT3x3_s2_ws_kernel<T, 0, SS>), dim3((unsigned)kp.grid), dim3(448), tw_lds_bytes(SS), stream, kp)
+        if (ss == 2) { if (p->terms == 1) SGV_TW_T(1, 2); else if (p->terms == 3) SGV_TW_T(3, 2); else SGV_TW_T(4, 2); }
+        else { if (p->terms == 1) SGV_TW_T(1, 4); else if (p->terms == 3) SGV_TW_T(3, 4); else SGV_TW_T(4, 4); }
     } else if (g_s2_ws) {
         kp.tiles = p->n * (p->h / TW_ROWS) * (p->w / SEG) * tiles_m(p->c_out);
         kp.grid = std::min(kp.tiles, g_cus);
-        if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_ws_kernel<1>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
-        else if (p->terms == 3) hipLaunchKernelGGL(convT3x3_s2_ws_kernel<3>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
-        else hipLaunchKernelGGL(convT3x3_s2_ws_kernel<4>, dim3((unsigned)kp.grid), dim3(448), TW_LDS_BYTES, stream, kp);
+        if (p->terms == 1) SGV_TW_T(1, 1); else if (p->terms == 3) SGV_TW_T(3, 1); else SGV_TW_T(4, 1);
+#undef SGV_TW_T
     } else {
         if (p->terms == 1) hipLaunchKernelGGL(convT3x3_s2_kernel<1>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);
         else hipLaunchKernelGGL(convT3x3_s2_kernel<3>, dim3((unsigned)kp.grid), dim3(512), T_LDS_BYTES, stream, kp);

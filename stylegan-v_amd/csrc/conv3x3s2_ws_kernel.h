@@ -649,8 +649,9 @@ __device__ __forceinline__ tile_pos decode_tile_tw(const s2_params& p, int tile)
 //   nothing more from 2; the WHOLE kernel is 3-9 % slower with 1 and within +-3 % with 2 (0.873 / 0.753 / 0.707 ms against 0.901 / 0.751 / 0.683): the
 //   operand reads are not what the loop waits for.  The same log splits the kernel's time: consumers alone 0.55-0.68 ms, producers + DMA + stores alone
 //   0.41-0.86, everything but the stores 0.62-0.64, the tile-end stores 0.06 (256 channels out) - 0.26 ms (64 channels out, 1.6 GB).
-template <int TERMS, int ABL = 0, int S = 1, int IO = 0, int CM = 0>
+template <int TERMS, int ABL = 0, int S = 1, int IO = 0, int CM = 0, int ST = 0>
 __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
+    static_assert(ST == 0 || CM == 0, "the store schedule is written for the one-row mapping");
     constexpr int F = sgv_conv::operand_format<TERMS, IO>();      // operand format of the products (sgv_split.h): TERMS, or 2 = fp16 operands for fp16 tensors
     using namespace sgv_io;
     static_assert(IO == 0 || TERMS == 1, "16-bit tensors are single bf16 operands");
@@ -896,6 +897,156 @@ __global__ __launch_bounds__(448, 2) void convT3x3_s2_ws_kernel(s2_params p) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
     }
+    return;
+    }
+    if constexpr (ST == 1) {
+    // ST = 1 (round 5; tools/convT_lab.hip only -- the product instantiates ST = 0).  Measured (profiles/r05_c6_convT_lab.log, same box): NOT faster -- whole kernel
+    // 0.996 / 0.761 / 0.685 ms against 0.955 / 0.753 / 0.688 for the burst form, in the step 14.9 against 14.2 ms per iteration -- while the no-store ablation of
+    // either form runs 0.61 - 0.65 ms: what the stores cost is the bytes through the CU's memory pipe (128 KiB per tile, shared with the producers' loads and the
+    // weight DMA), wherever the instructions sit in the wave's stream.
+    // The tile's 128 stores per wave are folded INTO the MFMA stream instead of being issued as one burst behind the last chunk, where every
+    // CU of the chip stores at once at HBM-write speed while its matrix pipe idles (profiles/r05_c1_convT_lab.log: 0.06 - 0.26 ms of 0.68 - 0.90 ms per layer).
+    // No extra registers: the nine taps of EVERY chunk run class by class -- oo (tap 4), oe (3, 5), eo (1, 7), ee (0, 2, 6, 8) -- so in a tile's last chunk a class is
+    // final as soon as its own taps are done, and its 32 stores (2 halves x 16 accumulator registers) leave between the MFMAs of the classes behind it; the class
+    // that finishes last, ee, is stored between the first taps of the NEXT chunk (the next tile's first), whose own ee taps come last.  Same products; the
+    // summation order within a chunk is the class order instead of the tap order.
+    f32x16 acc[4][2];   // [class a*2+b][m half]
+#pragma unroll
+    for (int cl = 0; cl < 4; cl++)
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[cl][hf][e] = 0.f;
+    // output addresses = a wave-uniform element offset (tile and accumulator register: scalar registers) + ONE per-lane offset that never changes: a store costs
+    // no address arithmetic in vector registers (24 stores in flight with 64-bit vector addresses each would not fit beside 128 accumulators + 72 operand registers)
+    const unsigned lane_off = (unsigned)(((size_t)((lane & 31) / SW) * p.m + 4 * (lane >> 5)) * plane_out) + 2u * ((lane & 31) % SW);     // (< 2^31 elements: host-checked tensor size)
+    size_t tb_prev = 0;           // the previous tile's uniform offset while its ee class is still to be stored
+
+    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_barrier();   // images 0 and 1 ready
+    asm volatile("" ::: "memory");
+    // stores [u0, u1) of class cl (unit u: half u >> 4, accumulator register u & 15) of the tile at uniform offset tb; the registers are cleared as they leave.
+    // (Whole 64-channel tiles only: the host keeps half-full last tiles on the burst form, ST = 0.)
+    auto store_units = [&](int cl, int u0, int u1, size_t tb) {
+#pragma unroll
+        for (int u = u0; u < u1; u++) {
+            const int hf = u >> 4, e = u & 15;
+            const size_t ub = tb + (size_t)(hf * 32 + (e & 3) + 8 * (e >> 2)) * plane_out + (size_t)(cl >> 1) * wout + (cl & 1);      // wave-uniform
+            if (ABL == 8 || ABL == 10) asm volatile("" :: "v"(acc[cl][hf][e]));   // lab: no stores
+            else out_store_lane<IO>((char*)p.y + ub * fmt<IO>::ES, lane_off, acc[cl][hf][e]);
+            acc[cl][hf][e] = 0.f;
+        }
+    };
+    // a class is final: undo the operands' block scales IN PLACE (TERMS = 4), so that the stores behind read the accumulator registers themselves -- a scaled copy
+    // per store in flight is 12 - 24 more live registers than the kernel has
+    auto finalize = [&](int cl) {
+        if (TERMS != 4) return;
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[cl][hf][e] = __builtin_ldexpf(acc[cl][hf][e], eu);
+    };
+    // One chunk.  LAST: the tile's last chunk (stores of oo / oe / eo behind their last taps); PEND: the previous tile's ee class is stored behind the first taps.
+    // Compile-time flags, and the three kinds of chunk of a tile -- first (PEND), middle, last (LAST) -- are three consecutive pieces of code in the tile loop,
+    // not the arms of a branch: the compiler hoists the common MFMA / read sequence out of an if / else over whole chunks and leaves the stores behind in
+    // conditional blocks, which loses the order below and spills 200 registers.
+    auto chunk = [&](int q, size_t tb, auto last_c, auto pend_c) {
+        constexpr bool LAST = decltype(last_c)::value, PEND = decltype(pend_c)::value;
+        const u32x4* xs = image(q);
+        const u32x4* ws = xs + TW_XS_WORDS;
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const int a_lane = (ln >> 5) * TM + (ln & 31);
+        const int b_lane = ((ln >> 5) * TW_RIN + wave + 1) * TW_PW + ((ln & 31) / SW) * (SW + 1) + (ln & 31) % SW + 1;      // - dy * PW - dx
+        if (ABL != 6) {
+            constexpr int ORD[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};      // oo | oe oe | eo eo | ee ee ee ee
+            u32x4 a[3][2][2];    // [buffer][half][hl]
+            u32x4 b[3][2];       // [buffer][hl]
+            auto fetch = [&](int buf, int tap) {
+                const int ky = tap / 3, kx = tap % 3;
+                const int pos = b_lane - (ky == 2 ? TW_PW : 0) - (kx == 2 ? 1 : 0);
+                b[buf][0] = xs[pos];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++)
+                    if (TERMS > 1) a[buf][hf][1] = ws[a_lane + ((1 * 9 + tap) * 2) * TM + hf * 32];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) a[buf][hf][0] = ws[a_lane + ((0 * 9 + tap) * 2) * TM + hf * 32];
+                if (TERMS > 1) b[buf][1] = xs[2 * TW_XS_PLANE + pos];
+            };
+            constexpr int RD = TERMS > 1 ? 6 : 3;
+            fetch(0, ORD[0]);
+            fetch(1, ORD[1]);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * RD, 0);
+#pragma unroll
+            for (int ps = 0; ps < 9; ps++) {
+                const int tap = ORD[ps];
+                const int ky = tap / 3, kx = tap % 3;
+                const int cl = (ky == 1 ? 2 : 0) + (kx == 1 ? 1 : 0);
+                const int bb = ps % 3;
+                if (ps + 2 < 9) fetch((ps + 2) % 3, ORD[ps + 2]);
+                // stores that leave behind this position's MFMAs: the previous tile's ee class (class 0) in positions 0 - 2; this tile's oo (class 3), final after
+                // position 0, in 1 - 3; oe (class 2), final after position 2, in 3 - 6; eo (class 1), final after position 4, in 6 - 8
+                int stores = 0;
+                if (PEND) {
+                    if (ps == 0) { store_units(0, 0, 12, tb_prev); stores += 12; }
+                    if (ps == 1) { store_units(0, 12, 24, tb_prev); stores += 12; }
+                    if (ps == 2) { store_units(0, 24, 32, tb_prev); stores += 8; }
+                }
+                if (LAST) {
+                    if (ps == 1) finalize(3);
+                    if (ps == 3) finalize(2);
+                    if (ps == 5) finalize(1);
+                    if (ps == 1) { store_units(3, 0, 12, tb); stores += 12; }
+                    if (ps == 2) { store_units(3, 12, 24, tb); stores += 12; }
+                    if (ps == 3) { store_units(3, 24, 32, tb); store_units(2, 0, 4, tb); stores += 12; }
+                    if (ps == 4) { store_units(2, 4, 16, tb); stores += 12; }
+                    if (ps == 5) { store_units(2, 16, 28, tb); stores += 12; }
+                    if (ps == 6) { store_units(2, 28, 32, tb); store_units(1, 0, 8, tb); stores += 12; }
+                    if (ps == 7) { store_units(1, 8, 20, tb); stores += 12; }
+                    if (ps == 8) { store_units(1, 20, 32, tb); stores += 12; }
+                }
+                if (TERMS > 1) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, F>(a[bb][hf][1], b[bb][0], acc[cl][hf]);
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, F>(a[bb][hf][0], b[bb][1], acc[cl][hf]);
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) acc[cl][hf] = ws_mma<0, F>(a[bb][hf][0], b[bb][0], acc[cl][hf]);
+                constexpr int MF = TERMS > 1 ? 6 : 2;
+                const int reads = ps + 2 < 9 ? RD : 0;
+                const int per_gap = (stores + MF - 1) / MF;
+#pragma unroll
+                for (int i = 0; i < MF; i++) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (i < reads) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (TERMS == 1 && i == 0 && reads > 0) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (ABL != 8 && ABL != 10) {      // up to six stores behind this MFMA (the group size must be a literal)
+#pragma unroll
+                        for (int k = 0; k < 6; k++)
+                            if (k < per_gap && i * per_gap + k < stores) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                    }
+                }
+            }
+            if (LAST) finalize(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    // tiles of this workgroup; chunks >= 2 (host-checked).  The first tile has no predecessor: its "previous tile" is itself -- the zeros that leave for its ee
+    // outputs are overwritten by the same wave's real stores later (stores of one wave to one address keep their order).
+    int q = 0;
+    for (int tl = 0; tl < my_tiles; tl++) {
+        const tile_pos tp = decode_tile_tw<S>(p, tile_of(q));
+        const size_t tb = ((size_t)tp.n * p.m + tp.mt * TM) * plane_out + (size_t)(2 * (tp.y0 + wave)) * wout + 2 * tp.x0;     // wave-uniform
+        if (tl == 0) tb_prev = tb;
+        chunk(q++, tb, std::false_type{}, std::true_type{});
+        for (int c = 1; c < chunks - 1; c++) chunk(q++, tb, std::false_type{}, std::false_type{});
+        chunk(q++, tb, std::true_type{}, std::false_type{});
+        tb_prev = tb;
+    }
+    store_units(0, 0, 32, tb_prev);     // the last tile's ee class
     return;
     }
     f32x16 acc[4][2];   // [class a*2+b][m half]

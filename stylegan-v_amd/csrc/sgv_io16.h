@@ -74,6 +74,12 @@ template <int IO> __device__ __forceinline__ void out_store(void* base, size_t i
     else if constexpr (IO == 1) ((uint16_t*)base)[index] = f32_to_bf16_rne(v);
     else { const _Float16 h = (_Float16)v; uint16_t b; __builtin_memcpy(&b, &h, 2); ((uint16_t*)base)[index] = b; }
 }
+// the same with a wave-uniform byte base (scalar registers) and a 32-bit unsigned per-lane ELEMENT offset: the scalar-base addressing mode, no 64-bit vector address
+template <int IO> __device__ __forceinline__ void out_store_lane(char* ubase, unsigned lane_index, float v) {
+    if constexpr (IO == 0) ((float*)ubase)[lane_index] = v;
+    else if constexpr (IO == 1) ((uint16_t*)ubase)[lane_index] = f32_to_bf16_rne(v);
+    else { const _Float16 h = (_Float16)v; uint16_t b; __builtin_memcpy(&b, &h, 2); ((uint16_t*)ubase)[lane_index] = b; }
+}
 // element pointer arithmetic on an untyped base
 template <int IO> __device__ __forceinline__ const char* at(const void* base, size_t index) { return (const char*)base + index * fmt<IO>::ES; }
 
