@@ -121,7 +121,7 @@ def emit(out):
 
 
 TIMED_FAMILIES = ('conv3x3_s1', 'upfirdn2d_lanes')      # kernel families whose launches are bracketed by HIP events inside the timed region
-PMC_FILES = ['r04_pmc_bench_step_FETCH_WRITE.json']   # collected by tools/gpu_recipes/pmc_fetch_write_passes.sh (separate --pmc passes of this command)
+PMC_FILES = ['r05_pmc_bench_step_FETCH_WRITE.json']   # collected by tools/gpu_recipes/pmc_fetch_write_passes.sh (separate --pmc passes of this command)
 
 
 def pmc_traffic(prefixes, dword_read_prefixes=(), files=None):
@@ -301,7 +301,7 @@ def synthesis_workload(args, world, rank, device):
         if 'upfirdn2d_lanes' in fam:
             r = fam['upfirdn2d_lanes']
             achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-            pmc_g = pmc_traffic_per_launch(files=[f'r04_pmc_{args.workload}_FETCH_WRITE.json'])     # this workload's own counter passes, when committed
+            pmc_g = pmc_traffic_per_launch(files=[f'r05_pmc_{args.workload}_FETCH_WRITE.json'])     # this workload's own counter passes, when committed
             roofline = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel (the FIR / 2x up-sampling chain of the synthesis network)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS,
                             unit='GB/s', frac=achieved / HBM_PEAK_GBPS, frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_g[0], traffic_source=pmc_g[1] + ' (reads x2, gfx950 correction)', launches=r['launches'],
                             launches_per_forward=r['launches'] / args.steps, algorithmic_bytes_per_forward=r['bytes'] / args.steps, avg_launch_us=1e3 * r['ms'] / r['launches'],

@@ -40,10 +40,39 @@ _SINKS_PER_ARENA = 64
 _sink_arenas = {}  # device index -> [zeroed fp32 tensor, blocks handed out]
 
 
+# While a hipGraph is being captured, slots and sinks come from arenas that belong to THAT capture: the arena's `zeros` is a fill node of the graph in front of
+# every kernel that uses a slot carved from it (capture order = replay order), so every replay starts from zero -- one fill per 4,096 bounds / 64 sinks instead of
+# one per bound (round 5: 338 fill launches per captured 8-video step, 1.6 ms of 50, profiles/r05_c2_kernels_b8_graphs.txt).  `capture_scope()` brackets a capture
+# (training/train_step.py); outside such a scope a capture falls back to one `zeros` per slot.
+_capture = None     # {'slots': [tensor, used], 'sinks': [tensor, used]} while a bracketed capture is running
+
+
+class capture_scope:
+    def __enter__(self):
+        global _capture
+        self._saved, _capture = _capture, dict(slots=None, sinks=None)
+        return self
+
+    def __exit__(self, *exc):
+        global _capture
+        _capture = self._saved
+        return False
+
+
+def _capture_carve(kind, device, block, per_arena):
+    a = _capture[kind]
+    if a is None or a[1] >= per_arena or a[0].device != device:
+        a = _capture[kind] = [torch.zeros([per_arena * block], dtype=torch.float32, device=device), 0]
+    a[1] += 1
+    return a[0][(a[1] - 1) * block:a[1] * block]
+
+
 def zero_sink(device):
     """A zeroed block for the library's bound side output (sgv_amax_sink): [0] receives the bound, [1 .. SINK_SLOTS] the producer's partial maxima.
     Carved from a zeroed arena like `zero_slot` (one 1-MiB fill per 64 sinks)."""
     if torch.cuda.is_current_stream_capturing():
+        if _capture is not None:
+            return _capture_carve('sinks', device, _SINK_BLOCK, _SINKS_PER_ARENA)
         return torch.zeros([_SINK_BLOCK], dtype=torch.float32, device=device)
     a = _sink_arenas.get(device.index)
     if a is None or a[1] >= _SINKS_PER_ARENA:
@@ -55,9 +84,11 @@ def zero_sink(device):
 def zero_slot(device):
     """A 1-element fp32 device tensor that holds 0.0f: what the bound kernels fold max |v| into (atomicMax of the bit pattern).  Slots are carved from a
     zeroed arena -- one fill launch per 4,096 bounds instead of one clearing command per bound (~600 per training step) -- and never handed out twice;
-    a view keeps its arena alive.  While a hipGraph is being captured every slot is its own `zeros` (the fill is then a node of THAT graph, so every
-    replay starts from zero; an arena cleared outside the graph would only ever grow)."""
+    a view keeps its arena alive.  While a hipGraph is being captured the arena belongs to the capture (`capture_scope`: its fill is a node of THAT graph, so
+    every replay starts from zero; an arena cleared outside the graph would only ever grow)."""
     if torch.cuda.is_current_stream_capturing():
+        if _capture is not None:
+            return _capture_carve('slots', device, 1, _ARENA)
         return torch.zeros([1], dtype=torch.float32, device=device)
     a = _arenas.get(device.index)
     if a is None or a[1] >= _ARENA:

@@ -37,7 +37,8 @@ class _HipGraph:
         # thread_local: the RCCL watchdog thread of an initialised process group queries events while this thread captures, which the
         # default (global) capture mode treats as an error in the OTHER thread (observed: segmentation fault in capture_end)
         kw = dict(pool=self._pool) if self._pool is not None else {}
-        with torch.cuda.graph(self.graph, capture_error_mode='thread_local', **kw):
+        from ..torch_utils.ops import amax as _amax      # (the magnitude-bound slots of the capture come from arenas the graph itself clears: ops/amax.py)
+        with _amax.capture_scope(), torch.cuda.graph(self.graph, capture_error_mode='thread_local', **kw):
             return fn()
 
     def pool(self):
