@@ -360,6 +360,7 @@ def main():
     ap.add_argument('--strict-steps', type=int, default=None, help='steps of the strict-fp32 companion measurement (all convolutions on the vendor fp32 path); 0 disables it')
     ap.add_argument('--lowp-steps', type=int, default=None, help="steps of the mixed-precision companion (bf16 tensors in the blocks >= 32^2: the reference's num_fp16_res=4 with bf16, BASELINE config 4); 0 disables it")
     ap.add_argument('--pl-steps', type=int, default=None, help='steps of the path-length-regularisation companion (F=1, pl_weight=2); 0 disables it')
+    ap.add_argument('--graph-steps', type=int, default=None, help='steps of the captured-step companion (Gmain / Dmain replayed as hipGraphs, single GPU); 0 disables it')
     ap.add_argument('--aug', choices=['noaug', 'ada'], default='noaug', help="discriminator augmentation: the reference's default is ada (bgc pipeline, adaptive p)")
     ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs (single GPU; pays off at small per-GPU batches)')
     ap.add_argument('--lowp', choices=['none', 'fp16', 'bf16'], default='none',
@@ -370,7 +371,7 @@ def main():
     multi = args.gpus > 1
     # 10 steps each from iteration 0: one R1 iteration in ten, the share the 20-step headline window has (an R1 iteration costs ~2x a plain one: with 8 steps a
     # companion would carry 1/8 and read 1.5 % low against the headline); the PL companion a whole period of its schedule (Greg every 4th, Dreg every 16th)
-    for name, dflt in (('ada_steps', 10), ('bf16_steps', 10), ('strict_steps', 10), ('lowp_steps', 10), ('pl_steps', 16), ('split3_steps', 10)):
+    for name, dflt in (('ada_steps', 10), ('bf16_steps', 10), ('strict_steps', 10), ('lowp_steps', 10), ('pl_steps', 16), ('split3_steps', 10), ('graph_steps', 10)):
         if getattr(args, name) is None:
             setattr(args, name, 0 if multi else dflt)
 
@@ -730,6 +731,35 @@ def main():
             del ts2
             torch.cuda.empty_cache()
 
+    # Captured-step companion: the same models' configuration with the Gmain / Dmain phases replayed as hipGraphs (TrainStep(use_graphs=True): two graphs
+    # per phase, the reg phases eager).  The eager step issues ~2,000 launches per iteration from Python and leaves the device idle for ~9 of its 158 ms
+    # (profiles/r05_bench_step_kernel_stats_final.csv: 144.7 ms of kernels per iteration); a replay has no such gaps.  Its own models (captures bind their tensors);
+    # same bracket and schedule.  The headline stays the eager step: per-launch HIP events -- the `roofline` objects -- cannot be recorded inside a replay.
+    graphc = None
+    if args.graph_steps > 0 and lowp is None and not args.graphs and world == 1:
+        ts3 = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=True, augment=args.aug)
+        try:
+            tw = time.perf_counter()
+            ts3.batch_idx = 1
+            ts3.step(); ts3.step()            # eager warm-up on a side stream + the captures + their first replays
+            ts3.batch_idx = 0
+            ts3.step()                        # ... and the eager reg phases
+            torch.cuda.synchronize()
+            if rank == 0:
+                log(f'[bench] captured-step companion: warm-up + capture {time.perf_counter() - tw:.1f} s')
+            ts3.batch_idx = 0
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.graph_steps):
+                ts3.step()
+            barrier()
+            t_g = time.perf_counter() - t1
+            graphc = dict(value=global_batch * args.frames * args.graph_steps / t_g, ms_per_step=1e3 * t_g / args.graph_steps, steps=args.graph_steps,
+                          what='same step with Gmain / Dmain replayed as hipGraphs (two graphs per phase: gradients | sanitise + Adam; Greg / Dreg eager)')
+        finally:
+            del ts3
+            torch.cuda.empty_cache()
+
     F32_LABEL = 'f32' if default_terms == (0, 0) else \
         ('f32 (fp32 tensors + accumulators; products = block-scaled 2-way fp16 split on MFMA: 22-bit operands, 2.7e-7 vs fp64 = vendor-fp32 class)' if default_terms == (4, 4) else
          'fp32 tensors + accumulators; products = 2-way bf16 split (16-bit operands, 4.4e-6 vs fp64: NOT fp32-grade)')
@@ -824,14 +854,14 @@ def main():
                                value_no_prof=value_no_prof['value'] if value_no_prof else None,
                                value_bf16_split=split3['value'] if split3 else None, value_vendor_fp32_convs=strict['value'] if strict else None,
                                value_aug_ada=ada['value'] if ada else None, value_bf16_products=bf16c['value'] if bf16c else None,
-                               value_lowp_bf16=lowpc['value'] if lowpc else None, value_pl_f1=plc['value'] if plc else None,
+                               value_lowp_bf16=lowpc['value'] if lowpc else None, value_pl_f1=plc['value'] if plc else None, value_hip_graphs=graphc['value'] if graphc else None,
                                conv_terms=default_terms[0], upfirdn2d_in_step_GBps=roofline_ufd['achieved'] if roofline_ufd else None,
                                upfirdn2d_in_step_frac=roofline_ufd['frac'] if roofline_ufd else None),
                    multi_gpu=multi_gpu, value_bf16_split=split3['value'] if split3 else None, bf16_split=split3,
                    value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof,
                    value_fp32_grade=value if (default_terms in ((0, 0), (4, 4)) and lowp is None) else None,     # the headline's products are fp32-GRADE (22-bit split operands, 2.7e-7), not strict fp32: the strict-fp32 figure is value_vendor_fp32_convs
                    value_vendor_fp32_convs=strict['value'] if strict else None, vendor_fp32_convs=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
-                   value_lowp_bf16=lowpc['value'] if lowpc else None, lowp_bf16=lowpc,
+                   value_lowp_bf16=lowpc['value'] if lowpc else None, lowp_bf16=lowpc, value_hip_graphs=graphc['value'] if graphc else None, hip_graphs=graphc,
                    roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, upfirdn2d_by_size=ufd_by_size, kernels=kernels, kernels_by_variant=variants, cpu_baseline=cpu)
         emit(out)
     if world > 1:

@@ -6,7 +6,7 @@ OUT=gpurun_out/r05_final
 mkdir -p $OUT/tables
 export TMPDIR=/tmp
 python -c "from stylegan_v_amd.torch_utils import custom_ops as c; import sys; print('csrc digest', c.source_digest()); sys.exit(0 if c.is_built() else 1)" || { echo "in-tree library is stale: stop"; exit 1; }
-OFF="--strict-steps 0 --bf16-steps 0 --pl-steps 0 --ada-steps 0 --lowp-steps 0 --split3-steps 0"
+OFF="--strict-steps 0 --bf16-steps 0 --pl-steps 0 --ada-steps 0 --lowp-steps 0 --split3-steps 0 --graph-steps 0"
 # 1. tests + smoke
 SGV_ERROR_TABLE_DIR=$OUT/tables timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -6 > $OUT/pytest_gpu.log; tail -2 $OUT/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
