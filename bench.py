@@ -47,6 +47,68 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class PowerSampler:
+    """Engine clock, socket power and hot-spot temperature of ONE device while a region runs: the amdgpu hwmon files of the card whose PCI address is the HIP device's,
+    read every `period` seconds on a thread.  Evidence for the regime the kernels run in (the step sits at the package power cap, far below the
+    2.4 GHz the MFMA peak is quoted at); never an input to `value`.  Silent when the files are not there."""
+
+    FILES = (('sclk_MHz', 'freq1_input', 1e-6), ('socket_W', 'power1_input', 1e-6), ('socket_W', 'power1_average', 1e-6), ('hotspot_C', 'temp2_input', 1e-3), ('cap_W', 'power1_cap', 1e-6))
+
+    def __init__(self, device_index=0, period=0.02):
+        import glob
+        self.period, self.files, self.rows, self.on, self.card = period, {}, [], False, None
+        try:
+            p = torch.cuda.get_device_properties(device_index)
+            want = f'{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}'
+        except Exception:      # noqa
+            return
+        for card in sorted(glob.glob('/sys/class/drm/card*/device')):
+            if not os.path.basename(os.path.realpath(card)).lower().startswith(want):
+                continue
+            for hw in glob.glob(os.path.join(card, 'hwmon', 'hwmon*')):
+                for key, name, scale in self.FILES:
+                    path = os.path.join(hw, name)
+                    if key not in self.files and os.path.exists(path):
+                        self.files[key] = (path, scale)
+            self.card = os.path.basename(os.path.dirname(card)) + ' @ ' + os.path.basename(os.path.realpath(card))
+
+    def _loop(self):
+        while self.on:
+            row = {}
+            for key, (path, scale) in self.files.items():
+                try:
+                    with open(path) as fh:
+                        row[key] = float(fh.read().strip()) * scale
+                except Exception:      # noqa
+                    pass
+            self.rows.append(row)
+            time.sleep(self.period)
+
+    def __enter__(self):
+        import threading
+        self.rows, self.on = [], bool(self.files)
+        self.thread = threading.Thread(target=self._loop, daemon=True)
+        self.thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.on = False
+        self.thread.join()
+
+    def summary(self):
+        """{key: median, key_min, key_max} over the samples of the last region; None without samples."""
+        if not self.rows or not self.files:
+            return None
+        out = dict(samples=len(self.rows), card=self.card)
+        for key in self.files:
+            v = sorted(r[key] for r in self.rows if key in r)
+            if v:
+                out[key] = round(v[len(v) // 2], 1)
+                if key != 'cap_W':
+                    out[key + '_min'], out[key + '_max'] = round(v[0], 1), round(v[-1], 1)
+        return out
+
+
 def _round_floats(o, sig=6):
     """Floats to `sig` significant digits (the compact line must survive an 8 KB tail: 17-digit floats are a third of it)."""
     if isinstance(o, float):
@@ -84,6 +146,8 @@ def compact_line(out, detail_path=None):
     optional += [(k, out[k]) for k in sorted(out) if k.startswith('value_') and not isinstance(out[k], (dict, list))]
     if out.get('multi_gpu'):
         optional.append(('multi_gpu', out['multi_gpu']))
+    if out.get('power'):       # engine clock / socket power sampled over the timed region (hwmon of the device's own card)
+        optional.append(('power', {k: v for k, v in out['power'].items() if k in ('sclk_MHz', 'socket_W', 'cap_W', 'hotspot_C', 'samples')}))
     optional.append(('detail', detail_path))
     for k, v in optional:
         line[k] = v
@@ -362,7 +426,8 @@ def main():
     ap.add_argument('--pl-steps', type=int, default=None, help='steps of the path-length-regularisation companion (F=1, pl_weight=2); 0 disables it')
     ap.add_argument('--graph-steps', type=int, default=None, help='steps of the captured-step companion (Gmain / Dmain replayed as hipGraphs, single GPU); 0 disables it')
     ap.add_argument('--aug', choices=['noaug', 'ada'], default='noaug', help="discriminator augmentation: the reference's default is ada (bgc pipeline, adaptive p)")
-    ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs (single GPU; pays off at small per-GPU batches)')
+    ap.add_argument('--graphs', action='store_true', help='replay Gmain / Dmain as hipGraphs WITHOUT any per-launch events (no roofline objects)')
+    ap.add_argument('--eager', action='store_true', help='single GPU: time the eager step instead of the captured one (the default headline of a one-GPU run is the captured step, with per-launch event nodes inside the graphs)')
     ap.add_argument('--lowp', choices=['none', 'fp16', 'bf16'], default='none',
                     help='mixed precision in the 4 highest resolutions (reference: fp16; BASELINE config 4: bf16). Default: full fp32')
     args = ap.parse_args()
@@ -418,19 +483,64 @@ def main():
     lowp = {'none': None, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.lowp]
     g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=(lowp is None),
                                                       num_frames_per_video=args.frames, lowp_dtype=lowp)
-    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=args.graphs, augment=args.aug)
+    # One GPU: the headline step is the CAPTURED one: Gmain / Dmain replayed as hipGraphs, the reg phases eager at their schedule --
+    # the same work, without the dispatch latency between ~2,000 dependent launches per iteration that costs the eager step ~9 of 158 ms.  The kernels the roofline
+    # objects are about are bracketed INSIDE the graphs (sgv_prof_resume around every capture: csrc/sgv_runtime.hip), so their durations are read
+    # live from the last replayed iteration of the timed region (device-clock timestamp kernels: the HIP runtime torch bundles refuses event records that can be
+    # read back from a capture).  Several GPUs (DDP's reducer cannot be captured) or --eager: the eager step with HIP events, as in rounds 1-4.
+    captured_headline = world == 1 and not args.eager and not args.graphs and not args.no_prof
+    if captured_headline:
+        import contextlib
+        from stylegan_v_amd.training import train_step as _tsmod
+        custom_ops.prof_families(TIMED_FAMILIES)
+        custom_ops.prof_enable(1 << 15)      # allocates the event pool and starts a new record list ...
+        custom_ops.prof_disable()            # ... which only the captures below append to
+
+        @contextlib.contextmanager
+        def _capture_events():
+            custom_ops.prof_resume()
+            try:
+                yield
+            finally:
+                custom_ops.prof_disable()
+    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=args.graphs or captured_headline, augment=args.aug)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    timed_graphs = None
+
+    def capture_timed_set():
+        """A SECOND set of graphs of the same step with the timing kernels inside (two one-thread timestamp kernels around each of the ~120 launches the roofline
+        objects are about).  The timed region replays the clean set and only its LAST iteration this one: the sample is taken live, inside the region, and whatever
+        the stamps cost a replay is paid once in K iterations."""
+        nonlocal timed_graphs
+        clean_graphs, ts._graphs = ts._graphs, {}
+        _tsmod._HipGraph.capture_hook = _capture_events
+        ts.batch_idx = 1             # (no regularisation phase in this iteration)
+        ts.step()                    # eager warm-up on the side with the training state put back, the captures, one replay of each
+        torch.cuda.synchronize()
+        _tsmod._HipGraph.capture_hook = None
+        timed_graphs, ts._graphs = ts._graphs, clean_graphs
+        ts.batch_idx = 0             # the next warm-up iteration runs all four phases behind BOTH captures (call 17: the first R1 iteration after a capture pays 0.5-0.8 s once)
+
     for i in range(args.warmup):
         tw = time.perf_counter()
-        ts.step()
+        if captured_headline and i == 1 and args.warmup >= 3:
+            capture_timed_set()      # warm-up iteration 0 captured the clean set; this one IS iteration 1; 2 .. W-1 replay the clean set with the eager R1 phases in between
+        else:
+            ts.step()
         torch.cuda.synchronize()
         if rank == 0:
             log(f'[bench] warm-up iteration {i}: {time.perf_counter() - tw:.2f} s (includes MIOpen kernel compilation on a cold cache)')
+    if captured_headline and timed_graphs is None:      # a warm-up too short to hold the second capture: two more untimed iterations
+        if not ts._graphs:
+            ts.step()
+        capture_timed_set()
+        ts.step()
+        torch.cuda.synchronize()
     # Start the timed window on an iteration that runs the regularisation phases, whatever the warm-up was.
     ts.batch_idx = 0
     launches0 = custom_ops.launch_count()
@@ -465,17 +575,29 @@ def main():
     # (TIMED_FAMILIES: the dominant stride-1 3x3 kernel and the upfirdn2d family, ~120 launches per iteration).  The full per-family / per-variant tables come from
     # a fully instrumented pass of their own behind the timed region.  `value` is the wall time of all K steps.
     prof_from = args.steps // 2
+    power = PowerSampler(device.index or 0) if rank == 0 else None
+    if power is not None:
+        power.__enter__()
     barrier()
     t0 = time.perf_counter()
     phases_run = {}
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # one event per iteration boundary: the per-iteration device times in the side file
+    step_marks[0].record()
     for i_step in range(args.steps):
-        if not args.no_prof and i_step == prof_from:
+        if not args.no_prof and not captured_headline and i_step == prof_from:
             custom_ops.prof_families(TIMED_FAMILIES)      # inside the timed region: the dominant kernel and the FIR family only (all 554 launches per iteration: 1.4 % of the step)
             custom_ops.prof_enable(1 << 17)
+        if timed_graphs is not None and i_step == args.steps - 1 and not os.environ.get('SGV_BENCH_NO_SWAP'):
+            ts._graphs = timed_graphs          # the last iteration of the region carries the per-launch timing
         for name in ts.step():
             phases_run[name] = phases_run.get(name, 0) + 1
+        step_marks[i_step + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    if power is not None:
+        power.__exit__()
+    step_ms = [round(step_marks[i].elapsed_time(step_marks[i + 1]), 3) for i in range(args.steps)]
+    log(f'[bench] per-iteration device time of the timed region (ms): {step_ms}')
     launches = custom_ops.launch_count() - launches0
     def collect_tables():
         """Stop recording and fold the per-launch records: per family, per kernel variant, and the upfirdn2d launches grouped by size."""
@@ -504,7 +626,19 @@ def main():
     ufd_by_size = None
     by_variant = None
     if not args.no_prof:
-        prof_timed, _, ufd_by_size = collect_tables()
+        prof_timed, _, ufd_by_size = collect_tables()      # (captured headline: the event nodes' recordings of the LAST replayed Gmain / Dmain iteration)
+    hip_graphs_headline = bool(ts.use_graphs)
+    headline_launches_per_step = launches / args.steps
+    if captured_headline:
+        # Everything behind the headline -- the eager step as a companion, the instrumented per-variant tables, the arithmetic / augmentation companions that switch
+        # dispatch flags at run time (a captured graph has them baked in) -- runs on an EAGER step with its own models; the captured one is released first.
+        _tsmod._HipGraph.capture_hook = None
+        del ts
+        torch.cuda.empty_cache()
+        ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=False, augment=args.aug)
+        ts.batch_idx = 1
+        ts.step(); ts.step()
+        torch.cuda.synchronize()
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
     multi_gpu = None
@@ -548,6 +682,9 @@ def main():
         value_no_prof = dict(value=global_batch * args.frames * k_clean / float(t_c.item()), ms_per_step=1e3 * float(t_c.item()) / k_clean, steps=k_clean)
     elif args.no_prof:
         value_no_prof = dict(value=value, ms_per_step=1e3 * elapsed / args.steps, steps=args.steps)
+    value_eager = None
+    if captured_headline:      # the K steps just timed WERE the eager step (no events): the headline's eager twin, not a "no_prof" repeat of it
+        value_eager, value_no_prof = value_no_prof, None
     # The full per-family / per-variant tables (`kernels`, `kernels_by_variant`, `roofline_conv_family`): every launch bracketed, in a pass of its own over the
     # same schedule positions as the recorded half of the timed window (iterations prof_from .. steps - 1), outside every timed region.
     if not args.no_prof:
@@ -558,8 +695,8 @@ def main():
             ts.step()
         barrier()
         prof, by_variant, _ = collect_tables()
-        for fam in TIMED_FAMILIES:              # the two families of the timed region keep their in-region figures in the family table
-            if prof_timed[fam]['launches']:
+        for fam in (() if captured_headline else TIMED_FAMILIES):      # the two families of the timed region keep their in-region figures in the family table
+            if prof_timed[fam]['launches'] and prof_timed[fam]['ms'] > 0:   # (captured headline: the tables stay the eager step's, the roofline objects take the in-graph sample)
                 for key in ('launches', 'ms', 'bytes', 'flops'):
                     if fam == 'conv3x3_s1':
                         prof['conv3x3'][key] += prof_timed[fam][key] - prof[fam][key]
@@ -736,7 +873,7 @@ def main():
     # (profiles/r05_bench_step_kernel_stats_final.csv: 144.7 ms of kernels per iteration); a replay has no such gaps.  Its own models (captures bind their tensors);
     # same bracket and schedule.  The headline stays the eager step: per-launch HIP events -- the `roofline` objects -- cannot be recorded inside a replay.
     graphc = None
-    if args.graph_steps > 0 and lowp is None and not args.graphs and world == 1:
+    if args.graph_steps > 0 and lowp is None and not args.graphs and world == 1 and not captured_headline:
         ts3 = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=True, augment=args.aug)
         try:
             tw = time.perf_counter()
@@ -760,6 +897,8 @@ def main():
             del ts3
             torch.cuda.empty_cache()
 
+    sample_note = (f'the launches of the LAST iteration of the timed steps (step {args.steps - 1}: Gmain + Dmain replayed from graphs that carry a device-clock timestamp kernel either side of each of these launches, sgv_prof_resume)'
+                   if captured_headline else f'all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1})')
     F32_LABEL = 'f32' if default_terms == (0, 0) else \
         ('f32 (fp32 tensors + accumulators; products = block-scaled 2-way fp16 split on MFMA: 22-bit operands, 2.7e-7 vs fp64 = vendor-fp32 class)' if default_terms == (4, 4) else
          'fp32 tensors + accumulators; products = 2-way bf16 split (16-bit operands, 4.4e-6 vs fp64: NOT fp32-grade)')
@@ -779,14 +918,15 @@ def main():
                 if e['flops'] > 0:
                     k['TFLOPs'] = e['flops'] / (e['ms'] * 1e-3) / 1e12
                 kernels[name] = k
-            r = prof['upfirdn2d_lanes']
+            in_region = prof_timed if (captured_headline and prof_timed is not None and prof_timed['conv3x3_s1']['ms'] > 0) else prof     # what the roofline objects are computed from
+            r = in_region['upfirdn2d_lanes']
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
                 roofline_ufd = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
                                     frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch()[0], launches=r['launches'],
                                     traffic_source=pmc_traffic_per_launch()[1] + ' (reads x2, gfx950 correction)',
                                     avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
-                                    note=f'all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1}; every layer size, fwd+bwd+double-bwd), size-weighted')
+                                    note=sample_note + ' (every layer size, fwd+bwd), size-weighted')
             # The contract's `roofline` is the step's dominant hand-written kernel (largest summed HIP-event time): the stride-1 producer / consumer
             # 3x3 kernel, accounted on its own (SGV_K_CONV3X3_S1); `roofline_conv_family` keeps the figure of the whole 3x3 family that earlier rounds'
             # lines reported under `roofline` (stride 1 + stride 2 + transposed + 16^2 / 8^2 + edge-strip members, flop-weighted).
@@ -800,7 +940,7 @@ def main():
                             avg_launch_us=1e3 * e['ms'] / e['launches'], algorithmic_flops_per_launch=e['flops'] / e['launches'],
                             executed_bf16_TFLOPs=achieved * terms, bf16_dense_peak_TFLOPs=MFMA_BF16_PEAK_TFLOPS, fp32_mfma_peak_TFLOPs=157.3,
                             note=f'algorithmic flops = 2*N*H*W*Cin*Cout*9 (fp32-equivalent); the kernel issues {terms} 16-bit MFMAs per product (hi/lo split, fp32 accumulate), '
-                                 f'so its ceiling is the 16-bit dense peak / {terms}; all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1}), flop-weighted')
+                                 f'so its ceiling is the 16-bit dense peak / {terms}; ' + sample_note + ', flop-weighted')
             roofline_family = None
             if prof['conv3x3']['launches']:
                 roofline_family = mfma_roofline(prof['conv3x3'], conv2d_gradfix.native_conv_terms,
@@ -808,7 +948,7 @@ def main():
             singles = {n: e for n, e in prof.items() if e['launches'] and n != 'conv3x3'}     # 'conv3x3' is a sum that contains 'conv3x3_s1'
             dom = max(singles, key=lambda n: singles[n]['ms'], default=None)
             if dom == 'conv3x3_s1':
-                roofline = mfma_roofline(prof[dom], conv2d_gradfix.native_conv_terms, 'conv3x3_ws_kernel (stride 1, forward and data gradient, incl. the variants with the layer tail in the store)',
+                roofline = mfma_roofline(in_region[dom], conv2d_gradfix.native_conv_terms, 'conv3x3_ws_kernel (stride 1, forward and data gradient, incl. the variants with the layer tail in the store)',
                                          pmc_traffic(('conv3x3_ws_kernel',)))
             elif dom == 'conv_wrw':
                 roofline = mfma_roofline(prof[dom], conv2d_gradfix.native_wrw_terms, 'wrw3x3_ws_kernel / wrw3x3_s2_ws_kernel', pmc_traffic(('wrw3x3',)))
@@ -845,20 +985,21 @@ def main():
         out = dict(metric='G+D train-step images/sec at 256^2', value=value, unit='img/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                    ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak', vs_baseline=None,
                    dtype={'none': F32_LABEL, 'fp16': 'f16 (blocks >= 32^2; f32 accumulate, f32 master weights)', 'bf16': 'bf16 (blocks >= 32^2; f32 accumulate, f32 master weights)'}[args.lowp], data='synthetic',
-                   config=dict(workload=f'FFS {args.res}x{args.res} full G+D train step (Gmain+Greg+Dmain+Dreg/R1), cfg=auto fmaps 0.5, ' + ('fp32' if lowp is None else args.lowp + ' mixed precision') + ', aug=' + args.aug,
+                   config=dict(workload=f'FFS {args.res}x{args.res} full G+D train step (Gmain+Greg+Dmain+Dreg/R1), cfg=auto fmaps 0.5, ' + ('fp32' if lowp is None else args.lowp + ' mixed precision') + ', aug=' + args.aug
+                               + (', Gmain / Dmain replayed as hipGraphs' if hip_graphs_headline else ''),
                                videos_per_gpu=args.batch_gpu, frames_per_video=args.frames, frames_per_gpu=args.batch_gpu * args.frames,
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
-                               native_launches_per_step=launches / args.steps, hip_graphs=bool(ts.use_graphs),
+                               native_launches_per_step=headline_launches_per_step, hip_graphs=hip_graphs_headline,
                                # companions of the same run as scalars (each is also a top-level value_* key with its details next to it)
-                               value_no_prof=value_no_prof['value'] if value_no_prof else None,
+                               value_no_prof=value_no_prof['value'] if value_no_prof else None, value_eager=value_eager['value'] if value_eager else None,
                                value_bf16_split=split3['value'] if split3 else None, value_vendor_fp32_convs=strict['value'] if strict else None,
                                value_aug_ada=ada['value'] if ada else None, value_bf16_products=bf16c['value'] if bf16c else None,
                                value_lowp_bf16=lowpc['value'] if lowpc else None, value_pl_f1=plc['value'] if plc else None, value_hip_graphs=graphc['value'] if graphc else None,
                                conv_terms=default_terms[0], upfirdn2d_in_step_GBps=roofline_ufd['achieved'] if roofline_ufd else None,
                                upfirdn2d_in_step_frac=roofline_ufd['frac'] if roofline_ufd else None),
-                   multi_gpu=multi_gpu, value_bf16_split=split3['value'] if split3 else None, bf16_split=split3,
-                   value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof,
+                   multi_gpu=multi_gpu, step_ms=step_ms, power=power.summary() if power is not None else None, value_bf16_split=split3['value'] if split3 else None, bf16_split=split3,
+                   value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof, value_eager=value_eager['value'] if value_eager else None, eager=value_eager,
                    value_fp32_grade=value if (default_terms in ((0, 0), (4, 4)) and lowp is None) else None,     # the headline's products are fp32-GRADE (22-bit split operands, 2.7e-7), not strict fp32: the strict-fp32 figure is value_vendor_fp32_convs
                    value_vendor_fp32_convs=strict['value'] if strict else None, vendor_fp32_convs=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
                    value_lowp_bf16=lowpc['value'] if lowpc else None, lowp_bf16=lowpc, value_hip_graphs=graphc['value'] if graphc else None, hip_graphs=graphc,

@@ -71,7 +71,7 @@
 extern "C" {
 #endif
 
-#define SGV_VERSION 102 /* major*100 + minor */
+#define SGV_VERSION 103 /* major*100 + minor */
 
 /* element types (the reference dispatches double/float/half: upfirdn2d.cpp:59, bias_act.cpp:76;
  * bf16 is this library's extension) */
@@ -541,6 +541,10 @@ typedef struct sgv_prof_entry {
 
 int sgv_prof_enable(int32_t max_records); /* allocates the event pool (host side only) */
 int sgv_prof_disable(void);
+/* Records again WITHOUT resetting the pool (sgv_prof_enable starts a new one).  A launch bracketed while its stream is being CAPTURED is timed by two one-thread
+ * kernels that store the device's constant-rate clock -- nodes of the graph like the launch itself: every replay rewrites the pair, and the collect calls then
+ * read that launch's duration inside the LAST replay (1.03; event records inside a capture cannot be read back under the HIP runtime PyTorch bundles). */
+int sgv_prof_resume(void);
 /* Bracket only the launches of the families whose bit (1 << enum sgv_kernel_family) is set; 0 = all (the default).  bench.py times the dominant kernels inside
  * its timed region with two families enabled (two events per launch of 554 launches per iteration cost 1.4 % of the step) and the full table in a pass of its own. */
 int sgv_prof_families(uint64_t mask);

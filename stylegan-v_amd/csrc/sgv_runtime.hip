@@ -1,6 +1,8 @@
 // Error strings, launch accounting and the per-launch HIP-event profiler of libsgv_hip.so.
 #include "sgv_common.h"
 
+#include <stdio.h>
+#include <stdlib.h>
 #include <atomic>
 #include <mutex>
 #include <vector>
@@ -43,6 +45,7 @@ struct prof_record {
     hipEvent_t start, stop;
     int family, variant;
     double bytes, flops;
+    bool stamped;       // bracketed by device-timestamp kernels instead of events (a launch recorded while its stream was being captured)
 };
 
 static std::mutex g_prof_mu;
@@ -50,6 +53,8 @@ static std::vector<prof_record> g_prof_pool;
 static std::atomic<int> g_prof_next{0};
 static std::atomic<bool> g_prof_on{false};
 static std::atomic<uint64_t> g_prof_mask{~0ull};     // bit f: launches of family f are bracketed
+static unsigned long long* g_stamps = nullptr;       // device: [2 * pool size] constant-rate clock readings (record i: 2 i = before, 2 i + 1 = behind its kernel)
+static size_t g_stamps_cap = 0;
 static void prof_note_variant(int v) {
     const int i = g_scope_slot;
     if (i >= 0 && i < (int)g_prof_pool.size() && g_prof_pool[i].variant < 0) g_prof_pool[i].variant = v;   // the first note of a call names it
@@ -64,6 +69,12 @@ extern "C" int sgv_prof_enable(int32_t max_records) {
             return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_enable: hipEventCreate failed");
         g_prof_pool.push_back(r);
     }
+    if (g_stamps_cap < g_prof_pool.size()) {
+        if (g_stamps) (void)hipFree(g_stamps);
+        g_stamps = nullptr;
+        if (hipMalloc((void**)&g_stamps, g_prof_pool.size() * 2 * sizeof(unsigned long long)) != hipSuccess) { g_stamps_cap = 0; return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_enable: hipMalloc failed"); }
+        g_stamps_cap = g_prof_pool.size();
+    }
     g_prof_next = 0;
     g_prof_on = true;
     return SGV_OK;
@@ -74,9 +85,29 @@ extern "C" int sgv_prof_disable(void) {
     return SGV_OK;
 }
 
+extern "C" int sgv_prof_resume(void) {
+    if (g_prof_pool.empty()) return sgv_fail(SGV_ERR_INVALID_ARG, "sgv_prof_resume: no pool (call sgv_prof_enable first)");
+    g_prof_on = true;
+    return SGV_OK;
+}
+
 extern "C" int sgv_prof_families(uint64_t mask) {
     g_prof_mask = mask ? mask : ~0ull;
     return SGV_OK;
+}
+
+// host copy of the timestamp pairs of the first n records (after the device has drained) + the clock's rate; empty if none of them is stamped
+static bool prof_read_stamps(int n, std::vector<unsigned long long>& host, double& ticks_per_ms) {
+    bool any = false;
+    for (int i = 0; i < n; i++) any = any || g_prof_pool[i].stamped;
+    if (!any || !g_stamps) return false;
+    if (hipDeviceSynchronize() != hipSuccess) return false;
+    host.resize((size_t)2 * n);
+    if (hipMemcpy(host.data(), g_stamps, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return false;
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) khz = 100000;
+    ticks_per_ms = (double)khz;
+    return true;
 }
 
 extern "C" int sgv_prof_collect(sgv_prof_entry* out) {
@@ -85,11 +116,19 @@ extern "C" int sgv_prof_collect(sgv_prof_entry* out) {
     for (int k = 0; k < SGV_K_COUNT; k++) out[k] = sgv_prof_entry{0, 0.0, 0.0, 0.0};
     int n = g_prof_next.load();
     if (n > (int)g_prof_pool.size()) n = (int)g_prof_pool.size();
+    std::vector<unsigned long long> stamps;
+    double ticks_per_ms = 1e5;
+    const bool have_stamps = prof_read_stamps(n, stamps, ticks_per_ms);
     for (int i = 0; i < n; i++) {
         prof_record& r = g_prof_pool[i];
-        if (hipEventSynchronize(r.stop) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_collect: event sync failed");
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+        if (r.stamped) {
+            if (!have_stamps || stamps[2 * i + 1] <= stamps[2 * i]) continue;
+            ms = (float)((double)(stamps[2 * i + 1] - stamps[2 * i]) / ticks_per_ms);
+        } else {
+            if (hipEventSynchronize(r.stop) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_collect: event sync failed");
+            if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) continue;
+        }
         sgv_prof_entry& e = out[r.family];
         e.launches += 1;
         e.ms += ms;
@@ -105,11 +144,18 @@ extern "C" int sgv_prof_collect_records(sgv_prof_record* out, int32_t max_record
     if (!out || max_records < 0) return sgv_fail(SGV_ERR_INVALID_ARG, "sgv_prof_collect_records: bad output array");
     int n = g_prof_next.load();
     if (n > (int)g_prof_pool.size()) n = (int)g_prof_pool.size();
+    std::vector<unsigned long long> stamps;
+    double ticks_per_ms = 1e5;
+    const bool have_stamps = prof_read_stamps(n, stamps, ticks_per_ms);
     for (int i = 0; i < n; i++) {
         prof_record& r = g_prof_pool[i];
-        if (hipEventSynchronize(r.stop) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_collect_records: event sync failed");
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) ms = 0.f;
+        if (r.stamped) {
+            if (have_stamps && stamps[2 * i + 1] > stamps[2 * i]) ms = (float)((double)(stamps[2 * i + 1] - stamps[2 * i]) / ticks_per_ms);
+        } else {
+            if (hipEventSynchronize(r.stop) != hipSuccess) return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_collect_records: event sync failed");
+            if (hipEventElapsedTime(&ms, r.start, r.stop) != hipSuccess) ms = 0.f;
+        }
         if (i < max_records) out[i] = sgv_prof_record{r.family, r.variant, ms, 0.f, r.bytes, r.flops};
     }
     g_prof_next = 0;
@@ -145,6 +191,19 @@ __global__ __launch_bounds__(256) void sgv_amax_reduce_kernel(unsigned* sink) {
     if ((threadIdx.x & 63) == 0 && m) atomicMax(sink, m);
 }
 
+// Timing a launch INSIDE a captured graph.  An ordinary hipEventRecord during stream capture leaves no node whose time can be read back, and the external
+// event-record form (hipEventRecordWithFlags(..., hipEventRecordExternal): works under the ROCm 7.2 runtime, tools/graph_event_lab.hip) is refused with "invalid
+// argument" by the HIP 7.0 runtime that PyTorch 2.10 bundles and this library shares a process with (profiles/r05_c13_graph_event_repro.log).  So a launch that
+// is recorded while its stream is being captured is bracketed by two one-thread KERNELS that store the device's constant-rate clock (wall_clock64, 100 MHz):
+// ordinary kernel nodes, replayed with the graph in stream order; the difference of a pair read after a replay is the launch's duration inside that replay plus the
+// dispatch gap in front of it (~1-2 us against launches of 30-2,000 us).  bench.py: the roofline objects of the captured headline step.
+__global__ void sgv_stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
+
+static bool prof_capturing(hipStream_t stream) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
+}
+
 sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count) : slot(-1), stream(s), amax_sink(g_amax_sink), amax_taken(nullptr) {
     g_amax_sink = nullptr;
     if (count) g_launches.fetch_add(1, std::memory_order_relaxed);
@@ -158,11 +217,17 @@ sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, doub
     r.flops = flops;
     slot = i;
     g_scope_slot = i;
-    (void)hipEventRecord(r.start, stream);
+    r.stamped = g_stamps != nullptr && prof_capturing(stream);
+    if (r.stamped) hipLaunchKernelGGL(sgv_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * (size_t)i);
+    else (void)hipEventRecord(r.start, stream);
 }
 
 sgv_launch_scope::~sgv_launch_scope() {
-    if (slot >= 0) { (void)hipEventRecord(g_prof_pool[slot].stop, stream); g_scope_slot = -1; }
+    if (slot >= 0) {
+        if (g_prof_pool[slot].stamped) hipLaunchKernelGGL(sgv_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * (size_t)slot + 1);
+        else (void)hipEventRecord(g_prof_pool[slot].stop, stream);
+        g_scope_slot = -1;
+    }
     // the one-workgroup fold of the partial maxima: behind the producer on its stream, outside the call's event bracket (the bracket times the op's own
     // kernel for the roofline tables; the fold is ~3 us of a single workgroup)
     if (amax_taken) hipLaunchKernelGGL(sgv_amax_reduce_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)amax_taken);

@@ -313,6 +313,7 @@ ABI_SYMBOLS = {
     'sgv_multi_scale_f32': (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_float), c_int32, c_void_p]),
     'sgv_prof_enable': (c_int, [c_int32]),
     'sgv_prof_disable': (c_int, []),
+    'sgv_prof_resume': (c_int, []),
     'sgv_prof_families': (c_int, [ctypes.c_uint64]),
     'sgv_prof_collect': (c_int, [ctypes.POINTER(ProfEntry)]),
     'sgv_prof_collect_records': (c_int, [ctypes.POINTER(ProfRecord), c_int32]),
@@ -391,6 +392,11 @@ def prof_enable(max_records=1 << 16):
 
 def prof_disable():
     check(get_native().sgv_prof_disable())
+
+
+def prof_resume():
+    """Record again without starting a new pool (see sgv_prof_resume: launches bracketed during a stream capture become re-recorded event nodes of the graph)."""
+    check(get_native().sgv_prof_resume())
 
 
 def prof_families(names=None):

@@ -33,12 +33,16 @@ class _HipGraph:
     def __init__(self, pool=None):
         self.graph, self._pool = torch.cuda.CUDAGraph(), pool
 
+    capture_hook = None      # optional context-manager factory entered around every capture (bench.py: per-launch event nodes for the kernels it times)
+
     def capture(self, fn):
         # thread_local: the RCCL watchdog thread of an initialised process group queries events while this thread captures, which the
         # default (global) capture mode treats as an error in the OTHER thread (observed: segmentation fault in capture_end)
         kw = dict(pool=self._pool) if self._pool is not None else {}
         from ..torch_utils.ops import amax as _amax      # (the magnitude-bound slots of the capture come from arenas the graph itself clears: ops/amax.py)
-        with _amax.capture_scope(), torch.cuda.graph(self.graph, capture_error_mode='thread_local', **kw):
+        import contextlib
+        hook = _HipGraph.capture_hook() if _HipGraph.capture_hook is not None else contextlib.nullcontext()
+        with _amax.capture_scope(), torch.cuda.graph(self.graph, capture_error_mode='thread_local', **kw), hook:
             return fn()
 
     def pool(self):
