@@ -188,6 +188,9 @@ TIMED_FAMILIES = ('conv3x3_s1', 'upfirdn2d_lanes')      # kernel families whose 
 PMC_FILES = ['r05_pmc_bench_step_FETCH_WRITE.json']   # collected by tools/gpu_recipes/pmc_fetch_write_passes.sh (separate --pmc passes of this command)
 
 
+PMC_NOT_THIS_WORKLOAD = None      # set when the run is not the workload the committed counter passes were collected on
+
+
 def pmc_traffic(prefixes, dword_read_prefixes=(), files=None):
     """HBM-side (L2 miss) bytes per launch of a kernel family from the newest committed rocprofv3 PMC summary
     (tools/pmc_summary.py over separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command: bench.py cannot
@@ -196,6 +199,8 @@ def pmc_traffic(prefixes, dword_read_prefixes=(), files=None):
     profiles/r01_pmc_headline_call_FETCH_WRITE.json); kernels reading with dword loads are taken as is; WRITE_SIZE is exact.
     Returns (bytes per launch or None, description of the source incl. the commit the counters were collected on)."""
     from stylegan_v_amd.torch_utils import custom_ops
+    if PMC_NOT_THIS_WORKLOAD and files is None:
+        return None, PMC_NOT_THIS_WORKLOAD
     stale = None
     for fname in (files or PMC_FILES):
         path = os.path.join(ROOT, 'profiles', fname)
@@ -479,6 +484,9 @@ def main():
     stylegan_v_amd.configure_miopen(immediate=os.environ.get('SGV_MIOPEN_FIND', '0') != '1')
     if args.workload != 'train256':
         return synthesis_workload(args, world, rank, device)
+    global PMC_NOT_THIS_WORKLOAD
+    if (args.batch_gpu, args.frames, args.res, args.lowp, args.aug) != (32, 3, 256, 'none', 'noaug'):
+        PMC_NOT_THIS_WORKLOAD = 'the committed counter passes are of the default workload (32 videos x 3 frames at 256^2, fp32, noaug): bytes per launch of another workload are not this run\'s'
     global_batch = args.batch_gpu * world
     lowp = {'none': None, 'fp16': torch.float16, 'bf16': torch.bfloat16}[args.lowp]
     g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=(lowp is None),
@@ -529,7 +537,18 @@ def main():
     for i in range(args.warmup):
         tw = time.perf_counter()
         if captured_headline and i == 1 and args.warmup >= 3:
-            capture_timed_set()      # warm-up iteration 0 captured the clean set; this one IS iteration 1; 2 .. W-1 replay the clean set with the eager R1 phases in between
+            try:
+                capture_timed_set()      # warm-up iteration 0 captured the clean set; this one IS iteration 1; 2 .. W-1 replay the clean set with the eager R1 phases in between
+            except torch.cuda.OutOfMemoryError:
+                # a second set of private pools (~63 GiB at 32 videos) did not fit next to the first: the headline stays the captured step, the roofline objects
+                # fall back to the eager pass behind the timed region (said in their note)
+                log('[bench] no memory for the timed graph set: per-launch durations come from the eager pass behind the timed region')
+                _tsmod._HipGraph.capture_hook = None
+                del ts
+                torch.cuda.empty_cache()
+                ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=True, augment=args.aug)
+                ts.step()
+                timed_graphs = False
         else:
             ts.step()
         torch.cuda.synchronize()
@@ -587,7 +606,7 @@ def main():
         if not args.no_prof and not captured_headline and i_step == prof_from:
             custom_ops.prof_families(TIMED_FAMILIES)      # inside the timed region: the dominant kernel and the FIR family only (all 554 launches per iteration: 1.4 % of the step)
             custom_ops.prof_enable(1 << 17)
-        if timed_graphs is not None and i_step == args.steps - 1 and not os.environ.get('SGV_BENCH_NO_SWAP'):
+        if timed_graphs and i_step == args.steps - 1:
             ts._graphs = timed_graphs          # the last iteration of the region carries the per-launch timing
         for name in ts.step():
             phases_run[name] = phases_run.get(name, 0) + 1
