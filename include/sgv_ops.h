@@ -539,7 +539,7 @@ typedef struct sgv_prof_entry {
     double flops; /* algorithmic flops (GEMM), else 0 */
 } sgv_prof_entry;
 
-int sgv_prof_enable(int32_t max_records); /* allocates the event pool (host side only) */
+int sgv_prof_enable(int32_t max_records); /* starts a new record list; grows the event pool and the device table of timestamp pairs (16 bytes per record) when needed */
 int sgv_prof_disable(void);
 /* Records again WITHOUT resetting the pool (sgv_prof_enable starts a new one).  A launch bracketed while its stream is being CAPTURED is timed by two one-thread
  * kernels that store the device's constant-rate clock -- nodes of the graph like the launch itself: every replay rewrites the pair, and the collect calls then

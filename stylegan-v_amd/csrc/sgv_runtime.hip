@@ -70,9 +70,13 @@ extern "C" int sgv_prof_enable(int32_t max_records) {
         g_prof_pool.push_back(r);
     }
     if (g_stamps_cap < g_prof_pool.size()) {
-        if (g_stamps) (void)hipFree(g_stamps);
-        g_stamps = nullptr;
-        if (hipMalloc((void**)&g_stamps, g_prof_pool.size() * 2 * sizeof(unsigned long long)) != hipSuccess) { g_stamps_cap = 0; return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_enable: hipMalloc failed"); }
+        // A table that captured graphs may still write to is never freed: a replay of a graph captured before the pool grew stores into the RETIRED table (16 bytes per
+        // record, kept for the life of the process) -- its durations are no longer collected, nothing is corrupted.
+        unsigned long long* fresh = nullptr;
+        const size_t bytes = g_prof_pool.size() * 2 * sizeof(unsigned long long);
+        if (hipMalloc((void**)&fresh, bytes) != hipSuccess || hipMemset(fresh, 0, bytes) != hipSuccess)
+            return sgv_fail(SGV_ERR_LAUNCH, "sgv_prof_enable: no device memory for the timestamp table");
+        g_stamps = fresh;       // (zeroed: a pair that no replay has written yet reads as "no duration")
         g_stamps_cap = g_prof_pool.size();
     }
     g_prof_next = 0;
