@@ -184,7 +184,8 @@ def emit(out):
     print(compact_line(out, written), flush=True)
 
 
-TIMED_FAMILIES = ('conv3x3_s1', 'upfirdn2d_lanes')      # kernel families whose launches are bracketed by HIP events inside the timed region
+TIMED_FAMILIES = ('conv3x3_s1', 'upfirdn2d_lanes')      # kernel families whose launches are bracketed by HIP events inside the timed region (eager headline)
+CAPTURED_FAMILIES = ('conv3x3_s1',)                     # captured headline: the family whose kernel writes its own timestamps inside the replayed graphs
 PMC_FILES = ['r05_pmc_bench_step_FETCH_WRITE.json']   # collected by tools/gpu_recipes/pmc_fetch_write_passes.sh (separate --pmc passes of this command)
 
 
@@ -492,17 +493,21 @@ def main():
     g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=args.res, batch_size=global_batch, num_gpus=world, fp32=(lowp is None),
                                                       num_frames_per_video=args.frames, lowp_dtype=lowp)
     # One GPU: the headline step is the CAPTURED one: Gmain / Dmain replayed as hipGraphs, the reg phases eager at their schedule --
-    # the same work, without the dispatch latency between ~2,000 dependent launches per iteration that costs the eager step ~9 of 158 ms.  The kernels the roofline
-    # objects are about are bracketed INSIDE the graphs (sgv_prof_resume around every capture: csrc/sgv_runtime.hip), so their durations are read
-    # live from the last replayed iteration of the timed region (device-clock timestamp kernels: the HIP runtime torch bundles refuses event records that can be
-    # read back from a capture).  Several GPUs (DDP's reducer cannot be captured) or --eager: the eager step with HIP events, as in rounds 1-4.
+    # the same work, without the dispatch latency between ~2,000 dependent launches per iteration (and at the clocks the chip reaches when those gaps are gone).  The
+    # roofline object needs the dominant kernel's per-launch duration from INSIDE the timed region, and a replay launches nothing from the host: the stride-1
+    # convolution writes its own timestamp pair when it is recorded during a capture (sgv_launch_scope::kernel_stamps, conv_ws_params::stamp: workgroup 0 stores the
+    # 100-MHz device clock as it starts, the consumer waves atomicMax it as they leave) -- no node is added to the graph, no gap opened, so EVERY replay carries the
+    # timing and the durations of the last iteration are read after the region.  (Round 5 first bracketed the launches with one-thread timestamp kernels: those gaps
+    # alone put the chip into its slow clock state for the iteration that carried them, profiles/r05_final3: 153 ms against 142.)  The upfirdn2d family's in-region
+    # sample, the per-variant tables and `value_eager` come from the eager step behind the region.  Several GPUs (DDP's reducer cannot be captured) or --eager: the
+    # eager step with HIP events, as in rounds 1-4.
     captured_headline = world == 1 and not args.eager and not args.graphs and not args.no_prof
     if captured_headline:
         import contextlib
         from stylegan_v_amd.training import train_step as _tsmod
-        custom_ops.prof_families(TIMED_FAMILIES)
-        custom_ops.prof_enable(1 << 15)      # allocates the event pool and starts a new record list ...
-        custom_ops.prof_disable()            # ... which only the captures below append to
+        custom_ops.prof_families(CAPTURED_FAMILIES)
+        custom_ops.prof_enable(1 << 15)      # allocates the pools and starts a new record list ...
+        custom_ops.prof_disable()            # ... which only the captures append to
 
         @contextlib.contextmanager
         def _capture_events():
@@ -511,6 +516,7 @@ def main():
                 yield
             finally:
                 custom_ops.prof_disable()
+        _tsmod._HipGraph.capture_hook = _capture_events
     ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=args.graphs or captured_headline, augment=args.aug)
 
     def barrier():
@@ -518,48 +524,21 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    timed_graphs = None
-
-    def capture_timed_set():
-        """A SECOND set of graphs of the same step with the timing kernels inside (two one-thread timestamp kernels around each of the ~120 launches the roofline
-        objects are about).  The timed region replays the clean set and only its LAST iteration this one: the sample is taken live, inside the region, and whatever
-        the stamps cost a replay is paid once in K iterations."""
-        nonlocal timed_graphs
-        clean_graphs, ts._graphs = ts._graphs, {}
-        _tsmod._HipGraph.capture_hook = _capture_events
-        ts.batch_idx = 1             # (no regularisation phase in this iteration)
-        ts.step()                    # eager warm-up on the side with the training state put back, the captures, one replay of each
-        torch.cuda.synchronize()
-        _tsmod._HipGraph.capture_hook = None
-        timed_graphs, ts._graphs = ts._graphs, clean_graphs
-        ts.batch_idx = 0             # the next warm-up iteration runs all four phases behind BOTH captures (call 17: the first R1 iteration after a capture pays 0.5-0.8 s once)
-
     for i in range(args.warmup):
         tw = time.perf_counter()
-        if captured_headline and i == 1 and args.warmup >= 3:
-            try:
-                capture_timed_set()      # warm-up iteration 0 captured the clean set; this one IS iteration 1; 2 .. W-1 replay the clean set with the eager R1 phases in between
-            except torch.cuda.OutOfMemoryError:
-                # a second set of private pools (~63 GiB at 32 videos) did not fit next to the first: the headline stays the captured step, the roofline objects
-                # fall back to the eager pass behind the timed region (said in their note)
-                log('[bench] no memory for the timed graph set: per-launch durations come from the eager pass behind the timed region')
-                _tsmod._HipGraph.capture_hook = None
-                del ts
-                torch.cuda.empty_cache()
-                ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=True, augment=args.aug)
-                ts.step()
-                timed_graphs = False
-        else:
-            ts.step()
+        ts.step()
         torch.cuda.synchronize()
         if rank == 0:
             log(f'[bench] warm-up iteration {i}: {time.perf_counter() - tw:.2f} s (includes MIOpen kernel compilation on a cold cache)')
-    if captured_headline and timed_graphs is None:      # a warm-up too short to hold the second capture: two more untimed iterations
-        if not ts._graphs:
+    if captured_headline:
+        if not ts._graphs:      # --warmup 0: the captures must not fall into the timed region
             ts.step()
-        capture_timed_set()
-        ts.step()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+        _tsmod._HipGraph.capture_hook = None
+        if args.warmup < 2:     # the first R1 iteration behind a capture pays 0.5-0.8 s once (profiles/r05_c17b_captured_steps.log): not inside the region
+            ts.batch_idx = 0
+            ts.step()
+            torch.cuda.synchronize()
     # Start the timed window on an iteration that runs the regularisation phases, whatever the warm-up was.
     ts.batch_idx = 0
     launches0 = custom_ops.launch_count()
@@ -606,8 +585,6 @@ def main():
         if not args.no_prof and not captured_headline and i_step == prof_from:
             custom_ops.prof_families(TIMED_FAMILIES)      # inside the timed region: the dominant kernel and the FIR family only (all 554 launches per iteration: 1.4 % of the step)
             custom_ops.prof_enable(1 << 17)
-        if timed_graphs and i_step == args.steps - 1:
-            ts._graphs = timed_graphs          # the last iteration of the region carries the per-launch timing
         for name in ts.step():
             phases_run[name] = phases_run.get(name, 0) + 1
         step_marks[i_step + 1].record()
@@ -713,7 +690,9 @@ def main():
         for _ in range(args.steps - prof_from):
             ts.step()
         barrier()
-        prof, by_variant, _ = collect_tables()
+        prof, by_variant, ufd_eager = collect_tables()
+        if captured_headline:
+            ufd_by_size = ufd_eager      # (no upfirdn2d launch is timed inside the replayed graphs)
         for fam in (() if captured_headline else TIMED_FAMILIES):      # the two families of the timed region keep their in-region figures in the family table
             if prof_timed[fam]['launches'] and prof_timed[fam]['ms'] > 0:   # (captured headline: the tables stay the eager step's, the roofline objects take the in-graph sample)
                 for key in ('launches', 'ms', 'bytes', 'flops'):
@@ -916,8 +895,10 @@ def main():
             del ts3
             torch.cuda.empty_cache()
 
-    sample_note = (f'the launches of the LAST iteration of the timed steps (step {args.steps - 1}: Gmain + Dmain replayed from graphs that carry a device-clock timestamp kernel either side of each of these launches, sgv_prof_resume)'
-                   if captured_headline else f'all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1})')
+    eager_note = (f'the eager step behind the timed region (HIP events around every launch of a pass of its own)' if captured_headline
+                  else f'all launches inside the second half of the timed steps (steps {args.steps // 2}..{args.steps - 1})')
+    sample_note = (f'the launches of the LAST iteration of the timed steps (step {args.steps - 1}: Gmain + Dmain replayed from hipGraphs; the kernel writes its own start / end in the 100-MHz device clock, '
+                   f'conv_ws_params::stamp -- no node added to the graphs)' if captured_headline else eager_note)
     F32_LABEL = 'f32' if default_terms == (0, 0) else \
         ('f32 (fp32 tensors + accumulators; products = block-scaled 2-way fp16 split on MFMA: 22-bit operands, 2.7e-7 vs fp64 = vendor-fp32 class)' if default_terms == (4, 4) else
          'fp32 tensors + accumulators; products = 2-way bf16 split (16-bit operands, 4.4e-6 vs fp64: NOT fp32-grade)')
@@ -937,15 +918,18 @@ def main():
                 if e['flops'] > 0:
                     k['TFLOPs'] = e['flops'] / (e['ms'] * 1e-3) / 1e12
                 kernels[name] = k
-            in_region = prof_timed if (captured_headline and prof_timed is not None and prof_timed['conv3x3_s1']['ms'] > 0) else prof     # what the roofline objects are computed from
-            r = in_region['upfirdn2d_lanes']
+            live = captured_headline and prof_timed is not None and prof_timed['conv3x3_s1']['ms'] > 0
+            in_region = prof_timed if live else prof     # what the `roofline` object is computed from
+            if not live:
+                sample_note = eager_note
+            r = prof['upfirdn2d_lanes'] if captured_headline else in_region['upfirdn2d_lanes']      # (captured headline: no timestamps inside this family's kernels -> the eager pass)
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
                 roofline_ufd = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
                                     frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch()[0], launches=r['launches'],
                                     traffic_source=pmc_traffic_per_launch()[1] + ' (reads x2, gfx950 correction)',
                                     avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
-                                    note=sample_note + ' (every layer size, fwd+bwd), size-weighted')
+                                    note=(eager_note if captured_headline else sample_note) + ' (every layer size, fwd+bwd), size-weighted')
             # The contract's `roofline` is the step's dominant hand-written kernel (largest summed HIP-event time): the stride-1 producer / consumer
             # 3x3 kernel, accounted on its own (SGV_K_CONV3X3_S1); `roofline_conv_family` keeps the figure of the whole 3x3 family that earlier rounds'
             # lines reported under `roofline` (stride 1 + stride 2 + transposed + 16^2 / 8^2 + edge-strip members, flop-weighted).

@@ -243,7 +243,8 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     kp.grid = std::min(kp.tiles, g_cus);
     const double elems = (double)p->n * p->h * p->w;
     const double es = io16(dtype) ? 2.0 : 4.0;
-    sgv_launch_scope scope(small ? SGV_K_CONV3X3 : SGV_K_CONV3X3_S1, stream, es * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9);
+    sgv_launch_scope scope(small ? SGV_K_CONV3X3 : SGV_K_CONV3X3_S1, stream, es * elems * (p->c_in + p->c_out) + 4.0 * p->c_in * p->c_out * 9, 2.0 * elems * p->c_in * (double)p->c_out * 9,
+                           true, /* own_stamps: conv3x3_ws_kernel writes its own timestamp pair when it is timed inside a capture */ !small);
     if (small) {
         if (kp.ksplit > 1 && hipMemsetAsync(p->y, 0, (size_t)p->n * p->c_out * p->h * p->w * sizeof(float), stream) != hipSuccess)
             return sgv_fail(SGV_ERR_LAUNCH, "conv3x3: clearing y for the split-K small-image kernel failed");
@@ -266,6 +267,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
     if (ep || g_use_ws || io16(dtype) || p->c_out % TM != 0 || p->terms == 4) {     // (half-full m tiles, the block-scaled split: the producer / consumer kernel only)
         conv_ws_params wp{};
         wp.c = kp;
+        wp.stamp = scope.kernel_stamps();
         int pro = 0, epi = 0;
         if (ep) {
             wp.xscale = ep->x_scale; wp.oscale = ep->out_scale; wp.bias = ep->bias;
@@ -287,6 +289,7 @@ int conv3x3_impl(const sgv_conv3x3_params* p, const sgv_conv3x3_epilogue* ep, in
         if (p->c_out % TM != 0) sgv_note_variant(SGV_V_conv_s1_half_tile);     // (the last 64-row tile is half full: the 32-channel layers at 1024^2)
         return sgv_check_launch("conv3x3_ws_kernel");
     }
+    scope.begin_stamp();      // (the four-wave kernel has no timestamp output: bracketed like every other launch)
     if (p->terms == 1) hipLaunchKernelGGL(conv3x3_kernel<1>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     else hipLaunchKernelGGL(conv3x3_kernel<3>, dim3((unsigned)kp.grid), dim3(256), LDS_BYTES, stream, kp);
     sgv_note_variant(SGV_V_conv_s1_4wave);

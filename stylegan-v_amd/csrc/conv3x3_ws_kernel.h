@@ -41,6 +41,8 @@ struct conv_ws_params {
     float alpha, gain, clamp;   // clamp < 0: none
     int accumulate;        // y += result (one no-return fp32 atomic per element) instead of y = result
     float* y_amax;         // fp32 tensors: max |stored value| as a by-product (sgv_amax_sink; with `accumulate`: of the INCREMENT), or NULL
+    unsigned long long* stamp;   // NULL, or {start, end} in the 100-MHz device clock, written by the kernel itself (sgv_launch_scope::kernel_stamps: per-launch timing inside a
+                                 // replayed hipGraph without bracketing kernels): start = workgroup 0 as it begins, end = atomicMax over the consumer waves as they leave
 };
 
 // PRO: 0 plain x, 1 x * xscale[n,k].
@@ -93,6 +95,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
     const int total = my_tiles * chunks;
 
     if (wave == 7) {
+        if (pp.stamp && blockIdx.x == 0 && lane == 0) *pp.stamp = wall_clock64();     // (this wave only ever waits for vmcnt(0))
         // =========================================== weight DMA wave ===========================================
         // The 36-KiB weight block of (tile, chunk) q is copied verbatim: 36 wave-instructions of 64 lanes x 16 B to a wave-uniform LDS base.
         // A wave of its own, so that the x waves' instruction stream contains no LDS-DMA (hipcc drains vmcnt to 0 at every use of an
@@ -463,6 +466,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_ws_kernel(conv_ws_params pp) {
         asm volatile("" ::: "memory");
     }
     if (IO == 0 && pp.y_amax) sgv_amax_commit(amx, pp.y_amax);     // (the four consumer waves; whole waves)
+    if (pp.stamp) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // the tile's stores have left
+        if (lane == 0) atomicMax(pp.stamp + 1, (unsigned long long)wall_clock64());      // the clock never runs backwards: no reset between replays
+    }
 }
 
 }  // namespace sgv_conv

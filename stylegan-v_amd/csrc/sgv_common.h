@@ -68,9 +68,16 @@ struct sgv_launch_scope {
     // Brackets one kernel launch: bumps the launch counter and, when profiling is enabled,
     // records a start/stop HIP event pair on `stream`.
     // `count` = false: a helper pass that is timed but not counted by sgv_launch_count (the tests pin launch counts of the ops themselves).
-    sgv_launch_scope(int family, hipStream_t stream, double bytes, double flops = 0.0, bool count = true);
+    // `own_stamps` = true: the launcher's kernel can write the record's timestamp pair ITSELF (first workgroup: start; every workgroup's last wave: atomicMax of
+    // the end).  When the launch is being captured with profiling on, the scope then adds no timestamp kernels around it -- no idle gap, nothing for the chip's power
+    // management to react to -- and the launcher passes kernel_stamps() to its kernel; a launcher that ends up on a kernel without that support calls begin_stamp()
+    // before its launch instead (the ordinary bracket).
+    sgv_launch_scope(int family, hipStream_t stream, double bytes, double flops = 0.0, bool count = true, bool own_stamps = false);
     ~sgv_launch_scope();
+    unsigned long long* kernel_stamps();     // device pointer to {start, end} of this record for the kernel to fill, or NULL (not capturing / not recording)
+    void begin_stamp();                      // own_stamps scopes only: fall back to the bracketing timestamp kernel
     int slot;
+    int stamp_mode;     // 0 events / nothing, 1 bracketing timestamp kernels, 2 deferred (own_stamps, undecided), 3 the kernel writes the pair
     hipStream_t stream;
     // The one-shot magnitude-bound side output armed by sgv_amax_sink() for THIS call (moved out of the thread's slot by the constructor, so that a call
     // that cannot serve it leaves it unserved instead of handing it to a later one).  A launcher that supports it calls take_amax_sink(): the pointer

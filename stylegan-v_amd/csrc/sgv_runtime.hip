@@ -208,7 +208,8 @@ static bool prof_capturing(hipStream_t stream) {
     return hipStreamIsCapturing(stream, &st) == hipSuccess && st == hipStreamCaptureStatusActive;
 }
 
-sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count) : slot(-1), stream(s), amax_sink(g_amax_sink), amax_taken(nullptr) {
+sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, double flops, bool count, bool own_stamps)
+    : slot(-1), stamp_mode(0), stream(s), amax_sink(g_amax_sink), amax_taken(nullptr) {
     g_amax_sink = nullptr;
     if (count) g_launches.fetch_add(1, std::memory_order_relaxed);
     if (!g_prof_on.load(std::memory_order_relaxed) || !((g_prof_mask.load(std::memory_order_relaxed) >> family) & 1ull)) return;
@@ -222,14 +223,29 @@ sgv_launch_scope::sgv_launch_scope(int family, hipStream_t s, double bytes, doub
     slot = i;
     g_scope_slot = i;
     r.stamped = g_stamps != nullptr && prof_capturing(stream);
-    if (r.stamped) hipLaunchKernelGGL(sgv_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * (size_t)i);
-    else (void)hipEventRecord(r.start, stream);
+    if (r.stamped) {
+        if (own_stamps) stamp_mode = 2;
+        else { stamp_mode = 1; hipLaunchKernelGGL(sgv_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * (size_t)i); }
+    } else (void)hipEventRecord(r.start, stream);
+}
+
+unsigned long long* sgv_launch_scope::kernel_stamps() {
+    if (slot < 0 || stamp_mode != 2) return nullptr;
+    stamp_mode = 3;
+    return g_stamps + 2 * (size_t)slot;
+}
+
+void sgv_launch_scope::begin_stamp() {
+    if (slot < 0 || stamp_mode != 2) return;
+    stamp_mode = 1;
+    hipLaunchKernelGGL(sgv_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * (size_t)slot);
 }
 
 sgv_launch_scope::~sgv_launch_scope() {
     if (slot >= 0) {
-        if (g_prof_pool[slot].stamped) hipLaunchKernelGGL(sgv_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * (size_t)slot + 1);
-        else (void)hipEventRecord(g_prof_pool[slot].stop, stream);
+        if (stamp_mode == 1) hipLaunchKernelGGL(sgv_stamp_kernel, dim3(1), dim3(1), 0, stream, g_stamps + 2 * (size_t)slot + 1);
+        else if (stamp_mode == 0 && !g_prof_pool[slot].stamped) (void)hipEventRecord(g_prof_pool[slot].stop, stream);
+        // (mode 3: the kernel writes both; mode 2 left undecided: the pair stays as it was -- zero or stale -- and the record reads as "no duration")
         g_scope_slot = -1;
     }
     // the one-workgroup fold of the partial maxima: behind the producer on its stream, outside the call's event bracket (the bracket times the op's own

@@ -444,6 +444,69 @@ def test_train_step_hipgraph_replay_matches_eager_schedule():
         assert torch.isfinite(ts.last_losses[k])
 
 
+def test_per_launch_timing_inside_a_replayed_graph():
+    """ABI 1.03: launches recorded while their stream is being captured are timed INSIDE the graph -- the stride-1 convolution writes its own timestamp pair
+    (sgv_launch_scope::kernel_stamps: no node added), every other family is bracketed by two one-thread timestamp kernels -- and the collect calls return the
+    durations of the LAST replay.  The durations must be positive and of the size HIP events give for the same launches outside a graph, and the captured results must equal the eager ones."""
+    import contextlib
+    from stylegan_v_amd.torch_utils.ops import conv2d_gradfix, upfirdn2d
+    from stylegan_v_amd.training import train_step as tsmod
+    torch.manual_seed(3)
+    x = torch.randn(16, 128, 64, 64, device='cuda')
+    w = torch.randn(128, 128, 3, 3, device='cuda') * 0.05
+    f = upfirdn2d.setup_filter([1, 3, 3, 1], device='cuda')
+
+    def work():
+        with torch.no_grad():
+            return conv2d_gradfix.conv2d(x, w, padding=1), upfirdn2d.filter2d(x, f)
+
+    want = work()
+    torch.cuda.synchronize()
+    # the same launches with HIP events (eager)
+    custom_ops.prof_families(None)
+    custom_ops.prof_enable(512)
+    work()
+    custom_ops.prof_disable()
+    torch.cuda.synchronize()
+    eager = {}
+    for fam, ms, _, _ in custom_ops.prof_collect_records(512):
+        eager[fam] = eager.get(fam, 0.0) + ms
+    assert eager.get('conv3x3_s1', 0) > 0 and eager.get('upfirdn2d_lanes', 0) > 0, eager
+
+    @contextlib.contextmanager
+    def hook():
+        custom_ops.prof_resume()
+        try:
+            yield
+        finally:
+            custom_ops.prof_disable()
+
+    custom_ops.prof_enable(512)
+    custom_ops.prof_disable()
+    graph = tsmod._HipGraph()
+    tsmod._HipGraph.capture_hook = hook
+    try:
+        n0 = custom_ops.launch_count()
+        got = graph.capture(work)
+    finally:
+        tsmod._HipGraph.capture_hook = None
+    assert custom_ops.launch_count() > n0
+    graph.replay()
+    graph.replay()
+    torch.cuda.synchronize()
+    recs = custom_ops.prof_collect_records(512)
+    assert len(recs) >= 2, recs
+    first = {}
+    for fam, ms, _, _ in recs:
+        first[fam] = first.get(fam, 0.0) + ms
+    for fam in ('conv3x3_s1', 'upfirdn2d_lanes'):
+        assert first.get(fam, 0) > 0, (fam, first)
+        assert 0.5 * eager[fam] < first[fam] < 2.0 * eager[fam] + 0.05, (fam, first[fam], eager[fam])     # same launch, same order of magnitude (events carry ~10 us of their own)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+    custom_ops.prof_families(None)
+
+
 def _small_train_step(**kw):
     from stylegan_v_amd.training import config as cfgs
     from stylegan_v_amd.training.train_step import TrainStep
