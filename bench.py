@@ -497,8 +497,8 @@ def main():
     # roofline object needs the dominant kernel's per-launch duration from INSIDE the timed region, and a replay launches nothing from the host: the stride-1
     # convolution writes its own timestamp pair when it is recorded during a capture (sgv_launch_scope::kernel_stamps, conv_ws_params::stamp: workgroup 0 stores the
     # 100-MHz device clock as it starts, the consumer waves atomicMax it as they leave) -- no node is added to the graph, no gap opened, so EVERY replay carries the
-    # timing and the durations of the last iteration are read after the region.  (Round 5 first bracketed the launches with one-thread timestamp kernels: those gaps
-    # alone put the chip into its slow clock state for the iteration that carried them, profiles/r05_final3: 153 ms against 142.)  The upfirdn2d family's in-region
+    # timing and the durations of the last iteration are read after the region.  (Round 5 first bracketed the launches with one-thread timestamp kernels in a second graph set that only the last iteration replayed: 2-4 ms
+    # of their own, and an odd iteration that ran in another clock state than its neighbours in three of four records.)  The upfirdn2d family's in-region
     # sample, the per-variant tables and `value_eager` come from the eager step behind the region.  Several GPUs (DDP's reducer cannot be captured) or --eager: the
     # eager step with HIP events, as in rounds 1-4.
     captured_headline = world == 1 and not args.eager and not args.graphs and not args.no_prof
