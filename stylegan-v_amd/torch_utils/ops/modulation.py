@@ -43,15 +43,27 @@ class _DemodCoefsFn(torch.autograd.Function):
             custom_ops.check(lib.sgv_weight_sqsum(w.data_ptr(), q.data_ptr(), oc, ic, kh * kw, _stream(w)), lib)
             custom_ops.check(lib.sgv_demod_coefs(s.data_ptr(), q.data_ptr(), d.data_ptr(), n, oc, ic, float(eps), _stream(w)), lib)
         ctx.eps = eps
-        ctx.save_for_backward(weight, styles)
+        ctx.save_for_backward(weight, styles, q, d)
         return d
 
     @staticmethod
     def backward(ctx, grad_d):
-        weight, styles = ctx.saved_tensors
-        # Everything below is rebuilt from the INPUTS with differentiable tensor ops (q and d are [O,I] / [N,O]: negligible work),
-        # so that a create_graph pass (path-length regularisation differentiates G twice) sees the dependence of both gradients
-        # on weight and styles.  Saved intermediates would come back as constants and silently drop those terms.
+        weight, styles, q0, d0 = ctx.saved_tensors
+        if not torch.is_grad_enabled():
+            # First-order pass (every backward of the FFS / SkyTimelapse configurations: pl_weight = 0): nothing will differentiate these gradients, so q and d come
+            # from the forward pass and the chain below is 8 launches instead of 17 on [N, O] / [O, I]-sized tensors (12 demodulated layers per generator
+            # backward: ~100 launches per iteration, profiles/r05_c30_small_launch_sources.txt).  Same formulas: g = -1/2 grad_d d^3, grad_w = 2 W (g^T s^2),
+            # grad_s = 2 s (g q); the factor 2 * (-1/2) is applied once, to g.
+            g = (grad_d * d0.pow(3)).neg_()                                  # [N, O] = 2 g
+            grad_w = grad_s = None
+            if ctx.needs_input_grad[0]:
+                grad_w = weight * (g.t() @ styles.square())[:, :, None, None]
+            if ctx.needs_input_grad[1]:
+                grad_s = styles * (g @ q0)
+            return grad_w, grad_s, None
+        # create_graph pass (path-length regularisation differentiates G twice): everything is rebuilt from the INPUTS with differentiable tensor ops (q and d are
+        # [O,I] / [N,O]: negligible work), so that the second differentiation sees the dependence of both gradients on weight and styles.  Saved intermediates
+        # would come back as constants and silently drop those terms.
         q = weight.square().sum(dim=[2, 3])                              # [O, I]
         d = (styles.square() @ q.t() + ctx.eps).rsqrt()                  # [N, O]
         # d = (s^2 q^T + eps)^(-1/2)  =>  dd/d(s^2 q^T) = -d^3 / 2

@@ -35,10 +35,15 @@ class FullyConnectedLayer(torch.nn.Module):
         self.weight_gain = lr_multiplier / math.sqrt(in_features)
         self.bias_gain = lr_multiplier
 
-    def forward(self, x, normalize_input=False):
-        """``normalize_input``: apply normalize_2nd_moment to x first (the mapping network's first layer; one kernel with the layer)."""
+    def forward(self, x, normalize_input=False, gain=None):
+        """``normalize_input``: apply normalize_2nd_moment to x first (the mapping network's first layer; one kernel with the layer).
+        ``gain``: the layer's output times a constant (ToRGB's ``affine(w) * weight_gain``, networks.py:314) -- rides on the kernel's activation gain instead of
+        costing a launch here and another in the backward pass."""
         if x.ndim == 2:   # one kernel on the GPU (ops/fc.py -> csrc/fc.hip); the torch composition elsewhere
-            return fc.dense(x, self.weight, self.bias, weight_gain=self.weight_gain, bias_gain=self.bias_gain, act=self.activation, normalize=normalize_input)
+            act_gain = None if gain is None else float(bias_act.activation_funcs[self.activation].def_gain * gain)
+            return fc.dense(x, self.weight, self.bias, weight_gain=self.weight_gain, bias_gain=self.bias_gain, act=self.activation, normalize=normalize_input, act_gain=act_gain)
+        if gain is not None:
+            return self.forward(x, normalize_input=normalize_input) * gain
         if normalize_input:
             x = normalize_2nd_moment(x)
         w = self.weight.to(x.dtype) * self.weight_gain

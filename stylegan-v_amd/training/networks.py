@@ -156,7 +156,7 @@ class ToRGBLayer(torch.nn.Module):
         self.weight_gain = 1 / math.sqrt(in_channels * kernel_size ** 2)
 
     def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w) * self.weight_gain
+        styles = self.affine(w, gain=self.weight_gain)      # (networks.py:314: affine(w) * weight_gain; the factor rides on the dense kernel's output gain)
         oc, ic, kh, kw = self.weight.shape
         if kh == 1 and kw == 1 and oc <= 4 and pointwise.enabled and x.is_cuda and x.is_contiguous():
             # y[n,o] = sum_i x[n,i] * (W[o,i] * s[n,i]): the style goes into per-sample weights [N,3,I] and the whole layer is
