@@ -199,8 +199,14 @@ class SynthesisBlock(torch.nn.Module):
                                     channels_last=self.channels_last)
 
     def forward(self, x, img, ws, motion_v=None, force_fp32=False, fused_modconv=None, **layer_kwargs):
-        misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
-        w_iter = iter(ws.unbind(dim=1))
+        if isinstance(ws, (tuple, list)):
+            # the per-layer latents already split by the caller (SynthesisNetwork.forward unbinds `ws` ONCE: one stack in the backward pass instead of a
+            # cat + zero-fill + copy + add per block, 20 launches per generator backward)
+            assert len(ws) == self.num_conv + self.num_torgb
+            w_iter, ws = iter(ws), ws[0]
+        else:
+            misc.assert_shape(ws, [None, self.num_conv + self.num_torgb, self.w_dim])
+            w_iter = iter(ws.unbind(dim=1))
         dtype = self.lowp_dtype if self.use_fp16 and not force_fp32 else torch.float32
         fmt = torch.channels_last if self.channels_last and not force_fp32 else torch.contiguous_format
         if fused_modconv is None:  # reference policy (networks.py:230-232)
@@ -278,10 +284,11 @@ class SynthesisNetwork(torch.nn.Module):
 
         x = img = None
         w_idx = 0
+        all_w = ws.unbind(dim=1)
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
             # each ToRGB shares its w with the next block's conv0: advance by num_conv only (networks.py:354-357)
-            cur_ws = ws.narrow(1, w_idx, block.num_conv + block.num_torgb)
+            cur_ws = all_w[w_idx:w_idx + block.num_conv + block.num_torgb]
             w_idx += block.num_conv
             x, img = block(x, img, cur_ws, motion_v=motion_v if cond == 'concat_const' else None, **block_kwargs)
         return img
