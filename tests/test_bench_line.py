@@ -61,3 +61,12 @@ def test_emit_prints_the_compact_line_last_and_writes_the_side_file(bench, tmp_p
     assert json.loads(out[0])['detail'] == 'bench_detail.json'
     for path in (tmp_path / 'bench_detail.json', tmp_path / 'gpurun_out' / 'bench_detail.json'):
         assert 'kernels_by_variant' in json.loads(path.read_text())
+
+
+def test_power_sampler_is_silent_without_a_device():
+    """bench.PowerSampler reads the hwmon files of the HIP device's own card; on a box without one it must do nothing -- no exception, no samples."""
+    import bench
+    s = bench.PowerSampler(0, period=0.001)
+    with s:
+        pass
+    assert s.summary() is None
