@@ -147,24 +147,29 @@ template <> __device__ __forceinline__ float widen<sgv_half_t>(uint16_t b) { sgv
 template <> __device__ __forceinline__ float widen<sgv_bf16_t>(uint16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
 template <typename T> __device__ __forceinline__ uint16_t narrow(float v) { T t; sgv_traits<T>::store(&t, v); return t.bits; }
 
-// Load N contiguous elements starting at p (element-aligned only) into dst[0..N) as fp32.
-template <typename T, int N> struct row_loader {
+// Load N contiguous elements starting at p (element-aligned only) into dst[0..N) as fp32.  NTL: non-temporal requests (data nobody re-reads: the loads of a
+// streaming pass then leave the caches to the lines that ARE shared, and a plain float4 copy gains 7 % from them alone: profiles/r06_c1_ufd_lab6.log).
+template <typename V, bool NTL> __device__ __forceinline__ V load_vec(const void* p) {
+    if constexpr (NTL) return __builtin_nontemporal_load((const V*)p);
+    else return *(const V*)p;
+}
+template <typename T, int N, bool NTL = false> struct row_loader {
     static __device__ __forceinline__ void run(const T* p, float* dst) {
         if constexpr (N >= 8 && sizeof(T) == 2) {     // eight 16-bit elements: one 16-byte request per lane (the tile kernel's CPL = 8 form)
-            typename vec_of<T, 8>::type v = *(const typename vec_of<T, 8>::type*)p;
+            typename vec_of<T, 8>::type v = load_vec<typename vec_of<T, 8>::type, NTL>(p);
 #pragma unroll
             for (int i = 0; i < 8; i++) dst[i] = widen<T>(v[i]);
-            row_loader<T, N - 8>::run(p + 8, dst + 8);
+            row_loader<T, N - 8, NTL>::run(p + 8, dst + 8);
         } else if constexpr (N >= 4) {
-            typename vec_of<T, 4>::type v = *(const typename vec_of<T, 4>::type*)p;
+            typename vec_of<T, 4>::type v = load_vec<typename vec_of<T, 4>::type, NTL>(p);
             if constexpr (sizeof(T) == 4) { dst[0] = v[0]; dst[1] = v[1]; dst[2] = v[2]; dst[3] = v[3]; }
             else { dst[0] = widen<T>(v[0]); dst[1] = widen<T>(v[1]); dst[2] = widen<T>(v[2]); dst[3] = widen<T>(v[3]); }
-            row_loader<T, N - 4>::run(p + 4, dst + 4);
+            row_loader<T, N - 4, NTL>::run(p + 4, dst + 4);
         } else if constexpr (N >= 2) {
-            typename vec_of<T, 2>::type v = *(const typename vec_of<T, 2>::type*)p;
+            typename vec_of<T, 2>::type v = load_vec<typename vec_of<T, 2>::type, NTL>(p);
             if constexpr (sizeof(T) == 4) { dst[0] = v[0]; dst[1] = v[1]; }
             else { dst[0] = widen<T>(v[0]); dst[1] = widen<T>(v[1]); }
-            row_loader<T, N - 2>::run(p + 2, dst + 2);
+            row_loader<T, N - 2, NTL>::run(p + 2, dst + 2);
         } else if constexpr (N == 1) {
             dst[0] = sgv_traits<T>::load(p);
         }
@@ -736,6 +741,7 @@ struct tile_params {
     int lpr_log2;      // lanes per plane row = 1 << lpr_log2 (64: one plane per wave row, col_groups column groups of 256 outputs)
     int col_groups;
     int row_tiles;     // ceil(out_h / 16)
+    int xcd_blocks;    // workgroups [0, xcd_blocks) are dealt so that the row tiles of one (plane group, column group) stay on ONE XCD; a multiple of 8 * row_tiles
     int nt_store;
     const float* ep_scale;  // EPI 1: [planes] or NULL
     const float* ep_bias;   // EPI 1: [chans] or NULL
@@ -761,7 +767,21 @@ inline int tile_lds_floats(int lpr_log2, int cpl = 4) { return TILE_IN_ROWS * (6
 //     16-bit lane asks for 8 bytes per row and the pass ran at the fp32 ELEMENT rate, i.e. half the bytes per second (bf16 [96,64,257,257]: 855 us
 //     against 913 us in fp32, profiles/r03_bench_step_lowp_bf16_kernel_stats.csv); with eight it issues the same 16-byte requests as the fp32 form.
 //     The LDS tile holds fp32 either way (19 rows x (64 x CPL + 8) floats).
+// Round 6 (tools/ufd_lab6.hip, profiles/r06_c1_ufd_lab6.log):
+//  * XCD-aware tile order.  Workgroups go to the 8 XCDs round-robin (blockIdx % 8) and each XCD has its own L2: with the row tiles of a plane on consecutive
+//    block indices the 3 halo rows two neighbouring tiles share were fetched through two different L2s, i.e. twice from the fabric (19 / 16 of the read
+//    bytes).  Now the 8 XCDs walk 8 different (plane group, column group) units, each through all its row tiles: +1-4 % (5.83 -> 5.89 TB/s at 32 frames,
+//    5.93 -> 6.17 at 96 on the lab form of this kernel).
+//  * The 12 input rows of a tile that no other tile reads are fetched with non-temporal requests; the shared ones keep the default policy (they are the lines
+//    the L2 should hold).
+//  * Measured and NOT kept (profiles/r06_c4_ufd_lab6_steady_state_ablation.log): (i) naturally aligned 16-byte stores for outputs of pitch 4 k + 1 (256 -> 257) built
+//    with DPP wave shifts plus dword stores by lanes 0 / 63: 7 % SLOWER than the misaligned 16-byte store + one dword (194 vs 180 us at 32 frames), although a
+//    float4 copy with a misaligned destination loses 7 %; the same through an LDS-staged linear span (tools/ufd_lab6.hip V8 stage1): +2-3 %, not worth a second
+//    barrier pair; (ii) a 64-register bound (8 waves per SIMD): 0 ... -2.7 %.  The window is still read in two steps (40 live window registers instead of 56).
 template <typename T, int XTRA, int EPI, bool WIDE, bool NT, bool F44, int CPL = 4>
+#ifndef SGV_TILE_LAB_OFF
+#define SGV_TILE_LAB_OFF 0      // lab builds (tools/ufd_lab6.hip): 2 = no non-temporal loads, 16 = scalar multiply-add chains, 32 = no running maximum
+#endif
 __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     constexpr int NH = 3 + XTRA, NOUT = CPL + XTRA;
     static_assert(CPL == 4 || CPL == 8, "4 or 8 output columns per lane");
@@ -769,9 +789,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     typedef float f4v __attribute__((ext_vector_type(4)));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rt = blockIdx.x % p.row_tiles;
-    const int cg = (blockIdx.x / p.row_tiles) % p.col_groups;
-    const int pg = blockIdx.x / (p.row_tiles * p.col_groups);
+    int rt, unit;
+    if ((int)blockIdx.x < p.xcd_blocks) { const int j = blockIdx.x >> 3; rt = j % p.row_tiles; unit = (j / p.row_tiles) * 8 + (blockIdx.x & 7); }
+    else { rt = blockIdx.x % p.row_tiles; unit = blockIdx.x / p.row_tiles; }
+    const int cg = unit % p.col_groups;
+    const int pg = unit / p.col_groups;
     const int lpr = WIDE ? 64 : 1 << p.lpr_log2;
     const int sub = WIDE ? lane : lane & (lpr - 1), slot = WIDE ? 0 : lane >> p.lpr_log2;
     const int plane = WIDE ? pg : pg * (64 >> p.lpr_log2) + slot;
@@ -813,7 +835,8 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
         for (int i = 0; i < CPL; i++) m[k][i] = 0.f;
         h[k] = 0.f;
         if (r < TILE_IN_ROWS) {
-            row_loader<T, CPL>::run(row + base, m[k]);
+            if (k >= 1 && k <= 3 && !(SGV_TILE_LAB_OFF & 2)) row_loader<T, CPL, true>::run(row + base, m[k]);     // tile rows 4 .. 15: read by this tile only
+            else row_loader<T, CPL>::run(row + base, m[k]);
             if (sub < NH) h[k] = sgv_traits<T>::load(row + ixh_c);
         }
     }
@@ -882,9 +905,10 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     __syncthreads();
 
     // ---- compute phase: output rows 4 wave .. 4 wave + 3 from LDS rows 4 wave .. 4 wave + 6 ----
+    // (the window is read in two steps -- rows 0 .. 4 in front of output rows 0 and 1, rows 5 and 6 behind them, where rows 0 and 1 are dead -- so that 40
+    // window registers are live instead of 56)
     float win[7][CPL + 4];
-#pragma unroll
-    for (int r = 0; r < 7; r++) {
+    auto read_win = [&](int r) {
         const float* lrow = tile_lds + (4 * wave + r) * row_pitch + slot * seg_pitch + CPL * sub;
 #pragma unroll
         for (int q = 0; q < CPL / 4 + 1; q++) {     // its own CPL columns and the next four
@@ -892,7 +916,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
 #pragma unroll
             for (int i = 0; i < 4; i++) win[r][4 * q + i] = a[i];
         }
-    }
+    };
+#pragma unroll
+    for (int r = 0; r < 5; r++) read_win(r);
     float ep_sc = 1.f, ep_bi = 0.f;
     if constexpr (EPI == 1) {
         if (plane_ok && p.ep_scale) ep_sc = p.ep_scale[plane];
@@ -904,6 +930,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     for (int k = 0; k < 4; k++) {
         const int oy = oy0 + 4 * wave + k;
         if (oy >= p.out_h) break;   // wave-uniform
+        if (k == 2) { read_win(5); read_win(6); }
         float o[NOUT];
         // The 16 multiply-adds of an output, for two neighbouring outputs at a time: v_pk_fma_f32 (two fp32 FMAs per lane and instruction; hipcc keeps a
         // copy of the window row shifted by one column for the odd taps).  Every output still sees its own chain in the reference's tap order -- the
@@ -913,6 +940,16 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
 #if defined(SGV_TILE_ABL) && (SGV_TILE_ABL & 1)     // lab build (tools/gpu_recipes): the pass without its 16 multiply-adds per output
 #pragma unroll
         for (int v = 0; v < NOUT; v++) fir[v] = win[k + 1][v + 1] * ff[1][1];
+#elif (SGV_TILE_LAB_OFF & 16)                      // lab build: one scalar chain per output instead of v_pk_fma_f32 pairs
+#pragma unroll
+        for (int v = 0; v < NOUT; v++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc = __builtin_fmaf(win[k + j][v + i], ff[j][i], acc);
+            fir[v] = acc;
+        }
 #else
         typedef float f2v __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -956,7 +993,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
                 if (v < CPL ? st_vec : st_xtra) sum_g += t;
             }
             o[v] = t;
-            if constexpr (sizeof(T) == 4) { if (v < CPL ? st_vec : st_xtra) amx = sgv_amax_fold(amx, t); }
+            if constexpr (sizeof(T) == 4 && !(SGV_TILE_LAB_OFF & 32)) { if (v < CPL ? st_vec : st_xtra) amx = sgv_amax_fold(amx, t); }
         }
         T* yr = yp + (size_t)oy * p.out_w + ox;
         if (st_vec) { if (NT) store_vec_nt<T, CPL>(yr, o); else store_vec_plain<T, CPL>(yr, o); }
@@ -1235,8 +1272,11 @@ int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dt
         tp.ep_act = e->act; tp.ep_alpha = e->alpha; tp.ep_gain = e->gain; tp.ep_clamp = e->clamp;
     }
     const int ppw = 64 >> lpr_log2;
-    const int64_t blocks = (int64_t)((tp.planes + ppw - 1) / ppw) * col_groups * tp.row_tiles;
+    const int64_t units = (int64_t)((tp.planes + ppw - 1) / ppw) * col_groups;
+    const int64_t blocks = units * tp.row_tiles;
     if (blocks > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: too many workgroups");
+    static const int xcd_on = []() { const char* e = getenv("SGV_TILE_XCD"); return e ? atoi(e) : 1; }();    // SGV_TILE_XCD=0: the row-tile-fastest order of rounds 3-5
+    tp.xcd_blocks = xcd_on ? (int)((units / 8) * 8 * tp.row_tiles) : 0;
     const size_t lds = (size_t)tile_lds_floats(lpr_log2, cpl) * sizeof(float);
     const dim3 grid((unsigned)blocks);
     const bool f44 = p->f_w == 4 && p->f_h == 4 && p->f_sw == 1 && p->f_sh == 4;
