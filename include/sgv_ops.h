@@ -144,7 +144,8 @@ int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e
 
 /* Which kernel sgv_upfirdn2d would run for p: 0 = generic gather kernel, 1 = register-window row walker
  * (contiguous NCHW, up/down in {1,2}, filter <= 4x4), 2 = lane-exchange kernel (the 2x up / 2x down hot-path geometries; the FIR
- * geometries when SGV_UFD_TILE=0), 3 = LDS-tile kernel (up = down = 1, filter <= 4x4, pad 0..3, output width % 4 in {0, 1}).
+ * geometries when SGV_UFD_TILE=0), 3 = LDS-tile kernel (up = down = 1, filter <= 4x4, pad 0..3, output width % 4 in {0, 1}),
+ * 4 = 2x down-sampling LDS-tile kernel (down = 2, 8 <= output width <= 128), 5 = 2x up-sampling LDS-tile kernel.
  * For tests/benchmarks. */
 int sgv_upfirdn2d_kernel_kind(const sgv_upfirdn2d_params* p, int dtype);
 

@@ -1008,6 +1008,338 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
 }
 
+// ---------------------------------------------------------------------------------------------
+// 2x down-sampling tile kernel (up = 1, down = 2 on both axes, filter <= 4x4, pad 0..3): the discriminator's skip branch and the gradient of a 2x up-sampling.
+// Round 6.  The lane-exchange kernel walks a strip per wave -- loads, arithmetic and stores interleaved for the wave's lifetime -- and runs these calls at
+// 4.0-4.7 TB/s; the LDS-tile structure of upfirdn2d_tile_kernel (every load of the workgroup in flight at t = 0, one barrier, short-lived workgroups, the row
+// tiles of a plane on one XCD) reaches 6.0-6.3 on the FIR passes.  Same structure here: a workgroup owns 8 output rows of 64 >> lpr_log2 planes; the 18 input
+// rows of each are dealt to the lanes as 16-byte requests (36 wave rows, 9 per wave), parked zero-padded in LDS (position q of a plane row = input column
+// q - pad_x); wave w then produces output rows 2 w and 2 w + 1 of every plane from LDS rows 4 w .. 4 w + 5: three aligned ds_read_b128 per lane and row (input
+// columns 8 l - pad_x .. + 11 for output columns 4 l .. 4 l + 3), one fmaf chain per output in the reference's tap order (ascending input row, then column).
+struct down2_params {
+    const void* x;
+    const float* f;
+    void* y;
+    int flip;
+    float gain;
+    int in_w, in_h, out_w, out_h;
+    int planes;
+    int f_w, f_h;
+    int64_t f_sw, f_sh;
+    int pad_x, pad_y;
+    int lpr_log2;      // lanes per OUTPUT row of a plane (out_w <= 4 << lpr_log2, 1 .. 5); 64 >> lpr_log2 planes side by side in a wave
+    int row_tiles;     // ceil(out_h / 8)
+    int xcd_blocks;    // as tile_params
+    float* y_amax;
+};
+constexpr int D2_ROWS = 8, D2_IN_ROWS = 2 * D2_ROWS + 2;
+inline int down2_lds_floats(int lpr_log2) { return D2_IN_ROWS * (64 >> lpr_log2) * ((8 << lpr_log2) + 8); }
+
+template <typename T, bool NT, bool F44>
+__global__ __launch_bounds__(256) void upfirdn2d_down2_tile_kernel(down2_params p) {
+    extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int rt, pg;
+    if ((int)blockIdx.x < p.xcd_blocks) { const int j = blockIdx.x >> 3; rt = j % p.row_tiles; pg = (j / p.row_tiles) * 8 + (blockIdx.x & 7); }
+    else { rt = blockIdx.x % p.row_tiles; pg = blockIdx.x / p.row_tiles; }
+    const int lpr = 1 << p.lpr_log2, ppw = 64 >> p.lpr_log2;
+    const int seg_pitch = 8 * lpr + 8, row_pitch = ppw * seg_pitch;
+    float ff[4][4];
+    if constexpr (F44) {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) ff[a][b] = p.flip ? p.f[a * 4 + b] : p.f[(3 - a) * 4 + (3 - b)];
+    }
+    const int oy0 = rt * D2_ROWS;
+    const int iy0 = 2 * oy0 - p.pad_y;
+
+    // ---- load phase: 18 rows x ppw planes = 36 wave rows of 64 lanes x 4 columns; wave row g = wave + 4 k holds the segments g * spw .. (rows of a plane fastest) ----
+    const int nl_log2 = p.lpr_log2 + 1, nl = 2 * lpr;            // lanes per INPUT row of a plane
+    const int sub = lane & (nl - 1), seg_in_row = lane >> nl_log2, spw = 64 >> nl_log2;
+    const int ix0 = 4 * sub - p.pad_x;
+    const int base = min(max(ix0, 0), p.in_w - 4);
+    const int sh = base - ix0;
+    const int over_u = (((-p.pad_x - p.in_w) % 4) + 4) % 4;
+    const bool cols_dead = ix0 >= p.in_w || ix0 + 3 < 0;
+    const int ixh = 4 * nl - p.pad_x + sub;                       // lanes sub < 8: the columns behind the last lane's block
+    const bool halo_ok = sub < 8 && ixh >= 0 && ixh < p.in_w;
+    const int ixh_c = min(max(ixh, 0), p.in_w - 1);
+    constexpr int NK = D2_IN_ROWS / 2;                            // 36 wave rows / 4 waves
+    float m[NK][4], h[NK];
+    int lofs[NK];
+    bool rok[NK];
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        const int id = (wave + 4 * k) * spw + seg_in_row;
+        const int slot = id / D2_IN_ROWS, r = id - slot * D2_IN_ROWS;
+        const int plane = pg * ppw + slot;
+        const bool plane_ok = plane < p.planes;
+        const int iy = iy0 + r;
+        rok[k] = plane_ok && iy >= 0 && iy < p.in_h;
+        lofs[k] = r * row_pitch + slot * seg_pitch;
+        const T* row = (const T*)p.x + ((size_t)(plane_ok ? plane : 0) * p.in_h + min(max(iy, 0), p.in_h - 1)) * p.in_w;
+        if (r >= 2 && r < D2_IN_ROWS - 2) row_loader<T, 4, true>::run(row + base, m[k]);     // rows no other tile reads
+        else row_loader<T, 4>::run(row + base, m[k]);
+        h[k] = 0.f;
+        if (sub < 8) h[k] = sgv_traits<T>::load(row + ixh_c);
+    }
+    if constexpr (!F44) {
+        const int fsh = (int)p.f_sh, fsw = (int)p.f_sw;
+        const int a0 = p.flip ? 0 : (p.f_h - 1) * fsh, da = p.flip ? fsh : -fsh;
+        const int b0 = p.flip ? 0 : (p.f_w - 1) * fsw, db = p.flip ? fsw : -fsw;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const bool live = a < p.f_h && b < p.f_w;
+                const float v = p.f[live ? a0 + a * da + b0 + b * db : 0];
+                ff[a][b] = live ? v : 0.f;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < NK; k++) {
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = m[k][i];
+#pragma unroll
+        for (int d = 1; d <= 3; d++)
+            if (p.pad_x == d) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = (sh > 0) ? (i - d >= 0 ? m[k][i - d] : 0.f) : o[i];
+            }
+#pragma unroll
+        for (int d = 1; d < 4; d++)
+            if (over_u == d) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = (sh < 0) ? (i + d < 4 ? m[k][i + d] : 0.f) : o[i];
+            }
+        const bool live = rok[k] && !cols_dead;
+        float* lrow = tile_lds + lofs[k];
+        *(f4v*)(lrow + 4 * sub) = f4v{live ? o[0] : 0.f, live ? o[1] : 0.f, live ? o[2] : 0.f, live ? o[3] : 0.f};
+        if (sub < 8) lrow[4 * nl + sub] = (rok[k] && halo_ok) ? h[k] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- compute phase: wave w -> output rows 2 w, 2 w + 1 of every plane, from LDS rows 4 w .. 4 w + 5 ----
+    const int l = lane & (lpr - 1), cslot = lane >> p.lpr_log2;
+    const int cplane = pg * ppw + cslot;
+    const bool cplane_ok = cplane < p.planes;
+    const int ox = 4 * l;
+    T* yp = (T*)p.y + (size_t)(cplane_ok ? cplane : 0) * p.out_h * p.out_w;
+    float win[6][12];
+    auto read_win = [&](int r) {
+        const float* lrow = tile_lds + (4 * wave + r) * row_pitch + cslot * seg_pitch + 8 * l;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const f4v a = *(const f4v*)(lrow + 4 * q);
+#pragma unroll
+            for (int i = 0; i < 4; i++) win[r][4 * q + i] = a[i];
+        }
+    };
+#pragma unroll
+    for (int r = 0; r < 4; r++) read_win(r);
+    unsigned amx = 0u;
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int oy = oy0 + 2 * wave + u;
+        if (oy >= p.out_h) break;       // wave-uniform
+        if (u == 1) { read_win(4); read_win(5); }
+        float o[4];
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int ky = 0; ky < 4; ky++)
+#pragma unroll
+                for (int kx = 0; kx < 4; kx++) acc = __builtin_fmaf(win[2 * u + ky][2 * v + kx], ff[ky][kx], acc);
+            o[v] = acc * p.gain;
+            if constexpr (sizeof(T) == 4) { if (cplane_ok && ox + v < p.out_w) amx = sgv_amax_fold(amx, o[v]); }
+        }
+        T* yr = yp + (size_t)oy * p.out_w + ox;
+        if (cplane_ok && ox + 4 <= p.out_w) { if (NT) store_vec_nt<T, 4>(yr, o); else store_vec_plain<T, 4>(yr, o); }
+        else if (cplane_ok) {
+#pragma unroll
+            for (int v = 0; v < 3; v++) if (ox + v < p.out_w) sgv_traits<T>::store(yr + v, o[v]);
+        }
+    }
+    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 2x up-sampling tile kernel (up = 2, down = 1 on both axes, filter <= 4x4, pad 0..3): the skip-RGB up-sampling and the gradient of a 2x down-sampling
+// (ADD: + the gradient that arrived from the tensor's other consumer, sgv_upfirdn2d_fused mode 4).  Round 6, same structure as the kernels above.  The pass
+// writes four times what it reads: a workgroup owns 16 output rows x (64 >> lpr_log2) planes x 4 << lpr_log2 columns; their <= 10 input rows are five wave rows
+// of 16-byte requests, parked zero-padded in LDS (position q of a plane row = input column q + floor((1 - pad_x) / 2)); wave w produces output rows 4 w .. 4 w + 3
+// from four LDS rows, each output from its 2 x 2 live taps (a zero-inserted image never multiplies the other 12) in the reference's order (input row, then column).
+struct up2_params {
+    const void* x;
+    const float* f;
+    void* y;
+    const void* addend;  // ADD: OUTPUT-shaped summand, dtype / layout of y
+    int flip;
+    float gain;
+    int in_w, in_h, out_w, out_h;
+    int planes;
+    int f_w, f_h;
+    int64_t f_sw, f_sh;
+    int pad_x, pad_y;
+    int lpr_log2;      // lanes per output row of a plane (out_w <= 4 << lpr_log2, 2 .. 6)
+    int row_tiles;     // ceil(out_h / 16)
+    int xcd_blocks;
+    float* y_amax;
+};
+constexpr int U2_ROWS = 16, U2_IN_ROWS = 10;
+inline int up2_lds_floats(int lpr_log2) { return U2_IN_ROWS * (64 >> lpr_log2) * ((2 << lpr_log2) + 4); }
+
+template <typename T, bool NT, bool ADD>
+__global__ __launch_bounds__(256) void upfirdn2d_up2_tile_kernel(up2_params p) {
+    extern __shared__ __attribute__((aligned(16))) float tile_lds[];
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef float f2v __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int rt, pg;
+    if ((int)blockIdx.x < p.xcd_blocks) { const int j = blockIdx.x >> 3; rt = j % p.row_tiles; pg = (j / p.row_tiles) * 8 + (blockIdx.x & 7); }
+    else { rt = blockIdx.x % p.row_tiles; pg = blockIdx.x / p.row_tiles; }
+    const int lpr = 1 << p.lpr_log2, ppw = 64 >> p.lpr_log2;
+    const int seg_pitch = 2 * lpr + 4, row_pitch = ppw * seg_pitch;
+    const int tx = 1 - p.pad_x, ty = 1 - p.pad_y;                 // mid = o + t; input index = floor(mid / 2); first live tap = 1 - (mid & 1)
+    const int cb = tx >> 1, rb = ty >> 1;                          // floor(t / 2): -1 or 0
+    const int oy0 = rt * U2_ROWS;
+    const int iyb = (oy0 >> 1) + rb;                               // input row of LDS row 0 (oy0 is even)
+
+    // ---- load phase: 10 rows x ppw planes, lpr / 2 lanes x 4 columns per row: five wave rows ----
+    const int nl_log2 = p.lpr_log2 - 1, nl = lpr >> 1;
+    const int sub = lane & (nl - 1), seg_in_row = lane >> nl_log2, spw = 64 >> nl_log2;
+    const int ix0 = 4 * sub + cb;
+    const int base = min(max(ix0, 0), p.in_w - 4);
+    const int sh = base - ix0;
+    const int over_u = (((cb - p.in_w) % 4) + 4) % 4;
+    const bool cols_dead = ix0 >= p.in_w || ix0 + 3 < 0;
+    const int ixh = 4 * nl + cb + sub;
+    const bool halo_ok = sub < 4 && ixh >= 0 && ixh < p.in_w;
+    const int ixh_c = min(max(ixh, 0), p.in_w - 1);
+    float m[2][4], h[2];
+    int lofs[2];
+    bool rok[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int g = wave + 4 * k;
+        const int id = min(g, 4) * spw + seg_in_row;
+        const int slot = id / U2_IN_ROWS, r = id - slot * U2_IN_ROWS;
+        const int plane = pg * ppw + slot;
+        const bool plane_ok = plane < p.planes;
+        const int iy = iyb + r;
+        rok[k] = plane_ok && iy >= 0 && iy < p.in_h;
+        lofs[k] = r * row_pitch + slot * seg_pitch;
+#pragma unroll
+        for (int i = 0; i < 4; i++) m[k][i] = 0.f;
+        h[k] = 0.f;
+        if (g < 5) {        // wave-uniform
+            const T* row = (const T*)p.x + ((size_t)(plane_ok ? plane : 0) * p.in_h + min(max(iy, 0), p.in_h - 1)) * p.in_w;
+            row_loader<T, 4>::run(row + base, m[k]);
+            if (sub < 4) h[k] = sgv_traits<T>::load(row + ixh_c);
+        }
+    }
+    // taps: ff[a][b] = flipped, zero-padded filter (the convention of every kernel in this file), through the scalar cache behind the row loads
+    float ff[4][4];
+    {
+        const int fsh = (int)p.f_sh, fsw = (int)p.f_sw;
+        const int a0 = p.flip ? 0 : (p.f_h - 1) * fsh, da = p.flip ? fsh : -fsh;
+        const int b0 = p.flip ? 0 : (p.f_w - 1) * fsw, db = p.flip ? fsw : -fsw;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const bool live = a < p.f_h && b < p.f_w;
+                const float v = p.f[live ? a0 + a * da + b0 + b * db : 0];
+                ff[a][b] = live ? v : 0.f;
+            }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        if (wave + 4 * k >= 5) continue;
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = m[k][i];
+        if (cb == -1) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) o[i] = (sh > 0) ? (i >= 1 ? m[k][i - 1] : 0.f) : o[i];
+        }
+#pragma unroll
+        for (int d = 1; d < 4; d++)
+            if (over_u == d) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) o[i] = (sh < 0) ? (i + d < 4 ? m[k][i + d] : 0.f) : o[i];
+            }
+        const bool live = rok[k] && !cols_dead;
+        float* lrow = tile_lds + lofs[k];
+        *(f4v*)(lrow + 4 * sub) = f4v{live ? o[0] : 0.f, live ? o[1] : 0.f, live ? o[2] : 0.f, live ? o[3] : 0.f};
+        if (sub < 4) lrow[4 * nl + sub] = (rok[k] && halo_ok) ? h[k] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- compute phase: wave w -> output rows 4 w .. 4 w + 3 from LDS rows rw .. rw + 3 ----
+    const int l = lane & (lpr - 1), cslot = lane >> p.lpr_log2;
+    const int cplane = pg * ppw + cslot;
+    const bool cplane_ok = cplane < p.planes;
+    const int ox = 4 * l;
+    const int rw = ((4 * wave + ty) >> 1) - rb;
+    float win[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const float* lrow = tile_lds + min(rw + r, U2_IN_ROWS - 1) * row_pitch + cslot * seg_pitch + 2 * l;
+        const f2v a = *(const f2v*)lrow, b = *(const f2v*)(lrow + 2);
+        win[r][0] = a[0]; win[r][1] = a[1]; win[r][2] = b[0]; win[r][3] = b[1];
+    }
+    T* yp = (T*)p.y + (size_t)(cplane_ok ? cplane : 0) * p.out_h * p.out_w;
+    const T* ap = ADD ? (const T*)p.addend + (size_t)(cplane_ok ? cplane : 0) * p.out_h * p.out_w : nullptr;
+    const bool st_vec = cplane_ok && ox + 4 <= p.out_w, st_any = cplane_ok && ox < p.out_w;
+    unsigned amx = 0u;
+    // one output: rows dr, dr + 1 and columns dc, dc + 1 of the window, taps (a0, a0 + 2) x (b0, b0 + 2)
+    auto out1 = [&](int dr, int a0, int dc, int b0) {
+        float acc = __builtin_fmaf(win[dr][dc], ff[a0][b0], 0.f);
+        acc = __builtin_fmaf(win[dr][dc + 1], ff[a0][b0 + 2], acc);
+        acc = __builtin_fmaf(win[dr + 1][dc], ff[a0 + 2][b0], acc);
+        acc = __builtin_fmaf(win[dr + 1][dc + 1], ff[a0 + 2][b0 + 2], acc);
+        return acc * p.gain;
+    };
+    auto row_out = [&](int k, int dr, int a0) {
+        const int oy = oy0 + 4 * wave + k;
+        if (oy >= p.out_h) return;      // wave-uniform
+        float o[4];
+        if ((tx & 1) == 0) { o[0] = out1(dr, a0, 0, 1); o[1] = out1(dr, a0, 0, 0); o[2] = out1(dr, a0, 1, 1); o[3] = out1(dr, a0, 1, 0); }
+        else               { o[0] = out1(dr, a0, 0, 0); o[1] = out1(dr, a0, 1, 1); o[2] = out1(dr, a0, 1, 0); o[3] = out1(dr, a0, 2, 1); }
+        T* yr = yp + (size_t)oy * p.out_w + ox;
+        if constexpr (ADD) {
+            float yo[4] = {0.f, 0.f, 0.f, 0.f};
+            const T* ar = ap + (size_t)oy * p.out_w + ox;
+            if (st_vec) row_loader<T, 4>::run(ar, yo);
+            else if (st_any) {
+#pragma unroll
+                for (int v = 0; v < 3; v++) if (ox + v < p.out_w) yo[v] = sgv_traits<T>::load(ar + v);
+            }
+#pragma unroll
+            for (int v = 0; v < 4; v++) o[v] += yo[v];
+        }
+        if constexpr (sizeof(T) == 4) {
+#pragma unroll
+            for (int v = 0; v < 4; v++) if (cplane_ok && ox + v < p.out_w) amx = sgv_amax_fold(amx, o[v]);
+        }
+        if (st_vec) { if (NT) store_vec_nt<T, 4>(yr, o); else store_vec_plain<T, 4>(yr, o); }
+        else if (st_any) {
+#pragma unroll
+            for (int v = 0; v < 3; v++) if (ox + v < p.out_w) sgv_traits<T>::store(yr + v, o[v]);
+        }
+    };
+    if ((ty & 1) == 0) { row_out(0, 0, 1); row_out(1, 0, 0); row_out(2, 1, 1); row_out(3, 1, 0); }
+    else               { row_out(0, 0, 0); row_out(1, 1, 1); row_out(2, 1, 0); row_out(3, 2, 1); }
+    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
+}
+
 typedef void (*lanes_fn)(lanes_params);
 constexpr int LANES_WPB = 4;  // waves per workgroup (8 measured equal: the halo hand-off already covers 3 of 4 strip seams)
 
@@ -1288,6 +1620,107 @@ int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dt
     return sgv_check_launch("upfirdn2d_tile_kernel");
 }
 
+// ---- upfirdn2d_down2_tile_kernel: planning and launch ----
+bool down2_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2) {
+    static const int on = []() { const char* e = getenv("SGV_UFD_TILE2X"); return e ? atoi(e) : 1; }();   // SGV_UFD_TILE2X=0: the lane-exchange kernels of rounds 1-5
+    if (!on || dtype == SGV_F64) return false;
+    if (p->up_x != 1 || p->up_y != 1 || p->down_x != 2 || p->down_y != 2 || p->f_w > 4 || p->f_h > 4) return false;
+    if (p->pad_x0 < 0 || p->pad_x0 > 3 || p->pad_y0 < 0 || p->pad_y0 > 3 || p->in_w < 4) return false;
+    if (p->out_w < 8 || p->out_w > 128) return false;
+    if (!dense_nchw(p->in_w, p->in_h, p->in_c, p->in_sw, p->in_sh, p->in_sc, p->in_sn)) return false;
+    if (!dense_nchw(p->out_w, p->out_h, p->in_c, p->out_sw, p->out_sh, p->out_sc, p->out_sn)) return false;
+    int l = 1;
+    while ((4 << l) < p->out_w) l++;
+    *lpr_log2 = l;
+    return true;
+}
+
+template <typename T>
+void launch_down2_t(const down2_params& dp, bool nt, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
+    if (!f44) hipLaunchKernelGGL((upfirdn2d_down2_tile_kernel<T, false, false>), grid, dim3(256), lds, stream, dp);
+    else if (nt) hipLaunchKernelGGL((upfirdn2d_down2_tile_kernel<T, true, true>), grid, dim3(256), lds, stream, dp);
+    else hipLaunchKernelGGL((upfirdn2d_down2_tile_kernel<T, false, true>), grid, dim3(256), lds, stream, dp);
+}
+
+int launch_down2(const sgv_upfirdn2d_params* p, int dtype, int lpr_log2, hipStream_t stream, sgv_launch_scope& scope) {
+    down2_params dp{};
+    dp.y_amax = dtype == SGV_F32 ? scope.take_amax_sink() : nullptr;
+    dp.x = p->x; dp.f = p->f; dp.y = p->y; dp.flip = p->flip; dp.gain = p->gain;
+    dp.in_w = p->in_w; dp.in_h = p->in_h; dp.out_w = p->out_w; dp.out_h = p->out_h; dp.planes = p->in_c * p->in_n;
+    dp.f_w = p->f_w; dp.f_h = p->f_h; dp.f_sw = p->f_sw; dp.f_sh = p->f_sh;
+    dp.pad_x = p->pad_x0; dp.pad_y = p->pad_y0;
+    dp.lpr_log2 = lpr_log2;
+    dp.row_tiles = (p->out_h + D2_ROWS - 1) / D2_ROWS;
+    const int ppw = 64 >> lpr_log2;
+    const int64_t units = (dp.planes + ppw - 1) / ppw;
+    const int64_t blocks = units * dp.row_tiles;
+    if (blocks > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: too many workgroups");
+    static const int xcd_on = []() { const char* e = getenv("SGV_TILE_XCD"); return e ? atoi(e) : 1; }();
+    dp.xcd_blocks = xcd_on ? (int)((units / 8) * 8 * dp.row_tiles) : 0;
+    const double out_bytes = (double)p->out_w * p->out_h * dp.planes * sgv_dtype_size(dtype);
+    const bool nt = out_bytes > 300e6;
+    const bool f44 = p->f_w == 4 && p->f_h == 4 && p->f_sw == 1 && p->f_sh == 4;
+    const size_t lds = (size_t)down2_lds_floats(lpr_log2) * sizeof(float);
+    const dim3 grid((unsigned)blocks);
+    if (dtype == SGV_F32) launch_down2_t<float>(dp, nt, f44, grid, lds, stream);
+    else if (dtype == SGV_F16) launch_down2_t<sgv_half_t>(dp, nt, f44, grid, lds, stream);
+    else launch_down2_t<sgv_bf16_t>(dp, nt, f44, grid, lds, stream);
+    sgv_note_variant(SGV_V_ufd_tile_down2);
+    return sgv_check_launch("upfirdn2d_down2_tile_kernel");
+}
+
+// ---- upfirdn2d_up2_tile_kernel: planning and launch ----
+bool up2_geometry(const sgv_upfirdn2d_params* p, int dtype, int* lpr_log2) {
+    static const int on = []() { const char* e = getenv("SGV_UFD_TILE2X"); return e ? atoi(e) : 1; }();
+    if (!on || dtype == SGV_F64) return false;
+    if (p->up_x != 2 || p->up_y != 2 || p->down_x != 1 || p->down_y != 1 || p->f_w > 4 || p->f_h > 4) return false;
+    if (p->pad_x0 < 0 || p->pad_x0 > 3 || p->pad_y0 < 0 || p->pad_y0 > 3 || p->in_w < 4) return false;
+    if (p->out_w < 9 || p->out_w > 256) return false;     // (4 lanes per plane row at least: the lanes of a row segment also write its 2 .. 4 halo words)
+    if (!dense_nchw(p->in_w, p->in_h, p->in_c, p->in_sw, p->in_sh, p->in_sc, p->in_sn)) return false;
+    if (!dense_nchw(p->out_w, p->out_h, p->in_c, p->out_sw, p->out_sh, p->out_sc, p->out_sn)) return false;
+    int l = 2;
+    while ((4 << l) < p->out_w) l++;
+    *lpr_log2 = l;
+    return true;
+}
+
+template <typename T>
+void launch_up2_t(const up2_params& up, bool nt, dim3 grid, size_t lds, hipStream_t stream) {
+    if (up.addend) {
+        if (nt) hipLaunchKernelGGL((upfirdn2d_up2_tile_kernel<T, true, true>), grid, dim3(256), lds, stream, up);
+        else hipLaunchKernelGGL((upfirdn2d_up2_tile_kernel<T, false, true>), grid, dim3(256), lds, stream, up);
+    } else {
+        if (nt) hipLaunchKernelGGL((upfirdn2d_up2_tile_kernel<T, true, false>), grid, dim3(256), lds, stream, up);
+        else hipLaunchKernelGGL((upfirdn2d_up2_tile_kernel<T, false, false>), grid, dim3(256), lds, stream, up);
+    }
+}
+
+int launch_up2(const sgv_upfirdn2d_params* p, const void* addend, int dtype, int lpr_log2, hipStream_t stream, sgv_launch_scope& scope) {
+    up2_params up{};
+    up.y_amax = dtype == SGV_F32 ? scope.take_amax_sink() : nullptr;
+    up.x = p->x; up.f = p->f; up.y = p->y; up.addend = addend; up.flip = p->flip; up.gain = p->gain;
+    up.in_w = p->in_w; up.in_h = p->in_h; up.out_w = p->out_w; up.out_h = p->out_h; up.planes = p->in_c * p->in_n;
+    up.f_w = p->f_w; up.f_h = p->f_h; up.f_sw = p->f_sw; up.f_sh = p->f_sh;
+    up.pad_x = p->pad_x0; up.pad_y = p->pad_y0;
+    up.lpr_log2 = lpr_log2;
+    up.row_tiles = (p->out_h + U2_ROWS - 1) / U2_ROWS;
+    const int ppw = 64 >> lpr_log2;
+    const int64_t units = (up.planes + ppw - 1) / ppw;
+    const int64_t blocks = units * up.row_tiles;
+    if (blocks > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: too many workgroups");
+    static const int xcd_on = []() { const char* e = getenv("SGV_TILE_XCD"); return e ? atoi(e) : 1; }();
+    up.xcd_blocks = xcd_on ? (int)((units / 8) * 8 * up.row_tiles) : 0;
+    const double out_bytes = (double)p->out_w * p->out_h * up.planes * sgv_dtype_size(dtype);
+    const bool nt = out_bytes > 300e6;
+    const size_t lds = (size_t)up2_lds_floats(lpr_log2) * sizeof(float);
+    const dim3 grid((unsigned)blocks);
+    if (dtype == SGV_F32) launch_up2_t<float>(up, nt, grid, lds, stream);
+    else if (dtype == SGV_F16) launch_up2_t<sgv_half_t>(up, nt, grid, lds, stream);
+    else launch_up2_t<sgv_bf16_t>(up, nt, grid, lds, stream);
+    sgv_note_variant(addend ? SGV_V_ufd_tile_up2_add : SGV_V_ufd_tile_up2);
+    return sgv_check_launch("upfirdn2d_up2_tile_kernel");
+}
+
 int validate(const sgv_upfirdn2d_params* p, int dtype) {
 
     if (!p) return sgv_fail(SGV_ERR_INVALID_ARG, "upfirdn2d: params is NULL");
@@ -1321,6 +1754,8 @@ extern "C" int sgv_upfirdn2d_kernel_kind(const sgv_upfirdn2d_params* p, int dtyp
     if (rc != SGV_OK) return rc;
     int lpr_log2, col_groups, xtra;
     if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra)) return 3;
+    if (down2_geometry(p, dtype, &lpr_log2)) return 4;
+    if (up2_geometry(p, dtype, &lpr_log2)) return 5;
     lanes_plan lplan;
     if (plan_lanes(p, dtype, &lplan)) return 2;
     rows_plan plan;
@@ -1338,6 +1773,17 @@ extern "C" int sgv_upfirdn2d(const sgv_upfirdn2d_params* p, int dtype, void* str
         if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra, &cpl)) {   // every up = down = 1 FIR pass: the LDS-tile kernel
             sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
             return launch_tile(p, nullptr, dtype, lpr_log2, col_groups, xtra, cpl, stream, scope);
+        }
+    }
+    {
+        int lpr_log2;
+        if (down2_geometry(p, dtype, &lpr_log2)) {   // 2x down-sampling with whole planes in a workgroup's lanes: the down2 tile kernel
+            sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
+            return launch_down2(p, dtype, lpr_log2, stream, scope);
+        }
+        if (up2_geometry(p, dtype, &lpr_log2)) {
+            sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, bytes);
+            return launch_up2(p, nullptr, dtype, lpr_log2, stream, scope);
         }
     }
     lanes_plan lplan;
@@ -1397,6 +1843,13 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
         if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra, &cpl)) {
             sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, nin0 * es0 + (e->mode == 3 ? 2.0 * nout0 : nout0) * es0);
             return launch_tile(p, e, dtype, lpr_log2, col_groups, xtra, cpl, stream, scope);
+        }
+    }
+    if (e->mode == 4) {
+        int lpr_log2;
+        if (up2_geometry(p, dtype, &lpr_log2)) {
+            sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, nin0 * es0 + 2.0 * nout0 * es0);
+            return launch_up2(p, e->yref, dtype, lpr_log2, stream, scope);
         }
     }
     lanes_plan lplan;

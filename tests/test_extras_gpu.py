@@ -673,7 +673,7 @@ def test_gemm_conv1x1_adds_a_residual_in_its_store():
     assert torch.equal(gr, dy)
 
 
-@pytest.mark.parametrize('shape', [(2, 8, 64, 64), (3, 4, 256, 256), (2, 6, 32, 32), (1, 3, 16, 16)])
+@pytest.mark.parametrize('shape', [(2, 8, 64, 64), (3, 4, 256, 256), (2, 6, 32, 32), (1, 3, 16, 16), (2, 5, 8, 8), (3, 2, 128, 128), (1, 2, 24, 40)])
 def test_fir_down_with_input_alias_sums_the_gradients_in_its_own_pass(shape):
     """fused_fir_act.fir_down_with_input_alias: the FIR + decimate node hands x to a second consumer; that consumer's gradient is added in the
     store of the node's gradient pass (sgv_upfirdn2d_fused mode 4) -- same values as autograd's separate addition, first and second order."""

@@ -99,7 +99,7 @@ ROWS_CONFIGS = [
     (1, 1, [1, 1, 1, 1], 4), (1, 1, [2, 2, 2, 2], 4), (2, 1, [2, 1, 2, 1], 4), (1, 2, [1, 1, 1, 1], 1),
     (2, 1, [1, 2, 1, 2], 1), (2, 1, [3, 0, 2, 1], 1), (1, 2, [2, 0, 0, 2], 1), (1, 1, [0, 3, -1, 2], 1), (1, 2, [-1, 3, 2, -2], 2),
 ]
-ROWS_SHAPES = [(1, 1, 5, 5), (2, 3, 9, 9), (1, 2, 16, 16), (3, 5, 17, 33), (1, 2, 64, 63), (2, 2, 37, 129), (1, 3, 19, 131), (1, 1, 65, 255),
+ROWS_SHAPES = [(1, 1, 5, 5), (1, 3, 4, 4), (2, 2, 8, 8), (1, 1, 6, 12), (3, 2, 7, 6), (2, 3, 9, 9), (1, 2, 16, 16), (3, 5, 17, 33), (1, 2, 64, 63), (2, 2, 37, 129), (1, 3, 19, 131), (1, 1, 65, 255),
                (2, 1, 31, 256), (1, 2, 33, 257), (1, 1, 12, 258), (1, 1, 9, 261), (1, 1, 40, 513), (1, 1, 7, 1025), (1, 1, 3, 300), (1, 1, 1, 140),
                # output rows of 40 / 72 / 192 / 200 / 320 (+1) / 1000 columns in the two FIR geometries: column blocks that do not fill the lanes of a plane
                # row -- the 16-bit tile kernel's eight-column lanes meet a window that overhangs the row's end by up to seven columns there
@@ -126,7 +126,12 @@ def test_upfirdn2d_row_walker_shapes_bit_exact(cfg, dtype):
                 xg, fg = x.to(DEV), f.to(DEV)
                 kind = _kind(xg, fg, up, down, padding)
                 hot = (up, down, padding[0], padding[2]) in ((1, 1, 1, 1), (1, 1, 2, 2), (2, 1, 2, 2), (1, 2, 1, 1))
-                assert kind in ((2, 3) if hot else (1,)), 'unexpected kernel selection'  # 3 = LDS tile, 2 = lane-exchange, 1 = row walker
+                # 3 = LDS tile, 4 / 5 = 2x down / up LDS tile (any pad 0..3), 2 = lane-exchange, 1 = row walker; never the generic gather kernel (0)
+                assert kind in ((2, 3, 4, 5) if hot else (1, 4, 5)), 'unexpected kernel selection'
+                if down == 2 and up == 1 and 8 <= ow <= 128 and shape[3] >= 4 and min(padding[0], padding[2]) >= 0 and max(padding[0], padding[2]) <= 3:
+                    dispatch_assert(kind == 4, '2x down-sampling with 8..128 output columns goes to the down2 tile kernel')
+                if up == 2 and down == 1 and 9 <= ow <= 256 and shape[3] >= 4 and min(padding[0], padding[2]) >= 0 and max(padding[0], padding[2]) <= 3:
+                    dispatch_assert(kind == 5, '2x up-sampling with 9..256 output columns goes to the up2 tile kernel')
                 if up == 1 and down == 1 and hot and ow % 4 in (0, 1) and ow > 4 and shape[3] >= 4:
                     dispatch_assert(kind == 3, 'the FIR geometries with whole output quads go to the tile kernel')
                 y = ufd.upfirdn2d(xg, fg, up=up, down=down, padding=padding, flip_filter=flip, gain=gain)
