@@ -136,7 +136,7 @@ def compact_line(out, detail_path=None):
     line = {k: out.get(k) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')}
     cfg = dict(out.get('config') or {})
     line['config'] = {k: cfg[k] for k in ('workload', 'videos_per_gpu', 'frames_per_video', 'clips_per_gpu', 'frames_per_clip', 'global_batch_videos', 'parallelism', 'phases_run',
-                                          'hip_graphs', 'conv_terms', 'native_launches_per_step') if k in cfg}
+                                          'hip_graphs', 'headline_mode', 'conv_terms', 'native_launches_per_step') if k in cfg}
     line['roofline'] = pick(out.get('roofline'), ROOFLINE_KEYS)
     cpu = pick(out.get('cpu_baseline'), CPU_KEYS)
     if cpu and len(str(cpu.get('sample', ''))) > 400:
@@ -409,6 +409,80 @@ def synthesis_workload(args, world, rank, device):
         torch.distributed.destroy_process_group()
 
 
+def build_headline_step(make_step, world, rank, want_captured, warmup, dev_sync, between_capture_and_region=None):
+    """Build the step the timed region runs, warm it up, and make every rank run the SAME kind of step.  -> (ts, mode)
+
+    want_captured: False (eager step: DDP buckets at world > 1), True (Gmain / Dmain replayed as hipGraphs; at world > 1 one flat eager all-reduce of the captured
+    gradient buffers between the two graphs of a phase, TrainStep(ddp_manual)), or 'emulate' (the host-side stand-in of a replayed graph: CPU tests of this path).
+    A capture that fails raises on its rank before that rank's first collective of the step; the ranks then agree (MIN over a flag) to rebuild the EAGER step -- the
+    line says so in `headline_mode` -- instead of mixing modes.  (A rank that failed AFTER its peers entered a collective would leave them waiting: `--eager` is the
+    way around a box where that happens.)
+    mode: 'captured' | 'emulated capture' | 'eager' | 'eager (capture failed: ...)'."""
+    import torch
+    ts, err = None, ''
+    if want_captured:
+        try:
+            ts = make_step(want_captured)
+            for i in range(max(warmup, 1)):         # the first step holds the captures: never inside the timed region
+                tw = time.perf_counter()
+                ts.step()
+                dev_sync()
+                if rank == 0:
+                    log(f'[bench] warm-up iteration {i}: {time.perf_counter() - tw:.2f} s (captures in the first one)')
+            if between_capture_and_region is not None:
+                between_capture_and_region(ts)
+            if warmup < 2:     # the first R1 iteration behind a capture pays 0.5-0.8 s once (profiles/r05_c17b_captured_steps.log): not inside the region
+                ts.batch_idx = 0
+                ts.step()
+                dev_sync()
+        except Exception as exc:      # noqa: BLE001  (whatever the runtime raised: the fallback is the documented behaviour)
+            err = f'{type(exc).__name__}: {exc}'[:200]
+            log(f'[bench] rank {rank}: the captured step failed ({err}); falling back to the eager step on every rank')
+            ts = None
+        ok = torch.tensor([1.0 if ts is not None else 0.0], device=getattr(ts, 'device', None) or ('cuda' if torch.cuda.is_available() else 'cpu'))
+        if world > 1:
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if float(ok.item()) > 0:
+            return ts, ('emulated capture' if want_captured == 'emulate' else 'captured')
+        del ts
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+    ts = make_step(False)
+    for i in range(warmup):
+        tw = time.perf_counter()
+        ts.step()
+        dev_sync()
+        if rank == 0:
+            log(f'[bench] warm-up iteration {i}: {time.perf_counter() - tw:.2f} s (includes MIOpen kernel compilation on a cold cache)')
+    return ts, ('eager' if not want_captured else f'eager (capture failed on a rank{": " + err if err else ""})')
+
+
+def timed_steps(ts, steps, world, dev_sync, device, before_step=None, after_step=None):
+    """The contract's timed region: barrier + device sync on both sides of exactly `steps` iterations, MAX over ranks.  -> (seconds, phases_run, per-rank seconds tensor)"""
+    import torch
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        dev_sync()
+    phases_run = {}
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if before_step is not None:
+            before_step(i)
+        for name in ts.step():
+            phases_run[name] = phases_run.get(name, 0) + 1
+        if after_step is not None:
+            after_step(i)
+    barrier()
+    mine = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    t_max = mine.clone()
+    if world > 1:
+        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
+    return float(t_max.item()), phases_run, mine
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -501,7 +575,7 @@ def main():
     # of their own, and an odd iteration that ran in another clock state than its neighbours in three of four records.)  The upfirdn2d family's in-region
     # sample, the per-variant tables and `value_eager` come from the eager step behind the region.  Several GPUs (DDP's reducer cannot be captured) or --eager: the
     # eager step with HIP events, as in rounds 1-4.
-    captured_headline = world == 1 and not args.eager and not args.graphs and not args.no_prof
+    captured_headline = not args.eager and not args.graphs and not args.no_prof      # (every N: the scaling curve compares like with like; --eager: the eager DDP step)
     if captured_headline:
         import contextlib
         from stylegan_v_amd.training import train_step as _tsmod
@@ -517,28 +591,24 @@ def main():
             finally:
                 custom_ops.prof_disable()
         _tsmod._HipGraph.capture_hook = _capture_events
-    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=args.graphs or captured_headline, augment=args.aug)
+    def make_step(graphs):
+        return TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=graphs, augment=args.aug)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        tw = time.perf_counter()
-        ts.step()
-        torch.cuda.synchronize()
-        if rank == 0:
-            log(f'[bench] warm-up iteration {i}: {time.perf_counter() - tw:.2f} s (includes MIOpen kernel compilation on a cold cache)')
-    if captured_headline:
-        if not ts._graphs:      # --warmup 0: the captures must not fall into the timed region
-            ts.step()
-            torch.cuda.synchronize()
+    def _captures_done(_ts):
         _tsmod._HipGraph.capture_hook = None
-        if args.warmup < 2:     # the first R1 iteration behind a capture pays 0.5-0.8 s once (profiles/r05_c17b_captured_steps.log): not inside the region
-            ts.batch_idx = 0
-            ts.step()
-            torch.cuda.synchronize()
+    ts, headline_mode = build_headline_step(make_step, world, rank, bool(args.graphs or captured_headline), args.warmup, torch.cuda.synchronize,
+                                            between_capture_and_region=_captures_done if captured_headline else None)
+    if captured_headline and headline_mode != 'captured':      # the agreed fallback: the eager step with HIP events, as --eager
+        _tsmod._HipGraph.capture_hook = None
+        custom_ops.prof_disable()
+        custom_ops.prof_families(None)
+        captured_headline = False
+    headline_sync = ('one flat all-reduce per phase between the two hipGraphs' if ts.ddp_manual else 'DDP buckets (eager)') if world > 1 else None
     # Start the timed window on an iteration that runs the regularisation phases, whatever the warm-up was.
     ts.batch_idx = 0
     launches0 = custom_ops.launch_count()
@@ -576,20 +646,15 @@ def main():
     power = PowerSampler(device.index or 0) if rank == 0 else None
     if power is not None:
         power.__enter__()
-    barrier()
-    t0 = time.perf_counter()
-    phases_run = {}
     step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # one event per iteration boundary: the per-iteration device times in the side file
-    step_marks[0].record()
-    for i_step in range(args.steps):
+
+    def _before(i_step):
+        if i_step == 0:
+            step_marks[0].record()
         if not args.no_prof and not captured_headline and i_step == prof_from:
             custom_ops.prof_families(TIMED_FAMILIES)      # inside the timed region: the dominant kernel and the FIR family only (all 554 launches per iteration: 1.4 % of the step)
             custom_ops.prof_enable(1 << 17)
-        for name in ts.step():
-            phases_run[name] = phases_run.get(name, 0) + 1
-        step_marks[i_step + 1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, phases_run, t_mine = timed_steps(ts, args.steps, world, torch.cuda.synchronize, device, before_step=_before, after_step=lambda i_step: step_marks[i_step + 1].record())
     if power is not None:
         power.__exit__()
     step_ms = [round(step_marks[i].elapsed_time(step_marks[i + 1]), 3) for i in range(args.steps)]
@@ -631,12 +696,12 @@ def main():
         _tsmod._HipGraph.capture_hook = None
         del ts
         torch.cuda.empty_cache()
-        ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=False, augment=args.aug)
+        ts = make_step(False)      # (world > 1: the eager DDP step -- `value_eager` at every N)
         ts.batch_idx = 1
         ts.step(); ts.step()
         torch.cuda.synchronize()
 
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    t_max = t_mine      # this rank's own time (`elapsed` is already the MAX over ranks)
     multi_gpu = None
     if world > 1:
         # what the ranks saw: every rank's own time, the number of ranks RCCL reduced over, and the flat gradient all-reduce of each phase on its own
@@ -655,9 +720,7 @@ def main():
             torch.cuda.synchronize()
             allreduce_ms[label] = dict(MB=flat.numel() * 4 / 1e6, ms=(time.perf_counter() - t1) / 5 * 1e3)
         multi_gpu = dict(rccl_ranks_seen=int(ones.item()), ms_per_step_by_rank=[1e3 * float(v.item()) / args.steps for v in per_rank], flat_gradient_allreduce=allreduce_ms,
-                         gradient_sync='DDP buckets (eager)' if not ts.ddp_manual else 'one flat all-reduce per phase between the two hipGraphs')
-        torch.distributed.all_reduce(t_max, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(t_max.item())
+                         gradient_sync=headline_sync, headline_mode=headline_mode)
     frames_total = global_batch * args.frames * args.steps
     value = frames_total / elapsed
 
@@ -994,6 +1057,7 @@ def main():
                                global_batch_videos=global_batch, parallelism=f'dp{world}', phases_run=phases_run,
                                pl_reg='off (reference config pl_weight=0; Greg phase is a no-op)', r1_gamma=train_cfg.r1_gamma,
                                native_launches_per_step=headline_launches_per_step, hip_graphs=hip_graphs_headline,
+                               headline_mode=headline_mode,      # captured | eager | eager (capture failed ...): what `value` measures, at every N (`value_eager`: the eager step's figure beside it)
                                # companions of the same run as scalars (each is also a top-level value_* key with its details next to it)
                                value_no_prof=value_no_prof['value'] if value_no_prof else None, value_eager=value_eager['value'] if value_eager else None,
                                value_bf16_split=split3['value'] if split3 else None, value_vendor_fp32_convs=strict['value'] if strict else None,

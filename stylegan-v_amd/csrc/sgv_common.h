@@ -106,6 +106,20 @@ __device__ __forceinline__ void sgv_amax_commit(unsigned m, float* sink) {
     }
 }
 
+// The same with ONE atomic per workgroup: the waves fold their maxima into an LDS word first (ds_max_u32).  `lds_word` holds 0 from before the workgroup's
+// last barrier; every thread of the workgroup calls this (it contains a barrier).  Round 6: the tile kernels of upfirdn2d retire a wave per 4 output rows --
+// four times the atomics of the strip walkers -- and the armed side output cost the 2x up-sampling pass 11 % (profiles/r06_c11_*).
+__device__ __forceinline__ void sgv_amax_commit_wg(unsigned m, float* sink, unsigned* lds_word) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(lds_word, m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned w = *lds_word;
+        if (w) atomicMax((unsigned*)sink + 1 + (blockIdx.x & (SGV_AMAX_SLOTS - 1)), w);
+    }
+}
+
 // Kernel variants (sgv_variant_count / sgv_variant_name of the public header): which member of a family a call took.
 #define SGV_VARIANTS(X) \
     X(conv_s1_ws) X(conv_s1_ws_fused) X(conv_s1_ws_accumulate) X(conv_s1_4wave) X(conv_small) \
@@ -114,7 +128,7 @@ __device__ __forceinline__ void sgv_amax_commit(unsigned m, float* sink) {
     X(wrw_s1_ws) X(wrw_s1_ws_scaled) X(wrw_s1_ws_packed) X(wrw_s1_4wave) X(wrw_s2_ws) X(wrw_s2_ws_packed) X(wrw_s2_4wave) X(wrw_s2_4wave_packed) \
     X(ufd_tile) X(ufd_tile_fused1) X(ufd_tile_fused3) X(ufd_lanes) X(ufd_lanes_seg) X(ufd_lanes_fused1) X(ufd_lanes_fused2) X(ufd_lanes_fused3) X(ufd_lanes_fused4) X(ufd_rows) X(ufd_generic) \
     X(pw_many2few) X(pw_few2many) X(pw_few2many_act) X(pw_outer) X(gemm_f32) X(gemm_bf16x3) X(fc) X(bias_act) X(conv_lowp) X(wrw_lowp) X(conv_s2_lowp) X(convT_lowp) X(wrw_s2_lowp) X(gemm_bf16x3_stream) X(conv1x1_wstat) \
-    X(conv_s1_half_tile) X(convT_half_tile) X(ufd_tile_down2) X(ufd_tile_up2) X(ufd_tile_up2_add)
+    X(conv_s1_half_tile) X(convT_half_tile) X(ufd_tile_down2) X(ufd_tile_up2) X(ufd_tile_up2_add) X(ufd_tile_fused2)
 enum sgv_variant_id {
 #define SGV_V_ENUM(name) SGV_V_##name,
     SGV_VARIANTS(SGV_V_ENUM)

@@ -498,11 +498,14 @@ __global__ __launch_bounds__(64 * WPB, (DOWN == 2 ? 4 : (EPI >= 2 ? 6 : 8))) voi
     };
     // grad-1 form (bias_act.cu:60-61,133-142): g = dy * act'(pre) * gain, zero where the forward output was clamped;
     // `pre` returns the pre-activation value recovered from the stored output (lrelu is invertible).
+    // (round 6: y / gain and y / alpha as products with reciprocals taken once per thread -- two IEEE divisions per ELEMENT were a third of the prologue's
+    // instructions; the sign test is unchanged, the recovered pre-activation moves by <= 1 ulp and only enters the plane sum of g * pre)
+    const float ep_inv_gain = (p.ep_gain != 0.f) ? 1.f / p.ep_gain : 0.f, ep_inv_alpha = (p.ep_alpha != 0.f) ? 1.f / p.ep_alpha : 0.f;
     auto epi_grad = [&](float dy, float yref, float& pre) {
-        const float yy = (p.ep_gain != 0.f) ? yref / p.ep_gain : 0.f;
+        const float yy = yref * ep_inv_gain;
         float g = dy;
         pre = yy;
-        if (p.ep_act == 3) { g = (yy > 0.f) ? dy : dy * p.ep_alpha; pre = (yy > 0.f) ? yy : yy / p.ep_alpha; }
+        if (p.ep_act == 3) { g = (yy > 0.f) ? dy : dy * p.ep_alpha; pre = (yy > 0.f) ? yy : yy * ep_inv_alpha; }
         g *= p.ep_gain;
         if (p.ep_clamp >= 0.f) g = (yref > -p.ep_clamp & yref < p.ep_clamp) ? g : 0.f;
         return g;
@@ -742,11 +745,13 @@ struct tile_params {
     int col_groups;
     int row_tiles;     // ceil(out_h / 16)
     int xcd_blocks;    // workgroups [0, xcd_blocks) are dealt so that the row tiles of one (plane group, column group) stay on ONE XCD; a multiple of 8 * row_tiles
+    int lds_amax_word; // float index of the workgroup's running-maximum word behind the tile image
     int nt_store;
     const float* ep_scale;  // EPI 1: [planes] or NULL
     const float* ep_bias;   // EPI 1: [chans] or NULL
-    const void* ep_yref;    // EPI 3: the forward output, OUTPUT-shaped
-    float* ep_sum_g;        // EPI 3: [planes], += sum of the result over the plane
+    const void* ep_yref;    // EPI 3: the forward output, OUTPUT-shaped; EPI 2: the forward output of the layer whose gradient arrives, INPUT-shaped
+    float* ep_sum_g;        // EPI 3: [planes], += sum of the result over the plane; EPI 2: += sum of g (the activation gradient, before the scale)
+    float* ep_sum_gv;       // EPI 2: [planes], += sum of g * pre-activation
     int ep_act;
     float ep_alpha, ep_gain, ep_clamp;
     int chans;
@@ -809,6 +814,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     }
     const T* xp = (const T*)p.x + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w;
     T* yp = (T*)p.y + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
+    float ep_sc = 1.f, ep_bi = 0.f;     // EPI 1: issued in front of the row loads (round 6; behind the barrier their latency sat in front of the first multiply-add)
+    if constexpr (EPI == 1) {
+        if (plane_ok && p.ep_scale) ep_sc = p.ep_scale[plane];
+        if (plane_ok && p.ep_bias) ep_bi = p.ep_bias[plane % p.chans];
+    }
     const int n_main = XTRA ? p.out_w - 1 : p.out_w;           // a multiple of CPL
     const int ox = (cg * 64 + sub) * CPL;
     const int ix0 = ox - p.pad_x;
@@ -840,6 +850,25 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
             if (sub < NH) h[k] = sgv_traits<T>::load(row + ixh_c);
         }
     }
+    // EPI 2 (round 6; the lane-exchange kernel served it at 4.5 TB/s): the rows hold the incoming gradient dy; the forward output at the same positions turns
+    // them into g = d(bias_act)/dx . dy before they are parked (times the plane's scale), and every input element is counted ONCE in the plane sums: by the
+    // lane that owns its column (not the neighbour whose clamped window also covers it), in the tile whose first 16 rows hold it (the last tile: all 19).
+    float yv[EPI == 2 ? RPW : 1][CPL], hy[EPI == 2 ? RPW : 1];
+    if constexpr (EPI == 2) {
+        const T* yrp = (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.in_h * p.in_w;
+#pragma unroll
+        for (int k = 0; k < RPW; k++) {
+            const int r = wave + 4 * k;
+            const T* yrow = yrp + (size_t)min(max(iy0 + r, 0), p.in_h - 1) * p.in_w;
+#pragma unroll
+            for (int i = 0; i < CPL; i++) yv[k][i] = 0.f;
+            hy[k] = 0.f;
+            if (r < TILE_IN_ROWS) {
+                row_loader<T, CPL, true>::run(yrow + base, yv[k]);
+                if (sub < NH) hy[k] = sgv_traits<T>::load(yrow + ixh_c);
+            }
+        }
+    }
     float yo[4][NOUT];
     if constexpr (EPI == 3) {   // the forward output at this wave's four output rows (same predicates as the stores)
         const T* yrp = (const T*)p.ep_yref + (size_t)(plane_ok ? plane : 0) * p.out_h * p.out_w;
@@ -868,6 +897,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
                 ff[a][b] = live ? v : 0.f;
             }
     }
+    float sum_g2 = 0.f, sum_gv2 = 0.f, ep_sc2 = 1.f;
+    if constexpr (EPI == 2) { if (plane_ok && p.ep_scale) ep_sc2 = p.ep_scale[plane]; }
+    // y / gain and y / alpha as products with reciprocals taken once per thread (the sign test is unchanged; the recovered pre-activation moves by <= 1 ulp)
+    const float inv_gain = (p.ep_gain != 0.f) ? 1.f / p.ep_gain : 0.f, inv_alpha = (p.ep_alpha != 0.f) ? 1.f / p.ep_alpha : 0.f;
+    if (threadIdx.x == 0) tile_lds[p.lds_amax_word] = 0.f;      // the workgroup's running maximum (sgv_amax_commit_wg), zeroed in front of the barrier
 #pragma unroll
     for (int k = 0; k < RPW; k++) {
         const int r = wave + 4 * k;
@@ -878,6 +912,30 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
         // lane whose window overhangs the row's end (sh = -over_u) moved, and both amounts are wave-uniform: a uniform branch picks the shift, every
         // element costs one select per side (the per-lane chain over |sh| = 1..3 cost six -- and covered overhangs up to 3 only, short of what
         // CPL = 8 can meet on rows whose column blocks do not fill the lanes).
+        if constexpr (EPI == 2) {
+            const bool counted = row_ok && plane_ok && (r < TILE_ROWS || rt == p.row_tiles - 1);
+#pragma unroll
+            for (int i = 0; i < CPL; i++) {
+                const float dy = m[k][i], yref = yv[k][i];
+                const float yy = yref * inv_gain;
+                float g = dy, pre = yy;
+                if (p.ep_act == 3) { g = (yy > 0.f) ? dy : dy * p.ep_alpha; pre = (yy > 0.f) ? yy : yy * inv_alpha; }
+                g *= p.ep_gain;
+                if (p.ep_clamp >= 0.f) g = (yref > -p.ep_clamp & yref < p.ep_clamp) ? g : 0.f;
+                if (counted && i + sh >= 0 && i + sh < CPL) { sum_g2 += g; sum_gv2 = __builtin_fmaf(g, pre, sum_gv2); }
+                m[k][i] = g * ep_sc2;
+            }
+            {
+                const float dy = h[k], yref = hy[k];
+                const float yy = yref * inv_gain;
+                float g = dy, pre = yy;
+                if (p.ep_act == 3) { g = (yy > 0.f) ? dy : dy * p.ep_alpha; pre = (yy > 0.f) ? yy : yy * inv_alpha; }
+                g *= p.ep_gain;
+                if (p.ep_clamp >= 0.f) g = (yref > -p.ep_clamp & yref < p.ep_clamp) ? g : 0.f;
+                if (counted && halo_ok && cg == p.col_groups - 1) { sum_g2 += g; sum_gv2 = __builtin_fmaf(g, pre, sum_gv2); }
+                h[k] = g * ep_sc2;
+            }
+        }
         float o[CPL];
 #pragma unroll
         for (int i = 0; i < CPL; i++) o[i] = m[k][i];
@@ -903,6 +961,12 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
         if (sub < 8) lrow[CPL * lpr + sub] = (row_ok && halo_ok) ? h[k] : 0.f;   // halo words; the rest of the 8 are zero
     }
     __syncthreads();
+    if constexpr (EPI == 2) {   // the plane sums of this wave's rows: reduce over the lanes of a plane row, one atomic pair per plane and wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1)
+            if (off < lpr) { sum_g2 += __shfl_xor(sum_g2, off, 64); sum_gv2 += __shfl_xor(sum_gv2, off, 64); }
+        if (sub == 0 && plane_ok) { atomicAdd(p.ep_sum_g + plane, sum_g2); atomicAdd(p.ep_sum_gv + plane, sum_gv2); }
+    }
 
     // ---- compute phase: output rows 4 wave .. 4 wave + 3 from LDS rows 4 wave .. 4 wave + 6 ----
     // (the window is read in two steps -- rows 0 .. 4 in front of output rows 0 and 1, rows 5 and 6 behind them, where rows 0 and 1 are dead -- so that 40
@@ -919,13 +983,28 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
     };
 #pragma unroll
     for (int r = 0; r < 5; r++) read_win(r);
-    float ep_sc = 1.f, ep_bi = 0.f;
-    if constexpr (EPI == 1) {
-        if (plane_ok && p.ep_scale) ep_sc = p.ep_scale[plane];
-        if (plane_ok && p.ep_bias) ep_bi = p.ep_bias[plane % p.chans];
-    }
     float sum_g = 0.f;
     unsigned amx = 0u;          // fp32 tensors: running max |stored value| (one VALU operation per output beside 16 multiply-adds; the pass is HBM-bound)
+    // gain -> [EPI 1: * scale + bias -> activation -> gain -> clamp] / [EPI 3: activation gradient at the forward output yref]
+    auto finish = [&](float fir, float sc, float bi, float yref) {
+        float t = fir * p.gain;
+        if constexpr (EPI == 1) {   // bias -> activation -> gain -> clamp, the operation order of bias_act.cu:51-142 (grad 0); identical to the lanes kernel's
+            t = t * sc;
+            t = t + bi;
+            if (p.ep_act == 3) t = (t > 0.f) ? t : t * p.ep_alpha;
+            t *= p.ep_gain;
+            if (p.ep_clamp >= 0.f) t = (t > -p.ep_clamp & t < p.ep_clamp) ? t : (t >= 0.f) ? p.ep_clamp : -p.ep_clamp;
+        }
+        if constexpr (EPI == 3) {   // grad-1 form (bias_act.cu:60-61,133-142): dy * act'(pre) * gain, zero where the forward output was clamped
+            const float yy = yref * inv_gain;
+            float g = t;
+            if (p.ep_act == 3) g = (yy > 0.f) ? t : t * p.ep_alpha;
+            g *= p.ep_gain;
+            if (p.ep_clamp >= 0.f) g = (yref > -p.ep_clamp & yref < p.ep_clamp) ? g : 0.f;
+            t = g;
+        }
+        return t;
+    };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int oy = oy0 + 4 * wave + k;
@@ -936,6 +1015,9 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
         // copy of the window row shifted by one column for the odd taps).  Every output still sees its own chain in the reference's tap order -- the
         // results are bit-identical to the scalar form -- at half the FMA issue slots: on 16-bit tensors the pass is bound by its VALU work, not by HBM
         // (profiles/r03_ufd_tile_valu_ablation.log: bf16 2.9 TB/s, 3.35 without the multiply-adds, fp32 unchanged at 5.5).
+        // (out_w = 4 k + 1: EVERY lane carries a fifth output and the last lane of a row stores it next to its four.  Round 6 tried the column as a phase of its own
+        // -- one thread per (row, plane), 16 multiply-adds once per workgroup instead of 25 % more in the whole loop: 6 % (256 -> 257) to 31 % (128 -> 129) SLOWER,
+        // profiles/r06_c12_*: the lone dword then reaches memory long after the rest of its cache line.)
         float fir[NOUT];
 #if defined(SGV_TILE_ABL) && (SGV_TILE_ABL & 1)     // lab build (tools/gpu_recipes): the pass without its 16 multiply-adds per output
 #pragma unroll
@@ -974,26 +1056,11 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
 #endif
 #pragma unroll
         for (int v = 0; v < NOUT; v++) {
-            float t = fir[v] * p.gain;
-            if constexpr (EPI == 1) {   // bias -> activation -> gain -> clamp, the operation order of bias_act.cu:51-142 (grad 0); identical to the lanes kernel's
-                t = t * ep_sc;
-                t = t + ep_bi;
-                if (p.ep_act == 3) t = (t > 0.f) ? t : t * p.ep_alpha;
-                t *= p.ep_gain;
-                if (p.ep_clamp >= 0.f) t = (t > -p.ep_clamp & t < p.ep_clamp) ? t : (t >= 0.f) ? p.ep_clamp : -p.ep_clamp;
-            }
-            if constexpr (EPI == 3) {   // grad-1 form (bias_act.cu:60-61,133-142): dy * act'(pre) * gain, zero where the forward output was clamped
-                const float yref = yo[k][v];
-                const float yy = (p.ep_gain != 0.f) ? yref / p.ep_gain : 0.f;
-                float g = t;
-                if (p.ep_act == 3) g = (yy > 0.f) ? t : t * p.ep_alpha;
-                g *= p.ep_gain;
-                if (p.ep_clamp >= 0.f) g = (yref > -p.ep_clamp & yref < p.ep_clamp) ? g : 0.f;
-                t = g;
-                if (v < CPL ? st_vec : st_xtra) sum_g += t;
-            }
+            const bool stored = v < CPL ? st_vec : st_xtra;
+            const float t = finish(fir[v], ep_sc, ep_bi, EPI == 3 ? yo[k][v] : 0.f);
+            if constexpr (EPI == 3) { if (stored) sum_g += t; }
             o[v] = t;
-            if constexpr (sizeof(T) == 4 && !(SGV_TILE_LAB_OFF & 32)) { if (v < CPL ? st_vec : st_xtra) amx = sgv_amax_fold(amx, t); }
+            if constexpr (sizeof(T) == 4 && !(SGV_TILE_LAB_OFF & 32)) { if (stored) amx = sgv_amax_fold(amx, t); }
         }
         T* yr = yp + (size_t)oy * p.out_w + ox;
         if (st_vec) { if (NT) store_vec_nt<T, CPL>(yr, o); else store_vec_plain<T, CPL>(yr, o); }
@@ -1005,7 +1072,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_tile_kernel(tile_params p) {
             if (off < lpr) sum_g += __shfl_xor(sum_g, off, 64);
         if (sub == 0 && plane_ok && oy0 + 4 * wave < p.out_h) atomicAdd(p.ep_sum_g + plane, sum_g);
     }
-    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
+    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit_wg(amx, p.y_amax, (unsigned*)(tile_lds + p.lds_amax_word)); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1030,6 +1097,7 @@ struct down2_params {
     int lpr_log2;      // lanes per OUTPUT row of a plane (out_w <= 4 << lpr_log2, 1 .. 5); 64 >> lpr_log2 planes side by side in a wave
     int row_tiles;     // ceil(out_h / 8)
     int xcd_blocks;    // as tile_params
+    int lds_amax_word; // as tile_params
     float* y_amax;
 };
 constexpr int D2_ROWS = 8, D2_IN_ROWS = 2 * D2_ROWS + 2;
@@ -1121,6 +1189,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_down2_tile_kernel(down2_params 
         *(f4v*)(lrow + 4 * sub) = f4v{live ? o[0] : 0.f, live ? o[1] : 0.f, live ? o[2] : 0.f, live ? o[3] : 0.f};
         if (sub < 8) lrow[4 * nl + sub] = (rok[k] && halo_ok) ? h[k] : 0.f;
     }
+    if (threadIdx.x == 0) tile_lds[p.lds_amax_word] = 0.f;
     __syncthreads();
 
     // ---- compute phase: wave w -> output rows 2 w, 2 w + 1 of every plane, from LDS rows 4 w .. 4 w + 5 ----
@@ -1165,7 +1234,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_down2_tile_kernel(down2_params 
             for (int v = 0; v < 3; v++) if (ox + v < p.out_w) sgv_traits<T>::store(yr + v, o[v]);
         }
     }
-    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
+    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit_wg(amx, p.y_amax, (unsigned*)(tile_lds + p.lds_amax_word)); }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1189,6 +1258,7 @@ struct up2_params {
     int lpr_log2;      // lanes per output row of a plane (out_w <= 4 << lpr_log2, 2 .. 6)
     int row_tiles;     // ceil(out_h / 16)
     int xcd_blocks;
+    int lds_amax_word;
     float* y_amax;
 };
 constexpr int U2_ROWS = 16, U2_IN_ROWS = 10;
@@ -1280,6 +1350,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_up2_tile_kernel(up2_params p) {
         *(f4v*)(lrow + 4 * sub) = f4v{live ? o[0] : 0.f, live ? o[1] : 0.f, live ? o[2] : 0.f, live ? o[3] : 0.f};
         if (sub < 4) lrow[4 * nl + sub] = (rok[k] && halo_ok) ? h[k] : 0.f;
     }
+    if (threadIdx.x == 0) tile_lds[p.lds_amax_word] = 0.f;
     __syncthreads();
 
     // ---- compute phase: wave w -> output rows 4 w .. 4 w + 3 from LDS rows rw .. rw + 3 ----
@@ -1337,7 +1408,7 @@ __global__ __launch_bounds__(256) void upfirdn2d_up2_tile_kernel(up2_params p) {
     };
     if ((ty & 1) == 0) { row_out(0, 0, 1); row_out(1, 0, 0); row_out(2, 1, 1); row_out(3, 1, 0); }
     else               { row_out(0, 0, 0); row_out(1, 1, 1); row_out(2, 1, 0); row_out(3, 2, 1); }
-    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit(amx, p.y_amax); }
+    if constexpr (sizeof(T) == 4) { if (p.y_amax) sgv_amax_commit_wg(amx, p.y_amax, (unsigned*)(tile_lds + p.lds_amax_word)); }
 }
 
 typedef void (*lanes_fn)(lanes_params);
@@ -1583,6 +1654,7 @@ template <typename T>
 void launch_tile_t(const tile_params& tp, int xtra, int epi, int cpl, bool f44, dim3 grid, size_t lds, hipStream_t stream) {
     if (epi == 0) { if (xtra) launch_tile_xe<T, 1, 0>(tp, cpl, f44, grid, lds, stream); else launch_tile_xe<T, 0, 0>(tp, cpl, f44, grid, lds, stream); }
     else if (epi == 1) { if (xtra) launch_tile_xe<T, 1, 1>(tp, cpl, f44, grid, lds, stream); else launch_tile_xe<T, 0, 1>(tp, cpl, f44, grid, lds, stream); }
+    else if (epi == 2) { if (xtra) launch_tile_xe<T, 1, 2>(tp, cpl, f44, grid, lds, stream); else launch_tile_xe<T, 0, 2>(tp, cpl, f44, grid, lds, stream); }
     else { if (xtra) launch_tile_xe<T, 1, 3>(tp, cpl, f44, grid, lds, stream); else launch_tile_xe<T, 0, 3>(tp, cpl, f44, grid, lds, stream); }
 }
 
@@ -1600,7 +1672,7 @@ int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dt
     tp.ep_act = 1; tp.ep_alpha = 0.f; tp.ep_gain = 1.f; tp.ep_clamp = -1.f; tp.chans = p->in_c;
     const int epi = e ? e->mode : 0;
     if (e) {
-        tp.ep_scale = e->scale; tp.ep_bias = e->bias; tp.ep_yref = e->yref; tp.ep_sum_g = e->sum_g;
+        tp.ep_scale = e->scale; tp.ep_bias = e->bias; tp.ep_yref = e->yref; tp.ep_sum_g = e->sum_g; tp.ep_sum_gv = e->sum_gv;
         tp.ep_act = e->act; tp.ep_alpha = e->alpha; tp.ep_gain = e->gain; tp.ep_clamp = e->clamp;
     }
     const int ppw = 64 >> lpr_log2;
@@ -1609,14 +1681,15 @@ int launch_tile(const sgv_upfirdn2d_params* p, const sgv_fir_epilogue* e, int dt
     if (blocks > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "upfirdn2d: too many workgroups");
     static const int xcd_on = []() { const char* e = getenv("SGV_TILE_XCD"); return e ? atoi(e) : 1; }();    // SGV_TILE_XCD=0: the row-tile-fastest order of rounds 3-5
     tp.xcd_blocks = xcd_on ? (int)((units / 8) * 8 * tp.row_tiles) : 0;
-    const size_t lds = (size_t)tile_lds_floats(lpr_log2, cpl) * sizeof(float);
+    tp.lds_amax_word = tile_lds_floats(lpr_log2, cpl);
+    const size_t lds = (size_t)(tile_lds_floats(lpr_log2, cpl) + 4) * sizeof(float);
     const dim3 grid((unsigned)blocks);
     const bool f44 = p->f_w == 4 && p->f_h == 4 && p->f_sw == 1 && p->f_sh == 4;
     if (!f44) tp.nt_store = 0;      // the general-filter form has one (plain-store) instantiation
     if (dtype == SGV_F32) launch_tile_t<float>(tp, xtra, epi, 4, f44, grid, lds, stream);
     else if (dtype == SGV_F16) launch_tile_t<sgv_half_t>(tp, xtra, epi, cpl, f44, grid, lds, stream);
     else launch_tile_t<sgv_bf16_t>(tp, xtra, epi, cpl, f44, grid, lds, stream);
-    sgv_note_variant(epi == 0 ? SGV_V_ufd_tile : epi == 1 ? SGV_V_ufd_tile_fused1 : SGV_V_ufd_tile_fused3);
+    sgv_note_variant(epi == 0 ? SGV_V_ufd_tile : epi == 1 ? SGV_V_ufd_tile_fused1 : epi == 2 ? SGV_V_ufd_tile_fused2 : SGV_V_ufd_tile_fused3);
     return sgv_check_launch("upfirdn2d_tile_kernel");
 }
 
@@ -1660,7 +1733,8 @@ int launch_down2(const sgv_upfirdn2d_params* p, int dtype, int lpr_log2, hipStre
     const double out_bytes = (double)p->out_w * p->out_h * dp.planes * sgv_dtype_size(dtype);
     const bool nt = out_bytes > 300e6;
     const bool f44 = p->f_w == 4 && p->f_h == 4 && p->f_sw == 1 && p->f_sh == 4;
-    const size_t lds = (size_t)down2_lds_floats(lpr_log2) * sizeof(float);
+    dp.lds_amax_word = down2_lds_floats(lpr_log2);
+    const size_t lds = (size_t)(down2_lds_floats(lpr_log2) + 4) * sizeof(float);
     const dim3 grid((unsigned)blocks);
     if (dtype == SGV_F32) launch_down2_t<float>(dp, nt, f44, grid, lds, stream);
     else if (dtype == SGV_F16) launch_down2_t<sgv_half_t>(dp, nt, f44, grid, lds, stream);
@@ -1712,7 +1786,8 @@ int launch_up2(const sgv_upfirdn2d_params* p, const void* addend, int dtype, int
     up.xcd_blocks = xcd_on ? (int)((units / 8) * 8 * up.row_tiles) : 0;
     const double out_bytes = (double)p->out_w * p->out_h * up.planes * sgv_dtype_size(dtype);
     const bool nt = out_bytes > 300e6;
-    const size_t lds = (size_t)up2_lds_floats(lpr_log2) * sizeof(float);
+    up.lds_amax_word = up2_lds_floats(lpr_log2);
+    const size_t lds = (size_t)(up2_lds_floats(lpr_log2) + 4) * sizeof(float);
     const dim3 grid((unsigned)blocks);
     if (dtype == SGV_F32) launch_up2_t<float>(up, nt, grid, lds, stream);
     else if (dtype == SGV_F16) launch_up2_t<sgv_half_t>(up, nt, grid, lds, stream);
@@ -1838,10 +1913,11 @@ extern "C" int sgv_upfirdn2d_fused(const sgv_upfirdn2d_params* p, const sgv_fir_
     hipStream_t stream = (hipStream_t)stream_;
     const double es0 = (double)sgv_dtype_size(dtype);
     const double nin0 = (double)p->in_w * p->in_h * p->in_c * p->in_n, nout0 = (double)p->out_w * p->out_h * p->in_c * p->in_n;
-    if (e->mode == 1 || e->mode == 3) {
+    static const int tile2_on = []() { const char* e = getenv("SGV_UFD_TILE_EPI2"); return e ? atoi(e) : 1; }();   // SGV_UFD_TILE_EPI2=0: mode 2 on the lane-exchange kernel (rounds 2-5)
+    if (e->mode == 1 || e->mode == 3 || (e->mode == 2 && tile2_on && p->pad_x0 == 2 && p->pad_y0 == 2 && p->out_w == p->in_w + 1 && p->out_h == p->in_h + 1)) {
         int lpr_log2, col_groups, xtra, cpl;
         if (tile_geometry(p, dtype, &lpr_log2, &col_groups, &xtra, &cpl)) {
-            sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, nin0 * es0 + (e->mode == 3 ? 2.0 * nout0 : nout0) * es0);
+            sgv_launch_scope scope(SGV_K_UPFIRDN2D_LANES, stream, (e->mode == 2 ? 2.0 * nin0 : nin0) * es0 + (e->mode == 3 ? 2.0 * nout0 : nout0) * es0);
             return launch_tile(p, e, dtype, lpr_log2, col_groups, xtra, cpl, stream, scope);
         }
     }

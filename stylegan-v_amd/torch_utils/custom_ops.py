@@ -152,11 +152,16 @@ def get_native(build=True):
     if _load_error is not None:
         raise _load_error
     try:
-        if not is_built():
-            if not build or os.environ.get('SGV_NO_BUILD') == '1':
-                raise NativeLibraryError('libsgv_hip.so is missing or stale (%s) and building is disabled' % LIB_PATH)
-            build_native()
-        lib = ctypes.CDLL(LIB_PATH)
+        lab = os.environ.get('SGV_LIB_PATH')     # lab switch (tools/fir_bench.py A/B runs on one box): another build of this library, loaded as it is
+        if lab:
+            lib = ctypes.CDLL(lab)
+            print('[sgv] LAB: loaded %s instead of the in-tree library' % lab, flush=True)
+        else:
+            if not is_built():
+                if not build or os.environ.get('SGV_NO_BUILD') == '1':
+                    raise NativeLibraryError('libsgv_hip.so is missing or stale (%s) and building is disabled' % LIB_PATH)
+                build_native()
+            lib = ctypes.CDLL(LIB_PATH)
         _declare(lib)
         if lib.sgv_version() // 100 != 1:
             raise NativeLibraryError('libsgv_hip.so ABI version mismatch: %d' % lib.sgv_version())

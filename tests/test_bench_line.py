@@ -42,6 +42,14 @@ def test_compact_line_is_small_and_complete(bench):
     assert d['detail'] == 'bench_detail.json'
 
 
+def test_compact_line_says_which_step_the_value_measures(bench):
+    full = canned()
+    full['config']['headline_mode'] = 'captured'
+    full['value_eager'] = 600.0
+    d = json.loads(bench.compact_line(full, None))
+    assert d['config']['headline_mode'] == 'captured' and d['value_eager'] == 600.0      # the same key must not silently mean two things
+
+
 def test_compact_line_hard_limit_drops_optional_parts_not_contract_keys(bench):
     full = canned()
     full['value_padding'] = 'x' * 20000          # a future scalar that would blow the line up

@@ -210,3 +210,59 @@ def test_graph_schedule_allreduces_the_captured_gradient_buffers(tmp_path):
         p.join(timeout=540)
         assert p.exitcode == 0, f'rank process failed with exit code {p.exitcode}'
     assert (tmp_path / 'graph_rank0.ok').exists() and (tmp_path / 'graph_rank1.ok').exists()
+
+
+def _bench_worker(rank, world, port, out_dir, fail):
+    """bench.py's own N > 1 headline path (build_headline_step + timed_steps) on two gloo ranks, with the host-side stand-in of a replayed graph."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import bench
+
+        def make_step(graphs):
+            ts_ = _make(world, rank, batch_gpu=2, ddp=True, use_graphs=graphs, reg_intervals=(2, 2))
+            if graphs and fail:      # a capture that the runtime refuses: raised inside the first step, in front of the step's first collective, on every rank
+                def refuse(*a, **k):
+                    raise RuntimeError('capture refused (injected)')
+                ts_._run_phase_graph = refuse
+            return ts_
+        ts, mode = bench.build_headline_step(make_step, world, rank, 'emulate', warmup=1, dev_sync=lambda: None)
+        if not fail:
+            assert mode == 'emulated capture' and ts.use_graphs and ts.ddp_manual, (mode, ts.use_graphs, ts.ddp_manual)
+            assert set(ts._graphs) == {'Gmain', 'Dmain'}, 'the warm-up must hold the captures: none inside the timed region'
+        else:
+            assert mode.startswith('eager (capture failed') and not ts.use_graphs and not ts.ddp_manual, mode     # EVERY rank fell back, not only the one that failed
+        ts.batch_idx = 0
+        seconds, phases, mine = bench.timed_steps(ts, 3, world, lambda: None, torch.device('cpu'))
+        assert phases == {'Gmain': 3, 'Dmain': 3, 'Greg': 2, 'Dreg': 2}, phases
+        assert seconds >= float(mine.item()) - 1e-9       # MAX over ranks
+        both = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(both, torch.tensor([seconds], dtype=torch.float64))
+        assert float(both[0]) == float(both[1]), 'every rank must report the same (max) time'
+        # the ranks trained ONE model: parameters identical after the collective-synchronised steps
+        flat = torch.cat([p.detach().reshape(-1) for m in (ts.G, ts.D) for p in m.parameters()])
+        peers = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(peers, flat)
+        assert torch.equal(peers[0], peers[1]), 'ranks diverged'
+        open(os.path.join(out_dir, f'bench_rank{rank}.ok'), 'w').write(mode)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize('fail', [False, True])
+def test_bench_multi_gpu_headline_path_runs_the_same_step_on_every_rank(tmp_path, fail):
+    """`bench.py --gpus N`: the captured step with the manual flat all-reduce at every N (here: its host-side stand-in on two gloo ranks), and -- when a rank's capture
+    is refused -- the agreed fallback of ALL ranks to the eager DDP step, reported in `headline_mode`."""
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, str(tmp_path), fail)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=840)
+        assert p.exitcode == 0, f'rank process failed with exit code {p.exitcode}'
+    modes = {(tmp_path / f'bench_rank{r}.ok').read_text() for r in range(2)}
+    assert len(modes) == 1

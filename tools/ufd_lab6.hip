@@ -348,7 +348,8 @@ int main(int argc, char** argv) {
         tp.ep_act = 1; tp.ep_gain = 1.f; tp.ep_clamp = -1.f; tp.chans = C;
         tp.xcd_blocks = xc ? (planes * tp.col_groups / 8) * 8 * tp.row_tiles : 0;
         const long blocks7 = (long)planes * tp.col_groups * tp.row_tiles;
-        const size_t lds7 = (size_t)tile_lds_floats(6) * 4;
+        tp.lds_amax_word = tile_lds_floats(6);
+        const size_t lds7 = (size_t)(tile_lds_floats(6) + 4) * 4;
         std::string nm = std::string("V7 product tile kernel LAB_OFF=") + std::to_string(SGV_TILE_LAB_OFF) + (xc ? " xcd1" : " xcd0");
         if (OW % 4 == 0)
             bench(nm.c_str(), [=](const float* xi, float* yo) { tile_params r = tp; r.x = xi; r.y = yo;
