@@ -257,28 +257,44 @@ def cpu_baseline(res, frames, seconds_cap):
     except OSError:
         pass
     physical = max(1, min(allowed, logical // smt))      # one thread per physical core
-    g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=res, batch_size=1, num_gpus=1, fp32=True, num_frames_per_video=frames)
-    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=1, world_size=1, ddp=False)
     t_start = time.time()
+    # The reference ITSELF where its checkout exists (the build container: tools/cpu_reference_step.py imports its modules and drives them as training_loop.py does);
+    # on the GPU box it does not, and the leg is this repo's port of the same step.  profiles/r06_cpu_baseline_reference_vs_port_container.json: both, one process.
+    kind = 'port'
+    one = None
+    try:
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import cpu_reference_step as _ref
+        if _ref.available() and res == 256:
+            one = _ref.make_reference_step(res, frames)
+            kind = 'reference'
+    except Exception as exc:      # noqa: BLE001
+        log(f'[bench] the reference checkout is present but could not be driven ({type(exc).__name__}: {exc}); timing the port')
+        one = None
+    if one is None:
+        g_kwargs, d_kwargs, train_cfg = cfgs.model_kwargs(resolution=res, batch_size=1, num_gpus=1, fp32=True, num_frames_per_video=frames)
+        ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=1, world_size=1, ddp=False)
 
-    def one(batch_idx):
-        ts.batch_idx = batch_idx
-        t1 = time.time()
-        phases = ts.step()
-        return time.time() - t1, phases
+        def one(batch_idx):
+            ts.batch_idx = batch_idx
+            t1 = time.time()
+            phases = ts.step()
+            return time.time() - t1, phases
     # Thread count: every physical core is the protocol -- but at one video per step more threads are not faster on a two-socket host (measured on the
-    # pool's 2 x 64-core EPYC 9575F: 9.7 s per main iteration with 128 threads, 5.7 s with 64).  Both are tried once (after a warm-up iteration) and the
-    # faster one is the baseline: the CPU gets its best configuration.
+    # pool's 2 x 64-core EPYC 9575F: 9.7 s per main iteration with 128 threads, 5.7 s with 64).  Both are tried once (after the warm-up iterations) and the
+    # faster one is the baseline: the CPU gets its best configuration.  TWO warm-up iterations (with one, the first timed sample was still warming:
+    # 5.1 / 4.58 / 4.52 s), and the probe samples are not reused as timed ones.
     candidates = [physical] + ([64] if physical > 64 else [])
     torch.set_num_threads(candidates[0])
     t_warm, phases_main = one(1)                       # warm-up: main phases (Gmain + Dmain; Greg is a no-op at pl_weight 0)
+    t_warm2 = one(1)[0]
     probe = {}
     for th in candidates:
         torch.set_num_threads(th)
         probe[th] = one(1)[0]
     threads = min(probe, key=probe.get)
     torch.set_num_threads(threads)
-    reps = [probe[threads]]
+    reps = []
     while len(reps) < 3 or (len(reps) < 5 and time.time() - t_start + 3.5 * reps[0] < seconds_cap):
         reps.append(one(1)[0])
     t_main = sorted(reps)[len(reps) // 2]
@@ -296,11 +312,13 @@ def cpu_baseline(res, frames, seconds_cap):
     except OSError:
         pass
     spent = time.time() - t_start
-    return dict(value=frames / per_iter, unit='img/s', cores=threads, host_physical_cores=physical, host_logical_cpus=logical, threads_per_core=smt, kind='port', cpu=model,
+    return dict(value=frames / per_iter, unit='img/s', cores=threads, host_physical_cores=physical, host_logical_cpus=logical, threads_per_core=smt, kind=kind, cpu=model,
                 seconds_main_iteration_by_threads={str(k): round(v, 3) for k, v in probe.items()},
-                kind_note="this repo's plain-PyTorch op path (= the reference's impl='ref' fallback ops + ATen CPU convolutions); the reference checkout does not exist on the GPU box",
-                seconds_main_iteration_median=t_main, main_iteration_samples=[round(v, 3) for v in reps], seconds_warmup_iteration=t_warm, seconds_reg_iteration=t_reg,
-                sample=f'batch 1 video x {frames} frames, {res}x{res}, fp32, {threads} threads (the faster of {candidates} on {physical} physical cores): 1 warm-up + {len(reps)} timed main iterations '
+                kind_note=("the reference's own modules, loss and update order (tools/cpu_reference_step.py), its pure-Python fallback ops" if kind == 'reference' else
+                           "this repo's plain-PyTorch op path (= the reference's impl='ref' fallback ops + ATen CPU convolutions); the reference checkout does not exist on the GPU box "
+                           "(both timed side by side in the build container: profiles/r06_cpu_baseline_reference_vs_port_container.json)"),
+                seconds_main_iteration_median=t_main, main_iteration_samples=[round(v, 3) for v in reps], seconds_warmup_iterations=[round(t_warm, 3), round(t_warm2, 3)], seconds_reg_iteration=t_reg,
+                sample=f'batch 1 video x {frames} frames, {res}x{res}, fp32, {threads} threads (the faster of {candidates} on {physical} physical cores): 2 warm-ups + {len(reps)} timed main iterations '
                        f'({"+".join(phases_main)}), median {t_main:.2f} s' + (f'; one R1 iteration ({"+".join(phases_reg)}) {t_reg:.1f} s, weighted 1/16: rate = frames / (t_main + (t_16 - t_main) / 16)'
                                                                        if t_reg is not None else '; the R1 iteration did not fit the budget and is not charged') + f'; {spent:.0f} s of CPU time')
 

@@ -1,5 +1,6 @@
 // 3x3 / stride 1 / pad 1 convolution on NCHW fp32 tensors -- producer / consumer form of conv3x3_kernel (conv3x3_kernel.h), same
-// arithmetic (bf16 hi/lo split products on v_mfma_f32_32x32x16_bf16, fp32 accumulate), same LDS images, same weight layout.
+// arithmetic (TERMS = 4, the default: block-scaled 2-way fp16 split, three v_mfma_f32_32x32x16_f16 per product, fp32 accumulate -- csrc/sgv_split.h;
+// TERMS = 3: the bf16 hi/lo split of rounds 1-3 on v_mfma_f32_32x32x16_bf16; TERMS = 1: one 16-bit product), same LDS images, same weight layout.
 //
 // Reference: the `conv2d` of SynthesisLayer / Conv2dLayer (src/training/networks.py:58-62 via conv2d_resample.py:40-54), its data
 // gradient (conv2d_gradfix.py:100-118), and -- with PRO / EPI -- the modulation multiplies and the bias_act that surround it in

@@ -1,9 +1,10 @@
 """2-D convolution with optional FIR up/down-sampling.
 
 Host-side mirror of the reference's ``src/torch_utils/ops/conv2d_resample.py`` (``conv2d_resample``
-:59).  It only decides WHICH kernels run: the convolutions go to MIOpen through
-``conv2d_gradfix``; every resampling step is an ``upfirdn2d`` launch (csrc/upfirdn2d.hip).  The
-decomposition per case is the one of conv2d_resample.py:107-154:
+:59).  It only decides WHICH kernels run (``plan``: pure geometry, a list of steps): the convolutions go
+through ``conv2d_gradfix`` -- this library's MFMA kernels for every 3x3 / 1x1 shape of the path, the vendor
+library for what they do not serve --; every resampling step is an ``upfirdn2d`` launch
+(csrc/upfirdn2d.hip).  The decomposition per case is the one of conv2d_resample.py:107-154:
 
   1x1 conv, down > 1 .......... FIR+decimate first, then convolve on the small image
   1x1 conv, up > 1 ............ convolve first, then zero-insert+FIR
@@ -55,17 +56,67 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     return op(x, w, stride=stride, padding=padding, groups=groups)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# Geometry.  Everything below works per AXIS on a pair (lo, hi) of paddings; a "plan" is the list of kernel launches a call decomposes into.
+
+def _footprint(pad, taps, up, down):
+    """Padding of one axis with the resampling filter's own footprint folded in (what ``upsample2d`` / ``downsample2d`` add for a `taps`-tap filter)."""
+    lo, hi = pad
+    if up > 1:
+        lo, hi = lo + (taps + up - 1) // 2, hi + (taps - up) // 2
+    if down > 1:
+        lo, hi = lo + (taps - down + 1) // 2, hi + (taps - down) // 2
+    return lo, hi
+
+
+def _axes(f, up, down, padding):
+    """((x_lo, x_hi), (y_lo, y_hi)) for filter f."""
+    fw, fh = _get_filter_size(f)
+    px0, px1, py0, py1 = _parse_padding(padding)
+    return _footprint((px0, px1), fw, up, down), _footprint((py0, py1), fh, up, down)
+
+
+def _flat(ax, ay):
+    return [ax[0], ax[1], ay[0], ay[1]]
+
+
+def _transposed_axis(pad, k, up):
+    """A stride-`up` transposed convolution with a k-tap kernel covers k - 1 (lo) and k - up (hi) of an axis' padding by itself; what is then negative is
+    cropped by the convolution (its `padding` argument: the part both ends share), the remainder stays with the FIR pass behind it.
+    -> (convolution padding, FIR (lo, hi))."""
+    lo, hi = pad[0] - (k - 1), pad[1] - (k - up)
+    crop = max(min(-lo, -hi), 0)
+    return crop, (lo + crop, hi + crop)
+
+
+def _transposed_weight(w, groups):
+    """[Cout, Cin/g, kh, kw] -> the [Cin, Cout/g, kh, kw] layout conv_transpose2d wants."""
+    out_ch, in_ch_per_group, kh, kw = _get_weight_shape(w)
+    if groups == 1:
+        return w.transpose(0, 1)
+    wt = w.reshape(groups, out_ch // groups, in_ch_per_group, kh, kw).transpose(1, 2)
+    return wt.reshape(groups * in_ch_per_group, out_ch // groups, kh, kw)
+
+
+def downsampling_pads(f, down, padding=0):
+    """(px0, px1, py0, py1) of the FIR pass in front of a stride-`down` convolution."""
+    return tuple(_flat(*_axes(f, 1, down, padding)))
+
+
+def downsampling_filter_pass(x, f, down, padding=0, kernel_hw=(3, 3), flip_filter=False):
+    """The FIR pass that ``conv2d_resample`` puts in front of its strided convolution (`down > 1 and up == 1`, non-pointwise kernel): returns the
+    filtered tensor the stride-`down` convolution then reads, so that a caller can run a fused convolution tail on it (ops/fused_down_act.py)."""
+    return _ufd.upfirdn2d(x=x, f=f, padding=list(downsampling_pads(f, down, padding)), flip_filter=flip_filter)
+
+
 def downsampling_conv1x1(x, w, f, down, padding=0, residual=None, flip_filter=False, prefiltered=False):
     """``conv2d_resample`` for a 1x1 kernel with ``down > 1`` (FIR + decimate, then convolve on the small image: the skip branch of the
     residual discriminator block) with the other branch's result added in the convolution's store where the MFMA GEMM serves the shape;
     the fallback adds out of place (the residual is another layer's activation output, which its backward pass still needs)."""
     out_ch, in_ch, kh, kw = _get_weight_shape(w)
     assert kh == 1 and kw == 1 and down > 1
-    fw, fh = _get_filter_size(f)
-    px0, px1, py0, py1 = _parse_padding(padding)
-    pads = [px0 + (fw - down + 1) // 2, px1 + (fw - down) // 2, py0 + (fh - down + 1) // 2, py1 + (fh - down) // 2]
     if not prefiltered:   # (prefiltered: the caller already ran this FIR + decimate pass, e.g. fused_fir_act.fir_down_with_input_alias)
-        x = _ufd.upfirdn2d(x=x, f=f, down=down, padding=pads, flip_filter=flip_filter)
+        x = _ufd.upfirdn2d(x=x, f=f, down=down, padding=list(downsampling_pads(f, down, padding)), flip_filter=flip_filter)
     if residual is not None and _gemm.enabled and w.dtype == torch.float32 and x.is_cuda and _gemm.is_full_tile_conv1x1(x, out_ch) \
             and residual.dtype == torch.float32 and tuple(residual.shape) == (x.shape[0], out_ch, x.shape[2], x.shape[3]):
         return _gemm.conv1x1(x, w, residual=residual)
@@ -73,50 +124,44 @@ def downsampling_conv1x1(x, w, f, down, padding=0, residual=None, flip_filter=Fa
     return y + residual if residual is not None else y
 
 
-def downsampling_pads(f, down, padding=0):
-    """(px0, px1, py0, py1) of the FIR pass in front of a stride-`down` convolution (the arithmetic of ``conv2d_resample`` below)."""
-    fw, fh = _get_filter_size(f)
-    px0, px1, py0, py1 = _parse_padding(padding)
-    return (px0 + (fw - down + 1) // 2, px1 + (fw - down) // 2, py0 + (fh - down + 1) // 2, py1 + (fh - down) // 2)
-
-
-def downsampling_filter_pass(x, f, down, padding=0, kernel_hw=(3, 3), flip_filter=False):
-    """The FIR pass that ``conv2d_resample`` puts in front of its strided convolution (`down > 1 and up == 1`, non-pointwise kernel): returns the
-    filtered tensor the stride-`down` convolution then reads, so that a caller can run a fused convolution tail on it (ops/fused_down_act.py)."""
-    fw, fh = _get_filter_size(f)
-    px0, px1, py0, py1 = _parse_padding(padding)
-    px0 += (fw - down + 1) // 2
-    px1 += (fw - down) // 2
-    py0 += (fh - down + 1) // 2
-    py1 += (fh - down) // 2
-    return _ufd.upfirdn2d(x=x, f=f, padding=[px0, px1, py0, py1], flip_filter=flip_filter)
-
-
 def upsampling_conv_parts(x, w, f, up, padding=0, groups=1, flip_weight=True):
-    """First half of the `up > 1` branch of conv2d_resample: the stride-`up` transposed convolution, WITHOUT the FIR
-    that follows it.  Returns (y, fir_padding): ``upfirdn2d(y, f, padding=fir_padding, gain=up**2)`` completes the op.
-    Used by the synthesis layer to fuse that FIR with the demodulation / bias / activation epilogue."""
+    """First half of the `up > 1` decomposition: the stride-`up` transposed convolution, WITHOUT the FIR that follows it.  Returns (y, fir_padding):
+    ``upfirdn2d(y, f, padding=fir_padding, gain=up**2)`` completes the op.  Used by the synthesis layer to fuse that FIR with the demodulation / bias /
+    activation epilogue."""
     assert up > 1
-    out_ch, in_ch_per_group, kh, kw = _get_weight_shape(w)
-    fw, fh = _get_filter_size(f)
-    px0, px1, py0, py1 = _parse_padding(padding)
-    px0 += (fw + up - 1) // 2
-    px1 += (fw - up) // 2
-    py0 += (fh + up - 1) // 2
-    py1 += (fh - up) // 2
-    if groups == 1:
-        wt = w.transpose(0, 1)
-    else:
-        wt = w.reshape(groups, out_ch // groups, in_ch_per_group, kh, kw).transpose(1, 2)
-        wt = wt.reshape(groups * in_ch_per_group, out_ch // groups, kh, kw)
-    px0 -= kw - 1
-    px1 -= kw - up
-    py0 -= kh - 1
-    py1 -= kh - up
-    pxt = max(min(-px0, -px1), 0)
-    pyt = max(min(-py0, -py1), 0)
-    y = _conv2d_wrapper(x=x, w=wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
-    return y, [px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt]
+    _, _, kh, kw = _get_weight_shape(w)
+    ax, ay = _axes(f, up, 1, padding)
+    cx, fx = _transposed_axis(ax, kw, up)
+    cy, fy = _transposed_axis(ay, kh, up)
+    y = _conv2d_wrapper(x=x, w=_transposed_weight(w, groups), stride=up, padding=[cy, cx], groups=groups, transpose=True, flip_weight=(not flip_weight))
+    return y, _flat(fx, fy)
+
+
+def plan(kernel_hw, f, up=1, down=1, padding=0):
+    """The launches ``conv2d_resample`` decomposes a call into, as a list of (kind, arguments) steps -- the case table of the module docstring, one row each:
+
+      kind 'fir'  : upfirdn2d(x, f or None, up, down, padding, gain = up ** 2)
+      kind 'conv' : convolution (stride, padding [y, x]); 'convT': transposed convolution on the transposed weight
+
+    Pure geometry: no tensors, so the selection is testable on its own (tests/test_ops_cpu.py)."""
+    kh, kw = kernel_hw
+    ax, ay = _axes(f, up, down, padding)
+    pointwise = kh == 1 and kw == 1
+    fir = lambda pads, u=1, d=1, with_filter=True: ('fir', dict(up=u, down=d, padding=pads, gain=u ** 2, with_filter=with_filter))      # noqa: E731
+    conv = lambda stride=1, pad=(0, 0): ('conv', dict(stride=stride, padding=list(pad)))                                              # noqa: E731
+    if up == 1 and down > 1:
+        # the decimation commutes with a 1x1 kernel (filter on the way down, convolve the small image); a k x k kernel strides over the filtered full-size image
+        return [fir(_flat(ax, ay), d=down), conv()] if pointwise else [fir(_flat(ax, ay)), conv(stride=down)]
+    if up > 1 and down == 1 and pointwise:
+        return [conv(), fir(_flat(ax, ay), u=up)]                 # convolve the small image, then zero-insert + filter
+    if up > 1:
+        cx, fx = _transposed_axis(ax, kw, up)
+        cy, fy = _transposed_axis(ay, kh, up)
+        steps = [('convT', dict(stride=up, padding=[cy, cx])), ('fir', dict(up=1, down=1, padding=_flat(fx, fy), gain=up ** 2, with_filter=True))]
+        return steps + ([fir([0, 0, 0, 0], d=down)] if down > 1 else [])
+    if ax[0] == ax[1] and ay[0] == ay[1] and ax[0] >= 0 and ay[0] >= 0:
+        return [conv(pad=(ay[0], ax[0]))]                         # no resampling, padding the convolution can apply itself
+    return [fir(_flat(ax, ay), with_filter=False), conv()]       # ragged / negative padding: pad (or crop) with a filterless pass first
 
 
 @misc.profiled_function
@@ -130,60 +175,12 @@ def conv2d_resample(x, w, f=None, up=1, down=1, padding=0, groups=1, flip_weight
     assert isinstance(up, int) and up >= 1
     assert isinstance(down, int) and down >= 1
     assert isinstance(groups, int) and groups >= 1
-    out_ch, in_ch_per_group, kh, kw = _get_weight_shape(w)
-    fw, fh = _get_filter_size(f)
-    px0, px1, py0, py1 = _parse_padding(padding)
-
-    # Fold the resampling filters' own footprint into the padding (same arithmetic as upsample2d/downsample2d).
-    if up > 1:
-        px0 += (fw + up - 1) // 2
-        px1 += (fw - up) // 2
-        py0 += (fh + up - 1) // 2
-        py1 += (fh - up) // 2
-    if down > 1:
-        px0 += (fw - down + 1) // 2
-        px1 += (fw - down) // 2
-        py0 += (fh - down + 1) // 2
-        py1 += (fh - down) // 2
-    pads = [px0, px1, py0, py1]
-    pointwise = kh == 1 and kw == 1
-
-    if pointwise and down > 1 and up == 1:
-        x = _ufd.upfirdn2d(x=x, f=f, down=down, padding=pads, flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-
-    if pointwise and up > 1 and down == 1:
-        x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-        return _ufd.upfirdn2d(x=x, f=f, up=up, padding=pads, gain=up ** 2, flip_filter=flip_filter)
-
-    if down > 1 and up == 1:
-        x = _ufd.upfirdn2d(x=x, f=f, padding=pads, flip_filter=flip_filter)
-        return _conv2d_wrapper(x=x, w=w, stride=down, groups=groups, flip_weight=flip_weight)
-
-    if up > 1:
-        # Transposed convolution wants [Cin, Cout/groups, kh, kw].
-        if groups == 1:
-            wt = w.transpose(0, 1)
+    _, _, kh, kw = _get_weight_shape(w)
+    for kind, a in plan((kh, kw), f, up=up, down=down, padding=padding):
+        if kind == 'fir':
+            x = _ufd.upfirdn2d(x=x, f=(f if a['with_filter'] else None), up=a['up'], down=a['down'], padding=a['padding'], gain=a['gain'], flip_filter=flip_filter)
+        elif kind == 'conv':
+            x = _conv2d_wrapper(x=x, w=w, stride=a['stride'], padding=a['padding'], groups=groups, flip_weight=flip_weight)
         else:
-            wt = w.reshape(groups, out_ch // groups, in_ch_per_group, kh, kw).transpose(1, 2)
-            wt = wt.reshape(groups * in_ch_per_group, out_ch // groups, kh, kw)
-        px0 -= kw - 1
-        px1 -= kw - up
-        py0 -= kh - 1
-        py1 -= kh - up
-        pxt = max(min(-px0, -px1), 0)
-        pyt = max(min(-py0, -py1), 0)
-        x = _conv2d_wrapper(x=x, w=wt, stride=up, padding=[pyt, pxt], groups=groups, transpose=True, flip_weight=(not flip_weight))
-        x = _ufd.upfirdn2d(x=x, f=f, padding=[px0 + pxt, px1 + pxt, py0 + pyt, py1 + pyt], gain=up ** 2, flip_filter=flip_filter)
-        if down > 1:
-            x = _ufd.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
-        return x
-
-    if up == 1 and down == 1 and px0 == px1 and py0 == py1 and px0 >= 0 and py0 >= 0:
-        return _conv2d_wrapper(x=x, w=w, padding=[py0, px0], groups=groups, flip_weight=flip_weight)
-
-    x = _ufd.upfirdn2d(x=x, f=(f if up > 1 else None), up=up, padding=pads, gain=up ** 2, flip_filter=flip_filter)
-    x = _conv2d_wrapper(x=x, w=w, groups=groups, flip_weight=flip_weight)
-    if down > 1:
-        x = _ufd.upfirdn2d(x=x, f=f, down=down, flip_filter=flip_filter)
+            x = _conv2d_wrapper(x=x, w=_transposed_weight(w, groups), stride=a['stride'], padding=a['padding'], groups=groups, transpose=True, flip_weight=(not flip_weight))
     return x

@@ -191,3 +191,27 @@ def test_gpu_dispatch_has_no_silent_fallback(monkeypatch):
         ufd.upfirdn2d(x, None)
     with pytest.raises((custom_ops.NativeLibraryError, RuntimeError)):
         ba.bias_act(x, None, act='lrelu')
+
+
+def test_conv2d_resample_plan_is_the_case_table_of_the_reference():
+    """`conv2d_resample.plan`: which launches a call decomposes into (src/torch_utils/ops/conv2d_resample.py:107-154), as pure geometry."""
+    from stylegan_v_amd.torch_utils.ops import conv2d_resample as cr, upfirdn2d as _u
+    f = _u.setup_filter([1, 3, 3, 1])
+    kinds = lambda steps: [k for k, _ in steps]      # noqa: E731
+    # 1x1 kernels: decimate first / convolve first
+    p = cr.plan((1, 1), f, down=2)
+    assert kinds(p) == ['fir', 'conv'] and p[0][1]['down'] == 2 and p[0][1]['padding'] == [1, 1, 1, 1] and p[1][1]['stride'] == 1
+    p = cr.plan((1, 1), f, up=2)
+    assert kinds(p) == ['conv', 'fir'] and p[1][1]['up'] == 2 and p[1][1]['gain'] == 4 and p[1][1]['padding'] == [2, 1, 2, 1]
+    # 3x3 kernels: FIR at full resolution then a strided convolution (r -> r + 1 -> r / 2) / transposed convolution then FIR (r -> 2 r + 1 -> 2 r)
+    p = cr.plan((3, 3), f, down=2, padding=1)
+    assert kinds(p) == ['fir', 'conv'] and p[0][1]['padding'] == [2, 2, 2, 2] and p[0][1]['down'] == 1 and p[1][1]['stride'] == 2
+    p = cr.plan((3, 3), f, up=2, padding=1)
+    assert kinds(p) == ['convT', 'fir'] and p[0][1] == dict(stride=2, padding=[0, 0]) and p[1][1]['padding'] == [1, 1, 1, 1] and p[1][1]['gain'] == 4
+    p = cr.plan((3, 3), f, up=2, down=2, padding=1)
+    assert kinds(p) == ['convT', 'fir', 'fir'] and p[2][1]['down'] == 2
+    # no resampling: the convolution pads itself when it can, a filterless pass pads / crops otherwise
+    assert cr.plan((3, 3), None, padding=1) == [('conv', dict(stride=1, padding=[1, 1]))]
+    p = cr.plan((3, 3), None, padding=[1, 0, -1, 2])
+    assert kinds(p) == ['fir', 'conv'] and p[0][1]['with_filter'] is False and p[0][1]['padding'] == [1, 0, -1, 2]
+    assert cr.downsampling_pads(f, 2, 1) == (2, 2, 2, 2)
