@@ -71,7 +71,7 @@
 extern "C" {
 #endif
 
-#define SGV_VERSION 103 /* major*100 + minor */
+#define SGV_VERSION 104 /* major*100 + minor */
 
 /* element types (the reference dispatches double/float/half: upfirdn2d.cpp:59, bias_act.cpp:76;
  * bf16 is this library's extension) */
@@ -497,6 +497,11 @@ typedef struct sgv_fc_params {
     int32_t accumulate;     /* C += epi(...) instead of C = epi(...) */
 } sgv_fc_params;
 int sgv_fc(const sgv_fc_params* p, void* stream);
+/* `count` independent problems (HOST array) in one launch per 24 problems: the style affines of a synthesis pass (src/training/networks.py:116,128,153,160 --
+ * `self.affine(w)` of every SynthesisLayer / ToRGBLayer) forward, their data gradients and their weight gradients.  The problems of one call may differ in every
+ * pointer, size, row stride, weight gain and activation gain; they share the operand contiguity (a_stride_k == 1, b_stride_k == 1 or not), act, alpha, epilogue_act,
+ * bias_gain, c_stride_n and accumulate, and none is batched or normalising (SGV_ERR_UNSUPPORTED otherwise). */
+int sgv_fc_grouped(const sgv_fc_params* problems, int32_t count, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * In-place torch.nan_to_num(x, nan, posinf, neginf) over a LIST of fp32 tensors in one launch per 96 tensors: the per-parameter gradient

@@ -53,7 +53,7 @@ constexpr int FC_WAVES = 16;     // at most
 
 // FC_UNROLL = k steps whose loads are issued together
 template <int AK, int BK, int FC_UNROLL>
-__global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
+__device__ __forceinline__ void fc_body(const fc_params& p, const size_t bz) {
     extern __shared__ float red[];          // [max(waves - 1, 1)][32 * 32]
     __shared__ float rowstat[32];
     const int waves = blockDim.x >> 6;
@@ -62,7 +62,6 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
     const int n0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
     const int am = m0 + r, bn = n0 + r;
     const bool a_ok = am < p.m, b_ok = bn < p.n;
-    const size_t bz = blockIdx.z;
     const float* ap = p.a + bz * p.sab + (size_t)(a_ok ? am : 0) * p.sam;
     const float* arp = p.aref ? p.aref + bz * p.sab + (size_t)(a_ok ? am : 0) * p.sam : nullptr;
     const float* bp = p.b + bz * p.sbb + (size_t)(b_ok ? bn : 0) * p.sbn;
@@ -161,6 +160,35 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) {
     }
 }
 
+template <int AK, int BK, int FC_UNROLL>
+__global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(fc_params p) { fc_body<AK, BK, FC_UNROLL>(p, blockIdx.z); }
+
+// Several independent small products in ONE launch (round 6): the style affines of a synthesis pass -- 21 dense layers [frames, 512] x [512, C_l] with their own
+// weight, bias, output and (ToRGB) output gain, each 10-14 us as a launch of its own whatever the batch: 107-118 dense launches per training iteration were 1.6 ms.
+// blockIdx.z picks the problem; the table rides in the kernel arguments (capture-safe); the grid spans the largest problem, workgroups outside their own problem leave.
+struct fc_group_item {
+    const float* a; const float* aref; const float* b; float* c; const float* bias; float* colsum;
+    int64_t sam, sak, sbk, sbn, scm;
+    int m, n, k;
+    float wgain, gain;
+};
+constexpr int FC_GROUP_MAX = 24;
+struct fc_group {
+    fc_params base;       // everything the problems share (activation, flags, bias gain, column strides)
+    fc_group_item item[FC_GROUP_MAX];
+};
+
+template <int AK, int BK>
+__global__ __launch_bounds__(FC_WAVES * 64) void fc_group_kernel(fc_group g) {
+    const fc_group_item& it = g.item[blockIdx.z];
+    if ((int)blockIdx.x * 32 >= it.n || (int)blockIdx.y * 32 >= it.m) return;      // (workgroup-uniform, in front of every barrier)
+    fc_params p = g.base;
+    p.a = it.a; p.aref = it.aref; p.b = it.b; p.c = it.c; p.bias = it.bias; p.colsum = it.colsum;
+    p.sam = it.sam; p.sak = it.sak; p.sbk = it.sbk; p.sbn = it.sbn; p.scm = it.scm;
+    p.m = it.m; p.n = it.n; p.k = it.k; p.wgain = it.wgain; p.gain = it.gain;
+    fc_body<AK, BK, 1>(p, 0);
+}
+
 }  // namespace sgv_fck
 
 static int sgv_fc_launch(const sgv_fc_params* q, hipStream_t stream, bool account) {
@@ -217,4 +245,52 @@ extern "C" int sgv_fc(const sgv_fc_params* q, void* stream_) {
     if ((q->m + 31) / 32 > 65535 || q->batch > 65535 || q->batch < 0) return sgv_fail(SGV_ERR_TOO_LARGE, "fc: too many rows / batches");
     if (q->batch > 1 && (q->a_rowsum || q->normalize_a)) return sgv_fail(SGV_ERR_UNSUPPORTED, "fc: row statistics are not batched");
     return sgv_fc_launch(q, (hipStream_t)stream_, true);
+}
+
+extern "C" int sgv_fc_grouped(const sgv_fc_params* q, int32_t count, void* stream_) {
+    if (!q || count < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "fc_grouped: no problems");
+    hipStream_t stream = (hipStream_t)stream_;
+    const bool ak = q[0].a_stride_k == 1, bk = q[0].b_stride_k == 1;
+    for (int i = 0; i < count; i++) {
+        const sgv_fc_params& e = q[i];
+        if (!e.a || !e.b || !e.c) return sgv_fail(SGV_ERR_INVALID_ARG, "fc_grouped: NULL pointer in problem %d", i);
+        if (e.m < 1 || e.n < 1 || e.k < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "fc_grouped: sizes must be positive (problem %d)", i);
+        if (e.batch > 1 || e.normalize_a) return sgv_fail(SGV_ERR_UNSUPPORTED, "fc_grouped: batched / normalising problems take sgv_fc");
+        if ((e.a_stride_k == 1) != ak || (e.b_stride_k == 1) != bk || e.act != q[0].act || e.epilogue_act != q[0].epilogue_act || e.alpha != q[0].alpha
+            || e.bias_gain != q[0].bias_gain || e.c_stride_n != q[0].c_stride_n || (e.a_ref == nullptr) != (q[0].a_ref == nullptr) || e.accumulate != q[0].accumulate)
+            return sgv_fail(SGV_ERR_UNSUPPORTED, "fc_grouped: the problems of one call share the operand contiguity, the activation and the bias gain (problem %d differs)", i);
+        if (e.act != 1 && e.act != 3) return sgv_fail(SGV_ERR_INVALID_ARG, "fc_grouped: act must be 1 (linear) or 3 (lrelu)");
+    }
+    for (int first = 0; first < count; first += sgv_fck::FC_GROUP_MAX) {
+        const int cnt = std::min(count - first, sgv_fck::FC_GROUP_MAX);
+        sgv_fck::fc_group g{};
+        const sgv_fc_params& h = q[first];
+        g.base.act = h.act; g.base.alpha = h.alpha; g.base.bgain = h.bias_gain; g.base.epilogue_act = h.epilogue_act; g.base.scn = h.c_stride_n; g.base.accumulate = h.accumulate;
+        int max_m = 0, max_n = 0, max_k = 0;
+        double bytes = 0.0, flops = 0.0;
+        for (int i = 0; i < cnt; i++) {
+            const sgv_fc_params& e = q[first + i];
+            sgv_fck::fc_group_item& it = g.item[i];
+            it.a = e.a; it.aref = e.a_ref; it.b = e.b; it.c = e.c; it.bias = e.bias; it.colsum = e.a_rowsum;
+            it.sam = e.a_stride_m; it.sak = e.a_stride_k; it.sbk = e.b_stride_k; it.sbn = e.b_stride_n; it.scm = e.c_stride_m;
+            it.m = e.m; it.n = e.n; it.k = e.k; it.wgain = e.weight_gain; it.gain = e.gain;
+            max_m = std::max(max_m, e.m); max_n = std::max(max_n, e.n); max_k = std::max(max_k, e.k);
+            bytes += 4.0 * ((double)e.m * e.k + (double)e.n * e.k + (double)e.m * e.n);
+            flops += 2.0 * e.m * (double)e.n * e.k;
+        }
+        if ((max_m + 31) / 32 > 65535) return sgv_fail(SGV_ERR_TOO_LARGE, "fc_grouped: too many rows");
+        const int steps = (max_k + 7) / 8;
+        const int waves = std::max(1, std::min(sgv_fck::FC_WAVES, steps));
+        const size_t lds = (size_t)std::max(waves - 1, 1) * 1024 * sizeof(float);
+        dim3 grid((unsigned)((max_n + 31) / 32), (unsigned)((max_m + 31) / 32), (unsigned)cnt), block(waves * 64);
+        sgv_launch_scope scope(SGV_K_FC, stream, bytes, flops);
+        if (ak && bk) hipLaunchKernelGGL((sgv_fck::fc_group_kernel<1, 1>), grid, block, lds, stream, g);
+        else if (ak) hipLaunchKernelGGL((sgv_fck::fc_group_kernel<1, 0>), grid, block, lds, stream, g);
+        else if (bk) hipLaunchKernelGGL((sgv_fck::fc_group_kernel<0, 1>), grid, block, lds, stream, g);
+        else hipLaunchKernelGGL((sgv_fck::fc_group_kernel<0, 0>), grid, block, lds, stream, g);
+        sgv_note_variant(SGV_V_fc_grouped);
+        const int rc = sgv_check_launch("fc_group_kernel");
+        if (rc != SGV_OK) return rc;
+    }
+    return SGV_OK;
 }

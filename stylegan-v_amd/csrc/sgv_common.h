@@ -128,7 +128,7 @@ __device__ __forceinline__ void sgv_amax_commit_wg(unsigned m, float* sink, unsi
     X(wrw_s1_ws) X(wrw_s1_ws_scaled) X(wrw_s1_ws_packed) X(wrw_s1_4wave) X(wrw_s2_ws) X(wrw_s2_ws_packed) X(wrw_s2_4wave) X(wrw_s2_4wave_packed) \
     X(ufd_tile) X(ufd_tile_fused1) X(ufd_tile_fused3) X(ufd_lanes) X(ufd_lanes_seg) X(ufd_lanes_fused1) X(ufd_lanes_fused2) X(ufd_lanes_fused3) X(ufd_lanes_fused4) X(ufd_rows) X(ufd_generic) \
     X(pw_many2few) X(pw_few2many) X(pw_few2many_act) X(pw_outer) X(gemm_f32) X(gemm_bf16x3) X(fc) X(bias_act) X(conv_lowp) X(wrw_lowp) X(conv_s2_lowp) X(convT_lowp) X(wrw_s2_lowp) X(gemm_bf16x3_stream) X(conv1x1_wstat) \
-    X(conv_s1_half_tile) X(convT_half_tile) X(ufd_tile_down2) X(ufd_tile_up2) X(ufd_tile_up2_add) X(ufd_tile_fused2)
+    X(conv_s1_half_tile) X(convT_half_tile) X(ufd_tile_down2) X(ufd_tile_up2) X(ufd_tile_up2_add) X(ufd_tile_fused2) X(fc_grouped)
 enum sgv_variant_id {
 #define SGV_V_ENUM(name) SGV_V_##name,
     SGV_VARIANTS(SGV_V_ENUM)

@@ -314,6 +314,7 @@ ABI_SYMBOLS = {
     'sgv_ada_geometric': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_gemm_f32': (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
     'sgv_fc': (c_int, [ctypes.POINTER(FcParams), c_void_p]),
+    'sgv_fc_grouped': (c_int, [ctypes.POINTER(FcParams), c_int32, c_void_p]),
     'sgv_multi_nan_to_num_f32': (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), c_int32, c_float, c_float, c_float, c_void_p]),
     'sgv_multi_scale_f32': (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int64), ctypes.POINTER(c_float), c_int32, c_void_p]),
     'sgv_prof_enable': (c_int, [c_int32]),

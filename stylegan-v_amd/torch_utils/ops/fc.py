@@ -117,3 +117,101 @@ def dense(x, weight, bias=None, weight_gain=1.0, bias_gain=1.0, act='linear', no
             return _ba.bias_act(_gemm.linear(x, weight * weight_gain), b, act=act, gain=again)
         return _DenseFn.apply(x, weight, bias, (float(weight_gain), float(bias_gain), act, bool(normalize), again))
     return dense_ref(x, weight, bias, weight_gain, bias_gain, act, normalize, act_gain)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------
+# The style affines of a synthesis pass as ONE launch forward and TWO backward (``sgv_fc_grouped``).  Every SynthesisLayer / ToRGBLayer owns
+# ``affine = FullyConnectedLayer(w_dim, in_channels, bias_init=1)`` (networks.py:116,153) and calls it on its own column of ws: 21 dense launches per
+# pass at FFS-256 (27 at 1024^2), 10-14 us each whatever the batch -- 1.6 ms of a 150-ms training iteration, 3.5 % of the 8-videos-per-GPU step.
+
+grouped = True
+
+
+def _fc_problem(a, sam, sak, b, sbk, sbn, c, scm, m, n, k, a_ref=None, bias=None, rowsum=None, act=1, alpha=0.0, gain=1.0, wgain=1.0, bgain=1.0, epilogue_act=False):
+    return custom_ops.FcParams(a, sam, sak, a_ref, b, sbk, sbn, c, scm, 1, bias, rowsum, m, n, k, 0, act, alpha, gain, wgain, bgain, int(epilogue_act), 1, 0, 0, 0, 0)
+
+
+def _launch_group(problems, device_tensor):
+    lib = custom_ops.get_native()
+    arr = (custom_ops.FcParams * len(problems))(*problems)
+    with custom_ops.device_guard(device_tensor):
+        custom_ops.check(lib.sgv_fc_grouped(arr, len(problems), custom_ops.raw_stream(device_tensor)), lib)
+
+
+class _GroupedAffineFn(torch.autograd.Function):
+    """styles_l = (ws[:, idx_l] @ (W_l * wg_l)^T + b_l * bg) * gain_l for every layer l, one launch; inputs: ws, W_0 .. W_{L-1}, b_0 .. b_{L-1}."""
+
+    @staticmethod
+    def forward(ctx, ws, cfg, *wb):
+        idx, wgains, bgain, gains = cfg
+        L = len(idx)
+        weights, biases = wb[:L], wb[L:]
+        wsc = ws if (ws.is_contiguous() and ws.data_ptr() % 16 == 0) else ws.contiguous()
+        m, nws, k = wsc.shape
+        outs = [torch.empty([m, w.shape[0]], dtype=torch.float32, device=ws.device) for w in weights]
+        wcs = [w.contiguous() for w in weights]
+        bcs = [b.contiguous() for b in biases]
+        _launch_group([_fc_problem(wsc.data_ptr() + 4 * k * i, nws * k, 1, w.data_ptr(), 1, k, y.data_ptr(), w.shape[0], m, w.shape[0], k, bias=b.data_ptr(),
+                                   gain=g, wgain=wg, bgain=bgain, epilogue_act=True) for i, w, b, y, wg, g in zip(idx, wcs, bcs, outs, wgains, gains)], wsc)
+        ctx.cfg = cfg
+        ctx.save_for_backward(ws, *wb)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        idx, wgains, bgain, gains = ctx.cfg
+        L = len(idx)
+        ws = ctx.saved_tensors[0]
+        weights, biases = ctx.saved_tensors[1:1 + L], ctx.saved_tensors[1 + L:]
+        if torch.is_grad_enabled():
+            # create_graph (path-length regularisation differentiates the styles twice): the composition, layer by layer
+            with torch.enable_grad():
+                ins = [t for t, need in zip((ws,) + tuple(weights) + tuple(biases), [ctx.needs_input_grad[0]] + list(ctx.needs_input_grad[2:])) if need]
+                ys = [dense_ref(ws[:, i], w, b, wg, bgain, 'linear', False, g) for i, w, b, wg, g in zip(idx, weights, biases, wgains, gains)]
+                live = [(y, dy) for y, dy in zip(ys, dys) if dy is not None]
+                grads = iter(torch.autograd.grad([y for y, _ in live], ins, [dy for _, dy in live], create_graph=True, allow_unused=True))
+            return (next(grads) if ctx.needs_input_grad[0] else None, None) + tuple(next(grads) if need else None for need in ctx.needs_input_grad[2:])
+        m, nws, k = ws.shape
+        wsc = ws if (ws.is_contiguous() and ws.data_ptr() % 16 == 0) else ws.contiguous()
+        dyc = [dy.contiguous() if dy is not None else torch.zeros([m, w.shape[0]], dtype=torch.float32, device=ws.device) for dy, w in zip(dys, weights)]
+        wcs = [w.contiguous() for w in weights]
+        d_ws = None
+        if ctx.needs_input_grad[0]:
+            # Every layer writes its data gradient straight into its column of d(ws) (row stride nws * k).  A column of ws may feed two layers (each ToRGB shares its
+            # w with the next block's conv0, networks.py:354-357): its second user ACCUMULATES, in a second launch behind the first.  (No index tensors, no host data:
+            # the pass is replayed inside hipGraphs.)
+            first, second, seen = [], [], set()
+            for j, i in enumerate(idx):
+                (second if i in seen else first).append(j)
+                seen.add(i)
+            d_ws = (torch.empty if len(seen) == nws else torch.zeros)([m, nws, k], dtype=torch.float32, device=ws.device)
+            for group, acc in ((first, 0), (second, 1)):
+                if group:
+                    probs = [_fc_problem(dyc[j].data_ptr(), wcs[j].shape[0], 1, wcs[j].data_ptr(), k, 1, d_ws.data_ptr() + 4 * k * idx[j], nws * k, m, k, wcs[j].shape[0],
+                                         a_ref=dyc[j].data_ptr(), gain=gains[j], wgain=wgains[j]) for j in group]      # (a_ref = dy: a linear activation only applies the output gain there)
+                    for pr in probs:
+                        pr.accumulate = acc
+                    _launch_group(probs, wsc)
+        d_w = [None] * L
+        d_b = [None] * L
+        need_w = list(ctx.needs_input_grad[2:2 + L])
+        need_b = list(ctx.needs_input_grad[2 + L:])
+        if any(need_w) or any(need_b):
+            d_w = [torch.empty_like(w) for w in wcs]
+            d_b = [torch.empty([w.shape[0]], dtype=torch.float32, device=ws.device) for w in wcs]
+            _launch_group([_fc_problem(dy.data_ptr(), 1, w.shape[0], wsc.data_ptr() + 4 * k * i, nws * k, 1, dw.data_ptr(), k, w.shape[0], k, m, a_ref=dy.data_ptr(),
+                                       rowsum=db.data_ptr(), gain=g, wgain=wg, bgain=bgain) for i, dy, w, dw, db, wg, g in zip(idx, dyc, wcs, d_w, d_b, wgains, gains)], wsc)
+        return (d_ws, None) + tuple(d_w) + tuple(d_b)
+
+
+def grouped_affine(ws, idx, layers, gains=None):
+    """[layer.forward(ws[:, i], gain=g) for layer, i, g in zip(layers, idx, gains)] for FullyConnectedLayer modules with linear activation and a bias, as one launch.
+    ws [M, num_ws, K] fp32; returns a tuple of [M, out_features_l] tensors.  Falls back to the per-layer calls where the kernel does not apply."""
+    gains = [1.0 if g is None else float(g) for g in (gains or [None] * len(layers))]
+    ok = (grouped and enabled and ws.is_cuda and ws.ndim == 3 and ws.dtype == torch.float32 and len(layers) > 1 and ws.shape[0] <= 65535 * 32
+          and all(l.activation == 'linear' and l.bias is not None and l.weight.dtype == torch.float32 and l.bias.dtype == torch.float32 and l.weight.shape[1] == ws.shape[2]
+                  and l.bias_gain == layers[0].bias_gain for l in layers))
+    if not ok:
+        return tuple(l(ws[:, i], gain=(None if g == 1.0 else g)) for l, i, g in zip(layers, idx, gains))
+    cfg = (tuple(int(i) for i in idx), tuple(float(l.weight_gain) for l in layers), float(layers[0].bias_gain), tuple(gains))
+    return _GroupedAffineFn.apply(ws, cfg, *[l.weight for l in layers], *[l.bias for l in layers])

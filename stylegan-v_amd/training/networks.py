@@ -31,7 +31,7 @@ import numpy as np
 import torch
 
 from ..torch_utils import misc
-from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, eqlr, fma, fused_conv_act, fused_fir_act, modulation, pointwise, upfirdn2d
+from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, eqlr, fc, fma, fused_conv_act, fused_fir_act, modulation, pointwise, upfirdn2d
 from .layers import Conv2dLayer, FullyConnectedLayer, GenInput, MappingNetwork, TemporalDifferenceEncoder
 from .motion import MotionMappingNetwork
 
@@ -105,10 +105,12 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1):
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, styles=None):
+        """``styles``: ``self.affine(w)`` already evaluated by the caller (SynthesisNetwork.forward runs the affines of a whole pass as one launch)."""
         assert noise_mode in ('random', 'const', 'none')
         misc.assert_shape(x, [None, self.weight.shape[1], self.resolution // self.up, self.resolution // self.up])
-        styles = self.affine(w)
+        if styles is None:
+            styles = self.affine(w)
         noise = None
         if self.cfg.use_noise and noise_mode == 'random':
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device) * self.noise_strength
@@ -155,8 +157,9 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / math.sqrt(in_channels * kernel_size ** 2)
 
-    def forward(self, x, w, fused_modconv=True):
-        styles = self.affine(w, gain=self.weight_gain)      # (networks.py:314: affine(w) * weight_gain; the factor rides on the dense kernel's output gain)
+    def forward(self, x, w, fused_modconv=True, styles=None):
+        if styles is None:
+            styles = self.affine(w, gain=self.weight_gain)      # (networks.py:314: affine(w) * weight_gain; the factor rides on the dense kernel's output gain)
         oc, ic, kh, kw = self.weight.shape
         if kh == 1 and kw == 1 and oc <= 4 and pointwise.enabled and x.is_cuda and x.is_contiguous():
             # y[n,o] = sum_i x[n,i] * (W[o,i] * s[n,i]): the style goes into per-sample weights [N,3,I] and the whole layer is
@@ -198,7 +201,12 @@ class SynthesisBlock(torch.nn.Module):
             self.skip = Conv2dLayer(in_channels, out_channels, kernel_size=1, bias=False, up=2, resample_filter=resample_filter,
                                     channels_last=self.channels_last)
 
-    def forward(self, x, img, ws, motion_v=None, force_fp32=False, fused_modconv=None, **layer_kwargs):
+    def affine_layers(self):
+        """The layers that own a style affine, in call order (one column of this block's ws each)."""
+        return ([self.conv0] if self.in_channels != 0 else []) + [self.conv1] + ([self.torgb] if (self.is_last or self.architecture == 'skip') else [])
+
+    def forward(self, x, img, ws, motion_v=None, force_fp32=False, fused_modconv=None, styles=None, **layer_kwargs):
+        s_iter = iter(styles) if styles is not None else iter(lambda: None, 0)      # (styles: one tensor per affine_layers() entry, or None: every layer runs its own)
         if isinstance(ws, (tuple, list)):
             # the per-layer latents already split by the caller (SynthesisNetwork.forward unbinds `ws` ONCE: one stack in the backward pass instead of a
             # cat + zero-fill + copy + add per block, 20 launches per generator backward)
@@ -216,24 +224,24 @@ class SynthesisBlock(torch.nn.Module):
 
         if self.in_channels == 0:
             x = self.input(ws.shape[0], motion_v=motion_v, dtype=dtype, memory_format=fmt)
-            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+            x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter), **layer_kwargs)
         else:
             misc.assert_shape(x, [None, self.in_channels, self.resolution // 2, self.resolution // 2])
             x = x.to(dtype=dtype, memory_format=fmt)
             if self.architecture == 'resnet':
                 y = self.skip(x, gain=math.sqrt(0.5))
-                x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-                x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=math.sqrt(0.5), **layer_kwargs)
+                x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter), **layer_kwargs)
+                x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=math.sqrt(0.5), styles=next(s_iter), **layer_kwargs)
                 x = y.add_(x)
             else:
-                x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
-                x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, **layer_kwargs)
+                x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter), **layer_kwargs)
+                x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter), **layer_kwargs)
 
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter)).to(dtype=torch.float32, memory_format=torch.contiguous_format)
             img = img.add_(y) if img is not None else y
         assert x.dtype == dtype
         assert img is None or img.dtype == torch.float32
@@ -285,12 +293,29 @@ class SynthesisNetwork(torch.nn.Module):
         x = img = None
         w_idx = 0
         all_w = ws.unbind(dim=1)
+        # The style affines of the whole pass (every SynthesisLayer / ToRGBLayer: `self.affine(w)`, networks.py:116,153) as ONE launch, and two in the backward
+        # pass (ops/fc.py `grouped_affine` -> sgv_fc_grouped): 21 launches of 10-14 us each at FFS-256 otherwise, whatever the batch.
+        all_styles = None
+        if fc.grouped and ws.is_cuda and ws.dtype == torch.float32:
+            layers, cols, gains, k = [], [], [], 0
+            for res in self.block_resolutions:
+                block = getattr(self, f'b{res}')
+                for j, layer in enumerate(block.affine_layers()):
+                    layers.append(layer.affine)
+                    cols.append(k + j)
+                    gains.append(layer.weight_gain if isinstance(layer, ToRGBLayer) else None)
+                k += block.num_conv
+            all_styles = fc.grouped_affine(ws, cols, layers, gains)
+        s_idx = 0
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
             # each ToRGB shares its w with the next block's conv0: advance by num_conv only (networks.py:354-357)
             cur_ws = all_w[w_idx:w_idx + block.num_conv + block.num_torgb]
             w_idx += block.num_conv
-            x, img = block(x, img, cur_ws, motion_v=motion_v if cond == 'concat_const' else None, **block_kwargs)
+            n_aff = block.num_conv + block.num_torgb
+            cur_styles = all_styles[s_idx:s_idx + n_aff] if all_styles is not None else None
+            s_idx += n_aff
+            x, img = block(x, img, cur_ws, motion_v=motion_v if cond == 'concat_const' else None, styles=cur_styles, **block_kwargs)
         return img
 
 

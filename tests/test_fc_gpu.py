@@ -7,7 +7,7 @@ import torch
 from stylegan_v_amd.torch_utils import custom_ops
 from stylegan_v_amd.torch_utils.ops import fc
 import oracle
-from util import dispatch_assert
+from util import assert_close, dispatch_assert
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -155,3 +155,49 @@ def test_row_strided_input_is_read_in_place():
         else:
             assert torch.equal(a, c), name
     assert fc._rows(ws[:, :, 5]) is not ws[:, :, 5]          # a column of the trailing dimension is not rows of contiguous floats: copied
+
+
+def test_grouped_affine_equals_the_per_layer_calls():
+    """ops/fc.py `grouped_affine` (sgv_fc_grouped: the style affines of a synthesis pass as one launch, two in the backward pass) against the per-layer
+    FullyConnectedLayer calls it replaces: outputs, d(ws) -- with columns of ws shared by two layers, as ToRGB / next conv0 share theirs --, d(weight), d(bias);
+    different widths, an output gain on some layers (ToRGB's weight_gain), a ws slice that is not contiguous."""
+    from stylegan_v_amd.training.layers import FullyConnectedLayer
+    torch.manual_seed(11)
+    m, nws, k = 96, 7, 512
+    widths = [512, 512, 512, 256, 256, 128, 64, 64, 3 * 40]
+    cols = [0, 1, 1, 2, 3, 3, 4, 5, 6]
+    gains = [None, None, 0.044, None, None, 0.0625, None, None, 0.5]
+    layers = [FullyConnectedLayer(k, n, bias_init=1).to(DEV) for n in widths]
+    for l in layers:
+        l.bias.data.normal_()
+    ws = torch.randn([m, nws, k], device=DEV).requires_grad_(True)
+    dys = [torch.randn([m, n], device=DEV) for n in widths]
+    before = custom_ops.launch_count()
+    got = fc.grouped_affine(ws, cols, layers, gains)
+    assert custom_ops.launch_count() - before == 1, 'the forward pass must be ONE launch'
+    params = [p for l in layers for p in (l.weight, l.bias)]
+    before = custom_ops.launch_count()
+    g_got = torch.autograd.grad(got, [ws] + params, dys)
+    assert custom_ops.launch_count() - before == 3, 'data gradients (first users of a ws column, then the accumulating second users) and weight gradients'
+    fc.grouped = False
+    try:
+        want = fc.grouped_affine(ws, cols, layers, gains)
+    finally:
+        fc.grouped = True
+    g_want = torch.autograd.grad(want, [ws] + params, dys)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), 'same kernel body, same arithmetic: bit-equal outputs'
+    for a, b, name in zip(g_got, g_want, ['ws'] + [f'layer{i // 2}.{"weight" if i % 2 == 0 else "bias"}' for i in range(len(params))]):
+        assert_close(a, b, atol=2e-6 * b.abs().max().item(), rtol=1e-6, what=name)       # (d(ws): two contributions per shared column, summed in another order)
+    # second order (the path-length regulariser differentiates the styles twice): the create_graph route exists and matches
+    got = fc.grouped_affine(ws, cols, layers, gains)
+    (g1,) = torch.autograd.grad(got, [ws], dys, create_graph=True)
+    (g2,) = torch.autograd.grad(g1.square().sum(), [layers[0].weight])
+    fc.grouped = False
+    try:
+        want = fc.grouped_affine(ws, cols, layers, gains)
+    finally:
+        fc.grouped = True
+    (h1,) = torch.autograd.grad(want, [ws], dys, create_graph=True)
+    (h2,) = torch.autograd.grad(h1.square().sum(), [layers[0].weight])
+    assert_close(g2, h2, atol=1e-5 * h2.abs().max().item(), rtol=1e-5, what='d2 / d(ws) d(weight)')
