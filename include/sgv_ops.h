@@ -188,6 +188,10 @@ int sgv_weight_sqsum(const float* w, float* wsq, int32_t oc, int32_t ic, int32_t
 /* dcoefs[n*O + o] = rsqrt(sum_i (styles[n*I+i])^2 * wsq[o*I+i] + eps) */
 int sgv_demod_coefs(const float* styles, const float* wsq, float* dcoefs, int32_t n, int32_t oc,
                     int32_t ic, float eps, void* stream);
+/* First-order gradients of sgv_demod_coefs in one launch: with g = -grad_d * dcoefs^3 ([n, oc]), grad_w[o,i,k] = weight[o,i,k] * sum_n g[n,o] styles[n,i]^2 and
+ * grad_s[n,i] = styles[n,i] * sum_o g[n,o] wsq[o,i]  (the backward of networks.py:59-61 without w[N,O,I,k,k]); grad_w or grad_s may be NULL.  kk = kh * kw. */
+int sgv_demod_coefs_backward(const float* grad_d, const float* dcoefs, const float* styles, const float* wsq, const float* weight, float* grad_w, float* grad_s,
+                             int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream);
 /* y[n,c,hw] = x[n,c,hw] * s[n*C + c] (+ optional per-[n,hw] noise), contiguous NCHW,
  * x/y of dtype `dtype`, s fp32.  Used for x*styles and x*dcoefs (networks.py:66,70-71). */
 /* out[p] += sum_i a[p,i] * b[p,i] over `planes` planes of hw elements (fp32 accumulate, atomics; the caller zero-initialises out):

@@ -334,6 +334,53 @@ extern "C" int sgv_demod_coefs(const float* styles, const float* wsq, float* dco
     return sgv_check_launch("demod_coefs_kernel");
 }
 
+// First-order backward of the demodulation coefficients (round 6: the chain was 8 torch launches per layer on [N, O] / [O, I]-sized tensors, ~100 per generator
+// backward):   g[n,o] = -grad_d[n,o] d[n,o]^3;   grad_w[o,i,k] = W[o,i,k] sum_n g[n,o] s[n,i]^2;   grad_s[n,i] = s[n,i] sum_o g[n,o] q[o,i]
+// (d = (s^2 q^T + eps)^(-1/2): dd/d(s^2 q^T) = -d^3 / 2, and the 2 of d(s^2) = 2 s ds, d(q) = 2 W dW cancels it).
+// One launch: workgroups [0, O x ceil(I / 256)) own one output channel and 256 input channels of grad_w, the next N x ceil(I / 256) one sample of grad_s.
+__global__ __launch_bounds__(256) void demod_backward_kernel(const float* __restrict__ grad_d, const float* __restrict__ d, const float* __restrict__ s, const float* __restrict__ q,
+                                                            const float* __restrict__ w, float* __restrict__ grad_w, float* __restrict__ grad_s,
+                                                            int n_samples, int oc, int ic, int kk, int w_blocks) {
+    const int itiles = (ic + 255) / 256;
+    if ((int)blockIdx.x < w_blocks) {
+        const int o = blockIdx.x / itiles, i = (blockIdx.x % itiles) * 256 + threadIdx.x;
+        if (i >= ic) return;
+        float acc = 0.f;
+        for (int n = 0; n < n_samples; n++) {
+            const float dd = d[(size_t)n * oc + o];
+            const float g = -grad_d[(size_t)n * oc + o] * dd * dd * dd;      // (wave-uniform: scalar loads)
+            const float sv = s[(size_t)n * ic + i];
+            acc = __builtin_fmaf(g, sv * sv, acc);
+        }
+        const size_t at = ((size_t)o * ic + i) * kk;
+        for (int k = 0; k < kk; k++) grad_w[at + k] = w[at + k] * acc;
+    } else {
+        const int b = blockIdx.x - w_blocks;
+        const int n = b / itiles, i = (b % itiles) * 256 + threadIdx.x;
+        if (i >= ic) return;
+        float acc = 0.f;
+        for (int o = 0; o < oc; o++) {
+            const float dd = d[(size_t)n * oc + o];
+            const float g = -grad_d[(size_t)n * oc + o] * dd * dd * dd;
+            acc = __builtin_fmaf(g, q[(size_t)o * ic + i], acc);
+        }
+        grad_s[(size_t)n * ic + i] = s[(size_t)n * ic + i] * acc;
+    }
+}
+
+extern "C" int sgv_demod_coefs_backward(const float* grad_d, const float* dcoefs, const float* styles, const float* wsq, const float* weight, float* grad_w, float* grad_s,
+                                        int32_t n, int32_t oc, int32_t ic, int32_t kk, void* stream_) {
+    if (!grad_d || !dcoefs || !styles || !wsq || (!grad_w && !grad_s) || (grad_w && !weight)) return sgv_fail(SGV_ERR_INVALID_ARG, "demod_coefs_backward: NULL pointer");
+    if (n < 1 || oc < 1 || ic < 1 || kk < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "demod_coefs_backward: sizes must be positive");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int itiles = (ic + 255) / 256;
+    const int64_t wb = grad_w ? (int64_t)oc * itiles : 0, sb = grad_s ? (int64_t)n * itiles : 0;
+    if (wb + sb > 0x7fffffff) return sgv_fail(SGV_ERR_TOO_LARGE, "demod_coefs_backward: too many workgroups");
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, ((double)oc * ic * (2.0 * kk + 1.0) + 2.0 * n * ic + 2.0 * n * oc) * 4.0);
+    hipLaunchKernelGGL(demod_backward_kernel, dim3((unsigned)(wb + sb)), dim3(256), 0, stream, grad_d, dcoefs, styles, wsq, weight, grad_w, grad_s, n, oc, ic, kk, (int)wb);
+    return sgv_check_launch("demod_backward_kernel");
+}
+
 extern "C" int sgv_scale_channels(const void* x, const float* s, void* y, int32_t n, int32_t c, int32_t hw, int dtype,
                                   void* stream_) {
     if (!x || !s || !y) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_channels: NULL pointer");

@@ -279,6 +279,7 @@ ABI_SYMBOLS = {
     'sgv_bias_act_db': (c_int, [ctypes.POINTER(BiasActParams), c_void_p, c_int, c_int, c_void_p]),
     'sgv_weight_sqsum': (c_int, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_demod_coefs': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p]),
+    'sgv_demod_coefs_backward': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_scale_channels': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int, c_void_p]),
     'sgv_plane_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int, c_void_p]),
     'sgv_act_grad_scale': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_void_p]),

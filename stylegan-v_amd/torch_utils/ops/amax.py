@@ -212,6 +212,15 @@ def set_tap_sum(f, value):
         pass
 
 
+def can_inherit_through_fir(x, f2d):
+    """True if `inherit_through_fir` will succeed for an output of x filtered with f2d: x carries a bound and the filter's tap sum is known (or may be read back now).
+    The caller then launches WITHOUT the side output: no atomics in the streaming kernel and no fold launch behind it (round 6: 179 fold launches per iteration)."""
+    if not (x.is_cuda and x.dtype == torch.float32 and tracking()) or cached(x) is None:
+        return False
+    rec = getattr(f2d, _TAPS_ATTR, None)
+    return (rec is not None and rec[0] == f2d._version and rec[1] == f2d.data_ptr()) or not torch.cuda.is_current_stream_capturing()
+
+
 def inherit_through_fir(y, x, f2d, gain):
     """Give y = upfirdn2d(x, f2d, gain=gain, ...) the bound gain * sum|f2d| * bound(x) if x has one and y has none yet.  `f2d`: the filter tensor OBJECT the
     tap sum is remembered on -- the caller's own tensor (a module buffer), not a per-call view of it: a fresh object has no record, and every miss is a
@@ -232,7 +241,21 @@ def inherit_through_fir(y, x, f2d, gain):
             setattr(f2d, _TAPS_ATTR, (f2d._version, f2d.data_ptr(), tap_sum))
         except (AttributeError, RuntimeError):
             pass
-    attach(y, bx * (abs(float(gain)) * tap_sum * 1.0000005))      # (a hair above: the FIR's own roundings)
+    factor = abs(float(gain)) * tap_sum
+    # factor <= 1 (the normalised low-pass at gain 1: every down-sampling / pre-convolution pass): the input's bound IS the output's -- shared, not multiplied: no launch
+    # at all (the split's scale leaves a factor 2 of headroom above the bound, csrc/sgv_split.h; the FIR's own roundings are 1e-7 of it)
+    attach(y, bx if factor <= 1.0001 else bx * (factor * 1.0000005))
+
+
+def same_values(new, src):
+    """`new` holds the values of `src` in another arrangement (a flip, a transposition, a contiguous or fp32 copy of a weight): max |new| = max |src|.  The bound is taken on
+    `src` -- a module parameter keeps it until the optimiser rewrites it -- instead of once per temporary (89 separate passes over weights per training iteration,
+    profiles/r06_c17_captured_census.txt)."""
+    if new is src or not (tracking() and src.is_cuda and src.dtype in _DT and new.is_cuda and new.dtype in _DT) or cached(new) is not None:
+        return new
+    if new.dtype != src.dtype and new.dtype != torch.float32:
+        return new        # a narrowing copy rounds: not the same values
+    return attach(new, bound(src))
 
 
 def share(alias, t):

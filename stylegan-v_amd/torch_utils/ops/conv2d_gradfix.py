@@ -218,6 +218,8 @@ def _native_conv(x, w, cfg):
     dt = _DT[x.dtype]
     terms = native_conv_terms if dt == 0 else 1      # 16-bit tensors: every value is one bf16 operand
     xc, wc = x.contiguous(), w.float().contiguous()  # the kernels read fp32 weights (a 16-bit copy handed in by a caller is widened again: same bf16 operands)
+    if terms == 4 and wc is not w:
+        _amax.same_values(wc, w)      # (a transposed view made dense: the bound of the view -- taken on the parameter's own values -- serves the copy)
     if xc.data_ptr() % 16 != 0:   # a dense view at a storage offset that is not 16-byte aligned: the kernels load 16-byte vectors
         xc = xc.clone()
     n, ci, h, wd = xc.shape

@@ -33,7 +33,8 @@ def _conv2d_wrapper(x, w, stride=1, padding=0, groups=1, transpose=False, flip_w
     ``False`` means true convolution, obtained by flipping the kernel spatially."""
     out_ch, in_ch_per_group, kh, kw = _get_weight_shape(w)
     if not flip_weight and (kh > 1 or kw > 1):
-        w = w.flip([2, 3])
+        from . import amax as _amax
+        w = _amax.same_values(w.flip([2, 3]), w) if (w.is_cuda and w.dtype == torch.float32) else w.flip([2, 3])
     # 1x1 convolution with <= 4 channels on one side (fromRGB, un-modulated ToRGB): a memory stream, not a GEMM.
     if kh == 1 and kw == 1 and stride == 1 and padding in (0, [0, 0], (0, 0)) and not transpose and groups == 1 \
             and min(out_ch, in_ch_per_group) <= 4 and _pw.enabled and x.is_cuda and x.is_contiguous() and (x.shape[2] * x.shape[3]) % 4 == 0:
@@ -93,6 +94,9 @@ def _transposed_weight(w, groups):
     """[Cout, Cin/g, kh, kw] -> the [Cin, Cout/g, kh, kw] layout conv_transpose2d wants."""
     out_ch, in_ch_per_group, kh, kw = _get_weight_shape(w)
     if groups == 1:
+        if w.is_cuda and w.dtype == torch.float32:
+            from . import amax as _amax
+            return _amax.same_values(w.transpose(0, 1), w)      # (the view's magnitude bound is the parameter's: taken once per optimiser step, not per call)
         return w.transpose(0, 1)
     wt = w.reshape(groups, out_ch // groups, in_ch_per_group, kh, kw).transpose(1, 2)
     return wt.reshape(groups * in_ch_per_group, out_ch // groups, kh, kw)

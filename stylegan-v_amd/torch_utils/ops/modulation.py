@@ -54,6 +54,19 @@ class _DemodCoefsFn(torch.autograd.Function):
             # from the forward pass and the chain below is 8 launches instead of 17 on [N, O] / [O, I]-sized tensors (12 demodulated layers per generator
             # backward: ~100 launches per iteration, profiles/r05_c30_small_launch_sources.txt).  Same formulas: g = -1/2 grad_d d^3, grad_w = 2 W (g^T s^2),
             # grad_s = 2 s (g q); the factor 2 * (-1/2) is applied once, to g.
+            # Round 6: ONE launch (sgv_demod_coefs_backward) for both gradients.
+            if grad_d.is_cuda and weight.dtype == torch.float32 and styles.dtype == torch.float32 and grad_d.dtype == torch.float32:
+                lib = custom_ops.get_native()
+                gd, wc, sc = grad_d.contiguous(), weight.contiguous(), styles.contiguous()
+                oc, ic, kh, kw = wc.shape
+                grad_w = torch.empty_like(wc) if ctx.needs_input_grad[0] else None
+                grad_s = torch.empty_like(sc) if ctx.needs_input_grad[1] else None
+                if grad_w is None and grad_s is None:
+                    return None, None, None
+                with custom_ops.device_guard(gd):
+                    custom_ops.check(lib.sgv_demod_coefs_backward(gd.data_ptr(), d0.data_ptr(), sc.data_ptr(), q0.data_ptr(), wc.data_ptr(), grad_w.data_ptr() if grad_w is not None else None,
+                                                                  grad_s.data_ptr() if grad_s is not None else None, sc.shape[0], oc, ic, kh * kw, _stream(gd)), lib)
+                return grad_w, grad_s, None
             g = (grad_d * d0.pow(3)).neg_()                                  # [N, O] = 2 g
             grad_w = grad_s = None
             if ctx.needs_input_grad[0]:

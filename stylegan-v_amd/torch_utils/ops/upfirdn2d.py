@@ -158,8 +158,14 @@ def _native_call(x, f2d, upx, upy, downx, downy, px0, px1, py0, py1, flip, gain,
                                    ow, oh, ys[3], ys[2], ys[1], ys[0])
     with custom_ops.device_guard(x):
         from . import amax as _amax      # (a FIR output usually feeds a convolution: the LDS-tile kernel leaves its magnitude bound behind)
-        custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x))), lib)
-        _amax.inherit_through_fir(y, x, f2d if f_src is None else f_src, gain)      # (a kernel without the side output: the bound follows from the input's, if that is known)
+        f_rec = f2d if f_src is None else f_src
+        if _amax.can_inherit_through_fir(x, f_rec):
+            # |FIR(x)| <= gain * sum|taps| * bound(x): the output's bound follows from the input's without touching the tensor -- no side output armed, so no
+            # atomics in the kernel and no fold launch behind it
+            custom_ops.check(lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x)), lib)
+        else:
+            custom_ops.check(_amax.launch_tracking(y, lambda: lib.sgv_upfirdn2d(p, _DTYPE_CODES[x.dtype], custom_ops.raw_stream(x))), lib)
+        _amax.inherit_through_fir(y, x, f_rec, gain)      # (no-op when the kernel left its own bound)
     return y
 
 

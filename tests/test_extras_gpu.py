@@ -59,6 +59,27 @@ def test_demod_coefs_gradients():
     assert_close(gs, gs_ref, atol=1e-5, rtol=1e-4, what='ds')
 
 
+@pytest.mark.parametrize('n,oc,ic,k', [(96, 512, 512, 3), (32, 64, 128, 3), (5, 3, 300, 1), (7, 257, 33, 3)])
+def test_demod_coefs_first_order_backward_is_one_launch(n, oc, ic, k):
+    """sgv_demod_coefs_backward: both gradients of the demodulation coefficients (networks.py:59-61) in ONE launch, against float64 autograd of the formula."""
+    g = torch.Generator().manual_seed(n + oc + ic)
+    w = torch.randn([oc, ic, k, k], generator=g) / (ic * k * k) ** 0.5
+    s = torch.randn([n, ic], generator=g) + 1
+    gd = torch.randn([n, oc], generator=g)
+    w64, s64 = w.double().requires_grad_(True), s.double().requires_grad_(True)
+    d64 = ((w64.unsqueeze(0) * s64.reshape(n, 1, ic, 1, 1)).square().sum(dim=[2, 3, 4]) + 1e-8).rsqrt()
+    gw_ref, gs_ref = torch.autograd.grad(d64, [w64, s64], gd.double())
+    wg, sg = w.to(DEV).requires_grad_(True), s.to(DEV).requires_grad_(True)
+    d = modulation.demod_coefs(wg, sg)
+    before = custom_ops.launch_count()
+    gw, gs = torch.autograd.grad(d, [wg, sg], gd.to(DEV))
+    assert custom_ops.launch_count() - before == 1
+    assert_close(gw, gw_ref, atol=2e-6 * gw_ref.abs().max().item(), rtol=1e-5, what='dW')
+    assert_close(gs, gs_ref, atol=2e-6 * gs_ref.abs().max().item(), rtol=1e-5, what='ds')
+    (gs_only,) = torch.autograd.grad(modulation.demod_coefs(wg.detach(), sg), [sg], gd.to(DEV))
+    assert torch.equal(gs_only, gs)
+
+
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float16, torch.bfloat16])
 @pytest.mark.parametrize('shape', [(3, 5, 4, 4), (2, 7, 3, 5), (4, 64, 32, 32)])
 def test_scale_channels(dtype, shape):
