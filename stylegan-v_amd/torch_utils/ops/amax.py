@@ -50,7 +50,7 @@ _capture = None     # {'slots': [tensor, used], 'sinks': [tensor, used]} while a
 class capture_scope:
     def __enter__(self):
         global _capture
-        self._saved, _capture = _capture, dict(slots=None, sinks=None)
+        self._saved, _capture = _capture, dict(slots=None, sinks=None, zeros=None)
         return self
 
     def __exit__(self, *exc):
@@ -79,6 +79,36 @@ def zero_sink(device):
         a = _sink_arenas[device.index] = [torch.zeros([_SINKS_PER_ARENA * _SINK_BLOCK], dtype=torch.float32, device=device), 0]
     a[1] += 1
     return a[0][(a[1] - 1) * _SINK_BLOCK:a[1] * _SINK_BLOCK]
+
+
+_ZBLOCK = 1 << 20          # floats per arena of small zeroed work buffers (4 MiB)
+_zero_arenas = {}          # device index -> [zeroed fp32 tensor, floats handed out]
+
+
+def zeros(shape, device):
+    """An fp32 tensor of zeros for a kernel's small accumulation target (per-plane sums, dot products, bias-gradient partials): carved from a zeroed arena, 256-byte
+    aligned, never handed out twice -- one fill launch per arena instead of one per buffer (round 6: ~130 fill launches per training iteration).  While a hipGraph
+    is being captured the arena belongs to the capture, like `zero_slot`'s.  Large requests (> 1/8 arena) get their own `torch.zeros`."""
+    numel = 1
+    for d in shape:
+        numel *= int(d)
+    device = torch.device(device)
+    if device.type != 'cuda' or numel == 0 or numel > _ZBLOCK // 8:
+        return torch.zeros(list(shape), dtype=torch.float32, device=device)
+    need = (numel + 63) // 64 * 64
+    if torch.cuda.is_current_stream_capturing():
+        if _capture is None:
+            return torch.zeros(list(shape), dtype=torch.float32, device=device)
+        a = _capture.get('zeros')
+        if a is None or a[1] + need > _ZBLOCK or a[0].device != device:
+            a = _capture['zeros'] = [torch.zeros([_ZBLOCK], dtype=torch.float32, device=device), 0]
+    else:
+        a = _zero_arenas.get(device.index)
+        if a is None or a[1] + need > _ZBLOCK:
+            a = _zero_arenas[device.index] = [torch.zeros([_ZBLOCK], dtype=torch.float32, device=device), 0]
+    off = a[1]
+    a[1] += need
+    return a[0][off:off + numel].view(list(shape))
 
 
 def zero_slot(device):

@@ -131,7 +131,7 @@ class _FusedConvBiasActFn(torch.autograd.Function):
         ci = x.shape[1]
         stream = custom_ops.raw_stream(dy)
         need_sums = (b is not None and ctx.needs_input_grad[4]) or (d is not None and ctx.needs_input_grad[3])
-        sums = torch.zeros([2, n * co], dtype=torch.float32, device=dy.device) if need_sums else None
+        sums = _amax.zeros([2, n * co], dy.device) if need_sums else None
         dzd = torch.empty_like(y)     # gradient w.r.t. the convolution result: bias_act gradient times dcoefs
         dt = _cg._DT[y.dtype]
         dy = dy.to(y.dtype)
@@ -151,7 +151,7 @@ class _FusedConvBiasActFn(torch.autograd.Function):
             dxs = _cg._native_conv(dzd, weight, tcfg) if _cg._native_conv_ok(dzd, weight, tcfg) else _cg._aten_conv(dzd, weight.to(dzd.dtype), None, tcfg)
             if s is not None:
                 d_x = torch.empty_like(dxs)
-                dot = torch.zeros([n * ci], dtype=torch.float32, device=dy.device)
+                dot = _amax.zeros([n * ci], dy.device)
                 with custom_ops.device_guard(dy):
                     custom_ops.check(lib.sgv_scale_dot_t(dxs.data_ptr(), x.data_ptr(), s.data_ptr(), d_x.data_ptr(), dot.data_ptr(), n * ci, h * w, dt, stream), lib)
                 d_s = dot.reshape(n, ci)
@@ -259,7 +259,7 @@ class _FusedConvActFirFn(torch.autograd.Function):
         dz = torch.empty_like(y0)
         dt = _cg._DT[y0.dtype]
         g = g.to(y0.dtype)
-        sums = torch.zeros([n * co], dtype=torch.float32, device=g.device)
+        sums = _amax.zeros([n * co], g.device)
         e = custom_ops.FirEpilogue(3, None, None, y0.data_ptr(), sums.data_ptr(), None, _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
         with custom_ops.device_guard(g):
             rc = _amax.launch_tracking(dz, lambda: lib.sgv_upfirdn2d_fused(_ffa._ufd_params(g, f, dz, bpads, True, 1.0), e, dt, custom_ops.raw_stream(g)))
@@ -270,7 +270,7 @@ class _FusedConvActFirFn(torch.autograd.Function):
                 d_b = sums.reshape(n, co).sum(0).to(ctx.bias_dtype)
         elif rc == -3:   # SGV_ERR_UNSUPPORTED (a geometry / width the lane-exchange kernel does not serve): the two passes
             gy = _ufd.upfirdn2d(g, f, padding=list(bpads), flip_filter=True)
-            s2 = torch.zeros([2, n * co], dtype=torch.float32, device=g.device) if need_db else None
+            s2 = _amax.zeros([2, n * co], g.device) if need_db else None
             with custom_ops.device_guard(g):
                 custom_ops.check(_amax.launch_tracking(dz, lambda: lib.sgv_act_grad_scale_t(
                     gy.data_ptr(), y0.data_ptr(), None, dz.data_ptr(), s2.data_ptr() if s2 is not None else None, n * co, h * w,

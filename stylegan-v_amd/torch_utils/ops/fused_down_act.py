@@ -97,7 +97,7 @@ class _FusedDownFn(torch.autograd.Function):
         if any(ctx.needs_input_grad[:3]):
             n, co, h, w = a.shape
             need_db = b is not None and ctx.needs_input_grad[2]
-            sums = torch.zeros([2, n * co], dtype=torch.float32, device=dy.device) if need_db else None
+            sums = _amax.zeros([2, n * co], dy.device) if need_db else None
             dz = torch.empty_like(a)
             dy = dy.to(a.dtype)
             with custom_ops.device_guard(dy):

@@ -120,7 +120,7 @@ class _FusedFirBiasActFn(torch.autograd.Function):
         # the gradient of upfirdn2d is upfirdn2d with the padding of upfirdn2d.py:251-261 and the filter flip inverted
         bpads = (fw - pads[0] - 1, iw - ow + pads[0], fh - pads[2] - 1, ih - oh + pads[2])
         dx = torch.empty(ctx.x_shape, dtype=dy.dtype, device=dy.device)
-        sums = torch.zeros([2, n * c], dtype=torch.float32, device=dy.device)
+        sums = _amax.zeros([2, n * c], dy.device)
         e = custom_ops.FirEpilogue(2, sc.data_ptr() if sc is not None else None, None, y.data_ptr(), sums[0].data_ptr(), sums[1].data_ptr(),
                                    _ba.activation_funcs[act].cuda_idx, alpha, gain, clamp)
         with custom_ops.device_guard(dy):

@@ -11,6 +11,11 @@ differentiable tensor ops, so gradients of any order are available.
 
 import torch
 
+
+def _amax_mod():
+    from . import amax
+    return amax
+
 from .. import custom_ops
 from .upfirdn2d import _DTYPE_CODES
 
@@ -133,7 +138,7 @@ class _PlaneDotFn(torch.autograd.Function):
         ac, bc = a.contiguous(), b.contiguous()
         n, c = ac.shape[:2]
         hw = ac.numel() // max(n * c, 1)
-        out = torch.zeros([n, c], dtype=torch.float32, device=ac.device)
+        out = _amax_mod().zeros([n, c], ac.device)
         if ac.numel():
             with custom_ops.device_guard(ac):
                 custom_ops.check(lib.sgv_plane_dot(ac.data_ptr(), bc.data_ptr(), out.data_ptr(), n * c, hw, _DTYPE_CODES[ac.dtype], _stream(ac)), lib)

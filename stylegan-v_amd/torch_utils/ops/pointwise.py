@@ -10,6 +10,11 @@ gradients of any order are available (R1 differentiates the discriminator's from
 
 import torch
 
+
+def _amax_mod():
+    from . import amax
+    return amax
+
 from .. import custom_ops
 from . import conv2d_gradfix
 from .upfirdn2d import _DTYPE_CODES
@@ -77,7 +82,7 @@ class _OuterFn(torch.autograd.Function):
         ac, bc = a.contiguous(), b.contiguous()
         n, f, h, wd = ac.shape
         m = bc.shape[1]
-        out = torch.zeros([n, f, m], dtype=torch.float32, device=ac.device)
+        out = _amax_mod().zeros([n, f, m], ac.device)
         with custom_ops.device_guard(ac):
             custom_ops.check(lib.sgv_pointwise_outer(ac.data_ptr(), bc.data_ptr(), out.data_ptr(), n, f, m, h * wd, _DTYPE_CODES[ac.dtype],
                                                      custom_ops.raw_stream(ac)), lib)
@@ -140,7 +145,7 @@ class _PointwiseActFn(torch.autograd.Function):
                 stream = custom_ops.raw_stream(dy)
                 if need_dw or need_db:
                     xc = x.contiguous()
-                    out = torch.zeros([n, ci + 1, co], dtype=torch.float32, device=dy.device)
+                    out = _amax_mod().zeros([n, ci + 1, co], dy.device)
                     custom_ops.check(lib.sgv_pointwise_outer_act(xc.data_ptr(), dy.data_ptr(), y.data_ptr(), out.data_ptr(), n, ci + 1, co, h * wd, 1, aidx, alpha, gain,
                                                                  clamp, _DTYPE_CODES[dy.dtype], stream), lib)
                     tot = out.sum(0)                                  # [ci + 1, co]
