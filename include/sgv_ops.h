@@ -212,6 +212,9 @@ int sgv_scale_dot(const float* a, const float* b, const float* s, float* out, fl
 int sgv_act_grad_scale_t(const void* dy, const void* y, const float* d, void* out, float* sums, int32_t planes, int32_t hw, int32_t act, float alpha,
                          float gain, float clamp, int dtype, void* stream);
 int sgv_scale_dot_t(const void* a, const void* b, const float* s, void* out, float* dot, int32_t planes, int32_t hw, int dtype, void* stream);
+/* The same with `addend` (dtype / layout of out, or NULL) summed into the store: out = a * s[plane] + addend -- the gradient that reached the tensor from its OTHER
+ * consumer (a synthesis block's output feeds the next block's up-sampling layer and its own ToRGB, networks.py:239-262), added here instead of by a pass of its own. */
+int sgv_scale_dot_add_t(const void* a, const void* b, const float* s, const void* addend, void* out, float* dot, int32_t planes, int32_t hw, int dtype, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * 1x1 convolutions with <= 4 channels on one side, as HBM streams (ToRGB Cin->3, fromRGB 3->C; NCHW, fp32 accumulate):

@@ -193,31 +193,42 @@ __global__ __launch_bounds__(256) void act_grad_scale_kernel(const T* __restrict
 
 // out = a * s[plane] and dot[plane] += sum a * b in one pass: the input gradient dx = dxs * styles of a modulated layer together with the
 // styles gradient sum_px dxs * x (networks.py:66), instead of plane_dot + scale_channels (5 tensor passes -> 3).
-template <typename T>
-__global__ __launch_bounds__(256) void scale_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ s, T* __restrict__ out,
+// ADD: out = a * s + addend (the gradient that arrived from the tensor's other consumer: the sum lands in this pass's store instead of a separate full-tensor addition)
+template <typename T, bool ADD>
+__global__ __launch_bounds__(256) void scale_dot_kernel(const T* __restrict__ a, const T* __restrict__ b, const float* __restrict__ s, const T* __restrict__ addend, T* __restrict__ out,
                                                         float* __restrict__ dot, int hw, int vec_ok) {
     constexpr int N = vec16<T>::N;
     const int plane = blockIdx.y;
     const int p0 = blockIdx.x * PD_CHUNK, p1 = min(hw, p0 + PD_CHUNK);
     const T* ap = a + (size_t)plane * hw;
     const T* bp = b + (size_t)plane * hw;
+    const T* dp = ADD ? addend + (size_t)plane * hw : nullptr;
     T* op = out + (size_t)plane * hw;
     const float sc = s[plane];
     float acc = 0.f;
     if (vec_ok) {
         for (int i = p0 + threadIdx.x * N; i < p1; i += 256 * N) {
             const vec16<T> va = *(const vec16<T>*)(ap + i), vb = *(const vec16<T>*)(bp + i);
-            vec16<T> o;
+            vec16<T> vd, o;
+            if constexpr (ADD) vd = *(const vec16<T>*)(dp + i);
 #pragma unroll
             for (int k = 0; k < N; k++) {
                 const float av = sgv_traits<T>::load(&va.e[k]);
                 acc = __builtin_fmaf(av, sgv_traits<T>::load(&vb.e[k]), acc);
-                sgv_traits<T>::store(&o.e[k], av * sc);
+                float r = av * sc;
+                if constexpr (ADD) r += sgv_traits<T>::load(&vd.e[k]);
+                sgv_traits<T>::store(&o.e[k], r);
             }
             *(vec16<T>*)(op + i) = o;
         }
     } else {
-        for (int i = p0 + threadIdx.x; i < p1; i += 256) { const float va = sgv_traits<T>::load(ap + i); acc = __builtin_fmaf(va, sgv_traits<T>::load(bp + i), acc); sgv_traits<T>::store(op + i, va * sc); }
+        for (int i = p0 + threadIdx.x; i < p1; i += 256) {
+            const float va = sgv_traits<T>::load(ap + i);
+            acc = __builtin_fmaf(va, sgv_traits<T>::load(bp + i), acc);
+            float r = va * sc;
+            if constexpr (ADD) r += sgv_traits<T>::load(dp + i);
+            sgv_traits<T>::store(op + i, r);
+        }
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
@@ -263,26 +274,36 @@ extern "C" int sgv_act_grad_scale(const float* dy, const float* y, const float* 
     return sgv_act_grad_scale_t(dy, y, d, out, sums, planes, hw, act, alpha, gain, clamp, SGV_F32, stream_);
 }
 
-extern "C" int sgv_scale_dot_t(const void* a, const void* b, const float* s, void* out, float* dot, int32_t planes, int32_t hw, int dtype, void* stream_) {
+template <typename T>
+static void launch_scale_dot(const char* ap, const char* bp, const float* s, const char* dp, char* op, float* dot, int hw, int vec_ok, dim3 grid, hipStream_t stream) {
+    if (dp) hipLaunchKernelGGL((scale_dot_kernel<T, true>), grid, dim3(256), 0, stream, (const T*)ap, (const T*)bp, s, (const T*)dp, (T*)op, dot, hw, vec_ok);
+    else hipLaunchKernelGGL((scale_dot_kernel<T, false>), grid, dim3(256), 0, stream, (const T*)ap, (const T*)bp, s, (const T*)nullptr, (T*)op, dot, hw, vec_ok);
+}
+
+extern "C" int sgv_scale_dot_add_t(const void* a, const void* b, const float* s, const void* addend, void* out, float* dot, int32_t planes, int32_t hw, int dtype, void* stream_) {
     if (!a || !b || !s || !out || !dot) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: NULL pointer");
     if (planes < 1 || hw < 1) return sgv_fail(SGV_ERR_INVALID_ARG, "scale_dot: needs planes >= 1, hw >= 1");
     if ((int64_t)planes * hw > INT32_MAX) return sgv_fail(SGV_ERR_TOO_LARGE, "scale_dot: tensors are too large");
     const size_t es = sgv_dtype_size(dtype);
     if (es == 0 || dtype == SGV_F64) return sgv_fail(SGV_ERR_UNSUPPORTED, "scale_dot: unsupported dtype %d", dtype);
     hipStream_t stream = (hipStream_t)stream_;
-    sgv_launch_scope scope(SGV_K_MODULATE, stream, 3.0 * planes * (double)hw * (double)es);
-    const int vec_ok = (hw % (16 / (int)es) == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) % 16 == 0);
+    sgv_launch_scope scope(SGV_K_MODULATE, stream, (addend ? 4.0 : 3.0) * planes * (double)hw * (double)es);
+    const int vec_ok = (hw % (16 / (int)es) == 0) && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out | (uintptr_t)addend) % 16 == 0);
     for (int p0 = 0; p0 < planes; p0 += 65535) {     // blockIdx.y <= 65535: planes in slabs, as act_grad_scale
         const int np = std::min(65535, planes - p0);
         const size_t off = (size_t)p0 * hw * es;
-        const char *ap = (const char*)a + off, *bp = (const char*)b + off;
+        const char *ap = (const char*)a + off, *bp = (const char*)b + off, *dp = addend ? (const char*)addend + off : nullptr;
         char* op = (char*)out + off;
         dim3 grid((unsigned)((hw + PD_CHUNK - 1) / PD_CHUNK), (unsigned)np);
-        if (dtype == SGV_F32) hipLaunchKernelGGL(scale_dot_kernel<float>, grid, dim3(256), 0, stream, (const float*)ap, (const float*)bp, s + p0, (float*)op, dot + p0, hw, vec_ok);
-        else if (dtype == SGV_F16) hipLaunchKernelGGL(scale_dot_kernel<sgv_half_t>, grid, dim3(256), 0, stream, (const sgv_half_t*)ap, (const sgv_half_t*)bp, s + p0, (sgv_half_t*)op, dot + p0, hw, vec_ok);
-        else hipLaunchKernelGGL(scale_dot_kernel<sgv_bf16_t>, grid, dim3(256), 0, stream, (const sgv_bf16_t*)ap, (const sgv_bf16_t*)bp, s + p0, (sgv_bf16_t*)op, dot + p0, hw, vec_ok);
+        if (dtype == SGV_F32) launch_scale_dot<float>(ap, bp, s + p0, dp, op, dot + p0, hw, vec_ok, grid, stream);
+        else if (dtype == SGV_F16) launch_scale_dot<sgv_half_t>(ap, bp, s + p0, dp, op, dot + p0, hw, vec_ok, grid, stream);
+        else launch_scale_dot<sgv_bf16_t>(ap, bp, s + p0, dp, op, dot + p0, hw, vec_ok, grid, stream);
     }
     return sgv_check_launch("scale_dot_kernel");
+}
+
+extern "C" int sgv_scale_dot_t(const void* a, const void* b, const float* s, void* out, float* dot, int32_t planes, int32_t hw, int dtype, void* stream_) {
+    return sgv_scale_dot_add_t(a, b, s, nullptr, out, dot, planes, hw, dtype, stream_);
 }
 
 extern "C" int sgv_scale_dot(const float* a, const float* b, const float* s, float* out, float* dot, int32_t planes, int32_t hw, void* stream_) {

@@ -69,7 +69,10 @@ template <int TERMS>
 __device__ __forceinline__ void split2(float a, float b, float S, unsigned& hi, unsigned& lo) {
     if constexpr (TERMS == 2) {
         // a product formed in fp32 on the way in (x * styles) may leave fp16's range: saturate like the reference's clamp would (conv_clamp = 256 bounds x)
-        hi = sp_pack_f16(__builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f));
+        // (NaN-preserving: v_med3_f32 returns the minimum of its operands when one is a NaN -- a NaN activation entered the product as a finite -65504 and the
+        // divergence the reference would show was masked; min / max drop the NaN the same way, so the NaN is put back explicitly)
+        const float ca = __builtin_amdgcn_fmed3f(a, -65504.f, 65504.f), cb = __builtin_amdgcn_fmed3f(b, -65504.f, 65504.f);
+        hi = sp_pack_f16(a != a ? a : ca, b != b ? b : cb);
         lo = 0u;
     } else if constexpr (TERMS == 4) {
         a *= S; b *= S;

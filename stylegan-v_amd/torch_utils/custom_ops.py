@@ -286,6 +286,7 @@ ABI_SYMBOLS = {
     'sgv_scale_dot': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_void_p]),
     'sgv_act_grad_scale_t': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_float, c_float, c_float, c_int, c_void_p]),
     'sgv_scale_dot_t': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int, c_void_p]),
+    'sgv_scale_dot_add_t': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int, c_void_p]),
     'sgv_pointwise_small': (c_int, [ctypes.POINTER(PointwiseParams), c_int, c_void_p]),
     'sgv_pointwise_act': (c_int, [ctypes.POINTER(PointwiseParams), c_void_p, c_int32, c_float, c_float, c_float, c_int, c_void_p]),
     'sgv_pointwise_small_gradin': (c_int, [ctypes.POINTER(PointwiseParams), c_void_p, c_int32, c_float, c_float, c_float, c_int, c_void_p]),

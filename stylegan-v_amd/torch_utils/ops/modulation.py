@@ -121,12 +121,65 @@ class _ScaleChannelsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, s = ctx.saved_tensors
-        dx = ds = None
-        if ctx.needs_input_grad[0]:
-            dx = scale_channels(dy, s)
-        if ctx.needs_input_grad[1]:
-            ds = plane_dot(dy, x).to(s.dtype)
-        return dx, ds
+        return _scale_channels_backward(ctx, x, s, dy, None)
+
+
+def _scale_channels_backward(ctx, x, s, dy, g_alias):
+    """(dx, ds) of y = x * s[n, c] for the incoming dy; `g_alias`: a gradient that reached x through another consumer (summed into dx).  First-order pass with both
+    gradients wanted: ONE streaming kernel (sgv_scale_dot_add_t: dx = dy * s (+ g_alias), ds = sum_px dy * x -- 3-4 tensor passes) instead of scale_channels +
+    plane_dot (+ autograd's addition): 4 (+3)."""
+    need_x, need_s = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+    if (need_x and need_s and not torch.is_grad_enabled() and dy.is_cuda and dy.dtype in _DTYPE_CODES and dy.dtype != torch.float64 and x.dtype == dy.dtype
+            and s.dtype == torch.float32 and (g_alias is None or (g_alias.dtype == dy.dtype and g_alias.shape == dy.shape))):
+        lib = custom_ops.get_native()
+        dyc, xc, sc = dy.contiguous(), x.contiguous(), s.contiguous()
+        ga = g_alias.contiguous() if g_alias is not None else None
+        n, c = xc.shape[:2]
+        hw = xc.numel() // max(n * c, 1)
+        dx = torch.empty_like(dyc)
+        from . import amax as _amax
+        dot = _amax.zeros([n * c], dyc.device)
+        with custom_ops.device_guard(dyc):
+            custom_ops.check(lib.sgv_scale_dot_add_t(dyc.data_ptr(), xc.data_ptr(), sc.data_ptr(), ga.data_ptr() if ga is not None else None, dx.data_ptr(), dot.data_ptr(),
+                                                     n * c, hw, _DTYPE_CODES[dyc.dtype], _stream(dyc)), lib)
+        return dx, dot.reshape(n, c).to(s.dtype)
+    dx = ds = None
+    if need_x:
+        dx = scale_channels(dy, s)
+        if g_alias is not None:
+            dx = dx + g_alias
+    elif g_alias is not None:
+        dx = g_alias
+    if need_s:
+        ds = plane_dot(dy, x).to(s.dtype)
+    return dx, ds
+
+
+class _ScaleChannelsAliasFn(torch.autograd.Function):
+    """(x * s, x): the second result is x itself, for x's OTHER consumer (a synthesis block's output feeds the next block's up-sampling layer -- here -- and its
+    own ToRGB, networks.py:239-262).  That consumer's gradient then arrives HERE as g_alias and is added in the store of this node's own gradient pass instead of
+    by autograd's separate full-tensor addition (the discriminator's residual blocks use the same device: fused_fir_act.fir_down_with_input_alias)."""
+
+    @staticmethod
+    def forward(ctx, x, s):
+        y = _ScaleChannelsFn.forward(ctx, x, s)
+        ctx.set_materialize_grads(False)
+        from . import amax as _amax
+        return y, _amax.share(x.view_as(x), x)
+
+    @staticmethod
+    def backward(ctx, dy, g_alias=None):
+        x, s = ctx.saved_tensors
+        if dy is None:
+            return g_alias, None
+        return _scale_channels_backward(ctx, x, s, dy, g_alias)
+
+
+def scale_channels_with_alias(x, s):
+    """(scale_channels(x, s), x) -- hand the second result to x's other consumer (see _ScaleChannelsAliasFn)."""
+    if x.is_cuda and x.ndim == 4 and x.dtype in (torch.float32, torch.float16, torch.bfloat16) and s.dtype == torch.float32 and x.is_contiguous() and x.numel() < 2 ** 31:
+        return _ScaleChannelsAliasFn.apply(x, s)
+    return scale_channels(x, s), x
 
 
 class _PlaneDotFn(torch.autograd.Function):

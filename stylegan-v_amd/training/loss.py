@@ -108,13 +108,19 @@ class StyleGAN2Loss:
             # One pass holds the autograd state of BOTH halves at once -- about twice the peak activation memory of the reference's schedule (loss.py:122-151
             # runs and differentiates the generated half before the real half exists).  A configuration that fits under two passes must not fail under one:
             # an out-of-memory error in the forward pass (nothing has been accumulated yet) switches this loss back to two passes for good.
-            logits = None
+            #  The cache is emptied BEHIND the except block -- inside it the exception's traceback still holds the failed pass's activations.  Only the
+            # forward pass is guarded: an out-of-memory error in the backward pass of the doubled batch has already accumulated part of the gradients and propagates.
+            # The switch is per rank (no collective in a failure path): ranks then differ in the minibatch-std grouping of this phase, not in collective counts.
+            logits, oom = None, False
             try:
                 with self._mbstd_segments(2):
                     logits = self.run_D(torch.cat([gen_img, real_img.detach()]), torch.cat([gen_c, real_c]), torch.cat([gen_t, real_t]), sync=sync)['image_logits']
             except torch.cuda.OutOfMemoryError:
                 if torch.cuda.is_current_stream_capturing():
                     raise
+                oom = True
+            if oom:
+                logits = None
                 self.d_concat = False
                 torch.cuda.empty_cache()
                 print('[sgv] Dmain as one discriminator pass over [generated, real] ran out of memory: two passes from here on (SGV_D_CONCAT=0)', flush=True)

@@ -35,6 +35,8 @@ from ..torch_utils.ops import bias_act, conv2d_gradfix, conv2d_resample, eqlr, f
 from .layers import Conv2dLayer, FullyConnectedLayer, GenInput, MappingNetwork, TemporalDifferenceEncoder
 from .motion import MotionMappingNetwork
 
+deferred_rgb = os.environ.get('SGV_DEFER_RGB', '1') != '0'      # a block's ToRGB runs inside the next block (see SynthesisNetwork.forward)
+
 
 prefer_native_inference = True   # GPU eval-mode synthesis: scale-conv-scale through the native kernels instead of the grouped convolution
 alias_in_fir = os.environ.get('SGV_ALIAS_IN_FIR', '0') != '0'       # which of the block input's two consumers receives the other's gradient (see DiscriminatorBlock.forward)
@@ -105,8 +107,14 @@ class SynthesisLayer(torch.nn.Module):
             self.noise_strength = torch.nn.Parameter(torch.zeros([]))
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
 
-    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, styles=None):
-        """``styles``: ``self.affine(w)`` already evaluated by the caller (SynthesisNetwork.forward runs the affines of a whole pass as one launch)."""
+    def forward(self, x, w, noise_mode='random', fused_modconv=True, gain=1, styles=None, alias=False):
+        """``styles``: ``self.affine(w)`` already evaluated by the caller (SynthesisNetwork.forward runs the affines of a whole pass as one launch).
+        ``alias=True``: return (y, x_alias) -- x_alias is x for its other consumer (the previous block's ToRGB), whose gradient is then summed inside this layer's
+        own backward pass (ops/modulation.py ``scale_channels_with_alias``); a path that cannot do that returns x itself."""
+        if alias is True:
+            box = [x]
+            y = self.forward(x, w, noise_mode=noise_mode, fused_modconv=fused_modconv, gain=gain, styles=styles, alias=box)
+            return y, box[0]
         assert noise_mode in ('random', 'const', 'none')
         misc.assert_shape(x, [None, self.weight.shape[1], self.resolution // self.up, self.resolution // self.up])
         if styles is None:
@@ -125,7 +133,10 @@ class SynthesisLayer(torch.nn.Module):
                 weight = weight * (1 / math.sqrt(weight[0].numel()) / weight.norm(float('inf'), dim=[1, 2, 3], keepdim=True))
                 s = s / s.norm(float('inf'), dim=1, keepdim=True)
             dcoefs = modulation.demod_coefs(weight, s)
-            x = modulation.scale_channels(x, s)
+            if isinstance(alias, list):
+                x, alias[0] = modulation.scale_channels_with_alias(x, s)
+            else:
+                x = modulation.scale_channels(x, s)
             x, fir_pad = conv2d_resample.upsampling_conv_parts(x, conv2d_gradfix.cast_weight(weight, x), self.resample_filter, up=self.up, padding=self.padding,
                                                                flip_weight=False)
             return fused_fir_act.fir_bias_act(x, self.resample_filter, scale=dcoefs, bias=self.bias, padding=fir_pad, fir_gain=self.up ** 2,
@@ -205,7 +216,10 @@ class SynthesisBlock(torch.nn.Module):
         """The layers that own a style affine, in call order (one column of this block's ws each)."""
         return ([self.conv0] if self.in_channels != 0 else []) + [self.conv1] + ([self.torgb] if (self.is_last or self.architecture == 'skip') else [])
 
-    def forward(self, x, img, ws, motion_v=None, force_fp32=False, fused_modconv=None, styles=None, **layer_kwargs):
+    def forward(self, x, img, ws, motion_v=None, force_fp32=False, fused_modconv=None, styles=None, pending_rgb=None, defer_rgb=False, **layer_kwargs):
+        """``defer_rgb`` / ``pending_rgb`` (SynthesisNetwork.forward, skip architecture): a block may leave its ToRGB to the NEXT block, which runs it on the alias of x
+        that its own conv0 hands back -- the two gradients of x (from ToRGB and from the next block's conv0) are then summed inside conv0's backward pass instead of by a
+        separate full-tensor addition.  With defer_rgb the block returns (x, img, pending) where img still lacks this block's RGB contribution."""
         s_iter = iter(styles) if styles is not None else iter(lambda: None, 0)      # (styles: one tensor per affine_layers() entry, or None: every layer runs its own)
         if isinstance(ws, (tuple, list)):
             # the per-layer latents already split by the caller (SynthesisNetwork.forward unbinds `ws` ONCE: one stack in the backward pass instead of a
@@ -234,18 +248,29 @@ class SynthesisBlock(torch.nn.Module):
                 x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, gain=math.sqrt(0.5), styles=next(s_iter), **layer_kwargs)
                 x = y.add_(x)
             else:
-                x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter), **layer_kwargs)
+                if pending_rgb is not None:
+                    x, x_prev = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter), alias=True, **layer_kwargs)
+                    img = pending_rgb(x_prev, img)      # the previous block's ToRGB, on the alias of its x
+                else:
+                    x = self.conv0(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter), **layer_kwargs)
                 x = self.conv1(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter), **layer_kwargs)
 
         if img is not None:
             misc.assert_shape(img, [None, self.img_channels, self.resolution // 2, self.resolution // 2])
             img = upfirdn2d.upsample2d(img, self.resample_filter)
         if self.is_last or self.architecture == 'skip':
-            y = self.torgb(x, next(w_iter), fused_modconv=fused_modconv, styles=next(s_iter)).to(dtype=torch.float32, memory_format=torch.contiguous_format)
-            img = img.add_(y) if img is not None else y
+            w_rgb, s_rgb = next(w_iter), next(s_iter)
+
+            def rgb(x_in, img_in):
+                y = self.torgb(x_in, w_rgb, fused_modconv=fused_modconv, styles=s_rgb).to(dtype=torch.float32, memory_format=torch.contiguous_format)
+                return img_in.add_(y) if img_in is not None else y
+            if defer_rgb:
+                assert x.dtype == dtype
+                return x, img, rgb
+            img = rgb(x, img)
         assert x.dtype == dtype
         assert img is None or img.dtype == torch.float32
-        return x, img
+        return (x, img, None) if defer_rgb else (x, img)
 
 
 class SynthesisNetwork(torch.nn.Module):
@@ -307,6 +332,12 @@ class SynthesisNetwork(torch.nn.Module):
                 k += block.num_conv
             all_styles = fc.grouped_affine(ws, cols, layers, gains)
         s_idx = 0
+        # Training pass on the GPU, skip architecture: every block but the last leaves its ToRGB to the next block (SynthesisBlock.forward `defer_rgb`): x_k's two
+        # gradients meet inside the next block's conv0 backward instead of in a separate addition (6 full-tensor additions per generator backward, 0.9 ms).
+        defer = (deferred_rgb and ws.is_cuda and torch.is_grad_enabled() and ws.requires_grad and block_kwargs.get('fused_modconv') in (None, False) and self.training
+                 and all(getattr(self, f'b{r}').architecture == 'skip' and not getattr(self, f'b{r}').use_fp16 for r in self.block_resolutions)
+                 and not block_kwargs.get('force_fp32', False) and not self.cfg.use_noise)
+        pending = None
         for res in self.block_resolutions:
             block = getattr(self, f'b{res}')
             # each ToRGB shares its w with the next block's conv0: advance by num_conv only (networks.py:354-357)
@@ -315,7 +346,12 @@ class SynthesisNetwork(torch.nn.Module):
             n_aff = block.num_conv + block.num_torgb
             cur_styles = all_styles[s_idx:s_idx + n_aff] if all_styles is not None else None
             s_idx += n_aff
-            x, img = block(x, img, cur_ws, motion_v=motion_v if cond == 'concat_const' else None, styles=cur_styles, **block_kwargs)
+            if defer:
+                is_final = res == self.block_resolutions[-1]
+                out = block(x, img, cur_ws, motion_v=motion_v if cond == 'concat_const' else None, styles=cur_styles, pending_rgb=pending, defer_rgb=not is_final, **block_kwargs)
+                x, img, pending = out[0], out[1], (out[2] if len(out) == 3 else None)
+            else:
+                x, img = block(x, img, cur_ws, motion_v=motion_v if cond == 'concat_const' else None, styles=cur_styles, **block_kwargs)
         return img
 
 

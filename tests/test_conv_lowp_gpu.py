@@ -357,3 +357,19 @@ def test_fused_downsampling_layer_on_16bit_activations(dtype):
     _check_layer(f'{dtype} fused down layer', y, grads, [xb, w, b], dy, False, 2, dtype)
     after2 = custom_ops.kernel_variant_counts()
     dispatch_assert(after2.get('convT_lowp', 0) == after.get('convT_lowp', 0) + 1 and after2.get('wrw_s2_lowp', 0) == after.get('wrw_s2_lowp', 0) + 1)
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+def test_nan_activation_propagates_through_the_16bit_convolution(dtype):
+    """A NaN activation must come out as NaN wherever its 3 x 3 footprint reaches, as in the reference's (and this repo's fp32) arithmetic -- the fp16 operand
+    path saturated with v_med3_f32, which returns a FINITE value for a NaN input and hid the divergence."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn([1, 64, 32, 32], generator=g)
+    x[0, 3, 10, 17] = float('nan')
+    w = (torch.randn([64, 64, 3, 3], generator=g) / 24).to(DEV)
+    y = _conv(x.to(DEV).to(dtype), w, False).float().cpu()
+    bad = torch.isnan(y[0])
+    assert bad[:, 9:12, 16:19].all(), 'the NaN did not reach every output of its footprint'
+    clean = bad.clone()
+    clean[:, 9:12, 16:19] = False
+    assert not clean.any(), 'NaN outside the footprint'
