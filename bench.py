@@ -186,7 +186,7 @@ def emit(out):
 
 TIMED_FAMILIES = ('conv3x3_s1', 'upfirdn2d_lanes')      # kernel families whose launches are bracketed by HIP events inside the timed region (eager headline)
 CAPTURED_FAMILIES = ('conv3x3_s1',)                     # captured headline: the family whose kernel writes its own timestamps inside the replayed graphs
-PMC_FILES = ['r05_pmc_bench_step_FETCH_WRITE.json']   # collected by tools/gpu_recipes/pmc_fetch_write_passes.sh (separate --pmc passes of this command)
+PMC_FILES = ['r06_pmc_bench_step_FETCH_WRITE.json']   # collected by tools/gpu_recipes/r06_final.sh (separate --pmc passes of this command), stamped with the kernel sources' digest
 
 
 PMC_NOT_THIS_WORKLOAD = None      # set when the run is not the workload the committed counter passes were collected on
@@ -232,7 +232,7 @@ def pmc_traffic_conv_family():
                         'conv3x3_s2_kernel'), dword_read_prefixes=('conv3x3_s2_kernel',))
 
 
-def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_tile'), files=None):
+def pmc_traffic_per_launch(prefixes=('upfirdn2d_lanes', 'upfirdn2d_tile', 'upfirdn2d_down2_tile', 'upfirdn2d_up2_tile'), files=None):
     return pmc_traffic(tuple(prefixes), files=files)
 
 
@@ -389,7 +389,7 @@ def synthesis_workload(args, world, rank, device):
         if 'upfirdn2d_lanes' in fam:
             r = fam['upfirdn2d_lanes']
             achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-            pmc_g = pmc_traffic_per_launch(files=[f'r05_pmc_{args.workload}_FETCH_WRITE.json'])     # this workload's own counter passes, when committed
+            pmc_g = pmc_traffic_per_launch(files=[f'r06_pmc_{args.workload}_FETCH_WRITE.json'])     # this workload's own counter passes, when committed
             roofline = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel (the FIR / 2x up-sampling chain of the synthesis network)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS,
                             unit='GB/s', frac=achieved / HBM_PEAK_GBPS, frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_g[0], traffic_source=pmc_g[1] + ' (reads x2, gfx950 correction)', launches=r['launches'],
                             launches_per_forward=r['launches'] / args.steps, algorithmic_bytes_per_forward=r['bytes'] / args.steps, avg_launch_us=1e3 * r['ms'] / r['launches'],
@@ -1006,7 +1006,7 @@ def main():
             r = prof['upfirdn2d_lanes'] if captured_headline else in_region['upfirdn2d_lanes']      # (captured headline: no timestamps inside this family's kernels -> the eager pass)
             if r['launches']:
                 achieved = r['bytes'] / (r['ms'] * 1e-3) / 1e9
-                roofline_ufd = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_lanes_kernel', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
+                roofline_ufd = dict(kernel='upfirdn2d_tile_kernel / upfirdn2d_down2_tile_kernel / upfirdn2d_up2_tile_kernel (+ the lane-exchange forms)', bound='hbm', achieved=achieved, peak=HBM_PEAK_GBPS, unit='GB/s', frac=achieved / HBM_PEAK_GBPS,
                                     frac_of_measured_copy_peak=achieved / HBM_COPY_GBPS, traffic=pmc_traffic_per_launch()[0], launches=r['launches'],
                                     traffic_source=pmc_traffic_per_launch()[1] + ' (reads x2, gfx950 correction)',
                                     avg_launch_us=1e3 * r['ms'] / r['launches'], algorithmic_bytes_per_launch=r['bytes'] / r['launches'],
