@@ -78,7 +78,12 @@ def _pad_small_image_channels(x, w, stride, padding, dilation, groups):
             and w.shape[1] == ci and ci % 64 != 0 and ci > 64 and w.shape[0] % 64 == 0):
         return x, w
     pad = 64 - ci % 64
-    return torch.nn.functional.pad(x, (0, 0, 0, 0, 0, pad)), torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad))
+    xp, wp = torch.nn.functional.pad(x, (0, 0, 0, 0, 0, pad)), torch.nn.functional.pad(w, (0, 0, 0, 0, 0, pad))
+    if native_conv_terms == 4:      # zero channels do not move a maximum: the padded tensors take their sources' magnitude bounds instead of a pass each
+        _amax.same_values(wp, w)
+        if _amax.cached(x) is not None:
+            _amax.attach(xp, _amax.cached(x))
+    return xp, wp
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
