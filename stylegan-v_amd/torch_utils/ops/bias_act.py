@@ -213,7 +213,8 @@ class _BiasActGradDbFn(torch.autograd.Function):
         spec = activation_funcs[act]
         ctx.memory_format = _memory_format_of(dy)
         slots = 64 if dy.numel() >= (1 << 22) else 1   # big tensors: spread the per-channel atomics over 64 partial rows
-        db32 = torch.zeros([slots, nb], dtype=torch.float32, device=dy.device)
+        from . import amax as _amax
+        db32 = _amax.zeros([slots, nb], dy.device) if dy.is_cuda else torch.zeros([slots, nb], dtype=torch.float32, device=dy.device)      # (zero arena: one fill per many buffers)
         bb = b if b is not None else torch.zeros([nb], dtype=dy.dtype, device=dy.device)   # carries size_b / step_b; its values are only read by 'x'-referencing activations
         dx = _native_call(dy, bb, x, y, None, 1, dim, spec.cuda_idx, alpha, gain, clamp, db=db32)
         ctx.cfg = cfg

@@ -180,12 +180,16 @@ class _GroupedAffineFn(torch.autograd.Function):
             # Every layer writes its data gradient straight into its column of d(ws) (row stride nws * k).  A column of ws may feed two layers (each ToRGB shares its
             # w with the next block's conv0, networks.py:354-357): its second user ACCUMULATES, in a second launch behind the first.  (No index tensors, no host data:
             # the pass is replayed inside hipGraphs.)
-            first, second, seen = [], [], set()
-            for j, i in enumerate(idx):
-                (second if i in seen else first).append(j)
-                seen.add(i)
-            d_ws = (torch.empty if len(seen) == nws else torch.zeros)([m, nws, k], dtype=torch.float32, device=ws.device)
-            for group, acc in ((first, 0), (second, 1)):
+            rounds, uses = [], {}
+            for j, i in enumerate(idx):       # the k-th user of a column goes into launch k: no two problems of one launch touch the same column
+                kth = uses.get(i, 0)
+                uses[i] = kth + 1
+                while len(rounds) <= kth:
+                    rounds.append([])
+                rounds[kth].append(j)
+            d_ws = (torch.empty if len(uses) == nws else torch.zeros)([m, nws, k], dtype=torch.float32, device=ws.device)
+            for kth, group in enumerate(rounds):
+                acc = 1 if kth else 0
                 if group:
                     probs = [_fc_problem(dyc[j].data_ptr(), wcs[j].shape[0], 1, wcs[j].data_ptr(), k, 1, d_ws.data_ptr() + 4 * k * idx[j], nws * k, m, k, wcs[j].shape[0],
                                          a_ref=dyc[j].data_ptr(), gain=gains[j], wgain=wgains[j]) for j in group]      # (a_ref = dy: a linear activation only applies the output gain there)

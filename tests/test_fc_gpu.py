@@ -165,7 +165,7 @@ def test_grouped_affine_equals_the_per_layer_calls():
     torch.manual_seed(11)
     m, nws, k = 96, 7, 512
     widths = [512, 512, 512, 256, 256, 128, 64, 64, 3 * 40]
-    cols = [0, 1, 1, 2, 3, 3, 4, 5, 6]
+    cols = [0, 1, 1, 1, 3, 3, 4, 5, 6]          # column 1 feeds three layers, column 3 two, column 2 none
     gains = [None, None, 0.044, None, None, 0.0625, None, None, 0.5]
     layers = [FullyConnectedLayer(k, n, bias_init=1).to(DEV) for n in widths]
     for l in layers:
@@ -178,7 +178,7 @@ def test_grouped_affine_equals_the_per_layer_calls():
     params = [p for l in layers for p in (l.weight, l.bias)]
     before = custom_ops.launch_count()
     g_got = torch.autograd.grad(got, [ws] + params, dys)
-    assert custom_ops.launch_count() - before == 3, 'data gradients (first users of a ws column, then the accumulating second users) and weight gradients'
+    assert custom_ops.launch_count() - before == 4, 'data gradients (one launch per k-th user of a ws column: three here) and weight gradients'
     fc.grouped = False
     try:
         want = fc.grouped_affine(ws, cols, layers, gains)
