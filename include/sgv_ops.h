@@ -55,7 +55,9 @@
  *   sgv_time_encode    <- `AlignedTimeEncoder.forward` element-wise tail src/training/motion.py:201-212
  *   sgv_affine_resample <- `affine_grid` + `grid_sample` of the ADA geometric execution src/training/augment.py:297-300 and its backward
  *   sgv_ada_geometric  <- reflect pad + upsample2d + affine_grid / grid_sample + downsample2d of augment.py:270-300 in one pass (forward)
- *                          src/torch_utils/ops/grid_sample_gradfix.py:45-83
+ *   sgv_ada_geometric_adjoint
+ *                      <- the backward of that block as one pass: autograd through F.pad / upfirdn2d.py:249-260 / grid_sample_gradfix.py:45-83
+ *                          (loss.py:91-110 differentiates through augmented fakes, :144-164 twice through augmented reals)
  *   sgv_prof_*, sgv_launch_count, sgv_variant_count, sgv_variant_name
  *                      <- no reference counterpart: per-launch HIP-event timing and launch / kernel-variant counters used by
  *                          bench.py (roofline numbers) and by the tests (proof of which kernel served a shape)
@@ -71,7 +73,7 @@
 extern "C" {
 #endif
 
-#define SGV_VERSION 104 /* major*100 + minor */
+#define SGV_VERSION 105 /* major*100 + minor */
 
 /* element types (the reference dispatches double/float/half: upfirdn2d.cpp:59, bias_act.cpp:76;
  * bf16 is this library's extension) */
@@ -410,6 +412,14 @@ int sgv_affine_resample(const float* src, float* dst, const float* theta, int32_
  * the staging buffers takes a direct form in the same launch). */
 int sgv_ada_geometric(const float* x, float* y, const float* theta, const float* filter12, int32_t n, int32_t c, int32_t h, int32_t w,
                       int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, void* stream);
+
+/* The adjoint of sgv_ada_geometric (same arguments, same coefficient and tap arithmetic): dx = A^T dy for the linear map y = A x of that call; dy, dx [n, c, h, w].
+ * With sgv_ada_geometric it serves every order of derivative w.r.t. the image (the backward of the reference's block: the backward of grid_sample_gradfix.py:45-83,
+ * of upfirdn2d.py:249-260 twice and of the reflect pad).  dx is written, not accumulated.  Any affine map: samples with a singular / non-finite map or a zoom-in
+ * beyond ~3.4 are served by an atomics kernel behind the main one (two launches; the second returns at once for every other sample).  The bilinear transpose adds
+ * into LDS words in no fixed order (the reference's own backward, ATen's grid_sampler_2d_backward, uses global atomics): results repeat to rounding, not bitwise. */
+int sgv_ada_geometric_adjoint(const float* dy, float* dx, const float* theta, const float* filter12, int32_t n, int32_t c, int32_t h, int32_t w,
+                              int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * AlignedTimeEncoder element-wise tail (motion.py:201-212), fp32:

@@ -21,6 +21,7 @@
 #include "sgv_common.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -396,6 +397,385 @@ __global__ __launch_bounds__(256) void ada_geometric_forward_kernel(geom_params 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// ... and its ADJOINT as one kernel:   dx = pad^T( up2^T( resample^T( down2^T( dy ) ) ) )
+//
+// the gradient of the block w.r.t. the image (the generator's phase differentiates through augmented fakes, the R1 penalty twice through augmented reals:
+// src/training/loss.py:91-110, :144-164; reference backward: autograd through F.pad, upfirdn2d.py:249-260, grid_sample_gradfix.py:45-83).  The block is linear in
+// the image, so this kernel and the forward kernel are each other's derivative to every order (ops/resample.py `_AdaGeometric`).
+//
+// A workgroup (512 threads) owns a 16 x 16 tile of dx for one sample.  A source pixel p appears in the (virtual) padded image up to 3 x 3 times -- itself, and its
+// reflections about the left / right / top / bottom edges where the margin reaches that far -- so the tile is the sum over <= 9 IMAGES of the tile in the padded image;
+// an image whose pre-image under the sample's map misses the resampled picture (the usual case for the reflections) is dropped by a bounding-box test.  Per image, every
+// step the transpose of the forward kernel's step with the forward's own coefficients and tap arithmetic, in LDS:
+//   0. (once per image, for all channels) resample^T as a GATHER: the tile's 16 x 16 padded-image pixels are fed by a (2 * 16 + 10)^2 block of up-sampled pixels; a thread
+//      owns four of them, finds the hi-res pixels whose bilinear footprint contains each (they lie in a 3 x 3 window around the pixel's pre-image for every map that
+//      moves less than ~1.5 hi-res pixels per up-sampled pixel, a 4 x 4 window below ~2), evaluates their weights with the forward's coordinate arithmetic and keeps
+//      the 9 / 16 weights (zeros for non-contributors) in registers;
+//   a. per channel: the hi-res pixels those windows reach lie in the pre-image of the block's footprint: its bounding box (<= ADJ_GB^2) fixes the box of dy pixels
+//      needed ((box / 2 + 6)^2), read once;
+//   b. down2^T: zero-insertion + FIR, separable (one thread makes an odd and an even hi-res position from the same six dy values);
+//   c. resample^T: 9 / 16 LDS reads + FMAs per up-sampled pixel with the kept weights -- fixed summation order, no atomics;
+//   d. up2^T: 12-tap FIR + decimation, separable; the last step lands in dx (first image: store; further images: the same thread adds), mirrored images read their
+//      row / column backwards.
+// A sample whose box does not fit (zoom-in by more than ~1.25 at 45 degrees, 1.8 axis-aligned) is served in 8 x 8, 4 x 4 or 2 x 2 sub-tiles by the same code; one that
+// moves 2 or more hi-res pixels per up-sampled pixel (zoom-in beyond 1.4 .. 2) takes step c as a scatter with LDS float atomics (measured 6x slower: 0.37 atomic
+// lane-operations per clock and CU); one whose map is singular / not finite / zooms in by more than ~3.4 gets zeros here and the atomics kernel below
+// (`..._rest_kernel`, which returns at once for every other sample).
+
+constexpr int ADJ_T = 16;                     // dx tile
+constexpr int ADJ_NT = 512;                   // threads
+constexpr int ADJ_GB = 80;                    // largest staged box of hi-res gradient pixels (even)
+constexpr int ADJ_DB = ADJ_GB / 2 + 7;        // dy box under it (odd pitch)
+constexpr int ADJ_UB = 2 * ADJ_T + 10;        // up-sampled block over a full tile
+constexpr int ADJ_NU = (ADJ_UB * ADJ_UB + ADJ_NT - 1) / ADJ_NT;      // up-sampled pixels a thread owns
+
+struct adj_map { float a, b, d, e, cx, cy, det, hx, hy; };
+
+// affine map hi-res pixel -> up-sampled pixel in pixel units (ix = a X + b Y + cx, iy = d X + e Y + cy), and the tile size the gather form can serve (0: none)
+__device__ __forceinline__ int adj_plan(const geom_params& p, const float* th, adj_map& m) {
+    const float wu = 2.f * (p.w + p.mx0 + p.mx1), hu = 2.f * (p.h + p.my0 + p.my1), wo = 2.f * (p.w + 6), ho = 2.f * (p.h + 6);
+    m.a = th[0] * wu / wo; m.b = th[1] * wu / ho;
+    m.d = th[3] * hu / wo; m.e = th[4] * hu / ho;
+    m.cx = ((th[0] * (1.f / wo - 1.f) + th[1] * (1.f / ho - 1.f) + th[2] + 1.f) * wu - 1.f) * 0.5f;
+    m.cy = ((th[3] * (1.f / wo - 1.f) + th[4] * (1.f / ho - 1.f) + th[5] + 1.f) * hu - 1.f) * 0.5f;
+    m.det = m.a * m.e - m.b * m.d;
+    m.hx = m.hy = 0.f;
+    if (!(fabsf(m.det) > 1e-12f) || !(fabsf(m.cx) < 1e6f) || !(fabsf(m.cy) < 1e6f)) return 0;
+    m.hx = (fabsf(m.e) + fabsf(m.b)) / fabsf(m.det);     // half-widths of the bounding box of M^-1 [-1, 1]^2: hi-res pixels per up-sampled pixel
+    m.hy = (fabsf(m.d) + fabsf(m.a)) / fabsf(m.det);
+#pragma unroll
+    for (int t = ADJ_T; t >= 2; t >>= 1) {
+        const float r = (float)(2 * t + 11);      // the block's footprint rectangle: [u0 - 1, u0 + 2 t + 10]
+        if (r * m.hx + 7.f <= (float)ADJ_GB && r * m.hy + 7.f <= (float)ADJ_GB) return t;    // (+ 7: floor / ceil, one pixel of slack per side, odd start, even length)
+    }
+    return 0;
+}
+
+struct adj_image { int active, qbx, dirx, pax, pbx, qlox, qby, diry, pay, pby, qloy, Xlo, Wb, Ylo, Hb; };
+
+// one axis of one image: padded position of source pixel p is q = qb + dir * p for p in [pa, pb]; qlo = the smallest such q
+__device__ __forceinline__ void adj_axis(int kind, int p0, int t, int size, int m0, int m1, int& qb, int& dir, int& pa, int& pb, int& qlo) {
+    if (kind == 0) { qb = m0; dir = 1; pa = p0; pb = min(p0 + t, size) - 1; }
+    else if (kind == 1) { qb = m0; dir = -1; pa = max(p0, 1); pb = min(min(p0 + t - 1, m0), size - 1); }
+    else { qb = m0 + 2 * (size - 1); dir = -1; pa = max(p0, size - 1 - m1); pb = min(p0 + t - 1, size - 2); }
+    qlo = dir > 0 ? qb + pa : qb - pb;
+}
+
+__device__ __forceinline__ int adj_clampi(float v) { return (int)fminf(fmaxf(v, -4e6f), 4e6f); }
+
+// lanes per row of a (rows x cols) step: the smallest power of two >= cols (cols <= 128); an item index splits into (row, column) by shift / mask
+__device__ __forceinline__ int adj_lg(int cols) { return cols <= 16 ? 4 : cols <= 32 ? 5 : cols <= 64 ? 6 : 7; }
+
+__global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_params p) {      // p.x = dy, p.y = dx
+    __shared__ __attribute__((aligned(16))) float s_a[ADJ_DB * ADJ_DB];                  // dy box; later the up-sampled gradient block [ADJ_UB][ADJ_UB + 1]
+    __shared__ __attribute__((aligned(16))) float s_b[ADJ_DB * ADJ_GB];                  // dy rows expanded along x; later the vertically decimated block [t][ADJ_UB]
+    __shared__ __attribute__((aligned(16))) float s_c[ADJ_GB * (ADJ_GB + 1)];            // hi-res gradient box
+    __shared__ adj_image s_img[9];
+    static_assert(ADJ_UB * (ADJ_UB + 1) <= ADJ_DB * ADJ_DB && ADJ_T * ADJ_UB <= ADJ_DB * ADJ_GB, "aliased buffers");
+    float* s_gu = s_a;
+    float* s_v = s_b;
+
+    const int tid = threadIdx.x;
+    const int n = blockIdx.z;
+    const int wp = p.w + p.mx0 + p.mx1, hp = p.h + p.my0 + p.my1, wu = 2 * wp, hu = 2 * hp;
+    const int wo = 2 * (p.w + 6), ho = 2 * (p.h + 6);
+    const float* th = p.theta + (size_t)n * 6;
+    const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
+    const size_t plane_sz = (size_t)p.h * p.w;
+    adj_map m;
+    const int T = adj_plan(p, th, m);
+    if (T == 0) {        // the atomics kernel adds this sample's gradient onto zeros
+        const int py = blockIdx.y * ADJ_T + tid / ADJ_T, px = blockIdx.x * ADJ_T + tid % ADJ_T;
+        if (tid < ADJ_T * ADJ_T && px < p.w && py < p.h)
+            for (int ch = 0; ch < p.c; ch++) p.y[((size_t)n * p.c + ch) * plane_sz + (size_t)py * p.w + px] = 0.f;
+        return;
+    }
+    // contributors of an up-sampled pixel fit a 3 x 3 / 4 x 4 window of hi-res pixels (an interval of length 2 h + 0.02 holds at most floor(2 h + 0.02) + 1 integers)
+    const int win = (m.hx < 1.48f && m.hy < 1.48f) ? 3 : (m.hx < 1.98f && m.hy < 1.98f) ? 4 : 0;
+    const int UBT = 2 * T + 10;
+    const int nsub = ADJ_T / T;
+    const float inv_det = 1.f / m.det;
+
+    // affine_resample_kernel's arithmetic for one hi-res pixel
+    auto source = [&](int X, int Y, float& ix, float& iy) {
+        const float xn = (2 * X + 1) / (float)wo - 1.f, yn = (2 * Y + 1) / (float)ho - 1.f;
+        const float gx = t0 * xn + t1 * yn + t2, gy = t3 * xn + t4 * yn + t5;
+        ix = ((gx + 1.f) * wu - 1.f) * 0.5f;
+        iy = ((gy + 1.f) * hu - 1.f) * 0.5f;
+    };
+
+    for (int sub = 0; sub < nsub * nsub; sub++) {
+        const int px0 = blockIdx.x * ADJ_T + (sub % nsub) * T, py0 = blockIdx.y * ADJ_T + (sub / nsub) * T;
+        if (px0 >= p.w || py0 >= p.h) continue;           // (uniform)
+        __syncthreads();                                   // the previous sub-tile's readers of s_img
+        if (tid < 9) {
+            adj_image im;
+            adj_axis(tid % 3, px0, T, p.w, p.mx0, p.mx1, im.qbx, im.dirx, im.pax, im.pbx, im.qlox);
+            adj_axis(tid / 3, py0, T, p.h, p.my0, p.my1, im.qby, im.diry, im.pay, im.pby, im.qloy);
+            im.active = im.pax <= im.pbx && im.pay <= im.pby;
+            im.Xlo = im.Ylo = 1; im.Wb = im.Hb = 0;
+            if (im.active) {
+                // footprint rectangle of the up-sampled block (clipped to the up-sampled image + 1: nothing outside it receives gradient)
+                const float rx0 = fmaxf((float)(2 * im.qlox - 6), -1.f), rx1 = fminf((float)(2 * im.qlox - 5 + UBT), (float)wu);
+                const float ry0 = fmaxf((float)(2 * im.qloy - 6), -1.f), ry1 = fminf((float)(2 * im.qloy - 5 + UBT), (float)hu);
+                float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const float ux = ((k & 1) ? rx1 : rx0) - m.cx, uy = ((k & 2) ? ry1 : ry0) - m.cy;
+                    const float X = (m.e * ux - m.b * uy) * inv_det, Y = (-m.d * ux + m.a * uy) * inv_det;
+                    xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+                }
+                int Xlo = max(adj_clampi(floorf(xmin)) - 1, 1), Xhi = min(adj_clampi(ceilf(xmax)) + 1, wo - 1);     // (hi-res column / row 0 is read by no output)
+                int Ylo = max(adj_clampi(floorf(ymin)) - 1, 1), Yhi = min(adj_clampi(ceilf(ymax)) + 1, ho - 1);
+                Xlo -= !(Xlo & 1); Ylo -= !(Ylo & 1);         // odd start: the pair (odd, even) shares its dy taps
+                im.Xlo = Xlo; im.Ylo = Ylo;
+                im.Wb = min((Xhi - Xlo + 2) & ~1, ADJ_GB);
+                im.Hb = min((Yhi - Ylo + 2) & ~1, ADJ_GB);
+                if (Xhi < Xlo || Yhi < Ylo || rx0 > rx1 || ry0 > ry1) im.active = 0;
+            }
+            s_img[tid] = im;
+        }
+        __syncthreads();
+
+        const int lyp = tid / T, lxp = tid - lyp * T;       // this thread's pixel of the sub-tile (tid < T * T)
+        const int px = px0 + lxp, py = py0 + lyp;
+        const bool mine = tid < T * T && px < p.w && py < p.h;
+        float* const out = p.y + (size_t)n * p.c * plane_sz + (size_t)py * p.w + px;
+
+        if (!s_img[0].active && mine)                       // (the tile itself sees nothing of the picture: the reflections, if any, add onto zeros)
+            for (int ch = 0; ch < p.c; ch++) out[(size_t)ch * plane_sz] = 0.f;
+
+        // one image of the tile, all channels; WIN = 3 / 4: resample^T as a gather over WIN x WIN windows, 0: as a scatter with LDS atomics
+        auto image_pass = [&](const adj_image& im, bool add, auto win_c) {
+            constexpr int WIN = decltype(win_c)::value;
+            constexpr int NW = WIN ? WIN * WIN : 1;
+            const int Xlo = im.Xlo, Ylo = im.Ylo, Wb = im.Wb, Hb = im.Hb, W2 = Wb >> 1, H2 = Hb >> 1;
+            const int oxlo = ((Xlo - 1) >> 1) - 5, oylo = ((Ylo - 1) >> 1) - 5;
+            const int dbw = W2 + 5, dbh = H2 + 5;
+            const int U0x = 2 * im.qlox - 5, U0y = 2 * im.qloy - 5;
+            const bool here = mine && px >= im.pax && px <= im.pbx && py >= im.pay && py <= im.pby;
+            const int qxl = im.qbx + im.dirx * px - im.qlox, qyl = im.qby + im.diry * py - im.qloy;
+            const int lg_a = adj_lg(dbw), lg_b1 = adj_lg((W2 + 1) >> 1), lg_b2 = adj_lg(Wb), lg_d1 = adj_lg(UBT);
+
+            // 0. resample^T as a gather: this thread's up-sampled pixels, their candidate windows, the forward's weights (1 - |ix - ux|) (1 - |iy - uy|), zero
+            //    for a hi-res pixel whose footprint misses the pixel
+            float wt[ADJ_NU][NW];
+            int wbase[ADJ_NU], woff[ADJ_NU];
+            if (WIN) {
+#pragma unroll
+                for (int k = 0; k < ADJ_NU; k++) {
+                    const int idx = tid + k * ADJ_NT;
+                    const int uyl = idx / UBT, uxl = idx - uyl * UBT;
+                    woff[k] = idx < UBT * UBT ? uyl * (ADJ_UB + 1) + uxl : -1;
+                    const int ux = U0x + uxl, uy = U0y + uyl;
+                    const bool inside = idx < UBT * UBT && ux >= 0 && ux < wu && uy >= 0 && uy < hu;
+                    const float dux = (float)ux - m.cx, duy = (float)uy - m.cy;
+                    const float qx = (m.e * dux - m.b * duy) * inv_det, qy = (-m.d * dux + m.a * duy) * inv_det;
+                    const int X0 = adj_clampi(ceilf(qx - m.hx - 0.01f)), Y0 = adj_clampi(ceilf(qy - m.hy - 0.01f));
+                    wbase[k] = inside ? (Y0 - Ylo) * (ADJ_GB + 1) + (X0 - Xlo) : 0;
+#pragma unroll
+                    for (int j = 0; j < NW; j++) {
+                        const int X = X0 + (j % (WIN ? WIN : 1)), Y = Y0 + (j / (WIN ? WIN : 1));
+                        float ix, iy;
+                        source(X, Y, ix, iy);
+                        const float wx = fmaxf(1.f - fabsf(ix - (float)ux), 0.f), wy = fmaxf(1.f - fabsf(iy - (float)uy), 0.f);
+                        const bool ok = inside && X >= Xlo && X < Xlo + Wb && Y >= Ylo && Y < Ylo + Hb && X < wo && Y < ho;
+                        wt[k][j] = ok ? wx * wy : 0.f;
+                    }
+                }
+            }
+
+            for (int ch = 0; ch < p.c; ch++) {
+                const float* plane = p.x + ((size_t)n * p.c + ch) * plane_sz;
+                // a. dy box (zeros outside the picture)
+                for (int idx = tid; idx < (dbh << lg_a); idx += ADJ_NT) {
+                    const int r = idx >> lg_a, ci = idx & ((1 << lg_a) - 1);
+                    if (ci >= dbw) continue;
+                    const int oy = oylo + r, ox = oxlo + ci;
+                    s_a[r * ADJ_DB + ci] = (ox >= 0 && ox < p.w && oy >= 0 && oy < p.h) ? plane[(size_t)oy * p.w + ox] : 0.f;
+                }
+                __syncthreads();
+                // b1. down2^T along x: hi-res columns Xlo + 2k (odd: taps fd[0], fd[2], ..) and Xlo + 2k + 1 (even: fd[1], fd[3], ..) from dy columns k .. k + 5;
+                //     a thread makes k and k + 1 (four hi-res columns) from seven dy values
+                for (int idx = tid; idx < (dbh << lg_b1); idx += ADJ_NT) {
+                    const int r = idx >> lg_b1, k = (idx & ((1 << lg_b1) - 1)) * 2;
+                    if (k >= W2) continue;
+                    const float* q = s_a + r * ADJ_DB + k;
+                    float v[7];
+#pragma unroll
+                    for (int j = 0; j < 7; j++) v[j] = q[j];
+                    float o0 = 0.f, e0 = 0.f, o1 = 0.f, e1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        o0 = __builtin_fmaf(p.fd[2 * j], v[5 - j], o0); e0 = __builtin_fmaf(p.fd[2 * j + 1], v[5 - j], e0);
+                        o1 = __builtin_fmaf(p.fd[2 * j], v[6 - j], o1); e1 = __builtin_fmaf(p.fd[2 * j + 1], v[6 - j], e1);
+                    }
+                    float* w_ = s_b + r * ADJ_GB + 2 * k;
+                    if (k + 1 < W2) *reinterpret_cast<float4*>(w_) = make_float4(o0, e0, o1, e1);
+                    else *reinterpret_cast<float2*>(w_) = make_float2(o0, e0);
+                }
+                __syncthreads();
+                // b2. ... along y: rows 2k, 2k + 1 (pair k) and 2k + 2, 2k + 3 (pair k + 1) from seven rows
+                for (int idx = tid; idx < (((H2 + 1) >> 1) << lg_b2); idx += ADJ_NT) {
+                    const int k = (idx >> lg_b2) * 2, j_ = idx & ((1 << lg_b2) - 1);
+                    if (j_ >= Wb) continue;
+                    const float* q = s_b + k * ADJ_GB + j_;
+                    float v[7];
+#pragma unroll
+                    for (int j = 0; j < 7; j++) v[j] = q[j * ADJ_GB];
+                    float o0 = 0.f, e0 = 0.f, o1 = 0.f, e1 = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 6; j++) {
+                        o0 = __builtin_fmaf(p.fd[2 * j], v[5 - j], o0); e0 = __builtin_fmaf(p.fd[2 * j + 1], v[5 - j], e0);
+                        o1 = __builtin_fmaf(p.fd[2 * j], v[6 - j], o1); e1 = __builtin_fmaf(p.fd[2 * j + 1], v[6 - j], e1);
+                    }
+                    float* w_ = s_c + (2 * k) * (ADJ_GB + 1) + j_;
+                    w_[0] = o0; w_[ADJ_GB + 1] = e0;
+                    if (k + 1 < H2) { w_[2 * (ADJ_GB + 1)] = o1; w_[3 * (ADJ_GB + 1)] = e1; }
+                }
+                if (!WIN)
+                    for (int e = tid; e < UBT * (ADJ_UB + 1); e += ADJ_NT) s_gu[e] = 0.f;       // (the dy box is dead)
+                __syncthreads();
+                // c. resample^T
+                if (WIN) {
+#pragma unroll
+                    for (int k = 0; k < ADJ_NU; k++) {
+                        if (woff[k] < 0) continue;
+                        const float* q = s_c + wbase[k];
+                        float v = 0.f;
+#pragma unroll
+                        for (int j = 0; j < NW; j++) {
+                            const float g = q[(j / (WIN ? WIN : 1)) * (ADJ_GB + 1) + (j % (WIN ? WIN : 1))];      // (may lie outside the box: stale words, weight zero)
+                            v = __builtin_fmaf(wt[k][j], wt[k][j] != 0.f ? g : 0.f, v);
+                        }
+                        s_gu[woff[k]] = v;
+                    }
+                } else {
+                    // the forward's taps, scattered (LDS float atomics: the order of the additions into one word is not fixed)
+                    for (int idx = tid; idx < (Hb << lg_b2); idx += ADJ_NT) {
+                        const int ly = idx >> lg_b2, lx = idx & ((1 << lg_b2) - 1);
+                        const int X = Xlo + lx, Y = Ylo + ly;
+                        if (lx >= Wb || X >= wo || Y >= ho) continue;
+                        const float g = s_c[ly * (ADJ_GB + 1) + lx];
+                        float ix, iy;
+                        source(X, Y, ix, iy);
+                        const float fx = floorf(ix), fy = floorf(iy);
+                        const float tx = ix - fx, ty = iy - fy;
+                        const int x0 = adj_clampi(fx), y0 = adj_clampi(fy);
+                        const int bx = x0 - U0x, by = y0 - U0y;
+                        const bool vx0 = x0 >= 0 && x0 < wu && bx >= 0 && bx < UBT, vx1 = x0 + 1 >= 0 && x0 + 1 < wu && bx + 1 >= 0 && bx + 1 < UBT;
+                        const bool vy0 = y0 >= 0 && y0 < hu && by >= 0 && by < UBT, vy1 = y0 + 1 >= 0 && y0 + 1 < hu && by + 1 >= 0 && by + 1 < UBT;
+                        float* q = s_gu + by * (ADJ_UB + 1) + bx;
+                        if (vy0 && vx0) atomicAdd(q, (1.f - tx) * (1.f - ty) * g);
+                        if (vy0 && vx1) atomicAdd(q + 1, tx * (1.f - ty) * g);
+                        if (vy1 && vx0) atomicAdd(q + ADJ_UB + 1, (1.f - tx) * ty * g);
+                        if (vy1 && vx1) atomicAdd(q + ADJ_UB + 2, tx * ty * g);
+                    }
+                }
+                __syncthreads();
+                // d1. up2^T along y: padded rows qloy + r, r + 1 <- up-sampled rows 2 r .. 2 r + 13 of the block (taps 2 f[k]: fe / fo interleaved)
+                for (int idx = tid; idx < ((T >> 1) << lg_d1); idx += ADJ_NT) {
+                    const int r = (idx >> lg_d1) * 2, j_ = idx & ((1 << lg_d1) - 1);
+                    if (j_ >= UBT) continue;
+                    const float* q = s_gu + (2 * r) * (ADJ_UB + 1) + j_;
+                    float v[14];
+#pragma unroll
+                    for (int k = 0; k < 14; k++) v[k] = q[k * (ADJ_UB + 1)];
+                    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        a0 = __builtin_fmaf(p.fo[5 - k], v[2 * k], a0); a0 = __builtin_fmaf(p.fe[5 - k], v[2 * k + 1], a0);
+                        a1 = __builtin_fmaf(p.fo[5 - k], v[2 * k + 2], a1); a1 = __builtin_fmaf(p.fe[5 - k], v[2 * k + 3], a1);
+                    }
+                    s_v[r * ADJ_UB + j_] = a0;
+                    s_v[(r + 1) * ADJ_UB + j_] = a1;
+                }
+                __syncthreads();
+                // d2. ... along x, into dx: the tile's own image stores, a reflection adds (the same thread, the same address)
+                if (here) {
+                    const float* q = s_v + qyl * ADJ_UB + 2 * qxl;
+                    float v = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) {
+                        v = __builtin_fmaf(p.fo[5 - k], q[2 * k], v);
+                        v = __builtin_fmaf(p.fe[5 - k], q[2 * k + 1], v);
+                    }
+                    float* o = out + (size_t)ch * plane_sz;
+                    *o = add ? *o + v : v;
+                }
+                // (the next channel's step a writes s_a = s_gu, last read before the barrier above; its step b1 writes s_b = s_v behind its own barrier)
+            }
+        };
+
+        for (int img = 0; img < 9; img++) {
+            const adj_image im = s_img[img];
+            if (!im.active) continue;                       // (uniform)
+            if (win == 3) image_pass(im, img != 0, std::integral_constant<int, 3>{});
+            else if (win == 4) image_pass(im, img != 0, std::integral_constant<int, 4>{});
+            else image_pass(im, img != 0, std::integral_constant<int, 0>{});
+        }
+    }
+}
+
+// the atomics form for the samples the kernel above zero-filled: one thread per hi-res pixel, the whole chain scattered (4 x 36 atomics per pixel and channel)
+__global__ __launch_bounds__(256) void ada_geometric_adjoint_rest_kernel(geom_params p) {
+    const int n = blockIdx.z;
+    const float* th = p.theta + (size_t)n * 6;
+    adj_map m;
+    if (adj_plan(p, th, m) != 0) return;
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int wp = p.w + p.mx0 + p.mx1, hp = p.h + p.my0 + p.my1, wu = 2 * wp, hu = 2 * hp;
+    const int wo = 2 * (p.w + 6), ho = 2 * (p.h + 6);
+    if (X < 1 || Y < 1 || X >= wo || Y >= ho) return;
+    const float xn = (2 * X + 1) / (float)wo - 1.f, yn = (2 * Y + 1) / (float)ho - 1.f;
+    const float gx = th[0] * xn + th[1] * yn + th[2], gy = th[3] * xn + th[4] * yn + th[5];
+    const float lim = 1e7f;
+    float ix = ((gx + 1.f) * wu - 1.f) * 0.5f, iy = ((gy + 1.f) * hu - 1.f) * 0.5f;
+    if (!(ix == ix) || !(iy == iy)) return;                // (NaN map: the forward's taps fall outside)
+    ix = fminf(fmaxf(ix, -lim), lim); iy = fminf(fmaxf(iy, -lim), lim);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const float tx = ix - fx, ty = iy - fy;
+    const int x0 = (int)fx, y0 = (int)fy;
+    const size_t plane_sz = (size_t)p.h * p.w;
+    const int bx_ = (X - 1) >> 1, by_ = (Y - 1) >> 1, ex = !(X & 1), ey = !(Y & 1);
+    for (int ch = 0; ch < p.c; ch++) {
+        const float* plane = p.x + ((size_t)n * p.c + ch) * plane_sz;
+        float* out = p.y + ((size_t)n * p.c + ch) * plane_sz;
+        float g = 0.f;
+        for (int jy = 0; jy < 6; jy++) {
+            const int oy = by_ - jy;
+            if (oy < 0 || oy >= p.h) continue;
+            float row = 0.f;
+            for (int jx = 0; jx < 6; jx++) {
+                const int ox = bx_ - jx;
+                if (ox >= 0 && ox < p.w) row = __builtin_fmaf(p.fd[2 * jx + ex], plane[(size_t)oy * p.w + ox], row);
+            }
+            g = __builtin_fmaf(p.fd[2 * jy + ey], row, g);
+        }
+        if (g == 0.f) continue;
+        for (int tap = 0; tap < 4; tap++) {
+            const int ux = x0 + (tap & 1), uy = y0 + (tap >> 1);
+            if (ux < 0 || ux >= wu || uy < 0 || uy >= hu) continue;
+            const float wgt = ((tap & 1) ? tx : 1.f - tx) * ((tap >> 1) ? ty : 1.f - ty) * g;
+            // up-sampled pixel 2 i <- fe[t] P[i + t - 3];  2 i + 1 <- fo[t] P[i + t - 2]
+            const int qx0 = (ux >> 1) - 3 + (ux & 1), qy0 = (uy >> 1) - 3 + (uy & 1);
+            for (int r = 0; r < 6; r++) {
+                const int qy = qy0 + r;
+                if (qy < 0 || qy >= hp) continue;
+                const float wr = ((uy & 1) ? p.fo[r] : p.fe[r]) * wgt;
+                const int sy = geo_reflect(qy - p.my0, p.h);
+                for (int t = 0; t < 6; t++) {
+                    const int qx = qx0 + t;
+                    if (qx < 0 || qx >= wp) continue;
+                    atomicAdd(out + (size_t)sy * p.w + geo_reflect(qx - p.mx0, p.w), ((ux & 1) ? p.fo[t] : p.fe[t]) * wr);
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int sgv_affine_resample(const float* src, float* dst, const float* theta, int32_t n, int32_t c, int32_t h, int32_t w, int32_t ho, int32_t wo,
@@ -445,4 +825,28 @@ extern "C" int sgv_ada_geometric(const float* x, float* y, const float* theta, c
     dim3 grid((unsigned)((w + GEO_TO - 1) / GEO_TO), (unsigned)((h + GEO_TO - 1) / GEO_TO), (unsigned)n);
     hipLaunchKernelGGL(ada_geometric_forward_kernel, grid, dim3(256), 0, stream, p);
     return sgv_check_launch("ada_geometric_forward_kernel");
+}
+
+extern "C" int sgv_ada_geometric_adjoint(const float* dy, float* dx, const float* theta, const float* filter12, int32_t n, int32_t c, int32_t h, int32_t w,
+                                         int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, void* stream_) {
+    if (!dy || !dx || !theta || !filter12) return sgv_fail(SGV_ERR_INVALID_ARG, "ada_geometric_adjoint: NULL pointer");
+    if (n < 1 || c < 1 || h < 2 || w < 2) return sgv_fail(SGV_ERR_INVALID_ARG, "ada_geometric_adjoint: sizes must be positive (images of at least 2x2)");
+    if (mx0 < 0 || mx1 < 0 || my0 < 0 || my1 < 0 || mx0 > w - 1 || mx1 > w - 1 || my0 > h - 1 || my1 > h - 1)
+        return sgv_fail(SGV_ERR_INVALID_ARG, "ada_geometric_adjoint: the reflect margin must lie in [0, size - 1]");
+    if (n > 65535 || (2 * (h + 6) + 3) / 4 > 65535) return sgv_fail(SGV_ERR_TOO_LARGE, "ada_geometric_adjoint: batch / height too large");
+    if ((int64_t)n * c * h * w > INT32_MAX || (int64_t)3 * w > (1 << 20) || (int64_t)3 * h > (1 << 20)) return sgv_fail(SGV_ERR_TOO_LARGE, "ada_geometric_adjoint: tensors are too large");
+    geom_params p{};
+    p.x = dy; p.y = dx; p.theta = theta;
+    p.n = n; p.c = c; p.h = h; p.w = w;
+    p.mx0 = mx0; p.mx1 = mx1; p.my0 = my0; p.my1 = my1;
+    for (int t = 0; t < 6; t++) { p.fe[t] = 2.f * filter12[11 - 2 * t]; p.fo[t] = 2.f * filter12[10 - 2 * t]; }      // the forward's coefficients, bit for bit
+    for (int m = 0; m < 12; m++) p.fd[m] = filter12[m];
+    hipStream_t stream = (hipStream_t)stream_;
+    sgv_launch_scope scope(SGV_K_POINTWISE, stream, 8.0 * n * c * (double)h * w);
+    dim3 grid((unsigned)((w + ADJ_T - 1) / ADJ_T), (unsigned)((h + ADJ_T - 1) / ADJ_T), (unsigned)n);
+    hipLaunchKernelGGL(ada_geometric_adjoint_kernel, grid, dim3(ADJ_NT), 0, stream, p);
+    // samples the gather form cannot serve (singular / extreme maps): zero-filled above, scattered here; every other sample's workgroups return at once
+    dim3 rgrid((unsigned)((2 * (w + 6) + 63) / 64), (unsigned)((2 * (h + 6) + 3) / 4), (unsigned)n);
+    hipLaunchKernelGGL(ada_geometric_adjoint_rest_kernel, rgrid, dim3(256), 0, stream, p);
+    return sgv_check_launch("ada_geometric_adjoint_kernel");
 }

@@ -314,6 +314,7 @@ ABI_SYMBOLS = {
     'sgv_time_encode': (c_int, [ctypes.POINTER(TimeEncodeParams), c_void_p]),
     'sgv_affine_resample': (c_int, [c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_ada_geometric': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
+    'sgv_ada_geometric_adjoint': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p]),
     'sgv_gemm_f32': (c_int, [ctypes.POINTER(GemmParams), c_void_p]),
     'sgv_fc': (c_int, [ctypes.POINTER(FcParams), c_void_p]),
     'sgv_fc_grouped': (c_int, [ctypes.POINTER(FcParams), c_int32, c_void_p]),

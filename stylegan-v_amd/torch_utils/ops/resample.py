@@ -71,23 +71,48 @@ def ada_geometric_ref(x, theta, f, margin):
 
 
 def ada_geometric_fused_ok(x, f):
-    """One-kernel forward (csrc/resample.hip `ada_geometric_forward_kernel`): fp32 CUDA images that nothing will differentiate, the 12-tap filter."""
+    """One-kernel forms (csrc/resample.hip `ada_geometric_forward_kernel` / `ada_geometric_adjoint_kernel`): fp32 CUDA images, the 12-tap filter."""
     return (enabled and x.is_cuda and x.dtype == torch.float32 and x.ndim == 4 and f.ndim == 1 and f.shape[0] == 12 and min(x.shape[2:]) >= 2
-            and not (x.requires_grad and torch.is_grad_enabled()) and x.shape[0] <= 65535)
+            and x.shape[0] <= 65535)
+
+
+def _launch_geometric(t, theta, taps, margin, adjoint):
+    import ctypes
+    lib = custom_ops.get_native()
+    tc = t.contiguous()
+    n, c, h, w = tc.shape
+    out = torch.empty_like(tc)
+    ctaps = (ctypes.c_float * 12)(*taps)
+    with custom_ops.device_guard(tc):
+        fn = lib.sgv_ada_geometric_adjoint if adjoint else lib.sgv_ada_geometric
+        custom_ops.check(fn(tc.data_ptr(), out.data_ptr(), theta.data_ptr(), ctypes.addressof(ctaps), n, c, h, w, *margin, custom_ops.raw_stream(tc)), lib)
+    return out
+
+
+class _AdaGeometric(torch.autograd.Function):
+    """y = A t (`adjoint` False: the block of augment.py:284-303 as one kernel) or A^T t (`adjoint` True: its backward as one kernel).  A is linear in the image,
+    so the derivative of either direction is the other: the node differentiates to any order -- the generator's phase (loss.py:91-110: one backward through
+    augmented fakes) and the R1 penalty (loss.py:144-164: a gradient of a gradient through augmented reals) run these two kernels and nothing else."""
+
+    @staticmethod
+    def forward(ctx, t, theta, taps, margin, adjoint):
+        ctx.args = (theta, taps, margin, adjoint)
+        return _launch_geometric(t, theta, taps, margin, adjoint)
+
+    @staticmethod
+    def backward(ctx, g):
+        theta, taps, margin, adjoint = ctx.args
+        return (_AdaGeometric.apply(g, theta, taps, margin, not adjoint) if ctx.needs_input_grad[0] else None), None, None, None, None
 
 
 def ada_geometric(x, theta, f, margin, f_host=None):
-    """y = down2(resample(up2(reflect_pad(x)))) -- ONE launch when ``ada_geometric_fused_ok`` (no gradient: backward passes keep the composition, whose
-    nodes differentiate to any order).  ``f_host``: the filter's taps as a list of floats (they travel as launch arguments; read back once otherwise)."""
+    """y = down2(resample(up2(reflect_pad(x)))) -- ONE launch when ``ada_geometric_fused_ok``, and one (plus an empty second one, see sgv_ops.h) per backward
+    pass of any order.  ``f_host``: the filter's taps as a list of floats (they travel as launch arguments; read back once otherwise)."""
     margin = tuple(int(m) for m in margin)
     if not ada_geometric_fused_ok(x, f) or theta.requires_grad:
         return ada_geometric_ref(x, theta, f, margin)
-    import ctypes
-    lib = custom_ops.get_native()
-    taps = (ctypes.c_float * 12)(*(f_host if f_host is not None else f.detach().cpu().tolist()))
-    xc, th = x.detach().contiguous(), theta.detach().contiguous().float()
-    n, c, h, w = xc.shape
-    y = torch.empty_like(xc)
-    with custom_ops.device_guard(xc):
-        custom_ops.check(lib.sgv_ada_geometric(xc.data_ptr(), y.data_ptr(), th.data_ptr(), ctypes.addressof(taps), n, c, h, w, *margin, custom_ops.raw_stream(xc)), lib)
-    return y
+    taps = tuple(f_host if f_host is not None else f.detach().cpu().tolist())
+    th = theta.detach().contiguous().float()
+    if x.requires_grad and torch.is_grad_enabled():
+        return _AdaGeometric.apply(x, th, taps, margin, False)
+    return _launch_geometric(x.detach(), th, taps, margin, False)

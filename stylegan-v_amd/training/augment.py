@@ -79,7 +79,7 @@ class AugmentPipe(torch.nn.Module):
         self.static_margin = False
         # True: draw / compose the per-sample parameters on the host and upload the results (module docstring).  Only takes effect for CUDA images outside capture.
         self.host_params = True
-        self.fused_geometric = True   # forward-only calls: the geometric execution as one kernel (ops/resample.py ada_geometric)
+        self.fused_geometric = True   # the geometric execution as one kernel per direction (ops/resample.py ada_geometric)
         self._p_host = None      # (id of the buffer's storage, its version, 0-d CPU tensor)
         self._const = {}
 
@@ -245,7 +245,7 @@ class AugmentPipe(torch.nn.Module):
         theta = self._upload(g_inv[:, :2, :].contiguous(), images.device)
         if self.fused_geometric and resample.ada_geometric_fused_ok(images, self.Hz_geom):
             # reflect pad -> up -> resample -> down as ONE kernel: no padded / up-sampled / resampled image in memory (csrc/resample.hip); calls that
-            # will be differentiated (the generator's phase, R1) keep the composition below, whose nodes differentiate to any order
+            # will be differentiated (the generator's phase, R1) get the node whose backward is the block's adjoint as one kernel
             return resample.ada_geometric(images, theta, self.Hz_geom, (mx0, mx1, my0, my1), f_host=self._filter_taps())
         images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
         images = upfirdn2d.upsample2d(images, self.Hz_geom, up=2)

@@ -664,18 +664,43 @@ def gen_ada_geometric():
     margin = margin + torch.tensor([Hz_pad * 2 - cx, Hz_pad * 2 - cy] * 2)
     margin = margin.max(torch.tensor([0.0, 0.0] * 2)).min(torch.tensor([w - 1.0, h - 1.0] * 2))
     mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().to(torch.int32))
-    images = torch.nn.functional.pad(input=x, pad=[mx0, mx1, my0, my1], mode='reflect')
-    G = A.translate2d((mx0 - mx1) / 2, (my0 - my1) / 2) @ G_inv
-    images = R_ufd.upsample2d(x=images, f=Hz, up=2)
-    G = A.scale2d(2, 2, device=dev) @ G @ A.scale2d_inv(2, 2, device=dev)
-    G = A.translate2d(-0.5, -0.5, device=dev) @ G @ A.translate2d_inv(-0.5, -0.5, device=dev)
-    shape = [n, ch, (h + Hz_pad * 2) * 2, (w + Hz_pad * 2) * 2]
-    G = A.scale2d(2 / images.shape[3], 2 / images.shape[2], device=dev) @ G @ A.scale2d_inv(2 / shape[3], 2 / shape[2], device=dev)
-    theta = G[:, :2, :]
-    grid = torch.nn.functional.affine_grid(theta=theta, size=shape, align_corners=False)
-    images = R_gs.grid_sample(images, grid)
-    y = R_ufd.downsample2d(x=images, f=Hz, down=2, padding=-Hz_pad * 2, flip_filter=True)
-    save('ada_geometric', dict(x=x, G_inv=G_inv, theta=theta, y=y, taps=Hz), dict(margin=[mx0, mx1, my0, my1], note='margin order: mx0, mx1, my0, my1 (the pad call of augment.py:284)'))
+    def block(x_in):
+        images = torch.nn.functional.pad(input=x_in, pad=[mx0, mx1, my0, my1], mode='reflect')
+        G = A.translate2d((mx0 - mx1) / 2, (my0 - my1) / 2) @ G_inv
+        images = R_ufd.upsample2d(x=images, f=Hz, up=2)
+        G = A.scale2d(2, 2, device=dev) @ G @ A.scale2d_inv(2, 2, device=dev)
+        G = A.translate2d(-0.5, -0.5, device=dev) @ G @ A.translate2d_inv(-0.5, -0.5, device=dev)
+        shape = [n, ch, (h + Hz_pad * 2) * 2, (w + Hz_pad * 2) * 2]
+        G = A.scale2d(2 / images.shape[3], 2 / images.shape[2], device=dev) @ G @ A.scale2d_inv(2 / shape[3], 2 / shape[2], device=dev)
+        theta = G[:, :2, :]
+        grid = torch.nn.functional.affine_grid(theta=theta, size=shape, align_corners=False)
+        images = R_gs.grid_sample(images, grid)
+        return R_ufd.downsample2d(x=images, f=Hz, down=2, padding=-Hz_pad * 2, flip_filter=True), theta
+
+    y, theta = block(x)
+    # first order (what Gmain's backward sends through the block, loss.py:91-110): dx = d<y, v>/dx
+    xg = x.clone().requires_grad_(True)
+    v = torch.randn(y.shape, generator=g)
+    (dx,) = torch.autograd.grad((block(xg)[0] * v).sum(), xg)
+    # second order, the shape of the R1 penalty (loss.py:144-164: loss = D(aug(x)); g = d loss / dx with create_graph; penalty = |g|^2; d penalty / d...):
+    # a cubic stands in for D.  s = sum(y^3), r1_g = ds/dx, r1_gg = d|r1_g|^2 / dx.
+    xg = x.clone().requires_grad_(True)
+    yg = block(xg)[0]
+    (r1_g,) = torch.autograd.grad((yg ** 3).sum(), xg, create_graph=True)
+    try:
+        (r1_gg,) = torch.autograd.grad(r1_g.square().sum(), xg)
+        how = 'autograd twice through the reference block'
+    except RuntimeError as err:
+        # this torch has no derivative for grid_sampler_2d_backward (the reason grid_sample_gradfix exists; its own hook needs torch 1.7-1.9 internals): the
+        # block is linear in the image (y = A x), so d|A^T(3 y^2)|^2/dx = A^T( 6 y * A(2 A^T(3 y^2)) ) -- every factor a reference forward / first-order backward
+        print('  (double backward through grid_sample unavailable here: %s)' % str(err).splitlines()[0])
+        r1_g = r1_g.detach()
+        a_g = block(2 * r1_g)[0]
+        xg = x.clone().requires_grad_(True)
+        (r1_gg,) = torch.autograd.grad((block(xg)[0] * (6 * y * a_g)).sum(), xg)
+        how = 'composed from reference forward / first-order backward evaluations (the block is linear in the image)'
+    extra = dict(v=v, dx=dx, r1_g=r1_g.detach(), r1_gg=r1_gg)
+    save('ada_geometric', dict(x=x, G_inv=G_inv, theta=theta, y=y, taps=Hz, **extra), dict(margin=[mx0, mx1, my0, my1], second_order=how, note='margin order: mx0, mx1, my0, my1 (the pad call of augment.py:284)'))
 
 
 def gen_time_encoder():

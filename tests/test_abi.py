@@ -25,7 +25,7 @@ def test_header_functions_all_exported_and_bound():
 
 def test_version_and_error_string():
     lib = custom_ops.get_native()
-    assert lib.sgv_version() == 104     # 1.04: sgv_fc_grouped (the style affines of a synthesis pass as one launch); upfirdn2d kernel kinds 4 / 5 (2x LDS-tile kernels); 1.01: terms = 4 (block-scaled fp16 split), sgv_absmax, the *_amax fields of the convolution / GEMM parameter blocks; 1.02: sgv_ada_geometric; 1.03: sgv_prof_resume (per-launch timing inside graph replays), x_amax2 required with x_scale, 4x4 images
+    assert lib.sgv_version() == 105     # 1.05: sgv_ada_geometric_adjoint; 1.04: sgv_fc_grouped (the style affines of a synthesis pass as one launch); upfirdn2d kernel kinds 4 / 5 (2x LDS-tile kernels); 1.01: terms = 4 (block-scaled fp16 split), sgv_absmax, the *_amax fields of the convolution / GEMM parameter blocks; 1.02: sgv_ada_geometric; 1.03: sgv_prof_resume (per-launch timing inside graph replays), x_amax2 required with x_scale, 4x4 images
     assert isinstance(lib.sgv_last_error(), bytes)
     assert lib.sgv_launch_count() >= 0
 

@@ -59,7 +59,7 @@ def test_static_worst_case_margin_reproduces_the_measured_margin_path():
 def test_augment_pipe_matches_reference_gpu():
     before = custom_ops.launch_count()
     _check_pipe('cuda', 1e-4)
-    assert custom_ops.launch_count() - before >= 5 * 6, 'upfirdn2d / resample kernels did not run'
+    assert custom_ops.launch_count() - before >= 5 * 4, 'geometric forward / adjoint + colour kernels did not run'
 
 
 @pytest.mark.gpu
@@ -133,7 +133,7 @@ def test_host_side_parameters_match_device_side_parameters_and_follow_p():
         ya = host(xa, debug_percentile=pct)
         launches_host = custom_ops.launch_count() - before
         yb = dev(xb, debug_percentile=pct)
-        assert launches_host >= 6            # up (2) + resample + down (2) + colour
+        assert launches_host == 2            # geometric execution (one kernel) + colour
         assert_close(ya, yb, atol=2e-5, rtol=2e-5, what=f'host- vs device-side parameters at percentile {pct}')
         v = torch.randn_like(ya)
         (ga,), (gb,) = torch.autograd.grad((ya * v).sum(), xa), torch.autograd.grad((yb * v).sum(), xb)
@@ -187,11 +187,84 @@ def test_geometric_execution_as_one_kernel_matches_the_four_pass_composition(sha
     assert ya.shape == yb.shape == x.shape
     for i in range(shape[0]):
         assert_close(ya[i], yb[i], atol=3e-5 * max(1.0, yb[i].abs().max().item()), rtol=1e-5, what=f'sample {i} (G_inv {g_inv[i].tolist()})')
-    # a call that will be differentiated keeps the composition (and so its gradients of any order)
+    # a call that will be differentiated is the same single launch (its backward: test_geometric_adjoint_*)
     xg = x.clone().requires_grad_(True)
     before = custom_ops.launch_count()
     yg = fused._resample(xg, g_inv)
-    assert custom_ops.launch_count() - before >= 4 and yg.requires_grad
+    assert custom_ops.launch_count() - before == 1 and yg.requires_grad
+    assert torch.equal(yg.detach(), ya)
+
+
+def _adjoint_maps():
+    """`_maps()` plus zoom-ins that take the adjoint kernel's 8 x 8, 4 x 4 and 2 x 2 sub-tiles, and maps it hands to the atomics kernel (singular, zoom-in by 5)."""
+    import math
+    extra = []
+    for ang, sx, sy, tx, ty in ((math.pi / 4, 0.72, 0.72, 1.0, 0.0), (0.5, 0.5, 0.55, -2.0, 1.5), (0.0, 0.34, 0.34, 0.0, 0.0), (0.3, 0.2, 0.2, 0.0, 0.0), (0.0, 0.0, 1.0, 0.0, 0.0),
+                                (0.0, 0.9, 1.05, 14.0, 9.0), (3.0, 1.0, 1.0, -12.0, 20.0)):
+        c, s_ = math.cos(ang), math.sin(ang)
+        extra.append([[sx * c, -sy * s_, tx], [sx * s_, sy * c, ty], [0.0, 0.0, 1.0]])
+    return torch.cat([_maps(), torch.tensor(extra)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,static', [((19, 9, 64, 64), False), ((19, 3, 40, 56), False), ((19, 2, 37, 23), False), ((19, 3, 48, 32), True), ((19, 1, 18, 70), True)])
+def test_geometric_adjoint_as_one_kernel_matches_the_composition_backward(shape, static):
+    """The block's backward as ONE kernel (csrc/resample.hip `ada_geometric_adjoint_kernel`; + the atomics kernel that returns at once unless a sample's map is
+    singular / an extreme zoom-in) against autograd through the four-pass composition: every map of the forward test, zoom-ins that take the sub-tile forms, maps for
+    the atomics kernel, translations that make the reflected copies of the image visible (the <= 9 images of a tile), measured and static margin, sizes that are not
+    multiples of the tile.  Then the inner-product identity <A x, v> = <x, A^T v> against the forward KERNEL (an exact pair up to summation order), and the
+    second derivative (the R1 shape) against the composition's."""
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(shape, generator=g).cuda()
+    v = torch.randn(shape, generator=g).cuda()
+    g_inv = _adjoint_maps()
+    fused, comp = AugmentPipe(**BGC).cuda(), AugmentPipe(**BGC).cuda()
+    comp.fused_geometric = False
+    fused.static_margin = comp.static_margin = static
+    if static:
+        g_inv = g_inv.cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya, yb = fused._resample(xa, g_inv), comp._resample(xb, g_inv)
+    before = custom_ops.launch_count()
+    (da,) = torch.autograd.grad((ya * v).sum(), xa)
+    assert custom_ops.launch_count() - before == 1, 'the backward pass is one call (the adjoint kernel + the atomics kernel that returns at once)'
+    (db,) = torch.autograd.grad((yb * v).sum(), xb)
+    for i in range(shape[0]):
+        assert_close(da[i], db[i], atol=3e-5 * max(1.0, db[i].abs().max().item()), rtol=1e-5, what=f'dx of sample {i} (G_inv {g_inv[i].tolist()})')
+        lhs, rhs = (ya[i].double() * v[i].double()).sum().item(), (x[i].double() * da[i].double()).sum().item()
+        assert abs(lhs - rhs) <= 2e-5 * (ya[i].double() * v[i].double()).abs().sum().item() + 1e-6, f'<A x, v> = {lhs} vs <x, A^T v> = {rhs} for sample {i}'
+    # second order: s = sum(y^3); g = ds/dx (graph kept); d|g|^2/dx -- backward of the adjoint node = the forward kernel, then the adjoint again
+    def second(pipe):
+        xs = x.clone().requires_grad_(True)
+        ys = pipe._resample(xs, g_inv)
+        (g1,) = torch.autograd.grad((ys ** 3).sum(), xs, create_graph=True)
+        (g2,) = torch.autograd.grad(g1.square().sum(), xs)
+        return g1.detach(), g2
+    (g1a, g2a), (g1b, g2b) = second(fused), second(comp)
+    for i in range(shape[0]):
+        assert_close(g1a[i], g1b[i], atol=1e-4 * max(1.0, g1b[i].abs().max().item()), rtol=1e-4, what=f'first derivative of the cubic, sample {i}')
+        assert_close(g2a[i], g2b[i], atol=2e-4 * max(1.0, g2b[i].abs().max().item()), rtol=2e-4, what=f'second derivative, sample {i}')
+
+
+@pytest.mark.gpu
+def test_geometric_adjoint_matches_the_reference_gpu():
+    """First and second derivative of the block through the two kernels against the REFERENCE's (tests/golden/ada_geometric.npz: `dx` = d<y, v>/dx by the
+    reference's autograd; `r1_g`, `r1_gg` = the R1-shaped pair for a cubic head, see make_golden.py gen_ada_geometric)."""
+    pipe = AugmentPipe(**BGC).cuda()
+    theta = GEO.t('theta', device='cuda')
+    x = GEO.t('x', device='cuda').requires_grad_(True)
+    y = resample.ada_geometric(x, theta, pipe.Hz_geom, GEO.meta['margin'])
+    (dx,) = torch.autograd.grad((y * GEO.t('v', device='cuda')).sum(), x)
+    assert_close(dx, GEO.t('dx', device='cuda'), atol=5e-5, rtol=5e-5, what='dx through the one-kernel adjoint vs the reference')
+    x = GEO.t('x', device='cuda').requires_grad_(True)
+    y = pipe._resample(x, GEO.t('G_inv'))
+    before = custom_ops.launch_count()
+    (g1,) = torch.autograd.grad((y ** 3).sum(), x, create_graph=True)
+    (g2,) = torch.autograd.grad(g1.square().sum(), x)
+    assert custom_ops.launch_count() - before == 3, 'adjoint; forward kernel (the derivative of the adjoint node); adjoint'
+    want1, want2 = GEO.t('r1_g', device='cuda'), GEO.t('r1_gg', device='cuda')
+    assert_close(g1.detach(), want1, atol=1e-4 * want1.abs().max().item(), rtol=1e-4, what='first derivative of the cubic head vs the reference')
+    assert_close(g2, want2, atol=2e-4 * want2.abs().max().item(), rtol=2e-4, what='R1-shaped second derivative vs the reference')
 
 
 @pytest.mark.gpu
@@ -228,6 +301,24 @@ def test_geometric_execution_from_the_inverse_maps_matches_the_reference_cpu():
     assert_close(y, GEO.t('y'), atol=2e-5, rtol=2e-5, what='geometric execution (composition, CPU)')
     y2 = resample.ada_geometric_ref(x, GEO.t('theta'), pipe.Hz_geom, GEO.meta['margin'])
     assert_close(y2, GEO.t('y'), atol=2e-5, rtol=2e-5, what='composition from the fixture margin and theta')
+    xg = x.clone().requires_grad_(True)
+    (dx,) = torch.autograd.grad((resample.ada_geometric_ref(xg, GEO.t('theta'), pipe.Hz_geom, GEO.meta['margin']) * GEO.t('v')).sum(), xg)
+    assert_close(dx, GEO.t('dx'), atol=5e-5, rtol=5e-5, what="composition's input gradient vs the reference's")
+
+
+def test_reference_geometric_gradients_are_the_adjoint_of_the_oracle_block():
+    """The fixture's gradients against the ORACLE's forward (float64, oracle.ada_geometric): the block is linear, y = A x, so the reference's dx = A^T v satisfies
+    <z, dx> = <A z, v> for any z, and its R1-shaped pair r1_g = A^T(3 y^2), r1_gg = A^T(6 y * A(2 r1_g)) can be probed the same way -- no autograd in the oracle."""
+    import numpy as np
+    theta, taps, margin = GEO.t('theta').numpy(), GEO.t('taps').numpy(), GEO.meta['margin']
+    x, v, y = GEO.t('x').double().numpy(), GEO.t('v').double().numpy(), GEO.t('y').double().numpy()
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal(x.shape)
+    az = oracle.ada_geometric(z, theta, taps, margin)
+    for name, cot in (('dx', v), ('r1_g', 3 * y ** 2), ('r1_gg', 6 * y * oracle.ada_geometric(2 * GEO.t('r1_g').double().numpy(), theta, taps, margin))):
+        got, want = (z * GEO.t(name).double().numpy()).sum(axis=(1, 2, 3)), (az * cot).sum(axis=(1, 2, 3))
+        scale = abs(az * cot).sum(axis=(1, 2, 3))
+        assert (abs(got - want) <= 2e-5 * scale).all(), (name, got, want)
 
 
 @pytest.mark.gpu
