@@ -881,6 +881,32 @@ def main():
         finally:
             ts.set_augment('noaug')
 
+    # ... and the same step the way the headline runs it: Gmain / Dmain replayed as hipGraphs (static worst-case reflect margin: nothing is read back to the host; the
+    # geometric block is one kernel per direction, so the wider virtual padding costs nothing).  Its own models; same bracket and schedule.  `value_aug_ada_captured / value`
+    # is the like-for-like cost of the augmentation when `headline_mode` is "captured".
+    ada_cap = None
+    if ada is not None and headline_mode == 'captured' and world == 1:
+        ts_a = TrainStep(g_kwargs, d_kwargs, train_cfg, device=device, batch_gpu=args.batch_gpu, world_size=world, rank=rank, use_graphs=True, augment='ada')
+        try:
+            ts_a.batch_idx = 1
+            for _ in range(4):
+                ts_a.step()            # eager warm-up on a side stream + the captures + their first replays
+            torch.cuda.synchronize()
+            ts_a.batch_idx = 0
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.ada_steps):
+                ts_a.step()
+            barrier()
+            t_a = time.perf_counter() - t1
+            ada_cap = dict(value=global_batch * args.frames * args.ada_steps / t_a, ms_per_step=1e3 * t_a / args.ada_steps, steps=args.ada_steps, p_final=float(ts_a.augment_pipe.p),
+                           graphs=sorted(ts_a._graphs), what='aug=ada with Gmain / Dmain replayed as hipGraphs (the mode of the headline); static reflect margin')
+        except Exception as err:      # (a companion: report, do not fail the line)
+            ada_cap = dict(value=None, error=str(err).splitlines()[0][:200])
+        finally:
+            del ts_a
+            torch.cuda.empty_cache()
+
     # Path-length companion ("time PL in a separate F=1 run"): the reference's PL term only runs with one frame per video
     # (loss.py:117), so this is config 3 with num_frames_per_video = 1 and pl_weight = 2 (the StyleGAN2 default, train.py:189): Gmain, Greg (PL:
     # second order through G) every 4th, Dmain, Dreg every 16th; its own models (the frame count changes D's input layer), same bracket.
@@ -1079,14 +1105,14 @@ def main():
                                # companions of the same run as scalars (each is also a top-level value_* key with its details next to it)
                                value_no_prof=value_no_prof['value'] if value_no_prof else None, value_eager=value_eager['value'] if value_eager else None,
                                value_bf16_split=split3['value'] if split3 else None, value_vendor_fp32_convs=strict['value'] if strict else None,
-                               value_aug_ada=ada['value'] if ada else None, value_bf16_products=bf16c['value'] if bf16c else None,
+                               value_aug_ada=ada['value'] if ada else None, value_aug_ada_captured=ada_cap['value'] if ada_cap else None, value_bf16_products=bf16c['value'] if bf16c else None,
                                value_lowp_bf16=lowpc['value'] if lowpc else None, value_pl_f1=plc['value'] if plc else None, value_hip_graphs=graphc['value'] if graphc else None,
                                conv_terms=default_terms[0], upfirdn2d_in_step_GBps=roofline_ufd['achieved'] if roofline_ufd else None,
                                upfirdn2d_in_step_frac=roofline_ufd['frac'] if roofline_ufd else None),
                    multi_gpu=multi_gpu, step_ms=step_ms, power=power.summary() if power is not None else None, value_bf16_split=split3['value'] if split3 else None, bf16_split=split3,
                    value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof, value_eager=value_eager['value'] if value_eager else None, eager=value_eager,
                    value_fp32_grade=value if (default_terms in ((0, 0), (4, 4)) and lowp is None) else None,     # the headline's products are fp32-GRADE (22-bit split operands, 2.7e-7), not strict fp32: the strict-fp32 figure is value_vendor_fp32_convs
-                   value_vendor_fp32_convs=strict['value'] if strict else None, vendor_fp32_convs=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
+                   value_vendor_fp32_convs=strict['value'] if strict else None, vendor_fp32_convs=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_aug_ada_captured=ada_cap['value'] if ada_cap else None, aug_ada_captured=ada_cap, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
                    value_lowp_bf16=lowpc['value'] if lowpc else None, lowp_bf16=lowpc, value_hip_graphs=graphc['value'] if graphc else None, hip_graphs=graphc,
                    roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, upfirdn2d_by_size=ufd_by_size, kernels=kernels, kernels_by_variant=variants, cpu_baseline=cpu)
         emit(out)

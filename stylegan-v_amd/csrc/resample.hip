@@ -405,18 +405,20 @@ __global__ __launch_bounds__(256) void ada_geometric_forward_kernel(geom_params 
 // src/training/loss.py:91-110, :144-164; reference backward: autograd through F.pad, upfirdn2d.py:249-260, grid_sample_gradfix.py:45-83).  The block is linear in
 // the image, so this kernel and the forward kernel are each other's derivative to every order (ops/resample.py `_AdaGeometric`).
 //
-// A workgroup (512 threads) owns a 16 x 16 tile of dx for one sample.  A source pixel p appears in the (virtual) padded image up to 3 x 3 times -- itself, and its
+// A workgroup (256 threads, three per CU) owns a 16 x 16 tile of dx for one sample.  A source pixel p appears in the (virtual) padded image up to 3 x 3 times -- itself, and its
 // reflections about the left / right / top / bottom edges where the margin reaches that far -- so the tile is the sum over <= 9 IMAGES of the tile in the padded image;
 // an image whose pre-image under the sample's map misses the resampled picture (the usual case for the reflections) is dropped by a bounding-box test.  Per image, every
 // step the transpose of the forward kernel's step with the forward's own coefficients and tap arithmetic, in LDS:
 //   0. (once per image, for all channels) resample^T as a GATHER: the tile's 16 x 16 padded-image pixels are fed by a (2 * 16 + 10)^2 block of up-sampled pixels; a thread
-//      owns four of them, finds the hi-res pixels whose bilinear footprint contains each (they lie in a 3 x 3 window around the pixel's pre-image for every map that
-//      moves less than ~1.5 hi-res pixels per up-sampled pixel, a 4 x 4 window below ~2), evaluates their weights with the forward's coordinate arithmetic and keeps
+//      owns seven of them, finds the hi-res pixels whose bilinear footprint contains each (they lie in a 3 x 3 window around the pixel's pre-image for every map that
+//      moves less than ~1.5 hi-res pixels per up-sampled pixel, a 4 x 4 window below ~2 -- those in 8 x 8 sub-tiles), evaluates their weights with the forward's coordinate arithmetic and keeps
 //      the 9 / 16 weights (zeros for non-contributors) in registers;
 //   a. per channel: the hi-res pixels those windows reach lie in the pre-image of the block's footprint: its bounding box (<= ADJ_GB^2) fixes the box of dy pixels
 //      needed ((box / 2 + 6)^2), read once;
 //   b. down2^T: zero-insertion + FIR, separable (one thread makes an odd and an even hi-res position from the same six dy values);
-//   c. resample^T: 9 / 16 LDS reads + FMAs per up-sampled pixel with the kept weights -- fixed summation order, no atomics;
+//   c. resample^T: 9 / 16 LDS reads + FMAs per up-sampled pixel with the kept weights -- fixed summation order, no atomics (a window word outside the box meets a
+//      zero weight: the buffers start as zeros so that such a word is finite; a NaN / Inf in dy reaches the up-sampled pixels within a window of it rather than its
+//      four taps only);
 //   d. up2^T: 12-tap FIR + decimation, separable; the last step lands in dx (first image: store; further images: the same thread adds), mirrored images read their
 //      row / column backwards.
 // A sample whose box does not fit (zoom-in by more than ~1.25 at 45 degrees, 1.8 axis-aligned) is served in 8 x 8, 4 x 4 or 2 x 2 sub-tiles by the same code; one that
@@ -425,11 +427,12 @@ __global__ __launch_bounds__(256) void ada_geometric_forward_kernel(geom_params 
 // (`..._rest_kernel`, which returns at once for every other sample).
 
 constexpr int ADJ_T = 16;                     // dx tile
-constexpr int ADJ_NT = 512;                   // threads
+constexpr int ADJ_NT = 256;                   // threads
 constexpr int ADJ_GB = 80;                    // largest staged box of hi-res gradient pixels (even)
 constexpr int ADJ_DB = ADJ_GB / 2 + 7;        // dy box under it (odd pitch)
 constexpr int ADJ_UB = 2 * ADJ_T + 10;        // up-sampled block over a full tile
-constexpr int ADJ_NU = (ADJ_UB * ADJ_UB + ADJ_NT - 1) / ADJ_NT;      // up-sampled pixels a thread owns
+constexpr int ADJ_NU = (ADJ_UB * ADJ_UB + ADJ_NT - 1) / ADJ_NT;      // up-sampled pixels a thread owns (full tile: 3 x 3 windows)
+constexpr int ADJ_NU4 = (26 * 26 + ADJ_NT - 1) / ADJ_NT;              // ... in an 8 x 8 sub-tile (4 x 4 windows: 16 weights per pixel)
 
 struct adj_map { float a, b, d, e, cx, cy, det, hx, hy; };
 
@@ -468,14 +471,15 @@ __device__ __forceinline__ int adj_clampi(float v) { return (int)fminf(fmaxf(v, 
 // lanes per row of a (rows x cols) step: the smallest power of two >= cols (cols <= 128); an item index splits into (row, column) by shift / mask
 __device__ __forceinline__ int adj_lg(int cols) { return cols <= 16 ? 4 : cols <= 32 ? 5 : cols <= 64 ? 6 : 7; }
 
-__global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_params p) {      // p.x = dy, p.y = dx
+__global__ __launch_bounds__(ADJ_NT, 3) void ada_geometric_adjoint_kernel(geom_params p) {      // p.x = dy, p.y = dx
     __shared__ __attribute__((aligned(16))) float s_a[ADJ_DB * ADJ_DB];                  // dy box; later the up-sampled gradient block [ADJ_UB][ADJ_UB + 1]
     __shared__ __attribute__((aligned(16))) float s_b[ADJ_DB * ADJ_GB];                  // dy rows expanded along x; later the vertically decimated block [t][ADJ_UB]
-    __shared__ __attribute__((aligned(16))) float s_c[ADJ_GB * (ADJ_GB + 1)];            // hi-res gradient box
+    __shared__ __attribute__((aligned(16))) float s_cs[(ADJ_GB + 6) * (ADJ_GB + 1) + 8];  // hi-res gradient box, three guard rows (+ 4 words) either side
     __shared__ adj_image s_img[9];
     static_assert(ADJ_UB * (ADJ_UB + 1) <= ADJ_DB * ADJ_DB && ADJ_T * ADJ_UB <= ADJ_DB * ADJ_GB, "aliased buffers");
     float* s_gu = s_a;
     float* s_v = s_b;
+    float* s_c = s_cs + 3 * (ADJ_GB + 1) + 4;
 
     const int tid = threadIdx.x;
     const int n = blockIdx.z;
@@ -484,8 +488,12 @@ __global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_p
     const float* th = p.theta + (size_t)n * 6;
     const float t0 = th[0], t1 = th[1], t2 = th[2], t3 = th[3], t4 = th[4], t5 = th[5];
     const size_t plane_sz = (size_t)p.h * p.w;
+    // the gather of step c reads words its zero weights cancel: none may hold a NaN / Inf pattern left by another kernel
+    for (int e = threadIdx.x; e < ADJ_DB * ADJ_DB; e += ADJ_NT) s_a[e] = 0.f;
+    for (int e = threadIdx.x; e < ADJ_DB * ADJ_GB; e += ADJ_NT) s_b[e] = 0.f;
+    for (int e = threadIdx.x; e < (ADJ_GB + 6) * (ADJ_GB + 1) + 8; e += ADJ_NT) s_cs[e] = 0.f;
     adj_map m;
-    const int T = adj_plan(p, th, m);
+    int T = adj_plan(p, th, m);
     if (T == 0) {        // the atomics kernel adds this sample's gradient onto zeros
         const int py = blockIdx.y * ADJ_T + tid / ADJ_T, px = blockIdx.x * ADJ_T + tid % ADJ_T;
         if (tid < ADJ_T * ADJ_T && px < p.w && py < p.h)
@@ -494,9 +502,10 @@ __global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_p
     }
     // contributors of an up-sampled pixel fit a 3 x 3 / 4 x 4 window of hi-res pixels (an interval of length 2 h + 0.02 holds at most floor(2 h + 0.02) + 1 integers)
     const int win = (m.hx < 1.48f && m.hy < 1.48f) ? 3 : (m.hx < 1.98f && m.hy < 1.98f) ? 4 : 0;
+    if (win == 4) T = min(T, 8);                            // (16 weights per pixel: fewer pixels per thread)
     const int UBT = 2 * T + 10;
     const int nsub = ADJ_T / T;
-    const float inv_det = 1.f / m.det;
+    const float inv_det = 1.f / m.det, inv_ubt = 1.f / (float)UBT;
 
     // affine_resample_kernel's arithmetic for one hi-res pixel
     auto source = [&](int X, int Y, float& ix, float& iy) {
@@ -548,8 +557,8 @@ __global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_p
             for (int ch = 0; ch < p.c; ch++) out[(size_t)ch * plane_sz] = 0.f;
 
         // one image of the tile, all channels; WIN = 3 / 4: resample^T as a gather over WIN x WIN windows, 0: as a scatter with LDS atomics
-        auto image_pass = [&](const adj_image& im, bool add, auto win_c) {
-            constexpr int WIN = decltype(win_c)::value;
+        auto image_pass = [&](const adj_image& im, bool add, auto win_c, auto nu_c) {
+            constexpr int WIN = decltype(win_c)::value, NUK = decltype(nu_c)::value;
             constexpr int NW = WIN ? WIN * WIN : 1;
             const int Xlo = im.Xlo, Ylo = im.Ylo, Wb = im.Wb, Hb = im.Hb, W2 = Wb >> 1, H2 = Hb >> 1;
             const int oxlo = ((Xlo - 1) >> 1) - 5, oylo = ((Ylo - 1) >> 1) - 5;
@@ -557,44 +566,61 @@ __global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_p
             const int U0x = 2 * im.qlox - 5, U0y = 2 * im.qloy - 5;
             const bool here = mine && px >= im.pax && px <= im.pbx && py >= im.pay && py <= im.pby;
             const int qxl = im.qbx + im.dirx * px - im.qlox, qyl = im.qby + im.diry * py - im.qloy;
-            const int lg_a = adj_lg(dbw), lg_b1 = adj_lg((W2 + 1) >> 1), lg_b2 = adj_lg(Wb), lg_d1 = adj_lg(UBT);
+            const int lg_b1 = adj_lg((W2 + 1) >> 1), lg_b2 = adj_lg(Wb);
 
             // 0. resample^T as a gather: this thread's up-sampled pixels, their candidate windows, the forward's weights (1 - |ix - ux|) (1 - |iy - uy|), zero
             //    for a hi-res pixel whose footprint misses the pixel
-            float wt[ADJ_NU][NW];
-            int wbase[ADJ_NU], woff[ADJ_NU];
+            constexpr int WN = WIN ? WIN : 1;
+            float wt[NUK][NW];
+            int wbase[NUK], woff[NUK];
             if (WIN) {
 #pragma unroll
-                for (int k = 0; k < ADJ_NU; k++) {
+                for (int k = 0; k < NUK; k++) {
                     const int idx = tid + k * ADJ_NT;
-                    const int uyl = idx / UBT, uxl = idx - uyl * UBT;
-                    woff[k] = idx < UBT * UBT ? uyl * (ADJ_UB + 1) + uxl : -1;
+                    const int uyl = (int)(((float)idx + 0.5f) * inv_ubt), uxl = idx - uyl * UBT;
+                    woff[k] = idx < UBT * UBT ? uyl * (ADJ_UB + 1) + uxl : ADJ_DB * ADJ_DB - 1;      // (a word of s_a nothing reads)
                     const int ux = U0x + uxl, uy = U0y + uyl;
                     const bool inside = idx < UBT * UBT && ux >= 0 && ux < wu && uy >= 0 && uy < hu;
                     const float dux = (float)ux - m.cx, duy = (float)uy - m.cy;
                     const float qx = (m.e * dux - m.b * duy) * inv_det, qy = (-m.d * dux + m.a * duy) * inv_det;
                     const int X0 = adj_clampi(ceilf(qx - m.hx - 0.01f)), Y0 = adj_clampi(ceilf(qy - m.hy - 0.01f));
-                    wbase[k] = inside ? (Y0 - Ylo) * (ADJ_GB + 1) + (X0 - Xlo) : 0;
+                    float xn[WN], yn[WN];
+                    bool vx[WN], vy[WN];
+#pragma unroll
+                    for (int j = 0; j < WN; j++) {
+                        const int X = X0 + j, Y = Y0 + j;
+                        xn[j] = (2 * X + 1) / (float)wo - 1.f; yn[j] = (2 * Y + 1) / (float)ho - 1.f;      // (the forward's expressions)
+                        vx[j] = X >= Xlo && X < Xlo + Wb && X < wo; vy[j] = inside && Y >= Ylo && Y < Ylo + Hb && Y < ho;
+                    }
+                    // a window with a column and a row inside the box starts at most WN - 1 rows / columns before it and ends at most WN - 1 behind it: inside the
+                    // guard band of s_c; any other window holds zero weights only and reads the box's first words
+                    bool anyx = false, anyy = false;
+#pragma unroll
+                    for (int j = 0; j < WN; j++) { anyx |= vx[j]; anyy |= vy[j]; }
+                    wbase[k] = anyx && anyy ? (Y0 - Ylo) * (ADJ_GB + 1) + (X0 - Xlo) : 0;
 #pragma unroll
                     for (int j = 0; j < NW; j++) {
-                        const int X = X0 + (j % (WIN ? WIN : 1)), Y = Y0 + (j / (WIN ? WIN : 1));
-                        float ix, iy;
-                        source(X, Y, ix, iy);
+                        const float xn_ = xn[j % WN], yn_ = yn[j / WN];
+                        const float gx = t0 * xn_ + t1 * yn_ + t2, gy = t3 * xn_ + t4 * yn_ + t5;
+                        const float ix = ((gx + 1.f) * wu - 1.f) * 0.5f, iy = ((gy + 1.f) * hu - 1.f) * 0.5f;
                         const float wx = fmaxf(1.f - fabsf(ix - (float)ux), 0.f), wy = fmaxf(1.f - fabsf(iy - (float)uy), 0.f);
-                        const bool ok = inside && X >= Xlo && X < Xlo + Wb && Y >= Ylo && Y < Ylo + Hb && X < wo && Y < ho;
-                        wt[k][j] = ok ? wx * wy : 0.f;
+                        wt[k][j] = vx[j % WN] && vy[j / WN] ? wx * wy : 0.f;
                     }
                 }
             }
 
+            const float inv_dbw = 1.f / (float)dbw;      // item -> (row, column) of the dy box by a float reciprocal ((item + 0.5) / dbw is never within 0.01 of an integer)
+            const int nbox = dbh * dbw;
+
             for (int ch = 0; ch < p.c; ch++) {
-                const float* plane = p.x + ((size_t)n * p.c + ch) * plane_sz;
                 // a. dy box (zeros outside the picture)
-                for (int idx = tid; idx < (dbh << lg_a); idx += ADJ_NT) {
-                    const int r = idx >> lg_a, ci = idx & ((1 << lg_a) - 1);
-                    if (ci >= dbw) continue;
-                    const int oy = oylo + r, ox = oxlo + ci;
-                    s_a[r * ADJ_DB + ci] = (ox >= 0 && ox < p.w && oy >= 0 && oy < p.h) ? plane[(size_t)oy * p.w + ox] : 0.f;
+                {
+                    const float* plane = p.x + ((size_t)n * p.c + ch) * plane_sz;
+                    for (int idx = tid; idx < nbox; idx += ADJ_NT) {
+                        const int r = (int)(((float)idx + 0.5f) * inv_dbw), ci = idx - r * dbw;
+                        const int oy = oylo + r, ox = oxlo + ci;
+                        s_a[r * ADJ_DB + ci] = (ox >= 0 && ox < p.w && oy >= 0 && oy < p.h) ? plane[(unsigned)(oy * p.w + ox)] : 0.f;
+                    }
                 }
                 __syncthreads();
                 // b1. down2^T along x: hi-res columns Xlo + 2k (odd: taps fd[0], fd[2], ..) and Xlo + 2k + 1 (even: fd[1], fd[3], ..) from dy columns k .. k + 5;
@@ -617,23 +643,33 @@ __global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_p
                     else *reinterpret_cast<float2*>(w_) = make_float2(o0, e0);
                 }
                 __syncthreads();
-                // b2. ... along y: rows 2k, 2k + 1 (pair k) and 2k + 2, 2k + 3 (pair k + 1) from seven rows
-                for (int idx = tid; idx < (((H2 + 1) >> 1) << lg_b2); idx += ADJ_NT) {
-                    const int k = (idx >> lg_b2) * 2, j_ = idx & ((1 << lg_b2) - 1);
-                    if (j_ >= Wb) continue;
-                    const float* q = s_b + k * ADJ_GB + j_;
-                    float v[7];
+                // b2. ... along y: a thread owns one column and a run of rows (wave w: the w-th quarter), two pairs per step -- rows 2k .. 2k + 3 from the seven
+                //     expanded dy rows k .. k + 6, five of which the previous step already holds
+                {
+                    const int npp = (H2 + 1) >> 1, seg = (npp + 3) >> 2;
+                    const int kk0 = (tid >> 6) * seg, kk1 = min(npp, kk0 + seg);
+                    for (int j_ = tid & 63; j_ < Wb; j_ += 64) {
+                        if (kk0 >= kk1) break;
+                        const float* q = s_b + (2 * kk0) * ADJ_GB + j_;
+                        float* w_ = s_c + (4 * kk0) * (ADJ_GB + 1) + j_;
+                        float v[7];
 #pragma unroll
-                    for (int j = 0; j < 7; j++) v[j] = q[j * ADJ_GB];
-                    float o0 = 0.f, e0 = 0.f, o1 = 0.f, e1 = 0.f;
+                        for (int j = 0; j < 5; j++) v[j + 2] = q[j * ADJ_GB];
+                        for (int kk = kk0; kk < kk1; kk++) {
 #pragma unroll
-                    for (int j = 0; j < 6; j++) {
-                        o0 = __builtin_fmaf(p.fd[2 * j], v[5 - j], o0); e0 = __builtin_fmaf(p.fd[2 * j + 1], v[5 - j], e0);
-                        o1 = __builtin_fmaf(p.fd[2 * j], v[6 - j], o1); e1 = __builtin_fmaf(p.fd[2 * j + 1], v[6 - j], e1);
+                            for (int j = 0; j < 5; j++) v[j] = v[j + 2];
+                            v[5] = q[5 * ADJ_GB]; v[6] = q[6 * ADJ_GB];
+                            float o0 = 0.f, e0 = 0.f, o1 = 0.f, e1 = 0.f;
+#pragma unroll
+                            for (int j = 0; j < 6; j++) {
+                                o0 = __builtin_fmaf(p.fd[2 * j], v[5 - j], o0); e0 = __builtin_fmaf(p.fd[2 * j + 1], v[5 - j], e0);
+                                o1 = __builtin_fmaf(p.fd[2 * j], v[6 - j], o1); e1 = __builtin_fmaf(p.fd[2 * j + 1], v[6 - j], e1);
+                            }
+                            w_[0] = o0; w_[ADJ_GB + 1] = e0;
+                            if (2 * kk + 1 < H2) { w_[2 * (ADJ_GB + 1)] = o1; w_[3 * (ADJ_GB + 1)] = e1; }
+                            q += 2 * ADJ_GB; w_ += 4 * (ADJ_GB + 1);
+                        }
                     }
-                    float* w_ = s_c + (2 * k) * (ADJ_GB + 1) + j_;
-                    w_[0] = o0; w_[ADJ_GB + 1] = e0;
-                    if (k + 1 < H2) { w_[2 * (ADJ_GB + 1)] = o1; w_[3 * (ADJ_GB + 1)] = e1; }
                 }
                 if (!WIN)
                     for (int e = tid; e < UBT * (ADJ_UB + 1); e += ADJ_NT) s_gu[e] = 0.f;       // (the dy box is dead)
@@ -641,15 +677,12 @@ __global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_p
                 // c. resample^T
                 if (WIN) {
 #pragma unroll
-                    for (int k = 0; k < ADJ_NU; k++) {
-                        if (woff[k] < 0) continue;
+                    for (int k = 0; k < NUK; k++) {
                         const float* q = s_c + wbase[k];
                         float v = 0.f;
 #pragma unroll
-                        for (int j = 0; j < NW; j++) {
-                            const float g = q[(j / (WIN ? WIN : 1)) * (ADJ_GB + 1) + (j % (WIN ? WIN : 1))];      // (may lie outside the box: stale words, weight zero)
-                            v = __builtin_fmaf(wt[k][j], wt[k][j] != 0.f ? g : 0.f, v);
-                        }
+                        for (int j = 0; j < NW; j++)      // (a word outside the box has weight zero: a stale but finite value -- the buffers start as zeros)
+                            v = __builtin_fmaf(wt[k][j], q[(j / (WIN ? WIN : 1)) * (ADJ_GB + 1) + (j % (WIN ? WIN : 1))], v);
                         s_gu[woff[k]] = v;
                     }
                 } else {
@@ -675,22 +708,23 @@ __global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_p
                     }
                 }
                 __syncthreads();
-                // d1. up2^T along y: padded rows qloy + r, r + 1 <- up-sampled rows 2 r .. 2 r + 13 of the block (taps 2 f[k]: fe / fo interleaved)
-                for (int idx = tid; idx < ((T >> 1) << lg_d1); idx += ADJ_NT) {
-                    const int r = (idx >> lg_d1) * 2, j_ = idx & ((1 << lg_d1) - 1);
-                    if (j_ >= UBT) continue;
-                    const float* q = s_gu + (2 * r) * (ADJ_UB + 1) + j_;
-                    float v[14];
+                // d1. up2^T along y: padded rows qloy + r, r + 1 <- up-sampled rows 2 r .. 2 r + 13 of the block (taps 2 f[k]: fe / fo interleaved); a thread owns one
+                //     column, wave w the row pairs w, w + 4, ..
+                if ((tid & 63) < UBT) {
+                    const int j_ = tid & 63;
+                    for (int rr = tid >> 6; rr < (T >> 1); rr += ADJ_NT / 64) {
+                        const float* q = s_gu + (4 * rr) * (ADJ_UB + 1) + j_;
+                        float a0 = 0.f, a1 = 0.f;
 #pragma unroll
-                    for (int k = 0; k < 14; k++) v[k] = q[k * (ADJ_UB + 1)];
-                    float a0 = 0.f, a1 = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) {
-                        a0 = __builtin_fmaf(p.fo[5 - k], v[2 * k], a0); a0 = __builtin_fmaf(p.fe[5 - k], v[2 * k + 1], a0);
-                        a1 = __builtin_fmaf(p.fo[5 - k], v[2 * k + 2], a1); a1 = __builtin_fmaf(p.fe[5 - k], v[2 * k + 3], a1);
+                        for (int k = 0; k < 6; k++) {
+                            const float v0 = q[(2 * k) * (ADJ_UB + 1)], v1 = q[(2 * k + 1) * (ADJ_UB + 1)];
+                            a0 = __builtin_fmaf(p.fo[5 - k], v0, a0); a0 = __builtin_fmaf(p.fe[5 - k], v1, a0);
+                            if (k > 0) { a1 = __builtin_fmaf(p.fo[6 - k], v0, a1); a1 = __builtin_fmaf(p.fe[6 - k], v1, a1); }
+                        }
+                        a1 = __builtin_fmaf(p.fo[0], q[12 * (ADJ_UB + 1)], a1); a1 = __builtin_fmaf(p.fe[0], q[13 * (ADJ_UB + 1)], a1);
+                        s_v[(2 * rr) * ADJ_UB + j_] = a0;
+                        s_v[(2 * rr + 1) * ADJ_UB + j_] = a1;
                     }
-                    s_v[r * ADJ_UB + j_] = a0;
-                    s_v[(r + 1) * ADJ_UB + j_] = a1;
                 }
                 __syncthreads();
                 // d2. ... along x, into dx: the tile's own image stores, a reflection adds (the same thread, the same address)
@@ -712,9 +746,9 @@ __global__ __launch_bounds__(ADJ_NT, 4) void ada_geometric_adjoint_kernel(geom_p
         for (int img = 0; img < 9; img++) {
             const adj_image im = s_img[img];
             if (!im.active) continue;                       // (uniform)
-            if (win == 3) image_pass(im, img != 0, std::integral_constant<int, 3>{});
-            else if (win == 4) image_pass(im, img != 0, std::integral_constant<int, 4>{});
-            else image_pass(im, img != 0, std::integral_constant<int, 0>{});
+            if (win == 3) image_pass(im, img != 0, std::integral_constant<int, 3>{}, std::integral_constant<int, ADJ_NU>{});
+            else if (win == 4) image_pass(im, img != 0, std::integral_constant<int, 4>{}, std::integral_constant<int, ADJ_NU4>{});
+            else image_pass(im, img != 0, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{});
         }
     }
 }
