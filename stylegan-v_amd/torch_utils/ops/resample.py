@@ -9,12 +9,15 @@ a gradient through augmented real images, loss.py:144-164) works.  ``theta`` (bu
 gradient.  CPU / non-fp32 tensors take the two-op formulation through ``grid_sample_gradfix``.
 """
 
+import os
+
 import torch
 
 from .. import custom_ops
 from . import grid_sample_gradfix
 
 enabled = True
+one_kernel_backward = os.environ.get('SGV_ADA_ADJOINT', '1') != '0'      # lab switch: 0 = differentiated calls of the ADA block run the four-pass composition (rounds 4-5)
 
 
 def affine_resample_ref(x, theta, out_hw):
@@ -114,5 +117,7 @@ def ada_geometric(x, theta, f, margin, f_host=None):
     taps = tuple(f_host if f_host is not None else f.detach().cpu().tolist())
     th = theta.detach().contiguous().float()
     if x.requires_grad and torch.is_grad_enabled():
+        if not one_kernel_backward:
+            return ada_geometric_ref(x, theta, f, margin)
         return _AdaGeometric.apply(x, th, taps, margin, False)
     return _launch_geometric(x.detach(), th, taps, margin, False)

@@ -81,6 +81,7 @@ class AugmentPipe(torch.nn.Module):
         self.host_params = True
         self.fused_geometric = True   # the geometric execution as one kernel per direction (ops/resample.py ada_geometric)
         self._p_host = None      # (id of the buffer's storage, its version, 0-d CPU tensor)
+        self._slots, self._slot_phase, self._slot_cursor = {}, None, 0      # parameter slots of captured phases (begin_phase)
         self._const = {}
 
     def _c(self, key, device, make):
@@ -134,7 +135,80 @@ class AugmentPipe(torch.nn.Module):
     def forward(self, images, debug_percentile=None):
         assert isinstance(images, torch.Tensor) and images.ndim == 4
         n, ch, h, w = images.shape
-        dev, pct, on = self._param_device(images), debug_percentile, self.mult     # dev: where the parameters are drawn and composed
+        prm = self._take_slot(images, debug_percentile)
+        if prm is None:
+            prm = self._fold_parameters(n, ch, h, w, self._param_device(images), debug_percentile)
+            prm = {k: (self._upload(v, images.device) if isinstance(v, torch.Tensor) else v) for k, v in prm.items()}
+        if prm['theta'] is not None:
+            images = self._execute(images, prm['theta'], prm['margin'])
+        if prm['colour'] == 'rgb':
+            # RGB, or F frames of one video folded into 3F channels (loss.py:58-66): the same matrix for every frame
+            f, cw, cb = ch // 3, prm['cw'], prm['cb']
+            if images.is_cuda and images.dtype == torch.float32:
+                # 3 -> 3 channels with per-sample weights: the streaming kernel ToRGB uses (csrc/pointwise.hip) instead of a batched 3x3 GEMM
+                # (rocBLAS: 0.42 ms per call on 150 MB, 10x its HBM time; profiles/r04_c8_ada_step_kernel_stats.csv)
+                y = pointwise.pointwise_conv(images.reshape(n * f, 3, h, w), cw)
+                flat = (y + cb.reshape(n * f, 3, 1, 1)) if y.requires_grad else y.add_(cb.reshape(n * f, 3, 1, 1))
+            else:
+                flat = cw @ images.reshape(n * f, 3, h * w) + cb
+            images = flat.reshape(n, ch, h, w)
+        elif prm['colour'] == 'l':
+            cm = prm['cw']
+            images = (images.reshape(n, ch, h * w) * cm[:, :, :3].sum(dim=2, keepdim=True) + cm[:, :, 3:]).reshape(n, ch, h, w)
+        return images
+
+    # -- parameter slots: what a captured phase reads instead of drawing ----------------------------------------------------------------
+    def begin_phase(self, name):
+        """A captured phase is about to run (its eager warm-up, its capture or a replay).  Every call of the pipe inside the phase takes its parameters from
+        persistent device tensors -- one "slot" per call, in call order -- which are filled HERE from a host-side draw and pinned, non-blocking copies on the current
+        stream: the replayed graph holds the two image kernels of a call and none of the ~260 launches of the device-side parameter table (790 per iteration,
+        13 ms of a 153 ms captured iteration: profiles/r06_c35_ada_in_step.txt).  Same distributions, same order of composition; `p` through its host mirror."""
+        self._slot_phase, self._slot_cursor = name, 0
+        for key, slot in self._slots.items():
+            if key[0] == name:
+                self._fill_slot(slot)
+
+    def rewind(self):
+        """The phase's function runs again from its first call (warm-up passes, then the capture)."""
+        self._slot_cursor = 0
+
+    def end_phase(self):
+        self._slot_phase = None
+
+    def _take_slot(self, images, pct):
+        if self._slot_phase is None or pct is not None or images.shape[1] % 3 != 0:
+            return None
+        key = (self._slot_phase, self._slot_cursor)
+        self._slot_cursor += 1
+        slot = self._slots.get(key)
+        if slot is None:
+            if images.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('AugmentPipe: call %d of phase %r first seen under stream capture (the eager warm-up passes create the slots)' % key[::-1])
+            n, ch, h, w = images.shape
+            host = self._fold_parameters(n, ch, h, w, torch.device('cpu'), None)
+            slot = self._slots[key] = dict(shape=tuple(images.shape), margin=host['margin'], colour=host['colour'],
+                                           **{k: (None if host[k] is None else torch.empty(host[k].shape, dtype=host[k].dtype, device=images.device)) for k in ('theta', 'cw', 'cb')})
+            self._fill_slot(slot, host)
+        if slot['shape'] != tuple(images.shape):
+            raise RuntimeError('AugmentPipe: call %d of phase %r changed shape: %s, captured with %s' % (key[1], key[0], tuple(images.shape), slot['shape']))
+        return slot
+
+    def _fill_slot(self, slot, host=None):
+        if host is None:
+            host = self._fold_parameters(*slot['shape'], torch.device('cpu'), None)
+        assert host['margin'] == slot['margin'] and host['colour'] == slot['colour']
+        for k in ('theta', 'cw', 'cb'):
+            if slot[k] is not None:
+                if slot[k].is_cuda:
+                    buf = torch.empty(host[k].shape, dtype=host[k].dtype, pin_memory=True)
+                    buf.copy_(host[k])
+                    slot[k].copy_(buf, non_blocking=True)
+                else:
+                    slot[k].copy_(host[k])
+
+    def _fold_parameters(self, n, ch, h, w, dev, pct):
+        """The parameter table folded on `dev`: -> dict(theta [n,2,3] | None, margin (mx0, mx1, my0, my1), colour 'rgb' | 'l' | None, cw, cb), tensors on `dev`."""
+        on = self.mult
         like = torch.empty(0, device=dev)
 
         # ---- inverse geometric transform G_inv (maps output pixels to input pixels), composed left to right (augment.py:185-268) ----
@@ -170,8 +244,7 @@ class AugmentPipe(torch.nn.Module):
             t = self._draw('xfrac', [n, 2], 'normal', 0, dev, pct) * self.xfrac_std
             push(_translate(-t[:, 0] * w, -t[:, 1] * h, like))
 
-        if geometric:
-            images = self._resample(images, g_inv)
+        theta, margin = self._theta(g_inv, h, w) if geometric else (None, None)
 
         # ---- colour transform C (augment.py:306-368) ----
         eye4 = self._c('eye4', dev, lambda: torch.eye(4))
@@ -196,32 +269,24 @@ class AugmentPipe(torch.nn.Module):
         if on['saturation'] > 0 and ch > 1:
             s = torch.exp2(self._draw('saturation', [n, 1, 1], 'normal', 0, dev, pct) * self.saturation_std)
             c_mat, coloured = (vv + (eye4 - vv) * s) @ c_mat, True
+        colour, cw, cb = None, None, None
         if coloured:
             c_mat = c_mat.expand(n, 4, 4)
-            flat = images.reshape(n, ch, h * w)
-            if ch % 3 == 0:                       # RGB, or F frames of one video folded into 3F channels (loss.py:58-66): the same matrix for every frame
+            if ch % 3 == 0:
                 f = ch // 3
                 cm = c_mat.repeat_interleave(f, dim=0) if f > 1 else c_mat
-                cw, cb = self._upload(cm[:, :3, :3].contiguous(), images.device), self._upload(cm[:, :3, 3:].contiguous(), images.device)
-                if images.is_cuda and images.dtype == torch.float32:
-                    # 3 -> 3 channels with per-sample weights: the streaming kernel ToRGB uses (csrc/pointwise.hip) instead of a batched 3x3 GEMM
-                    # (rocBLAS: 0.42 ms per call on 150 MB, 10x its HBM time; profiles/r04_c8_ada_step_kernel_stats.csv)
-                    y = pointwise.pointwise_conv(images.reshape(n * f, 3, h, w), cw)
-                    flat = (y + cb.reshape(n * f, 3, 1, 1)) if y.requires_grad else y.add_(cb.reshape(n * f, 3, 1, 1))
-                else:
-                    flat = cw @ flat.reshape(n * f, 3, h * w) + cb
+                colour, cw, cb = 'rgb', cm[:, :3, :3].contiguous(), cm[:, :3, 3:].contiguous()
             elif ch == 1:
-                cm = self._upload(c_mat[:, :3, :].mean(dim=1, keepdim=True).contiguous(), images.device)
-                flat = flat * cm[:, :, :3].sum(dim=2, keepdim=True) + cm[:, :, 3:]
+                colour, cw = 'l', c_mat[:, :3, :].mean(dim=1, keepdim=True).contiguous()
             else:
                 raise ValueError('Image must be RGB (3 channels) or L (1 channel)')
-            images = flat.reshape(n, ch, h, w)
-        return images
+        return dict(theta=theta, margin=margin, colour=colour, cw=cw, cb=cb)
 
     # -- geometric execution (augment.py:270-300) -----------------------------------------------------------------------------------
-    def _resample(self, images, g_inv):
-        n, ch, h, w = images.shape
-        dev = g_inv.device                                                     # the parameters' device (the host with `host_params`): the margin read below is free there
+    def _theta(self, g_inv, h, w):
+        """Margin of the reflect padding and the map the resampling step gets (augment.py:272-296), on the parameters' device (the host with `host_params` and for
+        the slots of a captured phase: the margin read below is free there)."""
+        dev = g_inv.device
         cx, cy = (w - 1) / 2, (h - 1) / 2
         pad = self.Hz_geom.shape[0] // 4
         if self.static_margin:
@@ -234,7 +299,7 @@ class AugmentPipe(torch.nn.Module):
             margin = margin + self._c(('moff', w, h, pad), dev, lambda: torch.tensor([pad * 2 - cx, pad * 2 - cy] * 2, dtype=torch.float32))
             margin = margin.clamp(min=0).minimum(self._c(('mmax', w, h), dev, lambda: torch.tensor([w - 1, h - 1] * 2, dtype=torch.float32)))
             mx0, my0, mx1, my1 = (int(v) for v in margin.ceil().tolist())     # one device -> host read per call, as in the reference (:283)
-        # the map the resampling step gets (augment.py:285-296): the padded, then 2x up-sampled image -> the (size + 2 pad) * 2 resampled image
+        # the padded, then 2x up-sampled image -> the (size + 2 pad) * 2 resampled image
         wu, hu = (w + mx0 + mx1) * 2, (h + my0 + my1) * 2
         g_inv = _translate((mx0 - mx1) / 2, (my0 - my1) / 2, g_inv) @ g_inv
         s2, s2i = _scale(2, 2, g_inv), _scale(0.5, 0.5, g_inv)
@@ -242,15 +307,25 @@ class AugmentPipe(torch.nn.Module):
         g_inv = _translate(-0.5, -0.5, g_inv) @ g_inv @ _translate(0.5, 0.5, g_inv)
         out_h, out_w = (h + pad * 2) * 2, (w + pad * 2) * 2
         g_inv = _scale(2 / wu, 2 / hu, g_inv) @ g_inv @ _scale(out_w / 2, out_h / 2, g_inv)
-        theta = self._upload(g_inv[:, :2, :].contiguous(), images.device)
+        return g_inv[:, :2, :].contiguous(), (mx0, mx1, my0, my1)
+
+    def _execute(self, images, theta, margin):
+        n, ch, h, w = images.shape
+        pad = self.Hz_geom.shape[0] // 4
+        mx0, mx1, my0, my1 = margin
         if self.fused_geometric and resample.ada_geometric_fused_ok(images, self.Hz_geom):
             # reflect pad -> up -> resample -> down as ONE kernel: no padded / up-sampled / resampled image in memory (csrc/resample.hip); calls that
             # will be differentiated (the generator's phase, R1) get the node whose backward is the block's adjoint as one kernel
-            return resample.ada_geometric(images, theta, self.Hz_geom, (mx0, mx1, my0, my1), f_host=self._filter_taps())
+            return resample.ada_geometric(images, theta, self.Hz_geom, margin, f_host=self._filter_taps())
         images = torch.nn.functional.pad(images, [mx0, mx1, my0, my1], mode='reflect')
         images = upfirdn2d.upsample2d(images, self.Hz_geom, up=2)
-        images = resample.affine_resample(images, theta, (out_h, out_w))
+        images = resample.affine_resample(images, theta, ((h + pad * 2) * 2, (w + pad * 2) * 2))
         return upfirdn2d.downsample2d(images, self.Hz_geom, down=2, padding=-pad * 2, flip_filter=True)
+
+    def _resample(self, images, g_inv):
+        """Geometric execution from the inverse maps (pixel coordinates about the image centre)."""
+        theta, margin = self._theta(g_inv, images.shape[2], images.shape[3])
+        return self._execute(images, self._upload(theta, images.device), margin)
 
     def _filter_taps(self):
         """`Hz_geom` as host floats (launch arguments of the fused kernel); a constant of the pipeline, read at construction."""

@@ -241,6 +241,8 @@ class TrainStep:
 
     # -- one phase: zero_grad -> accumulate_gradients -> nan_to_num -> Adam (training_loop.py:351-389) -----------------
     def _phase_gradients(self, phase, sync, real_img, real_c, real_t, gen_z, gen_c, gen_t):
+        if self.augment_pipe is not None:
+            self.augment_pipe.rewind()               # (a captured phase's function runs several times -- warm-up, capture -- over the same parameter slots)
         phase['opt'].zero_grad(set_to_none=True)
         phase['module'].requires_grad_(True)
         with motion.frame_times_bounded_by(self._t_bound):
@@ -293,6 +295,15 @@ class TrainStep:
         captured buffers and replay.  Every kernel of the native library launches on torch's current stream without allocating or
         synchronising, so it is capture-safe as is."""
         name = phase['name']
+        if self.augment_pipe is not None:
+            self.augment_pipe.begin_phase(name)      # the augmentation parameters of this run of the phase: drawn on the host, copied into the tensors the graph reads
+        try:
+            return self._run_phase_graph_body(phase, name, real_img, real_c, real_t, gen_z, gen_c, gen_t)
+        finally:
+            if self.augment_pipe is not None:
+                self.augment_pipe.end_phase()
+
+    def _run_phase_graph_body(self, phase, name, real_img, real_c, real_t, gen_z, gen_c, gen_t):
         entry = self._graphs.get(name)
         if entry is None:
             static = dict(real_img=real_img.clone(), real_c=real_c.clone(), real_t=real_t.clone(), gen_z=gen_z.clone(), gen_c=gen_c.clone(), gen_t=gen_t.clone())

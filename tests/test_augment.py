@@ -41,6 +41,42 @@ def test_augment_pipe_identity_at_p0_and_ada_update():
         AugmentPipe(noise=1)
 
 
+def test_parameter_slots_of_a_captured_phase():
+    """What a hipGraph-replayed phase does instead of drawing its augmentation parameters on the device (AugmentPipe.begin_phase): every call of the phase reads one
+    persistent set of tensors, filled from a host-side draw before the run -- same tensors (addresses) on every run, new values on every run, the same values for the
+    warm-up passes and the capture of one run, identity maps at p = 0, and no slot outside a phase."""
+    torch.manual_seed(5)
+    pipe = AugmentPipe(**BGC)
+    pipe.static_margin = True
+    x = torch.rand([4, 9, 24, 24]) * 2 - 1
+    pipe.begin_phase('Dmain')
+    y_a, y_b = pipe(x), pipe(x)                    # two calls of the phase: two slots, two draws
+    assert sorted(pipe._slots) == [('Dmain', 0), ('Dmain', 1)] and not torch.allclose(y_a, y_b)
+    pipe.rewind()
+    assert torch.equal(pipe(x), y_a) and torch.equal(pipe(x), y_b)      # the phase's function run again (warm-up, capture): the same parameters
+    slot = pipe._slots[('Dmain', 0)]
+    ptrs = {k: slot[k].data_ptr() for k in ('theta', 'cw', 'cb')}
+    theta_before = slot['theta'].clone()
+    pipe.begin_phase('Dmain')                      # the next run: new values in the same tensors
+    assert {k: slot[k].data_ptr() for k in ptrs} == ptrs and not torch.equal(slot['theta'], theta_before)
+    assert not torch.allclose(pipe(x), y_a)
+    with pytest.raises(RuntimeError, match='changed shape'):
+        pipe(x[:2])
+    pipe.begin_phase('Gmain')
+    pipe(x)
+    assert ('Gmain', 0) in pipe._slots and len(pipe._slots) == 3
+    pipe.end_phase()
+    pipe(x)                                        # outside a phase: drawn on the spot, no slot
+    assert len(pipe._slots) == 3
+    # p = 0: every slot holds the identity (theta of the static margin) and the pipe reproduces its input
+    pipe.p.copy_(torch.zeros([]))
+    pipe.begin_phase('Dmain')
+    want = pipe._fold_parameters(4, 9, 24, 24, torch.device('cpu'), None)
+    assert torch.allclose(slot['theta'], want['theta']) and slot['margin'] == (23, 23, 23, 23)
+    assert (pipe(x) - x).abs().max() < 5e-5
+    pipe.end_phase()
+
+
 def test_static_worst_case_margin_reproduces_the_measured_margin_path():
     """`static_margin` (what hipGraph capture needs: no device -> host read of the padding) pads by the bound the reference clamps its margin
     to; the extra padding is never sampled, so outputs and gradients match the reference goldens like the default path does."""

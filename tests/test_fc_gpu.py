@@ -151,7 +151,7 @@ def test_row_strided_input_is_read_in_place():
         outs.append((y, gx, gw, gb))
     for name, a, c in zip(('y', 'dx', 'dW', 'db'), *outs):
         if name == 'db':      # (the bias gradient's row sums meet through LDS atomics: the order of the additions varies from launch to launch)
-            assert torch.allclose(a, c, rtol=2e-6, atol=0)
+            assert torch.allclose(a, c, rtol=2e-6, atol=2e-6 * float(c.abs().max()))      # (sums of 96 terms that may cancel: the bound is relative to the largest sum)
         else:
             assert torch.equal(a, c), name
     assert fc._rows(ws[:, :, 5]) is not ws[:, :, 5]          # a column of the trailing dimension is not rows of contiguous floats: copied
