@@ -408,8 +408,8 @@ int sgv_affine_resample(const float* src, float* dst, const float* theta, int32_
  * with the 12-tap `Hz_geom` filter (`filter12`: HOST pointer, the taps travel as launch arguments) and theta [n, 2, 3] (DEVICE) exactly what
  * sgv_affine_resample would get for the resampling step: the map from the (2 (h + 6)) x (2 (w + 6)) resampled image to the up-sampled padded image
  * (2 (h + my0 + my1)) x (2 (w + mx0 + mx1)), both in affine_grid's normalised coordinates.  The padded, up-sampled and resampled images are never
- * written.  Margins in [0, size - 1] (the reference clamps there, augment.py:281-282).  Any affine map (a sample whose tile footprints do not fit
- * the staging buffers takes a direct form in the same launch). */
+ * written.  Margins in [0, size - 1] (the reference clamps there, augment.py:281-282).  Any affine map: samples whose 16 x 16 tile footprints do not fit the
+ * staging buffers are served in 8 x 8 / 4 x 4 sub-tiles by a second kernel (two launches, each sample in exactly one), extreme zoom-outs by a direct form. */
 int sgv_ada_geometric(const float* x, float* y, const float* theta, const float* filter12, int32_t n, int32_t c, int32_t h, int32_t w,
                       int32_t mx0, int32_t mx1, int32_t my0, int32_t my1, void* stream);
 

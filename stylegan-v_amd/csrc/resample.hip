@@ -184,10 +184,12 @@ __global__ __launch_bounds__(256) void affine_resample_adjoint_scatter_rest_kern
 //   2. up-sampling, separable, in LDS (one thread makes the even and the odd output of an input position: 7 LDS reads for 12 FMAs);
 //   3. the bilinear taps with `affine_resample_kernel`'s own arithmetic (same taps, same weights), from LDS;
 //   4. down-sampling, separable, in LDS; 256 stores.
-// A sample whose box does not fit (strong zoom-out: > 1.6 source pixels per output pixel) takes the direct form of step 1-3 in the same launch: each hi-res pixel evaluates
-// its four up-sampled taps from x (4 x 36 FMAs through L1 / L2) -- 20x the arithmetic, any map.
+// A sample whose box does not fit at 16 x 16 (zoom-out by more than ~1.15 at 45 degrees, 1.6 axis-aligned: a sixth of the maps ADA draws) is served in 8 x 8 or 4 x 4
+// sub-tiles by the same code (`ada_geometric_forward_sub_kernel`, a second launch whose workgroups return at once for every other sample: 32 drawn maps 0.73 ms
+// instead of 3.2 ms, profiles/r06_c37_*); beyond a zoom-out of ~4 the direct form of step 1-3: each hi-res pixel evaluates its four up-sampled taps from x
+// (4 x 36 FMAs through L1 / L2) -- 20x the arithmetic, any map.
 // The margin arrives by value: the batch's measured margin (host-side parameters) or the static worst case w - 1 / h - 1 (hipGraph capture) -- here it costs nothing
-// either way, the padded image being virtual.  Backward passes keep the four-pass composition (ops/resample.py).
+// either way, the padded image being virtual.  The backward pass: `ada_geometric_adjoint_kernel` below.
 
 constexpr int GEO_TO = 16;                    // output tile
 constexpr int GEO_HI = 2 * GEO_TO + 10;       // hi-res rows / columns a tile's down-sampling reads
@@ -244,17 +246,15 @@ __device__ float geo_hi_direct(const geom_params& p, const float* plane, float i
     return v;
 }
 
-__global__ __launch_bounds__(256) void ada_geometric_forward_kernel(geom_params p) {
-    __shared__ float s_pin[GEO_PMAX * (GEO_PMAX + 1)];
-    __shared__ float s_t[GEO_PMAX * GEO_BMAX];            // horizontally up-sampled rows; later the hi-res block + its horizontally down-sampled form
-    __shared__ float s_u[GEO_BMAX * (GEO_BMAX + 1)];
+// one TO x TO tile of y (TO = 16: the kernel's tile; 8, 4: sub-tiles for samples whose map spreads a 16-tile's footprint beyond the staging buffers)
+template <int TO>
+__device__ __forceinline__ void geo_forward_tile(const geom_params& p, const int n, const int ox0, const int oy0, float* s_pin, float* s_t, float* s_u) {
+    constexpr int GEO_TO = TO, GEO_HI = 2 * TO + 10;
     float* s_hi = s_t;                                      // [GEO_HI][GEO_HI + 1]
     float* s_dh = s_t + GEO_HI * (GEO_HI + 1);              // [GEO_HI][GEO_TO]
     static_assert(GEO_HI * (GEO_HI + 1) + GEO_HI * GEO_TO <= GEO_PMAX * GEO_BMAX, "the hi-res block shares the row buffer");
 
     const int tid = threadIdx.x;
-    const int n = blockIdx.z;
-    const int ox0 = blockIdx.x * GEO_TO, oy0 = blockIdx.y * GEO_TO;
     const int wp = p.w + p.mx0 + p.mx1, hp = p.h + p.my0 + p.my1, wu = 2 * wp, hu = 2 * hp;
     const int wo = 2 * (p.w + 6), ho = 2 * (p.h + 6);
     const int X0 = 2 * ox0 + 1, Y0 = 2 * oy0 + 1;           // first hi-res column / row of the tile
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(256) void ada_geometric_forward_kernel(geom_params 
         }
         __syncthreads();
         // 4b. ... along y, store
-        {
+        if (tid < GEO_TO * GEO_TO) {
             const int oy = tid / GEO_TO, ox = tid - oy * GEO_TO;
             float acc = 0.f;
 #pragma unroll
@@ -397,6 +397,41 @@ __global__ __launch_bounds__(256) void ada_geometric_forward_kernel(geom_params 
     }
 }
 
+
+
+// SUB = false: the samples served in 16 x 16 tiles (every map near the identity); SUB = true: the others.  Two launches, a sample's workgroups return at once
+// from the one that does not serve it (one kernel holding both paths needs 145 registers: 10 % slower on the common path).
+template <bool SUB>
+__device__ __forceinline__ void geo_forward_body(const geom_params& p) {
+    __shared__ float s_pin[GEO_PMAX * (GEO_PMAX + 1)];
+    __shared__ float s_t[GEO_PMAX * GEO_BMAX];            // horizontally up-sampled rows; later the hi-res block + its horizontally down-sampled form
+    __shared__ float s_u[GEO_BMAX * (GEO_BMAX + 1)];
+    const int n = blockIdx.z;
+    const int ox0 = blockIdx.x * 16, oy0 = blockIdx.y * 16;
+    // the tile size whose footprint in the up-sampled image fits the staging buffers for this sample's map (the footprint of a (2 t + 10)^2 hi-res block is a
+    // parallelogram; its bounding box grows with |a| + |b| up-sampled pixels per hi-res pixel): 16, else 8 x 8 or 4 x 4 sub-tiles (zoom-out up to ~2.7 / ~4 at any
+    // angle); a sample beyond that keeps the 16-tile and its direct form
+    const float* th = p.theta + (size_t)n * 6;
+    const float wu = 2.f * (p.w + p.mx0 + p.mx1), hu = 2.f * (p.h + p.my0 + p.my1), wo = 2.f * (p.w + 6), ho = 2.f * (p.h + 6);
+    const float sx = fabsf(th[0] * wu / wo) + fabsf(th[1] * wu / ho), sy = fabsf(th[3] * hu / wo) + fabsf(th[4] * hu / ho);
+    const float s = fmaxf(sx, sy);
+    int t = 16;
+    if (!(41.f * s + 6.f <= (float)GEO_BMAX)) t = 25.f * s + 6.f <= (float)GEO_BMAX ? 8 : (17.f * s + 6.f <= (float)GEO_BMAX ? 4 : 16);
+    if (!SUB) {
+        if (t == 16) geo_forward_tile<16>(p, n, ox0, oy0, s_pin, s_t, s_u);
+        return;
+    }
+    if (t == 16) return;
+    for (int sub = 0; sub < (16 / t) * (16 / t); sub++) {
+        const int sx0 = ox0 + (sub % (16 / t)) * t, sy0 = oy0 + (sub / (16 / t)) * t;
+        if (sx0 >= p.w || sy0 >= p.h) continue;           // (uniform)
+        if (t == 8) geo_forward_tile<8>(p, n, sx0, sy0, s_pin, s_t, s_u);
+        else geo_forward_tile<4>(p, n, sx0, sy0, s_pin, s_t, s_u);
+    }
+}
+
+__global__ __launch_bounds__(256, 4) void ada_geometric_forward_kernel(geom_params p) { geo_forward_body<false>(p); }
+__global__ __launch_bounds__(256) void ada_geometric_forward_sub_kernel(geom_params p) { geo_forward_body<true>(p); }
 
 // ---------------------------------------------------------------------------------------------------------------------------------------------
 // ... and its ADJOINT as one kernel:   dx = pad^T( up2^T( resample^T( down2^T( dy ) ) ) )
@@ -858,6 +893,7 @@ extern "C" int sgv_ada_geometric(const float* x, float* y, const float* theta, c
     sgv_launch_scope scope(SGV_K_POINTWISE, stream, 8.0 * n * c * (double)h * w);
     dim3 grid((unsigned)((w + GEO_TO - 1) / GEO_TO), (unsigned)((h + GEO_TO - 1) / GEO_TO), (unsigned)n);
     hipLaunchKernelGGL(ada_geometric_forward_kernel, grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(ada_geometric_forward_sub_kernel, grid, dim3(256), 0, stream, p);      // (samples whose map needs sub-tiles: none at p = 0)
     return sgv_check_launch("ada_geometric_forward_kernel");
 }
 
