@@ -45,6 +45,19 @@ python tools/pmc_summary.py $OUT/g1024 $OUT/r06_pmc_g1024_FETCH_WRITE.json "roun
 cp $OUT/r06_pmc_g1024_FETCH_WRITE.json profiles/ 2>/dev/null
 rm -rf $OUT/g1024
 timeout 400 python bench.py --workload g1024 --cpu-seconds 10 > $OUT/bench_g1024.json 2> $OUT/bench_g1024.err
+# 6b. the ADA geometric block: one-kernel forward / adjoint against the four-pass composition, and the cost of aug=ada in the step (eager and captured; SGV_ADA_ADJOINT=0:
+#     the differentiated calls run the composition, as in rounds 4-5)
+timeout 300 python tools/ada_bench.py --static 0 > $OUT/r06_ada_bench_measured_margin.log 2>&1
+timeout 300 python tools/ada_bench.py --static 1 > $OUT/r06_ada_bench_static_margin.log 2>&1
+{
+python tools/ada_step_bench.py --aug noaug 2>&1 | tail -1
+python tools/ada_step_bench.py --aug ada 2>&1 | tail -1
+SGV_ADA_ADJOINT=0 python tools/ada_step_bench.py --aug ada 2>&1 | tail -1
+python tools/ada_step_bench.py --aug noaug --graphs 1 2>&1 | tail -1
+python tools/ada_step_bench.py --aug ada --graphs 1 2>&1 | tail -1
+SGV_ADA_ADJOINT=0 python tools/ada_step_bench.py --aug ada --graphs 1 2>&1 | tail -1
+python tools/ada_step_bench.py --aug ada --graphs 1 --p 0.3 2>&1 | tail -1
+} > $OUT/r06_ada_in_step.txt 2>&1; cat $OUT/r06_ada_in_step.txt
 # 7. census of a captured main iteration
 ( cd /tmp && SGV_SELFTEST=0 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/census -- python $GRAFT_REPO_ROOT/tools/captured_census.py > /tmp/census.log 2>&1 )
 f=$(find /tmp/census -name "*kernel_trace.csv" | head -1); python tools/captured_census_report.py $f > $OUT/r06_captured_census.txt 2>&1; head -3 $OUT/r06_captured_census.txt
