@@ -880,6 +880,21 @@ def main():
                        p_final=float(ts.augment_pipe.p), what='same step with aug=ada (augpipe bgc, one transform per video, ADA target 0.6 / interval 4 / 500 kimg)')
         finally:
             ts.set_augment('noaug')
+        # the control: the same step object, aug=noaug, the same schedule window, straight behind the aug=ada window -- the chip's clock state drifts by several per
+        # cent over a bench run, so the cost of the augmentation is `value / noaug_control_value` of THIS pair, not `value_aug_ada / value`
+        ts.batch_idx = 0
+        ts.step(); ts.step()
+        ts.batch_idx = 0
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.ada_steps):
+            ts.step()
+        barrier()
+        t_c = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        if world > 1:
+            torch.distributed.all_reduce(t_c, op=torch.distributed.ReduceOp.MAX)
+        ada['noaug_control_value'] = global_batch * args.frames * args.ada_steps / float(t_c.item())
+        ada['ratio_to_control'] = ada['value'] / ada['noaug_control_value']
 
     # ... and the same step the way the headline runs it: Gmain / Dmain replayed as hipGraphs (static worst-case reflect margin: nothing is read back to the host; the
     # geometric block is one kernel per direction, so the wider virtual padding costs nothing).  Its own models; same bracket and schedule.  `value_aug_ada_captured / value`
@@ -1112,7 +1127,7 @@ def main():
                    multi_gpu=multi_gpu, step_ms=step_ms, power=power.summary() if power is not None else None, value_bf16_split=split3['value'] if split3 else None, bf16_split=split3,
                    value_no_prof=value_no_prof['value'] if value_no_prof else None, no_prof=value_no_prof, value_eager=value_eager['value'] if value_eager else None, eager=value_eager,
                    value_fp32_grade=value if (default_terms in ((0, 0), (4, 4)) and lowp is None) else None,     # the headline's products are fp32-GRADE (22-bit split operands, 2.7e-7), not strict fp32: the strict-fp32 figure is value_vendor_fp32_convs
-                   value_vendor_fp32_convs=strict['value'] if strict else None, vendor_fp32_convs=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_aug_ada_captured=ada_cap['value'] if ada_cap else None, aug_ada_captured=ada_cap, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
+                   value_vendor_fp32_convs=strict['value'] if strict else None, vendor_fp32_convs=strict, value_aug_ada=ada['value'] if ada else None, aug_ada=ada, value_aug_ada_over_noaug_control=ada.get('ratio_to_control') if ada else None, value_aug_ada_captured=ada_cap['value'] if ada_cap else None, aug_ada_captured=ada_cap, value_bf16_products=bf16c['value'] if bf16c else None, bf16_products=bf16c, value_pl_f1=plc['value'] if plc else None, pl_f1=plc,
                    value_lowp_bf16=lowpc['value'] if lowpc else None, lowp_bf16=lowpc, value_hip_graphs=graphc['value'] if graphc else None, hip_graphs=graphc,
                    roofline=roofline, roofline_conv_family=roofline_family, roofline_upfirdn2d=roofline_ufd, upfirdn2d_by_size=ufd_by_size, kernels=kernels, kernels_by_variant=variants, cpu_baseline=cpu)
         emit(out)
