@@ -370,3 +370,31 @@ def test_geometric_execution_as_one_kernel_matches_the_reference_gpu():
         assert custom_ops.launch_count() - before == 1
         assert_close(y, want, atol=3e-5, rtol=3e-5, what='one-kernel geometric execution vs the reference')
         assert_close(pipe._resample(x, GEO.t('G_inv')), want, atol=3e-5, rtol=3e-5, what='pipe bookkeeping + one kernel vs the reference')
+
+
+def test_captured_schedule_with_ada_takes_its_parameters_from_slots():
+    """TrainStep with the host-side graph stand-in (`use_graphs='emulate'`) and aug=ada: the replayed phases (Gmain, Dmain) read the augmentation parameters from the slots
+    `begin_phase` fills before every run -- new values every iteration, one slot per call of the pipe in the phase -- while the eager reg phases draw on the spot."""
+    from stylegan_v_amd.training import config as cfgs
+    from stylegan_v_amd.training.train_step import TrainStep
+    g_kwargs, d_kwargs = cfgs.small_test_model_kwargs(res=32)
+    train_cfg = cfgs.Config(r1_gamma=1.0, lr=0.0025, betas=(0.0, 0.99), ema_kimg=1.0, ema_rampup=0.05, G_reg_interval=4, D_reg_interval=2, pl_weight=0.0)
+    ts = TrainStep(g_kwargs, d_kwargs, train_cfg, device='cpu', batch_gpu=2, world_size=1, seed=0, use_graphs='emulate', augment='ada')
+    pipe = ts.augment_pipe
+    assert pipe.static_margin and pipe._slots == {}
+    pipe.p.copy_(torch.ones([]))                    # every augmentation on: the slots' values differ from run to run
+    g = torch.Generator().manual_seed(7)
+    seen = []
+    for it in range(3):
+        real = torch.rand([2, 3, 3, 32, 32], generator=g) * 2 - 1
+        real_t = torch.sort(torch.rand([2, 3], generator=g) * 30, dim=1).values
+        ran = ts.step(real, real_t)
+        assert ('Dreg' in ran) == (it % 2 == 0)
+        assert pipe._slot_phase is None             # (closed behind every captured phase: the eager reg phases draw on the spot)
+        assert {k[0] for k in pipe._slots} == {'Gmain', 'Dmain'} and ('Gmain', 0) in pipe._slots and ('Gmain', 1) not in pipe._slots
+        seen.append({k: v['theta'].clone() for k, v in pipe._slots.items()})
+        assert all(torch.isfinite(v).all() for v in ts.last_losses.values())
+    n_slots = len(seen[0])
+    assert n_slots >= 2 and all(len(s) == n_slots for s in seen)
+    for k in seen[0]:
+        assert not torch.equal(seen[0][k], seen[1][k]) and not torch.equal(seen[1][k], seen[2][k]), f'slot {k} was not refilled between iterations'
