@@ -212,3 +212,28 @@ def test_conv_stub_on_gpu_vs_oracle():
     close(sgv_conv.conv3x3_weight_grad(dev(dys), dev(xb), w.shape, 2), oracle.conv3x3_weight_grad(dys.numpy(), xb.numpy(), stride=2), 'stride-2 weight gradient')
     assert sgv_conv.conv3x3(dev(x[:, :3]), dev(w[:, :3]), False, 1) is None, 'unsupported shapes must hand back to the vendor library'
     assert sgv_conv.conv3x3(dev(x).half(), dev(w).half(), False, 1) is None
+
+
+@pytest.mark.gpu
+def test_augment_stub_on_gpu_vs_the_reference_fixture():
+    """integration/sgv_augment.py (the reference-side replacement of augment.py:284-303, ctypes only) against the reference's own evaluation of the block and of its
+    first / second derivatives (tests/golden/ada_geometric.npz)."""
+    from stylegan_v_amd.integration import sgv_augment
+    from util import Golden, assert_close
+    geo = Golden('ada_geometric')
+    taps = geo.t('taps', device='cuda')
+    theta, margin = geo.t('theta', device='cuda'), geo.meta['margin']
+    before = custom_ops.launch_count()
+    x = geo.t('x', device='cuda').requires_grad_(True)
+    y = sgv_augment.ada_geometric(x, theta, taps, margin)
+    assert_close(y.detach(), geo.t('y', device='cuda'), atol=3e-5, rtol=3e-5, what='stub forward vs the reference')
+    (dx,) = torch.autograd.grad((y * geo.t('v', device='cuda')).sum(), x)
+    assert_close(dx, geo.t('dx', device='cuda'), atol=5e-5, rtol=5e-5, what='stub backward vs the reference')
+    x = geo.t('x', device='cuda').requires_grad_(True)
+    y = sgv_augment.ada_geometric(x, theta, taps, margin)
+    (g1,) = torch.autograd.grad((y ** 3).sum(), x, create_graph=True)
+    (g2,) = torch.autograd.grad(g1.square().sum(), x)
+    want1, want2 = geo.t('r1_g', device='cuda'), geo.t('r1_gg', device='cuda')
+    assert_close(g1.detach(), want1, atol=1e-4 * want1.abs().max().item(), rtol=1e-4, what='stub first derivative of the cubic head')
+    assert_close(g2, want2, atol=2e-4 * want2.abs().max().item(), rtol=2e-4, what='stub R1-shaped second derivative')
+    assert custom_ops.launch_count() - before == 6, 'forward, adjoint; forward, adjoint, forward, adjoint: the stub reached the library this process has loaded'
